@@ -1,0 +1,117 @@
+"""Shimmed import of the REAL reference modules (TEST INFRASTRUCTURE).
+
+Only usable where ``/root/reference`` exists (the build container); the GPU
+box never has it, so nothing run there may call :func:`load_reference`.
+Used by oracle/make_golden.py and by CPU tests that skip when the reference is
+absent.  The reference is read in place — nothing is copied.
+
+Shims:
+ 1. stub ``diffusers.configuration_utils`` / ``diffusers.models.modeling_utils``
+    (not installed; model.py:7-8 imports them at top level);
+ 2. pre-register empty ``wan`` / ``wan.modules`` packages so their
+    ``__init__`` (torchvision, ftfy, ...) is bypassed;
+ 3. ``flash_attention`` (needs CUDA + flash_attn, attention.py:54,112) is
+    rebound to a masked fp32 softmax attention — mathematically what the
+    varlen kernel computes.
+"""
+import importlib
+import os
+import sys
+import tempfile
+import types
+
+import torch
+
+REFERENCE_ROOT = "/root/reference"
+
+
+def reference_available() -> bool:
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "seaweed_apt", "wan", "modules"))
+
+
+def _masked_sdpa(q, k, v, q_lens=None, k_lens=None, dropout_p=0., softmax_scale=None,
+                 q_scale=None, causal=False, window_size=(-1, -1), deterministic=False,
+                 dtype=torch.bfloat16, version=None):
+    assert q_lens is None and not causal and q_scale is None
+    B, Lq, N, D = q.shape
+    Lk = k.shape[1]
+    mask = None
+    if k_lens is not None:
+        mask = (torch.arange(Lk)[None, :] < k_lens.view(B, 1))[:, None, None, :]
+    out = torch.nn.functional.scaled_dot_product_attention(
+        q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2),
+        attn_mask=mask, scale=softmax_scale)
+    return out.transpose(1, 2).contiguous().type(q.dtype)
+
+
+_CACHE = {}
+
+
+def load_reference():
+    """Returns (model_module, vae_module) = the reference's wan.modules.model / .vae."""
+    if "mods" in _CACHE:
+        return _CACHE["mods"]
+    if not reference_available():
+        raise RuntimeError("reference tree not present")
+    sw = os.path.join(REFERENCE_ROOT, "seaweed_apt")
+    # the reference's logger writes project.log into the cwd: import from a temp dir
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp(prefix="omh_ref_")
+    os.chdir(tmp)
+    try:
+        if sw not in sys.path:
+            sys.path.insert(0, sw)
+        dcfg = types.ModuleType("diffusers.configuration_utils")
+
+        class ConfigMixin:  # noqa: D401 - stub
+            pass
+
+        def register_to_config(fn):
+            return fn
+
+        dcfg.ConfigMixin, dcfg.register_to_config = ConfigMixin, register_to_config
+        dmod = types.ModuleType("diffusers.models.modeling_utils")
+        dmod.ModelMixin = torch.nn.Module
+        for name, mod in (("diffusers", types.ModuleType("diffusers")),
+                          ("diffusers.models", types.ModuleType("diffusers.models")),
+                          ("diffusers.configuration_utils", dcfg),
+                          ("diffusers.models.modeling_utils", dmod)):
+            sys.modules.setdefault(name, mod)
+        wan = types.ModuleType("wan")
+        wan.__path__ = [os.path.join(sw, "wan")]
+        wmods = types.ModuleType("wan.modules")
+        wmods.__path__ = [os.path.join(sw, "wan", "modules")]
+        sys.modules.setdefault("wan", wan)
+        sys.modules.setdefault("wan.modules", wmods)
+        model = importlib.import_module("wan.modules.model")
+        vae = importlib.import_module("wan.modules.vae")
+        model.flash_attention = _masked_sdpa
+    finally:
+        os.chdir(cwd)
+    _CACHE["mods"] = (model, vae)
+    return model, vae
+
+
+def build_reference_dit(cfg, state_dict):
+    """Instantiate the reference WanModel with ``cfg`` (an oracle DiTConfig)
+    and load ``state_dict`` into it."""
+    model_mod, _ = load_reference()
+    m = model_mod.WanModel(
+        model_type=cfg.model_type, patch_size=cfg.patch_size, text_len=cfg.text_len,
+        in_dim=cfg.in_dim, dim=cfg.dim, ffn_dim=cfg.ffn_dim, freq_dim=cfg.freq_dim,
+        text_dim=cfg.text_dim, out_dim=cfg.out_dim, num_heads=cfg.num_heads,
+        num_layers=cfg.num_layers, qk_norm=cfg.qk_norm, cross_attn_norm=cfg.cross_attn_norm,
+        eps=cfg.eps, use_checkpoint=False)
+    missing, unexpected = m.load_state_dict(state_dict, strict=True)
+    torch.cuda.empty_cache = lambda: None  # model.py:503 calls it on every forward
+    return m.eval().requires_grad_(False)
+
+
+def build_reference_vae(state_dict, **cfg):
+    _, vae_mod = load_reference()
+    base = dict(dim=96, z_dim=16, dim_mult=[1, 2, 4, 4], num_res_blocks=2, attn_scales=[],
+                temperal_downsample=[False, True, True], dropout=0.0)
+    base.update(cfg)
+    m = vae_mod.WanVAE_(**base)
+    m.load_state_dict(state_dict, strict=True)
+    return m.eval().requires_grad_(False)
