@@ -1,0 +1,178 @@
+/*
+ * omh.h — C ABI of libomh.so, the MI355X (gfx950) kernel library under the
+ * Wan2.1 DiT / 3D-causal-VAE path of johndpope/OmniHuman-1-hack.
+ *
+ * The reference has no FFI for this path: its boundary is the Python
+ * nn.Module surface (WanModel.forward, WanVAE.encode/decode — SURVEY.md §8b)
+ * and every arithmetic op is delegated to PyTorch aten / flash-attn CUDA
+ * kernels.  Each entry point below replaces one of those delegated ops and
+ * cites the reference line(s) whose arithmetic it takes over; the host-side
+ * Python in omnihuman-1-hack_amd/wan/ keeps the reference's call surface and
+ * binds these symbols through ctypes.
+ *
+ * Conventions
+ *  - plain C types only: device pointers (void* / float*), sizes, strides in
+ *    ELEMENTS, a hipStream_t passed as void*.  No torch types.
+ *  - every call is asynchronous on the given stream, allocates nothing and
+ *    keeps no hidden state; the caller owns all buffers.
+ *  - return 0 on success, a negative OMH_E_* code on a rejected argument,
+ *    or the positive hipError_t of a failed launch.
+ *  - bf16 = 16-bit brain float (upper half of an IEEE fp32), fp32 accumulate
+ *    everywhere.
+ */
+#ifndef OMH_H
+#define OMH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OMH_ABI_VERSION 1
+
+#define OMH_E_BADARG   (-1)   /* null pointer / non-positive size             */
+#define OMH_E_ALIGN    (-2)   /* pointer or leading dimension not aligned     */
+#define OMH_E_SHAPE    (-3)   /* shape not supported by this kernel           */
+
+typedef void* omh_stream_t;   /* hipStream_t */
+
+int omh_abi_version(void);
+/* gfx arch string the library was built for ("gfx950"). */
+const char* omh_build_arch(void);
+
+/* ------------------------------------------------------------------------
+ * GEMM  C[m][n] = epilogue( sum_k A[m][k] * B[n][k] )          (bf16 MFMA)
+ * Replaces aten addmm under every nn.Linear of the DiT
+ * (model.py:125-128,144-146,160,176-178,185,272-274,344,465-467) and the
+ * patch-embedding Conv3d-as-GEMM (model.py:463,515).
+ * A: [M,K] bf16 row-major (lda), B: [N,K] bf16 row-major (ldb) — i.e. the
+ * nn.Linear weight layout [out,in].  K must be a multiple of 8; lda/ldb
+ * multiples of 8; A/B 16-byte aligned.
+ * ---------------------------------------------------------------------- */
+enum {
+    OMH_EPI_BF16      = 0,  /* C bf16  = acc + bias                               */
+    OMH_EPI_F32       = 1,  /* C fp32  = acc + bias                               */
+    OMH_EPI_GELU_BF16 = 2,  /* C bf16  = gelu_tanh(acc + bias)   (model.py:273)   */
+    OMH_EPI_RESID     = 3,  /* C fp32 += (acc + bias) * gate     (model.py:296,313,328) */
+    OMH_EPI_F32_ACCUM = 4   /* C fp32 += acc + bias               (used by backward) */
+};
+enum { OMH_BIAS_NONE = 0, OMH_BIAS_N = 1, OMH_BIAS_M = 2 };
+
+typedef struct omh_gemm_args {
+    const void* A; const void* B; void* C;
+    int32_t M, N, K;
+    int32_t lda, ldb, ldc;
+    int32_t batch;                /* >=1; grid.z                                  */
+    int64_t strideA, strideB, strideC;   /* per-batch element strides            */
+    int32_t epilogue;             /* OMH_EPI_*                                    */
+    int32_t bias_mode;            /* OMH_BIAS_*                                   */
+    const float* bias;            /* [N] or [M] fp32, may be NULL                 */
+    /* OMH_EPI_RESID gate = gate_const + gate0[n] + gate1[(m / gate_rows) * gate1_stride + n];
+       either pointer may be NULL (treated as 0).                                 */
+    const float* gate0; const float* gate1;
+    int64_t gate1_stride; int32_t gate_rows; float gate_const;
+} omh_gemm_args;
+
+int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Flash attention forward, head_dim 128, bf16, non-causal, key-length mask.
+ * Replaces flash_attn.flash_attn_varlen_func as called from
+ * attention.py:96-127 for self-attention (model.py:151-156) and
+ * cross-attention (model.py:181,221-223): out[b,i,h,:] =
+ * softmax_j<k_lens[b]( q[b,i,h,:].k[b,j,h,:] * scale ) v[b,j,h,:].
+ *   q  : [B, Lq, H, 128] bf16, element strides (q_bs, q_rs), head h at +h*128
+ *   k  : [B, Lk, H, 128] bf16, strides (k_bs, k_rs)
+ *   vt : V transposed, [B, H*128, ldv] bf16 (row = h*128+d, column = key);
+ *        ldv >= roundup(Lk,64), columns >= Lk must hold finite values
+ *   o  : [B, Lq, H, 128] bf16, strides (o_bs, o_rs)
+ *   k_lens: int32 [B] device pointer or NULL (= Lk); rows with k_lens 0 give 0.
+ * ---------------------------------------------------------------------- */
+typedef struct omh_attn_args {
+    const void* q; const void* k; const void* vt; void* o;
+    const int32_t* k_lens;
+    int32_t B, H, Lq, Lk;
+    int64_t q_bs, q_rs, k_bs, k_rs, vt_bs, o_bs, o_rs;
+    int32_t ldv;
+    float scale;                  /* softmax scale, 1/sqrt(128) in the reference  */
+    float* lse;                   /* optional [B,H,Lq] fp32 log-sum-exp (natural log) for backward; may be NULL */
+} omh_attn_args;
+
+int omh_flash_attn_fwd_d128(const omh_attn_args* args, omh_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * LayerNorm (no affine) fused with adaLN modulation, fp32 in -> bf16 out.
+ * Replaces WanLayerNorm + "x*(1+scale)+shift" (model.py:91-104,292-293,
+ * 314-315,358) and the affine norm3 (model.py:263-265,313).
+ *   y[r][c] = xhat[r][c] * (mul_const + mul0[c] + mul1[b*mul1_stride + c])
+ *                        + (add0[c] + add1[b*add1_stride + c]),  b = r / rows_per_batch
+ * any of mul0/mul1/add0/add1 may be NULL.  dim % 4 == 0, dim <= 8192.
+ * ---------------------------------------------------------------------- */
+int omh_layernorm_modulate(const float* x, void* y_bf16, int64_t rows, int32_t dim, float eps,
+                           float mul_const, const float* mul0, const float* mul1, int64_t mul1_stride,
+                           const float* add0, const float* add1, int64_t add1_stride,
+                           int64_t rows_per_batch, omh_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * WanRMSNorm over the full model dim (+ optional 3-axis RoPE), fp32 -> bf16.
+ * Replaces WanRMSNorm (model.py:72-88) and rope_apply (model.py:42-69) on
+ * the q/k projections (model.py:144-145,152-153,176-177,216-219).
+ *   x: [rows, ldx] fp32 (first `dim` columns used); y: [rows, dim] bf16
+ *   weight: [dim] fp32 or NULL (no gain, used when qk_norm is off -> plain cast)
+ *   do_norm: 0 = skip normalisation (Identity), 1 = RMS-normalise
+ *   rope: cos/sin tables [rope_len, head_dim/2] fp32 or NULL for no rotation;
+ *   grid: int32 [B,3] (f,h,w) on the device; rows = B*seq_len, token s of
+ *   sample b sits at row b*seq_len+s; tokens >= f*h*w are not rotated.
+ *   The first cf = c-2*(c/3) pair-columns use f, next c/3 use h, last c/3 use w.
+ * ---------------------------------------------------------------------- */
+int omh_rmsnorm_rope(const float* x, int64_t ldx, void* y_bf16, int64_t rows, int32_t dim,
+                     const float* weight, float eps, int32_t do_norm,
+                     const float* rope_cos, const float* rope_sin, int32_t rope_len,
+                     int32_t head_dim, const int32_t* grid, int32_t seq_len, omh_stream_t stream);
+
+/* fp32 -> bf16 cast (round to nearest even) of a contiguous buffer. */
+int omh_cast_f32_bf16(const float* x, void* y_bf16, int64_t n, omh_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Patchify: latent [C,F,H,W] fp32 -> token matrix [f*h*w, Kp] bf16 with
+ * column (c*pt + a)*ph*pw + i*pw + j  = x[c, f*pt+a, h*ph+i, w*pw+j]; columns
+ * >= C*pt*ph*pw (up to Kp) are zero.  With the Conv3d weight flattened to
+ * [dim, C*pt*ph*pw] this turns patch_embedding (model.py:463,515-518) into a GEMM.
+ * ---------------------------------------------------------------------- */
+int omh_patchify(const float* x, void* tokens_bf16, int32_t C, int32_t F, int32_t H, int32_t W,
+                 int32_t pt, int32_t ph, int32_t pw, int32_t Kp, omh_stream_t stream);
+
+/* Unpatchify (model.py:565-588): head output [f*h*w, pt*ph*pw*Cout] fp32 ->
+ * [Cout, f*pt, h*ph, w*pw] fp32, einsum 'fhwpqrc->cfphqwr'. */
+int omh_unpatchify(const float* tokens, float* out, int32_t Cout, int32_t f, int32_t h, int32_t w,
+                   int32_t pt, int32_t ph, int32_t pw, omh_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Small fp32 dense layer for the time embedding (model.py:469-471,526-528):
+ *   y[b][n] = act_out( sum_k act_in(x[b][k]) * W[n][k] + bias[n] )
+ * act: 0 none, 1 SiLU.  One wave per output element; B is tiny (batch).
+ * ---------------------------------------------------------------------- */
+int omh_dense_f32(const float* x, const float* W, const float* bias, float* y,
+                  int32_t B, int32_t N, int32_t K, int32_t act_in, int32_t act_out,
+                  omh_stream_t stream);
+
+/* sinusoidal_embedding_1d (model.py:17-27), computed in fp64, stored fp32:
+ * out[b] = [cos(t_b * 10000^(-i/half)) | sin(...)], i < half = dim/2. */
+int omh_sinusoidal_embedding(const float* t, float* out, int32_t B, int32_t dim, omh_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Classifier-free guidance + flow-matching sampler update on the latent
+ * (text2video.py:243-252; UniPC bh2 coefficients computed on the host):
+ *   v = uncond + g*(cond - uncond);  x0 = x - sigma*v  (stored to m0_out)
+ *   x_next = cx*x + c0*x0 + c1*m1 + c2*m2            (m1/m2 previous x0's or NULL)
+ * ---------------------------------------------------------------------- */
+int omh_cfg_sampler_step(const float* cond, const float* uncond, const float* x,
+                         const float* m1, const float* m2, float* m0_out, float* x_next,
+                         int64_t n, float guide, float sigma,
+                         float cx, float c0, float c1, float c2, omh_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMH_H */

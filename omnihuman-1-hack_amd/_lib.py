@@ -1,0 +1,91 @@
+"""ctypes binding of libomh.so — the C ABI declared in include/omh.h.
+
+The product path has no CPU fallback: if the library cannot be loaded (and
+cannot be built because hipcc is absent) importing this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libomh.so")
+
+
+class OmhError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        # build in-tree on first use (hipcc cross-compiles without a GPU)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_omh_build", os.path.join(_HERE, "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build(verbose=False)
+    try:
+        return C.CDLL(_LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise OmhError(f"cannot load the HIP kernel library {_LIB_PATH}: {e}") from e
+
+
+lib = _load()
+
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("C", vp),
+                ("M", i32), ("N", i32), ("K", i32),
+                ("lda", i32), ("ldb", i32), ("ldc", i32),
+                ("batch", i32),
+                ("strideA", i64), ("strideB", i64), ("strideC", i64),
+                ("epilogue", i32), ("bias_mode", i32),
+                ("bias", vp),
+                ("gate0", vp), ("gate1", vp),
+                ("gate1_stride", i64), ("gate_rows", i32), ("gate_const", f32)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("q", vp), ("k", vp), ("vt", vp), ("o", vp),
+                ("k_lens", vp),
+                ("B", i32), ("H", i32), ("Lq", i32), ("Lk", i32),
+                ("q_bs", i64), ("q_rs", i64), ("k_bs", i64), ("k_rs", i64),
+                ("vt_bs", i64), ("o_bs", i64), ("o_rs", i64),
+                ("ldv", i32), ("scale", f32), ("lse", vp)]
+
+
+EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID, EPI_F32_ACCUM = 0, 1, 2, 3, 4
+BIAS_NONE, BIAS_N, BIAS_M = 0, 1, 2
+
+_SIGS = {
+    "omh_abi_version": (i32, []),
+    "omh_build_arch": (C.c_char_p, []),
+    "omh_gemm_bf16": (i32, [C.POINTER(GemmArgs), vp]),
+    "omh_flash_attn_fwd_d128": (i32, [C.POINTER(AttnArgs), vp]),
+    "omh_layernorm_modulate": (i32, [vp, vp, i64, i32, f32, f32, vp, vp, i64, vp, vp, i64, i64, vp]),
+    "omh_rmsnorm_rope": (i32, [vp, i64, vp, i64, i32, vp, f32, i32, vp, vp, i32, i32, vp, i32, vp]),
+    "omh_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
+    "omh_patchify": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "omh_unpatchify": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "omh_dense_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "omh_sinusoidal_embedding": (i32, [vp, vp, i32, i32, vp]),
+    "omh_cfg_sampler_step": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp]),
+}
+
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)      # AttributeError here = header/library out of sync
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+EXPORTED = tuple(_SIGS)
+
+_ERR = {-1: "OMH_E_BADARG", -2: "OMH_E_ALIGN", -3: "OMH_E_SHAPE"}
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise OmhError(f"{what} failed: {_ERR.get(rc, 'hipError ' + str(rc))}")
+
+
+if lib.omh_abi_version() != 1:  # pragma: no cover
+    raise OmhError("libomh.so ABI version mismatch")

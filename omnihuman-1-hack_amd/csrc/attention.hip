@@ -1,0 +1,245 @@
+// Flash attention forward for gfx950: head_dim 128, bf16 in/out, fp32
+// accumulate, non-causal, per-batch key-length mask.
+//
+// Replaces flash_attn.flash_attn_varlen_func as called by the reference at
+// seaweed_apt/wan/modules/attention.py:96-127 (self-attention model.py:151-156,
+// cross-attention model.py:181,221-223).
+//
+// Formulation (everything "transposed" so softmax statistics are lane-local):
+//   S^T = K Q^T     MFMA A = K rows (from LDS), B = Q rows (registers)
+//   O^T = V^T P^T   MFMA A = V^T rows (from LDS), B = P (registers, bf16)
+// With v_mfma_f32_32x32x16_bf16 the C/D layout gives lane l = (q = l&31,
+// half h = l>>5) the scores of ONE query against 16 keys per 32-key block, so
+// row max / row sum are 16-value in-register reductions plus one exchange
+// with lane l^32, and O^T leaves each lane with its own query's outputs: the
+// online-softmax rescale is a per-lane scalar.  K rows are fed to the MFMA
+// with key bits 2 and 3 swapped, which makes a lane's 8 consecutive score
+// registers correspond to 8 CONSECUTIVE keys — exactly the B-operand layout
+// the P.V MFMA wants — so P never moves between lanes.  V is consumed
+// transposed ([d][key], produced that way by the V-projection GEMM).
+//
+// Workgroup = 4 waves x 32 query rows = 128 rows of one (batch, head);
+// KV tile = 64 keys; K tile [64][128] and V^T tile [128][64] bf16 staged
+// HBM -> registers -> LDS (XOR-swizzled 16-byte slots, conflict-free
+// ds_read_b128), double buffered, one barrier per tile, next tile's global
+// loads issued before the current tile's MFMAs.
+#include "omh_common.h"
+
+namespace {
+
+constexpr int D = 128;
+constexpr int QB = 128;   // query rows per workgroup
+constexpr int KB = 64;    // keys per tile
+constexpr int KT_BYTES = KB * D * 2;   // 16 KiB
+constexpr int VT_BYTES = D * KB * 2;   // 16 KiB
+
+__device__ __forceinline__ int swap_bits23(int i) {
+    return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
+}
+// K tile: [64 keys][128 d] bf16, 256-byte rows = 16 slots, slot ^= row & 15
+__device__ __forceinline__ uint32_t k_addr(int row, int slot) {
+    return (uint32_t)(row * 256 + ((slot ^ (row & 15)) << 4));
+}
+// V^T tile: [128 d][64 keys] bf16, 128-byte rows = 8 slots, slot ^= (row>>1)&7
+__device__ __forceinline__ uint32_t v_addr(int row, int slot) {
+    return (uint32_t)(row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+}
+
+__global__ __launch_bounds__(256, 2)
+void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (KT_BYTES + VT_BYTES)];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // work id -> (batch*head, q tile); consecutive ids (same head) share an XCD
+    const int nwg = q_tiles * p.H * p.B;
+    const int wid = xcd_remap(blockIdx.x, nwg);
+    const int bh = wid / q_tiles, qt = wid % q_tiles;
+    const int b = bh / p.H, head = bh % p.H;
+
+    int klen = p.k_lens ? p.k_lens[b] : p.Lk;
+    klen = min(max(klen, 0), p.Lk);
+    const int n_tiles = (klen + KB - 1) / KB;
+
+    const __bf16* __restrict__ Q = (const __bf16*)p.q + (int64_t)b * p.q_bs + head * D;
+    const __bf16* __restrict__ K = (const __bf16*)p.k + (int64_t)b * p.k_bs + head * D;
+    const __bf16* __restrict__ VT = (const __bf16*)p.vt + (int64_t)b * p.vt_bs + (int64_t)head * D * p.ldv;
+
+    // ---- Q fragments (MFMA B operand): lane (q = li, h) holds Q[q][16kk + 8h .. +7]
+    const int q_row = qt * QB + wave * 32 + li;
+    const int q_ld = min(q_row, p.Lq - 1);
+    bf16x8 qf[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+        qf[kk] = *(const bf16x8*)(Q + (int64_t)q_ld * p.q_rs + kk * 16 + lh * 8);
+
+    // ---- staging: 4 K chunks + 4 V^T chunks of 16 bytes per thread and tile
+    // K tile: chunk c -> row c>>4 (key), slot c&15 ; V^T tile: row c>>3 (d), slot c&7
+    uint4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+#define OMH_GLOAD1(RK, RV, J, KV0)                                                              \
+    {                                                                                           \
+        const int c_ = tid + 256 * (J);                                                         \
+        const int krow_ = min((KV0) + (c_ >> 4), p.Lk - 1);                                     \
+        RK = *(const uint4*)(K + (int64_t)krow_ * p.k_rs + (c_ & 15) * 8);                      \
+        const int vcol_ = (KV0) + (c_ & 7) * 8;                                                 \
+        RV = *(const uint4*)(VT + (int64_t)(c_ >> 3) * p.ldv + min(vcol_, p.ldv - 8));          \
+        if (vcol_ + 8 > p.ldv) RV = zero4;                                                      \
+    }
+#define OMH_GLOAD(T)                                                                            \
+    {                                                                                           \
+        const int kv0_ = (T) * KB;                                                              \
+        OMH_GLOAD1(rk0, rv0, 0, kv0_) OMH_GLOAD1(rk1, rv1, 1, kv0_)                             \
+        OMH_GLOAD1(rk2, rv2, 2, kv0_) OMH_GLOAD1(rk3, rv3, 3, kv0_)                             \
+    }
+#define OMH_LSTORE1(RK, RV, J, KT, VTL)                                                         \
+    {                                                                                           \
+        const int c_ = tid + 256 * (J);                                                         \
+        *(uint4*)((KT) + k_addr(c_ >> 4, c_ & 15)) = RK;                                        \
+        *(uint4*)((VTL) + v_addr(c_ >> 3, c_ & 7)) = RV;                                        \
+    }
+#define OMH_LSTORE(BUF)                                                                         \
+    {                                                                                           \
+        unsigned char* kt_ = smem + (BUF) * (KT_BYTES + VT_BYTES);                              \
+        unsigned char* vt_ = kt_ + KT_BYTES;                                                    \
+        OMH_LSTORE1(rk0, rv0, 0, kt_, vt_) OMH_LSTORE1(rk1, rv1, 1, kt_, vt_)                   \
+        OMH_LSTORE1(rk2, rv2, 2, kt_, vt_) OMH_LSTORE1(rk3, rv3, 3, kt_, vt_)                   \
+    }
+
+    f32x16 oacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc = p.scale * 1.4426950408889634f;   // scores -> log2 domain
+
+    if (n_tiles > 0) {
+        OMH_GLOAD(0)
+        OMH_LSTORE(0)
+    }
+    __syncthreads();
+
+    const int krow_l = swap_bits23(li);
+    for (int t = 0; t < n_tiles; ++t) {
+        const int buf = t & 1;
+        OMH_GLOAD(min(t + 1, n_tiles - 1))   // unconditional: keeps the staging registers out of scratch
+        const unsigned char* kt = smem + buf * (KT_BYTES + VT_BYTES);
+        const unsigned char* vt = kt + KT_BYTES;
+
+        // ---- S^T = K Q^T : two 32-key blocks
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const bf16x8 kf = *(const bf16x8*)(kt + k_addr(kb * 32 + krow_l, 2 * kk + lh));
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kb], 0, 0, 0);
+            }
+        }
+        // register r of block kb  <->  key kv0 + 32kb + 16(r>>3) + 8h + (r&7)
+        const int kv0 = t * KB;
+        if (kv0 + KB > klen) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + kb * 32 + ((r >> 3) << 4) + lh * 8 + (r & 7);
+                    if (key >= klen) s[kb][r] = -INFINITY;
+                }
+        }
+        // ---- online softmax (log2 domain)
+        float mx = s[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx * sc);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = exp2f(fmaf(s[kb][r], sc, -m_new));
+                s[kb][r] = pv;
+                rs += pv;
+            }
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+
+        // ---- P -> bf16 MFMA B operands: pf[kb][a] covers keys 32kb + 16a + 8h + 0..7
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                u32x4 cv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    cv[e] = pack_bf2(s[kb][8 * a + 2 * e], s[kb][8 * a + 2 * e + 1]);
+                pf[kb][a] = __builtin_bit_cast(bf16x8, cv);
+            }
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const bf16x8 vf = *(const bf16x8*)(vt + v_addr(db * 32 + li, 4 * kb + 2 * a + lh));
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][a], oacc[db], 0, 0, 0);
+                }
+
+        OMH_LSTORE(buf ^ 1)
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane holds O[q][32db + 8g + 4h + 0..3]
+    if (q_row < p.Lq) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        uint16_t* O = (uint16_t*)p.o + (int64_t)b * p.o_bs + (int64_t)q_row * p.o_rs + head * D;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                uint2 pk;
+                pk.x = pack_bf2(oacc[db][4 * gq] * inv, oacc[db][4 * gq + 1] * inv);
+                pk.y = pack_bf2(oacc[db][4 * gq + 2] * inv, oacc[db][4 * gq + 3] * inv);
+                *(uint2*)(O + db * 32 + gq * 8 + lh * 4) = pk;
+            }
+        if (p.lse && lh == 0) {
+            // natural-log LSE of the scaled scores
+            const float lse = l_run > 0.f ? (m_run + log2f(l_run)) * 0.6931471805599453f : -INFINITY;
+            p.lse[((int64_t)b * p.H + head) * p.Lq + q_row] = lse;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int omh_flash_attn_fwd_d128(const omh_attn_args* args, omh_stream_t stream) {
+    if (!args || !args->q || !args->k || !args->vt || !args->o) return OMH_E_BADARG;
+    const omh_attn_args& a = *args;
+    if (a.B <= 0 || a.H <= 0 || a.Lq <= 0 || a.Lk <= 0) return OMH_E_BADARG;
+    if ((a.q_rs & 7) || (a.k_rs & 7) || (a.o_rs & 3) || (a.ldv & 7) || (a.q_bs & 7) || (a.k_bs & 7) ||
+        (a.vt_bs & 7) || (a.o_bs & 3))
+        return OMH_E_ALIGN;
+    if (((uintptr_t)a.q & 15) || ((uintptr_t)a.k & 15) || ((uintptr_t)a.vt & 15) || ((uintptr_t)a.o & 7))
+        return OMH_E_ALIGN;
+    if (a.ldv < ((a.Lk + KB - 1) / KB) * KB) return OMH_E_SHAPE;
+    const int q_tiles = (a.Lq + QB - 1) / QB;
+    dim3 grid(q_tiles * a.H * a.B);
+    hipLaunchKernelGGL(flash_attn_fwd_d128_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, q_tiles);
+    return omh_launch_status();
+}

@@ -1,0 +1,344 @@
+// HBM-bound row kernels of the DiT block for gfx950: LayerNorm+adaLN
+// modulation, WanRMSNorm(+3-axis RoPE), casts, patchify / unpatchify, and the
+// tiny fp32 dense layers of the time embedding.  One 64-lane wave owns one
+// row; rows are read once with 16-byte loads and kept in registers.
+//
+// Reference arithmetic replaced (seaweed_apt/wan/modules/model.py):
+//   layernorm_modulate  :91-104, 292-293, 313-315, 358
+//   rmsnorm_rope        :72-88 (WanRMSNorm), :42-69 (rope_apply)
+//   patchify/unpatchify :463,515-518 / :565-588
+//   dense_f32, sinusoid :17-27, 469-471, 526-528
+#include "omh_common.h"
+
+namespace {
+
+constexpr int MAXV = 32;   // float4 chunks per lane -> dim <= 8192
+
+// ------------------------------------------------------------------ LayerNorm + modulate
+__global__ __launch_bounds__(256)
+void layernorm_modulate_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t rows, int dim,
+                               float eps, float mul_const, const float* __restrict__ mul0,
+                               const float* __restrict__ mul1, int64_t mul1_stride,
+                               const float* __restrict__ add0, const float* __restrict__ add1,
+                               int64_t add1_stride, int64_t rows_per_batch) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = dim >> 2;
+    const float4* xr = (const float4*)(x + row * dim);
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            v[i] = xr[c];
+            s += v[i].x + v[i].y + v[i].z + v[i].w;
+        }
+    }
+    const float mean = wave_sum(s) / dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            q += a * a + b * b + cc * cc + d * d;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / dim + eps);
+    const int64_t bidx = row / rows_per_batch;
+    const float4* m0 = (const float4*)mul0;
+    const float4* m1 = mul1 ? (const float4*)(mul1 + bidx * mul1_stride) : nullptr;
+    const float4* a0 = (const float4*)add0;
+    const float4* a1 = add1 ? (const float4*)(add1 + bidx * add1_stride) : nullptr;
+    uint2* yr = (uint2*)(y + row * dim);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            float4 mu = make_float4(mul_const, mul_const, mul_const, mul_const);
+            float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0) { const float4 t = m0[c]; mu.x += t.x; mu.y += t.y; mu.z += t.z; mu.w += t.w; }
+            if (m1) { const float4 t = m1[c]; mu.x += t.x; mu.y += t.y; mu.z += t.z; mu.w += t.w; }
+            if (a0) { const float4 t = a0[c]; ad.x += t.x; ad.y += t.y; ad.z += t.z; ad.w += t.w; }
+            if (a1) { const float4 t = a1[c]; ad.x += t.x; ad.y += t.y; ad.z += t.z; ad.w += t.w; }
+            uint2 o;
+            o.x = pack_bf2((v[i].x - mean) * rstd * mu.x + ad.x, (v[i].y - mean) * rstd * mu.y + ad.y);
+            o.y = pack_bf2((v[i].z - mean) * rstd * mu.z + ad.z, (v[i].w - mean) * rstd * mu.w + ad.w);
+            yr[c] = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ RMSNorm (+RoPE)
+__global__ __launch_bounds__(256)
+void rmsnorm_rope_kernel(const float* __restrict__ x, int64_t ldx, uint16_t* __restrict__ y, int64_t rows,
+                         int dim, const float* __restrict__ weight, float eps, int do_norm,
+                         const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
+                         int rope_len, int head_dim, const int* __restrict__ grid, int seq_len) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = dim >> 2;
+    const float4* xr = (const float4*)(x + row * ldx);
+    float4 v[MAXV];
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            v[i] = xr[c];
+            q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+        }
+    }
+    const float rinv = do_norm ? rsqrtf(wave_sum(q) / dim + eps) : 1.0f;
+
+    // token position for RoPE
+    bool rot = false;
+    int pf = 0, ph = 0, pw = 0;
+    const int hc = head_dim >> 1;                 // complex pairs per head
+    const int c3 = hc / 3, cf = hc - 2 * c3;
+    if (rope_cos) {
+        const int b = (int)(row / seq_len), s = (int)(row % seq_len);
+        const int gf = grid[3 * b], gh = grid[3 * b + 1], gw = grid[3 * b + 2];
+        if (s < gf * gh * gw) {
+            rot = true;
+            pf = s / (gh * gw);
+            ph = (s / gw) % gh;
+            pw = s % gw;
+        }
+    }
+    const float4* wv = (const float4*)weight;
+    uint2* yr = (uint2*)(y + row * dim);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            float4 t = v[i];
+            t.x *= rinv; t.y *= rinv; t.z *= rinv; t.w *= rinv;
+            if (wv) { const float4 g = wv[c]; t.x *= g.x; t.y *= g.y; t.z *= g.z; t.w *= g.w; }
+            if (rot) {
+                // columns 4c..4c+3 = complex pairs p0 = (4c mod head_dim)/2 and p0+1
+                const int p0 = ((4 * c) % head_dim) >> 1;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int pc = p0 + e;
+                    const int pos = pc < cf ? pf : (pc < cf + c3 ? ph : pw);
+                    const int idx = min(pos, rope_len - 1) * hc + pc;
+                    const float cs = rope_cos[idx], sn = rope_sin[idx];
+                    float& re = e == 0 ? t.x : t.z;
+                    float& im = e == 0 ? t.y : t.w;
+                    const float nr = re * cs - im * sn;
+                    const float ni = re * sn + im * cs;
+                    re = nr; im = ni;
+                }
+            }
+            uint2 o;
+            o.x = pack_bf2(t.x, t.y);
+            o.y = pack_bf2(t.z, t.w);
+            yr[c] = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ cast
+__global__ __launch_bounds__(256)
+void cast_f32_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t n) {
+    const int64_t nv = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+        const float4 t = ((const float4*)x)[i];
+        uint2 o;
+        o.x = pack_bf2(t.x, t.y);
+        o.y = pack_bf2(t.z, t.w);
+        ((uint2*)y)[i] = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (nv << 2) + threadIdx.x;
+        y[i] = f2bf(x[i]);
+    }
+}
+
+// ------------------------------------------------------------------ patchify / unpatchify
+__global__ __launch_bounds__(256)
+void patchify_kernel(const float* __restrict__ x, uint16_t* __restrict__ tok, int C, int F, int H, int W,
+                     int pt, int ph, int pw, int Kp) {
+    const int gf = F / pt, gh = H / ph, gw = W / pw;
+    const int64_t total = (int64_t)gf * gh * gw * Kp;
+    const int kvalid = C * pt * ph * pw;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int k = (int)(i % Kp);
+        const int64_t s = i / Kp;
+        float val = 0.f;
+        if (k < kvalid) {
+            const int j = k % pw, ii = (k / pw) % ph, a = (k / (pw * ph)) % pt, c = k / (pw * ph * pt);
+            const int w = (int)(s % gw), h = (int)((s / gw) % gh), f = (int)(s / ((int64_t)gw * gh));
+            val = x[(((int64_t)c * F + f * pt + a) * H + h * ph + ii) * W + w * pw + j];
+        }
+        tok[i] = f2bf(val);
+    }
+}
+
+__global__ __launch_bounds__(256)
+void unpatchify_kernel(const float* __restrict__ tok, float* __restrict__ out, int Cout, int gf, int gh, int gw,
+                       int pt, int ph, int pw) {
+    // out[c][f*pt+a][h*ph+i][w*pw+j] = tok[(f,h,w)][((a*ph+i)*pw+j)*Cout + c]
+    const int F = gf * pt, H = gh * ph, W = gw * pw;
+    const int64_t total = (int64_t)Cout * F * H * W;
+    const int ncol = pt * ph * pw * Cout;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int ww = (int)(i % W), hh = (int)((i / W) % H), ff = (int)((i / ((int64_t)W * H)) % F);
+        const int c = (int)(i / ((int64_t)W * H * F));
+        const int w = ww / pw, j = ww % pw, h = hh / ph, ii = hh % ph, f = ff / pt, a = ff % pt;
+        const int64_t s = ((int64_t)f * gh + h) * gw + w;
+        out[i] = tok[s * ncol + ((a * ph + ii) * pw + j) * Cout + c];
+    }
+}
+
+// ------------------------------------------------------------------ tiny fp32 dense / sinusoid
+__global__ __launch_bounds__(256)
+void dense_f32_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+                      float* __restrict__ y, int B, int N, int K, int act_in, int act_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // output index b*N + n
+    if (o >= (int64_t)B * N) return;
+    const int b = (int)(o / N), n = (int)(o % N);
+    const float* xr = x + (int64_t)b * K;
+    const float* wr = W + (int64_t)n * K;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        float xv = xr[k];
+        if (act_in == 1) xv = xv / (1.0f + expf(-xv));
+        s = fmaf(xv, wr[k], s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        if (bias) s += bias[n];
+        if (act_out == 1) s = s / (1.0f + expf(-s));
+        y[o] = s;
+    }
+}
+
+__global__ void sinusoid_kernel(const float* __restrict__ t, float* __restrict__ out, int B, int dim) {
+    const int half = dim / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half) return;
+    const int b = i / half, k = i % half;
+    const double ang = (double)t[b] * pow(10000.0, -(double)k / (double)half);
+    out[(int64_t)b * dim + k] = (float)cos(ang);
+    out[(int64_t)b * dim + half + k] = (float)sin(ang);
+}
+
+// ------------------------------------------------------------------ CFG + sampler update
+__global__ __launch_bounds__(256)
+void cfg_sampler_kernel(const float* __restrict__ cond, const float* __restrict__ uncond,
+                        const float* __restrict__ x, const float* __restrict__ m1, const float* __restrict__ m2,
+                        float* __restrict__ m0_out, float* __restrict__ x_next, int64_t n, float guide,
+                        float sigma, float cx, float c0, float c1, float c2) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float u = uncond[i];
+        const float v = u + guide * (cond[i] - u);
+        const float xv = x[i];
+        const float x0 = xv - sigma * v;
+        float r = cx * xv + c0 * x0;
+        if (m1) r += c1 * m1[i];
+        if (m2) r += c2 * m2[i];
+        if (m0_out) m0_out[i] = x0;
+        x_next[i] = r;
+    }
+}
+
+inline int grid_for(int64_t n, int per_block) {
+    int64_t g = (n + per_block - 1) / per_block;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+extern "C" int omh_layernorm_modulate(const float* x, void* y, int64_t rows, int32_t dim, float eps,
+                                      float mul_const, const float* mul0, const float* mul1, int64_t mul1_stride,
+                                      const float* add0, const float* add1, int64_t add1_stride,
+                                      int64_t rows_per_batch, omh_stream_t stream) {
+    if (!x || !y || rows <= 0 || dim <= 0 || rows_per_batch <= 0) return OMH_E_BADARG;
+    if ((dim & 3) || dim > MAXV * 256) return OMH_E_SHAPE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 7) || (mul1_stride & 3) || (add1_stride & 3)) return OMH_E_ALIGN;
+    hipLaunchKernelGGL(layernorm_modulate_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, x, (uint16_t*)y, rows, dim, eps, mul_const, mul0, mul1, mul1_stride,
+                       add0, add1, add1_stride, rows_per_batch);
+    return omh_launch_status();
+}
+
+extern "C" int omh_rmsnorm_rope(const float* x, int64_t ldx, void* y, int64_t rows, int32_t dim,
+                                const float* weight, float eps, int32_t do_norm, const float* rope_cos,
+                                const float* rope_sin, int32_t rope_len, int32_t head_dim, const int32_t* grid,
+                                int32_t seq_len, omh_stream_t stream) {
+    if (!x || !y || rows <= 0 || dim <= 0) return OMH_E_BADARG;
+    if ((dim & 3) || dim > MAXV * 256 || (ldx & 3)) return OMH_E_SHAPE;
+    if (rope_cos && (!rope_sin || !grid || seq_len <= 0 || head_dim <= 0 || (head_dim & 3) || dim % head_dim))
+        return OMH_E_BADARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return OMH_E_ALIGN;
+    hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       x, ldx, (uint16_t*)y, rows, dim, weight, eps, do_norm, rope_cos, rope_sin, rope_len,
+                       head_dim, grid, seq_len);
+    return omh_launch_status();
+}
+
+extern "C" int omh_cast_f32_bf16(const float* x, void* y, int64_t n, omh_stream_t stream) {
+    if (!x || !y || n <= 0) return OMH_E_BADARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return OMH_E_ALIGN;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, (uint16_t*)y, n);
+    return omh_launch_status();
+}
+
+extern "C" int omh_patchify(const float* x, void* tok, int32_t C, int32_t F, int32_t H, int32_t W, int32_t pt,
+                            int32_t ph, int32_t pw, int32_t Kp, omh_stream_t stream) {
+    if (!x || !tok || C <= 0 || F <= 0 || H <= 0 || W <= 0 || pt <= 0 || ph <= 0 || pw <= 0) return OMH_E_BADARG;
+    if (F % pt || H % ph || W % pw || Kp < C * pt * ph * pw) return OMH_E_SHAPE;
+    const int64_t total = (int64_t)(F / pt) * (H / ph) * (W / pw) * Kp;
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (uint16_t*)tok, C, F, H, W, pt, ph, pw, Kp);
+    return omh_launch_status();
+}
+
+extern "C" int omh_unpatchify(const float* tok, float* out, int32_t Cout, int32_t f, int32_t h, int32_t w,
+                              int32_t pt, int32_t ph, int32_t pw, omh_stream_t stream) {
+    if (!tok || !out || Cout <= 0 || f <= 0 || h <= 0 || w <= 0 || pt <= 0 || ph <= 0 || pw <= 0)
+        return OMH_E_BADARG;
+    const int64_t total = (int64_t)Cout * f * pt * h * ph * w * pw;
+    hipLaunchKernelGGL(unpatchify_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, tok, out,
+                       Cout, f, h, w, pt, ph, pw);
+    return omh_launch_status();
+}
+
+extern "C" int omh_dense_f32(const float* x, const float* W, const float* bias, float* y, int32_t B, int32_t N,
+                             int32_t K, int32_t act_in, int32_t act_out, omh_stream_t stream) {
+    if (!x || !W || !y || B <= 0 || N <= 0 || K <= 0) return OMH_E_BADARG;
+    const int64_t outs = (int64_t)B * N;
+    hipLaunchKernelGGL(dense_f32_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, W,
+                       bias, y, B, N, K, act_in, act_out);
+    return omh_launch_status();
+}
+
+extern "C" int omh_sinusoidal_embedding(const float* t, float* out, int32_t B, int32_t dim, omh_stream_t stream) {
+    if (!t || !out || B <= 0 || dim <= 0 || (dim & 1)) return OMH_E_BADARG;
+    const int n = B * (dim / 2);
+    hipLaunchKernelGGL(sinusoid_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, out, B, dim);
+    return omh_launch_status();
+}
+
+extern "C" int omh_cfg_sampler_step(const float* cond, const float* uncond, const float* x, const float* m1,
+                                    const float* m2, float* m0_out, float* x_next, int64_t n, float guide,
+                                    float sigma, float cx, float c0, float c1, float c2, omh_stream_t stream) {
+    if (!cond || !uncond || !x || !x_next || n <= 0) return OMH_E_BADARG;
+    hipLaunchKernelGGL(cfg_sampler_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, cond, uncond,
+                       x, m1, m2, m0_out, x_next, n, guide, sigma, cx, c0, c1, c2);
+    return omh_launch_status();
+}
+
+extern "C" int omh_abi_version(void) { return OMH_ABI_VERSION; }
+extern "C" const char* omh_build_arch(void) { return "gfx950"; }

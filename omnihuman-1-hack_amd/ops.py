@@ -1,0 +1,188 @@
+"""Tensor-level wrappers over the libomh.so C ABI (include/omh.h).
+
+PyTorch supplies device memory and the current HIP stream; every arithmetic
+op below is one of the hand-written gfx950 kernels.  There is no CPU path:
+a non-GPU tensor raises.
+"""
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (BIAS_M, BIAS_N, BIAS_NONE, EPI_BF16, EPI_F32, EPI_F32_ACCUM, EPI_GELU_BF16, EPI_RESID,
+                   AttnArgs, GemmArgs, OmhError, check, lib)
+
+__all__ = ["gemm", "flash_attn", "layernorm_modulate", "rmsnorm_rope", "cast_bf16", "patchify", "unpatchify",
+           "dense_f32", "sinusoidal_embedding", "cfg_sampler_step", "OmhError",
+           "EPI_BF16", "EPI_F32", "EPI_GELU_BF16", "EPI_RESID", "EPI_F32_ACCUM", "BIAS_NONE", "BIAS_N", "BIAS_M"]
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise OmhError("omnihuman-1-hack_amd ops run on the MI355X only: got a CPU tensor "
+                           "(there is no CPU fallback in the product path)")
+
+
+def _p(t: Optional[torch.Tensor], byte_off: int = 0):
+    return None if t is None else C.c_void_p(t.data_ptr() + byte_off)
+
+
+def ptr(t: torch.Tensor, elem_off: int = 0):
+    """Raw device pointer ``elem_off`` elements into ``t`` (for the *_raw ops)."""
+    return C.c_void_p(t.data_ptr() + elem_off * t.element_size())
+
+
+def gemm_raw(A, B, Cp, M, N, K, lda, ldb, ldc, epilogue, bias=None, bias_mode=BIAS_NONE, batch=1,
+             strideA=0, strideB=0, strideC=0, gate0=None, gate1=None, gate1_stride=0, gate_rows=1,
+             gate_const=0.0):
+    """C[m][n] = epi(sum_k A[m][k] B[n][k]); all pointers are c_void_p."""
+    a = GemmArgs(A, B, Cp, M, N, K, lda, ldb, ldc, batch, strideA, strideB, strideC, epilogue, bias_mode, bias,
+                 gate0, gate1, gate1_stride, gate_rows, gate_const)
+    check(lib.omh_gemm_bf16(C.byref(a), _stream()), "omh_gemm_bf16")
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+         epilogue: int = EPI_BF16):
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias[N]); a, w bf16 contiguous."""
+    _dev(a, w, out, bias)
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.dim() == 2 and w.dim() == 2
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.stride(1) == 1 and w.stride(1) == 1
+    if out is None:
+        odt = torch.bfloat16 if epilogue in (EPI_BF16, EPI_GELU_BF16) else torch.float32
+        out = torch.empty(M, N, dtype=odt, device=a.device)
+    gemm_raw(_p(a), _p(w), _p(out), M, N, K, a.stride(0), w.stride(0), out.stride(0), epilogue,
+             bias=_p(bias), bias_mode=BIAS_N if bias is not None else BIAS_NONE)
+    return out
+
+
+def flash_attn_raw(q, k, vt, o, k_lens, B, H, Lq, Lk, q_bs, q_rs, k_bs, k_rs, vt_bs, o_bs, o_rs, ldv, scale,
+                   lse=None):
+    a = AttnArgs(q, k, vt, o, k_lens, B, H, Lq, Lk, q_bs, q_rs, k_bs, k_rs, vt_bs, o_bs, o_rs, ldv, scale, lse)
+    check(lib.omh_flash_attn_fwd_d128(C.byref(a), _stream()), "omh_flash_attn_fwd_d128")
+
+
+def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, k_lens: Optional[torch.Tensor] = None,
+               scale: Optional[float] = None, out: Optional[torch.Tensor] = None):
+    """q [B,Lq,H,128], k [B,Lk,H,128] bf16; vt [B,H*128,ldv] bf16 (V transposed,
+    ldv >= roundup(Lk,64)); k_lens int32 [B] or None.  Returns [B,Lq,H,128] bf16."""
+    _dev(q, k, vt, k_lens, out)
+    B, Lq, H, D = q.shape
+    Lk = k.shape[1]
+    assert D == 128 and k.shape == (B, Lk, H, D) and vt.shape[0] == B and vt.shape[1] == H * D
+    assert q.dtype == k.dtype == vt.dtype == torch.bfloat16
+    assert q.stride(3) == 1 and q.stride(2) == D and k.stride(3) == 1 and k.stride(2) == D and vt.stride(2) == 1
+    if k_lens is not None:
+        assert k_lens.dtype == torch.int32
+    if out is None:
+        out = torch.empty(B, Lq, H, D, dtype=torch.bfloat16, device=q.device)
+    flash_attn_raw(_p(q), _p(k), _p(vt), _p(out), _p(k_lens), B, H, Lq, Lk, q.stride(0), q.stride(1), k.stride(0),
+                   k.stride(1), vt.stride(0), out.stride(0), out.stride(1), vt.stride(1),
+                   float(scale if scale is not None else D ** -0.5))
+    return out
+
+
+def layernorm_modulate_raw(x, y, rows, dim, eps, mul_const, mul0, mul1, mul1_stride, add0, add1, add1_stride,
+                           rows_per_batch):
+    check(lib.omh_layernorm_modulate(x, y, rows, dim, eps, mul_const, mul0, mul1, mul1_stride, add0, add1,
+                                     add1_stride, rows_per_batch, _stream()), "omh_layernorm_modulate")
+
+
+def layernorm_modulate(x: torch.Tensor, eps: float, mul_const: float = 1.0, mul0=None, mul1=None, add0=None,
+                       add1=None, rows_per_batch: Optional[int] = None, out=None):
+    """x fp32 [rows, dim] -> bf16; see include/omh.h."""
+    _dev(x, mul0, mul1, add0, add1)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    rows, dim = x.numel() // x.shape[-1], x.shape[-1]
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    layernorm_modulate_raw(_p(x), _p(out), rows, dim, eps, mul_const, _p(mul0), _p(mul1),
+                           mul1.stride(0) if mul1 is not None else 0, _p(add0), _p(add1),
+                           add1.stride(0) if add1 is not None else 0, rows_per_batch or rows)
+    return out
+
+
+def rmsnorm_rope_raw(x, ldx, y, rows, dim, weight, eps, do_norm, rope_cos, rope_sin, rope_len, head_dim, grid,
+                     seq_len):
+    check(lib.omh_rmsnorm_rope(x, ldx, y, rows, dim, weight, eps, do_norm, rope_cos, rope_sin, rope_len, head_dim,
+                               grid, seq_len, _stream()), "omh_rmsnorm_rope")
+
+
+def rmsnorm_rope(x: torch.Tensor, weight: Optional[torch.Tensor], eps: float, do_norm: bool = True,
+                 rope_cos=None, rope_sin=None, head_dim: int = 128, grid: Optional[torch.Tensor] = None,
+                 seq_len: int = 0, out=None):
+    """x fp32 [rows, dim] (row stride may exceed dim) -> bf16 [rows, dim]."""
+    _dev(x, weight, rope_cos, rope_sin, grid)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    rows, dim = x.shape
+    if out is None:
+        out = torch.empty(rows, dim, dtype=torch.bfloat16, device=x.device)
+    rmsnorm_rope_raw(_p(x), x.stride(0), _p(out), rows, dim, _p(weight), eps, int(do_norm), _p(rope_cos),
+                     _p(rope_sin), rope_cos.shape[0] if rope_cos is not None else 0, head_dim, _p(grid), seq_len)
+    return out
+
+
+def cast_bf16(x: torch.Tensor, out=None):
+    _dev(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(lib.omh_cast_f32_bf16(_p(x), _p(out), x.numel(), _stream()), "omh_cast_f32_bf16")
+    return out
+
+
+def patchify(x: torch.Tensor, patch, Kp: int, out=None):
+    """x fp32 [C,F,H,W] -> bf16 [f*h*w, Kp]."""
+    _dev(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    Cc, F, H, W = x.shape
+    pt, ph, pw = patch
+    n = (F // pt) * (H // ph) * (W // pw)
+    if out is None:
+        out = torch.empty(n, Kp, dtype=torch.bfloat16, device=x.device)
+    check(lib.omh_patchify(_p(x), _p(out), Cc, F, H, W, pt, ph, pw, Kp, _stream()), "omh_patchify")
+    return out
+
+
+def unpatchify(tok: torch.Tensor, c_out: int, grid, patch):
+    """tok fp32 [>= f*h*w, pt*ph*pw*c_out] -> fp32 [c_out, f*pt, h*ph, w*pw]."""
+    _dev(tok)
+    assert tok.dtype == torch.float32 and tok.is_contiguous()
+    f, h, w = grid
+    pt, ph, pw = patch
+    out = torch.empty(c_out, f * pt, h * ph, w * pw, dtype=torch.float32, device=tok.device)
+    check(lib.omh_unpatchify(_p(tok), _p(out), c_out, f, h, w, pt, ph, pw, _stream()), "omh_unpatchify")
+    return out
+
+
+def dense_f32(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act_in: int = 0, act_out: int = 0):
+    """y[b] = act_out(act_in(x[b]) @ w^T + bias), all fp32 (time embedding)."""
+    _dev(x, w, bias)
+    assert x.dtype == w.dtype == torch.float32 and x.is_contiguous() and w.is_contiguous()
+    B, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(B, N, dtype=torch.float32, device=x.device)
+    check(lib.omh_dense_f32(_p(x), _p(w), _p(bias), _p(y), B, N, K, act_in, act_out, _stream()), "omh_dense_f32")
+    return y
+
+
+def sinusoidal_embedding(t: torch.Tensor, dim: int):
+    _dev(t)
+    t = t.reshape(-1).to(torch.float32).contiguous()
+    out = torch.empty(t.shape[0], dim, dtype=torch.float32, device=t.device)
+    check(lib.omh_sinusoidal_embedding(_p(t), _p(out), t.shape[0], dim, _stream()), "omh_sinusoidal_embedding")
+    return out
+
+
+def cfg_sampler_step(cond, uncond, x, m1, m2, m0_out, x_next, guide, sigma, cx, c0, c1, c2):
+    _dev(cond, uncond, x, m1, m2, m0_out, x_next)
+    check(lib.omh_cfg_sampler_step(_p(cond), _p(uncond), _p(x), _p(m1), _p(m2), _p(m0_out), _p(x_next), x.numel(),
+                                   guide, sigma, cx, c0, c1, c2, _stream()), "omh_cfg_sampler_step")
+    return x_next

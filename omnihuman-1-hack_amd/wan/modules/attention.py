@@ -1,0 +1,48 @@
+"""``flash_attention`` with the reference's signature
+(seaweed_apt/wan/modules/attention.py:24-130) on the gfx950 kernel
+``omh_flash_attn_fwd_d128``.
+
+The reference packs variable-length sequences and calls flash-attn's varlen
+kernel; the result is softmax(q k^T * scale) v per head over the first
+``k_lens[b]`` keys of each sample, for every one of the Lq query rows
+(``q_lens`` is never passed by model.py).  This wrapper keeps that contract
+for head_dim 128.  The DiT blocks do not go through it (they hand the kernel
+pre-laid-out q / k / V^T buffers); it exists for callers of the reference API.
+"""
+import torch
+
+from .._backend import ops
+
+__all__ = ["flash_attention", "attention"]
+
+
+def flash_attention(q, k, v, q_lens=None, k_lens=None, dropout_p=0., softmax_scale=None, q_scale=None,
+                    causal=False, window_size=(-1, -1), deterministic=False, dtype=torch.bfloat16, version=None):
+    """q [B, Lq, N, 128], k/v [B, Lk, N, 128]; returns [B, Lq, N, 128] in q's dtype."""
+    assert dtype in (torch.float16, torch.bfloat16)
+    assert q.device.type == "cuda" and q.size(-1) <= 256
+    if q_lens is not None or causal or dropout_p != 0. or tuple(window_size) != (-1, -1):
+        raise NotImplementedError("only the reference's call pattern is built: q_lens=None, non-causal, "
+                                  "no dropout, full window (model.py:151-156,181,221-223)")
+    B, Lq, N, D = q.shape
+    Lk = k.shape[1]
+    if D != 128:
+        raise NotImplementedError("the gfx950 attention kernel is built for head_dim 128")
+    out_dtype = q.dtype
+    if q_scale is not None:
+        q = q * q_scale
+    qb = q.to(torch.bfloat16).contiguous()
+    kb = k.to(torch.bfloat16).contiguous()
+    Lp = (Lk + 63) // 64 * 64
+    vt = torch.zeros(B, N * D, Lp, dtype=torch.bfloat16, device=q.device)
+    vt[:, :, :Lk] = v.to(torch.bfloat16).reshape(B, Lk, N * D).transpose(1, 2)   # layout change only
+    kl = None if k_lens is None else k_lens.to(device=q.device, dtype=torch.int32).contiguous()
+    o = ops.flash_attn(qb, kb, vt, kl, scale=softmax_scale)
+    return o.type(out_dtype)
+
+
+def attention(q, k, v, q_lens=None, k_lens=None, dropout_p=0., softmax_scale=None, q_scale=None, causal=False,
+              window_size=(-1, -1), deterministic=False, dtype=torch.bfloat16, fa_version=None):
+    """attention.py:133-179 — same kernel; the reference's SDPA fallback is not needed here."""
+    return flash_attention(q, k, v, q_lens, k_lens, dropout_p, softmax_scale, q_scale, causal, window_size,
+                           deterministic, dtype, fa_version)

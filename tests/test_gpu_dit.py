@@ -1,0 +1,91 @@
+"""End-to-end parity of the HIP WanModel against the CPU oracle
+(oracle/wan_dit_oracle.py, itself pinned to the reference by tests/golden)."""
+import pytest
+import torch
+
+from conftest import rel_rms
+
+pytestmark = pytest.mark.gpu
+
+# Stated tolerance of the bf16 path vs the fp32 oracle (north_star: "within a
+# stated bf16 tolerance"): every GEMM/attention operand is rounded to bf16
+# (2^-9 relative), accumulation and the residual stream stay fp32.  Relative
+# RMS error of the final velocity grows ~sqrt(layers):
+TOL_TINY = 1.5e-2     # 2..13 layers, d=256
+TOL_FULL = 3.0e-2     # 30 layers, d=1536
+
+
+def _inputs(cfg, grids, ctx_lens, tag):
+    from oracle import detgen
+    xs = [torch.from_numpy(detgen.normalish(f"{tag}/x{i}", (cfg.in_dim, g[0], g[1] * 2, g[2] * 2)))
+          for i, g in enumerate(grids)]
+    ctx = [torch.from_numpy(detgen.normalish(f"{tag}/c{i}", (n, cfg.text_dim))) for i, n in enumerate(ctx_lens)]
+    return xs, ctx
+
+
+@pytest.mark.parametrize("layers", [2, 13])
+def test_tiny_model_matches_oracle(wan_model_mod, layers):
+    from oracle import wan_dit_oracle as O
+    cfg = O.DiTConfig(dim=256, ffn_dim=512, num_heads=2, num_layers=layers, text_dim=64, text_len=32, freq_dim=64)
+    sd = O.synth_state_dict(cfg, f"tiny{layers}")
+    grids, seq_len = [(2, 3, 4), (1, 2, 3)], 30
+    xs, ctx = _inputs(cfg, grids, [32, 11], f"tiny{layers}")
+    t = torch.tensor([999., 500.])
+    ref = O.dit_forward(sd, cfg, xs, t, ctx, seq_len)
+    m = wan_model_mod.WanModel(dim=256, ffn_dim=512, num_heads=2, num_layers=layers, text_dim=64, text_len=32,
+                               freq_dim=64)
+    m.load_state_dict(sd)
+    m = m.cuda().eval().requires_grad_(False)
+    out = m([u.cuda() for u in xs], t.cuda(), [c.cuda() for c in ctx], seq_len)
+    assert len(out) == 2
+    for o, r in zip(out, ref):
+        assert o.dtype == torch.float32 and o.shape == r.shape
+        assert rel_rms(o, r) < TOL_TINY
+    # batched-tensor input form used by distilled_trainer.py:273
+    xb = torch.stack([xs[0], xs[0]]).cuda()
+    out2 = m(xb, t.cuda(), [ctx[0].cuda(), ctx[0].cuda()], seq_len)
+    assert out2[0].shape == ref[0].shape
+
+
+def test_block_hooks_and_errors(wan_model_mod):
+    from oracle import wan_dit_oracle as O
+    cfg = O.DiTConfig(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64, text_len=32, freq_dim=64)
+    m = wan_model_mod.WanModel(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64, text_len=32, freq_dim=64)
+    m.load_state_dict(O.synth_state_dict(cfg, "hooks"))
+    m = m.cuda().eval().requires_grad_(False)
+    seen = []
+    h = m.blocks[1].register_forward_hook(lambda mod, inp, out: seen.append(tuple(out.shape)))
+    xs, ctx = _inputs(cfg, [(1, 2, 3)], [7], "hooks")
+    m([xs[0].cuda()], torch.tensor([3.]).cuda(), [ctx[0].cuda()], 8)
+    h.remove()
+    assert seen == [(1, 8, 256)]
+    with pytest.raises(AssertionError):
+        m([xs[0].cuda()], torch.tensor([3.]).cuda(), [ctx[0].cuda()], 5)   # tokens > seq_len (model.py:521)
+
+
+def test_wan_1_3b_single_frame_cfg_pair():
+    """BASELINE config 1: one [16,1,60,104] latent, S=1560, teacher CFG pair (generate.py:227-229)."""
+    import importlib
+    from oracle import wan_dit_oracle as O, detgen
+    mod = importlib.import_module("omnihuman-1-hack_amd.wan.modules.model")
+    cfg = O.DiTConfig.wan_t2v_1_3b()
+    sd = O.synth_state_dict(cfg, "wan1.3b")
+    noise = torch.from_numpy(detgen.normalish("c1/noise", (16, 1, 60, 104)))
+    cpos = torch.from_numpy(detgen.normalish("c1/ctx", (512, 4096)))
+    cneg = torch.from_numpy(detgen.normalish("c1/neg", (37, 4096)))
+    t = torch.tensor([999.])
+    ref = O.cfg_velocity(sd, cfg, noise, t, cpos, cneg, 1560, 7.5)
+    m = mod.WanModel(**{k: getattr(cfg, k) for k in ("model_type", "patch_size", "text_len", "in_dim", "dim", "ffn_dim",
+                                                      "freq_dim", "text_dim", "out_dim", "num_heads", "num_layers",
+                                                      "qk_norm", "cross_attn_norm", "eps")})
+    m.load_state_dict(sd)
+    m = m.cuda().eval().requires_grad_(False)
+    c = m([noise.cuda()], t.cuda(), [cpos.cuda()], 1560)[0]
+    u = m([noise.cuda()], t.cuda(), [cneg.cuda()], 1560)[0]
+    v = (u + 7.5 * (c - u)).cpu()
+    assert v.shape == (16, 1, 60, 104)
+    # CFG amplifies the difference of two bf16 forwards by 7.5: compare the
+    # individual forwards at TOL_FULL and the guided velocity at a looser bound
+    ref_u = O.dit_forward(sd, cfg, [noise], t, [cneg], 1560)[0]
+    assert rel_rms(u, ref_u) < TOL_FULL
+    assert rel_rms(v, ref) < 0.2

@@ -1,0 +1,180 @@
+"""Parity of each gfx950 kernel (through the C ABI) against a plain fp32
+PyTorch statement of the same op on the same bf16-rounded inputs."""
+import math
+
+import pytest
+import torch
+
+from conftest import rel_rms
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 72), (1560, 1536, 1536), (257, 64, 1536),
+                                   (64, 8960, 256), (1000, 1536, 8960)])
+def test_gemm_bf16_f32_bias(ops, M, N, K):
+    torch.manual_seed(M * 7 + N)
+    a = _bf(torch.randn(M, K, device="cuda"))
+    w = _bf(torch.randn(N, K, device="cuda") / math.sqrt(K))
+    bias = torch.randn(N, device="cuda")
+    ref = a.float() @ w.float().t() + bias
+    out = ops.gemm(a, w, bias=bias, epilogue=ops.EPI_F32)
+    assert rel_rms(out, ref) < 2e-5          # fp32 accumulate of identical bf16 inputs: ordering noise only
+    outb = ops.gemm(a, w, bias=bias, epilogue=ops.EPI_BF16)
+    assert rel_rms(outb.float(), ref) < 4e-3  # one bf16 rounding (2^-9 rel)
+    outg = ops.gemm(a, w, bias=bias, epilogue=ops.EPI_GELU_BF16)
+    refg = torch.nn.functional.gelu(ref, approximate="tanh")
+    assert rel_rms(outg.float(), refg) < 5e-3
+
+
+def test_gemm_asymmetric_layout(ops):
+    # A = identity-like selector, B asymmetric: catches a transposed C write
+    M = N = K = 128
+    a = torch.zeros(M, K, device="cuda")
+    a[torch.arange(M), torch.arange(M)] = 1.0
+    w = (torch.arange(N, device="cuda").float()[:, None] * 0.5 + torch.arange(K, device="cuda").float()[None, :] * 0.0078125)
+    out = ops.gemm(_bf(a), _bf(w), epilogue=ops.EPI_F32)
+    ref = _bf(a).float() @ _bf(w).float().t()
+    assert torch.equal(out, ref)
+
+
+def test_gemm_resid_gate_and_batch(ops):
+    B, S, d, K = 2, 200, 256, 320
+    torch.manual_seed(1)
+    a = _bf(torch.randn(B * S, K, device="cuda"))
+    w = _bf(torch.randn(d, K, device="cuda") / math.sqrt(K))
+    bias = torch.randn(d, device="cuda")
+    x0 = torch.randn(B * S, d, device="cuda")
+    mod = torch.randn(6, d, device="cuda")
+    e0 = torch.randn(B, 6, d, device="cuda")
+    x = x0.clone()
+    ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(x), B * S, d, K, K, K, d, ops.EPI_RESID, bias=ops.ptr(bias),
+                 bias_mode=ops.BIAS_N, gate0=ops.ptr(mod, 2 * d), gate1=ops.ptr(e0, 2 * d), gate1_stride=6 * d,
+                 gate_rows=S, gate_const=0.0)
+    gate = (mod[2][None] + e0[:, 2]).repeat_interleave(S, 0)
+    ref = x0 + (a.float() @ w.float().t() + bias) * gate
+    assert rel_rms(x, ref) < 1e-5
+    # batched "V^T" form: C[b][m][n] = W[m,:] . h[b,n,:] + bias[m]
+    h = _bf(torch.randn(B, S, K, device="cuda"))
+    Sp = 256
+    vt = torch.zeros(B, d, Sp, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_raw(ops.ptr(w), ops.ptr(h), ops.ptr(vt), d, S, K, K, K, Sp, ops.EPI_BF16, bias=ops.ptr(bias),
+                 bias_mode=ops.BIAS_M, batch=B, strideA=0, strideB=S * K, strideC=d * Sp)
+    refv = torch.einsum("mk,bnk->bmn", w.float(), h.float()) + bias[None, :, None]
+    assert rel_rms(vt[:, :, :S].float(), refv) < 4e-3
+    assert float(vt[:, :, S:].abs().max()) == 0.0
+
+
+def _attn_ref(q, k, v, k_lens, scale):
+    B, Lq, H, D = q.shape
+    out = torch.zeros(B, Lq, H, D, device=q.device)
+    for b in range(B):
+        kl = k.shape[1] if k_lens is None else int(k_lens[b])
+        if kl == 0:
+            continue
+        s = torch.einsum("qhd,khd->hqk", q[b].float(), k[b, :kl].float()) * scale
+        out[b] = torch.einsum("hqk,khd->qhd", torch.softmax(s, -1), v[b, :kl].float())
+    return out
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,klens", [
+    (1, 1, 128, 64, None), (2, 2, 200, 200, [200, 77]), (1, 12, 1560, 1560, [1560]),
+    (2, 3, 130, 512, [37, 512]), (1, 2, 64, 320, [257]), (2, 1, 100, 64, [0, 5])])
+def test_flash_attention(ops, B, H, Lq, Lk, klens):
+    torch.manual_seed(Lq + Lk)
+    D = 128
+    q = _bf(torch.randn(B, Lq, H, D, device="cuda"))
+    k = _bf(torch.randn(B, Lk, H, D, device="cuda"))
+    v = _bf(torch.randn(B, Lk, H, D, device="cuda"))
+    Lp = (Lk + 63) // 64 * 64
+    vt = torch.zeros(B, H * D, Lp, dtype=torch.bfloat16, device="cuda")
+    vt[:, :, :Lk] = v.reshape(B, Lk, H * D).transpose(1, 2)
+    kl = None if klens is None else torch.tensor(klens, dtype=torch.int32, device="cuda")
+    out = ops.flash_attn(q, k, vt, kl)
+    ref = _attn_ref(q, k, v, klens, D ** -0.5)
+    assert torch.isfinite(out.float()).all()
+    # P is rounded to bf16 before P.V and the output to bf16: ~2^-9 relative each
+    assert rel_rms(out.float(), ref) < 8e-3
+    assert float((out.float() - ref).abs().max()) < 3e-2
+
+
+def test_flash_attention_peaked_rows(ops):
+    """Forces large online-softmax rescales: one key dominates late in the sequence."""
+    torch.manual_seed(5)
+    B, H, L, D = 1, 2, 384, 128
+    q = _bf(torch.randn(B, L, H, D, device="cuda"))
+    k = _bf(torch.randn(B, L, H, D, device="cuda"))
+    v = _bf(torch.randn(B, L, H, D, device="cuda"))
+    k[0, 300] = q[0, 17] * 4.0      # row 17 spikes at key 300 (tile 4)
+    k[0, 70] = q[0, 90] * 3.0
+    vt = v.reshape(B, L, H * D).transpose(1, 2).contiguous()
+    out = ops.flash_attn(q, k, vt, None)
+    ref = _attn_ref(q, k, v, None, D ** -0.5)
+    assert rel_rms(out.float(), ref) < 8e-3
+
+
+def test_layernorm_modulate(ops):
+    torch.manual_seed(2)
+    B, S, d = 2, 50, 1536
+    x = torch.randn(B * S, d, device="cuda") * 3 + 0.5
+    mod = torch.randn(6, d, device="cuda")
+    e0 = torch.randn(B, 6, d, device="cuda")
+    y = torch.empty(B * S, d, dtype=torch.bfloat16, device="cuda")
+    ops.layernorm_modulate_raw(ops.ptr(x), ops.ptr(y), B * S, d, 1e-6, 1.0, ops.ptr(mod, d), ops.ptr(e0, d), 6 * d,
+                               ops.ptr(mod, 0), ops.ptr(e0, 0), 6 * d, S)
+    xh = torch.nn.functional.layer_norm(x, (d,), eps=1e-6)
+    ref = xh * (1 + (mod[1][None] + e0[:, 1]).repeat_interleave(S, 0)) + (mod[0][None] + e0[:, 0]).repeat_interleave(S, 0)
+    assert rel_rms(y.float(), ref) < 4e-3
+    w, b = torch.randn(d, device="cuda"), torch.randn(d, device="cuda")
+    y2 = ops.layernorm_modulate(x, 1e-6, 0.0, mul0=w, add0=b)
+    assert rel_rms(y2.float(), torch.nn.functional.layer_norm(x, (d,), w, b, 1e-6)) < 4e-3
+
+
+def test_rmsnorm_rope_matches_oracle(ops):
+    from oracle import wan_dit_oracle as O
+    torch.manual_seed(3)
+    B, S, N, D = 2, 30, 2, 128
+    d = N * D
+    grids = [(2, 3, 4), (1, 5, 6)]
+    x = torch.randn(B * S, 2 * d, device="cuda")
+    w = torch.rand(d, device="cuda") + 0.5
+    ang = O.rope_table(D)
+    cos, sin = torch.cos(ang).float().cuda(), torch.sin(ang).float().cuda()
+    grid = torch.tensor(grids, dtype=torch.int32, device="cuda")
+    y = torch.empty(B * S, d, dtype=torch.bfloat16, device="cuda")
+    ops.rmsnorm_rope_raw(ops.ptr(x, d), 2 * d, ops.ptr(y), B * S, d, ops.ptr(w), 1e-6, 1, ops.ptr(cos), ops.ptr(sin),
+                         1024, D, ops.ptr(grid), S)
+    xc = x[:, d:].cpu()
+    ref = O.rope_apply(O.rms_norm(xc, w.cpu(), 1e-6).view(B, S, N, D), grids, ang).view(B * S, d)
+    assert rel_rms(y.float(), ref) < 4e-3
+    # no rope, no weight
+    y2 = ops.rmsnorm_rope(x[:, :d], None, 1e-6)
+    assert rel_rms(y2.float(), O.rms_norm(x[:, :d].cpu(), torch.ones(d), 1e-6)) < 4e-3
+
+
+def test_patchify_unpatchify_dense_sinusoid(ops):
+    from oracle import wan_dit_oracle as O
+    torch.manual_seed(4)
+    x = torch.randn(16, 2, 6, 8, device="cuda")
+    tok = ops.patchify(x, (1, 2, 2), 64)
+    w = torch.randn(32, 16, 1, 2, 2, device="cuda")
+    ref = torch.nn.functional.conv3d(x[None].to(torch.bfloat16).float(), w, stride=(1, 2, 2)).flatten(2).transpose(1, 2)[0]
+    got = tok.float() @ w.flatten(1).t()
+    assert rel_rms(got, ref) < 1e-5
+    head = torch.randn(2 * 3 * 4, 64, device="cuda")
+    u = head.cpu().view(2, 3, 4, 1, 2, 2, 16)
+    refu = torch.einsum("fhwpqrc->cfphqwr", u).reshape(16, 2, 6, 8)
+    assert torch.equal(ops.unpatchify(head, 16, (2, 3, 4), (1, 2, 2)).cpu(), refu)
+    t = torch.tensor([0., 1., 999., 1000.], device="cuda")
+    s = ops.sinusoidal_embedding(t, 256)
+    assert float((s.cpu() - O.sinusoidal_embedding_1d(256, t.cpu()).float()).abs().max()) < 1e-6
+    xx, W, b = torch.randn(3, 300, device="cuda"), torch.randn(70, 300, device="cuda"), torch.randn(70, device="cuda")
+    y = ops.dense_f32(xx, W, b, 1, 1)
+    refy = torch.nn.functional.silu(torch.nn.functional.silu(xx) @ W.t() + b)
+    assert rel_rms(y, refy) < 1e-5
+    c = torch.randn(1000, device="cuda")
+    assert torch.equal(ops.cast_bf16(c), c.to(torch.bfloat16))
