@@ -1,0 +1,244 @@
+#!/usr/bin/env python
+"""Benchmark of the MI355X-native Wan2.1 denoising path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One *step* = one classifier-free-guided denoising step of the 50-step sampler
+of BASELINE config 2 (Wan2.1-T2V-1.3B, 81 frames 480x832 -> latent
+[16,21,60,104], 32 760 tokens): two full DiT forwards (conditional /
+unconditional context, text2video.py:238-241) + the fused CFG/UniPC latent
+update (text2video.py:243-252), all inputs resident in HBM, synthetic data,
+random-init weights of the real architecture.  Each rank runs its own replica
+on its own clip (inference shards by clip, no data-path collective:
+"scaling": "weak"); `value` = steps of all ranks / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (self-attention flash kernel): algorithmic
+                FLOPs per launch / average launch duration measured with HIP
+                events on the launch stream over the timed region, vs the
+                2.5 PFLOP/s dense bf16 MFMA peak.
+  cpu_baseline  the CPU oracle (oracle/wan_dit_oracle.py, fp32, a restatement
+                of the reference's own CPU path) timed on this box's host
+                cores on a bounded sample (rank 0, N=1 only).
+  vae           frames/s of the 3D causal VAE decode of the final latent.
+"""
+import argparse
+import importlib
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PKG = "omnihuman-1-hack_amd"
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBPS = 8000.0
+
+
+def dit_forward_flops(S, d=1536, f=8960, L=30, Lc=512, in_dim=16, text_dim=4096, freq=256, out=64):
+    """BASELINE.md §3 algorithmic work per forward (multiply-add = 2)."""
+    blk = 8 * S * d * d + 4 * S * S * d + (4 * S * d * d + 4 * Lc * d * d) + 4 * S * Lc * d + 4 * S * d * f
+    rest = 2 * 512 * (text_dim * d + d * d) + 2 * S * (4 * in_dim) * d + 2 * S * d * out + 2 * (freq * d + d * d + 6 * d * d)
+    return L * blk + rest
+
+
+class KernelTimer:
+    """Brackets every launch of one C-ABI entry point with HIP events recorded on
+    the stream the kernel is launched on (torch's current stream)."""
+
+    def __init__(self, ops_mod, fn_name, select):
+        self.ops, self.name, self.select = ops_mod, fn_name, select
+        self.pairs, self.enabled = [], False
+        self.orig = getattr(ops_mod, fn_name)
+
+        def wrapped(*a, **k):
+            if self.enabled and self.select(*a, **k):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = self.orig(*a, **k)
+                e.record()
+                self.pairs.append((s, e))
+                return r
+            return self.orig(*a, **k)
+        setattr(ops_mod, fn_name, wrapped)
+
+    def avg_ms(self):
+        if not self.pairs:
+            return None
+        return sum(s.elapsed_time(e) for s, e in self.pairs) / len(self.pairs)
+
+
+def build_model(device):
+    model_mod = importlib.import_module(PKG + ".wan.modules.model")
+    cfgs = importlib.import_module(PKG + ".wan.configs")
+    torch.manual_seed(1234)
+    with torch.device(device):
+        m = model_mod.WanModel(**cfgs.dit_kwargs(cfgs.t2v_1_3B))
+        # the reference zero-inits the head (model.py:612): re-randomise so the output depends on the network
+        torch.nn.init.xavier_uniform_(m.head.head.weight)
+        for p in m.parameters():
+            if p.dim() == 1 and p.abs().sum() == 0:
+                p.uniform_(-0.05, 0.05)
+    return m.eval().requires_grad_(False)
+
+
+def cpu_baseline(model, latent, t, ctx, seq_len, budget_s=60.0):
+    """Time the CPU oracle on a bounded sample: ONE of the 30 DiT blocks of ONE forward at the
+    benchmark's S (embeddings included), then scale to a CFG step (2 forwards x 30 blocks)."""
+    from oracle import wan_dit_oracle as O
+    cfg = O.DiTConfig.wan_t2v_1_3b()
+    keep = ("patch_embedding", "text_embedding", "time_embedding", "time_projection", "blocks.0.")
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items() if k.startswith(keep)}
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    lat, cc, tt = latent.cpu(), ctx.cpu(), t.cpu()
+    t0 = time.time()
+    O.dit_forward(sd, cfg, [lat], tt, [cc], seq_len, num_layers=0, return_hidden=True)
+    t_embed = time.time() - t0
+    t0 = time.time()
+    O.dit_forward(sd, cfg, [lat], tt, [cc], seq_len, num_layers=1, return_hidden=True)
+    t_blk = max(time.time() - t0 - t_embed, 1e-6)
+    step_s = 2 * (cfg.num_layers * t_blk + t_embed)
+    return {"value": 1.0 / step_s, "unit": "denoising steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 DiT: embeddings + 1 of 30 blocks of one forward at S={seq_len} "
+                      f"({t_blk:.1f}s/block, {t_embed:.1f}s embed), extrapolated x30 blocks x2 CFG forwards",
+            "tflops": dit_forward_flops(seq_len) / 30 / t_blk / 1e12}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=81, help="pixel frames (4n+1); 81 = BASELINE config 2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    ops = importlib.import_module(PKG + ".ops")
+    sched_mod = importlib.import_module(PKG + ".wan.utils.fm_solvers_unipc")
+    model = build_model(device)
+
+    lat_t = (args.frames - 1) // 4 + 1
+    shape = (16, lat_t, 60, 104)
+    seq_len = lat_t * 30 * 52
+    g = torch.Generator(device=device).manual_seed(100 + rank)
+    latent = torch.randn(shape, device=device, generator=g)
+    ctx = torch.randn(120, 4096, device=device, generator=g)       # prompt ~120 tokens
+    ctx_null = torch.randn(40, 4096, device=device, generator=g)   # negative prompt ~40 tokens
+    guide, shift, n_sampling = 5.0, 5.0, 50
+
+    timer = KernelTimer(ops, "flash_attn_raw", lambda *a, **k: a[7] == a[8] and a[7] == seq_len)  # Lq == Lk == S
+
+    def run_steps(n, sched, x):
+        for i in range(n):
+            t = sched.timesteps[sched.step_index or 0].reshape(1).to(device)
+            c = model([x], t, [ctx], seq_len)[0]
+            u = model([x], t, [ctx_null], seq_len)[0]
+            x = sched.step_cfg(c, u, guide, x)
+        return x
+
+    def fresh_sched():
+        s = sched_mod.FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+        s.set_timesteps(n_sampling, device=device, shift=shift)
+        s.set_begin_index(0)
+        return s
+
+    sched = fresh_sched()
+    x = run_steps(args.warmup, sched, latent)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    x = run_steps(args.steps, sched, x)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if dist:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(x).all(), "non-finite latent after the timed steps"
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    steps_per_s = world * args.steps / elapsed
+    fwd_flops = dit_forward_flops(seq_len)
+    attn_ms = timer.avg_ms()
+    attn_flops = 4.0 * seq_len * seq_len * 1536
+    roofline = None
+    if attn_ms:
+        ach = attn_flops / (attn_ms * 1e-3) / 1e12
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tj):
+            try:
+                traffic = json.load(open(tj)).get("flash_attn_fwd_d128_kernel")
+            except Exception:
+                traffic = None
+        roofline = {"kernel": "flash_attn_fwd_d128_kernel (self-attention, Lq=Lk=%d, 12 heads, D=128)" % seq_len,
+                    "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                    "launches_timed": len(timer.pairs), "avg_launch_ms": round(attn_ms, 4),
+                    "algorithmic_flops_per_launch": attn_flops}
+
+    vae = None
+    if not args.no_vae:
+        try:
+            vae_bench = importlib.import_module(PKG + ".wan.modules.vae").bench_decode
+            vae = vae_bench(x, device)
+        except (ImportError, AttributeError, NotImplementedError) as e:
+            vae = {"frames_per_s": None, "note": f"VAE path not built: {e}"}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(model, latent, torch.tensor([999.0]), ctx, seq_len)
+
+    if rank == 0:
+        out = {
+            "metric": "DiT denoising steps/sec + VAE frames/sec, Wan2.1-1.3B 480x832 81f",
+            "value": round(steps_per_s, 4), "unit": "denoising steps/s (1 step = 2 DiT forwards, CFG)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic", "config": {
+                "workload": f"Wan2.1-T2V-1.3B 50-step flow-matching sample, {args.frames}-frame 480x832 "
+                            f"(latent {list(shape)}, S={seq_len}), CFG step = cond+uncond DiT forward + fused "
+                            f"CFG/UniPC update, one clip per GPU",
+                "weights": "random-init (xavier) Wan2.1-T2V-1.3B architecture",
+                "context_tokens": [int(ctx.shape[0]), int(ctx_null.shape[0])]},
+            "dit": {"forward_tflop": round(fwd_flops / 1e12, 2),
+                    "achieved_tflops_per_gpu": round(2 * fwd_flops / (ms_per_step * 1e-3) / 1e12, 1),
+                    "mfma_roofline_frac": round(2 * fwd_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)},
+            "vae": vae, "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

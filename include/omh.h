@@ -162,15 +162,23 @@ int omh_dense_f32(const float* x, const float* W, const float* bias, float* y,
 int omh_sinusoidal_embedding(const float* t, float* out, int32_t B, int32_t dim, omh_stream_t stream);
 
 /* ------------------------------------------------------------------------
- * Classifier-free guidance + flow-matching sampler update on the latent
- * (text2video.py:243-252; UniPC bh2 coefficients computed on the host):
- *   v = uncond + g*(cond - uncond);  x0 = x - sigma*v  (stored to m0_out)
- *   x_next = cx*x + c0*x0 + c1*m1 + c2*m2            (m1/m2 previous x0's or NULL)
+ * Classifier-free guidance + one flow-matching UniPC (bh2, predict-x0) step
+ * on the latent, fused into one pass (text2video.py:243-252;
+ * fm_solvers_unipc.py:279-331 convert_model_output, :350-484 predictor,
+ * :486-626 corrector, :655-739 step).  Scalar coefficients come from the
+ * sigma schedule on the host.  All tensors fp32, n elements.
+ *   v      = uncond + guide * (cond - uncond)
+ *   m_t    = x - sigma * v                                   -> mt_out
+ *   x_c    = use_corr ? ca_last*last + ca_m1*m1 + ca_m2*m2 + ca_mt*m_t : x   -> xc_out
+ *   x_next = pb_x*x_c + pb_mt*m_t + pb_m1*m1                  -> x_next
+ * m1 / m2 (the previous two x0 predictions) and `last` may be NULL when their
+ * coefficient is 0.  xc_out may alias `last`; x_next may alias x.
  * ---------------------------------------------------------------------- */
-int omh_cfg_sampler_step(const float* cond, const float* uncond, const float* x,
-                         const float* m1, const float* m2, float* m0_out, float* x_next,
-                         int64_t n, float guide, float sigma,
-                         float cx, float c0, float c1, float c2, omh_stream_t stream);
+int omh_cfg_unipc_step(const float* cond, const float* uncond, const float* x, const float* last,
+                       const float* m1, const float* m2, float* mt_out, float* xc_out, float* x_next,
+                       int64_t n, float guide, float sigma, int32_t use_corr,
+                       float ca_last, float ca_m1, float ca_m2, float ca_mt,
+                       float pb_x, float pb_mt, float pb_m1, omh_stream_t stream);
 
 #ifdef __cplusplus
 }

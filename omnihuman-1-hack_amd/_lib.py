@@ -69,7 +69,8 @@ _SIGS = {
     "omh_unpatchify": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "omh_dense_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "omh_sinusoidal_embedding": (i32, [vp, vp, i32, i32, vp]),
-    "omh_cfg_sampler_step": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp]),
+    "omh_cfg_unipc_step": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, i32, f32, f32, f32, f32, f32,
+                                 f32, f32, vp]),
 }
 
 for _name, (_res, _args) in _SIGS.items():

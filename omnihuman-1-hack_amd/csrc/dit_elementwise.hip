@@ -232,23 +232,31 @@ __global__ void sinusoid_kernel(const float* __restrict__ t, float* __restrict__
     out[(int64_t)b * dim + half + k] = (float)sin(ang);
 }
 
-// ------------------------------------------------------------------ CFG + sampler update
+// ------------------------------------------------------------------ CFG + UniPC step
 __global__ __launch_bounds__(256)
-void cfg_sampler_kernel(const float* __restrict__ cond, const float* __restrict__ uncond,
-                        const float* __restrict__ x, const float* __restrict__ m1, const float* __restrict__ m2,
-                        float* __restrict__ m0_out, float* __restrict__ x_next, int64_t n, float guide,
-                        float sigma, float cx, float c0, float c1, float c2) {
+void cfg_unipc_kernel(const float* __restrict__ cond, const float* __restrict__ uncond, const float* x,
+                      const float* last, const float* __restrict__ m1, const float* __restrict__ m2,
+                      float* __restrict__ mt_out, float* xc_out, float* x_next, int64_t n, float guide, float sigma,
+                      int use_corr, float ca_last, float ca_m1, float ca_m2, float ca_mt, float pb_x, float pb_mt,
+                      float pb_m1) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float u = uncond[i];
         const float v = u + guide * (cond[i] - u);
         const float xv = x[i];
-        const float x0 = xv - sigma * v;
-        float r = cx * xv + c0 * x0;
-        if (m1) r += c1 * m1[i];
-        if (m2) r += c2 * m2[i];
-        if (m0_out) m0_out[i] = x0;
-        x_next[i] = r;
+        const float mt = xv - sigma * v;
+        const float a1 = m1 ? m1[i] : 0.f;
+        float xc = xv;
+        if (use_corr) {
+            xc = ca_last * last[i] + ca_mt * mt;
+            if (m1) xc += ca_m1 * a1;
+            if (m2) xc += ca_m2 * m2[i];
+        }
+        float xn = pb_x * xc + pb_mt * mt;
+        if (m1) xn += pb_m1 * a1;
+        if (mt_out) mt_out[i] = mt;
+        if (xc_out) xc_out[i] = xc;
+        x_next[i] = xn;
     }
 }
 
@@ -331,12 +339,16 @@ extern "C" int omh_sinusoidal_embedding(const float* t, float* out, int32_t B, i
     return omh_launch_status();
 }
 
-extern "C" int omh_cfg_sampler_step(const float* cond, const float* uncond, const float* x, const float* m1,
-                                    const float* m2, float* m0_out, float* x_next, int64_t n, float guide,
-                                    float sigma, float cx, float c0, float c1, float c2, omh_stream_t stream) {
+extern "C" int omh_cfg_unipc_step(const float* cond, const float* uncond, const float* x, const float* last,
+                                  const float* m1, const float* m2, float* mt_out, float* xc_out, float* x_next,
+                                  int64_t n, float guide, float sigma, int32_t use_corr, float ca_last, float ca_m1,
+                                  float ca_m2, float ca_mt, float pb_x, float pb_mt, float pb_m1,
+                                  omh_stream_t stream) {
     if (!cond || !uncond || !x || !x_next || n <= 0) return OMH_E_BADARG;
-    hipLaunchKernelGGL(cfg_sampler_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, cond, uncond,
-                       x, m1, m2, m0_out, x_next, n, guide, sigma, cx, c0, c1, c2);
+    if (use_corr && !last) return OMH_E_BADARG;
+    hipLaunchKernelGGL(cfg_unipc_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, cond, uncond, x,
+                       last, m1, m2, mt_out, xc_out, x_next, n, guide, sigma, use_corr, ca_last, ca_m1, ca_m2, ca_mt,
+                       pb_x, pb_mt, pb_m1);
     return omh_launch_status();
 }
 

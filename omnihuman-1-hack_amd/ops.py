@@ -14,7 +14,7 @@ from ._lib import (BIAS_M, BIAS_N, BIAS_NONE, EPI_BF16, EPI_F32, EPI_F32_ACCUM, 
                    AttnArgs, GemmArgs, OmhError, check, lib)
 
 __all__ = ["gemm", "flash_attn", "layernorm_modulate", "rmsnorm_rope", "cast_bf16", "patchify", "unpatchify",
-           "dense_f32", "sinusoidal_embedding", "cfg_sampler_step", "OmhError",
+           "dense_f32", "sinusoidal_embedding", "cfg_unipc_step", "OmhError",
            "EPI_BF16", "EPI_F32", "EPI_GELU_BF16", "EPI_RESID", "EPI_F32_ACCUM", "BIAS_NONE", "BIAS_N", "BIAS_M"]
 
 
@@ -181,8 +181,13 @@ def sinusoidal_embedding(t: torch.Tensor, dim: int):
     return out
 
 
-def cfg_sampler_step(cond, uncond, x, m1, m2, m0_out, x_next, guide, sigma, cx, c0, c1, c2):
-    _dev(cond, uncond, x, m1, m2, m0_out, x_next)
-    check(lib.omh_cfg_sampler_step(_p(cond), _p(uncond), _p(x), _p(m1), _p(m2), _p(m0_out), _p(x_next), x.numel(),
-                                   guide, sigma, cx, c0, c1, c2, _stream()), "omh_cfg_sampler_step")
+def cfg_unipc_step(cond, uncond, x, last, m1, m2, mt_out, xc_out, x_next, guide, sigma, use_corr, ca, pb):
+    """One fused CFG + UniPC update (include/omh.h); ca = (last, m1, m2, mt), pb = (x, mt, m1)."""
+    _dev(cond, uncond, x, last, m1, m2, mt_out, xc_out, x_next)
+    for t in (cond, uncond, x, last, m1, m2, mt_out, xc_out, x_next):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    check(lib.omh_cfg_unipc_step(_p(cond), _p(uncond), _p(x), _p(last), _p(m1), _p(m2), _p(mt_out), _p(xc_out),
+                                 _p(x_next), x.numel(), float(guide), float(sigma), int(use_corr), float(ca[0]),
+                                 float(ca[1]), float(ca[2]), float(ca[3]), float(pb[0]), float(pb[1]), float(pb[2]),
+                                 _stream()), "omh_cfg_unipc_step")
     return x_next

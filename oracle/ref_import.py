@@ -115,3 +115,55 @@ def build_reference_vae(state_dict, **cfg):
     m = vae_mod.WanVAE_(**base)
     m.load_state_dict(state_dict, strict=True)
     return m.eval().requires_grad_(False)
+
+
+def load_reference_unipc():
+    """The reference FlowUniPCMultistepScheduler, importable with a small stub of
+    the diffusers base classes it inherits from."""
+    if "unipc" in _CACHE:
+        return _CACHE["unipc"]
+    load_reference()
+    import functools
+    import inspect
+
+    class _Cfg(dict):
+        __getattr__ = dict.__getitem__
+
+    def register_to_config(init):
+        @functools.wraps(init)
+        def wrapped(self, *a, **k):
+            sig = inspect.signature(init)
+            bound = sig.bind(self, *a, **k)
+            bound.apply_defaults()
+            self.config = _Cfg({n: v for n, v in bound.arguments.items() if n != "self"})
+            init(self, *a, **k)
+        return wrapped
+
+    class ConfigMixin:
+        def register_to_config(self, **kw):
+            self.config.update(kw)
+
+    dcfg = sys.modules["diffusers.configuration_utils"]
+    dcfg.ConfigMixin, dcfg.register_to_config = ConfigMixin, register_to_config
+    su = types.ModuleType("diffusers.schedulers.scheduling_utils")
+
+    class SchedulerMixin:
+        pass
+
+    class SchedulerOutput:
+        def __init__(self, prev_sample):
+            self.prev_sample = prev_sample
+
+    su.SchedulerMixin, su.SchedulerOutput, su.KarrasDiffusionSchedulers = SchedulerMixin, SchedulerOutput, []
+    du = types.ModuleType("diffusers.utils")
+    du.deprecate = lambda *a, **k: None
+    du.is_scipy_available = lambda: False
+    sys.modules["diffusers.schedulers"] = types.ModuleType("diffusers.schedulers")
+    sys.modules["diffusers.schedulers.scheduling_utils"] = su
+    sys.modules["diffusers.utils"] = du
+    wutils = types.ModuleType("wan.utils")
+    wutils.__path__ = [os.path.join(REFERENCE_ROOT, "seaweed_apt", "wan", "utils")]
+    sys.modules.setdefault("wan.utils", wutils)
+    mod = importlib.import_module("wan.utils.fm_solvers_unipc")
+    _CACHE["unipc"] = mod.FlowUniPCMultistepScheduler
+    return _CACHE["unipc"]

@@ -1,0 +1,97 @@
+"""CPU restatement of the flow-matching UniPC sampler step (TEST INFRASTRUCTURE).
+
+Follows seaweed_apt/wan/utils/fm_solvers_unipc.py for the configuration
+WanT2V.generate uses (text2video.py:205-211): order 2, bh2, predict_x0,
+flow_prediction, lower_order_final, final sigma 0.  Written tensor-by-tensor
+(not through the product's coefficient folding) so it is an independent check
+of omnihuman-1-hack_amd/wan/utils/fm_solvers_unipc.py.
+
+Pinned against the real reference class by oracle/make_golden.py (the class
+imports with a ~20-line stub of diffusers' SchedulerMixin/ConfigMixin).
+"""
+import numpy as np
+import torch
+
+
+def sampling_sigmas(num_steps: int, shift: float, num_train_timesteps: int = 1000):
+    """fm_solvers_unipc.py:106-131,160-208 — float32 sigmas [n+1] (last 0) and int64 timesteps [n]."""
+    alphas = np.linspace(1, 1 / num_train_timesteps, num_train_timesteps)[::-1].copy()
+    base = torch.from_numpy(1.0 - alphas).to(torch.float32)          # constructor shift = 1
+    smax, smin = base[0].item(), base[-1].item()
+    s = np.linspace(smax, smin, num_steps + 1).copy()[:-1]
+    s = shift * s / (1 + (shift - 1) * s)
+    timesteps = torch.from_numpy(s * num_train_timesteps).to(torch.int64)
+    sig = torch.from_numpy(np.concatenate([s, [0]]).astype(np.float32))
+    return sig, timesteps
+
+
+class UniPCOracle:
+    def __init__(self, num_steps: int, shift: float, solver_order: int = 2):
+        self.sigmas, self.timesteps = sampling_sigmas(num_steps, shift)
+        self.order = solver_order
+        self.m = [None] * solver_order       # x0 predictions, oldest first
+        self.lower = 0
+        self.last = None
+        self.this_order = None
+        self.i = 0
+
+    @staticmethod
+    def _lam(s):
+        return torch.log(1 - s) - torch.log(s)
+
+    def _update(self, x, m0, older, s_t, s_0, s_older, order, model_t=None):
+        """Shared predictor (model_t None, :404-470) / corrector (:548-619) algebra."""
+        a_t = 1 - s_t
+        h = self._lam(s_t) - self._lam(s_0)
+        hh = -h
+        h_phi_1 = torch.expm1(hh)
+        B_h = torch.expm1(hh)
+        x_t_ = s_t / s_0 * x - a_t * h_phi_1 * m0
+        res = 0
+        rk = None
+        if order == 2:
+            rk = (self._lam(s_older) - self._lam(s_0)) / h
+            D1 = (older - m0) / rk
+        if model_t is None:                       # predictor
+            if order == 2:
+                res = 0.5 * D1
+            return x_t_ - a_t * B_h * res
+        if order == 1:
+            rhos = torch.tensor([0.5])
+        else:
+            h_phi_k = h_phi_1 / hh - 1
+            b, fact = [], 1
+            for k in range(1, 3):
+                b.append(h_phi_k * fact / B_h)
+                fact *= k + 1
+                h_phi_k = h_phi_k / hh - 1 / fact
+            R = torch.stack([torch.ones(2), torch.stack([rk, torch.tensor(1.0)])])
+            rhos = torch.linalg.solve(R, torch.stack(b))
+            res = rhos[0] * D1
+        return x_t_ - a_t * B_h * (res + rhos[-1] * (model_t - m0))
+
+    def step(self, v: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        """One scheduler.step(v, t_i, x) (:655-739)."""
+        i, sig = self.i, self.sigmas
+        m_t = x - sig[i] * v
+        if i > 0 and self.last is not None:
+            x = self._update(self.last, self.m[-1], self.m[-2] if self.order > 1 else None, sig[i], sig[i - 1],
+                             sig[i - 2] if i >= 2 else None, self.this_order, model_t=m_t)
+        self.m = self.m[1:] + [m_t]
+        order = min(self.order, len(self.timesteps) - i, self.lower + 1)
+        self.this_order = order
+        self.last = x
+        nxt = self._update(x, m_t, self.m[-2] if self.order > 1 else None, sig[i + 1], sig[i],
+                           sig[i - 1] if i >= 1 else None, order)
+        self.lower = min(self.lower + 1, self.order)
+        self.i += 1
+        return nxt
+
+
+def sample_loop(velocity_fn, x, num_steps, shift, guide):
+    """text2video.py:231-252 with velocity_fn(x, t) -> (cond, uncond)."""
+    sch = UniPCOracle(num_steps, shift)
+    for t in sch.timesteps:
+        c, u = velocity_fn(x, t)
+        x = sch.step(u + guide * (c - u), x)
+    return x
