@@ -83,9 +83,10 @@ def build_model(device):
         m = model_mod.WanModel(**cfgs.dit_kwargs(cfgs.t2v_1_3B))
         # the reference zero-inits the head (model.py:612): re-randomise so the output depends on the network
         torch.nn.init.xavier_uniform_(m.head.head.weight)
-        for p in m.parameters():
-            if p.dim() == 1 and p.abs().sum() == 0:
-                p.uniform_(-0.05, 0.05)
+        with torch.no_grad():
+            for p in m.parameters():
+                if p.dim() == 1 and p.abs().sum() == 0:
+                    p.uniform_(-0.05, 0.05)
     return m.eval().requires_grad_(False)
 
 

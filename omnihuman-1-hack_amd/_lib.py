@@ -6,6 +6,12 @@ cannot be built because hipcc is absent) importing this module raises.
 import ctypes as C
 import os
 
+# PyTorch must load ITS HIP runtime (libamdhip64) first: libomh.so then binds to
+# that same runtime instance by soname.  Loading libomh.so before torch would
+# pull in a second copy from /opt/rocm with no device/stream state in common
+# (every launch then fails with hipErrorNoDevice).
+import torch  # noqa: F401  (import order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "lib", "libomh.so")
 

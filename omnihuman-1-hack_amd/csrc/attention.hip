@@ -240,6 +240,7 @@ extern "C" int omh_flash_attn_fwd_d128(const omh_attn_args* args, omh_stream_t s
     if (a.ldv < ((a.Lk + KB - 1) / KB) * KB) return OMH_E_SHAPE;
     const int q_tiles = (a.Lq + QB - 1) / QB;
     dim3 grid(q_tiles * a.H * a.B);
+    omh_clear_status();
     hipLaunchKernelGGL(flash_attn_fwd_d128_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, q_tiles);
     return omh_launch_status();
 }

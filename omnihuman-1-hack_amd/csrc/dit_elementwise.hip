@@ -274,6 +274,7 @@ extern "C" int omh_layernorm_modulate(const float* x, void* y, int64_t rows, int
     if (!x || !y || rows <= 0 || dim <= 0 || rows_per_batch <= 0) return OMH_E_BADARG;
     if ((dim & 3) || dim > MAXV * 256) return OMH_E_SHAPE;
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 7) || (mul1_stride & 3) || (add1_stride & 3)) return OMH_E_ALIGN;
+    omh_clear_status();
     hipLaunchKernelGGL(layernorm_modulate_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
                        (hipStream_t)stream, x, (uint16_t*)y, rows, dim, eps, mul_const, mul0, mul1, mul1_stride,
                        add0, add1, add1_stride, rows_per_batch);
@@ -289,6 +290,7 @@ extern "C" int omh_rmsnorm_rope(const float* x, int64_t ldx, void* y, int64_t ro
     if (rope_cos && (!rope_sin || !grid || seq_len <= 0 || head_dim <= 0 || (head_dim & 3) || dim % head_dim))
         return OMH_E_BADARG;
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return OMH_E_ALIGN;
+    omh_clear_status();
     hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        x, ldx, (uint16_t*)y, rows, dim, weight, eps, do_norm, rope_cos, rope_sin, rope_len,
                        head_dim, grid, seq_len);
@@ -298,6 +300,7 @@ extern "C" int omh_rmsnorm_rope(const float* x, int64_t ldx, void* y, int64_t ro
 extern "C" int omh_cast_f32_bf16(const float* x, void* y, int64_t n, omh_stream_t stream) {
     if (!x || !y || n <= 0) return OMH_E_BADARG;
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return OMH_E_ALIGN;
+    omh_clear_status();
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream,
                        x, (uint16_t*)y, n);
     return omh_launch_status();
@@ -308,6 +311,7 @@ extern "C" int omh_patchify(const float* x, void* tok, int32_t C, int32_t F, int
     if (!x || !tok || C <= 0 || F <= 0 || H <= 0 || W <= 0 || pt <= 0 || ph <= 0 || pw <= 0) return OMH_E_BADARG;
     if (F % pt || H % ph || W % pw || Kp < C * pt * ph * pw) return OMH_E_SHAPE;
     const int64_t total = (int64_t)(F / pt) * (H / ph) * (W / pw) * Kp;
+    omh_clear_status();
     hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
                        (uint16_t*)tok, C, F, H, W, pt, ph, pw, Kp);
     return omh_launch_status();
@@ -318,6 +322,7 @@ extern "C" int omh_unpatchify(const float* tok, float* out, int32_t Cout, int32_
     if (!tok || !out || Cout <= 0 || f <= 0 || h <= 0 || w <= 0 || pt <= 0 || ph <= 0 || pw <= 0)
         return OMH_E_BADARG;
     const int64_t total = (int64_t)Cout * f * pt * h * ph * w * pw;
+    omh_clear_status();
     hipLaunchKernelGGL(unpatchify_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, tok, out,
                        Cout, f, h, w, pt, ph, pw);
     return omh_launch_status();
@@ -327,6 +332,7 @@ extern "C" int omh_dense_f32(const float* x, const float* W, const float* bias, 
                              int32_t K, int32_t act_in, int32_t act_out, omh_stream_t stream) {
     if (!x || !W || !y || B <= 0 || N <= 0 || K <= 0) return OMH_E_BADARG;
     const int64_t outs = (int64_t)B * N;
+    omh_clear_status();
     hipLaunchKernelGGL(dense_f32_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, W,
                        bias, y, B, N, K, act_in, act_out);
     return omh_launch_status();
@@ -335,6 +341,7 @@ extern "C" int omh_dense_f32(const float* x, const float* W, const float* bias, 
 extern "C" int omh_sinusoidal_embedding(const float* t, float* out, int32_t B, int32_t dim, omh_stream_t stream) {
     if (!t || !out || B <= 0 || dim <= 0 || (dim & 1)) return OMH_E_BADARG;
     const int n = B * (dim / 2);
+    omh_clear_status();
     hipLaunchKernelGGL(sinusoid_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, out, B, dim);
     return omh_launch_status();
 }
@@ -346,6 +353,7 @@ extern "C" int omh_cfg_unipc_step(const float* cond, const float* uncond, const 
                                   omh_stream_t stream) {
     if (!cond || !uncond || !x || !x_next || n <= 0) return OMH_E_BADARG;
     if (use_corr && !last) return OMH_E_BADARG;
+    omh_clear_status();
     hipLaunchKernelGGL(cfg_unipc_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, cond, uncond, x,
                        last, m1, m2, mt_out, xc_out, x_next, n, guide, sigma, use_corr, ca_last, ca_m1, ca_m2, ca_mt,
                        pb_x, pb_mt, pb_m1);

@@ -200,6 +200,7 @@ int launch(const omh_gemm_args& a, hipStream_t s) {
     g.tiles_m = (a.M + BM - 1) / BM;
     g.tiles_n = (a.N + BN - 1) / BN;
     dim3 grid(g.tiles_m * g.tiles_n, 1, a.batch);
+    omh_clear_status();
     hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, grid, dim3(256), 0, s, a, g);
     return omh_launch_status();
 }

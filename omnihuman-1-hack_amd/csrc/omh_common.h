@@ -49,6 +49,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
+// hipGetLastError() reports the last error of ANY earlier runtime call on this
+// thread (e.g. a probe made by the host framework): clear it before a launch
+// so the status returned after the launch belongs to that launch only.
+static inline void omh_clear_status() { (void)hipGetLastError(); }
 static inline int omh_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
