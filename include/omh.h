@@ -180,6 +180,53 @@ int omh_cfg_unipc_step(const float* cond, const float* uncond, const float* x, c
                        float ca_last, float ca_m1, float ca_m2, float ca_mt,
                        float pb_x, float pb_mt, float pb_m1, omh_stream_t stream);
 
+/* ========================================================================
+ * 3D causal VAE (seaweed_apt/wan/modules/vae.py).  Activations are
+ * channels-last bf16 [T, H, W, C]; a causal conv's temporal history (the
+ * reference's feat_cache slots, vae.py:205-217) is the leading frames of its
+ * input buffer.
+ * ====================================================================== */
+
+/* Implicit-GEMM convolution (CausalConv3d 3x3x3 / 3x1x1 / 1x1x1, Conv2d 3x3
+ * stride 1 or 2, optional folded nearest-2x upsample; vae.py:17-36,76-96).
+ *   y[to][yo][xo][co] = bias[co] + resid[...] + sum w[co][((kt*KH+dy)*KW+dx)*Cin+ci] *
+ *                       x[to*stride_t + kt][S(yo*stride_hw + dy - pad_h)][S(xo*stride_hw + dx - pad_w)][ci]
+ *   S(i) = i (or i>>1 with up2), zero outside [0, Hin) x [0, Win) (x2 with up2).
+ *   split_n > 0: the Cout channels are Cout/split_n consecutive output FRAMES
+ *   of split_n channels each (temporal upsample interleave, vae.py:134-137).
+ * Cin % 8 == 0; (Tout-1)*stride_t + KT <= Tin. */
+typedef struct omh_conv_args {
+    const void* x; const void* w; const float* bias; const void* resid; void* y;
+    int32_t Tin, Hin, Win, Cin;
+    int32_t Tout, Hout, Wout, Cout;
+    int32_t KT, KH, KW;
+    int32_t stride_t, stride_hw, pad_h, pad_w;
+    int32_t up2, out_f32, split_n;
+} omh_conv_args;
+
+int omh_conv_cl_bf16(const omh_conv_args* args, omh_stream_t stream);
+
+/* RMS_norm over channels (+ optional SiLU) per voxel (vae.py:39-54,195-197):
+ *   y[p][c] = act( x[p][c] / max(||x[p]||_2, 1e-12) * sqrt(C) * gamma[c] ),  x,y bf16 [P, C]. */
+int omh_rms_silu_cl(const void* x_bf16, const float* gamma, void* y_bf16, int64_t P, int32_t C,
+                    int32_t do_silu, omh_stream_t stream);
+
+/* Layout/precision converts at the VAE boundary (vae.py:547-553, 535-540, 661):
+ *   nchw_to_cl : y[t][h][w][c] = bf16( x[c][t0+t][h][w] * mul[c] + add[c] ), c < C; channels C..Cp-1 zero
+ *   cl_to_nchw : y[c][t0+t][h][w] = clamp( (x[t][h][w][c] + add[c]) * mul[c], lo, hi ), x fp32 with Cp channels
+ * The NCTHW tensor has t_total frames; the channels-last chunk covers frames [t0, t0+T).
+ * mul/add may be NULL (1 / 0). */
+int omh_nchw_to_cl(const float* x, void* y_bf16, int32_t C, int32_t T, int32_t H, int32_t W, int32_t Cp,
+                   const float* mul, const float* add, int32_t t_total, int32_t t0, omh_stream_t stream);
+int omh_cl_to_nchw(const float* x, float* y, int32_t C, int32_t T, int32_t H, int32_t W, int32_t Cp,
+                   const float* mul, const float* add, float lo, float hi, int32_t t_total, int32_t t0,
+                   omh_stream_t stream);
+
+/* Row softmax for the VAE's single-head mid-block attention (vae.py:252):
+ *   y[r][j] = bf16( softmax_j( x[r][j] * scale ) ), x fp32 [R, L] (ldx), y bf16 (ldy). */
+int omh_softmax_rows(const float* x, int64_t ldx, void* y_bf16, int64_t ldy, int64_t R, int32_t L, float scale,
+                     omh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,15 @@ class AttnArgs(C.Structure):
                 ("ldv", i32), ("scale", f32), ("lse", vp)]
 
 
+class ConvArgs(C.Structure):
+    _fields_ = [("x", vp), ("w", vp), ("bias", vp), ("resid", vp), ("y", vp),
+                ("Tin", i32), ("Hin", i32), ("Win", i32), ("Cin", i32),
+                ("Tout", i32), ("Hout", i32), ("Wout", i32), ("Cout", i32),
+                ("KT", i32), ("KH", i32), ("KW", i32),
+                ("stride_t", i32), ("stride_hw", i32), ("pad_h", i32), ("pad_w", i32),
+                ("up2", i32), ("out_f32", i32), ("split_n", i32)]
+
+
 EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID, EPI_F32_ACCUM = 0, 1, 2, 3, 4
 BIAS_NONE, BIAS_N, BIAS_M = 0, 1, 2
 
@@ -75,6 +84,11 @@ _SIGS = {
     "omh_unpatchify": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "omh_dense_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "omh_sinusoidal_embedding": (i32, [vp, vp, i32, i32, vp]),
+    "omh_conv_cl_bf16": (i32, [C.POINTER(ConvArgs), vp]),
+    "omh_rms_silu_cl": (i32, [vp, vp, vp, i64, i32, i32, vp]),
+    "omh_nchw_to_cl": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp]),
+    "omh_cl_to_nchw": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, f32, f32, i32, i32, vp]),
+    "omh_softmax_rows": (i32, [vp, i64, vp, i64, i64, i32, f32, vp]),
     "omh_cfg_unipc_step": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, i32, f32, f32, f32, f32, f32,
                                  f32, f32, vp]),
 }

@@ -1,0 +1,179 @@
+// HBM-bound kernels of the Wan 3D VAE on gfx950: per-voxel RMS norm + SiLU,
+// layout converts at the NCTHW fp32 boundary, row softmax of the mid-block
+// attention.  (seaweed_apt/wan/modules/vae.py:39-54, 223-262, 535-553, 661)
+#include "omh_common.h"
+
+namespace {
+
+// One voxel (C channels, bf16) is handled by G consecutive lanes, 8 channels
+// (16 bytes) per lane per pass.
+template <int G>
+__global__ __launch_bounds__(256)
+void rms_silu_kernel(const uint16_t* __restrict__ x, const float* __restrict__ gamma, uint16_t* __restrict__ y,
+                     int64_t P, int C, int do_silu) {
+    const int lane_g = threadIdx.x % G;
+    const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    if (p >= P) return;            // whole group exits together (G divides the wave)
+    const int nch = C >> 3;        // 16-byte chunks per voxel
+    constexpr int MAXC = 4;        // chunks per lane  -> C <= 8*G*MAXC
+    uint4 v[MAXC];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane_g + G * i;
+        if (c < nch) {
+            v[i] = *(const uint4*)(x + p * C + c * 8);
+            const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = bf2f((uint16_t)(w[e] & 0xffff)), b = bf2f((uint16_t)(w[e] >> 16));
+                ss += a * a + b * b;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float inv = sqrtf((float)C) / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane_g + G * i;
+        if (c < nch) {
+            const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+            uint32_t o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = bf2f((uint16_t)(w[e] & 0xffff)) * inv * gamma[c * 8 + 2 * e];
+                float b = bf2f((uint16_t)(w[e] >> 16)) * inv * gamma[c * 8 + 2 * e + 1];
+                if (do_silu) { a = silu(a); b = silu(b); }
+                o[e] = pack_bf2(a, b);
+            }
+            *(uint4*)(y + p * C + c * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256)
+void nchw_to_cl_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int C, int T, int H, int W, int Cp,
+                       const float* __restrict__ mul, const float* __restrict__ add, int t_total, int t0) {
+    const int64_t vox = (int64_t)T * H * W;
+    const int64_t total = vox * Cp;
+    const int64_t cstride = (int64_t)t_total * H * W, toff = (int64_t)t0 * H * W;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % Cp);
+        const int64_t v = i / Cp;
+        float val = 0.f;
+        if (c < C) {
+            val = x[(int64_t)c * cstride + toff + v];
+            if (mul) val *= mul[c];
+            if (add) val += add[c];
+        }
+        y[i] = f2bf(val);
+    }
+}
+
+__global__ __launch_bounds__(256)
+void cl_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int T, int H, int W, int Cp,
+                       const float* __restrict__ mul, const float* __restrict__ add, float lo, float hi,
+                       int t_total, int t0) {
+    const int64_t vox = (int64_t)T * H * W;
+    const int64_t total = vox * C;
+    const int64_t cstride = (int64_t)t_total * H * W, toff = (int64_t)t0 * H * W;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t v = i % vox;
+        const int c = (int)(i / vox);
+        float val = x[v * Cp + c];
+        if (add) val += add[c];
+        if (mul) val *= mul[c];
+        y[(int64_t)c * cstride + toff + v] = fminf(fmaxf(val, lo), hi);
+    }
+}
+
+// one 256-thread block per row
+__global__ __launch_bounds__(256)
+void softmax_rows_kernel(const float* __restrict__ x, int64_t ldx, uint16_t* __restrict__ y, int64_t ldy, int L,
+                         float scale) {
+    __shared__ float red[8];
+    const int64_t r = blockIdx.x;
+    const float* xr = x + r * ldx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float mx = -INFINITY;
+    for (int j = tid; j < L; j += 256) mx = fmaxf(mx, xr[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float sc = scale * 1.4426950408889634f;
+    float s = 0.f;
+    for (int j = tid; j < L; j += 256) s += exp2f((xr[j] - mx) * sc);
+    s = wave_sum(s);
+    if (lane == 0) red[4 + wave] = s;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    uint16_t* yr = y + r * ldy;
+    for (int j = tid; j < L; j += 256) yr[j] = f2bf(exp2f((xr[j] - mx) * sc) * inv);
+}
+
+inline int grid_for(int64_t n, int per_block) {
+    int64_t g = (n + per_block - 1) / per_block;
+    return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+}  // namespace
+
+extern "C" int omh_rms_silu_cl(const void* x, const float* gamma, void* y, int64_t P, int32_t C, int32_t do_silu,
+                               omh_stream_t stream) {
+    if (!x || !gamma || !y || P <= 0 || C <= 0) return OMH_E_BADARG;
+    if ((C & 7) || C > 8 * 64 * 4) return OMH_E_SHAPE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return OMH_E_ALIGN;
+    const int nch = C >> 3;
+    hipStream_t s = (hipStream_t)stream;
+    omh_clear_status();
+    // lanes per voxel: enough that each lane holds <= 4 chunks, rounded to a power of two
+    if (nch <= 16) {
+        hipLaunchKernelGGL(rms_silu_kernel<4>, dim3((unsigned)((P * 4 + 255) / 256)), dim3(256), 0, s,
+                           (const uint16_t*)x, gamma, (uint16_t*)y, P, C, do_silu);
+    } else if (nch <= 64) {
+        hipLaunchKernelGGL(rms_silu_kernel<16>, dim3((unsigned)((P * 16 + 255) / 256)), dim3(256), 0, s,
+                           (const uint16_t*)x, gamma, (uint16_t*)y, P, C, do_silu);
+    } else {
+        hipLaunchKernelGGL(rms_silu_kernel<64>, dim3((unsigned)((P * 64 + 255) / 256)), dim3(256), 0, s,
+                           (const uint16_t*)x, gamma, (uint16_t*)y, P, C, do_silu);
+    }
+    return omh_launch_status();
+}
+
+extern "C" int omh_nchw_to_cl(const float* x, void* y, int32_t C, int32_t T, int32_t H, int32_t W, int32_t Cp,
+                              const float* mul, const float* add, int32_t t_total, int32_t t0,
+                              omh_stream_t stream) {
+    if (!x || !y || C <= 0 || T <= 0 || H <= 0 || W <= 0 || Cp < C || t0 < 0 || t0 + T > t_total)
+        return OMH_E_BADARG;
+    const int64_t total = (int64_t)T * H * W * Cp;
+    omh_clear_status();
+    hipLaunchKernelGGL(nchw_to_cl_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (uint16_t*)y, C, T, H, W, Cp, mul, add, t_total, t0);
+    return omh_launch_status();
+}
+
+extern "C" int omh_cl_to_nchw(const float* x, float* y, int32_t C, int32_t T, int32_t H, int32_t W, int32_t Cp,
+                              const float* mul, const float* add, float lo, float hi, int32_t t_total,
+                              int32_t t0, omh_stream_t stream) {
+    if (!x || !y || C <= 0 || T <= 0 || H <= 0 || W <= 0 || Cp < C || t0 < 0 || t0 + T > t_total)
+        return OMH_E_BADARG;
+    const int64_t total = (int64_t)T * H * W * C;
+    omh_clear_status();
+    hipLaunchKernelGGL(cl_to_nchw_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, C, T,
+                       H, W, Cp, mul, add, lo, hi, t_total, t0);
+    return omh_launch_status();
+}
+
+extern "C" int omh_softmax_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t R, int32_t L, float scale,
+                                omh_stream_t stream) {
+    if (!x || !y || R <= 0 || L <= 0 || R > 0x7fffffff) return OMH_E_BADARG;
+    omh_clear_status();
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       (uint16_t*)y, ldy, L, scale);
+    return omh_launch_status();
+}

@@ -14,7 +14,8 @@ from ._lib import (BIAS_M, BIAS_N, BIAS_NONE, EPI_BF16, EPI_F32, EPI_F32_ACCUM, 
                    AttnArgs, GemmArgs, OmhError, check, lib)
 
 __all__ = ["gemm", "flash_attn", "layernorm_modulate", "rmsnorm_rope", "cast_bf16", "patchify", "unpatchify",
-           "dense_f32", "sinusoidal_embedding", "cfg_unipc_step", "OmhError",
+           "dense_f32", "sinusoidal_embedding", "cfg_unipc_step", "conv_cl", "rms_silu_cl", "nchw_to_cl", "cl_to_nchw",
+           "softmax_rows", "OmhError",
            "EPI_BF16", "EPI_F32", "EPI_GELU_BF16", "EPI_RESID", "EPI_F32_ACCUM", "BIAS_NONE", "BIAS_N", "BIAS_M"]
 
 
@@ -191,3 +192,69 @@ def cfg_unipc_step(cond, uncond, x, last, m1, m2, mt_out, xc_out, x_next, guide,
                                  float(ca[1]), float(ca[2]), float(ca[3]), float(pb[0]), float(pb[1]), float(pb[2]),
                                  _stream()), "omh_cfg_unipc_step")
     return x_next
+
+
+# ----------------------------------------------------------------------------- VAE kernels
+def conv_cl(x, w, bias, Tout, Hout, Wout, Cout, KT, KH, KW, stride_t=1, stride_hw=1, pad_h=0, pad_w=0, up2=False,
+            resid=None, out_f32=False, split_n=0, out=None):
+    """Implicit-GEMM conv on channels-last bf16 ``x`` [Tin, Hin, Win, Cin] (history frames first);
+    ``w`` bf16 [Cout, KT*KH*KW*Cin].  Returns [Tout*f, Hout, Wout, Cout/f] (f = Cout/split_n or 1)."""
+    _dev(x, w, bias, resid, out)
+    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_contiguous() and w.is_contiguous()
+    Tin, Hin, Win, Cin = x.shape
+    assert w.shape == (Cout, KT * KH * KW * Cin), (tuple(w.shape), Cout, KT, KH, KW, Cin)
+    f = Cout // split_n if split_n else 1
+    cch = split_n if split_n else Cout
+    if out is None:
+        out = torch.empty(Tout * f, Hout, Wout, cch, dtype=torch.float32 if out_f32 else torch.bfloat16,
+                          device=x.device)
+    assert out.is_contiguous() and (resid is None or (resid.is_contiguous() and resid.dtype == torch.bfloat16))
+    a = _lib.ConvArgs(_p(x), _p(w), _p(bias), _p(resid), _p(out), Tin, Hin, Win, Cin, Tout, Hout, Wout, Cout,
+                      KT, KH, KW, stride_t, stride_hw, pad_h, pad_w, int(up2), int(out_f32), split_n)
+    check(lib.omh_conv_cl_bf16(C.byref(a), _stream()), "omh_conv_cl_bf16")
+    return out
+
+
+def rms_silu_cl(x, gamma, out=None, do_silu=True):
+    """x bf16 [..., C] channels-last -> bf16, per-voxel RMS norm (* gamma) then SiLU."""
+    _dev(x, gamma, out)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and gamma.dtype == torch.float32
+    Cc = x.shape[-1]
+    if out is None:
+        out = torch.empty_like(x)
+    assert out.is_contiguous() and out.dtype == torch.bfloat16
+    check(lib.omh_rms_silu_cl(_p(x), _p(gamma), _p(out), x.numel() // Cc, Cc, int(do_silu), _stream()),
+          "omh_rms_silu_cl")
+    return out
+
+
+def nchw_to_cl(x, T, t0, Cp, mul=None, add=None, out=None):
+    """x fp32 [C, Ttot, H, W] frames [t0, t0+T) -> bf16 [T, H, W, Cp]."""
+    _dev(x, mul, add, out)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    Cc, Ttot, H, W = x.shape
+    if out is None:
+        out = torch.empty(T, H, W, Cp, dtype=torch.bfloat16, device=x.device)
+    check(lib.omh_nchw_to_cl(_p(x), _p(out), Cc, T, H, W, Cp, _p(mul), _p(add), Ttot, t0, _stream()),
+          "omh_nchw_to_cl")
+    return out
+
+
+def cl_to_nchw(x, out, t0, Cc, mul=None, add=None, lo=-3.0e38, hi=3.0e38):
+    """x fp32 [T, H, W, Cp] -> out fp32 [Cc, Ttot, H, W] frames [t0, t0+T)."""
+    _dev(x, out, mul, add)
+    assert x.dtype == torch.float32 and x.is_contiguous() and out.dtype == torch.float32 and out.is_contiguous()
+    T, H, W, Cp = x.shape
+    assert out.shape[0] == Cc and tuple(out.shape[2:]) == (H, W)
+    check(lib.omh_cl_to_nchw(_p(x), _p(out), Cc, T, H, W, Cp, _p(mul), _p(add), lo, hi, out.shape[1], t0,
+                             _stream()), "omh_cl_to_nchw")
+    return out
+
+
+def softmax_rows(x, out, L, scale):
+    """x fp32 [R, >=L] -> out bf16 [R, >=L] (first L columns), row softmax of x*scale."""
+    _dev(x, out)
+    assert x.dtype == torch.float32 and out.dtype == torch.bfloat16 and x.stride(1) == 1 and out.stride(1) == 1
+    check(lib.omh_softmax_rows(_p(x), x.stride(0), _p(out), out.stride(0), x.shape[0], L, scale, _stream()),
+          "omh_softmax_rows")
+    return out

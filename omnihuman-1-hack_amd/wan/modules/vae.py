@@ -1,9 +1,522 @@
-"""Wan 3D causal VAE (seaweed_apt/wan/modules/vae.py) — gfx950 build in progress."""
+"""Wan 3D causal VAE on hand-written gfx950 kernels — drop-in for the
+reference's ``wan.modules.vae`` (seaweed_apt/wan/modules/vae.py).
+
+Same module tree / state-dict keys as the reference ``WanVAE_``
+(``encoder.*, conv1.*, conv2.*, decoder.*``, vae.py:483-508) so
+``Wan2.1_VAE.pth`` loads unchanged, and the same ``WanVAE`` wrapper surface
+(``.model``, ``.mean``, ``.std``, ``.scale``, ``encode(list)``, ``decode(list)``,
+vae.py:619-663).  The modules only hold parameters; the arithmetic is a
+streaming executor over libomh.so kernels (include/omh.h):
+
+  * activations are channels-last bf16 ``[T, H, W, C]``;
+  * every causal conv owns an input buffer whose first frames are its temporal
+    history (what the reference keeps in ``feat_cache`` and re-concatenates
+    each chunk, vae.py:205-217) — the conv kernel never pads in time and the
+    producer writes straight behind the history;
+  * RMS_norm+SiLU is one HBM pass (``omh_rms_silu_cl``) feeding the conv's
+    buffer; the residual add rides in the conv epilogue; the nearest-2x
+    upsample is folded into the following conv's addressing; the temporal
+    upsample's channel->frame interleave is done by the conv's store;
+  * the reference's chunking is kept exactly (encode 1,4,4,... frames,
+    decode one latent frame per step, first-chunk bypass of the temporal
+    resamplers — vae.py:101-160,516-568) because it defines the numerics.
+
+Compute is bf16 MFMA with fp32 accumulation (the reference runs fp32); the
+tolerance is stated in tests/test_gpu_vae.py and DESIGN.md.
+"""
+import logging
+import math
+
 import torch
+import torch.nn as nn
+
+from .._backend import ops
 
 __all__ = ["WanVAE"]
 
+CACHE_T = 2
+
+
+# ----------------------------------------------------------------------------
+# parameter containers (names = the reference's state-dict keys)
+# ----------------------------------------------------------------------------
+class CausalConv3d(nn.Conv3d):
+    """vae.py:17-36."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._padding = (self.padding[2], self.padding[2], self.padding[1], self.padding[1], 2 * self.padding[0], 0)
+        self.padding = (0, 0, 0)
+
+
+class RMS_norm(nn.Module):
+    """vae.py:39-54."""
+
+    def __init__(self, dim, channel_first=True, images=True, bias=False):
+        super().__init__()
+        broadcastable_dims = (1, 1, 1) if not images else (1, 1)
+        shape = (dim, *broadcastable_dims) if channel_first else (dim,)
+        self.channel_first = channel_first
+        self.scale = dim ** 0.5
+        self.gamma = nn.Parameter(torch.ones(shape))
+        self.bias = nn.Parameter(torch.zeros(shape)) if bias else 0.
+
+
+class Upsample(nn.Upsample):
+    pass
+
+
+class Resample(nn.Module):
+    """vae.py:66-99."""
+
+    def __init__(self, dim, mode):
+        assert mode in ("none", "upsample2d", "upsample3d", "downsample2d", "downsample3d")
+        super().__init__()
+        self.dim, self.mode = dim, mode
+        if mode == "upsample2d":
+            self.resample = nn.Sequential(Upsample(scale_factor=(2., 2.), mode="nearest-exact"),
+                                          nn.Conv2d(dim, dim // 2, 3, padding=1))
+        elif mode == "upsample3d":
+            self.resample = nn.Sequential(Upsample(scale_factor=(2., 2.), mode="nearest-exact"),
+                                          nn.Conv2d(dim, dim // 2, 3, padding=1))
+            self.time_conv = CausalConv3d(dim, dim * 2, (3, 1, 1), padding=(1, 0, 0))
+        elif mode == "downsample2d":
+            self.resample = nn.Sequential(nn.ZeroPad2d((0, 1, 0, 1)), nn.Conv2d(dim, dim, 3, stride=(2, 2)))
+        elif mode == "downsample3d":
+            self.resample = nn.Sequential(nn.ZeroPad2d((0, 1, 0, 1)), nn.Conv2d(dim, dim, 3, stride=(2, 2)))
+            self.time_conv = CausalConv3d(dim, dim, (3, 1, 1), stride=(2, 1, 1), padding=(0, 0, 0))
+        else:
+            self.resample = nn.Identity()
+
+
+class ResidualBlock(nn.Module):
+    """vae.py:186-200."""
+
+    def __init__(self, in_dim, out_dim, dropout=0.0):
+        super().__init__()
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.residual = nn.Sequential(
+            RMS_norm(in_dim, images=False), nn.SiLU(), CausalConv3d(in_dim, out_dim, 3, padding=1),
+            RMS_norm(out_dim, images=False), nn.SiLU(), nn.Dropout(dropout),
+            CausalConv3d(out_dim, out_dim, 3, padding=1))
+        self.shortcut = CausalConv3d(in_dim, out_dim, 1) if in_dim != out_dim else nn.Identity()
+
+
+class AttentionBlock(nn.Module):
+    """vae.py:223-238."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+        self.norm = RMS_norm(dim)
+        self.to_qkv = nn.Conv2d(dim, dim * 3, 1)
+        self.proj = nn.Conv2d(dim, dim, 1)
+        nn.init.zeros_(self.proj.weight)
+
+
+class Encoder3d(nn.Module):
+    """vae.py:265-316."""
+
+    def __init__(self, dim=128, z_dim=4, dim_mult=[1, 2, 4, 4], num_res_blocks=2, attn_scales=[],
+                 temperal_downsample=[True, True, False], dropout=0.0):
+        super().__init__()
+        self.dim, self.z_dim, self.dim_mult = dim, z_dim, dim_mult
+        self.num_res_blocks, self.attn_scales, self.temperal_downsample = num_res_blocks, attn_scales, temperal_downsample
+        dims = [dim * u for u in [1] + dim_mult]
+        scale = 1.0
+        self.conv1 = CausalConv3d(3, dims[0], 3, padding=1)
+        downsamples = []
+        for i, (in_dim, out_dim) in enumerate(zip(dims[:-1], dims[1:])):
+            for _ in range(num_res_blocks):
+                downsamples.append(ResidualBlock(in_dim, out_dim, dropout))
+                if scale in attn_scales:
+                    downsamples.append(AttentionBlock(out_dim))
+                in_dim = out_dim
+            if i != len(dim_mult) - 1:
+                mode = "downsample3d" if temperal_downsample[i] else "downsample2d"
+                downsamples.append(Resample(out_dim, mode=mode))
+                scale /= 2.0
+        self.downsamples = nn.Sequential(*downsamples)
+        self.middle = nn.Sequential(ResidualBlock(out_dim, out_dim, dropout), AttentionBlock(out_dim),
+                                    ResidualBlock(out_dim, out_dim, dropout))
+        self.head = nn.Sequential(RMS_norm(out_dim, images=False), nn.SiLU(),
+                                  CausalConv3d(out_dim, z_dim, 3, padding=1))
+
+
+class Decoder3d(nn.Module):
+    """vae.py:369-421."""
+
+    def __init__(self, dim=128, z_dim=4, dim_mult=[1, 2, 4, 4], num_res_blocks=2, attn_scales=[],
+                 temperal_upsample=[False, True, True], dropout=0.0):
+        super().__init__()
+        self.dim, self.z_dim, self.dim_mult = dim, z_dim, dim_mult
+        self.num_res_blocks, self.attn_scales, self.temperal_upsample = num_res_blocks, attn_scales, temperal_upsample
+        dims = [dim * u for u in [dim_mult[-1]] + dim_mult[::-1]]
+        scale = 1.0 / 2 ** (len(dim_mult) - 2)
+        self.conv1 = CausalConv3d(z_dim, dims[0], 3, padding=1)
+        self.middle = nn.Sequential(ResidualBlock(dims[0], dims[0], dropout), AttentionBlock(dims[0]),
+                                    ResidualBlock(dims[0], dims[0], dropout))
+        upsamples = []
+        for i, (in_dim, out_dim) in enumerate(zip(dims[:-1], dims[1:])):
+            if i == 1 or i == 2 or i == 3:
+                in_dim = in_dim // 2
+            for _ in range(num_res_blocks + 1):
+                upsamples.append(ResidualBlock(in_dim, out_dim, dropout))
+                if scale in attn_scales:
+                    upsamples.append(AttentionBlock(out_dim))
+                in_dim = out_dim
+            if i != len(dim_mult) - 1:
+                mode = "upsample3d" if temperal_upsample[i] else "upsample2d"
+                upsamples.append(Resample(out_dim, mode=mode))
+                scale *= 2.0
+        self.upsamples = nn.Sequential(*upsamples)
+        self.head = nn.Sequential(RMS_norm(out_dim, images=False), nn.SiLU(), CausalConv3d(out_dim, 3, 3, padding=1))
+
+
+def count_conv3d(model):
+    return sum(1 for m in model.modules() if isinstance(m, CausalConv3d))
+
+
+# ----------------------------------------------------------------------------
+# streaming executor
+# ----------------------------------------------------------------------------
+def _round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+class _ConvState:
+    """Packed weight + temporal-history input buffer of one convolution."""
+
+    def __init__(self, conv, up2=False, stride_hw=1, pad=None):
+        w = conv.weight.detach()
+        if w.dim() == 4:                      # Conv2d -> [Cout, Cin, 1, kh, kw]
+            w = w.unsqueeze(2)
+        self.Cout, self.Cin_raw, self.KT, self.KH, self.KW = w.shape
+        self.Cin = _round_up(self.Cin_raw, 8)
+        wp = w.float().permute(0, 2, 3, 4, 1)                       # [Cout, kt, kh, kw, Cin]
+        if self.Cin != self.Cin_raw:
+            wp = torch.nn.functional.pad(wp, (0, self.Cin - self.Cin_raw))
+        self.w = ops.cast_bf16(wp.contiguous().view(self.Cout, -1))
+        self.bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
+        st = conv.stride if isinstance(conv.stride, tuple) else (conv.stride,) * 3
+        self.stride_t = st[0] if len(st) == 3 else 1
+        self.stride_hw = stride_hw
+        self.up2 = up2
+        self.pad = (self.KH // 2, self.KW // 2) if pad is None else pad
+        self.hist = self.KT - 1 if self.stride_t == 1 else 1      # history frames kept in front of the chunk
+        self.buf = None
+        self.T = 0
+
+    def slot(self, T, H, W, device):
+        """View [T, H, W, Cin] the producer writes the current chunk into."""
+        need = self.hist + T
+        if self.buf is None or self.buf.shape[0] < need or tuple(self.buf.shape[1:3]) != (H, W):
+            old = self.buf
+            self.buf = torch.zeros(need, H, W, self.Cin, dtype=torch.bfloat16, device=device)
+            if old is not None and self.hist and tuple(old.shape[1:3]) == (H, W):
+                self.buf[:self.hist].copy_(old[:self.hist])
+        self.T = T
+        return self.buf[self.hist:self.hist + T]
+
+    def run(self, resid=None, out_f32=False, split_n=0, out=None):
+        """Convolve over [history | chunk]; then keep the last frames as the new history."""
+        T, (_, H, W, _) = self.T, self.buf.shape
+        x = self.buf[:self.hist + T]
+        if self.stride_t == 1:
+            Tout = T
+        else:
+            Tout = (self.hist + T - self.KT) // self.stride_t + 1
+        eff_h, eff_w = (2 * H, 2 * W) if self.up2 else (H, W)
+        if self.stride_hw == 1:
+            Hout, Wout = eff_h, eff_w
+        else:                                               # ZeroPad2d((0,1,0,1)) + 3x3 stride 2 (vae.py:88-90)
+            Hout, Wout = (eff_h + 1 - self.KH) // 2 + 1, (eff_w + 1 - self.KW) // 2 + 1
+        y = ops.conv_cl(x, self.w, self.bias, Tout, Hout, Wout, self.Cout, self.KT, self.KH, self.KW,
+                        stride_t=self.stride_t, stride_hw=self.stride_hw, pad_h=self.pad[0], pad_w=self.pad[1],
+                        up2=self.up2, resid=resid, out_f32=out_f32, split_n=split_n, out=out)
+        # history <- last `hist` frames of [history | chunk]
+        h = self.hist
+        if h:
+            if T >= h:                                      # source and destination frames are disjoint
+                self.buf[:h].copy_(self.buf[T:T + h])
+            else:                                           # T == 1, hist == 2
+                self.buf[0].copy_(self.buf[1])
+                self.buf[1].copy_(self.buf[2])
+        return y
+
+
+class _Stream:
+    """All per-call state of one encode or decode (the reference's _feat_map)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.convs = {}
+        self.seen = set()
+
+    def conv(self, key, module, **kw):
+        st = self.convs.get(key)
+        if st is None:
+            st = self.convs[key] = _ConvState(module, **kw)
+        return st
+
+
+def _gamma(norm: RMS_norm):
+    return norm.gamma.detach().float().reshape(-1).contiguous()
+
+
+def _conv_on(st: _Stream, key, module, x, **run_kw):
+    """Feed tensor x (bf16 [T,H,W,C]) to a conv that has no fused producer."""
+    cs = st.conv(key, module)
+    T, H, W, _ = x.shape
+    cs.slot(T, H, W, x.device).copy_(x)
+    return cs.run(**run_kw)
+
+
+def _res_block(st, key, blk: ResidualBlock, x):
+    """vae.py:202-220."""
+    T, H, W, _ = x.shape
+    h = x
+    if not isinstance(blk.shortcut, nn.Identity):
+        h = _conv_on(st, key + ".shortcut", blk.shortcut, x)
+    ca = st.conv(key + ".residual.2", blk.residual[2])
+    ops.rms_silu_cl(x, _gamma(blk.residual[0]), out=ca.slot(T, H, W, x.device))
+    y = ca.run()
+    cb = st.conv(key + ".residual.6", blk.residual[6])
+    ops.rms_silu_cl(y, _gamma(blk.residual[3]), out=cb.slot(T, H, W, x.device))
+    return cb.run(resid=h)
+
+
+def _attention(st, key, blk: AttentionBlock, x):
+    """vae.py:240-262 — per-frame single-head attention, D = C.  Scores go through the GEMM kernel
+    (fp32 [HW, HW]) and a row-softmax kernel; it is 0.5 % of the decoder's work."""
+    T, H, W, Cc = x.shape
+    HW = H * W
+    HWp = _round_up(HW, 8)
+    dev = x.device
+    n = ops.rms_silu_cl(x, _gamma(blk.norm), do_silu=False).view(T * HW, Cc)
+    wk = "attn:" + key
+    if wk not in st.convs:
+        wqkv = blk.to_qkv.weight.detach().float().view(3 * Cc, Cc)
+        st.convs[wk] = (ops.cast_bf16(wqkv[:2 * Cc].contiguous()), blk.to_qkv.bias.detach().float()[:2 * Cc].contiguous(),
+                        ops.cast_bf16(wqkv[2 * Cc:].contiguous()), blk.to_qkv.bias.detach().float()[2 * Cc:].contiguous())
+    wqk, bqk, wv, bv = st.convs[wk]
+    qk = ops.gemm(n, wqk, bias=bqk, epilogue=ops.EPI_BF16)                  # [T*HW, 2C]
+    vt = torch.zeros(T, Cc, HWp, dtype=torch.bfloat16, device=dev)
+    ops.gemm_raw(ops.ptr(wv), ops.ptr(n), ops.ptr(vt), Cc, HW, Cc, Cc, Cc, HWp, ops.EPI_BF16, bias=ops.ptr(bv),
+                 bias_mode=ops.BIAS_M, batch=T, strideA=0, strideB=HW * Cc, strideC=Cc * HWp)
+    s = torch.empty(T, HW, HW, dtype=torch.float32, device=dev)
+    ops.gemm_raw(ops.ptr(qk), ops.ptr(qk, Cc), ops.ptr(s), HW, HW, Cc, 2 * Cc, 2 * Cc, HW, ops.EPI_F32, batch=T,
+                 strideA=HW * 2 * Cc, strideB=HW * 2 * Cc, strideC=HW * HW)
+    p = torch.zeros(T * HW, HWp, dtype=torch.bfloat16, device=dev)
+    ops.softmax_rows(s.view(T * HW, HW), p, HW, 1.0 / math.sqrt(Cc))
+    o = torch.empty(T, HW, Cc, dtype=torch.bfloat16, device=dev)
+    ops.gemm_raw(ops.ptr(p), ops.ptr(vt), ops.ptr(o), HW, Cc, HWp, HWp, HWp, Cc, ops.EPI_BF16, batch=T,
+                 strideA=HW * HWp, strideB=Cc * HWp, strideC=HW * Cc)
+    del s, p
+    cs = st.conv(key + ".proj", blk.proj)
+    cs.slot(T, H, W, dev).copy_(o.view(T, H, W, Cc))
+    return cs.run(resid=x)
+
+
+def _resample(st, key, rs: Resample, x):
+    """vae.py:101-160."""
+    T, H, W, Cc = x.shape
+    if rs.mode in ("upsample2d", "upsample3d"):
+        if rs.mode == "upsample3d":
+            if key not in st.seen:
+                st.seen.add(key)                    # first chunk: the reference's 'Rep' bypass (vae.py:106-108)
+            else:
+                x = _conv_on(st, key + ".time_conv", rs.time_conv, x, split_n=Cc)    # [2T, H, W, C]
+        cs = st.conv(key + ".resample.1", rs.resample[1], up2=True)
+        cs.slot(x.shape[0], H, W, x.device).copy_(x)
+        return cs.run()
+    if rs.mode in ("downsample2d", "downsample3d"):
+        cs = st.conv(key + ".resample.1", rs.resample[1], stride_hw=2, pad=(0, 0))
+        cs.slot(T, H, W, x.device).copy_(x)
+        x = cs.run()
+        if rs.mode == "downsample3d":
+            tc = st.conv(key + ".time_conv", rs.time_conv)
+            if key not in st.seen:
+                st.seen.add(key)                    # first chunk passes through, remembered as history (vae.py:146-148)
+                tc.slot(x.shape[0], x.shape[1], x.shape[2], x.device)
+                tc.buf[0].copy_(x[-1])
+            else:
+                tc.slot(x.shape[0], x.shape[1], x.shape[2], x.device).copy_(x)
+                x = tc.run()
+        return x
+    return x
+
+
+def _head(st, key, head: nn.Sequential, x, out_f32):
+    T, H, W, _ = x.shape
+    cs = st.conv(key + ".2", head[2])
+    ops.rms_silu_cl(x, _gamma(head[0]), out=cs.slot(T, H, W, x.device))
+    return cs.run(out_f32=out_f32)
+
+
+def _run_sequential(st, prefix, seq, x):
+    for i, layer in enumerate(seq):
+        key = f"{prefix}.{i}"
+        if isinstance(layer, ResidualBlock):
+            x = _res_block(st, key, layer, x)
+        elif isinstance(layer, AttentionBlock):
+            x = _attention(st, key, layer, x)
+        elif isinstance(layer, Resample):
+            x = _resample(st, key, layer, x)
+        else:  # pragma: no cover
+            raise TypeError(type(layer))
+    return x
+
+
+class WanVAE_(nn.Module):
+    """vae.py:483-589."""
+
+    def __init__(self, dim=128, z_dim=4, dim_mult=[1, 2, 4, 4], num_res_blocks=2, attn_scales=[],
+                 temperal_downsample=[True, True, False], dropout=0.0):
+        super().__init__()
+        self.dim, self.z_dim, self.dim_mult = dim, z_dim, dim_mult
+        self.num_res_blocks, self.attn_scales = num_res_blocks, attn_scales
+        self.temperal_downsample = temperal_downsample
+        self.temperal_upsample = temperal_downsample[::-1]
+        self.encoder = Encoder3d(dim, z_dim * 2, dim_mult, num_res_blocks, attn_scales, self.temperal_downsample,
+                                 dropout)
+        self.conv1 = CausalConv3d(z_dim * 2, z_dim * 2, 1)
+        self.conv2 = CausalConv3d(z_dim, z_dim, 1)
+        self.decoder = Decoder3d(dim, z_dim, dim_mult, num_res_blocks, attn_scales, self.temperal_upsample, dropout)
+
+    def _device(self):
+        return self.conv1.weight.device
+
+    @torch.no_grad()
+    def encode(self, x, scale):
+        """x fp32 [1, 3, T, H, W] -> mu [1, z, (T-1)/4+1, H/8, W/8] (vae.py:516-542)."""
+        dev = self._device()
+        if dev.type != "cuda":
+            raise ops.OmhError("WanVAE runs on the MI355X only (no CPU fallback)")
+        assert x.dim() == 5 and x.shape[0] == 1
+        vid = x[0].to(device=dev, dtype=torch.float32).contiguous()
+        _, T, H, W = vid.shape
+        n_chunks = 1 + (T - 1) // 4
+        st = _Stream(dev)
+        enc = self.encoder
+        out = None
+        t_lat = 0
+        for i in range(n_chunks):
+            t0, tn = (0, 1) if i == 0 else (1 + 4 * (i - 1), 4)
+            c1 = st.conv("encoder.conv1", enc.conv1)
+            ops.nchw_to_cl(vid, tn, t0, c1.Cin, out=c1.slot(tn, H, W, dev))
+            h = c1.run()
+            h = _run_sequential(st, "encoder.downsamples", enc.downsamples, h)
+            h = _run_sequential(st, "encoder.middle", enc.middle, h)
+            h = _head(st, "encoder.head", enc.head, h, out_f32=False)          # [t, h, w, 2z]
+            mu = _conv_on(st, "conv1", self.conv1, h, out_f32=True)
+            if out is None:
+                out = torch.empty(self.z_dim, n_chunks, h.shape[1], h.shape[2], dtype=torch.float32, device=dev)
+            if isinstance(scale[0], torch.Tensor):
+                add = (-scale[0]).to(device=dev, dtype=torch.float32).contiguous()
+                mul = scale[1].to(device=dev, dtype=torch.float32).contiguous()
+            else:
+                add = torch.full((self.z_dim,), -float(scale[0]), device=dev)
+                mul = torch.full((self.z_dim,), float(scale[1]), device=dev)
+            ops.cl_to_nchw(mu, out, t_lat, self.z_dim, mul=mul, add=add)
+            t_lat += mu.shape[0]
+        return out[:, :t_lat].unsqueeze(0)
+
+    @torch.no_grad()
+    def decode(self, z, scale, clamp=None):
+        """z [1, z, T', h, w] -> video fp32 [1, 3, 4(T'-1)+1, 8h, 8w] (vae.py:544-568)."""
+        dev = self._device()
+        if dev.type != "cuda":
+            raise ops.OmhError("WanVAE runs on the MI355X only (no CPU fallback)")
+        assert z.dim() == 5 and z.shape[0] == 1
+        lat = z[0].to(device=dev, dtype=torch.float32).contiguous()
+        _, Tl, h, w = lat.shape
+        if isinstance(scale[0], torch.Tensor):
+            mul = (1.0 / scale[1]).to(device=dev, dtype=torch.float32).contiguous()
+            add = scale[0].to(device=dev, dtype=torch.float32).contiguous()
+        else:
+            mul = torch.full((self.z_dim,), 1.0 / float(scale[1]), device=dev)
+            add = torch.full((self.z_dim,), float(scale[0]), device=dev)
+        st = _Stream(dev)
+        dec = self.decoder
+        zcl = ops.nchw_to_cl(lat, Tl, 0, _round_up(self.z_dim, 8), mul=mul, add=add)       # z/scale1 + scale0
+        x_all = _conv_on(st, "conv2", self.conv2, zcl)                                     # [T', h, w, z]
+        T_out = 4 * (Tl - 1) + 1
+        out = torch.empty(3, T_out, 8 * h, 8 * w, dtype=torch.float32, device=dev)
+        lo, hi = (-3.0e38, 3.0e38) if clamp is None else clamp
+        t_pix = 0
+        for i in range(Tl):
+            c1 = st.conv("decoder.conv1", dec.conv1)
+            c1.slot(1, h, w, dev).copy_(x_all[i:i + 1])
+            y = c1.run()
+            y = _run_sequential(st, "decoder.middle", dec.middle, y)
+            y = _run_sequential(st, "decoder.upsamples", dec.upsamples, y)
+            y = _head(st, "decoder.head", dec.head, y, out_f32=True)            # fp32 [t, 8h, 8w, 3]
+            ops.cl_to_nchw(y, out, t_pix, 3, lo=lo, hi=hi)
+            t_pix += y.shape[0]
+        assert t_pix == T_out
+        return out.unsqueeze(0)
+
+    def clear_cache(self):
+        """The reference resets its per-call feature caches here (vae.py:582-589); this build keeps
+        them in a per-call stream object, so there is nothing to clear.  Kept for API parity."""
+        self._conv_num = count_conv3d(self.decoder)
+        self._enc_conv_num = count_conv3d(self.encoder)
+
+
+def _video_vae(pretrained_path=None, z_dim=None, device="cpu", **kwargs):
+    """vae.py:592-616.  ``pretrained_path=None`` keeps the random initialisation (synthetic benchmarks)."""
+    cfg = dict(dim=96, z_dim=z_dim, dim_mult=[1, 2, 4, 4], num_res_blocks=2, attn_scales=[],
+               temperal_downsample=[False, True, True], dropout=0.0)
+    cfg.update(**kwargs)
+    if pretrained_path is None:
+        return WanVAE_(**cfg)
+    with torch.device("meta"):
+        model = WanVAE_(**cfg)
+    logging.info(f"loading {pretrained_path}")
+    model.load_state_dict(torch.load(pretrained_path, map_location=device), assign=True)
+    return model
+
 
 class WanVAE:
-    def __init__(self, z_dim=16, vae_pth=None, dtype=torch.float, device="cuda"):
-        raise NotImplementedError("WanVAE on gfx950: not built yet in this commit")
+    """vae.py:619-663."""
+
+    def __init__(self, z_dim=16, vae_pth="cache/vae_step_411000.pth", dtype=torch.float, device="cuda", **cfg):
+        self.dtype = dtype
+        self.device = device
+        mean = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508,
+                0.4134, -0.0715, 0.5517, -0.3632, -0.1922, -0.9497, 0.2503, -0.2921]
+        std = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743,
+               3.2687, 2.1526, 2.8652, 1.5579, 1.6382, 1.1253, 2.8251, 1.9160]
+        self.mean = torch.tensor(mean, dtype=dtype, device=device)
+        self.std = torch.tensor(std, dtype=dtype, device=device)
+        self.scale = [self.mean, 1.0 / self.std]
+        self.model = _video_vae(pretrained_path=vae_pth, z_dim=z_dim, **cfg).eval().requires_grad_(False).to(device)
+
+    def encode(self, videos):
+        """videos: list of [3, T, H, W] -> list of fp32 [z, (T-1)/4+1, H/8, W/8]."""
+        return [self.model.encode(u.unsqueeze(0), self.scale).float().squeeze(0) for u in videos]
+
+    def decode(self, zs):
+        """zs: list of [z, T', h, w] -> list of fp32 [3, 4(T'-1)+1, 8h, 8w] clamped to [-1, 1]."""
+        return [self.model.decode(u.unsqueeze(0), self.scale, clamp=(-1.0, 1.0)).float().squeeze(0) for u in zs]
+
+
+def bench_decode(latent, device, iters=1):
+    """bench.py hook: frames/s of decoding one [16, T', 60, 104] latent with a random-init VAE."""
+    import time
+    vae = WanVAE(vae_pth=None, device=device)
+    z = latent.detach().float()
+    z = (z - z.mean()) / z.std().clamp_min(1e-6)
+    vae.decode([z[:, :2]])                     # warm-up: two chunks (first + steady state)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        out = vae.decode([z])[0]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    frames = out.shape[1]
+    flops = (4.29 + (z.shape[1] - 1) * 13.49) * 1e12 * (z.shape[2] * z.shape[3]) / (60 * 104)
+    return {"frames_per_s": round(frames / dt, 2), "decode_s": round(dt, 3), "frames": int(frames),
+            "conv_tflops": round(flops / dt / 1e12, 1), "mfma_roofline_frac": round(flops / dt / 2.5e15, 4),
+            "finite": bool(torch.isfinite(out).all()), "weights": "random-init"}

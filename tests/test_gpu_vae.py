@@ -1,0 +1,125 @@
+"""Parity of the HIP 3D causal VAE (conv kernel + streaming executor) against
+the CPU oracle (oracle/wan_vae_oracle.py, pinned to the reference by tests/golden)."""
+import importlib
+
+import pytest
+import torch
+
+from conftest import rel_rms
+
+pytestmark = pytest.mark.gpu
+
+# The reference runs the VAE in fp32; this build stores activations in bf16 and
+# multiplies in bf16 MFMA with fp32 accumulation.  Through the ~35 conv layers of
+# the decoder the relative RMS error of the output video stays below:
+TOL_VAE = 3.0e-2
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(Cin=16, Cout=40, T=3, H=9, W=7, KT=3, KH=3, KW=3),
+    dict(Cin=96, Cout=96, T=2, H=12, W=20, KT=3, KH=3, KW=3),
+    dict(Cin=24, Cout=48, T=4, H=6, W=6, KT=3, KH=1, KW=1),
+    dict(Cin=32, Cout=136, T=2, H=5, W=5, KT=1, KH=1, KW=1),
+    dict(Cin=8, Cout=3, T=1, H=16, W=16, KT=3, KH=3, KW=3),
+])
+def test_conv_cl_matches_torch(ops, cfg):
+    torch.manual_seed(cfg["Cin"] + cfg["Cout"])
+    Cin, Cout, T, H, W, KT, KH, KW = (cfg[k] for k in ("Cin", "Cout", "T", "H", "W", "KT", "KH", "KW"))
+    hist = KT - 1
+    x = _bf(torch.randn(hist + T, H, W, Cin, device="cuda"))
+    w = _bf(torch.randn(Cout, Cin, KT, KH, KW, device="cuda") / (Cin * KT * KH * KW) ** 0.5)
+    bias = torch.randn(Cout, device="cuda")
+    resid = _bf(torch.randn(T, H, W, Cout, device="cuda"))
+    wp = w.permute(0, 2, 3, 4, 1).contiguous().view(Cout, -1)
+    y = ops.conv_cl(x, wp, bias, T, H, W, Cout, KT, KH, KW, pad_h=KH // 2, pad_w=KW // 2, resid=resid, out_f32=True)
+    xin = x.float().permute(3, 0, 1, 2)[None]                              # [1, C, T, H, W]
+    ref = torch.nn.functional.conv3d(torch.nn.functional.pad(xin, (KW // 2, KW // 2, KH // 2, KH // 2)), w.float(), bias)
+    ref = ref[0].permute(1, 2, 3, 0) + resid.float()
+    assert y.shape == ref.shape
+    assert rel_rms(y, ref) < 2e-5
+
+
+def test_conv_cl_upsample_downsample_stride_split(ops):
+    torch.manual_seed(9)
+    C, H, W = 32, 6, 10
+    x = _bf(torch.randn(2, H, W, C, device="cuda"))
+    # nearest-2x upsample folded into a 3x3 conv (vae.py:76-79)
+    w = _bf(torch.randn(16, C, 3, 3, device="cuda") / (9 * C) ** 0.5)
+    wp = w.permute(0, 2, 3, 1).contiguous().view(16, -1)
+    y = ops.conv_cl(x, wp, None, 2, 2 * H, 2 * W, 16, 1, 3, 3, pad_h=1, pad_w=1, up2=True, out_f32=True)
+    xi = x.float().permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.interpolate(xi, scale_factor=2.0, mode="nearest-exact"), w.float(),
+                                     padding=1).permute(0, 2, 3, 1)
+    assert rel_rms(y, ref) < 2e-5
+    # ZeroPad2d((0,1,0,1)) + stride-2 conv (vae.py:88-90)
+    w2 = _bf(torch.randn(C, C, 3, 3, device="cuda") / (9 * C) ** 0.5)
+    y2 = ops.conv_cl(x, w2.permute(0, 2, 3, 1).contiguous().view(C, -1), None, 2, H // 2, W // 2, C, 1, 3, 3,
+                     stride_hw=2, out_f32=True)
+    ref2 = torch.nn.functional.conv2d(torch.nn.functional.pad(xi, (0, 1, 0, 1)), w2.float(), stride=2).permute(0, 2, 3, 1)
+    assert rel_rms(y2, ref2) < 2e-5
+    # temporal stride-2 conv over [history(1) | 4 frames] (vae.py:95-96,156-157)
+    x5 = _bf(torch.randn(5, H, W, C, device="cuda"))
+    w3 = _bf(torch.randn(C, C, 3, 1, 1, device="cuda") / (3 * C) ** 0.5)
+    y3 = ops.conv_cl(x5, w3.permute(0, 2, 3, 4, 1).contiguous().view(C, -1), None, 2, H, W, C, 3, 1, 1, stride_t=2,
+                     out_f32=True)
+    ref3 = torch.nn.functional.conv3d(x5.float().permute(3, 0, 1, 2)[None], w3.float(), stride=(2, 1, 1))[0].permute(1, 2, 3, 0)
+    assert rel_rms(y3, ref3) < 2e-5
+    # channel -> frame interleave of the temporal upsample (vae.py:134-137)
+    x4 = _bf(torch.randn(2 + 2, H, W, C, device="cuda"))
+    w4 = _bf(torch.randn(2 * C, C, 3, 1, 1, device="cuda") / (3 * C) ** 0.5)
+    y4 = ops.conv_cl(x4, w4.permute(0, 2, 3, 4, 1).contiguous().view(2 * C, -1), None, 2, H, W, 2 * C, 3, 1, 1,
+                     split_n=C, out_f32=True)
+    r = torch.nn.functional.conv3d(x4.float().permute(3, 0, 1, 2)[None], w4.float())        # [1, 2C, 2, H, W]
+    r = r.reshape(1, 2, C, 2, H, W)
+    r = torch.stack((r[:, 0], r[:, 1]), 3).reshape(1, C, 4, H, W)[0].permute(1, 2, 3, 0)
+    assert y4.shape == (4, H, W, C)
+    assert rel_rms(y4, r) < 2e-5
+
+
+def test_rms_silu_softmax_layout(ops):
+    torch.manual_seed(11)
+    for C in (96, 192, 384, 16):
+        x = _bf(torch.randn(77, C, device="cuda") * 2)
+        g = torch.rand(C, device="cuda") + 0.5
+        ref = torch.nn.functional.silu(torch.nn.functional.normalize(x.float(), dim=1) * C ** 0.5 * g)
+        assert rel_rms(ops.rms_silu_cl(x, g).float(), ref) < 4e-3
+    s = torch.randn(50, 333, device="cuda") * 3
+    p = torch.zeros(50, 336, dtype=torch.bfloat16, device="cuda")
+    ops.softmax_rows(s, p, 333, 0.7)
+    assert rel_rms(p[:, :333].float(), torch.softmax(s * 0.7, -1)) < 4e-3
+    assert float(p[:, 333:].abs().max()) == 0
+    v = torch.randn(5, 7, 4, 6, device="cuda")
+    mul, add = torch.rand(5, device="cuda") + 0.5, torch.randn(5, device="cuda")
+    cl = ops.nchw_to_cl(v, 3, 2, 8, mul=mul, add=add)
+    ref = (v[:, 2:5] * mul[:, None, None, None] + add[:, None, None, None]).permute(1, 2, 3, 0)
+    assert rel_rms(cl[..., :5].float(), ref) < 4e-3 and float(cl[..., 5:].abs().max()) == 0
+    out = torch.zeros(5, 7, 4, 6, device="cuda")
+    src = torch.randn(3, 4, 6, 8, device="cuda")
+    ops.cl_to_nchw(src, out, 2, 5, mul=mul, add=add, lo=-1.0, hi=1.0)
+    ref2 = ((src[..., :5] + add) * mul).clamp(-1, 1).permute(3, 0, 1, 2)
+    assert torch.allclose(out[:, 2:5], ref2, atol=1e-6) and float(out[:, :2].abs().max()) == 0
+
+
+@pytest.mark.parametrize("dim", [32, 96])
+def test_vae_decode_encode_match_oracle(dim):
+    from oracle import wan_vae_oracle as V, detgen
+    vae_mod = importlib.import_module("omnihuman-1-hack_amd.wan.modules.vae")
+    cfg = V.VAEConfig(dim=dim)
+    sd = V.synth_state_dict(cfg, f"vae{dim}")
+    vae = vae_mod.WanVAE(vae_pth=None, device="cuda", dim=dim)
+    vae.model.load_state_dict(sd)
+    z = torch.from_numpy(detgen.normalish("vae/z", (16, 3, 8, 8)))
+    ref = V.vae_decode(sd, cfg, z)
+    out = vae.decode([z.cuda()])[0]
+    assert out.shape == ref.shape == (3, 9, 64, 64) and out.dtype == torch.float32
+    assert float(out.abs().max()) <= 1.0
+    assert rel_rms(out, ref) < TOL_VAE
+    vid = torch.from_numpy(detgen.uniform("vae/vid", (3, 9, 32, 32)))
+    refe = V.vae_encode(sd, cfg, vid)
+    oute = vae.encode([vid.cuda()])[0]
+    assert oute.shape == refe.shape == (16, 3, 4, 4)
+    assert rel_rms(oute, refe) < TOL_VAE
