@@ -1,6 +1,113 @@
-"""WanT2V pipeline surface (seaweed_apt/wan/text2video.py) — filled in after the DiT path."""
+"""``WanT2V`` — the text-to-video pipeline surface of the reference
+(seaweed_apt/wan/text2video.py:26-269) on the gfx950 DiT / VAE / sampler.
+
+Same constructor arguments, attributes (``model, vae, text_encoder, vae_stride,
+patch_size, num_train_timesteps, sample_neg_prompt, device, param_dtype``) and
+``generate(...)`` signature.  The umT5 text encoder is outside this path
+(a one-off per prompt whose output is an *input* here):
+a ``text_encoder`` callable ``(list[str], device) -> list[Tensor[L, 4096]]`` can
+be plugged in, or pre-computed contexts passed to ``generate``.
+
+What changes under the hood (text2video.py:231-259): the two CFG forwards run
+on the HIP DiT, the CFG combine + UniPC update is one fused kernel
+(``FlowUniPCMultistepScheduler.step_cfg``), nothing is offloaded to the CPU
+(the 1.3B/14B models fit one 288 GB MI355X), and the final latent goes through
+the HIP VAE decoder.  FSDP / USP options of the reference are not built
+(replicas only) and raise.
+"""
+import logging
+import math
+import os
+import random
+import sys
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .modules.model import WanModel
+from .modules.vae import WanVAE
+from .utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
 
 
 class WanT2V:
-    def __init__(self, *a, **k):
-        raise NotImplementedError("WanT2V: not built yet in this commit")
+
+    def __init__(self, config, checkpoint_dir, device_id=0, rank=0, t5_fsdp=False, dit_fsdp=False, use_usp=False,
+                 t5_cpu=False, disable_load_t5=False, text_encoder=None, model=None, vae=None):
+        if t5_fsdp or dit_fsdp or use_usp:
+            raise NotImplementedError("FSDP / USP sequence parallel are not part of this build: the DiT and VAE "
+                                      "fit one MI355X, multi-GPU inference shards by clip (replicas)")
+        self.device = torch.device(f"cuda:{device_id}")
+        self.config = config
+        self.rank = rank
+        self.t5_cpu = t5_cpu
+        self.num_train_timesteps = config.num_train_timesteps
+        self.param_dtype = config.param_dtype
+        self.text_encoder = text_encoder          # out of scope here; see module docstring
+        self.vae_stride = config.vae_stride
+        self.patch_size = config.patch_size
+        if vae is None:
+            vae = WanVAE(vae_pth=os.path.join(checkpoint_dir, config.vae_checkpoint), device=self.device)
+        self.vae = vae
+        if model is None:
+            logging.info(f"Creating WanModel from {checkpoint_dir}")
+            model = WanModel.from_pretrained(checkpoint_dir)
+        self.model = model
+        self.model.eval().requires_grad_(False)
+        self.sp_size = 1
+        if dist.is_initialized():
+            dist.barrier()
+        self.model.to(self.device)
+        self.sample_neg_prompt = config.sample_neg_prompt
+
+    def _encode(self, prompts: List[str]):
+        if self.text_encoder is None:
+            raise RuntimeError("no text encoder attached: pass context=/context_null= to generate(), or construct "
+                               "WanT2V(text_encoder=callable)")
+        return [t.to(self.device) for t in self.text_encoder(prompts, self.device)]
+
+    def generate(self, input_prompt, size=(720, 512), frame_num=81, shift=5.0, sample_solver="unipc",
+                 sampling_steps=50, guide_scale=5.0, n_prompt="", seed=-1, offload_model=True,
+                 context: Optional[List[torch.Tensor]] = None, context_null: Optional[List[torch.Tensor]] = None,
+                 return_latent: bool = False):
+        r"""text2video.py:112-269.  Returns the video ``[3, N, H, W]`` on rank 0 (else None)."""
+        F = frame_num
+        target_shape = (self.vae.model.z_dim, (F - 1) // self.vae_stride[0] + 1, size[1] // self.vae_stride[1],
+                        size[0] // self.vae_stride[2])
+        seq_len = math.ceil((target_shape[2] * target_shape[3]) / (self.patch_size[1] * self.patch_size[2]) *
+                            target_shape[1] / self.sp_size) * self.sp_size
+        if n_prompt == "":
+            n_prompt = self.sample_neg_prompt
+        seed = seed if seed >= 0 else random.randint(0, sys.maxsize)
+        seed_g = torch.Generator(device=self.device)
+        seed_g.manual_seed(seed)
+        if context is None:
+            context = self._encode([input_prompt])
+        if context_null is None:
+            context_null = self._encode([n_prompt])
+        context = [t.to(self.device) for t in context]
+        context_null = [t.to(self.device) for t in context_null]
+        noise = [torch.randn(*target_shape, dtype=torch.float32, device=self.device, generator=seed_g)]
+
+        if sample_solver != "unipc":
+            raise NotImplementedError("Unsupported solver: only 'unipc' (the reference default) is built")
+        with torch.no_grad():
+            sample_scheduler = FlowUniPCMultistepScheduler(num_train_timesteps=self.num_train_timesteps, shift=1,
+                                                           use_dynamic_shifting=False)
+            sample_scheduler.set_timesteps(sampling_steps, device=self.device, shift=shift)
+            sample_scheduler.set_begin_index(0)
+            timesteps = sample_scheduler.timesteps
+            latents = noise
+            for t in timesteps:
+                timestep = torch.stack([t])
+                cond = self.model(latents, t=timestep, context=context, seq_len=seq_len)[0]
+                uncond = self.model(latents, t=timestep, context=context_null, seq_len=seq_len)[0]
+                # noise_pred = uncond + g (cond - uncond); latents = scheduler.step(noise_pred, t, latents)
+                latents = [sample_scheduler.step_cfg(cond, uncond, guide_scale, latents[0])]
+            x0 = latents
+            videos = None
+            if self.rank == 0:
+                videos = x0 if return_latent else self.vae.decode(x0)
+        if dist.is_initialized():
+            dist.barrier()
+        return videos[0] if self.rank == 0 else None

@@ -1,0 +1,141 @@
+"""Generates the golden vectors under tests/golden/ by running the REAL
+reference (imported in place from /root/reference with the shims of
+oracle/ref_import.py) on deterministic detgen inputs.  TEST INFRASTRUCTURE.
+
+    python -m oracle.make_golden            # from the repo root, build container only
+
+Only inputs that detgen cannot regenerate and the reference's OUTPUTS are
+stored (small .npz files); weights and inputs are regenerated from their names
+by the tests.  The reference's source never leaves /root/reference.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import detgen, ref_import, sampler_oracle as SO, wan_dit_oracle as O, wan_vae_oracle as V  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+TINY = dict(dim=256, ffn_dim=512, num_heads=2, text_dim=64, text_len=32, freq_dim=64)
+
+
+def tiny_case(model_type, layers):
+    """Inputs of the tiny DiT cases (shared with tests/test_oracle_golden.py)."""
+    cfg = O.DiTConfig(model_type=model_type, in_dim=16 if model_type == "t2v" else 36, num_layers=layers, **TINY)
+    tag = f"golden/{model_type}{layers}"
+    xs = [torch.from_numpy(detgen.normalish(f"{tag}/x0", (16, 2, 6, 8))),
+          torch.from_numpy(detgen.normalish(f"{tag}/x1", (16, 1, 4, 6)))]
+    ctx = [torch.from_numpy(detgen.normalish(f"{tag}/c0", (32, 64))),
+           torch.from_numpy(detgen.normalish(f"{tag}/c1", (11, 64)))]
+    ys = clip = None
+    if model_type == "i2v":
+        ys = [torch.from_numpy(detgen.normalish(f"{tag}/y0", (20, 2, 6, 8))),
+              torch.from_numpy(detgen.normalish(f"{tag}/y1", (20, 1, 4, 6)))]
+        clip = torch.from_numpy(detgen.normalish(f"{tag}/clip", (2, 257, 1280)))
+    return cfg, tag, xs, ctx, torch.tensor([999., 500.]), 30, ys, clip
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_grad_enabled(False)
+    model_mod, vae_mod = ref_import.load_reference()
+
+    # ---- per-op fixtures
+    ops = {}
+    t = torch.tensor([0., 1., 999., 1000.])
+    ops["sinusoid"] = model_mod.sinusoidal_embedding_1d(256, t).float().numpy()
+    d = 128
+    freqs = torch.cat([model_mod.rope_params(1024, d - 4 * (d // 6)), model_mod.rope_params(1024, 2 * (d // 6)),
+                       model_mod.rope_params(1024, 2 * (d // 6))], dim=1)
+    xq = torch.from_numpy(detgen.normalish("golden/rope/x", (2, 30, 2, 128)))
+    ops["rope"] = model_mod.rope_apply(xq, torch.tensor([[2, 3, 4], [1, 5, 6]]), freqs).numpy()
+    rn = model_mod.WanRMSNorm(256, eps=1e-6)
+    rn.weight.data = torch.from_numpy(1.0 + detgen.uniform("golden/rms/w", (256,), -0.2, 0.2))
+    xr = torch.from_numpy(detgen.normalish("golden/rms/x", (3, 7, 256)))
+    ops["rmsnorm"] = rn(xr).numpy()
+    ln = model_mod.WanLayerNorm(256, eps=1e-6)
+    ops["layernorm"] = ln(xr * 3 + 0.5).numpy()
+    np.savez_compressed(os.path.join(OUT, "dit_ops.npz"), **ops)
+
+    # ---- tiny DiT models: t2v L=2, L=13 (crosses the block_idx>10 branch), i2v L=2
+    for mt, layers in (("t2v", 2), ("t2v", 13), ("i2v", 2)):
+        cfg, tag, xs, ctx, tt, seq_len, ys, clip = tiny_case(mt, layers)
+        sd = O.synth_state_dict(cfg, tag)
+        ref = ref_import.build_reference_dit(cfg, sd)
+        out = ref(xs, tt, ctx, seq_len, clip_fea=clip, y=ys)
+        np.savez_compressed(os.path.join(OUT, f"dit_{mt}_L{layers}.npz"), out0=out[0].numpy(), out1=out[1].numpy())
+        print("dit", mt, layers, float(out[0].abs().mean()))
+
+    # ---- trainer step (distilled_trainer.py:241-316 semantics) on the tiny t2v L=13 model:
+    #      loss = mse(v_student[0], v_teacher) (sample 0 only, broadcast) and selected gradients
+    cfg, tag, xs, ctx, tt, seq_len, _, _ = tiny_case("t2v", 13)
+    sd = O.synth_state_dict(cfg, tag)
+    ref = ref_import.build_reference_dit(cfg, sd)
+    ref.requires_grad_(True)
+    with torch.enable_grad():
+        noise = torch.stack([xs[0], torch.from_numpy(detgen.normalish(f"{tag}/x0b", (16, 2, 6, 8)))])
+        v_teacher = torch.from_numpy(detgen.normalish(f"{tag}/vt", (2, 16, 2, 6, 8)))
+        cl = [ctx[0], torch.from_numpy(detgen.normalish(f"{tag}/c0b", (32, 64)))]
+        out = ref(noise, torch.ones(2) * 1000.0, cl, 24)
+        loss = torch.nn.functional.mse_loss(out[0], v_teacher)
+        loss.backward()
+    grads = {"loss": np.float32(loss.item())}
+    for name in ("blocks.0.self_attn.q.weight", "blocks.0.self_attn.norm_k.weight", "blocks.10.ffn.0.weight",
+                 "blocks.12.cross_attn.v.bias", "blocks.5.modulation", "patch_embedding.weight",
+                 "head.head.weight", "time_projection.1.bias", "text_embedding.0.weight", "blocks.3.norm3.weight"):
+        g = dict(ref.named_parameters())[name].grad
+        grads[name] = g.numpy()
+    grads["ffn_grad_none_from"] = np.int32(min(i for i in range(13) if ref.blocks[i].ffn[0].weight.grad is None))
+    np.savez_compressed(os.path.join(OUT, "dit_train_t2v_L13.npz"), **grads)
+    print("train loss", loss.item(), "first block without FFN grad:", grads["ffn_grad_none_from"])
+
+    # ---- VAE: whole-model decode / encode at dim=16 and dim=96, plus a causal-conv-with-cache case
+    mean, std = torch.tensor(V.LATENT_MEAN), torch.tensor(V.LATENT_STD)
+    scale = [mean, 1.0 / std]
+    z = torch.from_numpy(detgen.normalish("golden/vae/z", (16, 3, 8, 8)))
+    vid = torch.from_numpy(detgen.uniform("golden/vae/vid", (3, 9, 32, 32)))
+    for dim in (16, 96):
+        cfgv = V.VAEConfig(dim=dim)
+        sdv = V.synth_state_dict(cfgv, f"golden/vae{dim}")
+        ref = ref_import.build_reference_vae(sdv, dim=dim)
+        dec = ref.decode(z.unsqueeze(0), scale).float().clamp_(-1, 1).squeeze(0)
+        enc = ref.encode(vid.unsqueeze(0), scale).float().squeeze(0)
+        np.savez_compressed(os.path.join(OUT, f"vae_dim{dim}.npz"), decode=dec.numpy().astype(np.float16)
+                            if dim == 96 else dec.numpy(), encode=enc.numpy())
+        print("vae", dim, float(dec.abs().mean()), float(enc.abs().mean()))
+
+    # ---- UniPC scheduler: trajectory of 6 steps, shift 3.0
+    Ref = ref_import.load_reference_unipc()
+    r = Ref(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+    r.set_timesteps(6, device="cpu", shift=3.0)
+    x = torch.from_numpy(detgen.normalish("golden/unipc/x", (1, 16, 2, 6, 8)))
+    traj = []
+    for k, tstep in enumerate(r.timesteps):
+        v = torch.from_numpy(detgen.normalish(f"golden/unipc/v{k}", (1, 16, 2, 6, 8)))
+        x = r.step(v, tstep, x, return_dict=False)[0]
+        traj.append(x.numpy())
+    np.savez_compressed(os.path.join(OUT, "unipc_6steps.npz"), traj=np.stack(traj), sigmas=r.sigmas.numpy(),
+                        timesteps=r.timesteps.numpy())
+
+    # ---- full-size Wan2.1-T2V-1.3B forward (config 1): checksums + 64 probe elements
+    if os.environ.get("OMH_GOLDEN_FULL", "1") == "1":
+        cfg = O.DiTConfig.wan_t2v_1_3b()
+        sd = O.synth_state_dict(cfg, "wan1.3b")
+        ref = ref_import.build_reference_dit(cfg, sd)
+        noise = torch.from_numpy(detgen.normalish("c1/noise", (16, 1, 60, 104)))
+        cneg = torch.from_numpy(detgen.normalish("c1/neg", (37, 4096)))
+        out = ref([noise], torch.tensor([999.]), [cneg], 1560)[0]
+        idx = (np.arange(64) * 1559 + 7) % out.numel()
+        np.savez_compressed(os.path.join(OUT, "dit_wan1_3b_c1.npz"), probe_idx=idx,
+                            probe=out.flatten()[idx].numpy(), mean=np.float64(out.double().mean()),
+                            abs_mean=np.float64(out.double().abs().mean()),
+                            coarse=out[:, 0, ::6, ::8].numpy())
+        print("1.3B", float(out.abs().mean()))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,103 @@
+"""CPU: the oracle (oracle/*.py) against the golden vectors produced by the REAL
+reference (oracle/make_golden.py), and against the live reference when
+/root/reference is present (build container only)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_rms
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _g(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def test_dit_ops_match_reference_vectors():
+    from oracle import detgen, wan_dit_oracle as O
+    g = _g("dit_ops.npz")
+    t = torch.tensor([0., 1., 999., 1000.])
+    assert np.abs(O.sinusoidal_embedding_1d(256, t).float().numpy() - g["sinusoid"]).max() < 1e-6
+    xq = torch.from_numpy(detgen.normalish("golden/rope/x", (2, 30, 2, 128)))
+    rope = O.rope_apply(xq, [(2, 3, 4), (1, 5, 6)], O.rope_table(128))
+    assert np.abs(rope.numpy() - g["rope"]).max() < 1e-6
+    w = torch.from_numpy(1.0 + detgen.uniform("golden/rms/w", (256,), -0.2, 0.2))
+    xr = torch.from_numpy(detgen.normalish("golden/rms/x", (3, 7, 256)))
+    assert np.abs(O.rms_norm(xr, w, 1e-6).numpy() - g["rmsnorm"]).max() < 1e-5
+    assert np.abs(O.layer_norm(xr * 3 + 0.5, 1e-6).numpy() - g["layernorm"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("mt,layers", [("t2v", 2), ("t2v", 13), ("i2v", 2)])
+def test_dit_forward_matches_reference_vectors(mt, layers):
+    from oracle import make_golden, wan_dit_oracle as O
+    cfg, tag, xs, ctx, tt, seq_len, ys, clip = make_golden.tiny_case(mt, layers)
+    sd = O.synth_state_dict(cfg, tag)
+    out = O.dit_forward(sd, cfg, xs, tt, ctx, seq_len, clip_fea=clip, y=ys)
+    g = _g(f"dit_{mt}_L{layers}.npz")
+    for o, k in zip(out, ("out0", "out1")):
+        assert o.shape == g[k].shape
+        assert np.abs(o.numpy() - g[k]).max() < 2e-5          # fp32 vs fp32, summation order only
+
+
+def test_vae_matches_reference_vectors():
+    from oracle import detgen, wan_vae_oracle as V
+    z = torch.from_numpy(detgen.normalish("golden/vae/z", (16, 3, 8, 8)))
+    vid = torch.from_numpy(detgen.uniform("golden/vae/vid", (3, 9, 32, 32)))
+    for dim, tol in ((16, 2e-5), (96, 1e-3)):               # dim 96 decode is stored as fp16
+        cfg = V.VAEConfig(dim=dim)
+        sd = V.synth_state_dict(cfg, f"golden/vae{dim}")
+        g = _g(f"vae_dim{dim}.npz")
+        dec = V.vae_decode(sd, cfg, z)
+        assert dec.shape == (3, 9, 64, 64)
+        assert np.abs(dec.numpy() - g["decode"].astype(np.float32)).max() < tol
+        enc = V.vae_encode(sd, cfg, vid)
+        assert np.abs(enc.numpy() - g["encode"]).max() < 2e-5
+
+
+def test_unipc_matches_reference_vectors():
+    from oracle import detgen, sampler_oracle as SO
+    g = _g("unipc_6steps.npz")
+    o = SO.UniPCOracle(6, 3.0)
+    assert np.array_equal(o.sigmas.numpy(), g["sigmas"]) and np.array_equal(o.timesteps.numpy(), g["timesteps"])
+    x = torch.from_numpy(detgen.normalish("golden/unipc/x", (1, 16, 2, 6, 8)))
+    for k in range(6):
+        v = torch.from_numpy(detgen.normalish(f"golden/unipc/v{k}", (1, 16, 2, 6, 8)))
+        x = o.step(v, x)
+        assert np.abs(x.numpy() - g["traj"][k]).max() < 1e-6
+    # closed forms: x0 = x - sigma v ; last step lands exactly on the x0 prediction
+    o1 = SO.UniPCOracle(1, 5.0)
+    x = torch.from_numpy(detgen.normalish("golden/unipc/x", (1, 16, 2, 6, 8)))
+    v = torch.from_numpy(detgen.normalish("golden/unipc/v0", (1, 16, 2, 6, 8)))
+    assert torch.allclose(o1.step(v, x), x - o1.sigmas[0] * v, atol=1e-6)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/seaweed_apt"), reason="reference tree not present")
+def test_oracle_against_live_reference():
+    from oracle import detgen, ref_import, wan_dit_oracle as O, wan_vae_oracle as V
+    cfg = O.DiTConfig(dim=128, ffn_dim=256, num_heads=1, num_layers=3, text_dim=32, text_len=16, freq_dim=32)
+    sd = O.synth_state_dict(cfg, "live")
+    ref = ref_import.build_reference_dit(cfg, sd)
+    xs = [torch.from_numpy(detgen.normalish("live/x", (16, 1, 4, 4)))]
+    ctx = [torch.from_numpy(detgen.normalish("live/c", (5, 32)))]
+    with torch.no_grad():
+        r = ref(xs, torch.tensor([7.]), ctx, 6)[0]
+    assert rel_rms(O.dit_forward(sd, cfg, xs, torch.tensor([7.]), ctx, 6)[0], r) < 1e-5
+    cfgv = V.VAEConfig(dim=16)
+    sdv = V.synth_state_dict(cfgv, "live/vae")
+    refv = ref_import.build_reference_vae(sdv, dim=16)
+    z = torch.from_numpy(detgen.normalish("live/z", (16, 2, 4, 4)))
+    scale = [torch.tensor(V.LATENT_MEAN), 1.0 / torch.tensor(V.LATENT_STD)]
+    assert rel_rms(V.vae_decode(sdv, cfgv, z), refv.decode(z[None], scale).clamp(-1, 1)[0]) < 1e-5
+
+
+def test_detgen_is_stable():
+    """The generator must give the same bits everywhere (weights are never shipped)."""
+    from oracle import detgen
+    a = detgen.uniform("stability", (5,))
+    assert a.dtype == np.float32
+    assert [float(v) for v in a] == [float(v) for v in detgen.uniform("stability", (5,))]
+    assert abs(float(detgen.normalish("stability", (100000,)).std()) - 1.0) < 0.02
+    assert float(np.abs(a).max()) < 1.0
