@@ -227,6 +227,52 @@ int omh_cl_to_nchw(const float* x, float* y, int32_t C, int32_t T, int32_t H, in
 int omh_softmax_rows(const float* x, int64_t ldx, void* y_bf16, int64_t ldy, int64_t R, int32_t L, float scale,
                      omh_stream_t stream);
 
+/* ========================================================================
+ * Backward pass of the DiT (training step, seaweed_apt/distilled_trainer.py:
+ * 241-316; the reference obtains it from autograd over aten).  Matrix products
+ * (dgrad / wgrad / attention dQ,dK,dV) reuse omh_gemm_bf16 on transposed
+ * operands; gradients of parameters and modulation vectors are ACCUMULATED
+ * (fp32 atomics) into caller-zeroed buffers.
+ * ====================================================================== */
+
+/* out[b][c][r] = in[b][r][c], bf16; ld_out >= R (pad columns untouched). */
+int omh_transpose_bf16(const void* in, void* out, int32_t R, int32_t C, int64_t ld_in, int64_t ld_out,
+                       int32_t batch, int64_t bs_in, int64_t bs_out, omh_stream_t stream);
+/* out[c] += sum_r x[r][c]  (x bf16 or fp32) — bias gradients. */
+int omh_colsum_accum(const void* x, int32_t is_bf16, int64_t ld, float* out, int64_t R, int32_t C, omh_stream_t stream);
+/* GELU-tanh on bf16 (model.py:273) and its backward dx = dy * gelu'(x_pre). */
+int omh_gelu_tanh_bf16(const void* x, void* y, int64_t n, omh_stream_t stream);
+int omh_gelu_tanh_bwd_bf16(const void* dy, const void* x_pre, void* dx, int64_t n, omh_stream_t stream);
+/* Gated residual (model.py:296,328): xo = xi + y*gate; gate = gate_const + gate0[c] + gate1[b*stride + c].
+ * bwd: dy = bf16(dx*gate); dgate[b*dgate_stride + c] += sum_rows dx*y (skipped when y or dgate is NULL). */
+int omh_gated_residual_fwd(const float* xi, const void* y_bf16, float* xo, int64_t rows, int32_t dim,
+                           float gate_const, const float* gate0, const float* gate1, int64_t gate1_stride,
+                           int64_t rows_per_batch, omh_stream_t stream);
+int omh_gated_residual_bwd(const float* dx, const void* y_bf16, void* dy_bf16, float* dgate, int64_t dgate_stride,
+                           int64_t rows, int32_t dim, float gate_const, const float* gate0, const float* gate1,
+                           int64_t gate1_stride, int64_t rows_per_batch, omh_stream_t stream);
+/* Backward of omh_layernorm_modulate: dx_accum += dL/dx; dmul[b*dstride+c] += dy*xhat; dadd[..] += dy. */
+int omh_layernorm_modulate_bwd(const float* x, const float* dy, float* dx_accum, int64_t rows, int32_t dim,
+                               float eps, float mul_const, const float* mul0, const float* mul1, int64_t mul1_stride,
+                               float* dmul, float* dadd, int64_t dstride, int64_t rows_per_batch, omh_stream_t stream);
+/* Backward of omh_rmsnorm_rope: dy fp32 [rows, dim] (grad of the rotated, normalised output) ->
+ * dx bf16 [rows, lddx]; dweight[c] += ... (may be NULL). */
+int omh_rmsnorm_rope_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, void* dx_bf16, int64_t lddx,
+                         float* dweight, int64_t rows, int32_t dim, const float* weight, float eps, int32_t do_norm,
+                         const float* rope_cos, const float* rope_sin, int32_t rope_len, int32_t head_dim,
+                         const int32_t* grid, int32_t seq_len, omh_stream_t stream);
+/* dS = P * (dP - sum_j P*dP) * scale per row (softmax backward of the unfused attention backward). */
+int omh_softmax_bwd_rows(const void* p_bf16, int64_t ldp, const float* dp, int64_t lddp, void* ds_bf16, int64_t ldds,
+                         int64_t R, int32_t L, float scale, omh_stream_t stream);
+/* Adjoint of omh_unpatchify: g fp32 [Cout, f*pt, h*ph, w*pw] -> dtok bf16 [f*h*w, pt*ph*pw*Cout]. */
+int omh_unpatchify_bwd(const float* g, void* dtok_bf16, int32_t Cout, int32_t f, int32_t h, int32_t w,
+                       int32_t pt, int32_t ph, int32_t pw, omh_stream_t stream);
+/* Backward of omh_dense_f32 (act_out must have been 0): dW += dy^T act(x), db += sum_b dy,
+ * dx (=|+=) (dy W) * act'(x).  dW_accum / dx may be NULL. */
+int omh_dense_f32_bwd(const float* x, const float* W, const float* dy, float* dW_accum, float* db_accum,
+                      float* dx, int32_t dx_accumulate, int32_t B, int32_t N, int32_t K, int32_t act_in,
+                      omh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

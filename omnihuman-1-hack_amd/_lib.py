@@ -89,6 +89,18 @@ _SIGS = {
     "omh_nchw_to_cl": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp]),
     "omh_cl_to_nchw": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, f32, f32, i32, i32, vp]),
     "omh_softmax_rows": (i32, [vp, i64, vp, i64, i64, i32, f32, vp]),
+    "omh_transpose_bf16": (i32, [vp, vp, i32, i32, i64, i64, i32, i64, i64, vp]),
+    "omh_colsum_accum": (i32, [vp, i32, i64, vp, i64, i32, vp]),
+    "omh_gelu_tanh_bf16": (i32, [vp, vp, i64, vp]),
+    "omh_gelu_tanh_bwd_bf16": (i32, [vp, vp, vp, i64, vp]),
+    "omh_gated_residual_fwd": (i32, [vp, vp, vp, i64, i32, f32, vp, vp, i64, i64, vp]),
+    "omh_gated_residual_bwd": (i32, [vp, vp, vp, vp, i64, i64, i32, f32, vp, vp, i64, i64, vp]),
+    "omh_layernorm_modulate_bwd": (i32, [vp, vp, vp, i64, i32, f32, f32, vp, vp, i64, vp, vp, i64, i64, vp]),
+    "omh_rmsnorm_rope_bwd": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, i32, vp, f32, i32, vp, vp, i32, i32, vp, i32,
+                                   vp]),
+    "omh_softmax_bwd_rows": (i32, [vp, i64, vp, i64, vp, i64, i64, i32, f32, vp]),
+    "omh_unpatchify_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "omh_dense_f32_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "omh_cfg_unipc_step": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, i32, f32, f32, f32, f32, f32,
                                  f32, f32, vp]),
 }

@@ -160,23 +160,25 @@ void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles) {
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx * sc);
-        const float alpha = exp2f(m_run - m_new);
+        const float alpha = fast_exp2(m_run - m_new);
         m_run = m_new;
         float rs = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(fmaf(s[kb][r], sc, -m_new));
+                const float pv = fast_exp2(fmaf(s[kb][r], sc, -m_new));
                 s[kb][r] = pv;
                 rs += pv;
             }
         rs += __shfl_xor(rs, 32, 64);
         l_run = l_run * alpha + rs;
+        if (!__all(alpha == 1.0f)) {          // wave-uniform: after the first tiles the running max rarely moves
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        }
 
         // ---- P -> bf16 MFMA B operands: pf[kb][a] covers keys 32kb + 16a + 8h + 0..7
         bf16x8 pf[2][2];

@@ -1,0 +1,479 @@
+// Backward-pass kernels of the DiT block for gfx950 (training step of
+// seaweed_apt/distilled_trainer.py:241-316; the reference gets all of this from
+// autograd over aten ops).  The matrix products of the backward pass (dgrad,
+// wgrad, attention dQ/dK/dV) reuse omh_gemm_bf16 on transposed operands; this
+// file holds what surrounds them: transposes, column sums (bias grads) and the
+// backward of LayerNorm+modulate, RMSNorm+RoPE, GELU-tanh, the gated residual
+// and the softmax, plus the tiny fp32 dense layers of the time embedding.
+// Parameter / modulation gradients are accumulated with fp32 atomics.
+#include "omh_common.h"
+
+namespace {
+
+constexpr int MAXV = 32;
+
+// ------------------------------------------------------------------ transpose
+// out[b][c][r] = in[b][r][c]   (bf16), 64x64 tiles through LDS
+__global__ __launch_bounds__(256)
+void transpose_bf16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int R, int C, int64_t ld_in,
+                           int64_t ld_out, int64_t bs_in, int64_t bs_out) {
+    __shared__ uint16_t tile[64][66];
+    const uint16_t* src = in + (int64_t)blockIdx.z * bs_in;
+    uint16_t* dst = out + (int64_t)blockIdx.z * bs_out;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? src[(int64_t)r * ld_in + c] : (uint16_t)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < R) dst[(int64_t)c * ld_out + r] = tile[tx][i];
+    }
+}
+
+// ------------------------------------------------------------------ column sums
+template <typename T>
+__device__ __forceinline__ float ldf(const T* p);
+template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldf<uint16_t>(const uint16_t* p) { return bf2f(*p); }
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void colsum_kernel(const T* __restrict__ x, int64_t ld, float* __restrict__ out, int64_t R, int C, int rows_per_block) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = min(R, r0 + rows_per_block);
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += ldf<T>(x + r * ld + c);
+    atomicAdd(out + c, s);
+}
+
+// ------------------------------------------------------------------ GELU-tanh fwd / bwd (bf16)
+__device__ __forceinline__ float gelu_tanh_grad(float x) {
+    const float c = 0.7978845608028654f, a = 0.044715f;
+    const float u = c * (x + a * x * x * x);
+    const float t = 1.0f - 2.0f / (1.0f + __expf(2.0f * u));          // tanh(u)
+    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * a * x * x);
+}
+
+__global__ __launch_bounds__(256)
+void gelu_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        y[i] = f2bf(gelu_tanh(bf2f(x[i])));
+}
+
+__global__ __launch_bounds__(256)
+void gelu_bwd_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ xpre, uint16_t* __restrict__ dx,
+                     int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dx[i] = f2bf(bf2f(dy[i]) * gelu_tanh_grad(bf2f(xpre[i])));
+}
+
+// ------------------------------------------------------------------ gated residual fwd / bwd
+// fwd: xo = xi + y * gate ; bwd: dy = dx * gate (bf16), dgate[b][c] += sum_rows dx * y
+__global__ __launch_bounds__(256)
+void gated_resid_fwd_kernel(const float* __restrict__ xi, const uint16_t* __restrict__ y, float* __restrict__ xo,
+                            int64_t rows, int dim, float gate_const, const float* __restrict__ gate0,
+                            const float* __restrict__ gate1, int64_t gate1_stride, int64_t rows_per_batch) {
+    const int64_t total = rows * dim;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % dim);
+        const int64_t r = i / dim;
+        float g = gate_const;
+        if (gate0) g += gate0[c];
+        if (gate1) g += gate1[(r / rows_per_batch) * gate1_stride + c];
+        xo[i] = xi[i] + bf2f(y[i]) * g;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void gated_resid_bwd_kernel(const float* __restrict__ dx, const uint16_t* __restrict__ y, uint16_t* __restrict__ dy,
+                            float* __restrict__ dgate, int64_t dgate_stride, int64_t rows, int dim, float gate_const,
+                            const float* __restrict__ gate0, const float* __restrict__ gate1, int64_t gate1_stride,
+                            int64_t rows_per_batch, int rows_per_block) {
+    // block = 256 columns x rows_per_block rows (all inside one batch element)
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= dim) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t b = r0 / rows_per_batch;
+    const int64_t r1 = min(min(rows, r0 + rows_per_block), (b + 1) * rows_per_batch);
+    float g = gate_const;
+    if (gate0) g += gate0[c];
+    if (gate1) g += gate1[b * gate1_stride + c];
+    float acc = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+        const float d = dx[r * dim + c];
+        dy[r * dim + c] = f2bf(d * g);
+        if (y) acc += d * bf2f(y[r * dim + c]);
+    }
+    if (dgate && y) atomicAdd(dgate + b * dgate_stride + c, acc);
+}
+
+// ------------------------------------------------------------------ LayerNorm + modulate backward
+// y = xhat * mul + add ;  dx += rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * mul
+// dmul[b][c] += dy * xhat ; dadd[b][c] += dy
+__global__ __launch_bounds__(256)
+void layernorm_modulate_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                   int64_t rows, int dim, float eps, float mul_const, const float* __restrict__ mul0,
+                                   const float* __restrict__ mul1, int64_t mul1_stride, float* __restrict__ dmul,
+                                   float* __restrict__ dadd, int64_t dstride, int64_t rows_per_batch) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = dim >> 2;
+    const float4* xr = (const float4*)(x + row * dim);
+    const float4* gr = (const float4*)(dy + row * dim);
+    const int64_t b = row / rows_per_batch;
+    const float4* m0 = (const float4*)mul0;
+    const float4* m1 = mul1 ? (const float4*)(mul1 + b * mul1_stride) : nullptr;
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) { v[i] = xr[c]; s += v[i].x + v[i].y + v[i].z + v[i].w; }
+    }
+    const float mean = wave_sum(s) / dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+            q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / dim + eps);
+    // pass 1: g = dy*mul, sums of g and g*xhat; parameter-side atomics
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float4 d = gr[c];
+            float4 mu = make_float4(mul_const, mul_const, mul_const, mul_const);
+            if (m0) { const float4 t = m0[c]; mu.x += t.x; mu.y += t.y; mu.z += t.z; mu.w += t.w; }
+            if (m1) { const float4 t = m1[c]; mu.x += t.x; mu.y += t.y; mu.z += t.z; mu.w += t.w; }
+            const float xh[4] = {v[i].x * rstd, v[i].y * rstd, v[i].z * rstd, v[i].w * rstd};
+            const float dd[4] = {d.x, d.y, d.z, d.w};
+            const float mm[4] = {mu.x, mu.y, mu.z, mu.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float g = dd[e] * mm[e];
+                sg += g;
+                sgx += g * xh[e];
+                if (dmul) atomicAdd(dmul + b * dstride + 4 * c + e, dd[e] * xh[e]);
+                if (dadd) atomicAdd(dadd + b * dstride + 4 * c + e, dd[e]);
+            }
+        }
+    }
+    const float mg = wave_sum(sg) / dim, mgx = wave_sum(sgx) / dim;
+    float4* dxr = (float4*)(dx + row * dim);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float4 d = gr[c];
+            float4 mu = make_float4(mul_const, mul_const, mul_const, mul_const);
+            if (m0) { const float4 t = m0[c]; mu.x += t.x; mu.y += t.y; mu.z += t.z; mu.w += t.w; }
+            if (m1) { const float4 t = m1[c]; mu.x += t.x; mu.y += t.y; mu.z += t.z; mu.w += t.w; }
+            float4 o = dxr[c];
+            o.x += rstd * (d.x * mu.x - mg - v[i].x * rstd * mgx);
+            o.y += rstd * (d.y * mu.y - mg - v[i].y * rstd * mgx);
+            o.z += rstd * (d.z * mu.z - mg - v[i].z * rstd * mgx);
+            o.w += rstd * (d.w * mu.w - mg - v[i].w * rstd * mgx);
+            dxr[c] = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ RMSNorm (+RoPE) backward
+// forward: y = rope( x * r * w ), r = rsqrt(mean(x^2)+eps).  g = unrope(dy);
+// dw[c] += g*x*r ; dx = r*(g*w) - x * r^3 * mean(x * g*w)   -> bf16
+__global__ __launch_bounds__(256)
+void rmsnorm_rope_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy,
+                             uint16_t* __restrict__ dx, int64_t lddx, float* __restrict__ dw, int64_t rows, int dim,
+                             const float* __restrict__ weight, float eps, int do_norm,
+                             const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, int rope_len,
+                             int head_dim, const int* __restrict__ grid, int seq_len) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = dim >> 2;
+    const float4* xr = (const float4*)(x + row * ldx);
+    const float4* gr = (const float4*)(dy + row * lddy);
+    const float4* wv = (const float4*)weight;
+    float4 v[MAXV];
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) { v[i] = xr[c]; q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w; }
+    }
+    const float r = do_norm ? rsqrtf(wave_sum(q) / dim + eps) : 1.0f;
+    bool rot = false;
+    int pf = 0, ph = 0, pw = 0;
+    const int hc = head_dim >> 1, c3 = hc / 3, cf = hc - 2 * c3;
+    if (rope_cos) {
+        const int b = (int)(row / seq_len), s = (int)(row % seq_len);
+        const int gf = grid[3 * b], gh = grid[3 * b + 1], gw = grid[3 * b + 2];
+        if (s < gf * gh * gw) { rot = true; pf = s / (gh * gw); ph = (s / gw) % gh; pw = s % gw; }
+    }
+    float4 g[MAXV];
+    float sxg = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            float4 t = gr[c];
+            if (rot) {
+                const int p0 = ((4 * c) % head_dim) >> 1;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int pc = p0 + e;
+                    const int pos = pc < cf ? pf : (pc < cf + c3 ? ph : pw);
+                    const int idx = min(pos, rope_len - 1) * hc + pc;
+                    const float cs = rope_cos[idx], sn = rope_sin[idx];
+                    float& re = e == 0 ? t.x : t.z;
+                    float& im = e == 0 ? t.y : t.w;
+                    const float nr = re * cs + im * sn;          // rotate by -theta
+                    const float ni = -re * sn + im * cs;
+                    re = nr; im = ni;
+                }
+            }
+            if (dw) {
+                atomicAdd(dw + 4 * c + 0, t.x * v[i].x * r); atomicAdd(dw + 4 * c + 1, t.y * v[i].y * r);
+                atomicAdd(dw + 4 * c + 2, t.z * v[i].z * r); atomicAdd(dw + 4 * c + 3, t.w * v[i].w * r);
+            }
+            if (wv) { const float4 w4 = wv[c]; t.x *= w4.x; t.y *= w4.y; t.z *= w4.z; t.w *= w4.w; }
+            g[i] = t;
+            sxg += v[i].x * t.x + v[i].y * t.y + v[i].z * t.z + v[i].w * t.w;
+        }
+    }
+    const float coef = do_norm ? wave_sum(sxg) / dim * r * r * r : 0.f;
+    uint2* dxr = (uint2*)(dx + row * lddx);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            uint2 o;
+            o.x = pack_bf2(r * g[i].x - v[i].x * coef, r * g[i].y - v[i].y * coef);
+            o.y = pack_bf2(r * g[i].z - v[i].z * coef, r * g[i].w - v[i].w * coef);
+            dxr[c] = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ softmax backward
+// dS = P * (dP - sum_j P*dP) * scale ; one 256-thread block per row
+__global__ __launch_bounds__(256)
+void softmax_bwd_rows_kernel(const uint16_t* __restrict__ p, int64_t ldp, const float* __restrict__ dp, int64_t lddp,
+                             uint16_t* __restrict__ ds, int64_t ldds, int L, float scale) {
+    __shared__ float red[4];
+    const int64_t r = blockIdx.x;
+    const uint16_t* pr = p + r * ldp;
+    const float* dr = dp + r * lddp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float s = 0.f;
+    for (int j = tid; j < L; j += 256) s += bf2f(pr[j]) * dr[j];
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float delta = red[0] + red[1] + red[2] + red[3];
+    uint16_t* o = ds + r * ldds;
+    for (int j = tid; j < L; j += 256) o[j] = f2bf(bf2f(pr[j]) * (dr[j] - delta) * scale);
+}
+
+// ------------------------------------------------------------------ unpatchify backward
+// dtok[s][((a*ph+i)*pw+j)*C + c] = g[c][f*pt+a][h*ph+i][w*pw+j]   (bf16 out)
+__global__ __launch_bounds__(256)
+void unpatchify_bwd_kernel(const float* __restrict__ g, uint16_t* __restrict__ dtok, int Cout, int gf, int gh, int gw,
+                           int pt, int ph, int pw) {
+    const int F = gf * pt, H = gh * ph, W = gw * pw;
+    const int ncol = pt * ph * pw * Cout;
+    const int64_t total = (int64_t)gf * gh * gw * ncol;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int col = (int)(i % ncol);
+        const int64_t s = i / ncol;
+        const int c = col % Cout, j = (col / Cout) % pw, ii = (col / (Cout * pw)) % ph, a = col / (Cout * pw * ph);
+        const int w = (int)(s % gw), h = (int)((s / gw) % gh), f = (int)(s / ((int64_t)gw * gh));
+        dtok[i] = f2bf(g[(((int64_t)c * F + f * pt + a) * H + h * ph + ii) * W + w * pw + j]);
+    }
+}
+
+// ------------------------------------------------------------------ tiny fp32 dense backward (time embedding)
+// forward: y[b][n] = sum_k act(x[b][k]) W[n][k] + bias[n]
+__global__ __launch_bounds__(256)
+void dense_f32_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dW,
+                            float* __restrict__ db, int B, int N, int K, int act_in) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * K) return;
+    const int n = (int)(i / K), k = (int)(i % K);
+    float s = 0.f, sb = 0.f;
+    for (int b = 0; b < B; ++b) {
+        float xv = x[(int64_t)b * K + k];
+        if (act_in == 1) xv = xv / (1.0f + expf(-xv));
+        const float d = dy[(int64_t)b * N + n];
+        s += d * xv;
+        sb += d;
+    }
+    dW[i] += s;
+    if (db && k == 0) db[n] += sb;
+}
+
+__global__ __launch_bounds__(256)
+void dense_f32_bwd_x_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ dy,
+                            float* __restrict__ dx, int B, int N, int K, int act_in, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * K) return;
+    const int b = (int)(i / K), k = (int)(i % K);
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += dy[(int64_t)b * N + n] * W[(int64_t)n * K + k];
+    if (act_in == 1) {
+        const float xv = x[i];
+        const float sg = 1.0f / (1.0f + expf(-xv));
+        s *= sg * (1.0f + xv * (1.0f - sg));
+    }
+    dx[i] = accumulate ? dx[i] + s : s;
+}
+
+inline int grid_for(int64_t n, int per_block) {
+    int64_t g = (n + per_block - 1) / per_block;
+    return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+}  // namespace
+
+extern "C" int omh_transpose_bf16(const void* in, void* out, int32_t R, int32_t C, int64_t ld_in, int64_t ld_out,
+                                  int32_t batch, int64_t bs_in, int64_t bs_out, omh_stream_t stream) {
+    if (!in || !out || R <= 0 || C <= 0 || batch <= 0 || ld_in < C || ld_out < R) return OMH_E_BADARG;
+    dim3 grid((C + 63) / 64, (R + 63) / 64, batch);
+    omh_clear_status();
+    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)in,
+                       (uint16_t*)out, R, C, ld_in, ld_out, bs_in, bs_out);
+    return omh_launch_status();
+}
+
+extern "C" int omh_colsum_accum(const void* x, int32_t is_bf16, int64_t ld, float* out, int64_t R, int32_t C,
+                                omh_stream_t stream) {
+    if (!x || !out || R <= 0 || C <= 0 || ld < C) return OMH_E_BADARG;
+    const int rpb = 128;
+    dim3 grid((C + 255) / 256, (unsigned)((R + rpb - 1) / rpb));
+    omh_clear_status();
+    if (is_bf16)
+        hipLaunchKernelGGL(colsum_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, ld,
+                           out, R, C, rpb);
+    else
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, out, R,
+                           C, rpb);
+    return omh_launch_status();
+}
+
+extern "C" int omh_gelu_tanh_bf16(const void* x, void* y, int64_t n, omh_stream_t stream) {
+    if (!x || !y || n <= 0) return OMH_E_BADARG;
+    omh_clear_status();
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)x, (uint16_t*)y, n);
+    return omh_launch_status();
+}
+
+extern "C" int omh_gelu_tanh_bwd_bf16(const void* dy, const void* x_pre, void* dx, int64_t n, omh_stream_t stream) {
+    if (!dy || !x_pre || !dx || n <= 0) return OMH_E_BADARG;
+    omh_clear_status();
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)dy, (const uint16_t*)x_pre, (uint16_t*)dx, n);
+    return omh_launch_status();
+}
+
+extern "C" int omh_gated_residual_fwd(const float* xi, const void* y_bf16, float* xo, int64_t rows, int32_t dim,
+                                      float gate_const, const float* gate0, const float* gate1, int64_t gate1_stride,
+                                      int64_t rows_per_batch, omh_stream_t stream) {
+    if (!xi || !y_bf16 || !xo || rows <= 0 || dim <= 0 || rows_per_batch <= 0) return OMH_E_BADARG;
+    omh_clear_status();
+    hipLaunchKernelGGL(gated_resid_fwd_kernel, dim3(grid_for(rows * dim, 256)), dim3(256), 0, (hipStream_t)stream, xi,
+                       (const uint16_t*)y_bf16, xo, rows, dim, gate_const, gate0, gate1, gate1_stride, rows_per_batch);
+    return omh_launch_status();
+}
+
+extern "C" int omh_gated_residual_bwd(const float* dx, const void* y_bf16, void* dy_bf16, float* dgate,
+                                      int64_t dgate_stride, int64_t rows, int32_t dim, float gate_const,
+                                      const float* gate0, const float* gate1, int64_t gate1_stride,
+                                      int64_t rows_per_batch, omh_stream_t stream) {
+    if (!dx || !dy_bf16 || rows <= 0 || dim <= 0 || rows_per_batch <= 0) return OMH_E_BADARG;
+    int rpb = 32;
+    while (rows_per_batch % rpb) rpb >>= 1;          // blocks never straddle two batch elements
+    dim3 grid((dim + 255) / 256, (unsigned)((rows + rpb - 1) / rpb));
+    omh_clear_status();
+    hipLaunchKernelGGL(gated_resid_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dx, (const uint16_t*)y_bf16,
+                       (uint16_t*)dy_bf16, dgate, dgate_stride, rows, dim, gate_const, gate0, gate1, gate1_stride,
+                       rows_per_batch, rpb);
+    return omh_launch_status();
+}
+
+extern "C" int omh_layernorm_modulate_bwd(const float* x, const float* dy, float* dx_accum, int64_t rows, int32_t dim,
+                                          float eps, float mul_const, const float* mul0, const float* mul1,
+                                          int64_t mul1_stride, float* dmul, float* dadd, int64_t dstride,
+                                          int64_t rows_per_batch, omh_stream_t stream) {
+    if (!x || !dy || !dx_accum || rows <= 0 || dim <= 0 || rows_per_batch <= 0) return OMH_E_BADARG;
+    if ((dim & 3) || dim > MAXV * 256) return OMH_E_SHAPE;
+    omh_clear_status();
+    hipLaunchKernelGGL(layernorm_modulate_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, x, dy, dx_accum, rows, dim, eps, mul_const, mul0, mul1, mul1_stride, dmul,
+                       dadd, dstride, rows_per_batch);
+    return omh_launch_status();
+}
+
+extern "C" int omh_rmsnorm_rope_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, void* dx_bf16,
+                                    int64_t lddx, float* dweight, int64_t rows, int32_t dim, const float* weight,
+                                    float eps, int32_t do_norm, const float* rope_cos, const float* rope_sin,
+                                    int32_t rope_len, int32_t head_dim, const int32_t* grid, int32_t seq_len,
+                                    omh_stream_t stream) {
+    if (!x || !dy || !dx_bf16 || rows <= 0 || dim <= 0) return OMH_E_BADARG;
+    if ((dim & 3) || dim > MAXV * 256 || (ldx & 3) || (lddy & 3) || (lddx & 3)) return OMH_E_SHAPE;
+    if (rope_cos && (!rope_sin || !grid || seq_len <= 0 || head_dim <= 0)) return OMH_E_BADARG;
+    omh_clear_status();
+    hipLaunchKernelGGL(rmsnorm_rope_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
+                       ldx, dy, lddy, (uint16_t*)dx_bf16, lddx, dweight, rows, dim, weight, eps, do_norm, rope_cos,
+                       rope_sin, rope_len, head_dim, grid, seq_len);
+    return omh_launch_status();
+}
+
+extern "C" int omh_softmax_bwd_rows(const void* p_bf16, int64_t ldp, const float* dp, int64_t lddp, void* ds_bf16,
+                                    int64_t ldds, int64_t R, int32_t L, float scale, omh_stream_t stream) {
+    if (!p_bf16 || !dp || !ds_bf16 || R <= 0 || L <= 0 || R > 0x7fffffff) return OMH_E_BADARG;
+    omh_clear_status();
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)p_bf16, ldp, dp, lddp, (uint16_t*)ds_bf16, ldds, L, scale);
+    return omh_launch_status();
+}
+
+extern "C" int omh_unpatchify_bwd(const float* g, void* dtok_bf16, int32_t Cout, int32_t f, int32_t h, int32_t w,
+                                  int32_t pt, int32_t ph, int32_t pw, omh_stream_t stream) {
+    if (!g || !dtok_bf16 || Cout <= 0 || f <= 0 || h <= 0 || w <= 0) return OMH_E_BADARG;
+    const int64_t total = (int64_t)f * h * w * pt * ph * pw * Cout;
+    omh_clear_status();
+    hipLaunchKernelGGL(unpatchify_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, g,
+                       (uint16_t*)dtok_bf16, Cout, f, h, w, pt, ph, pw);
+    return omh_launch_status();
+}
+
+extern "C" int omh_dense_f32_bwd(const float* x, const float* W, const float* dy, float* dW_accum, float* db_accum,
+                                 float* dx, int32_t dx_accumulate, int32_t B, int32_t N, int32_t K, int32_t act_in,
+                                 omh_stream_t stream) {
+    if (!x || !W || !dy || B <= 0 || N <= 0 || K <= 0) return OMH_E_BADARG;
+    omh_clear_status();
+    if (dW_accum)
+        hipLaunchKernelGGL(dense_f32_bwd_w_kernel, dim3((unsigned)(((int64_t)N * K + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, x, dy, dW_accum, db_accum, B, N, K, act_in);
+    if (dx)
+        hipLaunchKernelGGL(dense_f32_bwd_x_kernel, dim3((unsigned)(((int64_t)B * K + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, x, W, dy, dx, B, N, K, act_in, dx_accumulate);
+    return omh_launch_status();
+}

@@ -22,9 +22,16 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
 }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
+// two fp32 -> packed bf16x2 with the gfx950 hardware convert (RNE, NaN-safe);
+// there is no builtin for v_cvt_pk_bf16_f32, hence the one-line asm.
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
 }
+// raw v_exp_f32 (2^x): no denormal fix-up sequence; inputs here are <= 0 and
+// results below 2^-126 may flush to zero, which is what a softmax wants.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __device__ __forceinline__ float gelu_tanh(float x) {
     // 0.5 x (1 + tanh( sqrt(2/pi) (x + 0.044715 x^3) ))  ==  x * sigmoid(2u)

@@ -258,3 +258,96 @@ def softmax_rows(x, out, L, scale):
     check(lib.omh_softmax_rows(_p(x), x.stride(0), _p(out), out.stride(0), x.shape[0], L, scale, _stream()),
           "omh_softmax_rows")
     return out
+
+
+# ----------------------------------------------------------------------------- backward kernels (raw pointer API)
+def transpose_bf16_raw(src, dst, R, Cc, ld_in, ld_out, batch=1, bs_in=0, bs_out=0):
+    check(lib.omh_transpose_bf16(src, dst, R, Cc, ld_in, ld_out, batch, bs_in, bs_out, _stream()),
+          "omh_transpose_bf16")
+
+
+def transpose_bf16(x: torch.Tensor, pad_to: int = 8):
+    """x bf16 [R, C] (row stride free) -> zero-padded bf16 [C, roundup(R, pad_to)]."""
+    _dev(x)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+    R, Cc = x.shape
+    Rp = (R + pad_to - 1) // pad_to * pad_to
+    out = torch.zeros(Cc, Rp, dtype=torch.bfloat16, device=x.device) if Rp != R else \
+        torch.empty(Cc, Rp, dtype=torch.bfloat16, device=x.device)
+    transpose_bf16_raw(_p(x), _p(out), R, Cc, x.stride(0), Rp)
+    return out
+
+
+def colsum_accum(x: torch.Tensor, out: torch.Tensor):
+    """out[c] += sum_r x[r][c]; x bf16/fp32 [R, C]."""
+    _dev(x, out)
+    assert x.dim() == 2 and x.stride(1) == 1 and out.dtype == torch.float32
+    check(lib.omh_colsum_accum(_p(x), int(x.dtype == torch.bfloat16), x.stride(0), _p(out), x.shape[0], x.shape[1],
+                               _stream()), "omh_colsum_accum")
+    return out
+
+
+def gelu_tanh(x, out=None):
+    _dev(x)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    out = torch.empty_like(x) if out is None else out
+    check(lib.omh_gelu_tanh_bf16(_p(x), _p(out), x.numel(), _stream()), "omh_gelu_tanh_bf16")
+    return out
+
+
+def gelu_tanh_bwd(dy, x_pre, out=None):
+    _dev(dy, x_pre)
+    assert dy.dtype == x_pre.dtype == torch.bfloat16 and dy.is_contiguous() and x_pre.is_contiguous()
+    out = torch.empty_like(dy) if out is None else out
+    check(lib.omh_gelu_tanh_bwd_bf16(_p(dy), _p(x_pre), _p(out), dy.numel(), _stream()), "omh_gelu_tanh_bwd_bf16")
+    return out
+
+
+def gated_residual_fwd_raw(xi, y, xo, rows, dim, gate_const, gate0, gate1, gate1_stride, rows_per_batch):
+    check(lib.omh_gated_residual_fwd(xi, y, xo, rows, dim, gate_const, gate0, gate1, gate1_stride, rows_per_batch,
+                                     _stream()), "omh_gated_residual_fwd")
+
+
+def gated_residual_bwd_raw(dx, y, dy, dgate, dgate_stride, rows, dim, gate_const, gate0, gate1, gate1_stride,
+                           rows_per_batch):
+    check(lib.omh_gated_residual_bwd(dx, y, dy, dgate, dgate_stride, rows, dim, gate_const, gate0, gate1,
+                                     gate1_stride, rows_per_batch, _stream()), "omh_gated_residual_bwd")
+
+
+def layernorm_modulate_bwd_raw(x, dy, dx, rows, dim, eps, mul_const, mul0, mul1, mul1_stride, dmul, dadd, dstride,
+                               rows_per_batch):
+    check(lib.omh_layernorm_modulate_bwd(x, dy, dx, rows, dim, eps, mul_const, mul0, mul1, mul1_stride, dmul, dadd,
+                                         dstride, rows_per_batch, _stream()), "omh_layernorm_modulate_bwd")
+
+
+def rmsnorm_rope_bwd_raw(x, ldx, dy, lddy, dx, lddx, dw, rows, dim, weight, eps, do_norm, rope_cos, rope_sin,
+                         rope_len, head_dim, grid, seq_len):
+    check(lib.omh_rmsnorm_rope_bwd(x, ldx, dy, lddy, dx, lddx, dw, rows, dim, weight, eps, do_norm, rope_cos,
+                                   rope_sin, rope_len, head_dim, grid, seq_len, _stream()), "omh_rmsnorm_rope_bwd")
+
+
+def softmax_bwd_rows(p, dp, ds, L, scale):
+    _dev(p, dp, ds)
+    assert p.dtype == torch.bfloat16 and dp.dtype == torch.float32 and ds.dtype == torch.bfloat16
+    check(lib.omh_softmax_bwd_rows(_p(p), p.stride(0), _p(dp), dp.stride(0), _p(ds), ds.stride(0), p.shape[0], L,
+                                   scale, _stream()), "omh_softmax_bwd_rows")
+    return ds
+
+
+def unpatchify_bwd(g: torch.Tensor, grid, patch):
+    """g fp32 [Cout, F, H, W] -> bf16 [f*h*w, pt*ph*pw*Cout]."""
+    _dev(g)
+    assert g.dtype == torch.float32 and g.is_contiguous()
+    f, h, w = grid
+    pt, ph, pw = patch
+    out = torch.empty(f * h * w, pt * ph * pw * g.shape[0], dtype=torch.bfloat16, device=g.device)
+    check(lib.omh_unpatchify_bwd(_p(g), _p(out), g.shape[0], f, h, w, pt, ph, pw, _stream()), "omh_unpatchify_bwd")
+    return out
+
+
+def dense_f32_bwd(x, w, dy, dW=None, db=None, dx=None, dx_accumulate=False, act_in=0):
+    _dev(x, w, dy, dW, db, dx)
+    B, K = x.shape
+    N = w.shape[0]
+    check(lib.omh_dense_f32_bwd(_p(x), _p(w), _p(dy), _p(dW), _p(db), _p(dx), int(dx_accumulate), B, N, K, act_in,
+                                _stream()), "omh_dense_f32_bwd")

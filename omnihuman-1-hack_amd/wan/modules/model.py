@@ -462,6 +462,8 @@ class WanModel(nn.Module):
                            qk_norm=qk_norm, cross_attn_norm=cross_attn_norm, eps=eps)
         self.model_type = model_type
         self.use_checkpoint = use_checkpoint
+        # reference quirk (model.py:317-324): FFNs of blocks > 10 receive no gradient; False = full gradients
+        self.reference_ffn_freeze = True
         self.patch_size = tuple(patch_size)
         self.text_len, self.in_dim, self.dim, self.ffn_dim = text_len, in_dim, dim, ffn_dim
         self.freq_dim, self.text_dim, self.out_dim = freq_dim, text_dim, out_dim

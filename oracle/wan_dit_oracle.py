@@ -264,7 +264,7 @@ def cross_attention(sd, p, cfg, x, context, context_lens):
     return _lin(sd, p + "o", o)
 
 
-def attention_block(sd, i, cfg, x, e0, seq_lens, grid_sizes, angles, context, context_lens):
+def attention_block(sd, i, cfg, x, e0, seq_lens, grid_sizes, angles, context, context_lens, freeze_ffn=False):
     """model.py:279-330 (WanAttentionBlock.forward + cross_attn_ffn).  The
     reference's block_idx>10 CPU-offloaded FFN (model.py:317-324) is, in
     inference, the same fp32 FFN; only its gradient differs."""
@@ -279,7 +279,13 @@ def attention_block(sd, i, cfg, x, e0, seq_lens, grid_sizes, angles, context, co
         h = x
     x = x + cross_attention(sd, p + "cross_attn.", cfg, h, context, context_lens)
     h = layer_norm(x, cfg.eps) * (1 + e[4]) + e[3]
-    y = _lin(sd, p + "ffn.2", F.gelu(_lin(sd, p + "ffn.0", h), approximate="tanh"))
+    if freeze_ffn:
+        # model.py:317-324: FFN evaluated under no_grad (on the CPU), then "+ 0 * ffn_input"
+        with torch.no_grad():
+            y = _lin(sd, p + "ffn.2", F.gelu(_lin(sd, p + "ffn.0", h), approximate="tanh"))
+        y = y + 0 * h
+    else:
+        y = _lin(sd, p + "ffn.2", F.gelu(_lin(sd, p + "ffn.0", h), approximate="tanh"))
     return x + y * e[5]
 
 
@@ -340,6 +346,18 @@ def dit_forward(sd, cfg: DiTConfig, x_list: Sequence[torch.Tensor], t: torch.Ten
         x = attention_block(sd, i, cfg, x, e0, seq_lens, grid_sizes, angles, ctx, context_lens)
     if return_hidden:
         return x
+    return head_unpatchify(sd, cfg, x, e, grid_sizes)
+
+
+def dit_forward_autograd(sd, cfg: DiTConfig, x_list, t, context_list, seq_len, reference_ffn_freeze=True):
+    """The same forward with autograd enabled (``sd`` tensors with requires_grad): the oracle of the
+    training step (distilled_trainer.py:268-301).  ``reference_ffn_freeze`` reproduces the reference's
+    block_idx > 10 FFN quirk (model.py:317-324)."""
+    x, e, e0, ctx, context_lens, seq_lens, grid_sizes = embed_inputs(sd, cfg, x_list, t, context_list, seq_len)
+    angles = rope_table(cfg.dim // cfg.num_heads)
+    for i in range(cfg.num_layers):
+        x = attention_block(sd, i, cfg, x, e0, seq_lens, grid_sizes, angles, ctx, context_lens,
+                            freeze_ffn=reference_ffn_freeze and i > 10)
     return head_unpatchify(sd, cfg, x, e, grid_sizes)
 
 
