@@ -273,6 +273,14 @@ int omh_dense_f32_bwd(const float* x, const float* W, const float* dy, float* dW
                       float* dx, int32_t dx_accumulate, int32_t B, int32_t N, int32_t K, int32_t act_in,
                       omh_stream_t stream);
 
+/* Fused AdamW (decoupled weight decay, bias-corrected; torch.optim.AdamW semantics,
+ * distilled_trainer.py:69-75) on fp32 parameters; grads are divided by grad_scale first
+ * (GradScaler-style loss scaling, distilled_trainer.py:95,301).  step >= 1. */
+int omh_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int32_t step, float grad_scale, omh_stream_t stream);
+/* EMA of the weights, ema = decay*ema + (1-decay)*p (distilled_trainer.py:319-334). */
+int omh_ema_update(float* ema, const float* p, int64_t n, float decay, omh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,6 +101,8 @@ _SIGS = {
     "omh_softmax_bwd_rows": (i32, [vp, i64, vp, i64, vp, i64, i64, i32, f32, vp]),
     "omh_unpatchify_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "omh_dense_f32_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "omh_adamw_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
+    "omh_ema_update": (i32, [vp, vp, i64, f32, vp]),
     "omh_cfg_unipc_step": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, i32, f32, f32, f32, f32, f32,
                                  f32, f32, vp]),
 }

@@ -351,3 +351,17 @@ def dense_f32_bwd(x, w, dy, dW=None, db=None, dx=None, dx_accumulate=False, act_
     N = w.shape[0]
     check(lib.omh_dense_f32_bwd(_p(x), _p(w), _p(dy), _p(dW), _p(db), _p(dx), int(dx_accumulate), B, N, K, act_in,
                                 _stream()), "omh_dense_f32_bwd")
+
+
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    _dev(p, g, m, v)
+    for t in (p, g, m, v):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    check(lib.omh_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
+                             grad_scale, _stream()), "omh_adamw_step")
+
+
+def ema_update(ema, p, decay):
+    _dev(ema, p)
+    assert ema.dtype == p.dtype == torch.float32 and ema.is_contiguous() and p.is_contiguous()
+    check(lib.omh_ema_update(_p(ema), _p(p), p.numel(), decay, _stream()), "omh_ema_update")

@@ -1,0 +1,38 @@
+"""Optimizer side of the training step on gfx950 kernels: AdamW with the
+constructor of ``torch.optim.AdamW`` (seaweed_apt/distilled_trainer.py:69-75)
+and the EMA update of distilled_trainer.py:319-334 kept on the GPU."""
+import torch
+
+from . import ops
+
+
+class AdamW(torch.optim.Optimizer):
+    """``torch.optim.AdamW``-compatible (lr, betas, eps, weight_decay); one fused kernel per parameter."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: float = 1.0):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                ops.adamw_step(p.data, p.grad.contiguous(), st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2,
+                               group["eps"], group["weight_decay"], st["step"], grad_scale)
+        return loss
+
+
+@torch.no_grad()
+def update_ema_model(ema_model, model, decay):
+    """distilled_trainer.py:319-334 without the GPU->CPU round trip (the EMA copy lives in HBM)."""
+    for target, source in zip(ema_model.parameters(), model.parameters()):
+        ops.ema_update(target.data, source.data.to(target.device), decay)

@@ -1,0 +1,113 @@
+"""Data-parallel gradient synchronisation for the training step (BASELINE
+config 3): one process per GPU, ``torch.distributed`` backend "nccl" (= RCCL
+over xGMI) — "gloo" on CPU for the tests.
+
+The reference relies on ``accelerate`` wrapping the model in DDP
+(distilled_trainer.py:79-81).  This reducer does the same job with the knobs
+that matter on a point-to-point xGMI mesh exposed: gradients are packed into
+large flat buckets (default 256 MB — few, large collectives; 288 GB of HBM makes
+the staging copy free) in reverse parameter order, and each bucket's
+all-reduce is launched asynchronously the moment its last gradient has been
+accumulated, so communication overlaps with the rest of the backward (the
+block nodes of model_train.py release their gradients block by block).
+Parameters that receive no gradient (the reference's frozen FFNs of blocks
+> 10) are handled without ``find_unused_parameters``: every
+rank skips the same set.  With gradient accumulation, wrap the non-final
+micro-steps in ``no_sync()``.
+"""
+import contextlib
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class BucketedGradAllReduce:
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 256.0,
+                 group: Optional["dist.ProcessGroup"] = None, average: bool = True):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.average = average
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        self.enabled = True
+        cap = int(bucket_mb * 1024 * 1024)
+        self.buckets, cur, cur_bytes = [], [], 0
+        for p in reversed(self.params):                     # gradients become ready roughly in reverse order
+            nbytes = p.numel() * p.element_size()
+            if cur and cur_bytes + nbytes > cap:
+                self.buckets.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self.buckets.append(cur)
+        self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
+        self._flat = [None] * len(self.buckets)
+        self._reset()
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    def _reset(self):
+        self._ready = [set() for _ in self.buckets]
+        self._work = [None] * len(self.buckets)
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Skip the all-reduce (gradient accumulation micro-steps, distilled_trainer.py:372)."""
+        old, self.enabled = self.enabled, False
+        try:
+            yield
+        finally:
+            self.enabled = old
+
+    def _on_grad(self, p):
+        if not self.enabled or self.world == 1:
+            return
+        i = self._bucket_of[id(p)]
+        self._ready[i].add(id(p))
+        if len(self._ready[i]) == len(self.buckets[i]) and self._work[i] is None:
+            self._launch(i)
+
+    def _launch(self, i):
+        bucket = [p for p in self.buckets[i] if p.grad is not None]
+        if not bucket:
+            self._work[i] = (None, [])
+            return
+        n = sum(p.numel() for p in bucket)
+        flat = self._flat[i]
+        if flat is None or flat.numel() != n or flat.device != bucket[0].grad.device:
+            flat = self._flat[i] = torch.empty(n, dtype=bucket[0].grad.dtype, device=bucket[0].grad.device)
+        off = 0
+        for p in bucket:
+            flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+            off += p.numel()
+        # RCCL averages in the collective; gloo (CPU tests) has no AVG, so sum now and scale in finish()
+        self._avg_in_coll = self.average and dist.get_backend(self.group) == "nccl"
+        op = dist.ReduceOp.AVG if self._avg_in_coll else dist.ReduceOp.SUM
+        work = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
+        self._work[i] = (work, bucket)
+
+    def finish(self):
+        """Call after ``backward()``: launches buckets that never filled (unused parameters), waits for
+        all collectives and writes the averaged gradients back."""
+        if not self.enabled or self.world == 1:
+            self._reset()
+            return
+        for i in range(len(self.buckets)):
+            if self._work[i] is None:
+                self._launch(i)
+        for i, (work, bucket) in enumerate(self._work):
+            if work is None:
+                continue
+            work.wait()
+            flat, off = self._flat[i], 0
+            if self.average and not self._avg_in_coll:
+                flat.mul_(1.0 / self.world)
+            for p in bucket:
+                p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
+                off += p.numel()
+        self._reset()
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

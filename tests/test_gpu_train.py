@@ -128,3 +128,38 @@ def test_backward_kernels(ops):
                              1e-6, 1, ops.ptr(cos), ops.ptr(sin), 1024, D, ops.ptr(grid), S)
     assert rel_rms(dxq.float(), xc.grad) < 5e-3
     assert rel_rms(dw, wc.grad) < 1e-4
+
+
+def test_adamw_and_ema_match_torch(omh):
+    import importlib
+    optim = importlib.import_module("omnihuman-1-hack_amd.optim")
+    torch.manual_seed(0)
+    p0 = torch.randn(1000, device="cuda")
+    a = torch.nn.Parameter(p0.clone())
+    b = torch.nn.Parameter(p0.clone())
+    oa = optim.AdamW([a], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    ob = torch.optim.AdamW([b], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    for i in range(5):
+        g = torch.randn(1000, device="cuda")
+        a.grad, b.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    assert torch.allclose(a, b, atol=1e-6, rtol=1e-5)
+    ema, src = torch.nn.Linear(8, 8).cuda(), torch.nn.Linear(8, 8).cuda()
+    ref = [0.995 * t.detach().clone() + 0.005 * s.detach() for t, s in zip(ema.parameters(), src.parameters())]
+    optim.update_ema_model(ema, src, 0.995)
+    for t, r in zip(ema.parameters(), ref):
+        assert torch.allclose(t, r, atol=1e-7)
+
+
+def test_training_step_function_matches_reference_loss(wan_model_mod):
+    """trainer.training_step keeps distilled_trainer.py's semantics (sample 0 only, broadcast loss)."""
+    import importlib
+    trainer = importlib.import_module("omnihuman-1-hack_amd.trainer")
+    cfg, sd, m, noise, vt, cl = _setup(wan_model_mod)
+    # reshape the tiny case into the trainer's batch layout: contexts as one [B, L, C] tensor
+    ctx = torch.stack(cl)
+    g = np.load(os.path.join(GOLD, "dit_train_t2v_L13.npz"))
+    loss = trainer.training_step((noise, ctx, vt), m, num_train_timesteps=1000)
+    assert abs(loss - float(g["loss"])) < 2e-2 * float(g["loss"])
+    assert rel_rms(m.blocks[0].self_attn.q.weight.grad, torch.from_numpy(g["blocks.0.self_attn.q.weight"])) < TOL_GRAD
