@@ -55,7 +55,8 @@ enum {
     OMH_EPI_F32       = 1,  /* C fp32  = acc + bias                               */
     OMH_EPI_GELU_BF16 = 2,  /* C bf16  = gelu_tanh(acc + bias)   (model.py:273)   */
     OMH_EPI_RESID     = 3,  /* C fp32 += (acc + bias) * gate     (model.py:296,313,328) */
-    OMH_EPI_F32_ACCUM = 4   /* C fp32 += acc + bias               (used by backward) */
+    OMH_EPI_F32_ACCUM = 4,  /* C fp32 += acc + bias               (used by backward) */
+    OMH_EPI_GELU_ERF_BF16 = 5 /* C bf16 = gelu_erf(acc + bias)    (i2v MLPProj, model.py:369) */
 };
 enum { OMH_BIAS_NONE = 0, OMH_BIAS_N = 1, OMH_BIAS_M = 2 };
 

@@ -69,7 +69,7 @@ class ConvArgs(C.Structure):
                 ("up2", i32), ("out_f32", i32), ("split_n", i32)]
 
 
-EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID, EPI_F32_ACCUM = 0, 1, 2, 3, 4
+EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID, EPI_F32_ACCUM, EPI_GELU_ERF_BF16 = 0, 1, 2, 3, 4, 5
 BIAS_NONE, BIAS_N, BIAS_M = 0, 1, 2
 
 _SIGS = {

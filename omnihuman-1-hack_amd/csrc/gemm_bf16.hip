@@ -150,6 +150,10 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
                 }
+                if (EPI == OMH_EPI_GELU_ERF_BF16) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.7071067811865476f));
+                }
                 if (EPI == OMH_EPI_RESID) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -162,7 +166,7 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
                     }
                 }
                 const int64_t off = (int64_t)m * p.ldc + n;
-                if (EPI == OMH_EPI_BF16 || EPI == OMH_EPI_GELU_BF16) {
+                if (EPI == OMH_EPI_BF16 || EPI == OMH_EPI_GELU_BF16 || EPI == OMH_EPI_GELU_ERF_BF16) {
                     if (full) {
                         uint2 pk;
                         pk.x = pack_bf2(v[0], v[1]);
@@ -222,6 +226,7 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
         case OMH_EPI_GELU_BF16: return launch<OMH_EPI_GELU_BF16>(a, s);
         case OMH_EPI_RESID:     return launch<OMH_EPI_RESID>(a, s);
         case OMH_EPI_F32_ACCUM: return launch<OMH_EPI_F32_ACCUM>(a, s);
+        case OMH_EPI_GELU_ERF_BF16: return launch<OMH_EPI_GELU_ERF_BF16>(a, s);
         default: return OMH_E_BADARG;
     }
 }

@@ -10,13 +10,13 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (BIAS_M, BIAS_N, BIAS_NONE, EPI_BF16, EPI_F32, EPI_F32_ACCUM, EPI_GELU_BF16, EPI_RESID,
+from ._lib import (BIAS_M, BIAS_N, BIAS_NONE, EPI_BF16, EPI_F32, EPI_F32_ACCUM, EPI_GELU_BF16, EPI_GELU_ERF_BF16, EPI_RESID,
                    AttnArgs, GemmArgs, OmhError, check, lib)
 
 __all__ = ["gemm", "flash_attn", "layernorm_modulate", "rmsnorm_rope", "cast_bf16", "patchify", "unpatchify",
            "dense_f32", "sinusoidal_embedding", "cfg_unipc_step", "conv_cl", "rms_silu_cl", "nchw_to_cl", "cl_to_nchw",
            "softmax_rows", "OmhError",
-           "EPI_BF16", "EPI_F32", "EPI_GELU_BF16", "EPI_RESID", "EPI_F32_ACCUM", "BIAS_NONE", "BIAS_N", "BIAS_M"]
+           "EPI_BF16", "EPI_F32", "EPI_GELU_BF16", "EPI_GELU_ERF_BF16", "EPI_RESID", "EPI_F32_ACCUM", "BIAS_NONE", "BIAS_N", "BIAS_M"]
 
 
 def _stream():
@@ -57,7 +57,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, b
     N = w.shape[0]
     assert w.shape[1] == K and a.stride(1) == 1 and w.stride(1) == 1
     if out is None:
-        odt = torch.bfloat16 if epilogue in (EPI_BF16, EPI_GELU_BF16) else torch.float32
+        odt = torch.bfloat16 if epilogue in (EPI_BF16, EPI_GELU_BF16, EPI_GELU_ERF_BF16) else torch.float32
         out = torch.empty(M, N, dtype=odt, device=a.device)
     gemm_raw(_p(a), _p(w), _p(out), M, N, K, a.stride(0), w.stride(0), out.stride(0), epilogue,
              bias=_p(bias), bias_mode=BIAS_N if bias is not None else BIAS_NONE)

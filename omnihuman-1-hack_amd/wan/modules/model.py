@@ -396,8 +396,24 @@ class MLPProj(nn.Module):
                                   nn.Linear(in_dim, out_dim), nn.LayerNorm(out_dim))
         self._packed = _Packed()
 
+    def _w(self, i):
+        lin = self.proj[i]
+        return self._packed.get(f"l{i}", (lin.weight, lin.bias),
+                                lambda: (_bf16(lin.weight), lin.bias.detach().float().contiguous()))
+
     def forward(self, image_embeds):
-        raise NotImplementedError("i2v image-embedding projection: not built yet in this round")
+        """[B, 257, 1280] CLIP tokens -> bf16 [B, 257, out_dim]  (LayerNorm, Linear, GELU(erf), Linear, LayerNorm)."""
+        B, L, Cin = image_embeds.shape
+        x = image_embeds.float().contiguous().view(B * L, Cin)
+        ln0, ln4 = self.proj[0], self.proj[4]
+        h = ops.layernorm_modulate(x, ln0.eps, 0.0, mul0=ln0.weight.detach().float(), add0=ln0.bias.detach().float())
+        w1, b1 = self._w(1)
+        w3, b3 = self._w(3)
+        h = ops.gemm(h, w1, bias=b1, epilogue=ops.EPI_GELU_ERF_BF16)
+        h = ops.gemm(h, w3, bias=b3, epilogue=EPI_F32)
+        out = ops.layernorm_modulate(h, ln4.eps, 0.0, mul0=ln4.weight.detach().float(),
+                                     add0=ln4.bias.detach().float())
+        return out.view(B, L, -1)
 
 
 def _rope_tables(freqs: torch.Tensor, device):

@@ -89,3 +89,22 @@ def test_wan_1_3b_single_frame_cfg_pair():
     ref_u = O.dit_forward(sd, cfg, [noise], t, [cneg], 1560)[0]
     assert rel_rms(u, ref_u) < TOL_FULL
     assert rel_rms(v, ref) < 0.2
+
+
+def test_tiny_i2v_model_matches_oracle_and_reference_vectors(wan_model_mod):
+    """i2v: 36 input channels (latent + mask/first-frame `y`), CLIP tokens through img_emb, the extra
+    image-token attention (model.py:189-230, 362-374, 511-512, 534-537)."""
+    import os
+    import numpy as np
+    from oracle import make_golden
+    cfg, tag, xs, ctx, tt, seq_len, ys, clip = make_golden.tiny_case("i2v", 2)
+    from oracle import wan_dit_oracle as O
+    sd = O.synth_state_dict(cfg, tag)
+    m = wan_model_mod.WanModel(model_type="i2v", in_dim=36, num_layers=2, **make_golden.TINY)
+    m.load_state_dict(sd)
+    m = m.cuda().eval().requires_grad_(False)
+    out = m([u.cuda() for u in xs], tt.cuda(), [c.cuda() for c in ctx], seq_len, clip_fea=clip.cuda(),
+            y=[u.cuda() for u in ys])
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dit_i2v_L2.npz"))
+    for o, k in zip(out, ("out0", "out1")):
+        assert rel_rms(o, torch.from_numpy(g[k])) < TOL_TINY      # straight against the reference's own output
