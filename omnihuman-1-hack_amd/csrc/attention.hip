@@ -33,6 +33,14 @@ constexpr int KB = 64;    // keys per tile
 constexpr int KT_BYTES = KB * D * 2;   // 16 KiB
 constexpr int VT_BYTES = D * KB * 2;   // 16 KiB
 
+// combine a value with the one held by lane l^32 (the other half of the same query row):
+// one v_permlane32_swap instead of a ds_bpermute round trip through the LDS pipe
+__device__ __forceinline__ void xhalf(float x, float& lo, float& hi) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    lo = __uint_as_float(r[0]);
+    hi = __uint_as_float(r[1]);
+}
+
 __device__ __forceinline__ int swap_bits23(int i) {
     return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
 }
@@ -75,30 +83,40 @@ void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles) {
     for (int kk = 0; kk < 8; ++kk)
         qf[kk] = *(const bf16x8*)(Q + (int64_t)q_ld * p.q_rs + kk * 16 + lh * 8);
 
-    // ---- staging: 4 K chunks + 4 V^T chunks of 16 bytes per thread and tile
+    // ---- staging: 4 K chunks + 4 V^T chunks of 16 bytes per thread and tile, fetched with buffer
+    // loads: the descriptor (SGPRs) carries base + extent, so the per-tile address is ONE v_add per
+    // load and rows past the end of K read as zero in hardware (no clamping / select VALU).
     // K tile: chunk c -> row c>>4 (key), slot c&15 ; V^T tile: row c>>3 (d), slot c&7
-    uint4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-#define OMH_GLOAD1(RK, RV, J, KV0)                                                              \
-    {                                                                                           \
-        const int c_ = tid + 256 * (J);                                                         \
-        const int krow_ = min((KV0) + (c_ >> 4), p.Lk - 1);                                     \
-        RK = *(const uint4*)(K + (int64_t)krow_ * p.k_rs + (c_ & 15) * 8);                      \
-        const int vcol_ = (KV0) + (c_ & 7) * 8;                                                 \
-        RV = *(const uint4*)(VT + (int64_t)(c_ >> 3) * p.ldv + min(vcol_, p.ldv - 8));          \
-        if (vcol_ + 8 > p.ldv) RV = zero4;                                                      \
+    const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)K, 0, (int)((((int64_t)p.Lk - 1) * p.k_rs + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)VT, 0, (int)((int64_t)D * p.ldv * 2), 0x00020000);
+    uint32_t voff_k[4], voff_v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = tid + 256 * j;
+        voff_k[j] = (uint32_t)(((c >> 4) * (int)p.k_rs + (c & 15) * 8) * 2);
+        voff_v[j] = (uint32_t)(((c >> 3) * p.ldv + (c & 7) * 8) * 2);
     }
+    const uint32_t k_tile_bytes = (uint32_t)(KB * (int)p.k_rs * 2), v_tile_bytes = KB * 2;
+    u32x4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
 #define OMH_GLOAD(T)                                                                            \
     {                                                                                           \
-        const int kv0_ = (T) * KB;                                                              \
-        OMH_GLOAD1(rk0, rv0, 0, kv0_) OMH_GLOAD1(rk1, rv1, 1, kv0_)                             \
-        OMH_GLOAD1(rk2, rv2, 2, kv0_) OMH_GLOAD1(rk3, rv3, 3, kv0_)                             \
+        const uint32_t ko_ = (uint32_t)(T) * k_tile_bytes, vo_ = (uint32_t)(T) * v_tile_bytes;  \
+        rk0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_k, voff_k[0] + ko_, 0, 0);             \
+        rk1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_k, voff_k[1] + ko_, 0, 0);             \
+        rk2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_k, voff_k[2] + ko_, 0, 0);             \
+        rk3 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_k, voff_k[3] + ko_, 0, 0);             \
+        rv0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, voff_v[0] + vo_, 0, 0);             \
+        rv1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, voff_v[1] + vo_, 0, 0);             \
+        rv2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, voff_v[2] + vo_, 0, 0);             \
+        rv3 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, voff_v[3] + vo_, 0, 0);             \
     }
 #define OMH_LSTORE1(RK, RV, J, KT, VTL)                                                         \
     {                                                                                           \
         const int c_ = tid + 256 * (J);                                                         \
-        *(uint4*)((KT) + k_addr(c_ >> 4, c_ & 15)) = RK;                                        \
-        *(uint4*)((VTL) + v_addr(c_ >> 3, c_ & 7)) = RV;                                        \
+        *(u32x4*)((KT) + k_addr(c_ >> 4, c_ & 15)) = RK;                                        \
+        *(u32x4*)((VTL) + v_addr(c_ >> 3, c_ & 7)) = RV;                                        \
     }
 #define OMH_LSTORE(BUF)                                                                         \
     {                                                                                           \
@@ -129,21 +147,23 @@ void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles) {
         const unsigned char* kt = smem + buf * (KT_BYTES + VT_BYTES);
         const unsigned char* vt = kt + KT_BYTES;
 
-        // ---- S^T = K Q^T : two 32-key blocks
+        // ---- S^T = K Q^T : two 32-key blocks; the two accumulators alternate so that
+        //      consecutive MFMAs never wait on each other's result
         f32x16 s[2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                const bf16x8 kf = *(const bf16x8*)(kt + k_addr(kb * 32 + krow_l, 2 * kk + lh));
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kb], 0, 0, 0);
-            }
+        for (int kk = 0; kk < 8; ++kk) {
+            const bf16x8 kf0 = *(const bf16x8*)(kt + k_addr(krow_l, 2 * kk + lh));
+            const bf16x8 kf1 = *(const bf16x8*)(kt + k_addr(32 + krow_l, 2 * kk + lh));
+            s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[kk], s[0], 0, 0, 0);
+            s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[kk], s[1], 0, 0, 0);
         }
         // register r of block kb  <->  key kv0 + 32kb + 16(r>>3) + 8h + (r&7)
         const int kv0 = t * KB;
-        if (kv0 + KB > klen) {
+        if (__builtin_expect(kv0 + KB > klen, 0)) {   // only the last tile of a sequence
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -158,7 +178,7 @@ void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles) {
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        { float a_, b_; xhalf(mx, a_, b_); mx = fmaxf(a_, b_); }
         const float m_new = fmaxf(m_run, mx * sc);
         const float alpha = fast_exp2(m_run - m_new);
         m_run = m_new;
@@ -171,7 +191,7 @@ void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles) {
                 s[kb][r] = pv;
                 rs += pv;
             }
-        rs += __shfl_xor(rs, 32, 64);
+        { float a_, b_; xhalf(rs, a_, b_); rs = a_ + b_; }
         l_run = l_run * alpha + rs;
         if (!__all(alpha == 1.0f)) {          // wave-uniform: after the first tiles the running max rarely moves
 #pragma unroll
@@ -192,13 +212,13 @@ void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles) {
                     cv[e] = pack_bf2(s[kb][8 * a + 2 * e], s[kb][8 * a + 2 * e + 1]);
                 pf[kb][a] = __builtin_bit_cast(bf16x8, cv);
             }
-        // ---- O^T += V^T P^T
+        // ---- O^T += V^T P^T : four independent accumulators in rotation
 #pragma unroll
-        for (int db = 0; db < 4; ++db)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int a = 0; a < 2; ++a) {
+                for (int db = 0; db < 4; ++db) {
                     const bf16x8 vf = *(const bf16x8*)(vt + v_addr(db * 32 + li, 4 * kb + 2 * a + lh));
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][a], oacc[db], 0, 0, 0);
                 }

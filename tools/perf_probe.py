@@ -44,8 +44,9 @@ def main():
     vt = torch.zeros(1, H * D, Sp, dtype=torch.bfloat16, device="cuda")
     vt[:, :, :S] = torch.randn(1, H * D, S, device="cuda").to(torch.bfloat16)
     o = torch.empty_like(q)
-    ms = timeit(lambda: ops.flash_attn(q, k, vt, None, out=o), iters=5, warm=2)
-    res["self_attn"] = {"ms": ms, "tflops": 4.0 * S * S * H * D / ms / 1e9}
+    runs = sorted(timeit(lambda: ops.flash_attn(q, k, vt, None, out=o), iters=4, warm=1) for _ in range(5))
+    ms = runs[len(runs) // 2]
+    res["self_attn"] = {"ms": ms, "ms_min": runs[0], "ms_max": runs[-1], "tflops": 4.0 * S * S * H * D / ms / 1e9}
     xf = torch.randn(S, d, device="cuda")
     mod = torch.randn(6, d, device="cuda")
     y = torch.empty(S, d, dtype=torch.bfloat16, device="cuda")
