@@ -4,21 +4,30 @@
 // (seaweed_apt/wan/modules/model.py:125-128,160,176-178,185,272-274,344,465-467)
 // and the patch-embedding Conv3d-as-GEMM (model.py:463,515).
 //
-// Tiling: 128(m) x 128(n) x 64(k) per 256-thread workgroup, 4 waves as 2x2,
-// each wave a 64x64 sub-tile = 2x2 v_mfma_f32_32x32x16_bf16 accumulators.
+// Tiling (two instantiations, picked per problem size):
+//   big   256(m) x 256(n) x 64(k), 512 threads = 8 waves as 2(m) x 4(n), wave tile 128x64
+//         (4x2 MFMA accumulators): 128 flop per operand byte, for the S = 32 760 GEMMs;
+//   small 128(m) x 128(n) x 64(k), 256 threads = 4 waves as 2x2, wave tile 64x64, two
+//         workgroups per CU: keeps 256 CUs busy when M*N is small (context, training clips).
+// Each MFMA is v_mfma_f32_32x32x16_bf16.
 // The weight rows (n) go in the MFMA A slot and the activation rows (m) in
 // the B slot, so each lane ends up with runs of 4 consecutive n for one m:
 // 8-byte bf16 / 16-byte fp32 epilogue stores.  Both operand tiles are staged
-// HBM -> registers -> LDS ([128][64] bf16, 16-byte slots XOR-swizzled by
-// (row>>1)&7 so the ds_read_b128 fragment reads are bank-conflict free),
-// double buffered with one barrier per k-step; the next tile's global loads
-// are issued before the MFMA block of the current one.
+// HBM -> LDS directly with the LDS-DMA form of the buffer load
+// (buffer_load_dwordx4 ... lds: no VGPR round trip and, more importantly, no
+// ds_write_b128 pass — at 128x128 the register-staged version spent more LDS
+// cycles on writes+reads than the MFMA pipe spent computing).  The LDS image is
+// lane-linear per wave instruction, so the XOR swizzle ((row>>1)&7 on the
+// 16-byte slot, conflict-free ds_read_b128) is applied to the per-lane SOURCE
+// address and again on the read.  Rows past M/N and the K tail are out of the
+// buffer descriptor's range and arrive as zeros.  Double buffered, one barrier
+// per k-step; the next tile's DMA is issued before the MFMAs of the current one.
 #include "omh_common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
+constexpr int BK = 64;
 
 struct GemmGeom { int tiles_m, tiles_n; };
 
@@ -26,99 +35,101 @@ __device__ __forceinline__ uint32_t lds_slot_addr(int row, int slot) {
     return (uint32_t)(row * (BK * 2) + ((slot ^ ((row >> 1) & 7)) << 4));
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2)
+// WM x WN waves, each owning MT x NT 32x32 MFMA tiles
+template <int EPI, int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(64 * WM * WN, 2)
 void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];
+    constexpr int THREADS = 64 * WM * WN;
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int CA = BM * 8 / THREADS, CB = BN * 8 / THREADS;     // 16-byte chunks per thread and stage
+    static_assert(CA == 4 && CB == 4, "staging code assumes 4 chunks per operand per thread");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
 
     const int wid = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
-    const int tm = wid / g.tiles_n, tn = wid % g.tiles_n;
+    int tm, tn;
+    tile_of(wid, g.tiles_m, g.tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int64_t zb = blockIdx.z;
     const __bf16* __restrict__ A = (const __bf16*)p.A + zb * p.strideA;
     const __bf16* __restrict__ B = (const __bf16*)p.B + zb * p.strideB;
 
-    // staging assignment: 4 x 16-byte chunks per operand per thread
-    int st_row[4], st_slot[4];
-    const __bf16* a_src[4];
-    const __bf16* b_src[4];
+    // staging: 4 x 16-byte chunks per operand per thread.  Chunk c = tid + THREADS*j lands at LDS
+    // byte c*16 of the tile (row c>>3, physical slot c&7); it is fetched from logical slot
+    // (c&7) ^ ((row>>1)&7) of that row.  Offsets past the extent (rows >= M/N) read as zero.
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)A, 0, (int)((((int64_t)p.M - 1) * p.lda + p.K) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)B, 0, (int)((((int64_t)p.N - 1) * p.ldb + p.K) * 2), 0x00020000);
+    uint32_t voff_a[4], voff_b[4];
+    int lslot[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int c = tid + 256 * j;
-        st_row[j] = c >> 3;
-        st_slot[j] = c & 7;
-        const int am = min(m0 + st_row[j], p.M - 1);
-        const int bn = min(n0 + st_row[j], p.N - 1);
-        a_src[j] = A + (int64_t)am * p.lda + st_slot[j] * 8;
-        b_src[j] = B + (int64_t)bn * p.ldb + st_slot[j] * 8;
+        const int c = tid + THREADS * j;
+        const int row = c >> 3;
+        lslot[j] = (c & 7) ^ ((row >> 1) & 7);
+        voff_a[j] = (m0 + row < p.M) ? (uint32_t)((((int64_t)(m0 + row)) * p.lda + lslot[j] * 8) * 2) : 0x80000000u;
+        voff_b[j] = (n0 + row < p.N) ? (uint32_t)((((int64_t)(n0 + row)) * p.ldb + lslot[j] * 8) * 2) : 0x80000000u;
     }
+    // wave-uniform LDS byte offset of this wave's 1 KiB piece of chunk group j
+    const int wave_lds = __builtin_amdgcn_readfirstlane(wave) * 1024;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (p.K + BK - 1) / BK;
-    uint4 ra[4], rb[4];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#define GEMM_DMA1(RSRC, VOFF, J, DST)                                                          \
+    {                                                                                          \
+        const uint32_t ko_ = (k0_ + lslot[J] * 8 < p.K) ? (uint32_t)(k0_ * 2) : 0x80000000u;   \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(RSRC, (lds_ptr_t)((DST) + wave_lds + (J) * THREADS * 16), 16, \
+                                                 VOFF[J] + ko_, 0, 0, 0);                      \
+    }
+#define GEMM_DMA(KT_, BUF)                                                                     \
+    {                                                                                          \
+        const int k0_ = (KT_) * BK;                                                            \
+        unsigned char* xa_ = smem + (BUF) * STAGE_BYTES;                                       \
+        unsigned char* xb_ = xa_ + A_BYTES;                                                    \
+        GEMM_DMA1(rsrc_a, voff_a, 0, xa_) GEMM_DMA1(rsrc_a, voff_a, 1, xa_)                    \
+        GEMM_DMA1(rsrc_a, voff_a, 2, xa_) GEMM_DMA1(rsrc_a, voff_a, 3, xa_)                    \
+        GEMM_DMA1(rsrc_b, voff_b, 0, xb_) GEMM_DMA1(rsrc_b, voff_b, 1, xb_)                    \
+        GEMM_DMA1(rsrc_b, voff_b, 2, xb_) GEMM_DMA1(rsrc_b, voff_b, 3, xb_)                    \
+    }
 
-    auto gload = [&](int kt) {
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // K % 8 == 0: a chunk is entirely inside or outside [0, K); read a
-            // clamped in-bounds address and zero the value (no divergent pointers)
-            const int kc = k0 + st_slot[j] * 8;
-            const int kd = min(kc, p.K - 8) - st_slot[j] * 8;
-            ra[j] = *(const uint4*)(a_src[j] + kd);
-            rb[j] = *(const uint4*)(b_src[j] + kd);
-            if (kc >= p.K) { ra[j] = zero4; rb[j] = zero4; }
-        }
-    };
-    auto lstore = [&](int buf) {
-        unsigned char* xa = smem + buf * 2 * TILE_BYTES;
-        unsigned char* xb = xa + TILE_BYTES;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t off = lds_slot_addr(st_row[j], st_slot[j]);
-            *(uint4*)(xa + off) = ra[j];
-            *(uint4*)(xb + off) = rb[j];
-        }
-    };
-
-    gload(0);
-    lstore(0);
-    __syncthreads();
+    GEMM_DMA(0, 0)
+    __syncthreads();                                             // waits for the DMA (vmcnt) and the barrier
 
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
-        const unsigned char* xa = smem + buf * 2 * TILE_BYTES;   // activations (m)
-        const unsigned char* xb = xa + TILE_BYTES;               // weights (n)
+        if (kt + 1 < nk) GEMM_DMA(kt + 1, buf ^ 1)               // next tile straight into the other buffer
+        const unsigned char* xa = smem + buf * STAGE_BYTES;      // activations (m)
+        const unsigned char* xb = xa + A_BYTES;                  // weights (n)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 wf[2], xf[2];
+            bf16x8 wf[NT], xf[MT];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                wf[i] = *(const bf16x8*)(xb + lds_slot_addr(wn * 64 + i * 32 + li, 2 * kk + lh));
-                xf[i] = *(const bf16x8*)(xa + lds_slot_addr(wm * 64 + i * 32 + li, 2 * kk + lh));
-            }
+            for (int i = 0; i < NT; ++i)
+                wf[i] = *(const bf16x8*)(xb + lds_slot_addr((wn * NT + i) * 32 + li, 2 * kk + lh));
 #pragma unroll
-            for (int im = 0; im < 2; ++im)
+            for (int i = 0; i < MT; ++i)
+                xf[i] = *(const bf16x8*)(xa + lds_slot_addr((wm * MT + i) * 32 + li, 2 * kk + lh));
 #pragma unroll
-                for (int in = 0; in < 2; ++in)
+            for (int im = 0; im < MT; ++im)
+#pragma unroll
+                for (int in = 0; in < NT; ++in)
                     acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[in], xf[im], acc[im][in], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
 
@@ -127,16 +138,16 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
     float* Cf = (float*)p.C + zb * p.strideC;
     uint16_t* Ch = (uint16_t*)p.C + zb * p.strideC;
 #pragma unroll
-    for (int im = 0; im < 2; ++im) {
-        const int m = m0 + wm * 64 + im * 32 + li;
+    for (int im = 0; im < MT; ++im) {
+        const int m = m0 + (wm * MT + im) * 32 + li;
         if (m >= p.M) continue;
         const float bias_m = (p.bias_mode == OMH_BIAS_M && p.bias) ? p.bias[m] : 0.f;
         const int64_t gb = (EPI == OMH_EPI_RESID && p.gate1) ? (int64_t)(m / p.gate_rows) * p.gate1_stride : 0;
 #pragma unroll
-        for (int in = 0; in < 2; ++in) {
+        for (int in = 0; in < NT; ++in) {
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                const int n = n0 + wn * 64 + in * 32 + 8 * gq + 4 * lh;
+                const int n = n0 + (wn * NT + in) * 32 + 8 * gq + 4 * lh;
                 if (n >= p.N) continue;
                 float v[4];
 #pragma unroll
@@ -198,15 +209,33 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
     }
 }
 
-template <int EPI>
-int launch(const omh_gemm_args& a, hipStream_t s) {
+template <int EPI, int WM, int WN, int MT, int NT>
+int launch_cfg(const omh_gemm_args& a, hipStream_t s) {
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+    constexpr int LDS = 2 * (BM + BN) * BK * 2;
+    auto kern = gemm_bf16_nt_kernel<EPI, WM, WN, MT, NT>;
+    static bool attr_set = false;            // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
     GemmGeom g;
     g.tiles_m = (a.M + BM - 1) / BM;
     g.tiles_n = (a.N + BN - 1) / BN;
     dim3 grid(g.tiles_m * g.tiles_n, 1, a.batch);
     omh_clear_status();
-    hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, grid, dim3(256), 0, s, a, g);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), LDS, s, a, g);
     return omh_launch_status();
+}
+
+template <int EPI>
+int launch(const omh_gemm_args& a, hipStream_t s) {
+    // big tiles once they alone fill the chip (>= one workgroup per CU), small tiles otherwise
+    const int64_t big_tiles = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) * a.batch;
+    static const char* force = getenv("OMH_GEMM_TILE");        // "big" / "small": benchmarking override
+    const bool big = force ? (force[0] == 'b') : (big_tiles >= 256);
+    if (big) return launch_cfg<EPI, 2, 4, 4, 2>(a, s);
+    return launch_cfg<EPI, 2, 2, 2, 2>(a, s);
 }
 
 }  // namespace
@@ -219,6 +248,9 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
     if (((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15) || ((uintptr_t)a.C & 15)) return OMH_E_ALIGN;
     if ((a.strideA & 7) || (a.strideB & 7) || (a.strideC & 3)) return OMH_E_ALIGN;
     if (a.epilogue == OMH_EPI_RESID && a.gate1 && a.gate_rows <= 0) return OMH_E_BADARG;
+    // 32-bit buffer offsets: each operand (one batch element) must stay below 2 GiB
+    if (((int64_t)a.M + 128) * a.lda * 2 >= 0x7fffffffLL || ((int64_t)a.N + 128) * a.ldb * 2 >= 0x7fffffffLL)
+        return OMH_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     switch (a.epilogue) {
         case OMH_EPI_BF16:      return launch<OMH_EPI_BF16>(a, s);

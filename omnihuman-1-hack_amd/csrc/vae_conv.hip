@@ -39,7 +39,8 @@ void conv_cl_kernel(const omh_conv_args p, const int tiles_m, const int tiles_n)
     const int li = lane & 31, lh = lane >> 5;
 
     const int wid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tm = wid / tiles_n, tn = wid % tiles_n;
+    int tm, tn;
+    tile_of(wid, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int M = p.Tout * p.Hout * p.Wout;
     const int K = p.KT * p.KH * p.KW * p.Cin;
