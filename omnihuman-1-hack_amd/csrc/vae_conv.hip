@@ -14,10 +14,11 @@
 // out-of-range rows/columns contribute zero.
 //
 // GEMM view: M = Tout*Hout*Wout output voxels, N = Cout, K = taps*Cin with the
-// k index running (tap, ci); same 128x128x64 MFMA tile, LDS swizzle and
-// register-staged double buffering as gemm_bf16.hip — only the A-operand
-// loader differs: each 16-byte chunk (8 channels of one tap) is gathered from
-// the shifted voxel, so the 27-fold re-read of the input stays in L2.
+// k index running (tap, ci); same 128x128x64 MFMA tile, LDS swizzle and LDS-DMA
+// double buffering as the small configuration of gemm_bf16.hip — only the
+// A-operand source differs: each 16-byte chunk (8 channels of one tap) is
+// fetched from the shifted voxel (out-of-image taps get an out-of-range buffer
+// offset and arrive as zeros), so the 27-fold re-read of the input stays in L2.
 #include "omh_common.h"
 
 namespace {
@@ -49,21 +50,31 @@ void conv_cl_kernel(const omh_conv_args p, const int tiles_m, const int tiles_n)
     const __bf16* __restrict__ X = (const __bf16*)p.x;
     const __bf16* __restrict__ Wt = (const __bf16*)p.w;
 
-    // per-thread staging rows: voxel coordinates of the 4 A rows, weight rows of the 4 B rows
-    int slot = tid & 7;
+    // staging: chunk c = tid + 256 j lands at LDS byte 16 c of the tile (row c>>3, physical slot c&7) and
+    // is fetched from logical slot (c&7) ^ ((row>>1)&7).  The four rows of a thread are 32 apart, so they
+    // share the logical slot: one (tap, channel) decode per thread and k-step.
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)X, 0, (int)((int64_t)p.Tin * p.Hin * p.Win * p.Cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)Wt, 0, (int)((int64_t)p.Cout * K * 2), 0x00020000);
+    const int lslot = (tid & 7) ^ ((tid >> 4) & 7);
     int a_t[4], a_y[4], a_x[4];
-    const __bf16* b_src[4];
+    bool a_ok[4];
+    uint32_t voff_w[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int row = (tid + 256 * j) >> 3;
-        const int m = min(m0 + row, M - 1);
-        const int xo = m % p.Wout, yo = (m / p.Wout) % p.Hout, to = m / (p.Wout * p.Hout);
+        const int m = m0 + row;
+        a_ok[j] = m < M;
+        const int mc = min(m, M - 1);
+        const int xo = mc % p.Wout, yo = (mc / p.Wout) % p.Hout, to = mc / (p.Wout * p.Hout);
         a_t[j] = to * p.stride_t;
         a_y[j] = yo * p.stride_hw - p.pad_h;
         a_x[j] = xo * p.stride_hw - p.pad_w;
-        const int bn = min(n0 + row, p.Cout - 1);
-        b_src[j] = Wt + (int64_t)bn * K + slot * 8;
+        voff_w[j] = (n0 + row < p.Cout) ? (uint32_t)(((int64_t)(n0 + row) * K + lslot * 8) * 2) : 0x80000000u;
     }
+    const int wave_lds = __builtin_amdgcn_readfirstlane(wave) * 1024;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -74,55 +85,37 @@ void conv_cl_kernel(const omh_conv_args p, const int tiles_m, const int tiles_n)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (K + BK - 1) / BK;
-    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
 
-#define CONV_GLOAD1(RA, RB, J, KC, TAP_T, TAP_Y, TAP_X, CI, KOK)                                   \
+#define CONV_DMA1(J, XA, XB)                                                                       \
     {                                                                                              \
-        const int iy = a_y[J] + (TAP_Y), ix = a_x[J] + (TAP_X);                                    \
-        const bool ok = (KOK) && iy >= 0 && iy < Heff && ix >= 0 && ix < Weff;                     \
-        const int sy = p.up2 ? (max(iy, 0) >> 1) : max(iy, 0);                                     \
-        const int sx = p.up2 ? (max(ix, 0) >> 1) : max(ix, 0);                                     \
-        const int cy = min(sy, p.Hin - 1), cx = min(sx, p.Win - 1);                                \
-        const int64_t off = (((int64_t)(a_t[J] + (TAP_T)) * p.Hin + cy) * p.Win + cx) * p.Cin + (CI); \
-        RA = *(const uint4*)(X + off);                                                             \
-        if (!ok) RA = zero4;                                                                       \
-        RB = *(const uint4*)(b_src[J] + (KC) - slot * 8);                                          \
-        if (!(KOK)) RB = zero4;                                                                    \
+        const int iy = a_y[J] + tap_y, ix = a_x[J] + tap_x;                                        \
+        const bool ok = kok && a_ok[J] && iy >= 0 && iy < Heff && ix >= 0 && ix < Weff;            \
+        const int sy = p.up2 ? (iy >> 1) : iy, sx = p.up2 ? (ix >> 1) : ix;                        \
+        const uint32_t xo_ = ok ? (uint32_t)(((((a_t[J] + tap_t) * p.Hin + sy) * p.Win + sx) * p.Cin + ci) * 2) \
+                                : 0x80000000u;                                                     \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)((XA) + wave_lds + (J) * 4096), 16, xo_, 0, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)((XB) + wave_lds + (J) * 4096), 16,               \
+                                                 voff_w[J] + wko, 0, 0, 0);                        \
     }
-#define CONV_GLOAD(KT_)                                                                            \
+#define CONV_DMA(KT_, BUF)                                                                         \
     {                                                                                              \
-        const int kc_raw = (KT_) * BK + slot * 8;                                                  \
-        const bool kok = kc_raw < K;                                                               \
-        const int kc = min(kc_raw, K - 8);                                                         \
-        const int tap = kc / p.Cin, ci = kc - tap * p.Cin;                                         \
+        const int kc = (KT_) * BK + lslot * 8;                                                     \
+        const bool kok = kc < K;                                                                   \
+        const uint32_t wko = kok ? (uint32_t)((KT_) * BK * 2) : 0x80000000u;                       \
+        const int kcc = min(kc, K - 8);                                                            \
+        const int tap = kcc / p.Cin, ci = kcc - tap * p.Cin;                                       \
         const int tap_x = tap % p.KW, tap_y = (tap / p.KW) % p.KH, tap_t = tap / (p.KW * p.KH);    \
-        CONV_GLOAD1(ra0, rb0, 0, kc, tap_t, tap_y, tap_x, ci, kok)                                 \
-        CONV_GLOAD1(ra1, rb1, 1, kc, tap_t, tap_y, tap_x, ci, kok)                                 \
-        CONV_GLOAD1(ra2, rb2, 2, kc, tap_t, tap_y, tap_x, ci, kok)                                 \
-        CONV_GLOAD1(ra3, rb3, 3, kc, tap_t, tap_y, tap_x, ci, kok)                                 \
-    }
-#define CONV_LSTORE1(RA, RB, J, XA, XB)                                                            \
-    {                                                                                              \
-        const uint32_t off = lds_slot_addr((tid + 256 * (J)) >> 3, slot);                          \
-        *(uint4*)((XA) + off) = RA;                                                                \
-        *(uint4*)((XB) + off) = RB;                                                                \
-    }
-#define CONV_LSTORE(BUF)                                                                           \
-    {                                                                                              \
         unsigned char* xa_ = smem + (BUF) * 2 * TILE_BYTES;                                        \
         unsigned char* xb_ = xa_ + TILE_BYTES;                                                     \
-        CONV_LSTORE1(ra0, rb0, 0, xa_, xb_) CONV_LSTORE1(ra1, rb1, 1, xa_, xb_)                    \
-        CONV_LSTORE1(ra2, rb2, 2, xa_, xb_) CONV_LSTORE1(ra3, rb3, 3, xa_, xb_)                    \
+        CONV_DMA1(0, xa_, xb_) CONV_DMA1(1, xa_, xb_) CONV_DMA1(2, xa_, xb_) CONV_DMA1(3, xa_, xb_) \
     }
 
-    CONV_GLOAD(0)
-    CONV_LSTORE(0)
+    CONV_DMA(0, 0)
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        CONV_GLOAD(min(kt + 1, nk - 1))
+        if (kt + 1 < nk) CONV_DMA(kt + 1, buf ^ 1)
         const unsigned char* xa = smem + buf * 2 * TILE_BYTES;   // voxels (m)
         const unsigned char* xb = xa + TILE_BYTES;               // weights (n)
 #pragma unroll
@@ -139,7 +132,6 @@ void conv_cl_kernel(const omh_conv_args p, const int tiles_m, const int tiles_n)
                 for (int in = 0; in < 2; ++in)
                     acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[in], xf[im], acc[im][in], 0, 0, 0);
         }
-        CONV_LSTORE(buf ^ 1)
         __syncthreads();
     }
 
@@ -218,6 +210,8 @@ extern "C" int omh_conv_cl_bf16(const omh_conv_args* args, omh_stream_t stream) 
         return OMH_E_ALIGN;
     const int64_t M = (int64_t)a.Tout * a.Hout * a.Wout;
     if (M > 0x7fffffff) return OMH_E_SHAPE;
+    // 32-bit buffer offsets
+    if ((int64_t)a.Tin * a.Hin * a.Win * a.Cin * 2 >= 0x7fffffffLL) return OMH_E_SHAPE;
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (a.Cout + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n);
     omh_clear_status();
