@@ -12,9 +12,10 @@
 
 namespace {
 
-constexpr int MAXV = 32;   // float4 chunks per lane -> dim <= 8192
+constexpr int MAXV_GENERIC = 32;   // float4 chunks per lane -> dim <= 8192 (specialised: 6 = 1536, 20 = 5120)
 
 // ------------------------------------------------------------------ LayerNorm + modulate
+template <int MAXV>
 __global__ __launch_bounds__(256)
 void layernorm_modulate_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t rows, int dim,
                                float eps, float mul_const, const float* __restrict__ mul0,
@@ -72,6 +73,7 @@ void layernorm_modulate_kernel(const float* __restrict__ x, uint16_t* __restrict
 }
 
 // ------------------------------------------------------------------ RMSNorm (+RoPE)
+template <int MAXV>
 __global__ __launch_bounds__(256)
 void rmsnorm_rope_kernel(const float* __restrict__ x, int64_t ldx, uint16_t* __restrict__ y, int64_t rows,
                          int dim, const float* __restrict__ weight, float eps, int do_norm,
@@ -272,10 +274,12 @@ extern "C" int omh_layernorm_modulate(const float* x, void* y, int64_t rows, int
                                       const float* add0, const float* add1, int64_t add1_stride,
                                       int64_t rows_per_batch, omh_stream_t stream) {
     if (!x || !y || rows <= 0 || dim <= 0 || rows_per_batch <= 0) return OMH_E_BADARG;
-    if ((dim & 3) || dim > MAXV * 256) return OMH_E_SHAPE;
+    if ((dim & 3) || dim > MAXV_GENERIC * 256) return OMH_E_SHAPE;
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 7) || (mul1_stride & 3) || (add1_stride & 3)) return OMH_E_ALIGN;
     omh_clear_status();
-    hipLaunchKernelGGL(layernorm_modulate_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+    auto kern = dim <= 6 * 256 ? layernorm_modulate_kernel<6>
+                               : (dim <= 20 * 256 ? layernorm_modulate_kernel<20> : layernorm_modulate_kernel<MAXV_GENERIC>);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
                        (hipStream_t)stream, x, (uint16_t*)y, rows, dim, eps, mul_const, mul0, mul1, mul1_stride,
                        add0, add1, add1_stride, rows_per_batch);
     return omh_launch_status();
@@ -286,12 +290,13 @@ extern "C" int omh_rmsnorm_rope(const float* x, int64_t ldx, void* y, int64_t ro
                                 const float* rope_sin, int32_t rope_len, int32_t head_dim, const int32_t* grid,
                                 int32_t seq_len, omh_stream_t stream) {
     if (!x || !y || rows <= 0 || dim <= 0) return OMH_E_BADARG;
-    if ((dim & 3) || dim > MAXV * 256 || (ldx & 3)) return OMH_E_SHAPE;
+    if ((dim & 3) || dim > MAXV_GENERIC * 256 || (ldx & 3)) return OMH_E_SHAPE;
     if (rope_cos && (!rope_sin || !grid || seq_len <= 0 || head_dim <= 0 || (head_dim & 3) || dim % head_dim))
         return OMH_E_BADARG;
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return OMH_E_ALIGN;
     omh_clear_status();
-    hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+    auto kern = dim <= 6 * 256 ? rmsnorm_rope_kernel<6> : (dim <= 20 * 256 ? rmsnorm_rope_kernel<20> : rmsnorm_rope_kernel<MAXV_GENERIC>);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        x, ldx, (uint16_t*)y, rows, dim, weight, eps, do_norm, rope_cos, rope_sin, rope_len,
                        head_dim, grid, seq_len);
     return omh_launch_status();
