@@ -122,7 +122,7 @@ def train_bench(model, device, world, dist, steps=4, warmup=2):
     par = importlib.import_module(PKG + ".parallel")
     model.train().requires_grad_(True)
     opt = optim.AdamW(model.parameters(), lr=5e-6, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
-    red = par.BucketedGradAllReduce(model.parameters(), bucket_mb=256.0) if world > 1 else None
+    red = par.BucketedGradAllReduce(model.parameters(), bucket_mb=256.0, force=bool(dist and world == 1)) if dist else None
     g = torch.Generator(device=device).manual_seed(7 + int(os.environ.get("RANK", 0)))
     batch = (torch.randn(1, 16, 1, 60, 104, device=device, generator=g),
              torch.randn(1, 512, 4096, device=device, generator=g),
@@ -183,10 +183,22 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("OMH_FORCE_DIST"):      # OMH_FORCE_DIST: exercise the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        # RCCL prints a version banner on stdout at communicator creation: keep stdout clean for the
+        # single JSON line by pointing fd 1 at stderr until the first collective has run
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=device)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     ops = importlib.import_module(PKG + ".ops")
     sched_mod = importlib.import_module(PKG + ".wan.utils.fm_solvers_unipc")

@@ -24,9 +24,10 @@ import torch.distributed as dist
 
 class BucketedGradAllReduce:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 256.0,
-                 group: Optional["dist.ProcessGroup"] = None, average: bool = True):
+                 group: Optional["dist.ProcessGroup"] = None, average: bool = True, force: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = force and dist.is_initialized()        # run the collectives even on a 1-rank group (tests)
         self.average = average
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.enabled = True
@@ -60,7 +61,7 @@ class BucketedGradAllReduce:
             self.enabled = old
 
     def _on_grad(self, p):
-        if not self.enabled or self.world == 1:
+        if not self.enabled or (self.world == 1 and not self.force):
             return
         i = self._bucket_of[id(p)]
         self._ready[i].add(id(p))
@@ -89,7 +90,7 @@ class BucketedGradAllReduce:
     def finish(self):
         """Call after ``backward()``: launches buckets that never filled (unused parameters), waits for
         all collectives and writes the averaged gradients back."""
-        if not self.enabled or self.world == 1:
+        if not self.enabled or (self.world == 1 and not self.force):
             self._reset()
             return
         for i in range(len(self.buckets)):
