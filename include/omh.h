@@ -279,6 +279,10 @@ int omh_dense_f32_bwd(const float* x, const float* W, const float* dy, float* dW
  * (GradScaler-style loss scaling, distilled_trainer.py:95,301).  step >= 1. */
 int omh_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int32_t step, float grad_scale, omh_stream_t stream);
+/* The same update for n_tensors tensors in one launch: table is a DEVICE array of n_tensors x 5 int64
+ * {param ptr, grad ptr, exp_avg ptr, exp_avg_sq ptr, numel}; all tensors share `step`. */
+int omh_adamw_multi(const int64_t* table, int32_t n_tensors, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int32_t step, float grad_scale, omh_stream_t stream);
 /* EMA of the weights, ema = decay*ema + (1-decay)*p (distilled_trainer.py:319-334). */
 int omh_ema_update(float* ema, const float* p, int64_t n, float decay, omh_stream_t stream);
 

@@ -118,84 +118,110 @@ void gated_resid_bwd_kernel(const float* __restrict__ dx, const uint16_t* __rest
 // ------------------------------------------------------------------ LayerNorm + modulate backward
 // y = xhat * mul + add ;  dx += rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * mul
 // dmul[b][c] += dy * xhat ; dadd[b][c] += dy
+// One wave walks RPW consecutive rows and keeps the per-column sums in registers, so the
+// parameter-side atomics are issued once per RPW rows (they were 2/3 of this kernel's time).
+constexpr int RPW = 8;
+
+template <int NV>
 __global__ __launch_bounds__(256)
 void layernorm_modulate_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
                                    int64_t rows, int dim, float eps, float mul_const, const float* __restrict__ mul0,
                                    const float* __restrict__ mul1, int64_t mul1_stride, float* __restrict__ dmul,
                                    float* __restrict__ dadd, int64_t dstride, int64_t rows_per_batch) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= rows) return;
     const int nv = dim >> 2;
-    const float4* xr = (const float4*)(x + row * dim);
-    const float4* gr = (const float4*)(dy + row * dim);
-    const int64_t b = row / rows_per_batch;
     const float4* m0 = (const float4*)mul0;
-    const float4* m1 = mul1 ? (const float4*)(mul1 + b * mul1_stride) : nullptr;
-    float4 v[MAXV];
-    float s = 0.f;
+    float4 am[NV], aa[NV];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) { v[i] = xr[c]; s += v[i].x + v[i].y + v[i].z + v[i].w; }
-    }
-    const float mean = wave_sum(s) / dim;
-    float q = 0.f;
+    for (int i = 0; i < NV; ++i) { am[i] = make_float4(0, 0, 0, 0); aa[i] = make_float4(0, 0, 0, 0); }
+    int64_t cur_b = row0 / rows_per_batch;
+
+    auto flush = [&](int64_t b) {
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) {
-            v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
-            q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                if (dmul) {
+                    float* d = dmul + b * dstride + 4 * c;
+                    atomicAdd(d + 0, am[i].x); atomicAdd(d + 1, am[i].y); atomicAdd(d + 2, am[i].z); atomicAdd(d + 3, am[i].w);
+                }
+                if (dadd) {
+                    float* d = dadd + b * dstride + 4 * c;
+                    atomicAdd(d + 0, aa[i].x); atomicAdd(d + 1, aa[i].y); atomicAdd(d + 2, aa[i].z); atomicAdd(d + 3, aa[i].w);
+                }
+            }
+            am[i] = make_float4(0, 0, 0, 0);
+            aa[i] = make_float4(0, 0, 0, 0);
         }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / dim + eps);
-    // pass 1: g = dy*mul, sums of g and g*xhat; parameter-side atomics
-    float sg = 0.f, sgx = 0.f;
+    };
+
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int64_t row = row0 + rr;
+        if (row >= rows) break;
+        const int64_t b = row / rows_per_batch;
+        if (b != cur_b) { flush(cur_b); cur_b = b; }
+        const float4* xr = (const float4*)(x + row * dim);
+        const float4* gr = (const float4*)(dy + row * dim);
+        const float4* m1 = mul1 ? (const float4*)(mul1 + b * mul1_stride) : nullptr;
+        float4 v[NV], g[NV];
+        float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) {
-            const float4 d = gr[c];
-            float4 mu = make_float4(mul_const, mul_const, mul_const, mul_const);
-            if (m0) { const float4 t = m0[c]; mu.x += t.x; mu.y += t.y; mu.z += t.z; mu.w += t.w; }
-            if (m1) { const float4 t = m1[c]; mu.x += t.x; mu.y += t.y; mu.z += t.z; mu.w += t.w; }
-            const float xh[4] = {v[i].x * rstd, v[i].y * rstd, v[i].z * rstd, v[i].w * rstd};
-            const float dd[4] = {d.x, d.y, d.z, d.w};
-            const float mm[4] = {mu.x, mu.y, mu.z, mu.w};
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) { v[i] = xr[c]; s += v[i].x + v[i].y + v[i].z + v[i].w; }
+        }
+        const float mean = wave_sum(s) / dim;
+        float q = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float g = dd[e] * mm[e];
-                sg += g;
-                sgx += g * xh[e];
-                if (dmul) atomicAdd(dmul + b * dstride + 4 * c + e, dd[e] * xh[e]);
-                if (dadd) atomicAdd(dadd + b * dstride + 4 * c + e, dd[e]);
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+                q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / dim + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                const float4 d = gr[c];
+                float4 mu = make_float4(mul_const, mul_const, mul_const, mul_const);
+                if (m0) { const float4 t = m0[c]; mu.x += t.x; mu.y += t.y; mu.z += t.z; mu.w += t.w; }
+                if (m1) { const float4 t = m1[c]; mu.x += t.x; mu.y += t.y; mu.z += t.z; mu.w += t.w; }
+                v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;          // xhat
+                am[i].x += d.x * v[i].x; am[i].y += d.y * v[i].y; am[i].z += d.z * v[i].z; am[i].w += d.w * v[i].w;
+                aa[i].x += d.x; aa[i].y += d.y; aa[i].z += d.z; aa[i].w += d.w;
+                g[i] = make_float4(d.x * mu.x, d.y * mu.y, d.z * mu.z, d.w * mu.w);
+                sg += g[i].x + g[i].y + g[i].z + g[i].w;
+                sgx += g[i].x * v[i].x + g[i].y * v[i].y + g[i].z * v[i].z + g[i].w * v[i].w;
+            }
+        }
+        const float mg = wave_sum(sg) / dim, mgx = wave_sum(sgx) / dim;
+        float4* dxr = (float4*)(dx + row * dim);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                float4 o = dxr[c];
+                o.x += rstd * (g[i].x - mg - v[i].x * mgx);
+                o.y += rstd * (g[i].y - mg - v[i].y * mgx);
+                o.z += rstd * (g[i].z - mg - v[i].z * mgx);
+                o.w += rstd * (g[i].w - mg - v[i].w * mgx);
+                dxr[c] = o;
             }
         }
     }
-    const float mg = wave_sum(sg) / dim, mgx = wave_sum(sgx) / dim;
-    float4* dxr = (float4*)(dx + row * dim);
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) {
-            const float4 d = gr[c];
-            float4 mu = make_float4(mul_const, mul_const, mul_const, mul_const);
-            if (m0) { const float4 t = m0[c]; mu.x += t.x; mu.y += t.y; mu.z += t.z; mu.w += t.w; }
-            if (m1) { const float4 t = m1[c]; mu.x += t.x; mu.y += t.y; mu.z += t.z; mu.w += t.w; }
-            float4 o = dxr[c];
-            o.x += rstd * (d.x * mu.x - mg - v[i].x * rstd * mgx);
-            o.y += rstd * (d.y * mu.y - mg - v[i].y * rstd * mgx);
-            o.z += rstd * (d.z * mu.z - mg - v[i].z * rstd * mgx);
-            o.w += rstd * (d.w * mu.w - mg - v[i].w * rstd * mgx);
-            dxr[c] = o;
-        }
-    }
+    flush(cur_b);
 }
 
 // ------------------------------------------------------------------ RMSNorm (+RoPE) backward
 // forward: y = rope( x * r * w ), r = rsqrt(mean(x^2)+eps).  g = unrope(dy);
 // dw[c] += g*x*r ; dx = r*(g*w) - x * r^3 * mean(x * g*w)   -> bf16
+template <int NV>
 __global__ __launch_bounds__(256)
 void rmsnorm_rope_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy,
                              uint16_t* __restrict__ dx, int64_t lddx, float* __restrict__ dw, int64_t rows, int dim,
@@ -203,69 +229,84 @@ void rmsnorm_rope_bwd_kernel(const float* __restrict__ x, int64_t ldx, const flo
                              const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, int rope_len,
                              int head_dim, const int* __restrict__ grid, int seq_len) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= rows) return;
     const int nv = dim >> 2;
-    const float4* xr = (const float4*)(x + row * ldx);
-    const float4* gr = (const float4*)(dy + row * lddy);
     const float4* wv = (const float4*)weight;
-    float4 v[MAXV];
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) { v[i] = xr[c]; q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w; }
-    }
-    const float r = do_norm ? rsqrtf(wave_sum(q) / dim + eps) : 1.0f;
-    bool rot = false;
-    int pf = 0, ph = 0, pw = 0;
     const int hc = head_dim >> 1, c3 = hc / 3, cf = hc - 2 * c3;
-    if (rope_cos) {
-        const int b = (int)(row / seq_len), s = (int)(row % seq_len);
-        const int gf = grid[3 * b], gh = grid[3 * b + 1], gw = grid[3 * b + 2];
-        if (s < gf * gh * gw) { rot = true; pf = s / (gh * gw); ph = (s / gw) % gh; pw = s % gw; }
-    }
-    float4 g[MAXV];
-    float sxg = 0.f;
+    float4 aw[NV];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) {
-            float4 t = gr[c];
-            if (rot) {
-                const int p0 = ((4 * c) % head_dim) >> 1;
+    for (int i = 0; i < NV; ++i) aw[i] = make_float4(0, 0, 0, 0);
+
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int64_t row = row0 + rr;
+        if (row >= rows) break;
+        const float4* xr = (const float4*)(x + row * ldx);
+        const float4* gr = (const float4*)(dy + row * lddy);
+        float4 v[NV], g[NV];
+        float q = 0.f;
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int pc = p0 + e;
-                    const int pos = pc < cf ? pf : (pc < cf + c3 ? ph : pw);
-                    const int idx = min(pos, rope_len - 1) * hc + pc;
-                    const float cs = rope_cos[idx], sn = rope_sin[idx];
-                    float& re = e == 0 ? t.x : t.z;
-                    float& im = e == 0 ? t.y : t.w;
-                    const float nr = re * cs + im * sn;          // rotate by -theta
-                    const float ni = -re * sn + im * cs;
-                    re = nr; im = ni;
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) { v[i] = xr[c]; q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w; }
+        }
+        const float r = do_norm ? rsqrtf(wave_sum(q) / dim + eps) : 1.0f;
+        bool rot = false;
+        int pf = 0, ph = 0, pw = 0;
+        if (rope_cos) {
+            const int b = (int)(row / seq_len), s = (int)(row % seq_len);
+            const int gf = grid[3 * b], gh = grid[3 * b + 1], gw = grid[3 * b + 2];
+            if (s < gf * gh * gw) { rot = true; pf = s / (gh * gw); ph = (s / gw) % gh; pw = s % gw; }
+        }
+        float sxg = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                float4 t = gr[c];
+                if (rot) {
+                    const int p0 = ((4 * c) % head_dim) >> 1;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int pc = p0 + e;
+                        const int pos = pc < cf ? pf : (pc < cf + c3 ? ph : pw);
+                        const int idx = min(pos, rope_len - 1) * hc + pc;
+                        const float cs = rope_cos[idx], sn = rope_sin[idx];
+                        float& re = e == 0 ? t.x : t.z;
+                        float& im = e == 0 ? t.y : t.w;
+                        const float nr = re * cs + im * sn;          // rotate by -theta
+                        const float ni = -re * sn + im * cs;
+                        re = nr; im = ni;
+                    }
                 }
+                aw[i].x += t.x * v[i].x * r; aw[i].y += t.y * v[i].y * r;
+                aw[i].z += t.z * v[i].z * r; aw[i].w += t.w * v[i].w * r;
+                if (wv) { const float4 w4 = wv[c]; t.x *= w4.x; t.y *= w4.y; t.z *= w4.z; t.w *= w4.w; }
+                g[i] = t;
+                sxg += v[i].x * t.x + v[i].y * t.y + v[i].z * t.z + v[i].w * t.w;
             }
-            if (dw) {
-                atomicAdd(dw + 4 * c + 0, t.x * v[i].x * r); atomicAdd(dw + 4 * c + 1, t.y * v[i].y * r);
-                atomicAdd(dw + 4 * c + 2, t.z * v[i].z * r); atomicAdd(dw + 4 * c + 3, t.w * v[i].w * r);
+        }
+        const float coef = do_norm ? wave_sum(sxg) / dim * r * r * r : 0.f;
+        uint2* dxr = (uint2*)(dx + row * lddx);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                uint2 o;
+                o.x = pack_bf2(r * g[i].x - v[i].x * coef, r * g[i].y - v[i].y * coef);
+                o.y = pack_bf2(r * g[i].z - v[i].z * coef, r * g[i].w - v[i].w * coef);
+                dxr[c] = o;
             }
-            if (wv) { const float4 w4 = wv[c]; t.x *= w4.x; t.y *= w4.y; t.z *= w4.z; t.w *= w4.w; }
-            g[i] = t;
-            sxg += v[i].x * t.x + v[i].y * t.y + v[i].z * t.z + v[i].w * t.w;
         }
     }
-    const float coef = do_norm ? wave_sum(sxg) / dim * r * r * r : 0.f;
-    uint2* dxr = (uint2*)(dx + row * lddx);
+    if (dw) {
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) {
-            uint2 o;
-            o.x = pack_bf2(r * g[i].x - v[i].x * coef, r * g[i].y - v[i].y * coef);
-            o.y = pack_bf2(r * g[i].z - v[i].z * coef, r * g[i].w - v[i].w * coef);
-            dxr[c] = o;
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                atomicAdd(dw + 4 * c + 0, aw[i].x); atomicAdd(dw + 4 * c + 1, aw[i].y);
+                atomicAdd(dw + 4 * c + 2, aw[i].z); atomicAdd(dw + 4 * c + 3, aw[i].w);
+            }
         }
     }
 }
@@ -328,20 +369,23 @@ void dense_f32_bwd_w_kernel(const float* __restrict__ x, const float* __restrict
     if (db && k == 0) db[n] += sb;
 }
 
+// dx[b][k] (+)= act'(x[b][k]) * sum_n dy[b][n] W[n][k]; the n range is split over blockIdx.y and
+// combined with atomics (dx must be zero-filled by the caller unless it accumulates).
 __global__ __launch_bounds__(256)
 void dense_f32_bwd_x_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ dy,
-                            float* __restrict__ dx, int B, int N, int K, int act_in, int accumulate) {
+                            float* __restrict__ dx, int B, int N, int K, int act_in, int n_chunk) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)B * K) return;
     const int b = (int)(i / K), k = (int)(i % K);
+    const int n0 = blockIdx.y * n_chunk, n1 = min(N, n0 + n_chunk);
     float s = 0.f;
-    for (int n = 0; n < N; ++n) s += dy[(int64_t)b * N + n] * W[(int64_t)n * K + k];
+    for (int n = n0; n < n1; ++n) s += dy[(int64_t)b * N + n] * W[(int64_t)n * K + k];
     if (act_in == 1) {
         const float xv = x[i];
         const float sg = 1.0f / (1.0f + expf(-xv));
         s *= sg * (1.0f + xv * (1.0f - sg));
     }
-    dx[i] = accumulate ? dx[i] + s : s;
+    atomicAdd(dx + i, s);
 }
 
 inline int grid_for(int64_t n, int per_block) {
@@ -424,7 +468,9 @@ extern "C" int omh_layernorm_modulate_bwd(const float* x, const float* dy, float
     if (!x || !dy || !dx_accum || rows <= 0 || dim <= 0 || rows_per_batch <= 0) return OMH_E_BADARG;
     if ((dim & 3) || dim > MAXV * 256) return OMH_E_SHAPE;
     omh_clear_status();
-    hipLaunchKernelGGL(layernorm_modulate_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+    auto kern = dim <= 6 * 256 ? layernorm_modulate_bwd_kernel<6>
+                               : (dim <= 20 * 256 ? layernorm_modulate_bwd_kernel<20> : layernorm_modulate_bwd_kernel<MAXV>);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 4 * RPW - 1) / (4 * RPW))), dim3(256), 0,
                        (hipStream_t)stream, x, dy, dx_accum, rows, dim, eps, mul_const, mul0, mul1, mul1_stride, dmul,
                        dadd, dstride, rows_per_batch);
     return omh_launch_status();
@@ -439,7 +485,9 @@ extern "C" int omh_rmsnorm_rope_bwd(const float* x, int64_t ldx, const float* dy
     if ((dim & 3) || dim > MAXV * 256 || (ldx & 3) || (lddy & 3) || (lddx & 3)) return OMH_E_SHAPE;
     if (rope_cos && (!rope_sin || !grid || seq_len <= 0 || head_dim <= 0)) return OMH_E_BADARG;
     omh_clear_status();
-    hipLaunchKernelGGL(rmsnorm_rope_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
+    auto kern = dim <= 6 * 256 ? rmsnorm_rope_bwd_kernel<6>
+                               : (dim <= 20 * 256 ? rmsnorm_rope_bwd_kernel<20> : rmsnorm_rope_bwd_kernel<MAXV>);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 4 * RPW - 1) / (4 * RPW))), dim3(256), 0, (hipStream_t)stream, x,
                        ldx, dy, lddy, (uint16_t*)dx_bf16, lddx, dweight, rows, dim, weight, eps, do_norm, rope_cos,
                        rope_sin, rope_len, head_dim, grid, seq_len);
     return omh_launch_status();
@@ -472,8 +520,12 @@ extern "C" int omh_dense_f32_bwd(const float* x, const float* W, const float* dy
     if (dW_accum)
         hipLaunchKernelGGL(dense_f32_bwd_w_kernel, dim3((unsigned)(((int64_t)N * K + 255) / 256)), dim3(256), 0,
                            (hipStream_t)stream, x, dy, dW_accum, db_accum, B, N, K, act_in);
-    if (dx)
-        hipLaunchKernelGGL(dense_f32_bwd_x_kernel, dim3((unsigned)(((int64_t)B * K + 255) / 256)), dim3(256), 0,
-                           (hipStream_t)stream, x, W, dy, dx, B, N, K, act_in, dx_accumulate);
+    if (dx) {
+        if (!dx_accumulate) hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * K, (hipStream_t)stream);
+        const int n_chunk = 64;
+        dim3 grid((unsigned)(((int64_t)B * K + 255) / 256), (unsigned)((N + n_chunk - 1) / n_chunk));
+        hipLaunchKernelGGL(dense_f32_bwd_x_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, W, dy, dx, B, N, K,
+                           act_in, n_chunk);
+    }
     return omh_launch_status();
 }

@@ -361,6 +361,14 @@ def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale
                              grad_scale, _stream()), "omh_adamw_step")
 
 
+def adamw_multi(table, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    """table: int64 device tensor [n, 5] = (param, grad, exp_avg, exp_avg_sq pointers, numel)."""
+    _dev(table)
+    assert table.dtype == torch.int64 and table.is_contiguous()
+    check(lib.omh_adamw_multi(_p(table), n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, _stream()),
+          "omh_adamw_multi")
+
+
 def ema_update(ema, p, decay):
     _dev(ema, p)
     assert ema.dtype == p.dtype == torch.float32 and ema.is_contiguous() and p.is_contiguous()

@@ -17,6 +17,8 @@ class AdamW(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            by_step = {}
+            keep = []                                       # keeps .contiguous() copies alive until the launch
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -26,8 +28,16 @@ class AdamW(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
-                ops.adamw_step(p.data, p.grad.contiguous(), st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2,
-                               group["eps"], group["weight_decay"], st["step"], grad_scale)
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                keep.append(g)
+                assert p.dtype == torch.float32 and p.is_contiguous() and g.dtype == torch.float32
+                by_step.setdefault((st["step"], p.device), []).append(
+                    (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()))
+            # one multi-tensor launch per (step count, device): ~750 parameter tensors -> 1 kernel
+            for (step, dev), rows in by_step.items():
+                table = torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=False)
+                ops.adamw_multi(table, len(rows), group["lr"], b1, b2, group["eps"], group["weight_decay"], step,
+                                grad_scale)
         return loss
 
 

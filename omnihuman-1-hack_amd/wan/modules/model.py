@@ -91,7 +91,7 @@ def _round_up(a, b):
 class _FwdCtx:
     """Per-forward shared state handed to every block."""
     __slots__ = ("B", "S", "dim", "e0", "seq_lens32", "ctx_lens32", "grid32", "rope_cos", "rope_sin", "ctx",
-                 "Lc", "n_img")
+                 "Lc", "n_img", "seq_lens_host", "ctx_lens_host")
 
 
 # ----------------------------------------------------------------------------
@@ -611,6 +611,7 @@ class WanModel(nn.Module):
         fc.ctx_lens32 = torch.tensor(ctx_lens, dtype=torch.int32, device=device)
         fc.rope_cos, fc.rope_sin = self._rope(device)
         fc.ctx, fc.Lc = ctx, ctx.shape[1]
+        fc.seq_lens_host, fc.ctx_lens_host = list(lens), list(ctx_lens)     # host copies: no device sync later
         return xs, e, fc, grids, lens, ctx_lens
 
     def _forward_infer(self, x, t, context, seq_len, clip_fea=None, y=None):

@@ -54,9 +54,10 @@ def _wT(mod, key, weight_bf16):
     return mod._packed.get("T:" + key, (weight_bf16,), lambda: ops.transpose_bf16(weight_bf16))
 
 
-def _wgrad(dy, x):
-    """dW[N, K] = dy[R, N]^T @ x[R, K]  (fp32), both bf16 row-major."""
-    dyT, xT = ops.transpose_bf16(dy), ops.transpose_bf16(x)
+def _wgrad(dy, x, xT=None):
+    """dW[N, K] = dy[R, N]^T @ x[R, K]  (fp32), both bf16 row-major; xT = cached transpose of x."""
+    dyT = ops.transpose_bf16(dy)
+    xT = ops.transpose_bf16(x) if xT is None else xT
     N, K, Rp = dyT.shape[0], xT.shape[0], dyT.shape[1]
     out = torch.empty(N, K, dtype=torch.float32, device=dy.device)
     ops.gemm_raw(ptr(dyT), ptr(xT), ptr(out), N, K, Rp, Rp, Rp, K, EPI_F32)
@@ -194,8 +195,7 @@ def _block_backward(model, blk, idx, st, x0, dx):
     if i2v:
         raise NotImplementedError("training backward for the i2v cross-attention is not built")
     frozen_ffn = getattr(model, "reference_ffn_freeze", True) and idx > 10
-    seq_lens = [int(v) for v in fc.seq_lens32.tolist()]
-    ctx_lens = [int(v) for v in fc.ctx_lens32.tolist()]
+    seq_lens, ctx_lens = fc.seq_lens_host, fc.ctx_lens_host
     Lc = fc.Lc
     d_eb = torch.zeros(B, 6, d, dtype=torch.float32, device=dev)     # grads of e = modulation + e0
     g = {}
@@ -313,9 +313,10 @@ def _block_backward(model, blk, idx, st, x0, dx):
                              0, D, None, 0)
     if dnk is not None:
         g["cross_attn.norm_k.weight"] = dnk
-    g["cross_attn.k.weight"], g["cross_attn.k.bias"] = _wgrad(dkc_pre, ctx2), _bgrad(dkc_pre)
+    ctx2T = ops.transpose_bf16(ctx2)
+    g["cross_attn.k.weight"], g["cross_attn.k.bias"] = _wgrad(dkc_pre, ctx2, ctx2T), _bgrad(dkc_pre)
     dvc_b = ops.cast_bf16(dvc)
-    g["cross_attn.v.weight"], g["cross_attn.v.bias"] = _wgrad(dvc_b, ctx2), _bgrad(dvc_b)
+    g["cross_attn.v.weight"], g["cross_attn.v.bias"] = _wgrad(dvc_b, ctx2, ctx2T), _bgrad(dvc_b)
     dctx = st.d_ctx.view(Rc, d)
     _dgrad(dkc_pre, _wT(ca, "k", wkc), out=dctx, accumulate=True)
     _dgrad(dvc_b, _wT(ca, "v", wvc), out=dctx, accumulate=True)
@@ -342,11 +343,12 @@ def _block_backward(model, blk, idx, st, x0, dx):
                                  D, ptr(fc.grid32), S)
         if dnw is not None:
             g[f"self_attn.{nm}.weight"] = dnw
-    dwqk, dbqk = _wgrad(dqk_pre, h1), _bgrad(dqk_pre)
+    h1T = ops.transpose_bf16(h1)
+    dwqk, dbqk = _wgrad(dqk_pre, h1, h1T), _bgrad(dqk_pre)
     g["self_attn.q.weight"], g["self_attn.k.weight"] = dwqk[:d], dwqk[d:]
     g["self_attn.q.bias"], g["self_attn.k.bias"] = dbqk[:d], dbqk[d:]
     dv_b = ops.cast_bf16(dv)
-    g["self_attn.v.weight"], g["self_attn.v.bias"] = _wgrad(dv_b, h1), _bgrad(dv_b)
+    g["self_attn.v.weight"], g["self_attn.v.bias"] = _wgrad(dv_b, h1, h1T), _bgrad(dv_b)
     dh1 = _dgrad(dqk_pre, _wT(sa, "qk", wqk))
     _dgrad(dv_b, _wT(sa, "v", wv), out=dh1, accumulate=True)
     ln_bwd(x0, dh1, 0, 1)
