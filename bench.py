@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--only-train", action="store_true", help="profiling aid: run just the training leg")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -229,6 +230,9 @@ def main():
         s.set_begin_index(0)
         return s
 
+    if args.only_train:
+        print(json.dumps({"train": train_bench(model, device, world, dist)}), flush=True)
+        return
     sched = fresh_sched()
     x = run_steps(args.warmup, sched, latent)
     torch.cuda.synchronize()
