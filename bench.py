@@ -266,10 +266,10 @@ def main():
         tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tj):
             try:
-                traffic = json.load(open(tj)).get("flash_attn_fwd_d128_kernel")
+                traffic = json.load(open(tj)).get("flash_attn_fwd_d128_pp_kernel")
             except Exception:
                 traffic = None
-        roofline = {"kernel": "flash_attn_fwd_d128_kernel (self-attention, Lq=Lk=%d, 12 heads, D=128)" % seq_len,
+        roofline = {"kernel": "flash_attn_fwd_d128_pp_kernel (self-attention, Lq=Lk=%d, 12 heads, D=128)" % seq_len,
                     "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "launches_timed": len(timer.pairs), "avg_launch_ms": round(attn_ms, 4),

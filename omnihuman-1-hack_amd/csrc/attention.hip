@@ -24,6 +24,7 @@
 // ds_read_b128), double buffered, one barrier per tile, next tile's global
 // loads issued before the current tile's MFMAs.
 #include "omh_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -248,6 +249,242 @@ void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles) {
     }
 }
 
+// ============================================================================================
+// Ping-pong variant for long sequences: 8 waves = 256 query rows per workgroup, one workgroup per
+// CU.  The two waves that share a SIMD (w and w+4) run the SAME per-tile program half a period
+// apart, kept complementary by two workgroup barriers per tile: while waves 0-3 are in their
+// matrix segment {P.V of tile t, K.Q^T of tile t+1} waves 4-7 are in their softmax (VALU) segment
+// and vice versa, so each SIMD's MFMA pipe always has exactly one wave feeding it instead of
+// two independent workgroups colliding in the same phase.  K/V tiles arrive by LDS-DMA
+// (buffer_load ... lds) one tile ahead; the DMA is issued at the start of a slot and only
+// waited for (counted, by the issuing wave) one full slot later, so it never stalls a barrier.
+//
+//   global slot g:   group 0 (waves 0-3)              group 1 (waves 4-7)
+//        2t          softmax(t)                        P.V(t-1), K.Q^T(t)
+//        2t+1        DMA(t); P.V(t), K.Q^T(t+1)        DMA(t); softmax(t)
+//   DMA(t) = K(t+2) -> K slot t&1, V(t+1) -> V slot (t+1)&1   (both free since the end of slot 2t)
+// ============================================================================================
+constexpr int QB2 = 256;
+
+__global__ __launch_bounds__(512, 2)
+void flash_attn_fwd_d128_pp_kernel(const omh_attn_args p, const int q_tiles) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (KT_BYTES + VT_BYTES)];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+
+    const int nwg = q_tiles * p.H * p.B;
+    const int wid = xcd_remap(blockIdx.x, nwg);
+    const int bh = wid / q_tiles, qt = wid % q_tiles;
+    const int b = bh / p.H, head = bh % p.H;
+    int klen = p.k_lens ? p.k_lens[b] : p.Lk;
+    klen = min(max(klen, 0), p.Lk);
+    const int n_tiles = (klen + KB - 1) / KB;
+
+    const __bf16* __restrict__ Q = (const __bf16*)p.q + (int64_t)b * p.q_bs + head * D;
+    const __bf16* __restrict__ K = (const __bf16*)p.k + (int64_t)b * p.k_bs + head * D;
+    const __bf16* __restrict__ VT = (const __bf16*)p.vt + (int64_t)b * p.vt_bs + (int64_t)head * D * p.ldv;
+
+    const int q_row = qt * QB2 + wave * 32 + li;
+    const int q_ld = min(q_row, p.Lq - 1);
+    bf16x8 qf[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+        qf[kk] = *(const bf16x8*)(Q + (int64_t)q_ld * p.q_rs + kk * 16 + lh * 8);
+
+    // LDS-DMA staging: chunk c = tid + 512 j lands at byte 16 c of the tile; the XOR swizzle goes on the
+    // per-lane SOURCE slot (K: (c&15)^(row&15), V^T: (c&7)^((row>>1)&7)) and again on the read.
+    const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)K, 0, (int)((((int64_t)p.Lk - 1) * p.k_rs + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)VT, 0, (int)((int64_t)D * p.ldv * 2), 0x00020000);
+    uint32_t voff_k[2], voff_v[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = tid + 512 * j;
+        const int kr = c >> 4, vr = c >> 3;
+        voff_k[j] = (uint32_t)((kr * (int)p.k_rs + (((c & 15) ^ (kr & 15)) * 8)) * 2);
+        voff_v[j] = (uint32_t)((vr * p.ldv + (((c & 7) ^ ((vr >> 1) & 7)) * 8)) * 2);
+    }
+    const uint32_t k_tile_bytes = (uint32_t)(KB * (int)p.k_rs * 2), v_tile_bytes = KB * 2;
+    const int wave_lds = __builtin_amdgcn_readfirstlane(wave) * 1024;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    unsigned char* const kring = smem;
+    unsigned char* const vring = smem + 2 * KT_BYTES;
+#define PP_KDMA(T, BUF)                                                                         \
+    {                                                                                           \
+        const uint32_t ko_ = (uint32_t)(T) * k_tile_bytes;                                      \
+        unsigned char* d_ = kring + (BUF) * KT_BYTES + wave_lds;                                \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, (lds_ptr_t)(d_), 16, voff_k[0] + ko_, 0, 0, 0);        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, (lds_ptr_t)(d_ + 8192), 16, voff_k[1] + ko_, 0, 0, 0); \
+    }
+#define PP_VDMA(T, BUF)                                                                         \
+    {                                                                                           \
+        const uint32_t vo_ = (uint32_t)(T) * v_tile_bytes;                                      \
+        unsigned char* d_ = vring + (BUF) * VT_BYTES + wave_lds;                                \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lds_ptr_t)(d_), 16, voff_v[0] + vo_, 0, 0, 0);        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lds_ptr_t)(d_ + 8192), 16, voff_v[1] + vo_, 0, 0, 0); \
+    }
+#define PP_BARRIER() asm volatile("s_barrier" ::: "memory")
+#define PP_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+    const int krow_l = swap_bits23(li);
+    f32x16 oacc[4], s0, s1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc = p.scale * 1.4426950408889634f;
+    bf16x8 pf[2][2];
+    float alpha_keep = 1.0f;
+
+// fragment reads run two MFMA pairs ahead of their use (explicit register ring): a lone wave per
+// matrix segment has nobody to hide its ds_read latency behind
+#define PP_KFRAG(KT_, KK_) { *(const bf16x8*)((KT_) + k_addr(krow_l, 2 * (KK_) + lh)), \
+                             *(const bf16x8*)((KT_) + k_addr(32 + krow_l, 2 * (KK_) + lh)) }
+#define PP_QK(KBUF)                                                                             \
+    {                                                                                           \
+        const unsigned char* kt_ = kring + (KBUF) * KT_BYTES;                                   \
+        _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) { s0[r_] = 0.f; s1[r_] = 0.f; }       \
+        bf16x8 kr_[3][2];                                                                       \
+        kr_[0][0] = *(const bf16x8*)(kt_ + k_addr(krow_l, lh));                                 \
+        kr_[0][1] = *(const bf16x8*)(kt_ + k_addr(32 + krow_l, lh));                            \
+        kr_[1][0] = *(const bf16x8*)(kt_ + k_addr(krow_l, 2 + lh));                             \
+        kr_[1][1] = *(const bf16x8*)(kt_ + k_addr(32 + krow_l, 2 + lh));                        \
+        _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                      \
+            if (kk + 2 < 8) {                                                                   \
+                kr_[(kk + 2) % 3][0] = *(const bf16x8*)(kt_ + k_addr(krow_l, 2 * (kk + 2) + lh));      \
+                kr_[(kk + 2) % 3][1] = *(const bf16x8*)(kt_ + k_addr(32 + krow_l, 2 * (kk + 2) + lh)); \
+            }                                                                                   \
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr_[kk % 3][0], qf[kk], s0, 0, 0, 0);  \
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr_[kk % 3][1], qf[kk], s1, 0, 0, 0);  \
+        }                                                                                       \
+        /* pin the issue order: 4 reads up front, then {2 MFMA, 2 reads} x 6, then the last 4 MFMA */ \
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                      \
+        _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) {                                      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                  \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                  \
+        }                                                                                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                      \
+    }
+
+    if (n_tiles > 0) {
+        PP_KDMA(0, 0) PP_VDMA(0, 0) PP_KDMA(1, 1)
+    }
+    PP_WAIT_DMA();
+    PP_BARRIER();
+    if (n_tiles > 0) PP_QK(0)
+    if (grp == 1) PP_BARRIER();                        // group 1 runs one slot behind group 0
+
+    for (int t = 0; t < n_tiles; ++t) {
+        if (grp == 1) { PP_KDMA(t + 2, t & 1) PP_VDMA(t + 1, (t + 1) & 1) }
+        // ---------------- softmax segment (VALU): scores of tile t -> P (bf16), rescale O
+        {
+            const int kv0 = t * KB;
+            if (__builtin_expect(kv0 + KB > klen, 0)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + ((r >> 3) << 4) + lh * 8 + (r & 7);
+                    if (key >= klen) s0[r] = -INFINITY;
+                    if (key + 32 >= klen) s1[r] = -INFINITY;
+                }
+            }
+            float mx = s0[0];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+            { float a_, b_; xhalf(mx, a_, b_); mx = fmaxf(a_, b_); }
+            const float m_new = fmaxf(m_run, mx * sc);
+            const float alpha = fast_exp2(m_run - m_new);
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s0[r] = fast_exp2(fmaf(s0[r], sc, -m_new));
+                s1[r] = fast_exp2(fmaf(s1[r], sc, -m_new));
+            }
+            alpha_keep = alpha;      // row sum, P->bf16 and the O rescale ride in the matrix segment's issue gaps
+        }
+        if (grp == 0 && t > 0) PP_WAIT_DMA();          // this wave's share of DMA(t-1), issued one slot ago
+        PP_BARRIER();
+        if (grp == 0) { PP_KDMA(t + 2, t & 1) PP_VDMA(t + 1, (t + 1) & 1) }
+        // ---------------- matrix segment: O^T += V^T(t) P^T, then the scores of tile t+1
+        {
+            // VALU work moved here from the softmax segment (it was the longer of the two): the rescale of
+            // O, the row sum and the bf16 packing of P issue in the gaps between this segment's MFMAs
+            if (!__all(alpha_keep == 1.0f)) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha_keep;
+            }
+            float rs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rs += s0[r] + s1[r];
+            { float a_, b_; xhalf(rs, a_, b_); rs = a_ + b_; }
+            l_run = l_run * alpha_keep + rs;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                u32x4 c0, c1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    c0[e] = pack_bf2(s0[8 * a + 2 * e], s0[8 * a + 2 * e + 1]);
+                    c1[e] = pack_bf2(s1[8 * a + 2 * e], s1[8 * a + 2 * e + 1]);
+                }
+                pf[0][a] = __builtin_bit_cast(bf16x8, c0);
+                pf[1][a] = __builtin_bit_cast(bf16x8, c1);
+            }
+            const unsigned char* vt = vring + (t & 1) * VT_BYTES;
+            // 16 steps i = (kb, a, db); V^T fragments are read 4 steps ahead
+            bf16x8 vr_[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vr_[i] = *(const bf16x8*)(vt + v_addr(i * 32 + li, lh));
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kb = i >> 3, a = (i >> 2) & 1, db = i & 3;
+                if (i + 4 < 16) {
+                    const int j = i + 4, kbj = j >> 3, aj = (j >> 2) & 1, dbj = j & 3;
+                    vr_[j & 7] = *(const bf16x8*)(vt + v_addr(dbj * 32 + li, 4 * kbj + 2 * aj + lh));
+                }
+                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr_[i & 7], pf[kb][a], oacc[db], 0, 0, 0);
+            }
+            // issue order: cvt for the first P fragment + 4 fragment reads, then per MFMA one read and a
+            // few of the remaining VALU ops (row sum, packing)
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
+#pragma unroll
+            for (int g_ = 0; g_ < 12; ++g_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 1);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+            if (t + 1 < n_tiles) PP_QK((t + 1) & 1)
+        }
+        if (grp == 1) PP_WAIT_DMA();                   // this wave's share of DMA(t), issued one slot ago
+        PP_BARRIER();
+    }
+    if (grp == 0) PP_BARRIER();                        // match group 1's leading barrier
+
+    if (q_row < p.Lq) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        uint16_t* O = (uint16_t*)p.o + (int64_t)b * p.o_bs + (int64_t)q_row * p.o_rs + head * D;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                uint2 pk;
+                pk.x = pack_bf2(oacc[db][4 * gq] * inv, oacc[db][4 * gq + 1] * inv);
+                pk.y = pack_bf2(oacc[db][4 * gq + 2] * inv, oacc[db][4 * gq + 3] * inv);
+                *(uint2*)(O + db * 32 + gq * 8 + lh * 4) = pk;
+            }
+        if (p.lse && lh == 0) {
+            const float lse = l_run > 0.f ? (m_run + log2f(l_run)) * 0.6931471805599453f : -INFINITY;
+            p.lse[((int64_t)b * p.H + head) * p.Lq + q_row] = lse;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int omh_flash_attn_fwd_d128(const omh_attn_args* args, omh_stream_t stream) {
@@ -260,9 +497,18 @@ extern "C" int omh_flash_attn_fwd_d128(const omh_attn_args* args, omh_stream_t s
     if (((uintptr_t)a.q & 15) || ((uintptr_t)a.k & 15) || ((uintptr_t)a.vt & 15) || ((uintptr_t)a.o & 7))
         return OMH_E_ALIGN;
     if (a.ldv < ((a.Lk + KB - 1) / KB) * KB) return OMH_E_SHAPE;
-    const int q_tiles = (a.Lq + QB - 1) / QB;
-    dim3 grid(q_tiles * a.H * a.B);
+    // long sequences that fill the chip with 256-row workgroups take the ping-pong kernel
+    static const char* force = getenv("OMH_ATTN_KERNEL");          // "pp" / "base": benchmarking override
+    const int q_tiles2 = (a.Lq + QB2 - 1) / QB2;
+    const bool pp = force ? (force[0] == 'p') : ((int64_t)q_tiles2 * a.H * a.B >= 512 && a.Lk >= 1024);
     omh_clear_status();
-    hipLaunchKernelGGL(flash_attn_fwd_d128_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, q_tiles);
+    if (pp) {
+        hipLaunchKernelGGL(flash_attn_fwd_d128_pp_kernel, dim3(q_tiles2 * a.H * a.B), dim3(512), 0,
+                           (hipStream_t)stream, a, q_tiles2);
+    } else {
+        const int q_tiles = (a.Lq + QB - 1) / QB;
+        hipLaunchKernelGGL(flash_attn_fwd_d128_kernel, dim3(q_tiles * a.H * a.B), dim3(256), 0, (hipStream_t)stream,
+                           a, q_tiles);
+    }
     return omh_launch_status();
 }
