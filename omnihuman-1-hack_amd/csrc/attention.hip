@@ -326,7 +326,7 @@ void flash_attn_fwd_d128_pp_kernel(const omh_attn_args p, const int q_tiles) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lds_ptr_t)(d_), 16, voff_v[0] + vo_, 0, 0, 0);        \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lds_ptr_t)(d_ + 8192), 16, voff_v[1] + vo_, 0, 0, 0); \
     }
-#define PP_BARRIER() asm volatile("s_barrier" ::: "memory")
+#define PP_BARRIER() asm volatile("s_barrier" ::: "memory");
 #define PP_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
     const int krow_l = swap_bits23(li);
@@ -374,9 +374,9 @@ void flash_attn_fwd_d128_pp_kernel(const omh_attn_args p, const int q_tiles) {
         PP_KDMA(0, 0) PP_VDMA(0, 0) PP_KDMA(1, 1)
     }
     PP_WAIT_DMA();
-    PP_BARRIER();
+    PP_BARRIER()
     if (n_tiles > 0) PP_QK(0)
-    if (grp == 1) PP_BARRIER();                        // group 1 runs one slot behind group 0
+    if (grp == 1) PP_BARRIER()                        // group 1 runs one slot behind group 0
 
     for (int t = 0; t < n_tiles; ++t) {
         if (grp == 1) { PP_KDMA(t + 2, t & 1) PP_VDMA(t + 1, (t + 1) & 1) }
@@ -406,7 +406,7 @@ void flash_attn_fwd_d128_pp_kernel(const omh_attn_args p, const int q_tiles) {
             alpha_keep = alpha;      // row sum, P->bf16 and the O rescale ride in the matrix segment's issue gaps
         }
         if (grp == 0 && t > 0) PP_WAIT_DMA();          // this wave's share of DMA(t-1), issued one slot ago
-        PP_BARRIER();
+        PP_BARRIER()
         if (grp == 0) { PP_KDMA(t + 2, t & 1) PP_VDMA(t + 1, (t + 1) & 1) }
         // ---------------- matrix segment: O^T += V^T(t) P^T, then the scores of tile t+1
         {
@@ -462,9 +462,9 @@ void flash_attn_fwd_d128_pp_kernel(const omh_attn_args p, const int q_tiles) {
             if (t + 1 < n_tiles) PP_QK((t + 1) & 1)
         }
         if (grp == 1) PP_WAIT_DMA();                   // this wave's share of DMA(t), issued one slot ago
-        PP_BARRIER();
+        PP_BARRIER()
     }
-    if (grp == 0) PP_BARRIER();                        // match group 1's leading barrier
+    if (grp == 0) PP_BARRIER()                        // match group 1's leading barrier
 
     if (q_row < p.Lq) {
         const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
