@@ -8,7 +8,9 @@
 //   big   256(m) x 256(n) x 64(k), 512 threads = 8 waves as 2(m) x 4(n), wave tile 128x64
 //         (4x2 MFMA accumulators): 128 flop per operand byte, for the S = 32 760 GEMMs;
 //   small 128(m) x 128(n) x 64(k), 256 threads = 4 waves as 2x2, wave tile 64x64, two
-//         workgroups per CU: keeps 256 CUs busy when M*N is small (context, training clips).
+//         workgroups per CU;
+//   tiny  64 x 64 x 64, 4 waves, wave tile 32x32: keeps 256 CUs busy when M*N is small
+//         (context projections, the S = 1560 training clips).
 // Each MFMA is v_mfma_f32_32x32x16_bf16.
 // The weight rows (n) go in the MFMA A slot and the activation rows (m) in
 // the B slot, so each lane ends up with runs of 4 consecutive n for one m:
@@ -43,7 +45,8 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int CA = BM * 8 / THREADS, CB = BN * 8 / THREADS;     // 16-byte chunks per thread and stage
-    static_assert(CA == 4 && CB == 4, "staging code assumes 4 chunks per operand per thread");
+    static_assert(CA == CB && (CA == 4 || CA == 2), "staging code assumes 2 or 4 chunks per operand per thread");
+    constexpr int NCH = CA;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -70,7 +73,7 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
     uint32_t voff_a[4], voff_b[4];
     int lslot[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NCH; ++j) {
         const int c = tid + THREADS * j;
         const int row = c >> 3;
         lslot[j] = (c & 7) ^ ((row >> 1) & 7);
@@ -101,10 +104,10 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
         const int k0_ = (KT_) * BK;                                                            \
         unsigned char* xa_ = smem + (BUF) * STAGE_BYTES;                                       \
         unsigned char* xb_ = xa_ + A_BYTES;                                                    \
-        GEMM_DMA1(rsrc_a, voff_a, 0, xa_) GEMM_DMA1(rsrc_a, voff_a, 1, xa_)                    \
-        GEMM_DMA1(rsrc_a, voff_a, 2, xa_) GEMM_DMA1(rsrc_a, voff_a, 3, xa_)                    \
-        GEMM_DMA1(rsrc_b, voff_b, 0, xb_) GEMM_DMA1(rsrc_b, voff_b, 1, xb_)                    \
-        GEMM_DMA1(rsrc_b, voff_b, 2, xb_) GEMM_DMA1(rsrc_b, voff_b, 3, xb_)                    \
+        _Pragma("unroll") for (int j_ = 0; j_ < NCH; ++j_) {                                   \
+            GEMM_DMA1(rsrc_a, voff_a, j_, xa_)                                                 \
+            GEMM_DMA1(rsrc_b, voff_b, j_, xb_)                                                 \
+        }                                                                                      \
     }
 
     GEMM_DMA(0, 0)
@@ -235,6 +238,11 @@ int launch(const omh_gemm_args& a, hipStream_t s) {
     static const char* force = getenv("OMH_GEMM_TILE");        // "big" / "small": benchmarking override
     const bool big = force ? (force[0] == 'b') : (big_tiles >= 256);
     if (big) return launch_cfg<EPI, 2, 4, 4, 2>(a, s);
+    // tiny problems (training clips, context projections): 64x64 tiles so that more than 2 workgroups
+    // per CU exist at all
+    const int64_t mid_tiles = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
+    const bool tiny = force ? (force[0] == 't') : (mid_tiles < 512);
+    if (tiny) return launch_cfg<EPI, 2, 2, 1, 1>(a, s);
     return launch_cfg<EPI, 2, 2, 2, 2>(a, s);
 }
 
