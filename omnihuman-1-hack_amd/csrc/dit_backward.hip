@@ -120,7 +120,7 @@ void gated_resid_bwd_kernel(const float* __restrict__ dx, const uint16_t* __rest
 // dmul[b][c] += dy * xhat ; dadd[b][c] += dy
 // One wave walks RPW consecutive rows and keeps the per-column sums in registers, so the
 // parameter-side atomics are issued once per RPW rows (they were 2/3 of this kernel's time).
-constexpr int RPW = 8;
+constexpr int RPW = 4;
 
 template <int NV>
 __global__ __launch_bounds__(256)
@@ -408,7 +408,7 @@ extern "C" int omh_transpose_bf16(const void* in, void* out, int32_t R, int32_t 
 extern "C" int omh_colsum_accum(const void* x, int32_t is_bf16, int64_t ld, float* out, int64_t R, int32_t C,
                                 omh_stream_t stream) {
     if (!x || !out || R <= 0 || C <= 0 || ld < C) return OMH_E_BADARG;
-    const int rpb = 128;
+    const int rpb = 32;
     dim3 grid((C + 255) / 256, (unsigned)((R + rpb - 1) / rpb));
     omh_clear_status();
     if (is_bf16)
