@@ -38,6 +38,16 @@ def main():
         out = torch.empty(S, N, dtype=torch.float32 if epi == ops.EPI_F32 else torch.bfloat16, device="cuda")
         ms = timeit(lambda: ops.gemm(a, w, out=out, bias=bias, epilogue=epi))
         res[name] = {"ms": ms, "tflops": 2.0 * S * N * K / ms / 1e9}
+    # gated-residual epilogue (o-projection): x += (a w^T + b) * gate
+    a = torch.randn(S, d, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(d, d, device="cuda") / math.sqrt(d)).to(torch.bfloat16)
+    bias = torch.randn(d, device="cuda")
+    xres = torch.randn(S, d, device="cuda")
+    g0, g1 = torch.randn(d, device="cuda"), torch.randn(1, d, device="cuda")
+    ms = timeit(lambda: ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(xres), S, d, d, d, d, d, ops.EPI_RESID,
+                                     bias=ops.ptr(bias), bias_mode=ops.BIAS_N, gate0=ops.ptr(g0), gate1=ops.ptr(g1),
+                                     gate1_stride=d, gate_rows=S, gate_const=0.0))
+    res["o_resid"] = {"ms": ms, "tflops": 2.0 * S * d * d / ms / 1e9}
     q = torch.randn(1, S, H, D, device="cuda").to(torch.bfloat16)
     k = torch.randn(1, S, H, D, device="cuda").to(torch.bfloat16)
     Sp = (S + 63) // 64 * 64
