@@ -132,6 +132,13 @@ int omh_rmsnorm_rope(const float* x, int64_t ldx, void* y_bf16, int64_t rows, in
                      const float* rope_cos, const float* rope_sin, int32_t rope_len,
                      int32_t head_dim, const int32_t* grid, int32_t seq_len, omh_stream_t stream);
 
+/* Same with a bf16 input [rows, ldx] (the inference path keeps the q|k projection in bf16: half the
+ * HBM traffic of this HBM-bound step; the training recompute uses the fp32 form above). */
+int omh_rmsnorm_rope_bf16(const void* x_bf16, int64_t ldx, void* y_bf16, int64_t rows, int32_t dim,
+                          const float* weight, float eps, int32_t do_norm,
+                          const float* rope_cos, const float* rope_sin, int32_t rope_len,
+                          int32_t head_dim, const int32_t* grid, int32_t seq_len, omh_stream_t stream);
+
 /* fp32 -> bf16 cast (round to nearest even) of a contiguous buffer. */
 int omh_cast_f32_bf16(const float* x, void* y_bf16, int64_t n, omh_stream_t stream);
 

@@ -73,9 +73,9 @@ void layernorm_modulate_kernel(const float* __restrict__ x, uint16_t* __restrict
 }
 
 // ------------------------------------------------------------------ RMSNorm (+RoPE)
-template <int MAXV>
+template <int MAXV, bool IN_BF16>
 __global__ __launch_bounds__(256)
-void rmsnorm_rope_kernel(const float* __restrict__ x, int64_t ldx, uint16_t* __restrict__ y, int64_t rows,
+void rmsnorm_rope_kernel(const void* __restrict__ xv, int64_t ldx, uint16_t* __restrict__ y, int64_t rows,
                          int dim, const float* __restrict__ weight, float eps, int do_norm,
                          const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
                          int rope_len, int head_dim, const int* __restrict__ grid, int seq_len) {
@@ -83,14 +83,21 @@ void rmsnorm_rope_kernel(const float* __restrict__ x, int64_t ldx, uint16_t* __r
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nv = dim >> 2;
-    const float4* xr = (const float4*)(x + row * ldx);
+    const float4* xr = (const float4*)((const float*)xv + row * ldx);
+    const uint2* xh = (const uint2*)((const uint16_t*)xv + row * ldx);
     float4 v[MAXV];
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + 64 * i;
         if (c < nv) {
-            v[i] = xr[c];
+            if (IN_BF16) {
+                const uint2 h = xh[c];
+                v[i] = make_float4(bf2f((uint16_t)(h.x & 0xffff)), bf2f((uint16_t)(h.x >> 16)),
+                                   bf2f((uint16_t)(h.y & 0xffff)), bf2f((uint16_t)(h.y >> 16)));
+            } else {
+                v[i] = xr[c];
+            }
             q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
         }
     }
@@ -285,21 +292,39 @@ extern "C" int omh_layernorm_modulate(const float* x, void* y, int64_t rows, int
     return omh_launch_status();
 }
 
-extern "C" int omh_rmsnorm_rope(const float* x, int64_t ldx, void* y, int64_t rows, int32_t dim,
-                                const float* weight, float eps, int32_t do_norm, const float* rope_cos,
-                                const float* rope_sin, int32_t rope_len, int32_t head_dim, const int32_t* grid,
-                                int32_t seq_len, omh_stream_t stream) {
+template <bool IN_BF16>
+static int rmsnorm_rope_launch(const void* x, int64_t ldx, void* y, int64_t rows, int32_t dim, const float* weight,
+                               float eps, int32_t do_norm, const float* rope_cos, const float* rope_sin,
+                               int32_t rope_len, int32_t head_dim, const int32_t* grid, int32_t seq_len,
+                               omh_stream_t stream) {
     if (!x || !y || rows <= 0 || dim <= 0) return OMH_E_BADARG;
     if ((dim & 3) || dim > MAXV_GENERIC * 256 || (ldx & 3)) return OMH_E_SHAPE;
     if (rope_cos && (!rope_sin || !grid || seq_len <= 0 || head_dim <= 0 || (head_dim & 3) || dim % head_dim))
         return OMH_E_BADARG;
-    if (((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return OMH_E_ALIGN;
+    if (((uintptr_t)x & (IN_BF16 ? 7 : 15)) || ((uintptr_t)y & 7)) return OMH_E_ALIGN;
     omh_clear_status();
-    auto kern = dim <= 6 * 256 ? rmsnorm_rope_kernel<6> : (dim <= 20 * 256 ? rmsnorm_rope_kernel<20> : rmsnorm_rope_kernel<MAXV_GENERIC>);
+    auto kern = dim <= 6 * 256 ? rmsnorm_rope_kernel<6, IN_BF16>
+                               : (dim <= 20 * 256 ? rmsnorm_rope_kernel<20, IN_BF16> : rmsnorm_rope_kernel<MAXV_GENERIC, IN_BF16>);
     hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        x, ldx, (uint16_t*)y, rows, dim, weight, eps, do_norm, rope_cos, rope_sin, rope_len,
                        head_dim, grid, seq_len);
     return omh_launch_status();
+}
+
+extern "C" int omh_rmsnorm_rope(const float* x, int64_t ldx, void* y, int64_t rows, int32_t dim,
+                                const float* weight, float eps, int32_t do_norm, const float* rope_cos,
+                                const float* rope_sin, int32_t rope_len, int32_t head_dim, const int32_t* grid,
+                                int32_t seq_len, omh_stream_t stream) {
+    return rmsnorm_rope_launch<false>(x, ldx, y, rows, dim, weight, eps, do_norm, rope_cos, rope_sin, rope_len,
+                                      head_dim, grid, seq_len, stream);
+}
+
+extern "C" int omh_rmsnorm_rope_bf16(const void* x_bf16, int64_t ldx, void* y, int64_t rows, int32_t dim,
+                                     const float* weight, float eps, int32_t do_norm, const float* rope_cos,
+                                     const float* rope_sin, int32_t rope_len, int32_t head_dim,
+                                     const int32_t* grid, int32_t seq_len, omh_stream_t stream) {
+    return rmsnorm_rope_launch<true>(x_bf16, ldx, y, rows, dim, weight, eps, do_norm, rope_cos, rope_sin, rope_len,
+                                     head_dim, grid, seq_len, stream);
 }
 
 extern "C" int omh_cast_f32_bf16(const float* x, void* y, int64_t n, omh_stream_t stream) {

@@ -116,6 +116,12 @@ def rmsnorm_rope_raw(x, ldx, y, rows, dim, weight, eps, do_norm, rope_cos, rope_
                                grid, seq_len, _stream()), "omh_rmsnorm_rope")
 
 
+def rmsnorm_rope_bf16_raw(x, ldx, y, rows, dim, weight, eps, do_norm, rope_cos, rope_sin, rope_len, head_dim, grid,
+                          seq_len):
+    check(lib.omh_rmsnorm_rope_bf16(x, ldx, y, rows, dim, weight, eps, do_norm, rope_cos, rope_sin, rope_len,
+                                    head_dim, grid, seq_len, _stream()), "omh_rmsnorm_rope_bf16")
+
+
 def rmsnorm_rope(x: torch.Tensor, weight: Optional[torch.Tensor], eps: float, do_norm: bool = True,
                  rope_cos=None, rope_sin=None, head_dim: int = 128, grid: Optional[torch.Tensor] = None,
                  seq_len: int = 0, out=None):

