@@ -13,8 +13,8 @@
 //         (context projections, the S = 1560 training clips).
 // Each MFMA is v_mfma_f32_32x32x16_bf16.
 // The weight rows (n) go in the MFMA A slot and the activation rows (m) in
-// the B slot, so each lane ends up with runs of 4 consecutive n for one m:
-// 8-byte bf16 / 16-byte fp32 epilogue stores.  Both operand tiles are staged
+// the B slot, so each lane ends up with runs of 4 consecutive n for one m; the
+// epilogue transposes through LDS to row-major 16-byte accesses.  Both operand tiles are staged
 // HBM -> LDS directly with the LDS-DMA form of the buffer load
 // (buffer_load_dwordx4 ... lds: no VGPR round trip and, more importantly, no
 // ds_write_b128 pass — at 128x128 the register-staged version spent more LDS
@@ -23,7 +23,8 @@
 // 16-byte slot, conflict-free ds_read_b128) is applied to the per-lane SOURCE
 // address and again on the read.  Rows past M/N and the K tail are out of the
 // buffer descriptor's range and arrive as zeros.  Double buffered, one barrier
-// per k-step; the next tile's DMA is issued before the MFMAs of the current one.
+// per k-step; a stage's DMA is issued as soon as the barrier frees its buffer
+// (one full k-step ahead), and the MFMA fragments are read one 16-wide k group ahead.
 #include "omh_common.h"
 #include <stdlib.h>
 
@@ -110,105 +111,173 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
         }                                                                                      \
     }
 
-    GEMM_DMA(0, 0)
-    __syncthreads();                                             // waits for the DMA (vmcnt) and the barrier
+    // Fragment loads are software-pipelined one MFMA group ahead (register double buffer), across the
+    // stage boundary too.  Per k-step: three groups read the next group's fragments while they compute;
+    // then one wait+barrier proves (a) stage kt+1 has landed for every wave and (b) every wave has read
+    // the last fragments of stage kt, so the DMA for stage kt+2 may overwrite it — it gets a whole
+    // k-step to land.
+#define GEMM_FRAGS(WF, XF, STAGE, KK)                                                          \
+    {                                                                                          \
+        const unsigned char* xa_ = smem + (STAGE) * STAGE_BYTES;                               \
+        const unsigned char* xb_ = xa_ + A_BYTES;                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < NT; ++i_)                                      \
+            WF[i_] = *(const bf16x8*)(xb_ + lds_slot_addr((wn * NT + i_) * 32 + li, 2 * (KK) + lh)); \
+        _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                      \
+            XF[i_] = *(const bf16x8*)(xa_ + lds_slot_addr((wm * MT + i_) * 32 + li, 2 * (KK) + lh)); \
+    }
+#define GEMM_MFMAS(WF, XF)                                                                     \
+    _Pragma("unroll") for (int im_ = 0; im_ < MT; ++im_)                                       \
+        _Pragma("unroll") for (int in_ = 0; in_ < NT; ++in_)                                   \
+            acc[im_][in_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[in_], XF[im_], acc[im_][in_], 0, 0, 0);
+    // one MFMA, then one LDS read, ... so the reads hide under the matrix pipe
+#define GEMM_INTERLEAVE()                                                                      \
+    _Pragma("unroll") for (int s_ = 0; s_ < MT + NT; ++s_) {                                   \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                     \
+    }                                                                                          \
+    __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - (MT + NT) > 0 ? MT * NT - (MT + NT) : 0, 0);
 
+    GEMM_DMA(0, 0)
+    if (nk > 1) GEMM_DMA(1, 1)
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCH) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    bf16x8 wf0[NT], xf0[MT], wf1[NT], xf1[MT];
+    GEMM_FRAGS(wf0, xf0, 0, 0)
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) GEMM_DMA(kt + 1, buf ^ 1)               // next tile straight into the other buffer
-        const unsigned char* xa = smem + buf * STAGE_BYTES;      // activations (m)
-        const unsigned char* xb = xa + A_BYTES;                  // weights (n)
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 wf[NT], xf[MT];
-#pragma unroll
-            for (int i = 0; i < NT; ++i)
-                wf[i] = *(const bf16x8*)(xb + lds_slot_addr((wn * NT + i) * 32 + li, 2 * kk + lh));
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-                xf[i] = *(const bf16x8*)(xa + lds_slot_addr((wm * MT + i) * 32 + li, 2 * kk + lh));
-#pragma unroll
-            for (int im = 0; im < MT; ++im)
-#pragma unroll
-                for (int in = 0; in < NT; ++in)
-                    acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[in], xf[im], acc[im][in], 0, 0, 0);
-        }
-        __syncthreads();
+        GEMM_FRAGS(wf1, xf1, buf, 1)
+        GEMM_MFMAS(wf0, xf0)
+        GEMM_INTERLEAVE()
+        GEMM_FRAGS(wf0, xf0, buf, 2)
+        GEMM_MFMAS(wf1, xf1)
+        GEMM_INTERLEAVE()
+        GEMM_FRAGS(wf1, xf1, buf, 3)
+        GEMM_MFMAS(wf0, xf0)
+        GEMM_INTERLEAVE()
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + 2 < nk) GEMM_DMA(kt + 2, buf)
+        if (kt + 1 < nk) GEMM_FRAGS(wf0, xf0, buf ^ 1, 0)
+        GEMM_MFMAS(wf1, xf1)
     }
 
     // ---------------- epilogue ----------------
-    const bool vec_ok = (p.ldc & 3) == 0;
+    // The MFMA result layout gives each lane 4 consecutive n of ONE output row, 32 rows per
+    // instruction: stored directly that is 64 separate 8/16-byte segments per store.  Instead each
+    // wave transposes one 32(m) x NT*32(n) strip at a time through a private LDS patch (row pitch
+    // NT*32+4 floats keeps the ds_write_b128 conflict-free) and then walks it row-major, so that
+    // every global access is a 16-byte vector with LPR consecutive lanes covering one contiguous
+    // row segment — full 128/256-byte lines for stores and for the residual read-modify-write.
+    // All LDS reads of the main loop completed before its last barrier, so no extra barrier here.
+    constexpr bool OUT_BF16 = (EPI == OMH_EPI_BF16 || EPI == OMH_EPI_GELU_BF16 || EPI == OMH_EPI_GELU_ERF_BF16);
+    constexpr int PITCH = NT * 32 + 4;                 // floats
+    constexpr int VEC = OUT_BF16 ? 8 : 4;              // elements per 16-byte global access
+    constexpr int LPR = NT * 32 / VEC;                 // lanes per row
+    constexpr int RPP = 64 / LPR;                      // rows per pass
+    constexpr int PASSES = 32 / RPP;
+    static_assert(WM * WN * 32 * PITCH * 4 <= 2 * STAGE_BYTES, "epilogue patch does not fit the staging LDS");
+    float* ep = (float*)smem + wave * (32 * PITCH);
     float* Cf = (float*)p.C + zb * p.strideC;
     uint16_t* Ch = (uint16_t*)p.C + zb * p.strideC;
+    const int rr = lane / LPR, cc = (lane % LPR) * VEC;
+    const int n = n0 + wn * NT * 32 + cc;
+    const bool n_any = n < p.N;
+    const bool vec_ok = (p.ldc % VEC) == 0 && (((uintptr_t)(OUT_BF16 ? (void*)Ch : (void*)Cf)) & 15) == 0 &&
+                        n + VEC <= p.N;
+    float bn[VEC], g0[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const bool ok = n + e < p.N;
+        bn[e] = (p.bias_mode == OMH_BIAS_N && p.bias && ok) ? p.bias[n + e] : 0.f;
+        g0[e] = (EPI == OMH_EPI_RESID) ? p.gate_const + ((p.gate0 && ok) ? p.gate0[n + e] : 0.f) : 0.f;
+    }
 #pragma unroll
     for (int im = 0; im < MT; ++im) {
-        const int m = m0 + (wm * MT + im) * 32 + li;
-        if (m >= p.M) continue;
-        const float bias_m = (p.bias_mode == OMH_BIAS_M && p.bias) ? p.bias[m] : 0.f;
-        const int64_t gb = (EPI == OMH_EPI_RESID && p.gate1) ? (int64_t)(m / p.gate_rows) * p.gate1_stride : 0;
+        const int mrow = m0 + (wm * MT + im) * 32;
+        if (mrow >= p.M) break;                                    // wave-uniform
+        const float bias_m = (p.bias_mode == OMH_BIAS_M && p.bias && mrow + li < p.M) ? p.bias[mrow + li] : 0.f;
+        // read-modify-write epilogues: fetch the old values first, their latency hides under the transposition
+        constexpr bool RMW = (EPI == OMH_EPI_RESID || EPI == OMH_EPI_F32_ACCUM);
+        float4 cold[RMW ? PASSES : 1];
+        if (RMW && vec_ok) {
 #pragma unroll
-        for (int in = 0; in < NT; ++in) {
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int m = mrow + ps * RPP + rr;
+                cold[ps] = (m < p.M) ? *(const float4*)(Cf + (int64_t)m * p.ldc + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int n = n0 + (wn * NT + in) * 32 + 8 * gq + 4 * lh;
-                if (n >= p.N) continue;
-                float v[4];
+        for (int in = 0; in < NT; ++in)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[im][in][4 * gq + e] + bias_m;
-                const bool full = vec_ok && (n + 3 < p.N);
-                if (p.bias_mode == OMH_BIAS_N && p.bias) {
+            for (int gq = 0; gq < 4; ++gq)
+                *(float4*)(ep + li * PITCH + in * 32 + 8 * gq + 4 * lh) =
+                    make_float4(acc[im][in][4 * gq] + bias_m, acc[im][in][4 * gq + 1] + bias_m,
+                                acc[im][in][4 * gq + 2] + bias_m, acc[im][in][4 * gq + 3] + bias_m);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // wave-private patch: no barrier needed
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += p.bias[n + e];
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int r = ps * RPP + rr;
+            const int m = mrow + r;
+            float v[VEC];
+#pragma unroll
+            for (int q = 0; q < VEC / 4; ++q) {
+                const float4 t = *(const float4*)(ep + r * PITCH + cc + 4 * q);
+                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            }
+            if (m >= p.M || !n_any) continue;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] += bn[e];
+            if (EPI == OMH_EPI_GELU_BF16) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] = gelu_tanh(v[e]);
+            }
+            if (EPI == OMH_EPI_GELU_ERF_BF16) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.7071067811865476f));
+            }
+            if (EPI == OMH_EPI_RESID) {
+                if (p.gate1) {
+                    const float* g1 = p.gate1 + (int64_t)(m / p.gate_rows) * p.gate1_stride + n;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] *= g0[e] + ((n + e < p.N) ? g1[e] : 0.f);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] *= g0[e];
                 }
-                if (EPI == OMH_EPI_GELU_BF16) {
+            }
+            const int64_t off = (int64_t)m * p.ldc + n;
+            if (OUT_BF16) {
+                if (vec_ok) {
+                    uint4 pk;
+                    pk.x = pack_bf2(v[0], v[1]);
+                    pk.y = pack_bf2(v[2], v[3]);
+                    pk.z = pack_bf2(v[4 % VEC], v[5 % VEC]);
+                    pk.w = pack_bf2(v[6 % VEC], v[7 % VEC]);
+                    *(uint4*)(Ch + off) = pk;
+                } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+                    for (int e = 0; e < VEC; ++e) if (n + e < p.N) Ch[off + e] = f2bf(v[e]);
                 }
-                if (EPI == OMH_EPI_GELU_ERF_BF16) {
+            } else if (EPI == OMH_EPI_F32) {
+                if (vec_ok) {
+                    *(float4*)(Cf + off) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.7071067811865476f));
+                    for (int e = 0; e < VEC; ++e) if (n + e < p.N) Cf[off + e] = v[e];
                 }
-                if (EPI == OMH_EPI_RESID) {
+            } else {  // RESID / F32_ACCUM: read-modify-write
+                if (vec_ok) {
+                    float4 o = cold[RMW ? ps : 0];
+                    o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
+                    *(float4*)(Cf + off) = o;
+                } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (n + e < p.N) {
-                            float gt = p.gate_const;
-                            if (p.gate0) gt += p.gate0[n + e];
-                            if (p.gate1) gt += p.gate1[gb + n + e];
-                            v[e] *= gt;
-                        }
-                    }
-                }
-                const int64_t off = (int64_t)m * p.ldc + n;
-                if (EPI == OMH_EPI_BF16 || EPI == OMH_EPI_GELU_BF16 || EPI == OMH_EPI_GELU_ERF_BF16) {
-                    if (full) {
-                        uint2 pk;
-                        pk.x = pack_bf2(v[0], v[1]);
-                        pk.y = pack_bf2(v[2], v[3]);
-                        *(uint2*)(Ch + off) = pk;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (n + e < p.N) Ch[off + e] = f2bf(v[e]);
-                    }
-                } else if (EPI == OMH_EPI_F32) {
-                    if (full) {
-                        *(float4*)(Cf + off) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (n + e < p.N) Cf[off + e] = v[e];
-                    }
-                } else {  // RESID / F32_ACCUM: read-modify-write
-                    if (full) {
-                        float4 o = *(const float4*)(Cf + off);
-                        o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
-                        *(float4*)(Cf + off) = o;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (n + e < p.N) Cf[off + e] += v[e];
-                    }
+                    for (int e = 0; e < VEC; ++e) if (n + e < p.N) Cf[off + e] += v[e];
                 }
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // patch is rewritten by the next strip
     }
 }
 
@@ -219,7 +288,7 @@ int launch_cfg(const omh_gemm_args& a, hipStream_t s) {
     auto kern = gemm_bf16_nt_kernel<EPI, WM, WN, MT, NT>;
     static bool attr_set = false;            // > 64 KiB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     GemmGeom g;

@@ -20,6 +20,7 @@
 // fetched from the shifted voxel (out-of-image taps get an out-of-range buffer
 // offset and arrive as zeros), so the 27-fold re-read of the input stays in L2.
 #include "omh_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -195,6 +196,269 @@ void conv_cl_kernel(const omh_conv_args p, const int tiles_m, const int tiles_n)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Wide configuration: 8 waves, each owning a 64(m) x 96(n) patch (2 x 3 MFMA tiles), so that the tile's N
+// extent is a multiple of 96 — the VAE's channel counts are 96/192/384/768 and a 128-wide tile idles a
+// quarter of the matrix pipe on them.  WM x WN = 8x1 (512 x 96, Cout <= 96) or 4x2 (256 x 192).
+// Same LDS image, swizzle and DMA staging as above; the main loop is the one of gemm_bf16.hip's big tile
+// (fragments read one 16-wide k group ahead, one barrier per k-step, stage kt+2 issued right after the
+// barrier), and the epilogue goes through a per-wave LDS patch so that global accesses are row-major
+// 16-byte vectors (a [*, 96] bf16 output is one contiguous 6 KiB run per 32-row strip).
+template <bool OUT_F32, int WM, int WN>
+__global__ __launch_bounds__(512)
+void conv_cl_wide_kernel(const omh_conv_args p, const int tiles_m, const int tiles_n) {
+    constexpr int MT = 2, NT = 3, THREADS = 512;
+    constexpr int WBM = WM * MT * 32, WBN = WN * NT * 32;
+    constexpr int A_BYTES = WBM * BK * 2, B_BYTES = WBN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int CA = WBM * 8 / THREADS;                            // 16-byte chunks per thread: voxels
+    constexpr int CB = (WBN * 8 + THREADS - 1) / THREADS;            //                            weights
+    static_assert(WM * WN == 8 && WBM * 8 % THREADS == 0, "8 waves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int wid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int tm, tn;
+    tile_of(wid, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * WBM, n0 = tn * WBN;
+    const int M = p.Tout * p.Hout * p.Wout;
+    const int K = p.KT * p.KH * p.KW * p.Cin;
+    const int Heff = p.up2 ? 2 * p.Hin : p.Hin, Weff = p.up2 ? 2 * p.Win : p.Win;
+    const int HWin = p.Hin * p.Win;
+
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.x, 0, (int)((int64_t)p.Tin * p.Hin * p.Win * p.Cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.w, 0, (int)((int64_t)p.Cout * K * 2), 0x00020000);
+    // chunk c = tid + 512 j -> tile row (tid>>3) + 64 j, physical slot tid&7: all rows of a thread share the
+    // logical slot, i.e. one (tap, channel) position per thread and k-step.
+    const int lslot = (tid & 7) ^ ((tid >> 4) & 7);
+    int a_vox[CA], a_yx[CA];                                         // frame base voxel; (y<<16 | x) of tap (0,0)
+#pragma unroll
+    for (int j = 0; j < CA; ++j) {
+        const int m = m0 + (tid >> 3) + 64 * j;
+        const int mc = min(m, M - 1);
+        const int xo = mc % p.Wout, yo = (mc / p.Wout) % p.Hout, to = mc / (p.Wout * p.Hout);
+        a_vox[j] = to * p.stride_t * HWin;
+        const int ay = (m < M) ? yo * p.stride_hw - p.pad_h : -16384;  // rows past M never pass the bounds test
+        const int ax = xo * p.stride_hw - p.pad_w;
+        a_yx[j] = (ay << 16) | (ax & 0xffff);
+    }
+    static_assert(CB <= 3, "weight chunks per thread");
+    uint32_t voff_w[3];                                              // (fixed extent: a dependent one loses the host-side kernel stub)
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+        const int row = (tid >> 3) + 64 * j;
+        voff_w[j] = (row < WBN && n0 + row < p.Cout) ? (uint32_t)(((int64_t)(n0 + row) * K + lslot * 8) * 2) : 0x80000000u;
+    }
+    const int wave_lds = __builtin_amdgcn_readfirstlane(wave) * 1024;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (K + BK - 1) / BK;
+    // running (tap, channel) position of this thread's slot, advanced by BK per staged k-step
+    int s_ci = lslot * 8, s_tx = 0, s_ty = 0, s_tt = 0, s_k = lslot * 8;
+    while (s_ci >= p.Cin) {
+        s_ci -= p.Cin;
+        if (++s_tx == p.KW) { s_tx = 0; if (++s_ty == p.KH) { s_ty = 0; ++s_tt; } }
+    }
+#define WCONV_DMA(KT_, BUF)                                                                        \
+    {                                                                                              \
+        unsigned char* xa_ = smem + (BUF) * STAGE_BYTES;                                           \
+        unsigned char* xb_ = xa_ + A_BYTES;                                                        \
+        const bool kok = s_k < K;                                                                  \
+        const int tapvox = s_tt * HWin;                                                            \
+        _Pragma("unroll") for (int j_ = 0; j_ < CA; ++j_) {                                        \
+            const int iy = (a_yx[j_] >> 16) + s_ty, ix = (int)(short)(a_yx[j_] & 0xffff) + s_tx;   \
+            const bool ok = kok && iy >= 0 && iy < Heff && ix >= 0 && ix < Weff;                   \
+            const int sy = p.up2 ? (iy >> 1) : iy, sx = p.up2 ? (ix >> 1) : ix;                    \
+            const uint32_t xo_ = ok ? (uint32_t)(((a_vox[j_] + tapvox + sy * p.Win + sx) * p.Cin + s_ci) * 2) \
+                                    : 0x80000000u;                                                 \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(xa_ + wave_lds + j_ * 8192), 16, xo_, 0, 0, 0); \
+        }                                                                                          \
+        const uint32_t wko = kok ? (uint32_t)((KT_) * BK * 2) : 0x80000000u;                       \
+        _Pragma("unroll") for (int j_ = 0; j_ < CB; ++j_)                                          \
+            if (wave * 64 + 512 * j_ < WBN * 8)                                                    \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(xb_ + wave_lds + j_ * 8192), 16, \
+                                                         voff_w[j_] + wko, 0, 0, 0);               \
+        s_k += BK; s_ci += BK;                                                                     \
+        while (s_ci >= p.Cin) {                                                                    \
+            s_ci -= p.Cin;                                                                         \
+            if (++s_tx == p.KW) { s_tx = 0; if (++s_ty == p.KH) { s_ty = 0; ++s_tt; } }            \
+        }                                                                                          \
+    }
+#define WCONV_FRAGS(WF, XF, STAGE, KK)                                                             \
+    {                                                                                              \
+        const unsigned char* xa_ = smem + (STAGE) * STAGE_BYTES;                                   \
+        const unsigned char* xb_ = xa_ + A_BYTES;                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < NT; ++i_)                                          \
+            WF[i_] = *(const bf16x8*)(xb_ + lds_slot_addr((wn * NT + i_) * 32 + li, 2 * (KK) + lh)); \
+        _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                          \
+            XF[i_] = *(const bf16x8*)(xa_ + lds_slot_addr((wm * MT + i_) * 32 + li, 2 * (KK) + lh)); \
+    }
+#define WCONV_MFMAS(WF, XF)                                                                        \
+    _Pragma("unroll") for (int im_ = 0; im_ < MT; ++im_)                                           \
+        _Pragma("unroll") for (int in_ = 0; in_ < NT; ++in_)                                       \
+            acc[im_][in_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[in_], XF[im_], acc[im_][in_], 0, 0, 0);
+#define WCONV_INTERLEAVE()                                                                         \
+    _Pragma("unroll") for (int s_ = 0; s_ < MT + NT; ++s_) {                                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
+    }                                                                                              \
+    __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - (MT + NT), 0);
+
+    WCONV_DMA(0, 0)
+    if (nk > 1) {
+        WCONV_DMA(1, 1)
+        // wait for stage 0 only: stage 1's loads (issued later) may still be in flight
+        if (wave * 64 + 512 * (CB - 1) < WBN * 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CA + CB) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CA + CB - 1) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+
+    bf16x8 wf0[NT], xf0[MT], wf1[NT], xf1[MT];
+    WCONV_FRAGS(wf0, xf0, 0, 0)
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        WCONV_FRAGS(wf1, xf1, buf, 1)
+        WCONV_MFMAS(wf0, xf0)
+        WCONV_INTERLEAVE()
+        WCONV_FRAGS(wf0, xf0, buf, 2)
+        WCONV_MFMAS(wf1, xf1)
+        WCONV_INTERLEAVE()
+        WCONV_FRAGS(wf1, xf1, buf, 3)
+        WCONV_MFMAS(wf0, xf0)
+        WCONV_INTERLEAVE()
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + 2 < nk) WCONV_DMA(kt + 2, buf)
+        if (kt + 1 < nk) WCONV_FRAGS(wf0, xf0, buf ^ 1, 0)
+        WCONV_MFMAS(wf1, xf1)
+    }
+
+    // ---------------- epilogue: + bias (+ residual), bf16 or fp32, optional frame interleave
+    constexpr int PITCH = NT * 32 + 4;                                // floats; 100 mod 32 = 4: conflict-free b128 writes
+    constexpr int VEC = OUT_F32 ? 4 : 8;
+    constexpr int CPR = NT * 32 / VEC;                                // 16-byte chunks per strip row
+    constexpr int PASSES = 32 * CPR / 64;
+    static_assert(8 * 32 * PITCH * 4 <= 2 * STAGE_BYTES, "epilogue patch does not fit the staging LDS");
+    float* ep = (float*)smem + wave * (32 * PITCH);
+    const int HW = p.Hout * p.Wout;
+    const int nsplit = p.split_n > 0 ? p.split_n : p.Cout;            // channels per output frame
+    const int fmul = p.Cout / nsplit;                                 // frames produced per input frame
+    float* Yf = (float*)p.y;
+    uint16_t* Yh = (uint16_t*)p.y;
+    const uint16_t* R = (const uint16_t*)p.resid;
+    const bool vec_all = (nsplit % VEC) == 0;
+#pragma unroll
+    for (int im = 0; im < MT; ++im) {
+        const int mrow = m0 + (wm * MT + im) * 32;
+        if (mrow >= M) break;                                         // wave-uniform
+        // output offsets of this lane's chunks, and the residual fetched up front so that its latency
+        // hides under the LDS transposition
+        int64_t offs[PASSES];
+        uint4 rres[PASSES];
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int q = ps * 64 + lane;
+            const int r = q / CPR, cc = (q - r * CPR) * VEC;
+            const int m = mrow + r, n = n0 + wn * (NT * 32) + cc;
+            if (fmul == 1) {
+                offs[ps] = (int64_t)m * p.Cout + n;
+            } else {
+                const int to = m / HW, pix = m - to * HW;
+                const int jf = n / nsplit, c = n - jf * nsplit;
+                offs[ps] = ((int64_t)(to * fmul + jf) * HW + pix) * nsplit + c;
+            }
+            rres[ps] = make_uint4(0, 0, 0, 0);
+            if (!OUT_F32 && R && m < M && vec_all && n + VEC <= p.Cout) rres[ps] = *(const uint4*)(R + offs[ps]);
+        }
+#pragma unroll
+        for (int in = 0; in < NT; ++in)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                *(float4*)(ep + li * PITCH + in * 32 + 8 * gq + 4 * lh) =
+                    make_float4(acc[im][in][4 * gq], acc[im][in][4 * gq + 1], acc[im][in][4 * gq + 2], acc[im][in][4 * gq + 3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int q = ps * 64 + lane;
+            const int r = q / CPR, cc = (q - r * CPR) * VEC;
+            const int m = mrow + r, n = n0 + wn * (NT * 32) + cc;
+            float v[VEC];
+#pragma unroll
+            for (int h = 0; h < VEC / 4; ++h) {
+                const float4 t = *(const float4*)(ep + r * PITCH + cc + 4 * h);
+                v[4 * h] = t.x; v[4 * h + 1] = t.y; v[4 * h + 2] = t.z; v[4 * h + 3] = t.w;
+            }
+            if (m >= M || n >= p.Cout) continue;
+            const bool full = vec_all && n + VEC <= p.Cout;
+            if (p.bias) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) if (n + e < p.Cout) v[e] += p.bias[n + e];
+            }
+            const int64_t off = offs[ps];
+            if (R) {
+                if (full && !OUT_F32) {
+                    const uint32_t rw[4] = {rres[ps].x, rres[ps].y, rres[ps].z, rres[ps].w};
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] += bf2f((uint16_t)((rw[(e >> 1) & 3] >> (16 * (e & 1))) & 0xffff));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) if (n + e < p.Cout) v[e] += bf2f(R[off + e]);
+                }
+            }
+            if (OUT_F32) {
+                if (full) *(float4*)(Yf + off) = make_float4(v[0], v[1], v[2], v[3]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) if (n + e < p.Cout) Yf[off + e] = v[e];
+                }
+            } else {
+                if (full) {
+                    uint4 pk;
+                    pk.x = pack_bf2(v[0], v[1]);
+                    pk.y = pack_bf2(v[2], v[3]);
+                    pk.z = pack_bf2(v[4 % VEC], v[5 % VEC]);
+                    pk.w = pack_bf2(v[6 % VEC], v[7 % VEC]);
+                    *(uint4*)(Yh + off) = pk;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) if (n + e < p.Cout) Yh[off + e] = f2bf(v[e]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+template <bool OUT_F32, int WM, int WN>
+int launch_wide(const omh_conv_args& a, int64_t M, hipStream_t s) {
+    constexpr int WBM = WM * 64, WBN = WN * 96;
+    constexpr int LDS = 2 * (WBM + WBN) * BK * 2;
+    auto kern = conv_cl_wide_kernel<OUT_F32, WM, WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    const int tiles_m = (int)((M + WBM - 1) / WBM), tiles_n = (a.Cout + WBN - 1) / WBN;
+    omh_clear_status();
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), LDS, s, a, tiles_m, tiles_n);
+    return omh_launch_status();
+}
+
 }  // namespace
 
 extern "C" int omh_conv_cl_bf16(const omh_conv_args* args, omh_stream_t stream) {
@@ -212,6 +476,19 @@ extern "C" int omh_conv_cl_bf16(const omh_conv_args* args, omh_stream_t stream) 
     if (M > 0x7fffffff) return OMH_E_SHAPE;
     // 32-bit buffer offsets
     if ((int64_t)a.Tin * a.Hin * a.Win * a.Cin * 2 >= 0x7fffffffLL) return OMH_E_SHAPE;
+    // wide tiles (N extent 96 / 192) once they give every CU most of a workgroup; the 128x128 tile otherwise
+    const char* force = getenv("OMH_CONV_TILE");                     // "wide" / "small": test / benchmarking override
+    const bool narrow = a.Cout <= 96;
+    const int64_t wide_tiles = narrow ? (M + 511) / 512 : ((M + 255) / 256) * ((a.Cout + 191) / 192);
+    bool wide = wide_tiles >= 192;
+    if (force && force[0] == 'w') wide = true;
+    if (force && force[0] == 's') wide = false;
+    if (((uintptr_t)a.resid & 15) || ((uintptr_t)a.bias & 3)) wide = false;
+    if (wide) {
+        hipStream_t s = (hipStream_t)stream;
+        if (narrow) return a.out_f32 ? launch_wide<true, 8, 1>(a, M, s) : launch_wide<false, 8, 1>(a, M, s);
+        return a.out_f32 ? launch_wide<true, 4, 2>(a, M, s) : launch_wide<false, 4, 2>(a, M, s);
+    }
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (a.Cout + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n);
     omh_clear_status();

@@ -25,8 +25,14 @@ def _bf(x):
     dict(Cin=24, Cout=48, T=4, H=6, W=6, KT=3, KH=1, KW=1),
     dict(Cin=32, Cout=136, T=2, H=5, W=5, KT=1, KH=1, KW=1),
     dict(Cin=8, Cout=3, T=1, H=16, W=16, KT=3, KH=3, KW=3),
+    dict(Cin=96, Cout=96, T=2, H=24, W=27, KT=3, KH=3, KW=3),     # 1296 voxels: 3 ragged 512-row tiles
+    dict(Cin=192, Cout=192, T=1, H=20, W=31, KT=3, KH=3, KW=3),   # one full 192-column tile
+    dict(Cin=64, Cout=384, T=2, H=11, W=13, KT=3, KH=3, KW=3),    # two 192-column tiles
+    dict(Cin=48, Cout=200, T=1, H=17, W=17, KT=1, KH=3, KW=3),    # ragged second column tile
 ])
-def test_conv_cl_matches_torch(ops, cfg):
+@pytest.mark.parametrize("tile", ["small", "wide"])
+def test_conv_cl_matches_torch(ops, cfg, tile, monkeypatch):
+    monkeypatch.setenv("OMH_CONV_TILE", tile)            # both tile configurations on every shape
     torch.manual_seed(cfg["Cin"] + cfg["Cout"])
     Cin, Cout, T, H, W, KT, KH, KW = (cfg[k] for k in ("Cin", "Cout", "T", "H", "W", "KT", "KH", "KW"))
     hist = KT - 1
@@ -41,9 +47,14 @@ def test_conv_cl_matches_torch(ops, cfg):
     ref = ref[0].permute(1, 2, 3, 0) + resid.float()
     assert y.shape == ref.shape
     assert rel_rms(y, ref) < 2e-5
+    # bf16 output (the layout every inner layer uses): same values, one bf16 rounding
+    yb = ops.conv_cl(x, wp, bias, T, H, W, Cout, KT, KH, KW, pad_h=KH // 2, pad_w=KW // 2, resid=resid)
+    assert yb.dtype == torch.bfloat16 and torch.equal(yb, y.to(torch.bfloat16))
 
 
-def test_conv_cl_upsample_downsample_stride_split(ops):
+@pytest.mark.parametrize("tile", ["small", "wide"])
+def test_conv_cl_upsample_downsample_stride_split(ops, tile, monkeypatch):
+    monkeypatch.setenv("OMH_CONV_TILE", tile)
     torch.manual_seed(9)
     C, H, W = 32, 6, 10
     x = _bf(torch.randn(2, H, W, C, device="cuda"))
