@@ -13,7 +13,8 @@ import os
 import torch  # noqa: F401  (import order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "lib", "libomh.so")
+# OMH_LIB: another build of the same ABI (A/B timing of kernel revisions on one box); normally unset
+_LIB_PATH = os.environ.get("OMH_LIB") or os.path.join(_HERE, "lib", "libomh.so")
 
 
 class OmhError(RuntimeError):

@@ -27,6 +27,7 @@ import torch.distributed as dist
 
 from .modules.model import WanModel
 from .modules.vae import WanVAE
+from .utils.fm_solvers import FlowDPMSolverMultistepScheduler, get_sampling_sigmas, retrieve_timesteps
 from .utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
 
 
@@ -89,15 +90,24 @@ class WanT2V:
         context_null = [t.to(self.device) for t in context_null]
         noise = [torch.randn(*target_shape, dtype=torch.float32, device=self.device, generator=seed_g)]
 
-        if sample_solver != "unipc":
-            raise NotImplementedError("Unsupported solver: only 'unipc' (the reference default) is built")
+        if sample_solver not in ("unipc", "dpm++"):
+            raise NotImplementedError("Unsupported solver.")
         with torch.no_grad():
-            sample_scheduler = FlowUniPCMultistepScheduler(num_train_timesteps=self.num_train_timesteps, shift=1,
-                                                           use_dynamic_shifting=False)
-            sample_scheduler.set_timesteps(sampling_steps, device=self.device, shift=shift)
+            if sample_solver == "unipc":                       # text2video.py:204-211
+                sample_scheduler = FlowUniPCMultistepScheduler(num_train_timesteps=self.num_train_timesteps, shift=1,
+                                                               use_dynamic_shifting=False)
+                sample_scheduler.set_timesteps(sampling_steps, device=self.device, shift=shift)
+                timesteps = sample_scheduler.timesteps
+            else:                                              # text2video.py:212-221
+                sample_scheduler = FlowDPMSolverMultistepScheduler(num_train_timesteps=self.num_train_timesteps,
+                                                                   shift=1, use_dynamic_shifting=False)
+                timesteps, _ = retrieve_timesteps(sample_scheduler, device=self.device,
+                                                  sigmas=get_sampling_sigmas(sampling_steps, shift))
             sample_scheduler.set_begin_index(0)
-            timesteps = sample_scheduler.timesteps
             latents = noise
+            # text embedding + per-block cross-attention K/V do not depend on (x, t): once per sample, not 100x
+            if hasattr(self.model, "encode_context"):
+                context, context_null = self.model.encode_context(context), self.model.encode_context(context_null)
             for t in timesteps:
                 timestep = torch.stack([t])
                 cond = self.model(latents, t=timestep, context=context, seq_len=seq_len)[0]

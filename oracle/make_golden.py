@@ -39,6 +39,22 @@ def tiny_case(model_type, layers):
     return cfg, tag, xs, ctx, torch.tensor([999., 500.]), 30, ys, clip
 
 
+def golden_dpmpp():
+    os.makedirs(OUT, exist_ok=True)
+    # ---- DPM-Solver++ scheduler (sample_solver='dpm++', text2video.py:212-221): 6 steps, shift 3.0
+    Dpm, get_sigmas, retrieve = ref_import.load_reference_dpmpp()
+    r = Dpm(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+    tsteps, _ = retrieve(r, device="cpu", sigmas=get_sigmas(6, 3.0))
+    x = torch.from_numpy(detgen.normalish("golden/dpmpp/x", (1, 16, 2, 6, 8)))
+    traj = []
+    for k, tstep in enumerate(tsteps):
+        v = torch.from_numpy(detgen.normalish(f"golden/dpmpp/v{k}", (1, 16, 2, 6, 8)))
+        x = r.step(v, tstep, x, return_dict=False)[0]
+        traj.append(x.numpy())
+    np.savez_compressed(os.path.join(OUT, "dpmpp_6steps.npz"), traj=np.stack(traj), sigmas=r.sigmas.numpy(),
+                        timesteps=r.timesteps.numpy())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_grad_enabled(False)
@@ -121,6 +137,8 @@ def main():
     np.savez_compressed(os.path.join(OUT, "unipc_6steps.npz"), traj=np.stack(traj), sigmas=r.sigmas.numpy(),
                         timesteps=r.timesteps.numpy())
 
+    golden_dpmpp()
+
     # ---- full-size Wan2.1-T2V-1.3B forward (config 1): checksums + 64 probe elements
     if os.environ.get("OMH_GOLDEN_FULL", "1") == "1":
         cfg = O.DiTConfig.wan_t2v_1_3b()
@@ -138,4 +156,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "dpmpp":        # regenerate just that fixture
+        torch.set_grad_enabled(False)
+        golden_dpmpp()
+    else:
+        main()

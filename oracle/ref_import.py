@@ -164,6 +164,20 @@ def load_reference_unipc():
     wutils = types.ModuleType("wan.utils")
     wutils.__path__ = [os.path.join(REFERENCE_ROOT, "seaweed_apt", "wan", "utils")]
     sys.modules.setdefault("wan.utils", wutils)
+    tu = types.ModuleType("diffusers.utils.torch_utils")
+    tu.randn_tensor = lambda shape, generator=None, device=None, dtype=None: torch.randn(
+        shape, generator=generator, device=device, dtype=dtype)
+    sys.modules["diffusers.utils.torch_utils"] = tu
     mod = importlib.import_module("wan.utils.fm_solvers_unipc")
     _CACHE["unipc"] = mod.FlowUniPCMultistepScheduler
     return _CACHE["unipc"]
+
+
+def load_reference_dpmpp():
+    """(FlowDPMSolverMultistepScheduler, get_sampling_sigmas, retrieve_timesteps) of the reference
+    (seaweed_apt/wan/utils/fm_solvers.py), through the same diffusers base-class stub."""
+    if "dpmpp" not in _CACHE:
+        load_reference_unipc()
+        mod = importlib.import_module("wan.utils.fm_solvers")
+        _CACHE["dpmpp"] = (mod.FlowDPMSolverMultistepScheduler, mod.get_sampling_sigmas, mod.retrieve_timesteps)
+    return _CACHE["dpmpp"]

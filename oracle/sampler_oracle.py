@@ -88,10 +88,64 @@ class UniPCOracle:
         return nxt
 
 
-def sample_loop(velocity_fn, x, num_steps, shift, guide):
-    """text2video.py:231-252 with velocity_fn(x, t) -> (cond, uncond)."""
-    sch = UniPCOracle(num_steps, shift)
+def sample_loop(velocity_fn, x, num_steps, shift, guide, solver="unipc"):
+    """text2video.py:204-252 with velocity_fn(x, t) -> (cond, uncond)."""
+    sch = UniPCOracle(num_steps, shift) if solver == "unipc" else DPMSolverOracle(num_steps, shift)
     for t in sch.timesteps:
         c, u = velocity_fn(x, t)
         x = sch.step(u + guide * (c - u), x)
     return x
+
+
+# --------------------------------------------------------------------------------------------------
+# Flow DPM-Solver++ (2M, midpoint) — seaweed_apt/wan/utils/fm_solvers.py, the sample_solver='dpm++'
+# branch of WanT2V.generate (text2video.py:212-221).  Pinned against the reference class by
+# oracle/make_golden.py -> tests/golden/dpmpp_6steps.npz.
+# --------------------------------------------------------------------------------------------------
+def dpm_sampling_sigmas(num_steps: int, shift: float, num_train_timesteps: int = 1000):
+    """get_sampling_sigmas (fm_solvers.py:22-26) fed to set_timesteps(sigmas=...) (:226-290) of a scheduler
+    constructed with shift=1: float32 sigmas [n+1] (first exactly 1, last 0), int64 (truncated) timesteps [n]."""
+    s = np.linspace(1, 0, num_steps + 1)[:num_steps]
+    s = shift * s / (1 + (shift - 1) * s)
+    s = 1.0 * s / (1 + (1.0 - 1) * s)                       # the scheduler's own shift (=1)
+    timesteps = torch.from_numpy(s * num_train_timesteps).to(torch.int64)
+    sig = torch.from_numpy(np.concatenate([s, [0]]).astype(np.float32))
+    return sig, timesteps
+
+
+class DPMSolverOracle:
+    """solver_order 2, dpmsolver++, midpoint, flow_prediction, lower_order_final, final sigma 0."""
+
+    def __init__(self, num_steps: int, shift: float):
+        self.sigmas, self.timesteps = dpm_sampling_sigmas(num_steps, shift)
+        self.m = [None, None]                               # x0 predictions, oldest first
+        self.lower = 0
+        self.i = 0
+
+    @staticmethod
+    def _lam(s):
+        return torch.log(1 - s) - torch.log(s)              # log(alpha) - log(sigma)    (:333-334,459-460)
+
+    def step(self, v: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        """One scheduler.step(v, t_i, x) (:706-798)."""
+        i, sig, n = self.i, self.sigmas, len(self.timesteps)
+        lower_order_final = (i == n - 1)                    # final_sigmas_type == "zero"       (:745-748)
+        lower_order_second = (i == n - 2) and n < 15        # lower_order_final and few steps   (:749-751)
+        m0 = x - sig[i] * v                                 # convert_model_output              (:377-379)
+        self.m = [self.m[1], m0]
+        s_t, s_0 = sig[i + 1], sig[i]
+        a_t = 1 - s_t
+        h = self._lam(s_t) - self._lam(s_0)
+        if self.lower < 1 or lower_order_final:             # first-order update                (:456-467)
+            nxt = (s_t / s_0) * x - (a_t * (torch.exp(-h) - 1.0)) * m0
+        else:                                               # 2M midpoint                       (:528-556)
+            _ = lower_order_second                          # (order 2 either way)
+            s_1 = sig[i - 1]
+            h_0 = self._lam(s_0) - self._lam(s_1)
+            r0 = h_0 / h
+            D0, D1 = m0, (1.0 / r0) * (m0 - self.m[0])
+            nxt = ((s_t / s_0) * x - (a_t * (torch.exp(-h) - 1.0)) * D0 - 0.5 * (a_t * (torch.exp(-h) - 1.0)) * D1)
+        if self.lower < 2:
+            self.lower += 1
+        self.i += 1
+        return nxt

@@ -112,6 +112,32 @@ def test_unipc_host_coefficients_match_oracle(omh):
             assert float((x - xo).abs().max()) < 2e-5, (n, i)
 
 
+def test_dpmpp_host_coefficients_match_oracle(omh):
+    """DPM-Solver++ folded into 3 scalars per step; emulate the kernel's formula on CPU."""
+    from oracle import detgen, sampler_oracle as SO
+    sch = importlib.import_module(PKG + ".wan.utils.fm_solvers")
+    assert np.allclose(sch.get_sampling_sigmas(6, 3.0), [1, 0.9375, 6 / 7, 0.75, 0.6, 0.375], rtol=1e-15)
+    for n, shift in ((6, 3.0), (50, 5.0), (20, 5.0), (2, 1.0), (1, 5.0)):
+        s = sch.FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+        ts, cnt = sch.retrieve_timesteps(s, device="cpu", sigmas=sch.get_sampling_sigmas(n, shift))
+        o = SO.DPMSolverOracle(n, shift)
+        assert cnt == n and torch.equal(s.sigmas, o.sigmas) and torch.equal(ts, o.timesteps)
+        x = xo = torch.from_numpy(detgen.normalish("coef/x", (4, 5)))
+        m1, lower = None, 0
+        for i in range(n):
+            v = torch.from_numpy(detgen.normalish(f"coef/v{i}", (4, 5)))
+            first = lower < 1 or i == n - 1
+            sigma, (cx, c0, c1) = sch.dpmpp_coefficients(s.sigmas, i, 1 if first else 2)
+            assert all(np.isfinite(c) for c in (sigma, cx, c0, c1))
+            mt = x - sigma * v
+            xn = cx * x + c0 * mt + (c1 * m1 if not first else 0)
+            m1, lower, x = mt, min(lower + 1, 2), xn
+            xo = o.step(v, xo)
+            assert float((x - xo).abs().max()) < 2e-5, (n, i)
+    with pytest.raises(ValueError):
+        sch.retrieve_timesteps(s, timesteps=[1], sigmas=[1.0])
+
+
 def test_configs(omh):
     cfgs = importlib.import_module(PKG + ".wan.configs")
     c = cfgs.t2v_1_3B

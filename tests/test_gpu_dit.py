@@ -48,6 +48,41 @@ def test_tiny_model_matches_oracle(wan_model_mod, layers):
     assert out2[0].shape == ref[0].shape
 
 
+def test_context_state_reuse_is_bit_identical(wan_model_mod):
+    """encode_context() (text embedding + per-block cross-attention K/V computed once per sample)
+    must not change a single bit of the forward, for t2v and for i2v (image-token K/V cached too)."""
+    from oracle import wan_dit_oracle as O, make_golden
+    cfg = O.DiTConfig(dim=256, ffn_dim=512, num_heads=2, num_layers=3, text_dim=64, text_len=32, freq_dim=64)
+    m = wan_model_mod.WanModel(dim=256, ffn_dim=512, num_heads=2, num_layers=3, text_dim=64, text_len=32, freq_dim=64)
+    m.load_state_dict(O.synth_state_dict(cfg, "ctxstate"))
+    m = m.cuda().eval().requires_grad_(False)
+    xs, ctx = _inputs(cfg, [(2, 3, 4), (1, 2, 3)], [32, 11], "ctxstate")
+    xs, ctx = [u.cuda() for u in xs], [c.cuda() for c in ctx]
+    st = m.encode_context(ctx)
+    for tval in (999., 250.):                      # first use fills the K/V cache, second use reads it
+        t = torch.tensor([tval, tval / 2]).cuda()
+        plain = m(xs, t, ctx, 30)
+        cached = m(xs, t, st, 30)
+        assert all(torch.equal(a, b) for a, b in zip(plain, cached))
+    assert len(st.kv) == 3
+    with torch.no_grad():
+        m.blocks[1].cross_attn.k.weight.mul_(1.5)  # stale cache must be refused, not silently reused
+    with pytest.raises(ValueError):
+        m(xs, t, st, 30)
+    # i2v
+    cfg, tag, xs, ctx, tt, seq_len, ys, clip = make_golden.tiny_case("i2v", 2)
+    mi = wan_model_mod.WanModel(model_type="i2v", in_dim=36, num_layers=2, **make_golden.TINY)
+    mi.load_state_dict(O.synth_state_dict(cfg, tag))
+    mi = mi.cuda().eval().requires_grad_(False)
+    xs, ctx, ys, clip = [u.cuda() for u in xs], [c.cuda() for c in ctx], [u.cuda() for u in ys], clip.cuda()
+    sti = mi.encode_context(ctx, clip_fea=clip)
+    plain = mi(xs, tt.cuda(), ctx, seq_len, clip_fea=clip, y=ys)
+    for _ in range(2):
+        cached = mi(xs, tt.cuda(), sti, seq_len, y=ys)
+        assert all(torch.equal(a, b) for a, b in zip(plain, cached))
+    assert len(sti.kv) == 4                        # (k, k_img) x 2 blocks
+
+
 def test_block_hooks_and_errors(wan_model_mod):
     from oracle import wan_dit_oracle as O
     cfg = O.DiTConfig(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64, text_len=32, freq_dim=64)

@@ -74,6 +74,25 @@ def test_unipc_matches_reference_vectors():
     assert torch.allclose(o1.step(v, x), x - o1.sigmas[0] * v, atol=1e-6)
 
 
+def test_dpmpp_matches_reference_vectors():
+    """sample_solver='dpm++' (fm_solvers.py): the oracle reproduces the reference trajectory bit for bit."""
+    from oracle import detgen, sampler_oracle as SO
+    g = _g("dpmpp_6steps.npz")
+    o = SO.DPMSolverOracle(6, 3.0)
+    assert np.array_equal(o.sigmas.numpy(), g["sigmas"]) and np.array_equal(o.timesteps.numpy(), g["timesteps"])
+    assert o.sigmas[0] == 1.0 and o.sigmas[-1] == 0.0          # lambda = -/+inf at both ends: must stay finite
+    x = torch.from_numpy(detgen.normalish("golden/dpmpp/x", (1, 16, 2, 6, 8)))
+    for k in range(6):
+        v = torch.from_numpy(detgen.normalish(f"golden/dpmpp/v{k}", (1, 16, 2, 6, 8)))
+        x = o.step(v, x)
+        assert np.array_equal(x.numpy(), g["traj"][k])
+    # closed forms: one step lands on x0 = x - v (sigma 1 -> 0); the last step of any run returns the x0 prediction
+    o1 = SO.DPMSolverOracle(1, 5.0)
+    x = torch.from_numpy(detgen.normalish("golden/dpmpp/x", (1, 16, 2, 6, 8)))
+    v = torch.from_numpy(detgen.normalish("golden/dpmpp/v0", (1, 16, 2, 6, 8)))
+    assert torch.allclose(o1.step(v, x), x - v, atol=1e-6)
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/seaweed_apt"), reason="reference tree not present")
 def test_oracle_against_live_reference():
     from oracle import detgen, ref_import, wan_dit_oracle as O, wan_vae_oracle as V
