@@ -99,3 +99,59 @@ def test_wan_t2v_generate_tiny_matches_oracle(solver):
     assert vid.shape == (3, 5, 48, 64) and bool(torch.isfinite(vid).all()) and float(vid.abs().max()) <= 1.0
     with pytest.raises(NotImplementedError):
         pipe.generate("", sample_solver="euler", context=ctx, context_null=ctx0)
+
+
+def test_wan_i2v_generate_tiny_matches_oracle():
+    """WanI2V.generate end to end (image2video.py:129-347): VAE-encoded conditioning clip + first-frame mask as
+    ``y``, CLIP tokens through img_emb and the image-token attention, cached contexts, 3 CFG steps; against the
+    oracle VAE encoder + oracle i2v DiT + oracle sampler fed the same noise."""
+    from oracle import detgen, make_golden, sampler_oracle as SO, wan_dit_oracle as O, wan_vae_oracle as V
+    wan = importlib.import_module(PKG + ".wan")
+    cfgs = importlib.import_module(PKG + ".wan.configs")
+    vae_mod = importlib.import_module(PKG + ".wan.modules.vae")
+    ocfg = O.DiTConfig(model_type="i2v", in_dim=36, num_layers=2, **make_golden.TINY)
+    sd = O.synth_state_dict(ocfg, "i2vgen")
+    model = wan.modules.model.WanModel(model_type="i2v", in_dim=36, num_layers=2, **make_golden.TINY)
+    model.load_state_dict(sd)
+    vcfg = V.VAEConfig(dim=16)
+    vsd = V.synth_state_dict(vcfg, "i2vgen/vae")
+    vae = vae_mod.WanVAE(vae_pth=None, device="cuda", dim=16)
+    vae.model.load_state_dict(vsd)
+    clip_fea = torch.from_numpy(detgen.normalish("i2vgen/clip", (1, 257, 1280)))
+
+    class _Clip:                                    # stands in for CLIP ViT-H (out of scope): records its input
+        def visual(self, videos):
+            self.seen = [tuple(v.shape) for v in videos]
+            return clip_fea.cuda()
+    clip = _Clip()
+    pipe = wan.WanI2V(cfgs.i2v_14B, checkpoint_dir="", model=model, vae=vae, clip=clip)
+    img = torch.from_numpy(detgen.uniform("i2vgen/img", (3, 40, 60), 0.0, 1.0))
+    ctx = [torch.from_numpy(detgen.normalish("i2vgen/c", (9, 64)))]
+    ctx0 = [torch.from_numpy(detgen.normalish("i2vgen/n", (21, 64)))]
+    kw = dict(max_area=48 * 64, frame_num=5, shift=3.0, sampling_steps=3, guide_scale=4.0, seed=5, context=ctx,
+              context_null=ctx0)
+    lat = pipe.generate("", img, return_latent=True, **kw)
+    assert clip.seen == [(3, 1, 40, 60)]
+    # ---- the same thing on the oracle
+    aspect = 40 / 60
+    lat_h = round(np.sqrt(48 * 64 * aspect) // 8 // 2 * 2)
+    lat_w = round(np.sqrt(48 * 64 / aspect) // 8 // 2 * 2)
+    assert lat.shape == (16, 2, lat_h, lat_w)
+    h, w = lat_h * 8, lat_w * 8
+    first = torch.nn.functional.interpolate((img[None] - 0.5) / 0.5, size=(h, w), mode="bicubic").transpose(0, 1)
+    y_lat = V.vae_encode(vsd, vcfg, torch.concat([first, torch.zeros(3, 4, h, w)], dim=1))
+    i2v = importlib.import_module(PKG + ".wan.image2video")
+    y = torch.concat([i2v.first_frame_mask(5, lat_h, lat_w), y_lat])
+    assert y.shape == (20, 2, lat_h, lat_w) and float(y[:4, 0].min()) == 1.0 and float(y[:4, 1:].max()) == 0.0
+    noise = torch.randn(16, 2, lat_h, lat_w, dtype=torch.float32, device="cuda",
+                        generator=torch.Generator(device="cuda").manual_seed(5)).cpu()
+    seq_len = 2 * lat_h * lat_w // 4
+
+    def vel(x, t):
+        tt = torch.stack([t]).float()
+        return (O.dit_forward(sd, ocfg, [x], tt, ctx, seq_len, clip_fea=clip_fea, y=[y])[0],
+                O.dit_forward(sd, ocfg, [x], tt, ctx0, seq_len, clip_fea=clip_fea, y=[y])[0])
+    ref = SO.sample_loop(vel, noise, 3, 3.0, 4.0)
+    assert rel_rms(lat, ref) < 3e-2                 # bf16 VAE encoder feeding 6 chained bf16 forwards
+    vid = pipe.generate("", img, sample_solver="dpm++", **kw)
+    assert vid.shape == (3, 5, h, w) and bool(torch.isfinite(vid).all()) and float(vid.abs().max()) <= 1.0
