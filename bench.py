@@ -21,7 +21,7 @@ Extra objects on the JSON line:
   cpu_baseline  the CPU oracle (oracle/wan_dit_oracle.py, fp32, a restatement
                 of the reference's own CPU path) timed on this box's host
                 cores on a bounded sample (rank 0, N=1 only).
-  vae           frames/s of the 3D causal VAE decode of the final latent.
+  vae           frames/s of the 3D causal VAE decode of the final latent and of encoding the decoded clip.
 """
 import argparse
 import importlib
@@ -215,6 +215,9 @@ def main():
     guide, shift, n_sampling = 5.0, 5.0, 50
 
     timer = KernelTimer(ops, "flash_attn_raw", lambda *a, **k: a[7] == a[8] and a[7] == seq_len)  # Lq == Lk == S
+    # secondary in-situ timings: the widest GEMM (FFN up-projection + GELU) and the HBM-bound LN+modulate pass
+    gemm_timer = KernelTimer(ops, "gemm_raw", lambda *a, **k: a[3] == seq_len and a[4] == 8960 and a[5] == 1536)
+    ln_timer = KernelTimer(ops, "layernorm_modulate_raw", lambda *a, **k: a[2] == seq_len and a[3] == 1536)
 
     def run_steps(n, sched, x):
         for i in range(n):
@@ -239,7 +242,7 @@ def main():
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = True
+    timer.enabled = gemm_timer.enabled = ln_timer.enabled = True
     t0 = time.perf_counter()
     x = run_steps(args.steps, sched, x)
     torch.cuda.synchronize()
@@ -247,7 +250,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timer.enabled = False
+    timer.enabled = gemm_timer.enabled = ln_timer.enabled = False
     if dist:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -274,6 +277,19 @@ def main():
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "launches_timed": len(timer.pairs), "avg_launch_ms": round(attn_ms, 4),
                     "algorithmic_flops_per_launch": attn_flops}
+
+    secondary = {}
+    g_ms, l_ms = gemm_timer.avg_ms(), ln_timer.avg_ms()
+    if g_ms:      # [S,1536] x [1536,8960] + bias + GELU-tanh, bf16 out
+        gf = 2.0 * seq_len * 8960 * 1536
+        secondary["ffn_up_gemm_gelu"] = {"avg_launch_ms": round(g_ms, 4), "tflops": round(gf / g_ms / 1e9, 1),
+                                        "mfma_frac": round(gf / g_ms / 1e9 / PEAK_BF16_TFLOPS, 4),
+                                        "launches_timed": len(gemm_timer.pairs)}
+    if l_ms:      # LayerNorm + adaLN modulate: fp32 in, bf16 out = 6 bytes per element
+        lb = 6.0 * seq_len * 1536
+        secondary["layernorm_modulate"] = {"avg_launch_ms": round(l_ms, 4), "hbm_GBps": round(lb / l_ms / 1e6, 1),
+                                          "hbm_frac_of_8TBps": round(lb / l_ms / 1e6 / 8000.0, 4),
+                                          "launches_timed": len(ln_timer.pairs)}
 
     vae = None
     if not args.no_vae:
@@ -308,7 +324,8 @@ def main():
                 "context_tokens": [int(ctx.shape[0]), int(ctx_null.shape[0])]},
             "dit": {"forward_tflop": round(fwd_flops / 1e12, 2),
                     "achieved_tflops_per_gpu": round(2 * fwd_flops / (ms_per_step * 1e-3) / 1e12, 1),
-                    "mfma_roofline_frac": round(2 * fwd_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)},
+                    "mfma_roofline_frac": round(2 * fwd_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                    "kernels": secondary},
             "vae": vae, "train": train, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -503,7 +503,8 @@ class WanVAE:
 
 
 def bench_decode(latent, device, iters=1):
-    """bench.py hook: frames/s of decoding one [16, T', 60, 104] latent with a random-init VAE."""
+    """bench.py hook: frames/s of decoding one [16, T', 60, 104] latent, and of encoding the decoded clip back,
+    with a random-init VAE.  Conv flops per frame from SURVEY.md section 8(d) (linear in H*W)."""
     import time
     vae = WanVAE(vae_pth=None, device=device)
     z = latent.detach().float()
@@ -516,7 +517,20 @@ def bench_decode(latent, device, iters=1):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
     frames = out.shape[1]
-    flops = (4.29 + (z.shape[1] - 1) * 13.49) * 1e12 * (z.shape[2] * z.shape[3]) / (60 * 104)
-    return {"frames_per_s": round(frames / dt, 2), "decode_s": round(dt, 3), "frames": int(frames),
-            "conv_tflops": round(flops / dt / 1e12, 1), "mfma_roofline_frac": round(flops / dt / 2.5e15, 4),
-            "finite": bool(torch.isfinite(out).all()), "weights": "random-init"}
+    area = (z.shape[2] * z.shape[3]) / (60 * 104)
+    flops = (4.29 + (z.shape[1] - 1) * 13.49) * 1e12 * area
+    res = {"frames_per_s": round(frames / dt, 2), "decode_s": round(dt, 3), "frames": int(frames),
+           "conv_tflops": round(flops / dt / 1e12, 1), "mfma_roofline_frac": round(flops / dt / 2.5e15, 4),
+           "finite": bool(torch.isfinite(out).all()), "weights": "random-init"}
+    vae.encode([out[:, :5]])                   # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        lat = vae.encode([out])[0]
+    torch.cuda.synchronize()
+    de = (time.perf_counter() - t0) / iters
+    eflops = (2.66 + (z.shape[1] - 1) * 7.99) * 1e12 * area
+    res.update({"encode_frames_per_s": round(frames / de, 2), "encode_s": round(de, 3),
+                "encode_conv_tflops": round(eflops / de / 1e12, 1),
+                "encode_finite": bool(torch.isfinite(lat).all()) and tuple(lat.shape) == tuple(z.shape)})
+    return res

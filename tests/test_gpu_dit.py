@@ -144,3 +144,30 @@ def test_tiny_i2v_model_matches_oracle_and_reference_vectors(wan_model_mod):
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dit_i2v_L2.npz"))
     for o, k in zip(out, ("out0", "out1")):
         assert rel_rms(o, torch.from_numpy(g[k])) < TOL_TINY      # straight against the reference's own output
+
+
+@pytest.mark.parametrize("model_type", ["t2v", "i2v"])
+def test_wan_14b_width_one_layer(wan_model_mod, model_type):
+    """The 14B geometry (d=5120, 40 heads x 128, ffn 13824; wan_t2v_14B.py / wan_i2v_14B.py:26-35) on one
+    layer (0.4 G synthetic parameters): every kernel at its widest row (LN/RMSNorm 20 vectors per lane, 40-head attention, K=13824 GEMM)."""
+    from oracle import wan_dit_oracle as O, detgen
+    i2v = model_type == "i2v"
+    kw = dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=1, text_dim=4096, text_len=512, freq_dim=256)
+    cfg = O.DiTConfig(model_type=model_type, in_dim=36 if i2v else 16, **kw)
+    sd = O.synth_state_dict(cfg, f"wan14b/{model_type}")
+    grids, seq_len = [(2, 6, 10), (1, 4, 6)], 128
+    xs = [torch.from_numpy(detgen.normalish(f"w14/x{i}", (16, g[0], g[1] * 2, g[2] * 2))) for i, g in enumerate(grids)]
+    ctx = [torch.from_numpy(detgen.normalish(f"w14/c{i}", (n, 4096))) for i, n in enumerate((77, 512))]
+    ys = clip = None
+    if i2v:
+        ys = [torch.from_numpy(detgen.normalish(f"w14/y{i}", (20, g[0], g[1] * 2, g[2] * 2))) for i, g in enumerate(grids)]
+        clip = torch.from_numpy(detgen.normalish("w14/clip", (2, 257, 1280)))
+    t = torch.tensor([937., 250.])
+    ref = O.dit_forward(sd, cfg, xs, t, ctx, seq_len, clip_fea=clip, y=ys)
+    m = wan_model_mod.WanModel(model_type=model_type, in_dim=36 if i2v else 16, **kw)
+    m.load_state_dict(sd)
+    m = m.cuda().eval().requires_grad_(False)
+    out = m([u.cuda() for u in xs], t.cuda(), [c.cuda() for c in ctx], seq_len,
+            clip_fea=clip.cuda() if i2v else None, y=[u.cuda() for u in ys] if i2v else None)
+    for o, r in zip(out, ref):
+        assert o.shape == r.shape and rel_rms(o, r) < TOL_TINY
