@@ -38,8 +38,8 @@ __device__ __forceinline__ uint32_t lds_slot_addr(int row, int slot) {
     return (uint32_t)(row * (BK * 2) + ((slot ^ ((row >> 1) & 7)) << 4));
 }
 
-// WM x WN waves, each owning MT x NT 32x32 MFMA tiles
-template <int EPI, int WM, int WN, int MT, int NT>
+// WM x WN waves, each owning MT x NT 32x32 MFMA tiles; STAGES-deep LDS ring
+template <int EPI, int WM, int WN, int MT, int NT, int STAGES>
 __global__ __launch_bounds__(64 * WM * WN, 2)
 void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
     constexpr int THREADS = 64 * WM * WN;
@@ -137,16 +137,23 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
     }                                                                                          \
     __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - (MT + NT) > 0 ? MT * NT - (MT + NT) : 0, 0);
 
-    GEMM_DMA(0, 0)
-    if (nk > 1) GEMM_DMA(1, 1)
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCH) : "memory");
+    // STAGES-deep ring: stages kt+1 .. kt+STAGES-1 are in flight while stage kt is consumed; rings deeper than 2
+    // wait with a counted vmcnt (loads retire in order: allowing the STAGES-2 youngest stages to stay
+    // outstanding proves stage kt+1 has landed).  Every shipped configuration uses 2: a deeper ring measured no
+    // faster on any of them (the 64x64 tile is L2->LDS-bandwidth bound at ~13 TB/s aggregate, not latency bound,
+    // and 64 KiB of LDS per workgroup halves the resident workgroups — DESIGN.md section 4.4).
+    constexpr int PER_STAGE = 2 * NCH;                           // DMA instructions per wave and stage
+#pragma unroll
+    for (int st = 0; st < STAGES; ++st)
+        if (st < nk) GEMM_DMA(st, st)
+    if (nk >= STAGES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (STAGES - 1)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     bf16x8 wf0[NT], xf0[MT], wf1[NT], xf1[MT];
     GEMM_FRAGS(wf0, xf0, 0, 0)
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+        const int buf = kt % STAGES;
         GEMM_FRAGS(wf1, xf1, buf, 1)
         GEMM_MFMAS(wf0, xf0)
         GEMM_INTERLEAVE()
@@ -156,9 +163,13 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
         GEMM_FRAGS(wf1, xf1, buf, 3)
         GEMM_MFMAS(wf0, xf0)
         GEMM_INTERLEAVE()
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (kt + 2 < nk) GEMM_DMA(kt + 2, buf)
-        if (kt + 1 < nk) GEMM_FRAGS(wf0, xf0, buf ^ 1, 0)
+        // (in the tail fewer stages are in flight than the count assumes: wait for everything there)
+        if (STAGES > 2 && kt + STAGES - 1 < nk)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PER_STAGE * (STAGES - 2)) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + STAGES < nk) GEMM_DMA(kt + STAGES, buf)
+        if (kt + 1 < nk) GEMM_FRAGS(wf0, xf0, (kt + 1) % STAGES, 0)
         GEMM_MFMAS(wf1, xf1)
     }
 
@@ -176,7 +187,7 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
     constexpr int LPR = NT * 32 / VEC;                 // lanes per row
     constexpr int RPP = 64 / LPR;                      // rows per pass
     constexpr int PASSES = 32 / RPP;
-    static_assert(WM * WN * 32 * PITCH * 4 <= 2 * STAGE_BYTES, "epilogue patch does not fit the staging LDS");
+    static_assert(WM * WN * 32 * PITCH * 4 <= STAGES * STAGE_BYTES, "epilogue patch does not fit the staging LDS");
     float* ep = (float*)smem + wave * (32 * PITCH);
     float* Cf = (float*)p.C + zb * p.strideC;
     uint16_t* Ch = (uint16_t*)p.C + zb * p.strideC;
@@ -281,11 +292,11 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
     }
 }
 
-template <int EPI, int WM, int WN, int MT, int NT>
+template <int EPI, int WM, int WN, int MT, int NT, int STAGES>
 int launch_cfg(const omh_gemm_args& a, hipStream_t s) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
-    constexpr int LDS = 2 * (BM + BN) * BK * 2;
-    auto kern = gemm_bf16_nt_kernel<EPI, WM, WN, MT, NT>;
+    constexpr int LDS = STAGES * (BM + BN) * BK * 2;
+    auto kern = gemm_bf16_nt_kernel<EPI, WM, WN, MT, NT, STAGES>;
     static bool attr_set = false;            // > 64 KiB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -306,13 +317,13 @@ int launch(const omh_gemm_args& a, hipStream_t s) {
     const int64_t big_tiles = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) * a.batch;
     static const char* force = getenv("OMH_GEMM_TILE");        // "big" / "small": benchmarking override
     const bool big = force ? (force[0] == 'b') : (big_tiles >= 256);
-    if (big) return launch_cfg<EPI, 2, 4, 4, 2>(a, s);
+    if (big) return launch_cfg<EPI, 2, 4, 4, 2, 2>(a, s);
     // tiny problems (training clips, context projections): 64x64 tiles so that more than 2 workgroups
     // per CU exist at all
     const int64_t mid_tiles = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
     const bool tiny = force ? (force[0] == 't') : (mid_tiles < 512);
-    if (tiny) return launch_cfg<EPI, 2, 2, 1, 1>(a, s);
-    return launch_cfg<EPI, 2, 2, 2, 2>(a, s);
+    if (tiny) return launch_cfg<EPI, 2, 2, 1, 1, 2>(a, s);
+    return launch_cfg<EPI, 2, 2, 2, 2, 2>(a, s);
 }
 
 }  // namespace
