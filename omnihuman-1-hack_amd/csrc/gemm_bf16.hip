@@ -32,7 +32,7 @@ namespace {
 
 constexpr int BK = 64;
 
-struct GemmGeom { int tiles_m, tiles_n; };
+struct GemmGeom { int tiles_m, tiles_n, group_m; };
 
 __device__ __forceinline__ uint32_t lds_slot_addr(int row, int slot) {
     return (uint32_t)(row * (BK * 2) + ((slot ^ ((row >> 1) & 7)) << 4));
@@ -57,7 +57,7 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
 
     const int wid = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
     int tm, tn;
-    tile_of(wid, g.tiles_m, g.tiles_n, tm, tn);
+    tile_of(wid, g.tiles_m, g.tiles_n, tm, tn, g.group_m);
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int64_t zb = blockIdx.z;
@@ -305,6 +305,11 @@ int launch_cfg(const omh_gemm_args& a, hipStream_t s) {
     GemmGeom g;
     g.tiles_m = (a.M + BM - 1) / BM;
     g.tiles_n = (a.N + BN - 1) / BN;
+    // m-tiles walked together by one XCD: as many A panels (BM x K bf16) as stay resident in ~3 MiB of its 4 MiB
+    // L2 while the n-tiles stream past (measured: 4 at K=1536 and 2 at K>=6144 beat the former fixed 8 by 2-4 %)
+    static const char* gme = getenv("OMH_GEMM_GROUP_M");
+    const int fit = (int)(3200000LL / ((int64_t)BM * a.K * 2));
+    g.group_m = gme ? atoi(gme) : (fit < 2 ? 2 : (fit > 8 ? 8 : fit));
     dim3 grid(g.tiles_m * g.tiles_n, 1, a.batch);
     omh_clear_status();
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), LDS, s, a, g);

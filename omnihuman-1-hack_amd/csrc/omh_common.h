@@ -65,8 +65,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // Work id -> output tile.  Consecutive ids (which xcd_remap keeps on one XCD, ~64 resident at a
 // time) walk 8 m-tiles x all n-tiles in m-fastest order, so the resident set is an 8 x 8 patch of
 // tiles: 8 A panels + 8 B panels live in that XCD's 4 MiB L2 instead of 1 + 64.
-__device__ __forceinline__ void tile_of(int wid, int tiles_m, int tiles_n, int& tm, int& tn) {
-    const int GM = 8;
+__device__ __forceinline__ void tile_of(int wid, int tiles_m, int tiles_n, int& tm, int& tn, const int GM = 8) {
     const int per_group = GM * tiles_n;
     const int gid = wid / per_group, in_g = wid - gid * per_group;
     const int first_m = gid * GM;
