@@ -145,3 +145,40 @@ def test_configs(omh):
     assert cfgs.i2v_14B.dim == 5120 and cfgs.SIZE_CONFIGS["480*832"] == (480, 832)
     kw = cfgs.dit_kwargs(c)
     assert kw["dim"] // kw["num_heads"] == 128
+
+
+def test_from_pretrained_diffusers_layout_and_module_surface(omh, tmp_path):
+    """`WanModel.from_pretrained(dir)` on the diffusers layout the reference loads (text2video.py:86: config.json
+    with diffusers' private keys + sharded diffusion_pytorch_model-*.safetensors), and the module surface callers
+    poke at: attributes, indexable hookable blocks, deepcopy, stable parameter order, state-dict keys."""
+    import copy
+    import json
+    from safetensors.torch import save_file
+    from oracle import wan_dit_oracle as O
+    model_mod = importlib.import_module(PKG + ".wan.modules.model")
+    kw = dict(dim=256, ffn_dim=512, num_heads=2, num_layers=3, text_dim=64, text_len=32, freq_dim=64)
+    sd = O.synth_state_dict(O.DiTConfig(**kw), "pretrained")
+    cfg = dict(kw, model_type="t2v", patch_size=[1, 2, 2], in_dim=16, out_dim=16, window_size=[-1, -1], qk_norm=True,
+               cross_attn_norm=True, eps=1e-6, _class_name="WanModel", _diffusers_version="0.30.0")
+    (tmp_path / "config.json").write_text(json.dumps(cfg))
+    keys = sorted(sd)
+    save_file({k: sd[k].contiguous() for k in keys[::2]}, str(tmp_path / "diffusion_pytorch_model-00001-of-00002.safetensors"))
+    save_file({k: sd[k].contiguous() for k in keys[1::2]}, str(tmp_path / "diffusion_pytorch_model-00002-of-00002.safetensors"))
+    m = model_mod.WanModel.from_pretrained(str(tmp_path))
+    got = m.state_dict()
+    assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    assert "freqs" not in got                                     # not a buffer in the reference (model.py:484)
+    assert (m.dim, m.num_heads, m.qk_norm, m.eps, tuple(m.patch_size), m.text_len, m.freq_dim) == \
+        (256, 2, True, 1e-6, (1, 2, 2), 32, 64)
+    assert len(m.blocks) == 3 and hasattr(m.blocks[1], "register_forward_hook") and hasattr(m, "use_checkpoint")
+    assert [n for n, _ in m.named_parameters()] == [n for n, _ in copy.deepcopy(m).named_parameters()]
+    m2 = copy.deepcopy(m)
+    with torch.no_grad():
+        m2.head.head.weight.add_(1.0)
+    assert not torch.equal(m2.head.head.weight, m.head.head.weight)   # deep copies do not share storage
+    (tmp_path / "diffusion_pytorch_model-00002-of-00002.safetensors").unlink()
+    with pytest.raises(RuntimeError):                             # missing shard -> strict load fails loudly
+        model_mod.WanModel.from_pretrained(str(tmp_path))
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception, match="MI355X|GPU|cuda"):
+            m([torch.zeros(16, 1, 4, 4)], torch.tensor([1.0]), [torch.zeros(3, 64)], 4)   # no CPU fallback

@@ -134,3 +134,19 @@ def test_vae_decode_encode_match_oracle(dim):
     oute = vae.encode([vid.cuda()])[0]
     assert oute.shape == refe.shape == (16, 3, 4, 4)
     assert rel_rms(oute, refe) < TOL_VAE
+
+
+def test_vae_decode_at_wide_tile_sizes_matches_oracle():
+    """A decode large enough ([16,2,30,52] -> [3,5,240,416], dim 96) that the C=96 and C=192 stages run the
+    512x96 / 256x192 convolution tiles, ragged last tiles and the frame-interleaving time conv included."""
+    from oracle import wan_vae_oracle as V, detgen
+    vae_mod = importlib.import_module("omnihuman-1-hack_amd.wan.modules.vae")
+    cfg = V.VAEConfig(dim=96)
+    sd = V.synth_state_dict(cfg, "vae96wide")
+    vae = vae_mod.WanVAE(vae_pth=None, device="cuda", dim=96)
+    vae.model.load_state_dict(sd)
+    z = torch.from_numpy(detgen.normalish("vae/zwide", (16, 2, 30, 52)))
+    ref = V.vae_decode(sd, cfg, z)
+    out = vae.decode([z.cuda()])[0]
+    assert out.shape == ref.shape == (3, 5, 240, 416)
+    assert rel_rms(out, ref) < TOL_VAE
