@@ -42,6 +42,15 @@ __device__ __forceinline__ void xhalf(float x, float& lo, float& hi) {
     hi = __uint_as_float(r[1]);
 }
 
+// max of three without the IEEE canonicalisation fmaxf() drags in: hipcc emits `v_max_f32 x, x, x` (sNaN
+// quieting) in front of every fmaxf operand it cannot prove canonical — MFMA results are such — which made the
+// row max 58 VALU instructions per 64-key tile instead of 16.  Scores are finite or -inf here.
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 __device__ __forceinline__ int swap_bits23(int i) {
     return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
 }
@@ -174,13 +183,14 @@ void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles) {
                 }
         }
         // ---- online softmax (log2 domain)
-        float mx = s[0][0];
+        float mx = s[0][0], mx2 = s[1][0];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-        { float a_, b_; xhalf(mx, a_, b_); mx = fmaxf(a_, b_); }
-        const float m_new = fmaxf(m_run, mx * sc);
+        for (int r = 0; r < 16; r += 2) {                           // two independent v_max3 chains
+            mx = vmax3(mx, s[0][r], s[1][r]);
+            mx2 = vmax3(mx2, s[0][r + 1], s[1][r + 1]);
+        }
+        { float a_, b_; xhalf(vmax3(mx, mx2, mx2), a_, b_); mx = a_; mx2 = b_; }
+        const float m_new = vmax3(m_run, mx * sc, mx2 * sc);
         const float alpha = fast_exp2(m_run - m_new);
         m_run = m_new;
         float rs = 0.f;
@@ -342,21 +352,33 @@ void flash_attn_fwd_d128_pp_kernel(const omh_attn_args p, const int q_tiles) {
 
 // fragment reads run two MFMA pairs ahead of their use (explicit register ring): a lone wave per
 // matrix segment has nobody to hide its ds_read latency behind
-#define PP_KFRAG(KT_, KK_) { *(const bf16x8*)((KT_) + k_addr(krow_l, 2 * (KK_) + lh)), \
-                             *(const bf16x8*)((KT_) + k_addr(32 + krow_l, 2 * (KK_) + lh)) }
+    // per-lane LDS byte offsets of this lane's K / V^T fragments inside a ring slot, computed once and made
+    // opaque to the optimiser (it otherwise re-adds row and swizzled-slot parts in front of every ds_read:
+    // 16 v_add per tile); ring slot, second 32-row block and d-block are immediate offsets on top.
+    uint32_t ka[8], va[4];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        ka[kk] = k_addr(krow_l, 2 * kk + lh);
+        asm volatile("" : "+v"(ka[kk]));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        va[j] = v_addr(li, 2 * j + lh);
+        asm volatile("" : "+v"(va[j]));
+    }
 #define PP_QK(KBUF)                                                                             \
     {                                                                                           \
         const unsigned char* kt_ = kring + (KBUF) * KT_BYTES;                                   \
         _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) { s0[r_] = 0.f; s1[r_] = 0.f; }       \
         bf16x8 kr_[3][2];                                                                       \
-        kr_[0][0] = *(const bf16x8*)(kt_ + k_addr(krow_l, lh));                                 \
-        kr_[0][1] = *(const bf16x8*)(kt_ + k_addr(32 + krow_l, lh));                            \
-        kr_[1][0] = *(const bf16x8*)(kt_ + k_addr(krow_l, 2 + lh));                             \
-        kr_[1][1] = *(const bf16x8*)(kt_ + k_addr(32 + krow_l, 2 + lh));                        \
+        kr_[0][0] = *(const bf16x8*)(kt_ + ka[0]);                                              \
+        kr_[0][1] = *(const bf16x8*)(kt_ + ka[0] + 8192);                                       \
+        kr_[1][0] = *(const bf16x8*)(kt_ + ka[1]);                                              \
+        kr_[1][1] = *(const bf16x8*)(kt_ + ka[1] + 8192);                                       \
         _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                      \
             if (kk + 2 < 8) {                                                                   \
-                kr_[(kk + 2) % 3][0] = *(const bf16x8*)(kt_ + k_addr(krow_l, 2 * (kk + 2) + lh));      \
-                kr_[(kk + 2) % 3][1] = *(const bf16x8*)(kt_ + k_addr(32 + krow_l, 2 * (kk + 2) + lh)); \
+                kr_[(kk + 2) % 3][0] = *(const bf16x8*)(kt_ + ka[kk + 2]);                      \
+                kr_[(kk + 2) % 3][1] = *(const bf16x8*)(kt_ + ka[kk + 2] + 8192);               \
             }                                                                                   \
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr_[kk % 3][0], qf[kk], s0, 0, 0, 0);  \
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr_[kk % 3][1], qf[kk], s1, 0, 0, 0);  \
@@ -378,91 +400,101 @@ void flash_attn_fwd_d128_pp_kernel(const omh_attn_args p, const int q_tiles) {
     if (n_tiles > 0) PP_QK(0)
     if (grp == 1) PP_BARRIER()                        // group 1 runs one slot behind group 0
 
-    for (int t = 0; t < n_tiles; ++t) {
-        if (grp == 1) { PP_KDMA(t + 2, t & 1) PP_VDMA(t + 1, (t + 1) & 1) }
-        // ---------------- softmax segment (VALU): scores of tile t -> P (bf16), rescale O
-        {
-            const int kv0 = t * KB;
-            if (__builtin_expect(kv0 + KB > klen, 0)) {
+    // two tiles per trip so that the LDS ring slot is a compile-time constant in each copy: the fragment
+    // addresses become per-lane bases (hoisted) + immediate offsets instead of 16 v_add per tile
+    for (int t2 = 0; t2 < n_tiles; t2 += 2) {
 #pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int t = t2 + par;
+            if (t >= n_tiles) break;                   // wave-uniform
+            if (grp == 1) { PP_KDMA(t + 2, par) PP_VDMA(t + 1, par ^ 1) }
+            // ---------------- softmax segment (VALU): scores of tile t -> P (bf16), rescale O
+            {
+                const int kv0 = t * KB;
+                if (__builtin_expect(kv0 + KB > klen, 0)) {
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kv0 + ((r >> 3) << 4) + lh * 8 + (r & 7);
+                        if (key >= klen) s0[r] = -INFINITY;
+                        if (key + 32 >= klen) s1[r] = -INFINITY;
+                    }
+                }
+                float mx = s0[0], mx2 = s1[0];
+    #pragma unroll
+                for (int r = 0; r < 16; r += 2) {                       // two independent chains
+                    mx = vmax3(mx, s0[r], s1[r]);
+                    mx2 = vmax3(mx2, s0[r + 1], s1[r + 1]);
+                }
+                { float a_, b_; xhalf(vmax3(mx, mx2, mx2), a_, b_); mx = a_; mx2 = b_; }
+                const float m_new = vmax3(m_run, mx * sc, mx2 * sc);
+                const float alpha = fast_exp2(m_run - m_new);
+                m_run = m_new;
+    #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = kv0 + ((r >> 3) << 4) + lh * 8 + (r & 7);
-                    if (key >= klen) s0[r] = -INFINITY;
-                    if (key + 32 >= klen) s1[r] = -INFINITY;
+                    s0[r] = fast_exp2(fmaf(s0[r], sc, -m_new));
+                    s1[r] = fast_exp2(fmaf(s1[r], sc, -m_new));
                 }
+                alpha_keep = alpha;      // row sum, P->bf16 and the O rescale ride in the matrix segment's issue gaps
             }
-            float mx = s0[0];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
-            { float a_, b_; xhalf(mx, a_, b_); mx = fmaxf(a_, b_); }
-            const float m_new = fmaxf(m_run, mx * sc);
-            const float alpha = fast_exp2(m_run - m_new);
-            m_run = m_new;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s0[r] = fast_exp2(fmaf(s0[r], sc, -m_new));
-                s1[r] = fast_exp2(fmaf(s1[r], sc, -m_new));
+            if (grp == 0 && t > 0) PP_WAIT_DMA();          // this wave's share of DMA(t-1), issued one slot ago
+            PP_BARRIER()
+            if (grp == 0) { PP_KDMA(t + 2, par) PP_VDMA(t + 1, par ^ 1) }
+            // ---------------- matrix segment: O^T += V^T(t) P^T, then the scores of tile t+1
+            {
+                // VALU work moved here from the softmax segment (it was the longer of the two): the rescale of
+                // O, the row sum and the bf16 packing of P issue in the gaps between this segment's MFMAs
+                if (!__all(alpha_keep == 1.0f)) {
+    #pragma unroll
+                    for (int i = 0; i < 4; ++i)
+    #pragma unroll
+                        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha_keep;
+                }
+                float rs = 0.f;
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) rs += s0[r] + s1[r];
+                { float a_, b_; xhalf(rs, a_, b_); rs = a_ + b_; }
+                l_run = l_run * alpha_keep + rs;
+    #pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    u32x4 c0, c1;
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        c0[e] = pack_bf2(s0[8 * a + 2 * e], s0[8 * a + 2 * e + 1]);
+                        c1[e] = pack_bf2(s1[8 * a + 2 * e], s1[8 * a + 2 * e + 1]);
+                    }
+                    pf[0][a] = __builtin_bit_cast(bf16x8, c0);
+                    pf[1][a] = __builtin_bit_cast(bf16x8, c1);
+                }
+                const unsigned char* vt = vring + (par) * VT_BYTES;
+                // 16 steps i = (kb, a, db); V^T fragments are read 4 steps ahead
+                bf16x8 vr_[8];
+    #pragma unroll
+                for (int i = 0; i < 4; ++i) vr_[i] = *(const bf16x8*)(vt + va[0] + i * 4096);
+    #pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int kb = i >> 3, a = (i >> 2) & 1, db = i & 3;
+                    if (i + 4 < 16) {
+                        const int j = i + 4, kbj = j >> 3, aj = (j >> 2) & 1, dbj = j & 3;
+                        vr_[j & 7] = *(const bf16x8*)(vt + va[2 * kbj + aj] + dbj * 4096);
+                    }
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr_[i & 7], pf[kb][a], oacc[db], 0, 0, 0);
+                }
+                // issue order: cvt for the first P fragment + 4 fragment reads, then per MFMA one read and a
+                // few of the remaining VALU ops (row sum, packing)
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
+    #pragma unroll
+                for (int g_ = 0; g_ < 12; ++g_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 1);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+                if (t + 1 < n_tiles) PP_QK(par ^ 1)
             }
-            alpha_keep = alpha;      // row sum, P->bf16 and the O rescale ride in the matrix segment's issue gaps
+            if (grp == 1) PP_WAIT_DMA();                   // this wave's share of DMA(t), issued one slot ago
+            PP_BARRIER()
         }
-        if (grp == 0 && t > 0) PP_WAIT_DMA();          // this wave's share of DMA(t-1), issued one slot ago
-        PP_BARRIER()
-        if (grp == 0) { PP_KDMA(t + 2, t & 1) PP_VDMA(t + 1, (t + 1) & 1) }
-        // ---------------- matrix segment: O^T += V^T(t) P^T, then the scores of tile t+1
-        {
-            // VALU work moved here from the softmax segment (it was the longer of the two): the rescale of
-            // O, the row sum and the bf16 packing of P issue in the gaps between this segment's MFMAs
-            if (!__all(alpha_keep == 1.0f)) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha_keep;
-            }
-            float rs = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) rs += s0[r] + s1[r];
-            { float a_, b_; xhalf(rs, a_, b_); rs = a_ + b_; }
-            l_run = l_run * alpha_keep + rs;
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                u32x4 c0, c1;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    c0[e] = pack_bf2(s0[8 * a + 2 * e], s0[8 * a + 2 * e + 1]);
-                    c1[e] = pack_bf2(s1[8 * a + 2 * e], s1[8 * a + 2 * e + 1]);
-                }
-                pf[0][a] = __builtin_bit_cast(bf16x8, c0);
-                pf[1][a] = __builtin_bit_cast(bf16x8, c1);
-            }
-            const unsigned char* vt = vring + (t & 1) * VT_BYTES;
-            // 16 steps i = (kb, a, db); V^T fragments are read 4 steps ahead
-            bf16x8 vr_[8];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) vr_[i] = *(const bf16x8*)(vt + v_addr(i * 32 + li, lh));
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int kb = i >> 3, a = (i >> 2) & 1, db = i & 3;
-                if (i + 4 < 16) {
-                    const int j = i + 4, kbj = j >> 3, aj = (j >> 2) & 1, dbj = j & 3;
-                    vr_[j & 7] = *(const bf16x8*)(vt + v_addr(dbj * 32 + li, 4 * kbj + 2 * aj + lh));
-                }
-                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr_[i & 7], pf[kb][a], oacc[db], 0, 0, 0);
-            }
-            // issue order: cvt for the first P fragment + 4 fragment reads, then per MFMA one read and a
-            // few of the remaining VALU ops (row sum, packing)
-            __builtin_amdgcn_sched_group_barrier(0x002, 8, 1);
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
-#pragma unroll
-            for (int g_ = 0; g_ < 12; ++g_) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 1);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
-            if (t + 1 < n_tiles) PP_QK((t + 1) & 1)
-        }
-        if (grp == 1) PP_WAIT_DMA();                   // this wave's share of DMA(t), issued one slot ago
-        PP_BARRIER()
     }
     if (grp == 0) PP_BARRIER()                        // match group 1's leading barrier
 
