@@ -340,7 +340,7 @@ void flash_attn_fwd_d128_pp_kernel(const omh_attn_args p, const int q_tiles) {
 #define PP_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
     const int krow_l = swap_bits23(li);
-    f32x16 oacc[4], s0, s1;
+    f32x16 oacc[4], S[2][2];          // S[t & 1]: scores of tile t (then its exponentials); S[~t & 1]: tile t+1
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -366,111 +366,133 @@ void flash_attn_fwd_d128_pp_kernel(const omh_attn_args p, const int q_tiles) {
         va[j] = v_addr(li, 2 * j + lh);
         asm volatile("" : "+v"(va[j]));
     }
-#define PP_QK(KBUF)                                                                             \
-    {                                                                                           \
-        const unsigned char* kt_ = kring + (KBUF) * KT_BYTES;                                   \
-        _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) { s0[r_] = 0.f; s1[r_] = 0.f; }       \
+// K fragments: 2 per 16-wide d step, read two steps ahead of their MFMAs (explicit register ring)
+#define PP_QK_LOADS(KBUF, KK_)                                                                  \
+        kr_[(KK_) % 3][0] = *(const bf16x8*)(kring + (KBUF) * KT_BYTES + ka[KK_]);              \
+        kr_[(KK_) % 3][1] = *(const bf16x8*)(kring + (KBUF) * KT_BYTES + ka[KK_] + 8192);
+#define PP_QK_BODY(KBUF, DST)                                                                   \
         bf16x8 kr_[3][2];                                                                       \
-        kr_[0][0] = *(const bf16x8*)(kt_ + ka[0]);                                              \
-        kr_[0][1] = *(const bf16x8*)(kt_ + ka[0] + 8192);                                       \
-        kr_[1][0] = *(const bf16x8*)(kt_ + ka[1]);                                              \
-        kr_[1][1] = *(const bf16x8*)(kt_ + ka[1] + 8192);                                       \
+        PP_QK_LOADS(KBUF, 0)                                                                    \
+        PP_QK_LOADS(KBUF, 1)                                                                    \
         _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                      \
-            if (kk + 2 < 8) {                                                                   \
-                kr_[(kk + 2) % 3][0] = *(const bf16x8*)(kt_ + ka[kk + 2]);                      \
-                kr_[(kk + 2) % 3][1] = *(const bf16x8*)(kt_ + ka[kk + 2] + 8192);               \
+            if (kk + 2 < 8) { PP_QK_LOADS(KBUF, kk + 2) }                                       \
+            if (kk == 0) {                                                                      \
+                const f32x16 z_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
+                S[DST][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr_[0][0], qf[0], z_, 0, 0, 0); \
+                S[DST][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr_[0][1], qf[0], z_, 0, 0, 0); \
+            } else {                                                                            \
+                S[DST][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr_[kk % 3][0], qf[kk], S[DST][0], 0, 0, 0); \
+                S[DST][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr_[kk % 3][1], qf[kk], S[DST][1], 0, 0, 0); \
             }                                                                                   \
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr_[kk % 3][0], qf[kk], s0, 0, 0, 0);  \
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr_[kk % 3][1], qf[kk], s1, 0, 0, 0);  \
+        }
+// scores of the current tile -> exponentials (log2 domain) -> bf16 P fragments
+#define PP_EXP_PACK(CUR)                                                                        \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                        \
+            S[CUR][0][r] = fast_exp2(fmaf(S[CUR][0][r], sc, -m_run));                           \
+            S[CUR][1][r] = fast_exp2(fmaf(S[CUR][1][r], sc, -m_run));                           \
         }                                                                                       \
-        /* pin the issue order: 4 reads up front, then {2 MFMA, 2 reads} x 6, then the last 4 MFMA */ \
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                      \
-        _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) {                                      \
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                  \
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                  \
-        }                                                                                       \
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                      \
-    }
+        _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                         \
+            u32x4 c0, c1;                                                                       \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                     \
+                c0[e] = pack_bf2(S[CUR][0][8 * a + 2 * e], S[CUR][0][8 * a + 2 * e + 1]);       \
+                c1[e] = pack_bf2(S[CUR][1][8 * a + 2 * e], S[CUR][1][8 * a + 2 * e + 1]);       \
+            }                                                                                   \
+            pf[0][a] = __builtin_bit_cast(bf16x8, c0);                                          \
+            pf[1][a] = __builtin_bit_cast(bf16x8, c1);                                          \
+        }
 
     if (n_tiles > 0) {
         PP_KDMA(0, 0) PP_VDMA(0, 0) PP_KDMA(1, 1)
     }
     PP_WAIT_DMA();
     PP_BARRIER()
-    if (n_tiles > 0) PP_QK(0)
+    if (n_tiles > 0) {
+        PP_QK_BODY(0, 0)
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int g_ = 0; g_ < 6; ++g_) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
     if (grp == 1) PP_BARRIER()                        // group 1 runs one slot behind group 0
 
-    // two tiles per trip so that the LDS ring slot is a compile-time constant in each copy: the fragment
-    // addresses become per-lane bases (hoisted) + immediate offsets instead of 16 v_add per tile
+    // Two tiles per trip so that the LDS ring slot and the score register set are compile-time constants in each
+    // copy (fragment addresses = hoisted per-lane bases + immediate offsets).
+    //
+    // Per tile a wave runs a short softmax segment (row max of the scores of tile t, new running max) and, after
+    // the barrier, its matrix segment in two phases:
+    //   phase 1  K(t+1)·Qᵀ into the OTHER score set   ∥  exp2 / bf16 packing of tile t on the VALU
+    //   phase 2  O^T += V^T(t)·P^T(t)                 ∥  row sum of tile t
+    // The scores of tile t+1 do not depend on the softmax of tile t, so putting them first gives the 80 VALU
+    // instructions of the exponentials 16 MFMAs to hide under, instead of serialising them in front of P·V.
     for (int t2 = 0; t2 < n_tiles; t2 += 2) {
 #pragma unroll
         for (int par = 0; par < 2; ++par) {
             const int t = t2 + par;
             if (t >= n_tiles) break;                   // wave-uniform
             if (grp == 1) { PP_KDMA(t + 2, par) PP_VDMA(t + 1, par ^ 1) }
-            // ---------------- softmax segment (VALU): scores of tile t -> P (bf16), rescale O
+            // ---------------- softmax segment: row max of tile t
             {
                 const int kv0 = t * KB;
                 if (__builtin_expect(kv0 + KB > klen, 0)) {
-    #pragma unroll
+#pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = kv0 + ((r >> 3) << 4) + lh * 8 + (r & 7);
-                        if (key >= klen) s0[r] = -INFINITY;
-                        if (key + 32 >= klen) s1[r] = -INFINITY;
+                        if (key >= klen) S[par][0][r] = -INFINITY;
+                        if (key + 32 >= klen) S[par][1][r] = -INFINITY;
                     }
                 }
-                float mx = s0[0], mx2 = s1[0];
-    #pragma unroll
+                float mx = S[par][0][0], mx2 = S[par][1][0];
+#pragma unroll
                 for (int r = 0; r < 16; r += 2) {                       // two independent chains
-                    mx = vmax3(mx, s0[r], s1[r]);
-                    mx2 = vmax3(mx2, s0[r + 1], s1[r + 1]);
+                    mx = vmax3(mx, S[par][0][r], S[par][1][r]);
+                    mx2 = vmax3(mx2, S[par][0][r + 1], S[par][1][r + 1]);
                 }
                 { float a_, b_; xhalf(vmax3(mx, mx2, mx2), a_, b_); mx = a_; mx2 = b_; }
                 const float m_new = vmax3(m_run, mx * sc, mx2 * sc);
-                const float alpha = fast_exp2(m_run - m_new);
+                alpha_keep = fast_exp2(m_run - m_new);
                 m_run = m_new;
-    #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    s0[r] = fast_exp2(fmaf(s0[r], sc, -m_new));
-                    s1[r] = fast_exp2(fmaf(s1[r], sc, -m_new));
-                }
-                alpha_keep = alpha;      // row sum, P->bf16 and the O rescale ride in the matrix segment's issue gaps
             }
             if (grp == 0 && t > 0) PP_WAIT_DMA();          // this wave's share of DMA(t-1), issued one slot ago
             PP_BARRIER()
             if (grp == 0) { PP_KDMA(t + 2, par) PP_VDMA(t + 1, par ^ 1) }
-            // ---------------- matrix segment: O^T += V^T(t) P^T, then the scores of tile t+1
+            // ---------------- matrix segment
             {
-                // VALU work moved here from the softmax segment (it was the longer of the two): the rescale of
-                // O, the row sum and the bf16 packing of P issue in the gaps between this segment's MFMAs
-                if (!__all(alpha_keep == 1.0f)) {
-    #pragma unroll
+                if (!__all(alpha_keep == 1.0f)) {          // wave-uniform: the running max rarely moves after the first tiles
+#pragma unroll
                     for (int i = 0; i < 4; ++i)
-    #pragma unroll
+#pragma unroll
                         for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha_keep;
                 }
+                // phase 1
+                if (t + 1 < n_tiles) {
+                    PP_QK_BODY(par ^ 1, par ^ 1)
+                    PP_EXP_PACK(par)
+                    // 4 fragment reads up front, then per MFMA pair: 2 reads (while any remain) + 10 of the 80 VALU
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 2);
+#pragma unroll
+                    for (int g_ = 0; g_ < 8; ++g_) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 2);
+                        if (g_ < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 2);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 10, 2);
+                    }
+                } else {
+                    PP_EXP_PACK(par)
+                }
+                // phase 2
                 float rs = 0.f;
-    #pragma unroll
-                for (int r = 0; r < 16; ++r) rs += s0[r] + s1[r];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rs += S[par][0][r] + S[par][1][r];
                 { float a_, b_; xhalf(rs, a_, b_); rs = a_ + b_; }
                 l_run = l_run * alpha_keep + rs;
-    #pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    u32x4 c0, c1;
-    #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        c0[e] = pack_bf2(s0[8 * a + 2 * e], s0[8 * a + 2 * e + 1]);
-                        c1[e] = pack_bf2(s1[8 * a + 2 * e], s1[8 * a + 2 * e + 1]);
-                    }
-                    pf[0][a] = __builtin_bit_cast(bf16x8, c0);
-                    pf[1][a] = __builtin_bit_cast(bf16x8, c1);
-                }
                 const unsigned char* vt = vring + (par) * VT_BYTES;
                 // 16 steps i = (kb, a, db); V^T fragments are read 4 steps ahead
                 bf16x8 vr_[8];
-    #pragma unroll
+#pragma unroll
                 for (int i = 0; i < 4; ++i) vr_[i] = *(const bf16x8*)(vt + va[0] + i * 4096);
-    #pragma unroll
+#pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int kb = i >> 3, a = (i >> 2) & 1, db = i & 3;
                     if (i + 4 < 16) {
@@ -479,18 +501,15 @@ void flash_attn_fwd_d128_pp_kernel(const omh_attn_args p, const int q_tiles) {
                     }
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr_[i & 7], pf[kb][a], oacc[db], 0, 0, 0);
                 }
-                // issue order: cvt for the first P fragment + 4 fragment reads, then per MFMA one read and a
-                // few of the remaining VALU ops (row sum, packing)
-                __builtin_amdgcn_sched_group_barrier(0x002, 8, 1);
+                // 4 fragment reads, then per MFMA one read and 3 of the row-sum adds
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
-    #pragma unroll
+#pragma unroll
                 for (int g_ = 0; g_ < 12; ++g_) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 1);
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
-                if (t + 1 < n_tiles) PP_QK(par ^ 1)
             }
             if (grp == 1) PP_WAIT_DMA();                   // this wave's share of DMA(t), issued one slot ago
             PP_BARRIER()
