@@ -260,19 +260,24 @@ void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles) {
 }
 
 // ============================================================================================
-// Ping-pong variant for long sequences: 8 waves = 256 query rows per workgroup, one workgroup per
-// CU.  The two waves that share a SIMD (w and w+4) run the SAME per-tile program half a period
-// apart, kept complementary by two workgroup barriers per tile: while waves 0-3 are in their
-// matrix segment {P.V of tile t, K.Q^T of tile t+1} waves 4-7 are in their softmax (VALU) segment
-// and vice versa, so each SIMD's MFMA pipe always has exactly one wave feeding it instead of
-// two independent workgroups colliding in the same phase.  K/V tiles arrive by LDS-DMA
-// (buffer_load ... lds) one tile ahead; the DMA is issued at the start of a slot and only
-// waited for (counted, by the issuing wave) one full slot later, so it never stalls a barrier.
+// Long-sequence kernel: 8 waves = 256 query rows per workgroup, one workgroup per CU, K/V tiles by LDS-DMA
+// (buffer_load ... lds) one tile ahead, ONE workgroup barrier per 64-key tile.
 //
-//   global slot g:   group 0 (waves 0-3)              group 1 (waves 4-7)
-//        2t          softmax(t)                        P.V(t-1), K.Q^T(t)
-//        2t+1        DMA(t); P.V(t), K.Q^T(t+1)        DMA(t); softmax(t)
-//   DMA(t) = K(t+2) -> K slot t&1, V(t+1) -> V slot (t+1)&1   (both free since the end of slot 2t)
+// Per tile t every wave runs
+//   softmax segment   row max of the scores of tile t (held in score set t&1), new running max
+//   wait own DMA; barrier                      -> K(t+1), V(t) visible; every wave is past the reads of tile t-1
+//   DMA  K(t+2) -> K slot t&1, V(t+1) -> V slot (t+1)&1   (their previous contents were last read in tile t-1)
+//   matrix segment
+//     phase 1  K(t+1).Q^T into the other score set   ||  exp2 + bf16 packing of tile t on the VALU
+//     phase 2  O^T += V^T(t).P^T(t)                  ||  row sum of tile t
+// The scores of tile t+1 do not depend on the softmax of tile t, so computing them first lets the 80 VALU
+// instructions of the exponentials hide under 16 MFMAs instead of serialising in front of P.V.
+//
+// History: this kernel started as a "ping-pong" — the two waves sharing a SIMD ran the
+// per-tile program half a period apart (two barriers per tile), one in its matrix segment while the other did
+// its softmax.  Once the exponentials moved under the score MFMAs the softmax segment became a few dozen
+// instructions and the enforced alternation only parked a wave at a barrier: without the offset, with one
+// barrier per tile, the two waves of a SIMD fill each other's MFMA stalls (+3.4 %).  The kernel keeps its name.
 // ============================================================================================
 constexpr int QB2 = 256;
 
@@ -282,7 +287,6 @@ void flash_attn_fwd_d128_pp_kernel(const omh_attn_args p, const int q_tiles) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
 
     const int nwg = q_tiles * p.H * p.B;
     const int wid = xcd_remap(blockIdx.x, nwg);
@@ -416,7 +420,6 @@ void flash_attn_fwd_d128_pp_kernel(const omh_attn_args p, const int q_tiles) {
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     }
-    if (grp == 1) PP_BARRIER()                        // group 1 runs one slot behind group 0
 
     // Two tiles per trip so that the LDS ring slot and the score register set are compile-time constants in each
     // copy (fragment addresses = hoisted per-lane bases + immediate offsets).
@@ -432,7 +435,6 @@ void flash_attn_fwd_d128_pp_kernel(const omh_attn_args p, const int q_tiles) {
         for (int par = 0; par < 2; ++par) {
             const int t = t2 + par;
             if (t >= n_tiles) break;                   // wave-uniform
-            if (grp == 1) { PP_KDMA(t + 2, par) PP_VDMA(t + 1, par ^ 1) }
             // ---------------- softmax segment: row max of tile t
             {
                 const int kv0 = t * KB;
@@ -455,9 +457,9 @@ void flash_attn_fwd_d128_pp_kernel(const omh_attn_args p, const int q_tiles) {
                 alpha_keep = fast_exp2(m_run - m_new);
                 m_run = m_new;
             }
-            if (grp == 0 && t > 0) PP_WAIT_DMA();          // this wave's share of DMA(t-1), issued one slot ago
+            if (t > 0) PP_WAIT_DMA();                      // this wave's share of DMA(t-1), issued one tile ago
             PP_BARRIER()
-            if (grp == 0) { PP_KDMA(t + 2, par) PP_VDMA(t + 1, par ^ 1) }
+            PP_KDMA(t + 2, par) PP_VDMA(t + 1, par ^ 1)
             // ---------------- matrix segment
             {
                 if (!__all(alpha_keep == 1.0f)) {          // wave-uniform: the running max rarely moves after the first tiles
@@ -511,11 +513,8 @@ void flash_attn_fwd_d128_pp_kernel(const omh_attn_args p, const int q_tiles) {
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
             }
-            if (grp == 1) PP_WAIT_DMA();                   // this wave's share of DMA(t), issued one slot ago
-            PP_BARRIER()
         }
     }
-    if (grp == 0) PP_BARRIER()                        // match group 1's leading barrier
 
     if (q_row < p.Lq) {
         const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
