@@ -128,15 +128,26 @@ void layernorm_modulate_bwd_kernel(const float* __restrict__ x, const float* __r
                                    int64_t rows, int dim, float eps, float mul_const, const float* __restrict__ mul0,
                                    const float* __restrict__ mul1, int64_t mul1_stride, float* __restrict__ dmul,
                                    float* __restrict__ dadd, int64_t dstride, int64_t rows_per_batch) {
+    // Parameter-side sums: a workgroup whose rows all belong to one batch element first combines its 4 waves
+    // in LDS (ds_add_f32) and then issues ONE set of global atomics — at S = 1560 the 390 waves hammering the
+    // same 2 x 1536 addresses were 2/3 of this kernel's time.  Workgroups that straddle a batch boundary keep
+    // the per-wave flush.
+    extern __shared__ float wred[];                                 // [2][dim]
     const int lane = threadIdx.x & 63;
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
-    if (row0 >= rows) return;
+    const int64_t wg_row0 = (int64_t)blockIdx.x * 4 * RPW;
+    const int64_t wg_last = min(wg_row0 + 4 * RPW, rows) - 1;
+    const bool one_batch = (wg_row0 / rows_per_batch) == (wg_last / rows_per_batch);   // workgroup-uniform
+    if (one_batch) {
+        for (int i = threadIdx.x; i < 2 * dim; i += 256) wred[i] = 0.f;
+        __syncthreads();
+    }
+    const int64_t row0 = wg_row0 + (int64_t)(threadIdx.x >> 6) * RPW;
     const int nv = dim >> 2;
     const float4* m0 = (const float4*)mul0;
     float4 am[NV], aa[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) { am[i] = make_float4(0, 0, 0, 0); aa[i] = make_float4(0, 0, 0, 0); }
-    int64_t cur_b = row0 / rows_per_batch;
+    int64_t cur_b = min(row0, rows - 1) / rows_per_batch;
 
     auto flush = [&](int64_t b) {
 #pragma unroll
@@ -161,7 +172,7 @@ void layernorm_modulate_bwd_kernel(const float* __restrict__ x, const float* __r
         const int64_t row = row0 + rr;
         if (row >= rows) break;
         const int64_t b = row / rows_per_batch;
-        if (b != cur_b) { flush(cur_b); cur_b = b; }
+        if (!one_batch && b != cur_b) { flush(cur_b); cur_b = b; }
         const float4* xr = (const float4*)(x + row * dim);
         const float4* gr = (const float4*)(dy + row * dim);
         const float4* m1 = mul1 ? (const float4*)(mul1 + b * mul1_stride) : nullptr;
@@ -215,7 +226,26 @@ void layernorm_modulate_bwd_kernel(const float* __restrict__ x, const float* __r
             }
         }
     }
-    flush(cur_b);
+    if (!one_batch) {
+        if (row0 < rows) flush(cur_b);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv && row0 < rows) {
+            atomicAdd(&wred[4 * c + 0], am[i].x); atomicAdd(&wred[4 * c + 1], am[i].y);
+            atomicAdd(&wred[4 * c + 2], am[i].z); atomicAdd(&wred[4 * c + 3], am[i].w);
+            atomicAdd(&wred[dim + 4 * c + 0], aa[i].x); atomicAdd(&wred[dim + 4 * c + 1], aa[i].y);
+            atomicAdd(&wred[dim + 4 * c + 2], aa[i].z); atomicAdd(&wred[dim + 4 * c + 3], aa[i].w);
+        }
+    }
+    __syncthreads();
+    const int64_t bo = (wg_row0 / rows_per_batch) * dstride;
+    for (int i = threadIdx.x; i < dim; i += 256) {
+        if (dmul) atomicAdd(dmul + bo + i, wred[i]);
+        if (dadd) atomicAdd(dadd + bo + i, wred[dim + i]);
+    }
 }
 
 // ------------------------------------------------------------------ RMSNorm (+RoPE) backward
@@ -228,9 +258,13 @@ void rmsnorm_rope_bwd_kernel(const float* __restrict__ x, int64_t ldx, const flo
                              const float* __restrict__ weight, float eps, int do_norm,
                              const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, int rope_len,
                              int head_dim, const int* __restrict__ grid, int seq_len) {
+    extern __shared__ float wred[];                                 // [dim]: the 4 waves' dw partials (see LN backward)
     const int lane = threadIdx.x & 63;
+    if (dw) {
+        for (int i = threadIdx.x; i < dim; i += 256) wred[i] = 0.f;
+        __syncthreads();
+    }
     const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
-    if (row0 >= rows) return;
     const int nv = dim >> 2;
     const float4* wv = (const float4*)weight;
     const int hc = head_dim >> 1, c3 = hc / 3, cf = hc - 2 * c3;
@@ -303,11 +337,13 @@ void rmsnorm_rope_bwd_kernel(const float* __restrict__ x, int64_t ldx, const flo
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
-            if (c < nv) {
-                atomicAdd(dw + 4 * c + 0, aw[i].x); atomicAdd(dw + 4 * c + 1, aw[i].y);
-                atomicAdd(dw + 4 * c + 2, aw[i].z); atomicAdd(dw + 4 * c + 3, aw[i].w);
+            if (c < nv && row0 < rows) {
+                atomicAdd(&wred[4 * c + 0], aw[i].x); atomicAdd(&wred[4 * c + 1], aw[i].y);
+                atomicAdd(&wred[4 * c + 2], aw[i].z); atomicAdd(&wred[4 * c + 3], aw[i].w);
             }
         }
+        __syncthreads();
+        for (int i = threadIdx.x; i < dim; i += 256) atomicAdd(dw + i, wred[i]);
     }
 }
 
@@ -470,7 +506,7 @@ extern "C" int omh_layernorm_modulate_bwd(const float* x, const float* dy, float
     omh_clear_status();
     auto kern = dim <= 6 * 256 ? layernorm_modulate_bwd_kernel<6>
                                : (dim <= 20 * 256 ? layernorm_modulate_bwd_kernel<20> : layernorm_modulate_bwd_kernel<MAXV>);
-    hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 4 * RPW - 1) / (4 * RPW))), dim3(256), 0,
+    hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 4 * RPW - 1) / (4 * RPW))), dim3(256), 2 * dim * sizeof(float),
                        (hipStream_t)stream, x, dy, dx_accum, rows, dim, eps, mul_const, mul0, mul1, mul1_stride, dmul,
                        dadd, dstride, rows_per_batch);
     return omh_launch_status();
@@ -487,8 +523,9 @@ extern "C" int omh_rmsnorm_rope_bwd(const float* x, int64_t ldx, const float* dy
     omh_clear_status();
     auto kern = dim <= 6 * 256 ? rmsnorm_rope_bwd_kernel<6>
                                : (dim <= 20 * 256 ? rmsnorm_rope_bwd_kernel<20> : rmsnorm_rope_bwd_kernel<MAXV>);
-    hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 4 * RPW - 1) / (4 * RPW))), dim3(256), 0, (hipStream_t)stream, x,
-                       ldx, dy, lddy, (uint16_t*)dx_bf16, lddx, dweight, rows, dim, weight, eps, do_norm, rope_cos,
+    hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 4 * RPW - 1) / (4 * RPW))), dim3(256), dim * sizeof(float),
+                       (hipStream_t)stream, x, ldx, dy, lddy, (uint16_t*)dx_bf16, lddx, dweight, rows, dim, weight, eps,
+                       do_norm, rope_cos,
                        rope_sin, rope_len, head_dim, grid, seq_len);
     return omh_launch_status();
 }

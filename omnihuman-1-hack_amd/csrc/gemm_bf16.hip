@@ -326,7 +326,7 @@ int launch(const omh_gemm_args& a, hipStream_t s) {
     // tiny problems (training clips, context projections): 64x64 tiles so that more than 2 workgroups
     // per CU exist at all
     const int64_t mid_tiles = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
-    const bool tiny = force ? (force[0] == 't') : (mid_tiles < 512);
+    const bool tiny = force ? (force[0] == 't') : (mid_tiles < 256);
     if (tiny) return launch_cfg<EPI, 2, 2, 1, 1, 2>(a, s);
     return launch_cfg<EPI, 2, 2, 2, 2, 2>(a, s);
 }
