@@ -548,7 +548,7 @@ extern "C" int omh_flash_attn_fwd_d128(const omh_attn_args* args, omh_stream_t s
         return OMH_E_ALIGN;
     if (a.ldv < ((a.Lk + KB - 1) / KB) * KB) return OMH_E_SHAPE;
     // long sequences that fill the chip with 256-row workgroups take the ping-pong kernel
-    static const char* force = getenv("OMH_ATTN_KERNEL");          // "pp" / "base": benchmarking override
+    const char* force = getenv("OMH_ATTN_KERNEL");                 // "pp" / "base": test / benchmarking override
     const int q_tiles2 = (a.Lq + QB2 - 1) / QB2;
     const bool pp = force ? (force[0] == 'p') : ((int64_t)q_tiles2 * a.H * a.B >= 512 && a.Lk >= 1024);
     omh_clear_status();

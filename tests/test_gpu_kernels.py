@@ -84,7 +84,9 @@ def _attn_ref(q, k, v, k_lens, scale):
 @pytest.mark.parametrize("B,H,Lq,Lk,klens", [
     (1, 1, 128, 64, None), (2, 2, 200, 200, [200, 77]), (1, 12, 1560, 1560, [1560]),
     (2, 3, 130, 512, [37, 512]), (1, 2, 64, 320, [257]), (2, 1, 100, 64, [0, 5])])
-def test_flash_attention(ops, B, H, Lq, Lk, klens):
+@pytest.mark.parametrize("kernel", ["base", "pp"])
+def test_flash_attention(ops, B, H, Lq, Lk, klens, kernel, monkeypatch):
+    monkeypatch.setenv("OMH_ATTN_KERNEL", kernel)      # both kernels on every shape (ragged rows/keys, empty rows)
     torch.manual_seed(Lq + Lk)
     D = 128
     q = _bf(torch.randn(B, Lq, H, D, device="cuda"))
@@ -102,8 +104,28 @@ def test_flash_attention(ops, B, H, Lq, Lk, klens):
     assert float((out.float() - ref).abs().max()) < 3e-2
 
 
-def test_flash_attention_peaked_rows(ops):
+def test_flash_attention_long_sequence_dispatch(ops):
+    """A shape that takes the long-sequence kernel through the normal dispatch (>= 512 workgroups of 256 rows),
+    ragged in both rows and keys, two samples with different key lengths."""
+    torch.manual_seed(77)
+    B, H, Lq, Lk, D = 2, 12, 5601, 5601, 128
+    klens = [5601, 4000]
+    q = _bf(torch.randn(B, Lq, H, D, device="cuda"))
+    k = _bf(torch.randn(B, Lk, H, D, device="cuda"))
+    v = _bf(torch.randn(B, Lk, H, D, device="cuda"))
+    Lp = (Lk + 63) // 64 * 64
+    vt = torch.zeros(B, H * D, Lp, dtype=torch.bfloat16, device="cuda")
+    vt[:, :, :Lk] = v.reshape(B, Lk, H * D).transpose(1, 2)
+    out = ops.flash_attn(q, k, vt, torch.tensor(klens, dtype=torch.int32, device="cuda"))
+    ref = _attn_ref(q, k, v, klens, D ** -0.5)
+    assert rel_rms(out.float(), ref) < 8e-3
+    assert float((out.float() - ref).abs().max()) < 3e-2
+
+
+@pytest.mark.parametrize("kernel", ["base", "pp"])
+def test_flash_attention_peaked_rows(ops, kernel, monkeypatch):
     """Forces large online-softmax rescales: one key dominates late in the sequence."""
+    monkeypatch.setenv("OMH_ATTN_KERNEL", kernel)
     torch.manual_seed(5)
     B, H, L, D = 1, 2, 384, 128
     q = _bf(torch.randn(B, L, H, D, device="cuda"))
