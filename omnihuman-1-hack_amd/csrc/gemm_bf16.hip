@@ -320,7 +320,7 @@ template <int EPI>
 int launch(const omh_gemm_args& a, hipStream_t s) {
     // big tiles once they alone fill the chip (>= one workgroup per CU), small tiles otherwise
     const int64_t big_tiles = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) * a.batch;
-    static const char* force = getenv("OMH_GEMM_TILE");        // "big" / "small": benchmarking override
+    const char* force = getenv("OMH_GEMM_TILE");               // "big" / "small" / "tiny": test / benchmarking override
     const bool big = force ? (force[0] == 'b') : (big_tiles >= 256);
     if (big) return launch_cfg<EPI, 2, 4, 4, 2, 2>(a, s);
     // tiny problems (training clips, context projections): 64x64 tiles so that more than 2 workgroups

@@ -16,7 +16,9 @@ def _bf(x):
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 72), (1560, 1536, 1536), (257, 64, 1536),
                                    (64, 8960, 256), (1000, 1536, 8960)])
-def test_gemm_bf16_f32_bias(ops, M, N, K):
+@pytest.mark.parametrize("tile", ["big", "small", "tiny"])
+def test_gemm_bf16_f32_bias(ops, M, N, K, tile, monkeypatch):
+    monkeypatch.setenv("OMH_GEMM_TILE", tile)          # all three tile configurations on every (ragged) shape
     torch.manual_seed(M * 7 + N)
     a = _bf(torch.randn(M, K, device="cuda"))
     w = _bf(torch.randn(N, K, device="cuda") / math.sqrt(K))
@@ -42,7 +44,9 @@ def test_gemm_asymmetric_layout(ops):
     assert torch.equal(out, ref)
 
 
-def test_gemm_resid_gate_and_batch(ops):
+@pytest.mark.parametrize("tile", ["big", "small", "tiny"])
+def test_gemm_resid_gate_and_batch(ops, tile, monkeypatch):
+    monkeypatch.setenv("OMH_GEMM_TILE", tile)
     B, S, d, K = 2, 200, 256, 320
     torch.manual_seed(1)
     a = _bf(torch.randn(B * S, K, device="cuda"))
