@@ -104,10 +104,26 @@ def cpu_baseline(model, latent, t, ctx, seq_len, budget_s=60.0):
     O.dit_forward(sd, cfg, [lat], tt, [cc], seq_len, num_layers=0, return_hidden=True)
     t_embed = time.time() - t0
     t0 = time.time()
-    O.dit_forward(sd, cfg, [lat], tt, [cc], seq_len, num_layers=1, return_hidden=True)
+    hid = O.dit_forward(sd, cfg, [lat], tt, [cc], seq_len, num_layers=1, return_hidden=True)
     t_blk = max(time.time() - t0 - t_embed, 1e-6)
     step_s = 2 * (cfg.num_layers * t_blk + t_embed)
+    # the same sample doubles as a full-size parity check: residual stream after block 0 at S = 32 760, HIP vs oracle
+    parity = None
+    try:
+        dev = next(model.parameters()).device
+        with torch.no_grad():
+            xs, _e, fc, grids, lens, ctx_lens = model._embed([latent.to(dev)], t.to(dev), [ctx.to(dev)], seq_len, None, None)
+            sl = torch.tensor(lens, dtype=torch.long, device=dev)
+            gs = torch.tensor(grids, dtype=torch.long, device=dev)
+            cl = torch.tensor(ctx_lens, dtype=torch.long, device=dev)
+            xs = model.blocks[0](xs, fc.e0, sl, gs, (fc.rope_cos, fc.rope_sin), fc.ctx, cl, block_idx=0, _fc=fc)
+        ref = hid if torch.is_tensor(hid) else hid[0]
+        diff = (xs.float().cpu().reshape(-1) - ref.float().reshape(-1))
+        parity = float(diff.pow(2).mean().sqrt() / ref.float().pow(2).mean().sqrt().clamp_min(1e-30))
+    except Exception as e:  # the timing must survive a failure of this extra check
+        parity = repr(e)[:200]
     return {"value": 1.0 / step_s, "unit": "denoising steps/s", "cores": cores, "kind": "port",
+            "parity_rel_rms_block0_full_size": parity,
             "sample": f"oracle fp32 DiT: embeddings + 1 of 30 blocks of one forward at S={seq_len} "
                       f"({t_blk:.1f}s/block, {t_embed:.1f}s embed), extrapolated x30 blocks x2 CFG forwards",
             "tflops": dit_forward_flops(seq_len) / 30 / t_blk / 1e12}
