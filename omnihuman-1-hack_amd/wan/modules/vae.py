@@ -354,8 +354,27 @@ def _head(st, key, head: nn.Sequential, x, out_f32):
     return cs.run(out_f32=out_f32)
 
 
-def _run_sequential(st, prefix, seq, x):
+def _first_resample(seq):
+    """Index of the first Resample in a layer list (len(seq) if none)."""
     for i, layer in enumerate(seq):
+        if isinstance(layer, Resample):
+            return i
+    return len(seq)
+
+
+def _last_resample(seq):
+    """Index just past the last Resample in a layer list (0 if none)."""
+    last = 0
+    for i, layer in enumerate(seq):
+        if isinstance(layer, Resample):
+            last = i + 1
+    return last
+
+
+def _run_sequential(st, prefix, seq, x, start=0, stop=None):
+    for i, layer in enumerate(seq):
+        if i < start or (stop is not None and i >= stop):
+            continue
         key = f"{prefix}.{i}"
         if isinstance(layer, ResidualBlock):
             x = _res_block(st, key, layer, x)
@@ -401,25 +420,33 @@ class WanVAE_(nn.Module):
         enc = self.encoder
         out = None
         t_lat = 0
+        # The chunked schedule (1, 4, 4, ... frames; vae.py:523-535) is kept where it matters — through the
+        # Resample layers, whose first chunk is special.  Everything after the last Resample works at latent
+        # resolution on ONE frame per chunk (6 240 voxels at 480x832: a quarter of the chip per convolution);
+        # causal convolutions over [history | frames] give the same values whether the frames arrive one per call
+        # or all together, so that tail runs once over all n_chunks frames.
+        n_tail = _last_resample(enc.downsamples)
+        rows = []
         for i in range(n_chunks):
             t0, tn = (0, 1) if i == 0 else (1 + 4 * (i - 1), 4)
             c1 = st.conv("encoder.conv1", enc.conv1)
             ops.nchw_to_cl(vid, tn, t0, c1.Cin, out=c1.slot(tn, H, W, dev))
             h = c1.run()
-            h = _run_sequential(st, "encoder.downsamples", enc.downsamples, h)
-            h = _run_sequential(st, "encoder.middle", enc.middle, h)
-            h = _head(st, "encoder.head", enc.head, h, out_f32=False)          # [t, h, w, 2z]
-            mu = _conv_on(st, "conv1", self.conv1, h, out_f32=True)
-            if out is None:
-                out = torch.empty(self.z_dim, n_chunks, h.shape[1], h.shape[2], dtype=torch.float32, device=dev)
-            if isinstance(scale[0], torch.Tensor):
-                add = (-scale[0]).to(device=dev, dtype=torch.float32).contiguous()
-                mul = scale[1].to(device=dev, dtype=torch.float32).contiguous()
-            else:
-                add = torch.full((self.z_dim,), -float(scale[0]), device=dev)
-                mul = torch.full((self.z_dim,), float(scale[1]), device=dev)
-            ops.cl_to_nchw(mu, out, t_lat, self.z_dim, mul=mul, add=add)
-            t_lat += mu.shape[0]
+            rows.append(_run_sequential(st, "encoder.downsamples", enc.downsamples, h, stop=n_tail))
+        h = torch.cat(rows, dim=0) if len(rows) > 1 else rows[0]                   # [n_chunks, h, w, C]
+        h = _run_sequential(st, "encoder.downsamples", enc.downsamples, h, start=n_tail)
+        h = _run_sequential(st, "encoder.middle", enc.middle, h)
+        h = _head(st, "encoder.head", enc.head, h, out_f32=False)                  # [t, h, w, 2z]
+        mu = _conv_on(st, "conv1", self.conv1, h, out_f32=True)
+        out = torch.empty(self.z_dim, n_chunks, h.shape[1], h.shape[2], dtype=torch.float32, device=dev)
+        if isinstance(scale[0], torch.Tensor):
+            add = (-scale[0]).to(device=dev, dtype=torch.float32).contiguous()
+            mul = scale[1].to(device=dev, dtype=torch.float32).contiguous()
+        else:
+            add = torch.full((self.z_dim,), -float(scale[0]), device=dev)
+            mul = torch.full((self.z_dim,), float(scale[1]), device=dev)
+        ops.cl_to_nchw(mu, out, 0, self.z_dim, mul=mul, add=add)
+        t_lat = mu.shape[0]
         return out[:, :t_lat].unsqueeze(0)
 
     @torch.no_grad()
@@ -445,12 +472,18 @@ class WanVAE_(nn.Module):
         out = torch.empty(3, T_out, 8 * h, 8 * w, dtype=torch.float32, device=dev)
         lo, hi = (-3.0e38, 3.0e38) if clamp is None else clamp
         t_pix = 0
+        # Latent-resolution front (conv1, middle, the residual blocks before the first Resample) over ALL latent
+        # frames in one pass — same values as frame by frame (causal convolutions, per-frame attention), 21x the
+        # rows per launch; from the first Resample on, one latent frame per step as the reference (its first chunk
+        # skips the temporal upsample, vae.py:105-125).
+        n_front = _first_resample(dec.upsamples)
+        c1 = st.conv("decoder.conv1", dec.conv1)
+        c1.slot(Tl, h, w, dev).copy_(x_all)
+        y_all = c1.run()
+        y_all = _run_sequential(st, "decoder.middle", dec.middle, y_all)
+        y_all = _run_sequential(st, "decoder.upsamples", dec.upsamples, y_all, stop=n_front)
         for i in range(Tl):
-            c1 = st.conv("decoder.conv1", dec.conv1)
-            c1.slot(1, h, w, dev).copy_(x_all[i:i + 1])
-            y = c1.run()
-            y = _run_sequential(st, "decoder.middle", dec.middle, y)
-            y = _run_sequential(st, "decoder.upsamples", dec.upsamples, y)
+            y = _run_sequential(st, "decoder.upsamples", dec.upsamples, y_all[i:i + 1], start=n_front)
             y = _head(st, "decoder.head", dec.head, y, out_f32=True)            # fp32 [t, 8h, 8w, 3]
             ops.cl_to_nchw(y, out, t_pix, 3, lo=lo, hi=hi)
             t_pix += y.shape[0]
