@@ -130,7 +130,7 @@ def cpu_baseline(model, latent, t, ctx, seq_len, budget_s=60.0):
 
 
 def train_bench(model, device, world, dist, steps=4, warmup=2):
-    """BASELINE config 3: the distilled_trainer.py student step on one [16,1,60,104] clip per GPU
+    """BASELINE config 3: the distilled_trainer.py student step on a batch of [16,1,60,104] clips per GPU
     (forward + per-block recompute + backward on the HIP kernels, bucketed RCCL gradient all-reduce
     overlapped with the backward, fused AdamW).  Returns clips/s over all ranks."""
     trainer = importlib.import_module(PKG + ".trainer")
@@ -140,9 +140,12 @@ def train_bench(model, device, world, dist, steps=4, warmup=2):
     opt = optim.AdamW(model.parameters(), lr=5e-6, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
     red = par.BucketedGradAllReduce(model.parameters(), bucket_mb=256.0, force=bool(dist and world == 1)) if dist else None
     g = torch.Generator(device=device).manual_seed(7 + int(os.environ.get("RANK", 0)))
-    batch = (torch.randn(1, 16, 1, 60, 104, device=device, generator=g),
-             torch.randn(1, 512, 4096, device=device, generator=g),
-             torch.randn(1, 16, 1, 60, 104, device=device, generator=g))
+    # clips per GPU and step: BASELINE config 3 is "a batch of [16,1,60,104] clips" (distilled_trainer.py --batch_size;
+    # SURVEY 8(d) lists B in {1, 4}); 4 by default, 1 (the reference's argparse default) via OMH_TRAIN_BATCH=1
+    bsz = int(os.environ.get("OMH_TRAIN_BATCH", "4"))
+    batch = (torch.randn(bsz, 16, 1, 60, 104, device=device, generator=g),
+             torch.randn(bsz, 512, 4096, device=device, generator=g),
+             torch.randn(bsz, 16, 1, 60, 104, device=device, generator=g))
 
     def one():
         loss = trainer.training_step(batch, model, num_train_timesteps=1000)
@@ -174,10 +177,10 @@ def train_bench(model, device, world, dist, steps=4, warmup=2):
         red.remove()
     model.eval().requires_grad_(False)
     fwd = dit_forward_flops(1560)
-    return {"clips_per_s": round(world * steps / el, 3), "ms_per_step": round(el * 1e3 / steps, 2),
-            "clips_per_gpu_step": 1, "steps": steps, "finite_loss": bool(math.isfinite(loss)),
+    return {"clips_per_s": round(world * bsz * steps / el, 3), "ms_per_step": round(el * 1e3 / steps, 2),
+            "clips_per_gpu_step": bsz, "steps": steps, "finite_loss": bool(math.isfinite(loss)),
             "work": "fwd + per-block recompute + bwd (reference FFN-freeze quirk on) + grad all-reduce + AdamW",
-            "achieved_tflops_per_gpu_at_4x_fwd": round(4 * fwd * steps / el / 1e12, 1)}
+            "achieved_tflops_per_gpu_at_4x_fwd": round(4 * fwd * bsz * steps / el / 1e12, 1)}
 
 
 def main():

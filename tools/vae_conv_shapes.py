@@ -20,7 +20,7 @@ vae = vae_mod.WanVAE(vae_pth=None, device="cuda")
 z = torch.randn(16, 5, 60, 104, device="cuda")
 vae.decode([z[:, :2]])
 ops.conv_cl = timed
-vae.decode([z])
+vae.decode([z]) if os.environ.get("MODE", "decode") == "decode" else vae.encode([torch.rand(3, 17, 480, 832, device="cuda") * 2 - 1])
 tot = sum(v[1] for v in stats.values())
 for k, (n, ms) in sorted(stats.items(), key=lambda kv: -kv[1][1]):
     xs, To, Ho, Wo, Co, KT, KH, KW, st, up, f32, res, sp = k
