@@ -129,6 +129,50 @@ def cpu_baseline(model, latent, t, ctx, seq_len, budget_s=60.0):
             "tflops": dit_forward_flops(seq_len) / 30 / t_blk / 1e12}
 
 
+def single_frame_bench(model, device, iters=20):
+    """BASELINE config 1 on the GPU: the CFG teacher pair of generate.py:205-229 — two DiT forwards on one
+    [16,1,60,104] latent (S = 1560, t = 999) + v = u + 7.5 (c - u) — as eager launches and as hipGraph replays."""
+    graphs = importlib.import_module(PKG + ".graphs")
+    g = torch.Generator(device=device).manual_seed(11)
+    x = [torch.randn(16, 1, 60, 104, device=device, generator=g)]
+    t = torch.tensor([999.0], device=device)
+    st_c = model.encode_context([torch.randn(120, 4096, device=device, generator=g)])
+    st_u = model.encode_context([torch.randn(40, 4096, device=device, generator=g)])
+
+    def eager():
+        c, u = model(x, t, st_c, 1560)[0], model(x, t, st_u, 1560)[0]
+        return torch.add(u, c - u, alpha=7.5)
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            v = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters, v
+
+    te, ve = timed(eager)
+    res = {"workload": "CFG teacher pair: 2 DiT forwards at S=1560 + guidance combine",
+           "eager_ms": round(te * 1e3, 3)}
+    try:
+        gc, gu = graphs.GraphedForward(model, x, t, st_c, 1560), graphs.GraphedForward(model, x, t, st_u, 1560)
+
+        def graphed():
+            c, u = gc(x, t)[0], gu(x, t)[0]
+            return torch.add(u, c - u, alpha=7.5)
+        tg, vg = timed(graphed)
+        res.update({"hipgraph_ms": round(tg * 1e3, 3), "hipgraph_equals_eager": bool(torch.equal(vg, ve))})
+    except Exception as e:
+        tg = None
+        res["hipgraph_error"] = repr(e)[:200]
+    best = min(te, tg) if tg else te
+    fl = 2 * dit_forward_flops(1560)
+    res.update({"pairs_per_s": round(1 / best, 2), "achieved_tflops": round(fl / best / 1e12, 1),
+                "mfma_roofline_frac": round(fl / best / 1e12 / PEAK_BF16_TFLOPS, 4)})
+    return res
+
+
 def train_bench(model, device, world, dist, steps=4, warmup=2):
     """BASELINE config 3: the distilled_trainer.py student step on a batch of [16,1,60,104] clips per GPU
     (forward + per-block recompute + backward on the HIP kernels, bucketed RCCL gradient all-reduce
@@ -147,13 +191,26 @@ def train_bench(model, device, world, dist, steps=4, warmup=2):
              torch.randn(bsz, 512, 4096, device=device, generator=g),
              torch.randn(bsz, 16, 1, 60, 104, device=device, generator=g))
 
-    def one():
-        loss = trainer.training_step(batch, model, num_train_timesteps=1000)
+    def one_eager():
+        loss = trainer.forward_backward(batch, model, num_train_timesteps=1000)
         if red is not None:
             red.finish()
         opt.step()
         opt.zero_grad(set_to_none=True)
         return loss
+
+    # the step is ~4 600 short launches per clip: replay it as one hipGraph (graphs.py) unless OMH_TRAIN_GRAPH=0;
+    # the gradient all-reduce and AdamW run after the replay
+    one, mode = one_eager, "eager launches"
+    if os.environ.get("OMH_TRAIN_GRAPH", "1") != "0":
+        graphs = importlib.import_module(PKG + ".graphs")
+        try:
+            gstep = graphs.GraphedTrainingStep(model, batch, optimizer=opt, reducer=red, num_train_timesteps=1000)
+            one, mode = (lambda: gstep(batch)), "hipGraph replay of fwd+recompute+bwd, then all-reduce + AdamW"
+        except Exception as e:          # keep the leg alive on a capture failure, and say so
+            mode = f"eager launches (hipGraph capture failed: {repr(e)[:160]})"
+            for p in model.parameters():
+                p.grad = None
 
     for _ in range(warmup):
         one()
@@ -178,7 +235,8 @@ def train_bench(model, device, world, dist, steps=4, warmup=2):
     model.eval().requires_grad_(False)
     fwd = dit_forward_flops(1560)
     return {"clips_per_s": round(world * bsz * steps / el, 3), "ms_per_step": round(el * 1e3 / steps, 2),
-            "clips_per_gpu_step": bsz, "steps": steps, "finite_loss": bool(math.isfinite(loss)),
+            "clips_per_gpu_step": bsz, "steps": steps, "finite_loss": bool(math.isfinite(float(loss))),
+            "launch_mode": mode,
             "work": "fwd + per-block recompute + bwd (reference FFN-freeze quirk on) + grad all-reduce + AdamW",
             "achieved_tflops_per_gpu_at_4x_fwd": round(4 * fwd * bsz * steps / el / 1e12, 1)}
 
@@ -192,6 +250,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-single-frame", action="store_true")
     ap.add_argument("--only-train", action="store_true", help="profiling aid: run just the training leg")
     args = ap.parse_args()
 
@@ -321,16 +380,24 @@ def main():
         except (ImportError, AttributeError, NotImplementedError) as e:
             vae = {"frames_per_s": None, "note": f"VAE path not built: {e}"}
 
+    single = None
+    if not args.no_single_frame:
+        try:
+            single = single_frame_bench(model, device)
+        except Exception as e:
+            single = {"forwards_per_s": None, "error": repr(e)[:300]}
+
+    # before the training leg: that one updates the weights the full-size parity check compares
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(model, latent, torch.tensor([999.0]), ctx, seq_len)
+
     train = None
     if not args.no_train:
         try:
             train = train_bench(model, device, world, dist)
         except Exception as e:  # the headline line must survive a failure of this extra leg
             train = {"clips_per_s": None, "error": repr(e)[:300]}
-
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(model, latent, torch.tensor([999.0]), ctx, seq_len)
 
     if rank == 0:
         out = {
@@ -348,7 +415,7 @@ def main():
                     "achieved_tflops_per_gpu": round(2 * fwd_flops / (ms_per_step * 1e-3) / 1e12, 1),
                     "mfma_roofline_frac": round(2 * fwd_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                     "kernels": secondary},
-            "vae": vae, "train": train, "roofline": roofline, "cpu_baseline": cpu,
+            "single_frame": single, "vae": vae, "train": train, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if dist:

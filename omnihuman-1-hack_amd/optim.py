@@ -19,6 +19,7 @@ class AdamW(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             by_step = {}
             keep = []                                       # keeps .contiguous() copies alive until the launch
+            touched = []
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -30,14 +31,25 @@ class AdamW(torch.optim.Optimizer):
                 st["step"] += 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 keep.append(g)
+                touched.append(p)
                 assert p.dtype == torch.float32 and p.is_contiguous() and g.dtype == torch.float32
                 by_step.setdefault((st["step"], p.device), []).append(
                     (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()))
             # one multi-tensor launch per (step count, device): ~750 parameter tensors -> 1 kernel
             for (step, dev), rows in by_step.items():
-                table = torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=False)
+                # the pointer table is re-uploaded only when an address changed (never under a graphed step,
+                # whose gradients live at fixed addresses): no host-to-device copy in the steady state
+                cache = self.__dict__.setdefault("_tables", {})
+                ent = cache.get(dev)
+                if ent is None or ent[0] != rows:
+                    ent = cache[dev] = (rows, torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=False))
+                table = ent[1]
                 ops.adamw_multi(table, len(rows), group["lr"], b1, b2, group["eps"], group["weight_decay"], step,
                                 grad_scale)
+            # the kernel writes through raw pointers: tell autograd (and the packed bf16 weight copies keyed on
+            # ``_version``, model.py:_Packed) that these parameters changed
+            if touched:
+                torch.autograd.graph.increment_version(touched)
         return loss
 
 
@@ -46,3 +58,4 @@ def update_ema_model(ema_model, model, decay):
     """distilled_trainer.py:319-334 without the GPU->CPU round trip (the EMA copy lives in HBM)."""
     for target, source in zip(ema_model.parameters(), model.parameters()):
         ops.ema_update(target.data, source.data.to(target.device), decay)
+        torch.autograd.graph.increment_version(target)

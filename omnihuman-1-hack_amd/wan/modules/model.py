@@ -59,7 +59,13 @@ def rope_params(max_seq_len, dim, theta=10000):
 
 
 class _Packed:
-    """bf16 copies of weights, rebuilt when the source parameter changes."""
+    """bf16 copies of weights, rebuilt when the source parameter changes.
+
+    ``always_rebuild`` (set by graphs.py while a training step is captured into a hipGraph): every lookup runs
+    its builder, so the packing kernels are nodes of the graph and each replay re-packs the weights the
+    optimizer has just updated — a host-side version check cannot run inside a replay."""
+
+    always_rebuild = False
 
     def __init__(self):
         self.store = {}
@@ -67,7 +73,7 @@ class _Packed:
     def get(self, key, params, builder):
         sig = tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
         ent = self.store.get(key)
-        if ent is None or ent[0] != sig:
+        if ent is None or ent[0] != sig or _Packed.always_rebuild:
             with torch.no_grad():
                 ent = (sig, builder())
             self.store[key] = ent
@@ -86,6 +92,22 @@ def _bf16(w: torch.Tensor) -> torch.Tensor:
 
 def _round_up(a, b):
     return (a + b - 1) // b * b
+
+
+_CONST_CACHE = {}
+
+
+def _dev_ints(values, dtype, device):
+    """Small integer table (sequence lengths, grids) as a device tensor, cached by value: the forward issues no
+    host-to-device copy after the first call with a given geometry (each one is a synchronous pageable copy, and
+    none is allowed while a hipGraph is being captured).  Read-only by convention."""
+    key = (str(device), dtype, tuple(tuple(v) if isinstance(v, (tuple, list)) else v for v in values))
+    t = _CONST_CACHE.get(key)
+    if t is None:
+        if len(_CONST_CACHE) > 4096:
+            _CONST_CACHE.clear()
+        t = _CONST_CACHE[key] = torch.tensor(values, dtype=dtype, device=device)
+    return t
 
 
 class _FwdCtx:
@@ -617,9 +639,9 @@ class WanModel(nn.Module):
         fc = _FwdCtx()
         fc.B, fc.S, fc.dim = B, seq_len, d
         fc.e0 = e0.contiguous()
-        fc.seq_lens32 = torch.tensor(lens, dtype=torch.int32, device=device)
-        fc.grid32 = torch.tensor(grids, dtype=torch.int32, device=device)
-        fc.ctx_lens32 = torch.tensor(ctx_lens, dtype=torch.int32, device=device)
+        fc.seq_lens32 = _dev_ints(lens, torch.int32, device)
+        fc.grid32 = _dev_ints(grids, torch.int32, device)
+        fc.ctx_lens32 = _dev_ints(ctx_lens, torch.int32, device)
         fc.rope_cos, fc.rope_sin = self._rope(device)
         fc.ctx, fc.Lc = ctx, ctx.shape[1]
         fc.kv = state.kv if state is not None else None
@@ -672,9 +694,9 @@ class WanModel(nn.Module):
 
     def _forward_infer(self, x, t, context, seq_len, clip_fea=None, y=None):
         xs, e, fc, grids, lens, ctx_lens = self._embed(x, t, context, seq_len, clip_fea, y)
-        seq_lens = torch.tensor(lens, dtype=torch.long, device=xs.device)
-        grid_sizes = torch.tensor(grids, dtype=torch.long, device=xs.device)
-        context_lens = torch.tensor(ctx_lens, dtype=torch.long, device=xs.device)
+        seq_lens = _dev_ints(lens, torch.long, xs.device)
+        grid_sizes = _dev_ints(grids, torch.long, xs.device)
+        context_lens = _dev_ints(ctx_lens, torch.long, xs.device)
         freqs = (fc.rope_cos, fc.rope_sin)
         for i, block in enumerate(self.blocks):
             # module __call__ so forward hooks on blocks fire (seaweed_apt/model.py:150-155)

@@ -167,3 +167,41 @@ def test_training_step_function_matches_reference_loss(wan_model_mod):
     loss = trainer.training_step((noise, ctx, vt), m, num_train_timesteps=1000)
     assert abs(loss - float(g["loss"])) < 2e-2 * float(g["loss"])
     assert rel_rms(m.blocks[0].self_attn.q.weight.grad, torch.from_numpy(g["blocks.0.self_attn.q.weight"])) < TOL_GRAD
+
+
+def test_optimizer_step_reaches_the_next_forward(wan_model_mod):
+    """AdamW / EMA write parameters through raw pointers: the packed bf16 weight copies the forward uses must be
+    rebuilt afterwards (a second step that still saw the old weights would train nothing)."""
+    import importlib
+    trainer = importlib.import_module("omnihuman-1-hack_amd.trainer")
+    optim = importlib.import_module("omnihuman-1-hack_amd.optim")
+    cfg, sd, m, noise, vt, cl = _setup(wan_model_mod)
+    ctx = torch.stack(cl)
+    opt = optim.AdamW(m.parameters(), lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    args = (noise.cuda(), torch.ones(2, device="cuda") * 1000.0, [c.cuda() for c in cl], 24)
+    with torch.no_grad():
+        before = torch.stack(m(*args))
+    loss0 = trainer.training_step((noise, ctx, vt), m, num_train_timesteps=1000)
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    with torch.no_grad():
+        after = torch.stack(m(*args))
+    assert rel_rms(after, before) > 1e-3, "the forward did not see the optimizer update"
+    fresh = wan_model_mod.WanModel(num_layers=13, **__import__("oracle.make_golden", fromlist=["TINY"]).TINY)
+    fresh.load_state_dict(m.state_dict())
+    fresh = fresh.cuda().eval()
+    with torch.no_grad():
+        ref = torch.stack(fresh(*args))
+    assert torch.equal(after, ref)
+    # and the EMA copy likewise
+    ema = wan_model_mod.WanModel(num_layers=13, **__import__("oracle.make_golden", fromlist=["TINY"]).TINY)
+    ema.load_state_dict(sd)
+    ema = ema.cuda().eval()
+    with torch.no_grad():
+        e0 = torch.stack(ema(*args))
+    optim.update_ema_model(ema, m, 0.5)
+    with torch.no_grad():
+        e1 = torch.stack(ema(*args))
+    assert rel_rms(e1, e0) > 1e-4
+    loss1 = trainer.training_step((noise, ctx, vt), m, num_train_timesteps=1000)
+    assert loss1 != loss0
