@@ -199,10 +199,12 @@ def train_bench(model, device, world, dist, steps=4, warmup=2):
         opt.zero_grad(set_to_none=True)
         return loss
 
-    # the step is ~4 600 short launches per clip: replay it as one hipGraph (graphs.py) unless OMH_TRAIN_GRAPH=0;
-    # the gradient all-reduce and AdamW run after the replay
+    # OMH_TRAIN_GRAPH=1 replays the step as one hipGraph (graphs.py), all-reduce + AdamW after the replay.  Measured
+    # (profiles/r01_graph_vs_eager_probe.json): replay time = eager time (87.8 / 87.8 ms at 1 clip, 217 / 217 ms at
+    # 4) — the ~4 600 short kernels per clip are executed back to back by the GPU either way, the host is not the
+    # limit — so the default stays eager, which also keeps the all-reduce overlapped with the backward.
     one, mode = one_eager, "eager launches"
-    if os.environ.get("OMH_TRAIN_GRAPH", "1") != "0":
+    if os.environ.get("OMH_TRAIN_GRAPH", "0") == "1":
         graphs = importlib.import_module(PKG + ".graphs")
         try:
             gstep = graphs.GraphedTrainingStep(model, batch, optimizer=opt, reducer=red, num_train_timesteps=1000)

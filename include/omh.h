@@ -219,6 +219,11 @@ int omh_conv_cl_bf16(const omh_conv_args* args, omh_stream_t stream);
 int omh_rms_silu_cl(const void* x_bf16, const float* gamma, void* y_bf16, int64_t P, int32_t C,
                     int32_t do_silu, omh_stream_t stream);
 
+/* In-place ReLU on a bf16 buffer (n % 8 == 0): the nn.ReLU between the Conv3d layers of the OmniHuman pose
+ * guider (Omnihuman/omnihuman_wan_t2v.py:37-45,149-157), whose convolutions run on omh_conv_cl_bf16.
+ * A negative NaN becomes +0 as well (torch.relu would keep it): inputs here are finite conv outputs. */
+int omh_relu_bf16(void* x_bf16, int64_t n, omh_stream_t stream);
+
 /* Layout/precision converts at the VAE boundary (vae.py:547-553, 535-540, 661):
  *   nchw_to_cl : y[t][h][w][c] = bf16( x[c][t0+t][h][w] * mul[c] + add[c] ), c < C; channels C..Cp-1 zero
  *   cl_to_nchw : y[c][t0+t][h][w] = clamp( (x[t][h][w][c] + add[c]) * mul[c], lo, hi ), x fp32 with Cp channels

@@ -183,7 +183,13 @@ void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles) {
                 }
         }
         // ---- online softmax (log2 domain)
-        float mx = s[0][0], mx2 = s[1][0];
+        // Both chains start from a COMPILER-VISIBLE max over one register of each score accumulator: hipcc's hazard
+        // recognizer inserts the MFMA-write -> VALU-read wait states (19 for this MFMA) only for instructions it
+        // knows, not for the inline-asm v_max3 below, and the last K·Q^T MFMA is issued one instruction earlier.
+        // Without it the max was sometimes taken from scores missing their last k-slice: still a valid softmax
+        // offset, but a different one from run to run, i.e. outputs that differed in the last bf16 bit.
+        const float mx_seed = fmaxf(s[0][0], s[1][0]);
+        float mx = mx_seed, mx2 = mx_seed;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {                           // two independent v_max3 chains
             mx = vmax3(mx, s[0][r], s[1][r]);
@@ -446,7 +452,9 @@ void flash_attn_fwd_d128_pp_kernel(const omh_attn_args p, const int q_tiles) {
                         if (key + 32 >= klen) S[par][1][r] = -INFINITY;
                     }
                 }
-                float mx = S[par][0][0], mx2 = S[par][1][0];
+                // compiler-visible first read of both score accumulators (MFMA -> VALU wait states, see the base kernel)
+                const float mx_seed = fmaxf(S[par][0][0], S[par][1][0]);
+                float mx = mx_seed, mx2 = mx_seed;
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {                       // two independent chains
                     mx = vmax3(mx, S[par][0][r], S[par][1][r]);

@@ -121,7 +121,32 @@ inline int grid_for(int64_t n, int per_block) {
     return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
 }
 
+// in-place ReLU over bf16, 8 elements (16 bytes) per lane and trip: sign bit set -> +0
+__global__ __launch_bounds__(256) void relu_bf16_kernel(uint4* __restrict__ x, int64_t nvec) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        uint4 v = x[i];
+        uint32_t* w = (uint32_t*)&v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint32_t u = w[e];
+            if (u & 0x00008000u) u &= 0xffff0000u;
+            if (u & 0x80000000u) u &= 0x0000ffffu;
+            w[e] = u;
+        }
+        x[i] = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int omh_relu_bf16(void* x, int64_t n, omh_stream_t stream) {
+    if (!x || n <= 0) return OMH_E_BADARG;
+    if ((n & 7) || ((uintptr_t)x & 15)) return OMH_E_ALIGN;
+    omh_clear_status();
+    hipLaunchKernelGGL(relu_bf16_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (uint4*)x,
+                       n / 8);
+    return omh_launch_status();
+}
 
 extern "C" int omh_rms_silu_cl(const void* x, const float* gamma, void* y, int64_t P, int32_t C, int32_t do_silu,
                                omh_stream_t stream) {

@@ -234,6 +234,14 @@ def rms_silu_cl(x, gamma, out=None, do_silu=True):
     return out
 
 
+def relu_bf16_(x):
+    """In-place ReLU on a contiguous bf16 tensor (numel % 8 == 0)."""
+    _dev(x)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    check(lib.omh_relu_bf16(_p(x), x.numel(), _stream()), "omh_relu_bf16")
+    return x
+
+
 def nchw_to_cl(x, T, t0, Cp, mul=None, add=None, out=None):
     """x fp32 [C, Ttot, H, W] frames [t0, t0+T) -> bf16 [T, H, W, Cp]."""
     _dev(x, mul, add, out)

@@ -581,10 +581,15 @@ class WanModel(nn.Module):
             self._rope_dev = (str(device),) + _rope_tables(self.freqs, device)
         return self._rope_dev[1], self._rope_dev[2]
 
-    def forward(self, x, t, context, seq_len, clip_fea=None, y=None):
+    def forward(self, x, t, context, seq_len, clip_fea=None, y=None, extra_conditions=None):
         r"""Same contract as the reference (model.py:502-563):
         x: list (or batched tensor) of [C_in, F, H, W]; t: [B]; context: list of [L, text_dim];
-        returns list of fp32 [C_out, F, H, W]."""
+        returns list of fp32 [C_out, F, H, W].
+
+        ``extra_conditions`` is the keyword Omnihuman/omnihuman_wan_t2v.py:408-414 passes (the reference model does
+        not accept it): a ``[B, Ne, dim]`` tensor of condition tokens in model width, or a dict holding it under
+        ``"tokens"``.  They are prepended to the embedded text context (t2v, inference), so every block's
+        cross-attention attends to them — see omnihuman_wan_t2v.OmniHumanWanT2V.condition_tokens."""
         device = self.patch_embedding.weight.device
         if device.type != "cuda":
             raise ops.OmhError("WanModel.forward runs on the MI355X only (no CPU fallback): move the model "
@@ -592,12 +597,14 @@ class WanModel(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             if isinstance(context, ContextState):
                 raise ValueError("a ContextState is an inference-time cache: pass the raw context when training")
+            if extra_conditions is not None:
+                raise NotImplementedError("extra_conditions are an inference-time input (no backward is built for them)")
             from .model_train import forward_train
             return forward_train(self, x, t, context, seq_len, clip_fea, y)
         with torch.no_grad():
-            return self._forward_infer(x, t, context, seq_len, clip_fea, y)
+            return self._forward_infer(x, t, context, seq_len, clip_fea, y, extra_conditions)
 
-    def _embed(self, x, t, context, seq_len, clip_fea, y):
+    def _embed(self, x, t, context, seq_len, clip_fea, y, extra_conditions=None):
         device = self.patch_embedding.weight.device
         d = self.dim
         if y is not None:
@@ -634,8 +641,10 @@ class WanModel(nn.Module):
                 raise ValueError("ContextState does not belong to this model / batch or the weights changed since "
                                  "encode_context(): call encode_context() again")
             ctx, ctx_lens = state.ctx, list(state.ctx_lens)
+            if extra_conditions is not None:
+                raise ValueError("pass extra condition tokens to encode_context(), not next to a ContextState")
         else:
-            ctx, ctx_lens = self._embed_context(context, clip_fea)
+            ctx, ctx_lens = self._embed_context(context, clip_fea, extra_conditions)
         fc = _FwdCtx()
         fc.B, fc.S, fc.dim = B, seq_len, d
         fc.e0 = e0.contiguous()
@@ -648,8 +657,8 @@ class WanModel(nn.Module):
         fc.seq_lens_host, fc.ctx_lens_host = list(lens), list(ctx_lens)     # host copies: no device sync later
         return xs, e, fc, grids, lens, ctx_lens
 
-    def _embed_context(self, context, clip_fea=None):
-        """text_embedding (and img_emb) of zero-padded contexts: bf16 [B, (257+)text_len, dim] and true lengths."""
+    def _embed_context(self, context, clip_fea=None, extra_tokens=None):
+        """text_embedding (and img_emb) of zero-padded contexts: bf16 [B, (257+ | Ne+)text_len, dim] and true lengths."""
         device = self.patch_embedding.weight.device
         d, B = self.dim, len(context)
         ctx_lens = [int(u.shape[0]) for u in context]
@@ -667,6 +676,16 @@ class WanModel(nn.Module):
             ctx_img = self.img_emb(clip_fea.to(device))                    # bf16 [B, 257, dim]
             ctx = torch.cat([ctx_img, ctx], dim=1).contiguous()
             ctx_lens = [c + ctx_img.shape[1] for c in ctx_lens]
+        if extra_tokens is not None:
+            tok = extra_tokens.get("tokens") if isinstance(extra_tokens, dict) else extra_tokens
+            if tok is not None:
+                if self.model_type != "t2v":
+                    raise NotImplementedError("extra condition tokens are defined for the t2v backbone")
+                if tok.dim() != 3 or tok.shape[0] != B or tok.shape[2] != d:
+                    raise ValueError(f"extra condition tokens must be [B={B}, Ne, dim={d}], got {tuple(tok.shape)}")
+                tokb = ops.cast_bf16(tok.to(device=device, dtype=torch.float32).contiguous())
+                ctx = torch.cat([tokb, ctx], dim=1).contiguous()
+                ctx_lens = [c + tok.shape[1] for c in ctx_lens]
         return ctx, ctx_lens
 
     def _context_signature(self):
@@ -684,16 +703,17 @@ class WanModel(nn.Module):
         return tuple((p.data_ptr(), p._version) for p in ps)
 
     @torch.no_grad()
-    def encode_context(self, context, clip_fea=None) -> "ContextState":
-        """Pre-compute what depends only on (context, clip_fea).  Pass the result as ``context`` to forward()
-        (inference only); every block adds its cross-attention K / V^T on first use and reuses them afterwards."""
+    def encode_context(self, context, clip_fea=None, extra_conditions=None) -> "ContextState":
+        """Pre-compute what depends only on (context, clip_fea, extra_conditions).  Pass the result as ``context`` to
+        forward() (inference only); every block adds its cross-attention K / V^T on first use and reuses them
+        afterwards."""
         st = ContextState()
-        st.ctx, st.ctx_lens = self._embed_context(context, clip_fea)
+        st.ctx, st.ctx_lens = self._embed_context(context, clip_fea, extra_conditions)
         st.kv, st.B, st.model_id, st.version = {}, len(context), id(self), self._context_signature()
         return st
 
-    def _forward_infer(self, x, t, context, seq_len, clip_fea=None, y=None):
-        xs, e, fc, grids, lens, ctx_lens = self._embed(x, t, context, seq_len, clip_fea, y)
+    def _forward_infer(self, x, t, context, seq_len, clip_fea=None, y=None, extra_conditions=None):
+        xs, e, fc, grids, lens, ctx_lens = self._embed(x, t, context, seq_len, clip_fea, y, extra_conditions)
         seq_lens = _dev_ints(lens, torch.long, xs.device)
         grid_sizes = _dev_ints(grids, torch.long, xs.device)
         context_lens = _dev_ints(ctx_lens, torch.long, xs.device)

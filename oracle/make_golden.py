@@ -55,6 +55,73 @@ def golden_dpmpp():
                         timesteps=r.timesteps.numpy())
 
 
+OMNI_TINY = dict(model_dim=256, num_frames=5, audio_dim=32, pose_keypoints=6)
+
+
+def omni_state_dict(tag="golden/omni", pose_prefix="pose_guider.", widths=(64, 128), **kw):
+    """detgen weights of an ``OmniConditionsModule`` (names/shapes as the reference's, omnihuman_wan_t2v.py:28-51);
+    ``pose_prefix='pose_processor.', widths=(128, 256)`` gives the ``OmniHumanWanT2V`` variant (:149-157)."""
+    c = dict(OMNI_TINY)
+    c.update(kw)
+    d, a, k, t = c["model_dim"], c["audio_dim"], c["pose_keypoints"], c["num_frames"]
+    w0, w1 = widths
+    pp = pose_prefix
+    shapes = {"temporal_embed": (1, t, d), "audio_processor.0.weight": (d, a), "audio_processor.0.bias": (d,),
+              "audio_processor.2.weight": (d, d), "audio_processor.2.bias": (d,),
+              pp + "0.weight": (w0, k, 3, 3, 3), pp + "0.bias": (w0,),
+              pp + "2.weight": (w1, w0, 3, 3, 3), pp + "2.bias": (w1,),
+              pp + "4.weight": (d // 4, w1, 3, 3, 3), pp + "4.bias": (d // 4,),
+              "pose_fc.weight": (d, (d // 4) * 256), "pose_fc.bias": (d,),
+              "condition_projector.weight": (d, d), "condition_projector.bias": (d,)}
+    sd = {}
+    for name, shp in shapes.items():
+        fan_in = int(np.prod(shp[1:])) if len(shp) > 1 else shp[0]
+        scale = 0.1 if name.endswith("bias") else (1.0 / d ** 0.5 if name == "temporal_embed" else (3.0 / fan_in) ** 0.5)
+        sd[name] = torch.from_numpy(detgen.uniform(f"{tag}/{name}", shp, -1.0, 1.0) * np.float32(scale))
+    return sd
+
+
+def omni_inputs(tag="golden/omni", **kw):
+    c = dict(OMNI_TINY)
+    c.update(kw)
+    audio = torch.from_numpy(detgen.normalish(f"{tag}/audio", (2, c["num_frames"], c["audio_dim"])))
+    pose = torch.from_numpy(detgen.uniform(f"{tag}/pose", (2, c["pose_keypoints"], c["num_frames"], 64, 64), 0.0, 1.0))
+    return audio, pose
+
+
+def golden_omnihuman():
+    """OmniHuman adapters through the reference's own OmniConditionsModule (omnihuman_wan_t2v.py:13-92):
+    process_audio as written, and the pose Conv3d stack on [B, K, T, H, W] (process_pose itself raises a
+    shape error in the reference for T != C' — recorded in the fixture)."""
+    os.makedirs(OUT, exist_ok=True)
+    mod = ref_import.load_reference_omnihuman()
+    m = mod.OmniConditionsModule(**OMNI_TINY)
+    m.load_state_dict(omni_state_dict(), strict=True)
+    audio, pose = omni_inputs()
+    with torch.no_grad():
+        a = m.process_audio(audio)
+        pf = m.pose_guider(pose)
+        try:
+            m.process_pose(pose)
+            pose_err = ""
+        except RuntimeError as e:
+            pose_err = str(e)[:120]
+    # the default-schedule DPM-Solver++ the OmniHuman loop uses (scheduler built with shift=1.0, set_timesteps(n))
+    Dpm, _, _ = ref_import.load_reference_dpmpp()
+    r = Dpm(num_train_timesteps=1000, solver_order=2, prediction_type="flow_prediction", shift=1.0)
+    r.set_timesteps(5, device="cpu")
+    x = torch.from_numpy(detgen.normalish("golden/omni/x", (1, 16, 2, 6, 8)))
+    traj = []
+    for k, tstep in enumerate(r.timesteps):
+        v = torch.from_numpy(detgen.normalish(f"golden/omni/v{k}", (1, 16, 2, 6, 8)))
+        x = r.step(v, tstep, x, return_dict=False)[0]
+        traj.append(x.numpy())
+    np.savez_compressed(os.path.join(OUT, "omnihuman_adapters.npz"), audio_tokens=a.numpy(), pose_features=pf.numpy(),
+                        process_pose_error=np.array(pose_err), dpm_traj=np.stack(traj), dpm_sigmas=r.sigmas.numpy(),
+                        dpm_timesteps=r.timesteps.numpy())
+    print("omnihuman: audio", tuple(a.shape), "pose feat", tuple(pf.shape), "reference process_pose:", pose_err or "ran")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_grad_enabled(False)
@@ -154,6 +221,11 @@ def main():
                             coarse=out[:, 0, ::6, ::8].numpy())
         print("1.3B", float(out.abs().mean()))
 
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "omnihuman":
+    torch.set_grad_enabled(False)
+    golden_omnihuman()
+    sys.exit(0)
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "dpmpp":        # regenerate just that fixture

@@ -181,3 +181,38 @@ def load_reference_dpmpp():
         mod = importlib.import_module("wan.utils.fm_solvers")
         _CACHE["dpmpp"] = (mod.FlowDPMSolverMultistepScheduler, mod.get_sampling_sigmas, mod.retrieve_timesteps)
     return _CACHE["dpmpp"]
+
+
+def load_reference_omnihuman():
+    """The reference's ``Omnihuman/omnihuman_wan_t2v.py`` module (for ``OmniConditionsModule`` and the unbound
+    methods of ``OmniHumanWanT2V``), imported in place.  Its top-level imports that are unavailable here are
+    stubbed: ``omegaconf`` (DictConfig = dict), ``wan.WanT2V`` / ``wan.modules.t5`` / ``wan.configs`` (T5, tokenizers
+    and easydict are outside this path and not installed).  Nothing the golden vectors exercise runs through a stub."""
+    if "omni" in _CACHE:
+        return _CACHE["omni"]
+    load_reference_dpmpp()
+    import importlib.util
+    wan = sys.modules["wan"]
+    if not hasattr(wan, "WanT2V"):
+        wan.WanT2V = type("WanT2V", (), {})
+    t5 = types.ModuleType("wan.modules.t5")
+    t5.T5EncoderModel = type("T5EncoderModel", (), {})
+    sys.modules.setdefault("wan.modules.t5", t5)
+    cfgs = types.ModuleType("wan.configs")
+    cfgs.t2v_14B = {}
+    sys.modules.setdefault("wan.configs", cfgs)
+    oc = types.ModuleType("omegaconf")
+    oc.DictConfig, oc.OmegaConf = dict, type("OmegaConf", (), {})
+    sys.modules.setdefault("omegaconf", oc)
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp(prefix="omh_ref_")
+    os.chdir(tmp)
+    try:
+        spec = importlib.util.spec_from_file_location(
+            "ref_omnihuman_wan_t2v", os.path.join(REFERENCE_ROOT, "Omnihuman", "omnihuman_wan_t2v.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        os.chdir(cwd)
+    _CACHE["omni"] = mod
+    return mod

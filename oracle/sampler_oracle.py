@@ -113,11 +113,28 @@ def dpm_sampling_sigmas(num_steps: int, shift: float, num_train_timesteps: int =
     return sig, timesteps
 
 
-class DPMSolverOracle:
-    """solver_order 2, dpmsolver++, midpoint, flow_prediction, lower_order_final, final sigma 0."""
+def dpm_default_sigmas(num_steps: int, shift: float, num_train_timesteps: int = 1000):
+    """``set_timesteps(num_inference_steps)`` WITHOUT explicit sigmas (fm_solvers.py:226-290) of a scheduler constructed
+    with ``shift`` (:177-190) — the call Omnihuman/omnihuman_wan_t2v.py:172-180,383 makes: the constructor's shifted
+    table gives sigma_max / sigma_min, the linspace between them is shifted once more by config.shift."""
+    alphas = np.linspace(1, 1 / num_train_timesteps, num_train_timesteps)[::-1].copy()
+    base = torch.from_numpy(1.0 - alphas).to(torch.float32)
+    base = shift * base / (1 + (shift - 1) * base)
+    smax, smin = base[0].item(), base[-1].item()
+    s = np.linspace(smax, smin, num_steps + 1).copy()[:-1]
+    s = shift * s / (1 + (shift - 1) * s)
+    timesteps = torch.from_numpy(s * num_train_timesteps).to(torch.int64)
+    sig = torch.from_numpy(np.concatenate([s, [0]]).astype(np.float32))
+    return sig, timesteps
 
-    def __init__(self, num_steps: int, shift: float):
-        self.sigmas, self.timesteps = dpm_sampling_sigmas(num_steps, shift)
+
+class DPMSolverOracle:
+    """solver_order 2, dpmsolver++, midpoint, flow_prediction, lower_order_final, final sigma 0.
+    ``default_schedule``: the sigma table of ``set_timesteps(n)`` (dpm_default_sigmas) instead of the
+    ``get_sampling_sigmas`` one WanT2V.generate feeds in."""
+
+    def __init__(self, num_steps: int, shift: float, default_schedule: bool = False):
+        self.sigmas, self.timesteps = (dpm_default_sigmas if default_schedule else dpm_sampling_sigmas)(num_steps, shift)
         self.m = [None, None]                               # x0 predictions, oldest first
         self.lower = 0
         self.i = 0

@@ -289,8 +289,10 @@ def attention_block(sd, i, cfg, x, e0, seq_lens, grid_sizes, angles, context, co
     return x + y * e[5]
 
 
-def embed_inputs(sd, cfg: DiTConfig, x_list, t, context_list, seq_len, clip_fea=None, y=None):
-    """model.py:511-537 — everything before the block loop."""
+def embed_inputs(sd, cfg: DiTConfig, x_list, t, context_list, seq_len, clip_fea=None, y=None, extra_tokens=None):
+    """model.py:511-537 — everything before the block loop.  ``extra_tokens`` ([B, Ne, dim], already in model
+    width) are the OmniHuman condition tokens (oracle/omnihuman_oracle.py): prepended to the embedded text
+    context the way the i2v CLIP tokens are (model.py:534-537), so the cross-attention attends to them."""
     if y is not None:
         x_list = [torch.cat([u, v], dim=0) for u, v in zip(x_list, y)]
     emb = [F.conv3d(u.unsqueeze(0).float(), sd["patch_embedding.weight"],
@@ -315,6 +317,10 @@ def embed_inputs(sd, cfg: DiTConfig, x_list, t, context_list, seq_len, clip_fea=
         c = F.layer_norm(c, (cfg.dim,), sd["img_emb.proj.4.weight"], sd["img_emb.proj.4.bias"])
         ctx = torch.cat([c, ctx], dim=1)
         context_lens = context_lens + c.shape[1]
+    if extra_tokens is not None:
+        assert cfg.model_type == "t2v" and extra_tokens.shape[0] == ctx.shape[0] and extra_tokens.shape[2] == cfg.dim
+        ctx = torch.cat([extra_tokens.float(), ctx], dim=1)
+        context_lens = context_lens + extra_tokens.shape[1]
     return x, e, e0, ctx, context_lens, seq_lens, grid_sizes
 
 
@@ -334,12 +340,12 @@ def head_unpatchify(sd, cfg: DiTConfig, x, e, grid_sizes):
 def dit_forward(sd, cfg: DiTConfig, x_list: Sequence[torch.Tensor], t: torch.Tensor,
                 context_list: Sequence[torch.Tensor], seq_len: int,
                 clip_fea: Optional[torch.Tensor] = None, y=None,
-                num_layers: Optional[int] = None, return_hidden: bool = False):
+                num_layers: Optional[int] = None, return_hidden: bool = False, extra_tokens=None):
     """model.py:502-563.  ``num_layers`` truncates the block loop (used by the
     bounded cpu_baseline sample); ``return_hidden`` returns the residual
     stream after the last executed block instead of the unpatchified output."""
     x, e, e0, ctx, context_lens, seq_lens, grid_sizes = embed_inputs(
-        sd, cfg, x_list, t, context_list, seq_len, clip_fea, y)
+        sd, cfg, x_list, t, context_list, seq_len, clip_fea, y, extra_tokens)
     angles = rope_table(cfg.dim // cfg.num_heads)
     L = cfg.num_layers if num_layers is None else num_layers
     for i in range(L):

@@ -1,0 +1,134 @@
+"""OmniHuman conditioning path (BASELINE config 4; Omnihuman/omnihuman_wan_t2v.py) on the HIP kernels against
+oracle/omnihuman_oracle.py and the vectors produced by the reference's own OmniConditionsModule."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_rms
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# fp32 dense kernels: accumulation order only.  bf16 conv stack (3 layers, bf16 activations): 3 roundings.
+TOL_F32, TOL_CONV = 2e-5, 1.5e-2
+
+
+@pytest.fixture(scope="module")
+def omni(omh):
+    return importlib.import_module("omnihuman-1-hack_amd.omnihuman_wan_t2v")
+
+
+def test_relu_kernel(ops):
+    x = torch.randn(4099 * 8, device="cuda").bfloat16()
+    x[5] = -0.0
+    want = torch.relu(x.float()).bfloat16()
+    got = ops.relu_bf16_(x.clone())
+    assert torch.equal(got, want) and not torch.signbit(got.float()).any()
+
+
+def test_adapters_match_reference_vectors_and_oracle(omni):
+    from oracle import make_golden, omnihuman_oracle as OH
+    g = np.load(os.path.join(GOLD, "omnihuman_adapters.npz"))
+    sd = make_golden.omni_state_dict()
+    audio, pose = make_golden.omni_inputs()
+    m = omni.OmniConditionsModule(**make_golden.OMNI_TINY)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    a = m.process_audio(audio.cuda())
+    assert rel_rms(a, torch.from_numpy(g["audio_tokens"])) < TOL_F32          # the reference's own output
+    feat = m.pose_features(pose.cuda())
+    assert tuple(feat.shape) == (2, 64, 5, 16, 16)
+    assert rel_rms(feat, torch.from_numpy(g["pose_features"])) < TOL_CONV      # the reference's own Conv3d stack
+    tok = m.process_pose(pose.cuda())
+    want = OH.process_pose(sd, pose, prefix="pose_guider.")
+    assert tuple(tok.shape) == (2, 5, 256) and rel_rms(tok, want) < 2 * TOL_CONV
+    ct = m.condition_tokens(a, tok)
+    assert rel_rms(ct, OH.condition_tokens(sd, OH.process_audio(sd, audio), want)) < 2 * TOL_CONV
+    # exact-input check of the projector alone
+    ct2 = m.condition_tokens(OH.process_audio(sd, audio).cuda(), want.cuda())
+    assert rel_rms(ct2, OH.condition_tokens(sd, OH.process_audio(sd, audio), want)) < TOL_F32
+    out = m(audio=audio.cuda(), pose=pose.cuda())
+    assert set(out) == {"audio", "pose", "temporal"} and tuple(out["temporal"].shape) == (2, 5, 256)
+
+
+def test_dit_forward_with_condition_tokens(wan_model_mod):
+    """WanModel.forward(extra_conditions=...) — the call of omnihuman_wan_t2v.py:408-414 — against the oracle:
+    tokens prepended to the text context, masked text padding behind them still excluded."""
+    from oracle import detgen, make_golden, wan_dit_oracle as O
+    cfg, tag, xs, ctx, tt, seq_len, _, _ = make_golden.tiny_case("t2v", 2)
+    sd = O.synth_state_dict(cfg, tag)
+    extra = torch.from_numpy(detgen.normalish("omni/extra", (2, 13, 256)))
+    want = O.dit_forward(sd, cfg, xs, tt, ctx, seq_len, extra_tokens=extra)
+    base = O.dit_forward(sd, cfg, xs, tt, ctx, seq_len)
+    m = wan_model_mod.WanModel(num_layers=2, **make_golden.TINY)
+    m.load_state_dict(sd)
+    m = m.cuda().eval().requires_grad_(False)
+    x, c = [u.cuda() for u in xs], [u.cuda() for u in ctx]
+    got = m(x, tt.cuda(), c, seq_len, extra_conditions={"tokens": extra.cuda()})
+    st = m.encode_context(c, extra_conditions=extra.cuda())
+    got2 = m(x, tt.cuda(), st, seq_len)
+    for o, o2, w, b in zip(got, got2, want, base):
+        assert rel_rms(o, w) < 8e-3 and torch.equal(o, o2)
+        assert rel_rms(w, b) > 5e-2                     # the tokens matter: this is not the plain forward
+    with pytest.raises(ValueError):
+        m(x, tt.cuda(), c, seq_len, extra_conditions=extra[:1].cuda())
+
+
+class _StubVAE:
+    """process_reference / the final decode only move data here; the VAE itself is covered by test_gpu_vae.py."""
+
+    class model:
+        z_dim = 16
+
+    def __init__(self, ref):
+        self.ref = ref
+
+    def encode(self, xs):
+        return [self.ref.to(xs[0].device)]
+
+    def decode(self, zs):
+        return [z * 1.0 for z in zs]
+
+
+class _StubT2V:
+    def __init__(self, model, vae):
+        self.model, self.vae, self.text_encoder = model, vae, None
+
+
+def test_omnihuman_sampling_loop_matches_oracle(omni, wan_model_mod):
+    """The whole conditioning path: adapters -> condition tokens -> reference-latent concat -> uncond / cond DiT
+    forwards -> annealed CFG -> DPM-Solver++ (default schedule), 3 steps, against oracle/omnihuman_oracle.sample."""
+    from oracle import detgen, make_golden, omnihuman_oracle as OH, wan_dit_oracle as O
+    cfg = O.DiTConfig(model_type="t2v", in_dim=16, num_layers=2, **make_golden.TINY)
+    dsd = O.synth_state_dict(cfg, "omni/dit")
+    dsd["head.head.weight"] = torch.from_numpy(detgen.uniform("omni/dit/headw", tuple(dsd["head.head.weight"].shape),
+                                                              -0.08, 0.08))
+    kw = dict(model_dim=256, num_frames=5, audio_dim=32, pose_keypoints=6)
+    osd = make_golden.omni_state_dict("omni/sd", pose_prefix="pose_processor.", widths=(128, 256), **kw)
+    audio, pose = make_golden.omni_inputs("omni/in", **kw)
+    audio, pose = audio[:1], pose[:1]
+    noise = torch.from_numpy(detgen.normalish("omni/noise", (16, 2, 4, 6)))
+    ref = torch.from_numpy(detgen.normalish("omni/ref", (16, 1, 4, 6)))
+    ctx = torch.from_numpy(detgen.normalish("omni/ctx", (20, 64)))
+    ctx_null = torch.from_numpy(detgen.normalish("omni/ctxn", (7, 64)))
+    want = OH.sample(dsd, cfg, osd, noise, ctx, ctx_null, reference_latent=ref, audio=audio, pose=pose,
+                     num_inference_steps=3, cfg_scale=7.5)
+    plain = OH.sample(dsd, cfg, osd, noise, ctx, ctx_null, reference_latent=ref, num_inference_steps=3, cfg_scale=7.5)
+    dit = wan_model_mod.WanModel(num_layers=2, **make_golden.TINY)
+    dit.load_state_dict(dsd)
+    dit = dit.cuda().eval().requires_grad_(False)
+    m = omni.OmniHumanWanT2V(dict(num_frames=5, num_keypoints=6, model_dim=256, audio_dim=32), device_id=0,
+                             wan_t2v=_StubT2V(dit, _StubVAE(ref)))
+    missing, unexpected = m.load_state_dict(osd, strict=False)
+    assert not unexpected and all(k.startswith("wan_t2v") for k in missing), (missing, unexpected)
+    got = m(audio=audio, pose=pose, reference_image=torch.zeros(3, 1, 32, 48), num_inference_steps=3, cfg_scale=7.5,
+            text_context=ctx, text_context_null=ctx_null, noise=noise, return_latent=True)
+    assert tuple(got.shape) == (16, 2, 4, 6)
+    assert rel_rms(got, want) < 2e-2
+    assert rel_rms(want, plain) > 2e-2                  # audio / pose conditioning changes the sample
+    video = m(reference_image=torch.zeros(3, 1, 32, 48), num_inference_steps=2, text_context=ctx,
+              text_context_null=ctx_null, noise=noise)
+    assert tuple(video.shape) == (16, 2, 4, 6) and torch.isfinite(video).all()

@@ -120,3 +120,31 @@ def test_detgen_is_stable():
     assert [float(v) for v in a] == [float(v) for v in detgen.uniform("stability", (5,))]
     assert abs(float(detgen.normalish("stability", (100000,)).std()) - 1.0) < 0.02
     assert float(np.abs(a).max()) < 1.0
+
+
+def test_omnihuman_adapters_match_reference_vectors():
+    """OmniHuman conditioning adapters (Omnihuman/omnihuman_wan_t2v.py:13-92): process_audio and the pose Conv3d
+    stack of the oracle against outputs of the reference's own OmniConditionsModule; the default-schedule
+    DPM-Solver++ its sampling loop uses (scheduler shift 1.0, set_timesteps(n)) bit for bit."""
+    from oracle import detgen, make_golden, omnihuman_oracle as OH, sampler_oracle as SO
+    g = _g("omnihuman_adapters.npz")
+    sd = make_golden.omni_state_dict()
+    audio, pose = make_golden.omni_inputs()
+    assert rel_rms(OH.process_audio(sd, audio), torch.from_numpy(g["audio_tokens"])) < 1e-6
+    feat = OH.pose_conv_stack(sd, pose, prefix="pose_guider.")
+    assert tuple(feat.shape) == tuple(g["pose_features"].shape) == (2, 64, 5, 16, 16)
+    assert rel_rms(feat, torch.from_numpy(g["pose_features"])) < 1e-5
+    # the reference's own process_pose cannot run (axis labels swapped before pose_fc): the fixture records its error
+    assert "shapes cannot be multiplied" in str(g["process_pose_error"])
+    tok = OH.process_pose(sd, pose, prefix="pose_guider.")
+    assert tuple(tok.shape) == (2, 5, 256)
+    ct = OH.condition_tokens(sd, OH.process_audio(sd, audio), tok)
+    assert tuple(ct.shape) == (2, 2 * 4 + 5, 256)
+    o = SO.DPMSolverOracle(5, 1.0, default_schedule=True)
+    assert np.array_equal(o.sigmas.numpy(), g["dpm_sigmas"]) and np.array_equal(o.timesteps.numpy(), g["dpm_timesteps"])
+    x = torch.from_numpy(detgen.normalish("golden/omni/x", (1, 16, 2, 6, 8)))
+    for k in range(5):
+        v = torch.from_numpy(detgen.normalish(f"golden/omni/v{k}", (1, 16, 2, 6, 8)))
+        x = o.step(v, x)
+        assert np.array_equal(x.numpy(), g["dpm_traj"][k])
+    assert OH.annealed_cfg(0, 50, 7.5) == 7.5 and abs(OH.annealed_cfg(25, 50, 7.5) - 4.25) < 1e-12
