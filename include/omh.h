@@ -103,6 +103,34 @@ typedef struct omh_attn_args {
 int omh_flash_attn_fwd_d128(const omh_attn_args* args, omh_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Flash attention backward, head_dim 128 (training step: the autograd of
+ * flash_attn_varlen_func under the per-block checkpoint, model.py:544-548,
+ * distilled_trainer.py:289-301).  With P = exp(scale q k^T - lse) over keys
+ * < k_lens[b]:  dP = dO V^T,  dV = P^T dO,  dS = P (dP - rowsum(P dP)),
+ * dQ = scale dS K,  dK = scale dS^T Q.   No atomics: repeatable bit for bit.
+ *   q, dout    : [B, Lq, H, 128] bf16 (strides q_bs,q_rs / o_bs,o_rs); o: unused (may be NULL)
+ *   k, v       : [B, Lk, H, 128] bf16 (k_bs, k_rs)
+ *   qt, dot    : Q^T and dO^T, [B, H*128, ldq] bf16 (batch stride qt_bs), kt: K^T [B, H*128, ldk] (kt_bs);
+ *                ldq >= roundup(Lq,32), ldk >= roundup(Lk,32), pad columns ZERO (omh_transpose_bf16 into a
+ *                zero-filled buffer)
+ *   lse        : [B, H, Lq] fp32 from omh_flash_attn_fwd_d128;  delta: [B, H, Lq] fp32 workspace (written)
+ *   dq         : [B, Lq, H, 128] fp32 (dq_bs, dq_rs);  dk, dv: [B, Lk, H, 128] fp32 (dk_bs, dk_rs); fully written
+ * ---------------------------------------------------------------------- */
+typedef struct omh_attn_bwd_args {
+    const void* q; const void* k; const void* v; const void* o; const void* dout;
+    const void* qt; const void* dot; const void* kt;
+    const float* lse; float* delta;
+    float* dq; float* dk; float* dv;
+    const int32_t* k_lens;
+    int32_t B, H, Lq, Lk;
+    int64_t q_bs, q_rs, k_bs, k_rs, o_bs, o_rs, dq_bs, dq_rs, dk_bs, dk_rs, qt_bs, kt_bs;
+    int32_t ldq, ldk;
+    float scale;
+} omh_attn_bwd_args;
+
+int omh_flash_attn_bwd_d128(const omh_attn_bwd_args* args, omh_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * LayerNorm (no affine) fused with adaLN modulation, fp32 in -> bf16 out.
  * Replaces WanLayerNorm + "x*(1+scale)+shift" (model.py:91-104,292-293,
  * 314-315,358) and the affine norm3 (model.py:263-265,313).

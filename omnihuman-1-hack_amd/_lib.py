@@ -61,6 +61,18 @@ class AttnArgs(C.Structure):
                 ("ldv", i32), ("scale", f32), ("lse", vp)]
 
 
+class AttnBwdArgs(C.Structure):
+    _fields_ = [("q", vp), ("k", vp), ("v", vp), ("o", vp), ("dout", vp),
+                ("qt", vp), ("dot", vp), ("kt", vp),
+                ("lse", vp), ("delta", vp),
+                ("dq", vp), ("dk", vp), ("dv", vp),
+                ("k_lens", vp),
+                ("B", i32), ("H", i32), ("Lq", i32), ("Lk", i32),
+                ("q_bs", i64), ("q_rs", i64), ("k_bs", i64), ("k_rs", i64), ("o_bs", i64), ("o_rs", i64),
+                ("dq_bs", i64), ("dq_rs", i64), ("dk_bs", i64), ("dk_rs", i64), ("qt_bs", i64), ("kt_bs", i64),
+                ("ldq", i32), ("ldk", i32), ("scale", f32)]
+
+
 class ConvArgs(C.Structure):
     _fields_ = [("x", vp), ("w", vp), ("bias", vp), ("resid", vp), ("y", vp),
                 ("Tin", i32), ("Hin", i32), ("Win", i32), ("Cin", i32),
@@ -78,6 +90,7 @@ _SIGS = {
     "omh_build_arch": (C.c_char_p, []),
     "omh_gemm_bf16": (i32, [C.POINTER(GemmArgs), vp]),
     "omh_flash_attn_fwd_d128": (i32, [C.POINTER(AttnArgs), vp]),
+    "omh_flash_attn_bwd_d128": (i32, [C.POINTER(AttnBwdArgs), vp]),
     "omh_layernorm_modulate": (i32, [vp, vp, i64, i32, f32, f32, vp, vp, i64, vp, vp, i64, i64, vp]),
     "omh_rmsnorm_rope": (i32, [vp, i64, vp, i64, i32, vp, f32, i32, vp, vp, i32, i32, vp, i32, vp]),
     "omh_rmsnorm_rope_bf16": (i32, [vp, i64, vp, i64, i32, vp, f32, i32, vp, vp, i32, i32, vp, i32, vp]),

@@ -90,6 +90,35 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, k_lens: Optio
     return out
 
 
+def flash_attn_bwd(q, k, v, o, dout, lse, k_lens, B, H, Lq, Lk, scale=None):
+    """Fused attention backward (include/omh.h).  q, o, dout: bf16 [B*Lq, H*128]; k, v: bf16 [B*Lk, H*128]
+    (contiguous); lse fp32 [B, H, Lq] from ``flash_attn_raw(..., lse=)``; k_lens int32 [B] or None.
+    Returns fp32 dq [B*Lq, H*128], dk, dv [B*Lk, H*128]."""
+    _dev(q, k, v, o, dout, lse, k_lens)
+    d = H * 128
+    for t in (q, k, v, o, dout):
+        assert t.dtype == torch.bfloat16 and t.is_contiguous() and t.shape[-1] == d
+    assert lse.dtype == torch.float32 and lse.is_contiguous() and lse.numel() == B * H * Lq
+    dev = q.device
+    ldq, ldk = (Lq + 63) // 64 * 64, (Lk + 63) // 64 * 64
+    qt = torch.zeros(B, d, ldq, dtype=torch.bfloat16, device=dev)
+    dot = torch.zeros(B, d, ldq, dtype=torch.bfloat16, device=dev)
+    kt = torch.zeros(B, d, ldk, dtype=torch.bfloat16, device=dev)
+    transpose_bf16_raw(ptr(q), ptr(qt), Lq, d, d, ldq, batch=B, bs_in=Lq * d, bs_out=d * ldq)
+    transpose_bf16_raw(ptr(dout), ptr(dot), Lq, d, d, ldq, batch=B, bs_in=Lq * d, bs_out=d * ldq)
+    transpose_bf16_raw(ptr(k), ptr(kt), Lk, d, d, ldk, batch=B, bs_in=Lk * d, bs_out=d * ldk)
+    delta = torch.empty(B, H, Lq, dtype=torch.float32, device=dev)
+    dq = torch.empty(B * Lq, d, dtype=torch.float32, device=dev)
+    dk = torch.empty(B * Lk, d, dtype=torch.float32, device=dev)
+    dv = torch.empty(B * Lk, d, dtype=torch.float32, device=dev)
+    a = _lib.AttnBwdArgs(_p(q), _p(k), _p(v), _p(o), _p(dout), _p(qt), _p(dot), _p(kt), _p(lse), _p(delta),
+                         _p(dq), _p(dk), _p(dv), _p(k_lens), B, H, Lq, Lk,
+                         Lq * d, d, Lk * d, d, Lq * d, d, Lq * d, d, Lk * d, d, d * ldq, d * ldk, ldq, ldk,
+                         float(scale if scale is not None else 128 ** -0.5))
+    check(lib.omh_flash_attn_bwd_d128(C.byref(a), _stream()), "omh_flash_attn_bwd_d128")
+    return dq, dk, dv
+
+
 def layernorm_modulate_raw(x, y, rows, dim, eps, mul_const, mul0, mul1, mul1_stride, add0, add1, add1_stride,
                            rows_per_batch):
     check(lib.omh_layernorm_modulate(x, y, rows, dim, eps, mul_const, mul0, mul1, mul1_stride, add0, add1,

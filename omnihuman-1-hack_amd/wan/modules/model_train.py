@@ -27,6 +27,7 @@ The attention backward is un-fused (scores materialised per head): sized for the
 single-frame training clips of config 3 (S = 1560), not for S = 32 760.
 """
 import math
+import os
 
 import torch
 
@@ -94,13 +95,20 @@ def _vt_from_v(v, B, L, d):
     return vt, Lp
 
 
-def _attn_fwd(q, k, v, klens32, B, Lq, Lk, H, D):
+def _attn_fwd(q, k, v, klens32, B, Lq, Lk, H, D, want_lse=False):
     d = H * D
     vt, Lp = _vt_from_v(v, B, Lk, d)
     o = torch.empty(B * Lq, d, dtype=torch.bfloat16, device=q.device)
+    lse = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device) if want_lse else None
     ops.flash_attn_raw(ptr(q), ptr(k), ptr(vt), ptr(o), ptr(klens32) if klens32 is not None else None, B, H, Lq, Lk,
-                       Lq * d, d, Lk * d, d, d * Lp, Lq * d, d, Lp, D ** -0.5)
-    return o
+                       Lq * d, d, Lk * d, d, d * Lp, Lq * d, d, Lp, D ** -0.5, lse=ptr(lse) if want_lse else None)
+    return (o, lse) if want_lse else o
+
+
+# OMH_ATTN_BWD=unfused keeps the first implementation (scores materialised per head through the GEMM kernel, ~14
+# launches per sample) for A/B timing and as a second opinion in the tests; the default is the fused kernel pair
+# of csrc/attention_bwd.hip (3 launches + 3 transposes per call, whole batch at once).
+_FUSED_ATTN_BWD = os.environ.get("OMH_ATTN_BWD", "fused") != "unfused"
 
 
 def _attn_bwd(q, k, v, do, klens, B, Lq, Lk, H, D):
@@ -246,7 +254,7 @@ def _block_backward(model, blk, idx, st, x0, dx):
                              ptr(fc.grid32), S)
     wv, bv = sa._w("v")
     v = lin(h1, wv, bv)
-    o = _attn_fwd(q, k, v, fc.seq_lens32, B, S, S, N, D)
+    o, lse_sa = _attn_fwd(q, k, v, fc.seq_lens32, B, S, S, N, D, want_lse=True)
     wo, bo = sa._w("o")
     y1 = lin(o, wo, bo)
     x1 = resid_fwd(x0, y1, 2)
@@ -267,7 +275,7 @@ def _block_backward(model, blk, idx, st, x0, dx):
     kc_pre = lin(ctx2, wkc, bkc, EPI_F32)
     kc = ops.rmsnorm_rope(kc_pre, ca._norm_w("norm_k"), ca.eps, do_norm=ca.qk_norm)
     vc = lin(ctx2, wvc, bvc)
-    oc = _attn_fwd(qc, kc, vc, fc.ctx_lens32, B, S, Lc, N, D)
+    oc, lse_ca = _attn_fwd(qc, kc, vc, fc.ctx_lens32, B, S, Lc, N, D, want_lse=True)
     woc, boc = ca._w("o")
     y2 = lin(oc, woc, boc)
     x2 = resid_fwd(x1, y2, None)
@@ -295,7 +303,10 @@ def _block_backward(model, blk, idx, st, x0, dx):
     dy2 = resid_bwd(None, None)
     g["cross_attn.o.weight"], g["cross_attn.o.bias"] = _wgrad(dy2, oc), _bgrad(dy2)
     doc = ops.gemm(dy2, _wT(ca, "o", woc), epilogue=EPI_BF16)
-    dqc, dkc, dvc = _attn_bwd(qc, kc, vc, doc, ctx_lens, B, S, Lc, N, D)
+    if _FUSED_ATTN_BWD:
+        dqc, dkc, dvc = ops.flash_attn_bwd(qc, kc, vc, oc, doc, lse_ca, fc.ctx_lens32, B, N, S, Lc, D ** -0.5)
+    else:
+        dqc, dkc, dvc = _attn_bwd(qc, kc, vc, doc, ctx_lens, B, S, Lc, N, D)
     dqc_pre = torch.empty(R, d, dtype=torch.bfloat16, device=dev)
     dnq = torch.zeros(d, dtype=torch.float32, device=dev) if ca.qk_norm else None
     ops.rmsnorm_rope_bwd_raw(ptr(qc_pre), d, ptr(dqc), d, ptr(dqc_pre), d, ptr(dnq) if dnq is not None else None, R, d,
@@ -333,7 +344,10 @@ def _block_backward(model, blk, idx, st, x0, dx):
     dy1 = resid_bwd(y1, 2)
     g["self_attn.o.weight"], g["self_attn.o.bias"] = _wgrad(dy1, o), _bgrad(dy1)
     do = ops.gemm(dy1, _wT(sa, "o", wo), epilogue=EPI_BF16)
-    dq, dk, dv = _attn_bwd(q, k, v, do, seq_lens, B, S, S, N, D)
+    if _FUSED_ATTN_BWD:
+        dq, dk, dv = ops.flash_attn_bwd(q, k, v, o, do, lse_sa, fc.seq_lens32, B, N, S, S, D ** -0.5)
+    else:
+        dq, dk, dv = _attn_bwd(q, k, v, do, seq_lens, B, S, S, N, D)
     dqk_pre = torch.empty(R, 2 * d, dtype=torch.bfloat16, device=dev)
     for off, dyy, w, nm in ((0, dq, nq, "norm_q"), (d, dk, nk, "norm_k")):
         dnw = torch.zeros(d, dtype=torch.float32, device=dev) if sa.qk_norm else None

@@ -225,3 +225,54 @@ def test_flash_attention_is_bitwise_repeatable(ops, kernel, monkeypatch):
         ref = ops.flash_attn(q, k, vt, k_lens=kl).clone()
         for _ in range(8):
             assert torch.equal(ops.flash_attn(q, k, vt, k_lens=kl), ref)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,klens", [
+    (1, 2, 64, 64, None),
+    (2, 3, 200, 131, [131, 77]),          # ragged rows / keys, masked keys
+    (2, 2, 97, 512, [512, 1]),            # cross-attention shape: one sample with a single valid key
+    (1, 12, 1560, 1560, [1560]),          # BASELINE config 3 self-attention
+    (2, 1, 40, 70, [0, 70]),              # a sample without keys: zero gradients, no NaN
+])
+def test_flash_attention_backward(ops, B, H, Lq, Lk, klens):
+    """omh_flash_attn_bwd_d128 against autograd through a masked fp32 softmax attention on the same bf16 inputs."""
+    g = torch.Generator(device="cuda").manual_seed(Lq * 7 + Lk)
+    d = H * 128
+    q = torch.randn(B * Lq, d, device="cuda", generator=g).bfloat16()
+    k = torch.randn(B * Lk, d, device="cuda", generator=g).bfloat16()
+    v = torch.randn(B * Lk, d, device="cuda", generator=g).bfloat16()
+    do = torch.randn(B * Lq, d, device="cuda", generator=g).bfloat16()
+    kl = None if klens is None else torch.tensor(klens, dtype=torch.int32, device="cuda")
+    scale = 128 ** -0.5
+    # forward on the product kernel (o and lse feed the backward)
+    Lp = (Lk + 63) // 64 * 64
+    vt = torch.zeros(B, d, Lp, device="cuda", dtype=torch.bfloat16)
+    vt[:, :, :Lk] = v.view(B, Lk, d).transpose(1, 2)
+    o = torch.empty(B * Lq, d, device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(B, H, Lq, device="cuda", dtype=torch.float32)
+    ops.flash_attn_raw(ops.ptr(q), ops.ptr(k), ops.ptr(vt), ops.ptr(o), ops.ptr(kl) if kl is not None else None, B, H,
+                       Lq, Lk, Lq * d, d, Lk * d, d, d * Lp, Lq * d, d, Lp, scale, lse=ops.ptr(lse))
+    dq, dk, dv = ops.flash_attn_bwd(q, k, v, o, do, lse, kl, B, H, Lq, Lk, scale)
+    # reference
+    qr, kr, vr = (t.float().view(B, -1, H, 128).transpose(1, 2).detach().requires_grad_(True) for t in (q, k, v))
+    s = torch.einsum("bhid,bhjd->bhij", qr, kr) * scale
+    if kl is not None:
+        mask = torch.arange(Lk, device="cuda")[None, :] >= kl[:, None].long()
+        s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    p = torch.nan_to_num(p, nan=0.0)                      # rows without any key
+    out = torch.einsum("bhij,bhjd->bhid", p, vr)
+    out.backward(do.float().view(B, Lq, H, 128).transpose(1, 2))
+    for got, ref, L in ((dq, qr.grad, Lq), (dk, kr.grad, Lk), (dv, vr.grad, Lk)):
+        ref = torch.nan_to_num(ref, nan=0.0).transpose(1, 2).reshape(B * L, d)
+        assert torch.isfinite(got).all()
+        if float(ref.abs().max()) == 0:
+            assert float(got.abs().max()) == 0
+        else:
+            assert rel_rms(got, ref) < 1.2e-2
+    if klens is not None and 0 in klens:
+        b0 = klens.index(0)
+        assert float(dq.view(B, Lq, d)[b0].abs().max()) == 0 and float(dk.view(B, Lk, d)[b0].abs().max()) == 0
+    # repeatable bit for bit (no atomics)
+    dq2, dk2, dv2 = ops.flash_attn_bwd(q, k, v, o, do, lse, kl, B, H, Lq, Lk, scale)
+    assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
