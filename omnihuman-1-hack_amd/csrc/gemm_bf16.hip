@@ -318,16 +318,36 @@ int launch_cfg(const omh_gemm_args& a, hipStream_t s) {
 
 template <int EPI>
 int launch(const omh_gemm_args& a, hipStream_t s) {
-    // big tiles once they alone fill the chip (>= one workgroup per CU), small tiles otherwise
+    // Tile configuration by estimated time = sum over the rounds the tiles take on the chip, with per-round times
+    // measured on MI355X (tools/gemm_tile_probe.py; k = K / 1536; a round is "light" when few workgroups share the
+    // L2 / fabric, "heavy" when the chip is mostly full):
+    //   256x256 tile, one workgroup per CU  (256 slots): light (<= 192 tiles) 9 + 27.5 k us, heavy 9 + 32 k us
+    //   128x128 tile, two workgroups per CU (512 slots): light (<= 160 tiles) 4 + 15.5 k us, heavy 5 + 21 k us
+    //   64x64 tile: only when even the 128x128 tiles cannot give every CU a workgroup (context projections, one
+    //   training clip) — there it wins by 15-40 %.
+    // The former rule (big iff >= 256 big tiles) put e.g. 6240 x 1536 x 1536 (150 big tiles = ONE round of 37 us) on
+    // 588 small tiles = TWO rounds, and 300 big tiles (two rounds) ahead of 1176 small ones (2 + a light one):
+    // 10-38 % slower on 11 of the 28 shapes probed, all of them in the training step and the S = 1560 forward.
     const int64_t big_tiles = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) * a.batch;
-    const char* force = getenv("OMH_GEMM_TILE");               // "big" / "small" / "tiny": test / benchmarking override
-    const bool big = force ? (force[0] == 'b') : (big_tiles >= 256);
-    if (big) return launch_cfg<EPI, 2, 4, 4, 2, 2>(a, s);
-    // tiny problems (training clips, context projections): 64x64 tiles so that more than 2 workgroups
-    // per CU exist at all
     const int64_t mid_tiles = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
-    const bool tiny = force ? (force[0] == 't') : (mid_tiles < 256);
-    if (tiny) return launch_cfg<EPI, 2, 2, 1, 1, 2>(a, s);
+    const char* force = getenv("OMH_GEMM_TILE");               // "big" / "small" / "tiny": test / benchmarking override
+    if (force) {
+        if (force[0] == 'b') return launch_cfg<EPI, 2, 4, 4, 2, 2>(a, s);
+        if (force[0] == 't') return launch_cfg<EPI, 2, 2, 1, 1, 2>(a, s);
+        return launch_cfg<EPI, 2, 2, 2, 2, 2>(a, s);
+    }
+    if (mid_tiles < 256) return launch_cfg<EPI, 2, 2, 1, 1, 2>(a, s);
+    static const char* rule = getenv("OMH_GEMM_RULE");         // "old": the former rule, for A/B timing on one box
+    if (rule && rule[0] == 'o')
+        return big_tiles >= 256 ? launch_cfg<EPI, 2, 4, 4, 2, 2>(a, s) : launch_cfg<EPI, 2, 2, 2, 2, 2>(a, s);
+    const float k = (float)a.K * (1.0f / 1536.0f);
+    auto cost = [](int64_t tiles, int64_t slots, int64_t light_max, float light, float heavy) {
+        const int64_t full = tiles / slots, last = tiles % slots;
+        return (float)full * heavy + (last == 0 ? 0.0f : (last <= light_max ? light : heavy));
+    };
+    const float cost_big = cost(big_tiles, 256, 192, 9.0f + 27.5f * k, 9.0f + 32.0f * k);
+    const float cost_small = cost(mid_tiles, 512, 160, 4.0f + 15.5f * k, 5.0f + 21.0f * k);
+    if (cost_big <= cost_small) return launch_cfg<EPI, 2, 4, 4, 2, 2>(a, s);
     return launch_cfg<EPI, 2, 2, 2, 2, 2>(a, s);
 }
 
