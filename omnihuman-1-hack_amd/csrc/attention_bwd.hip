@@ -44,6 +44,10 @@ __device__ __forceinline__ uint32_t t_addr(int row, int slot) {
     return (uint32_t)(row * 64 + ((slot ^ ((row >> 2) & 3)) << 4));
 }
 
+// component-wise (a ?: on the whole struct becomes a select between two stack slots: scratch traffic)
+__device__ __forceinline__ uint4 keep_if(bool ok, const uint4 v) {
+    return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+}
 __device__ __forceinline__ uint4 ld16(const uint16_t* p, bool ok) {
     return ok ? *(const uint4*)p : make_uint4(0u, 0u, 0u, 0u);
 }
@@ -120,32 +124,53 @@ void attn_bwd_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks) {
     const float sc = p.scale * LOG2E;
     const int qrow_l = swap_bits23(li);
 
+    // global -> register prefetch one tile ahead: the loads of tile t+1 fly while tile t is computed.  Loads are
+    // unconditional from a clamped row (a select on the loaded value would make the wave wait for it at once);
+    // rows past the end are zeroed when the registers go to LDS, between the two barriers of the next trip.
+    // (explicit scalars, not arrays: indexed by a loop variable inside a conditional block hipcc kept the arrays in
+    // scratch memory — store after every load, reload before every LDS write — which made the prefetch a loss)
+    uint4 gq0, gq1, gdo0, gdo1, gqt0, gqt1, gdot0, gdot1;
+    float glse = 0.f, gdel = 0.f;
+#define BWD_KV_PREFETCH1(Q0, J)                                                                               \
+    {                                                                                                         \
+        const int c = tid + 256 * J;                                                                          \
+        const int row = min((Q0) + (c >> 4), p.Lq - 1), slot = c & 15;                                        \
+        gq##J = *(const uint4*)(Q + (int64_t)row * p.q_rs + slot * 8);                                        \
+        gdo##J = *(const uint4*)(DO + (int64_t)row * p.o_rs + slot * 8);                                      \
+        const int64_t off = (int64_t)(c >> 2) * p.ldq + (Q0) + (c & 3) * 8;                                   \
+        gqt##J = *(const uint4*)(QT + off);                                                                   \
+        gdot##J = *(const uint4*)(DOT + off);                                                                 \
+    }
+#define BWD_KV_PREFETCH(Q0)                                                                                   \
+    {                                                                                                         \
+        BWD_KV_PREFETCH1(Q0, 0) BWD_KV_PREFETCH1(Q0, 1)                                                       \
+        if (tid < 32) {                                                                                       \
+            const int q = min((Q0) + tid, p.Lq - 1);                                                          \
+            glse = LSE[q];                                                                                    \
+            gdel = DEL[q];                                                                                    \
+        }                                                                                                     \
+    }
+#define BWD_KV_TO_LDS1(Q0, J)                                                                                 \
+    {                                                                                                         \
+        const int c = tid + 256 * J;                                                                          \
+        const bool in = (Q0) + (c >> 4) < p.Lq;                                                               \
+        *(uint4*)(Qs + r_addr(c >> 4, c & 15)) = keep_if(in, gq##J);      /* Q, dO rows: 32 x 16 chunks */    \
+        *(uint4*)(dOs + r_addr(c >> 4, c & 15)) = keep_if(in, gdo##J);                                        \
+        *(uint4*)(QTs + t_addr(c >> 2, c & 3)) = gqt##J;                  /* Q^T, dO^T: 128 x 4 chunks */     \
+        *(uint4*)(dOTs + t_addr(c >> 2, c & 3)) = gdot##J;                                                    \
+    }
+    BWD_KV_PREFETCH(0)
     for (int q0 = 0; q0 < p.Lq; q0 += 32) {
         __syncthreads();                                   // every wave is done with the previous tile
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c = tid + 256 * j;
-            {   // Q, dO rows: 32 x 16 chunks
-                const int row = c >> 4, slot = c & 15;
-                const bool in = q0 + row < p.Lq;
-                *(uint4*)(Qs + r_addr(row, slot)) = ld16(Q + (int64_t)(q0 + row) * p.q_rs + slot * 8, in);
-                *(uint4*)(dOs + r_addr(row, slot)) = ld16(DO + (int64_t)(q0 + row) * p.o_rs + slot * 8, in);
-            }
-            {   // Q^T, dO^T: 128 x 4 chunks (zero padded to ldq >= q0 + 32)
-                const int row = c >> 2, slot = c & 3;
-                const int64_t off = (int64_t)row * p.ldq + q0 + slot * 8;
-                *(uint4*)(QTs + t_addr(row, slot)) = *(const uint4*)(QT + off);
-                *(uint4*)(dOTs + t_addr(row, slot)) = *(const uint4*)(DOT + off);
-            }
-        }
+        BWD_KV_TO_LDS1(q0, 0) BWD_KV_TO_LDS1(q0, 1)
         if (tid < 32) {
-            const int q = q0 + tid;
-            float l = (q < p.Lq) ? LSE[q] : INFINITY;
-            if (!(l > -INFINITY)) l = INFINITY;            // a row without keys: P = 0
+            const bool in = q0 + tid < p.Lq;
+            const float l = (in && glse > -INFINITY) ? glse : INFINITY;       // no keys / past the end: P = 0
             lse_s[tid] = l * LOG2E;
-            dl_s[tid] = (q < p.Lq) ? DEL[q] : 0.f;
+            dl_s[tid] = in ? gdel : 0.f;
         }
         __syncthreads();
+        if (q0 + 32 < p.Lq) BWD_KV_PREFETCH(q0 + 32)
 
         // S = Q K^T and dP = dO V^T as [query][key], lane = key; register r <-> query q0 + 16(r>>3) + 8 lh + (r&7)
         f32x16 s, dp;
@@ -194,7 +219,9 @@ void attn_bwd_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks) {
 }
 
 // ---------------------------------------------------------------------------------------------- dQ
-__global__ __launch_bounds__(256)
+// two workgroups per CU (<= 256 registers per lane): one wave per SIMD leaves every LDS-read -> MFMA -> exp2 chain
+// exposed; a second resident workgroup fills those gaps
+__global__ __launch_bounds__(256, 2)
 void attn_bwd_dq_kernel(const omh_attn_bwd_args p, const int q_blocks) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 8192];
     unsigned char* Ks = smem;
@@ -233,17 +260,33 @@ void attn_bwd_dq_kernel(const omh_attn_bwd_args p, const int q_blocks) {
 
     // ---- pass 1: delta_i = sum_j P_ij dP_ij (this lane's query; its two half-lanes hold different keys)
     float del = 0.f;
+    // K / V / K^T tiles are prefetched into registers one tile ahead (unconditional loads from a clamped row; rows
+    // past Lk are zeroed on the way to LDS), see the dK/dV kernel
+    uint4 gk0, gk1, gv0, gv1, gkt0 = make_uint4(0u, 0u, 0u, 0u), gkt1 = gkt0;
+#define BWD_Q_PREFETCH1(K0, WITH_KT, J)                                                                       \
+    {                                                                                                         \
+        const int c = tid + 256 * J;                                                                          \
+        const int row = min((K0) + (c >> 4), p.Lk - 1), slot = c & 15;                                        \
+        gk##J = *(const uint4*)(K + (int64_t)row * p.k_rs + slot * 8);                                        \
+        gv##J = *(const uint4*)(V + (int64_t)row * p.k_rs + slot * 8);                                        \
+        if (WITH_KT) gkt##J = *(const uint4*)(KT + (int64_t)(c >> 2) * p.ldk + (K0) + (c & 3) * 8);           \
+    }
+#define BWD_Q_PREFETCH(K0, WITH_KT) { BWD_Q_PREFETCH1(K0, WITH_KT, 0) BWD_Q_PREFETCH1(K0, WITH_KT, 1) }
+#define BWD_Q_TO_LDS1(K0, WITH_KT, J)                                                                         \
+    {                                                                                                         \
+        const int c = tid + 256 * J;                                                                          \
+        const bool in = (K0) + (c >> 4) < p.Lk;                                                               \
+        *(uint4*)(Ks + r_addr(c >> 4, c & 15)) = keep_if(in, gk##J);                                          \
+        *(uint4*)(Vs + r_addr(c >> 4, c & 15)) = keep_if(in, gv##J);                                          \
+        if (WITH_KT) *(uint4*)(KTs + t_addr(c >> 2, c & 3)) = gkt##J;                                         \
+    }
+#define BWD_Q_TO_LDS(K0, WITH_KT) { BWD_Q_TO_LDS1(K0, WITH_KT, 0) BWD_Q_TO_LDS1(K0, WITH_KT, 1) }
+    if (klen > 0) BWD_Q_PREFETCH(0, false)
     for (int k0 = 0; k0 < klen; k0 += 32) {
         __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c = tid + 256 * j;
-            const int row = c >> 4, slot = c & 15;
-            const bool in = k0 + row < p.Lk;
-            *(uint4*)(Ks + r_addr(row, slot)) = ld16(K + (int64_t)(k0 + row) * p.k_rs + slot * 8, in);
-            *(uint4*)(Vs + r_addr(row, slot)) = ld16(V + (int64_t)(k0 + row) * p.k_rs + slot * 8, in);
-        }
+        BWD_Q_TO_LDS(k0, false)
         __syncthreads();
+        if (k0 + 32 < klen) BWD_Q_PREFETCH(k0 + 32, false)
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -273,23 +316,12 @@ void attn_bwd_dq_kernel(const omh_attn_bwd_args p, const int q_blocks) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
     // ---- pass 2: dQ
+    if (klen > 0) BWD_Q_PREFETCH(0, true)
     for (int k0 = 0; k0 < klen; k0 += 32) {
         __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c = tid + 256 * j;
-            {
-                const int row = c >> 4, slot = c & 15;
-                const bool in = k0 + row < p.Lk;
-                *(uint4*)(Ks + r_addr(row, slot)) = ld16(K + (int64_t)(k0 + row) * p.k_rs + slot * 8, in);
-                *(uint4*)(Vs + r_addr(row, slot)) = ld16(V + (int64_t)(k0 + row) * p.k_rs + slot * 8, in);
-            }
-            {
-                const int row = c >> 2, slot = c & 3;
-                *(uint4*)(KTs + t_addr(row, slot)) = *(const uint4*)(KT + (int64_t)row * p.ldk + k0 + slot * 8);
-            }
-        }
+        BWD_Q_TO_LDS(k0, true)
         __syncthreads();
+        if (k0 + 32 < klen) BWD_Q_PREFETCH(k0 + 32, true)
         // S^T = K Q^T and dP^T = V dO^T as [key][query], lane = query; register r <-> key k0 + 16(r>>3) + 8 lh + (r&7)
         f32x16 s, dp;
 #pragma unroll
