@@ -101,9 +101,12 @@ def flash_attn_bwd(q, k, v, o, dout, lse, k_lens, B, H, Lq, Lk, scale=None):
     assert lse.dtype == torch.float32 and lse.is_contiguous() and lse.numel() == B * H * Lq
     dev = q.device
     ldq, ldk = (Lq + 63) // 64 * 64, (Lk + 63) // 64 * 64
-    qt = torch.zeros(B, d, ldq, dtype=torch.bfloat16, device=dev)
-    dot = torch.zeros(B, d, ldq, dtype=torch.bfloat16, device=dev)
-    kt = torch.zeros(B, d, ldk, dtype=torch.bfloat16, device=dev)
+    def padded(L, ld):                     # only the pad columns need the zeros (the transpose writes the rest)
+        t = torch.empty(B, d, ld, dtype=torch.bfloat16, device=dev)
+        if ld != L:
+            t[:, :, L:].zero_()
+        return t
+    qt, dot, kt = padded(Lq, ldq), padded(Lq, ldq), padded(Lk, ldk)
     transpose_bf16_raw(ptr(q), ptr(qt), Lq, d, d, ldq, batch=B, bs_in=Lq * d, bs_out=d * ldq)
     transpose_bf16_raw(ptr(dout), ptr(dot), Lq, d, d, ldq, batch=B, bs_in=Lq * d, bs_out=d * ldq)
     transpose_bf16_raw(ptr(k), ptr(kt), Lk, d, d, ldk, batch=B, bs_in=Lk * d, bs_out=d * ldk)

@@ -90,7 +90,9 @@ def _axpy_rows(dst2d, src2d):
 # ----------------------------------------------------------------------------- attention (training)
 def _vt_from_v(v, B, L, d):
     Lp = _ru(L, 64)
-    vt = torch.zeros(B, d, Lp, dtype=torch.bfloat16, device=v.device)
+    vt = torch.empty(B, d, Lp, dtype=torch.bfloat16, device=v.device)
+    if Lp != L:
+        vt[:, :, L:].zero_()                       # pad columns only; the transpose writes the rest
     ops.transpose_bf16_raw(ptr(v), ptr(vt), L, d, d, Lp, batch=B, bs_in=L * d, bs_out=d * Lp)
     return vt, Lp
 
