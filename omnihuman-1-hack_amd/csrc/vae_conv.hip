@@ -197,6 +197,114 @@ void conv_cl_kernel(const omh_conv_args p, const int tiles_m, const int tiles_n)
 }
 
 
+// Epilogue shared by the wide kernels: + bias (+ residual), bf16 or fp32, optional frame interleave, through a
+// per-wave LDS patch so that global accesses are row-major 16-byte vectors.  Tile-local row t stands for output
+// voxel m_base + t and is stored iff row_lo <= t <= row_hi and 0 <= m < M.
+template <bool OUT_F32, int WM, int WN, int MT, int NT, int STAGE_BYTES_>
+__device__ __forceinline__ void wide_epilogue(const omh_conv_args& p, f32x16 (&acc)[MT][NT], unsigned char* smem,
+                                              const int wave, const int lane, const int wm, const int wn,
+                                              const int m_base, const int n0, const int M, const int row_lo,
+                                              const int row_hi) {
+    constexpr int STAGE_BYTES = STAGE_BYTES_;
+    const int li = lane & 31, lh = lane >> 5;
+    // ---------------- epilogue: + bias (+ residual), bf16 or fp32, optional frame interleave
+    constexpr int PITCH = NT * 32 + 4;                                // floats; 100 mod 32 = 4: conflict-free b128 writes
+    constexpr int VEC = OUT_F32 ? 4 : 8;
+    constexpr int CPR = NT * 32 / VEC;                                // 16-byte chunks per strip row
+    constexpr int PASSES = 32 * CPR / 64;
+    static_assert(8 * 32 * PITCH * 4 <= 2 * STAGE_BYTES, "epilogue patch does not fit the staging LDS");
+    float* ep = (float*)smem + wave * (32 * PITCH);
+    const int HW = p.Hout * p.Wout;
+    const int nsplit = p.split_n > 0 ? p.split_n : p.Cout;            // channels per output frame
+    const int fmul = p.Cout / nsplit;                                 // frames produced per input frame
+    float* Yf = (float*)p.y;
+    uint16_t* Yh = (uint16_t*)p.y;
+    const uint16_t* R = (const uint16_t*)p.resid;
+    const bool vec_all = (nsplit % VEC) == 0;
+#pragma unroll
+    for (int im = 0; im < MT; ++im) {
+        const int trow = (wm * MT + im) * 32;                         // tile-local first row of the strip
+        const int mrow = m_base + trow;
+        if (mrow >= M) break;                                         // wave-uniform
+        // output offsets of this lane's chunks, and the residual fetched up front so that its latency
+        // hides under the LDS transposition
+        int64_t offs[PASSES];
+        uint4 rres[PASSES];
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int q = ps * 64 + lane;
+            const int r = q / CPR, cc = (q - r * CPR) * VEC;
+            const int m = mrow + r, n = n0 + wn * (NT * 32) + cc;
+            if (fmul == 1) {
+                offs[ps] = (int64_t)m * p.Cout + n;
+            } else {
+                const int to = m / HW, pix = m - to * HW;
+                const int jf = n / nsplit, c = n - jf * nsplit;
+                offs[ps] = ((int64_t)(to * fmul + jf) * HW + pix) * nsplit + c;
+            }
+            rres[ps] = make_uint4(0, 0, 0, 0);
+            const bool row_ok = trow + r >= row_lo && trow + r <= row_hi && m >= 0 && m < M;
+            if (!OUT_F32 && R && row_ok && vec_all && n + VEC <= p.Cout) rres[ps] = *(const uint4*)(R + offs[ps]);
+        }
+#pragma unroll
+        for (int in = 0; in < NT; ++in)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                *(float4*)(ep + li * PITCH + in * 32 + 8 * gq + 4 * lh) =
+                    make_float4(acc[im][in][4 * gq], acc[im][in][4 * gq + 1], acc[im][in][4 * gq + 2], acc[im][in][4 * gq + 3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int q = ps * 64 + lane;
+            const int r = q / CPR, cc = (q - r * CPR) * VEC;
+            const int m = mrow + r, n = n0 + wn * (NT * 32) + cc;
+            float v[VEC];
+#pragma unroll
+            for (int h = 0; h < VEC / 4; ++h) {
+                const float4 t = *(const float4*)(ep + r * PITCH + cc + 4 * h);
+                v[4 * h] = t.x; v[4 * h + 1] = t.y; v[4 * h + 2] = t.z; v[4 * h + 3] = t.w;
+            }
+            if (trow + r < row_lo || trow + r > row_hi || m < 0 || m >= M || n >= p.Cout) continue;
+            const bool full = vec_all && n + VEC <= p.Cout;
+            if (p.bias) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) if (n + e < p.Cout) v[e] += p.bias[n + e];
+            }
+            const int64_t off = offs[ps];
+            if (R) {
+                if (full && !OUT_F32) {
+                    const uint32_t rw[4] = {rres[ps].x, rres[ps].y, rres[ps].z, rres[ps].w};
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] += bf2f((uint16_t)((rw[(e >> 1) & 3] >> (16 * (e & 1))) & 0xffff));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) if (n + e < p.Cout) v[e] += bf2f(R[off + e]);
+                }
+            }
+            if (OUT_F32) {
+                if (full) *(float4*)(Yf + off) = make_float4(v[0], v[1], v[2], v[3]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) if (n + e < p.Cout) Yf[off + e] = v[e];
+                }
+            } else {
+                if (full) {
+                    uint4 pk;
+                    pk.x = pack_bf2(v[0], v[1]);
+                    pk.y = pack_bf2(v[2], v[3]);
+                    pk.z = pack_bf2(v[4 % VEC], v[5 % VEC]);
+                    pk.w = pack_bf2(v[6 % VEC], v[7 % VEC]);
+                    *(uint4*)(Yh + off) = pk;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) if (n + e < p.Cout) Yh[off + e] = f2bf(v[e]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Wide configuration: 8 waves, each owning a 64(m) x 96(n) patch (2 x 3 MFMA tiles), so that the tile's N
 // extent is a multiple of 96 — the VAE's channel counts are 96/192/384/768 and a 128-wide tile idles a
@@ -347,100 +455,193 @@ void conv_cl_wide_kernel(const omh_conv_args p, const int tiles_m, const int til
         WCONV_MFMAS(wf1, xf1)
     }
 
-    // ---------------- epilogue: + bias (+ residual), bf16 or fp32, optional frame interleave
-    constexpr int PITCH = NT * 32 + 4;                                // floats; 100 mod 32 = 4: conflict-free b128 writes
-    constexpr int VEC = OUT_F32 ? 4 : 8;
-    constexpr int CPR = NT * 32 / VEC;                                // 16-byte chunks per strip row
-    constexpr int PASSES = 32 * CPR / 64;
-    static_assert(8 * 32 * PITCH * 4 <= 2 * STAGE_BYTES, "epilogue patch does not fit the staging LDS");
-    float* ep = (float*)smem + wave * (32 * PITCH);
-    const int HW = p.Hout * p.Wout;
-    const int nsplit = p.split_n > 0 ? p.split_n : p.Cout;            // channels per output frame
-    const int fmul = p.Cout / nsplit;                                 // frames produced per input frame
-    float* Yf = (float*)p.y;
-    uint16_t* Yh = (uint16_t*)p.y;
-    const uint16_t* R = (const uint16_t*)p.resid;
-    const bool vec_all = (nsplit % VEC) == 0;
+    wide_epilogue<OUT_F32, WM, WN, MT, NT, STAGE_BYTES>(p, acc, smem, wave, lane, wm, wn, m0, n0, M, 0, WBM - 1);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// kw-shared configuration for the layers that carry the VAE's time: 3x3x3 / 1x3x3 "same" convolutions with
+// stride 1, no folded upsample, Cin a multiple of 32 (the residual-block convs at 96 / 192 / 384 channels).
+// Every MFMA kernel of this build sits on the same wall — about 22 B/clk per CU from L2 into LDS (DESIGN.md
+// section 8) — so what decides the rate is bytes per flop, and an implicit GEMM re-fetches every input voxel once per
+// tap: 27 times.  Here a stage is one (kt, kh) tap pair and one block of 32 input channels for ALL THREE kw taps:
+//   A slab  [WBM voxels][32 ch]   consecutive output voxels v0-1 .. v0+WBM-2 in (t, y, x) order, fetched ONCE;
+//   B tile  [WBN couts][3 taps x 32 ch].
+// Tap kw of output row j is slab row j + kw - 1 — the same LDS bytes read with a shifted row index — so the voxel
+// traffic per flop drops 3x (512x96 tile: 83 -> 184 flop per staged byte; 256x192: 112 -> 177).  Rows 0 and WBM-1
+// of a tile lack a neighbour: they are computed and dropped, tiles advance by WBM-2 voxels.  The x neighbours of
+// the first / last voxel of an image row are the previous / next row's end voxels in linear order: their A
+// fragments are zeroed by an unconditional AND with a per-lane word (a wave-uniform branch around it, skipping the
+// 12 of 13 strips without an edge voxel, cut the k-step into small basic blocks, the MFMA / ds_read interleave was
+// lost and the stage time became the SUM of its DMA, LDS and MFMA times: 825 TF instead of the figure below).
+// Out-of-image rows (kh) and frames past the buffer arrive as zeros from the buffer descriptor, as before.
+__device__ __forceinline__ uint32_t a3_addr(int row, int slot) {      // [rows][32 ch]: 64-byte rows, 4 slots
+    return (uint32_t)(row * 64 + ((slot ^ ((row >> 2) & 3)) << 4));
+}
+__device__ __forceinline__ uint32_t b3_addr(int row, int slot) {      // [rows][3 x 32]: 192-byte rows, 12 slots
+    return (uint32_t)(row * 192 + ((slot ^ ((row >> 2) & 3)) << 4));
+}
+
+template <bool OUT_F32, int WM, int WN>
+__global__ __launch_bounds__(512)
+void conv_cl_kw3_kernel(const omh_conv_args p, const int tiles_m, const int tiles_n) {
+    constexpr int MT = 2, NT = 3, THREADS = 512;
+    constexpr int WBM = WM * MT * 32, WBN = WN * NT * 32, VM = WBM - 2;
+    constexpr int A_BYTES = WBM * 64, B_BYTES = WBN * 192, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int CA = WBM * 4 / THREADS;                             // A chunks per thread and stage (4 or 2)
+    constexpr int BCH = WBN * 12;                                     // B chunks per stage (1152 or 2304)
+    constexpr int CB = (BCH + THREADS - 1) / THREADS;                 // rounds of B chunks (3 or 5)
+    static_assert(WM * WN == 8 && BCH % 64 == 0, "8 waves; whole wave instructions");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int wid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int tm, tn;
+    tile_of(wid, tiles_m, tiles_n, tm, tn);
+    const int M = p.Tout * p.Hout * p.Wout;
+    const int vbase = tm * VM - 1;                                    // voxel of slab row 0 / output row 0
+    const int n0 = tn * WBN;
+    const int K = p.KT * 9 * p.Cin;
+    const int HW = p.Hin * p.Win;
+    const int cblocks = p.Cin >> 5;
+
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.x, 0, (int)((int64_t)p.Tin * HW * p.Cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.w, 0, (int)((int64_t)p.Cout * K * 2), 0x00020000);
+
+    // A staging: chunk c = tid + 512 j -> slab row c>>2, physical slot c&3, fetched from logical slot
+    // (c&3) ^ ((row>>2)&3), i.e. channels 8*slot .. +7 of the stage's 32-channel block
+    int a_off[CA], a_y[CA];                                           // element offset of (frame t, row 0, x) + slot; y - pad
 #pragma unroll
-    for (int im = 0; im < MT; ++im) {
-        const int mrow = m0 + (wm * MT + im) * 32;
-        if (mrow >= M) break;                                         // wave-uniform
-        // output offsets of this lane's chunks, and the residual fetched up front so that its latency
-        // hides under the LDS transposition
-        int64_t offs[PASSES];
-        uint4 rres[PASSES];
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
-            const int q = ps * 64 + lane;
-            const int r = q / CPR, cc = (q - r * CPR) * VEC;
-            const int m = mrow + r, n = n0 + wn * (NT * 32) + cc;
-            if (fmul == 1) {
-                offs[ps] = (int64_t)m * p.Cout + n;
-            } else {
-                const int to = m / HW, pix = m - to * HW;
-                const int jf = n / nsplit, c = n - jf * nsplit;
-                offs[ps] = ((int64_t)(to * fmul + jf) * HW + pix) * nsplit + c;
-            }
-            rres[ps] = make_uint4(0, 0, 0, 0);
-            if (!OUT_F32 && R && m < M && vec_all && n + VEC <= p.Cout) rres[ps] = *(const uint4*)(R + offs[ps]);
-        }
-#pragma unroll
-        for (int in = 0; in < NT; ++in)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
-                *(float4*)(ep + li * PITCH + in * 32 + 8 * gq + 4 * lh) =
-                    make_float4(acc[im][in][4 * gq], acc[im][in][4 * gq + 1], acc[im][in][4 * gq + 2], acc[im][in][4 * gq + 3]);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
-            const int q = ps * 64 + lane;
-            const int r = q / CPR, cc = (q - r * CPR) * VEC;
-            const int m = mrow + r, n = n0 + wn * (NT * 32) + cc;
-            float v[VEC];
-#pragma unroll
-            for (int h = 0; h < VEC / 4; ++h) {
-                const float4 t = *(const float4*)(ep + r * PITCH + cc + 4 * h);
-                v[4 * h] = t.x; v[4 * h + 1] = t.y; v[4 * h + 2] = t.z; v[4 * h + 3] = t.w;
-            }
-            if (m >= M || n >= p.Cout) continue;
-            const bool full = vec_all && n + VEC <= p.Cout;
-            if (p.bias) {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) if (n + e < p.Cout) v[e] += p.bias[n + e];
-            }
-            const int64_t off = offs[ps];
-            if (R) {
-                if (full && !OUT_F32) {
-                    const uint32_t rw[4] = {rres[ps].x, rres[ps].y, rres[ps].z, rres[ps].w};
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) v[e] += bf2f((uint16_t)((rw[(e >> 1) & 3] >> (16 * (e & 1))) & 0xffff));
-                } else {
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) if (n + e < p.Cout) v[e] += bf2f(R[off + e]);
-                }
-            }
-            if (OUT_F32) {
-                if (full) *(float4*)(Yf + off) = make_float4(v[0], v[1], v[2], v[3]);
-                else {
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) if (n + e < p.Cout) Yf[off + e] = v[e];
-                }
-            } else {
-                if (full) {
-                    uint4 pk;
-                    pk.x = pack_bf2(v[0], v[1]);
-                    pk.y = pack_bf2(v[2], v[3]);
-                    pk.z = pack_bf2(v[4 % VEC], v[5 % VEC]);
-                    pk.w = pack_bf2(v[6 % VEC], v[7 % VEC]);
-                    *(uint4*)(Yh + off) = pk;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) if (n + e < p.Cout) Yh[off + e] = f2bf(v[e]);
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int j = 0; j < CA; ++j) {
+        const int c = tid + THREADS * j;
+        const int row = c >> 2;
+        const int ls = (c & 3) ^ ((row >> 2) & 3);
+        const int v = vbase + row;
+        const bool ok = v >= 0 && v < M;
+        const int vc = min(max(v, 0), M - 1);
+        const int xo = vc % p.Wout, yo = (vc / p.Wout) % p.Hout, to = vc / (p.Wout * p.Hout);
+        a_off[j] = (to * HW + xo) * p.Cin + ls * 8;
+        a_y[j] = ok ? yo - p.pad_h : -16384;                          // rows outside the volume never pass the bounds test
     }
+    // B staging: chunk c -> cout row c/12, physical slot c%12; logical slot = tap kw (slot>>2) and 8-channel group
+    static_assert(CB <= 5, "weight chunk rounds");
+    uint32_t w_off[5];                                                // (fixed extent: a dependent one loses the host-side kernel stub)
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+        const int c = tid + THREADS * j;
+        const int row = c / 12, ps = c - row * 12;
+        const int ls = ps ^ ((row >> 2) & 3);
+        const int kw = ls >> 2, c8 = ls & 3;
+        w_off[j] = (c < BCH && n0 + row < p.Cout) ? (uint32_t)((((int64_t)(n0 + row)) * K + kw * p.Cin + c8 * 8) * 2)
+                                                   : 0x80000000u;
+    }
+    const int wave_lds = __builtin_amdgcn_readfirstlane(wave) * 1024;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    // fragment addresses: output row r of strip i reads slab rows r-1, r, r+1 (clamped: rows 0 / WBM-1 are dropped)
+    uint32_t xaddr[MT][3][2];
+    uint32_t edge0[MT], edge2[MT];                                    // AND words: 0 where the x neighbour is outside the image
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int r = (wm * MT + i) * 32 + li;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int row = min(max(r + kw - 1, 0), WBM - 1);
+            xaddr[i][kw][0] = a3_addr(row, lh);
+            xaddr[i][kw][1] = a3_addr(row, 2 + lh);
+        }
+        const int v = vbase + r;
+        const int xo = (v >= 0 && v < M) ? v % p.Wout : 1;
+        edge0[i] = (xo == 0) ? 0u : 0xffffffffu;
+        edge2[i] = (xo == p.Wout - 1) ? 0u : 0xffffffffu;
+    }
+    uint32_t waddr[NT], wsw[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int row = (wn * NT + i) * 32 + li;
+        waddr[i] = (uint32_t)(row * 192);
+        wsw[i] = (uint32_t)((row >> 2) & 3);
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int ns = p.KT * 3 * cblocks;                                // stages: (kt, kh, channel block)
+    int s_cb = 0, s_kh = 0, s_kt = 0;                                 // position of the NEXT stage to be staged
+#define K3_DMA(BUF)                                                                                \
+    {                                                                                              \
+        unsigned char* xa_ = smem + (BUF) * STAGE_BYTES;                                           \
+        unsigned char* xb_ = xa_ + A_BYTES;                                                        \
+        const int aoff_ = s_kt * HW * p.Cin + s_cb * 32;                                           \
+        _Pragma("unroll") for (int j_ = 0; j_ < CA; ++j_) {                                        \
+            const int iy = a_y[j_] + s_kh;                                                         \
+            const uint32_t xo_ = (iy >= 0 && iy < p.Hin) ? (uint32_t)((a_off[j_] + aoff_ + iy * p.Win * p.Cin) * 2) \
+                                                         : 0x80000000u;                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(xa_ + wave_lds + j_ * 8192), 16, xo_, 0, 0, 0); \
+        }                                                                                          \
+        const uint32_t wk_ = (uint32_t)((((s_kt * 3 + s_kh) * 3) * p.Cin + s_cb * 32) * 2);        \
+        _Pragma("unroll") for (int j_ = 0; j_ < CB; ++j_)                                          \
+            if (wave * 64 + THREADS * j_ < BCH)                                                    \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(xb_ + wave_lds + j_ * 8192), 16, \
+                                                         w_off[j_] + wk_, 0, 0, 0);                \
+        if (++s_cb == cblocks) { s_cb = 0; if (++s_kh == 3) { s_kh = 0; ++s_kt; } }                \
+    }
+    // group G of a stage: tap kw = G>>1, 16-channel half G&1
+#define K3_FRAGS(WF, XF, STAGE, G)                                                                 \
+    {                                                                                              \
+        const unsigned char* xa_ = smem + (STAGE) * STAGE_BYTES;                                   \
+        const unsigned char* xb_ = xa_ + A_BYTES;                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < NT; ++i_)                                          \
+            WF[i_] = *(const bf16x8*)(xb_ + waddr[i_] + ((((uint32_t)(2 * (G)) + lh) ^ wsw[i_]) << 4)); \
+        _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_) {                                        \
+            u32x4 t_ = *(const u32x4*)(xa_ + xaddr[i_][(G) >> 1][(G) & 1]);                        \
+            if (((G) >> 1) != 1) {                         /* compile-time: the dx = -1 / +1 taps */ \
+                const uint32_t m_ = ((G) >> 1) == 0 ? edge0[i_] : edge2[i_];                       \
+                t_[0] &= m_; t_[1] &= m_; t_[2] &= m_; t_[3] &= m_;                                \
+            }                                                                                      \
+            XF[i_] = __builtin_bit_cast(bf16x8, t_);                                               \
+        }                                                                                          \
+    }
+
+    K3_DMA(0)
+    if (ns > 1) K3_DMA(1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    bf16x8 wf0[NT], xf0[MT], wf1[NT], xf1[MT];
+    K3_FRAGS(wf0, xf0, 0, 0)
+    for (int st = 0; st < ns; ++st) {
+        const int buf = st & 1;
+        K3_FRAGS(wf1, xf1, buf, 1)
+        WCONV_MFMAS(wf0, xf0)
+        WCONV_INTERLEAVE()
+        K3_FRAGS(wf0, xf0, buf, 2)
+        WCONV_MFMAS(wf1, xf1)
+        WCONV_INTERLEAVE()
+        K3_FRAGS(wf1, xf1, buf, 3)
+        WCONV_MFMAS(wf0, xf0)
+        WCONV_INTERLEAVE()
+        K3_FRAGS(wf0, xf0, buf, 4)
+        WCONV_MFMAS(wf1, xf1)
+        WCONV_INTERLEAVE()
+        K3_FRAGS(wf1, xf1, buf, 5)
+        WCONV_MFMAS(wf0, xf0)
+        WCONV_INTERLEAVE()
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (st + 2 < ns) K3_DMA(buf)
+        if (st + 1 < ns) K3_FRAGS(wf0, xf0, buf ^ 1, 0)
+        WCONV_MFMAS(wf1, xf1)
+    }
+    wide_epilogue<OUT_F32, WM, WN, MT, NT, STAGE_BYTES>(p, acc, smem, wave, lane, wm, wn, vbase, n0, M, 1, WBM - 2);
 }
 
 template <bool OUT_F32, int WM, int WN>
@@ -454,6 +655,22 @@ int launch_wide(const omh_conv_args& a, int64_t M, hipStream_t s) {
         attr_set = true;
     }
     const int tiles_m = (int)((M + WBM - 1) / WBM), tiles_n = (a.Cout + WBN - 1) / WBN;
+    omh_clear_status();
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), LDS, s, a, tiles_m, tiles_n);
+    return omh_launch_status();
+}
+
+template <bool OUT_F32, int WM, int WN>
+int launch_kw3(const omh_conv_args& a, int64_t M, hipStream_t s) {
+    constexpr int WBM = WM * 64, WBN = WN * 96;
+    constexpr int LDS = 2 * (WBM * 64 + WBN * 192);
+    auto kern = conv_cl_kw3_kernel<OUT_F32, WM, WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    const int tiles_m = (int)((M + WBM - 3) / (WBM - 2)), tiles_n = (a.Cout + WBN - 1) / WBN;
     omh_clear_status();
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), LDS, s, a, tiles_m, tiles_n);
     return omh_launch_status();
@@ -486,6 +703,15 @@ extern "C" int omh_conv_cl_bf16(const omh_conv_args* args, omh_stream_t stream) 
     if (((uintptr_t)a.resid & 15) || ((uintptr_t)a.bias & 3)) wide = false;
     if (wide) {
         hipStream_t s = (hipStream_t)stream;
+        // 3x3 "same" convolutions with stride 1 at >= 32 channels: the kw-shared kernel (3x less voxel traffic)
+        const char* kw3e = getenv("OMH_CONV_KW3");                     // "0": off (tests / A/B timing)
+        const bool kw3 = !(kw3e && kw3e[0] == '0') && a.KW == 3 && a.KH == 3 && (a.KT == 3 || a.KT == 1) &&
+                         a.stride_hw == 1 && a.stride_t == 1 && !a.up2 && a.pad_h == 1 && a.pad_w == 1 &&
+                         a.Hout == a.Hin && a.Wout == a.Win && (a.Cin & 31) == 0 && a.split_n == 0 && a.Wout >= 3;
+        if (kw3) {
+            if (narrow) return a.out_f32 ? launch_kw3<true, 8, 1>(a, M, s) : launch_kw3<false, 8, 1>(a, M, s);
+            return a.out_f32 ? launch_kw3<true, 4, 2>(a, M, s) : launch_kw3<false, 4, 2>(a, M, s);
+        }
         if (narrow) return a.out_f32 ? launch_wide<true, 8, 1>(a, M, s) : launch_wide<false, 8, 1>(a, M, s);
         return a.out_f32 ? launch_wide<true, 4, 2>(a, M, s) : launch_wide<false, 4, 2>(a, M, s);
     }

@@ -29,10 +29,16 @@ def _bf(x):
     dict(Cin=192, Cout=192, T=1, H=20, W=31, KT=3, KH=3, KW=3),   # one full 192-column tile
     dict(Cin=64, Cout=384, T=2, H=11, W=13, KT=3, KH=3, KW=3),    # two 192-column tiles
     dict(Cin=48, Cout=200, T=1, H=17, W=17, KT=1, KH=3, KW=3),    # ragged second column tile
+    dict(Cin=32, Cout=96, T=3, H=17, W=20, KT=1, KH=3, KW=3),     # 1020 voxels = exactly two 510-voxel kw-shared tiles
+    dict(Cin=32, Cout=64, T=1, H=1, W=3, KT=3, KH=3, KW=3),       # one image row of three voxels: every voxel is an edge
+    dict(Cin=384, Cout=384, T=1, H=9, W=29, KT=3, KH=3, KW=3),    # 12 channel blocks per tap pair, 254-voxel tiles
 ])
-@pytest.mark.parametrize("tile", ["small", "wide"])
+@pytest.mark.parametrize("tile", ["small", "wide", "wide-nokw3"])
 def test_conv_cl_matches_torch(ops, cfg, tile, monkeypatch):
-    monkeypatch.setenv("OMH_CONV_TILE", tile)            # both tile configurations on every shape
+    # every tile configuration on every shape: 128x128; wide tiles with the kw-shared kernel where it applies
+    # (3x3 taps, stride 1, Cin % 32 == 0); wide tiles without it
+    monkeypatch.setenv("OMH_CONV_TILE", tile.split("-")[0])
+    monkeypatch.setenv("OMH_CONV_KW3", "0" if tile.endswith("nokw3") else "1")
     torch.manual_seed(cfg["Cin"] + cfg["Cout"])
     Cin, Cout, T, H, W, KT, KH, KW = (cfg[k] for k in ("Cin", "Cout", "T", "H", "W", "KT", "KH", "KW"))
     hist = KT - 1
