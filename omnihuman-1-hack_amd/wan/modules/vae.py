@@ -27,6 +27,8 @@ tolerance is stated in tests/test_gpu_vae.py and DESIGN.md.
 import logging
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -206,22 +208,50 @@ class _ConvState:
         self.hist = self.KT - 1 if self.stride_t == 1 else 1      # history frames kept in front of the chunk
         self.buf = None
         self.T = 0
+        self.off = 0                                               # frame index of the history inside ``buf``
+
+    # The input buffer is a WINDOW several chunks long that the [history | chunk] region slides through: after a
+    # convolution the last ``hist`` frames of the region already ARE the next chunk's history, so the region just
+    # moves up by T frames; only when it reaches the end of the buffer are the history frames copied back to the
+    # front.  (The first version kept a buffer of exactly hist + T frames and copied the history down after every
+    # convolution: 2 frames x 35 layers x 21 chunks — 6.6 % of the VAE's GPU time in `__amd_rocclr_copyBuffer`,
+    # profiles/r01_v7_kernel_stats_full_bench.csv.)  Window size: 8 chunks, capped at OMH_VAE_WINDOW_MB (default
+    # 1024) per layer — 288 GB of HBM make that an easy trade.
+    _WINDOW_BYTES = int(os.environ.get("OMH_VAE_WINDOW_MB", "1024")) << 20
 
     def slot(self, T, H, W, device):
         """View [T, H, W, Cin] the producer writes the current chunk into."""
         need = self.hist + T
-        if self.buf is None or self.buf.shape[0] < need or tuple(self.buf.shape[1:3]) != (H, W):
-            old = self.buf
-            self.buf = torch.zeros(need, H, W, self.Cin, dtype=torch.bfloat16, device=device)
-            if old is not None and self.hist and tuple(old.shape[1:3]) == (H, W):
-                self.buf[:self.hist].copy_(old[:self.hist])
+        fresh = self.buf is None or tuple(self.buf.shape[1:3]) != (H, W)
+        if fresh or self.buf.shape[0] < need:
+            old, old_off = (None, 0) if fresh else (self.buf, self.off)
+            frame_bytes = H * W * self.Cin * 2
+            cap = need if not self.hist else max(need, min(self.hist + 8 * max(T, 4), self._WINDOW_BYTES // frame_bytes))
+            self.buf = torch.empty(cap, H, W, self.Cin, dtype=torch.bfloat16, device=device)
+            self.off = 0
+            if self.hist:
+                if old is not None:
+                    self.buf[:self.hist].copy_(old[old_off:old_off + self.hist])
+                else:
+                    self.buf[:self.hist].zero_()                   # the causal zero padding in front of the clip
+        elif self.off + need > self.buf.shape[0]:                  # end of the window: history back to the front
+            if self.off >= self.hist:
+                self.buf[:self.hist].copy_(self.buf[self.off:self.off + self.hist])
+            else:                                                  # overlapping ranges: frame by frame, ascending
+                for i in range(self.hist):
+                    self.buf[i].copy_(self.buf[self.off + i])
+            self.off = 0
         self.T = T
-        return self.buf[self.hist:self.hist + T]
+        return self.buf[self.off + self.hist:self.off + self.hist + T]
+
+    def set_history(self, frame):
+        """Overwrite the (single) history frame — the encoder's first-chunk bypass of a strided time conv."""
+        self.buf[self.off].copy_(frame)
 
     def run(self, resid=None, out_f32=False, split_n=0, out=None):
-        """Convolve over [history | chunk]; then keep the last frames as the new history."""
+        """Convolve over [history | chunk]; the last ``hist`` frames of that region become the new history."""
         T, (_, H, W, _) = self.T, self.buf.shape
-        x = self.buf[:self.hist + T]
+        x = self.buf[self.off:self.off + self.hist + T]
         if self.stride_t == 1:
             Tout = T
         else:
@@ -234,14 +264,8 @@ class _ConvState:
         y = ops.conv_cl(x, self.w, self.bias, Tout, Hout, Wout, self.Cout, self.KT, self.KH, self.KW,
                         stride_t=self.stride_t, stride_hw=self.stride_hw, pad_h=self.pad[0], pad_w=self.pad[1],
                         up2=self.up2, resid=resid, out_f32=out_f32, split_n=split_n, out=out)
-        # history <- last `hist` frames of [history | chunk]
-        h = self.hist
-        if h:
-            if T >= h:                                      # source and destination frames are disjoint
-                self.buf[:h].copy_(self.buf[T:T + h])
-            else:                                           # T == 1, hist == 2
-                self.buf[0].copy_(self.buf[1])
-                self.buf[1].copy_(self.buf[2])
+        if self.hist:
+            self.off += T                                   # the region slides: no copy
         return y
 
 
@@ -339,7 +363,7 @@ def _resample(st, key, rs: Resample, x):
             if key not in st.seen:
                 st.seen.add(key)                    # first chunk passes through, remembered as history (vae.py:146-148)
                 tc.slot(x.shape[0], x.shape[1], x.shape[2], x.device)
-                tc.buf[0].copy_(x[-1])
+                tc.set_history(x[-1])
             else:
                 tc.slot(x.shape[0], x.shape[1], x.shape[2], x.device).copy_(x)
                 x = tc.run()
