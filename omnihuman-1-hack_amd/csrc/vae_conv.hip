@@ -423,7 +423,7 @@ void conv_cl_wide_kernel(const omh_conv_args p, const int tiles_m, const int til
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
     }                                                                                              \
-    __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - (MT + NT), 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - (MT + NT) > 0 ? MT * NT - (MT + NT) : 0, 0);
 
     WCONV_DMA(0, 0)
     if (nk > 1) {
@@ -481,10 +481,10 @@ __device__ __forceinline__ uint32_t b3_addr(int row, int slot) {      // [rows][
     return (uint32_t)(row * 192 + ((slot ^ ((row >> 2) & 3)) << 4));
 }
 
-template <bool OUT_F32, int WM, int WN>
+template <bool OUT_F32, int WM, int WN, int NT_>
 __global__ __launch_bounds__(512)
 void conv_cl_kw3_kernel(const omh_conv_args p, const int tiles_m, const int tiles_n) {
-    constexpr int MT = 2, NT = 3, THREADS = 512;
+    constexpr int MT = 2, NT = NT_, THREADS = 512;                    // NT = 1: Cout <= 32 (the 3-channel head conv)
     constexpr int WBM = WM * MT * 32, WBN = WN * NT * 32, VM = WBM - 2;
     constexpr int A_BYTES = WBM * 64, B_BYTES = WBN * 192, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int CA = WBM * 4 / THREADS;                             // A chunks per thread and stage (4 or 2)
@@ -660,11 +660,11 @@ int launch_wide(const omh_conv_args& a, int64_t M, hipStream_t s) {
     return omh_launch_status();
 }
 
-template <bool OUT_F32, int WM, int WN>
+template <bool OUT_F32, int WM, int WN, int NT = 3>
 int launch_kw3(const omh_conv_args& a, int64_t M, hipStream_t s) {
-    constexpr int WBM = WM * 64, WBN = WN * 96;
+    constexpr int WBM = WM * 64, WBN = WN * NT * 32;
     constexpr int LDS = 2 * (WBM * 64 + WBN * 192);
-    auto kern = conv_cl_kw3_kernel<OUT_F32, WM, WN>;
+    auto kern = conv_cl_kw3_kernel<OUT_F32, WM, WN, NT>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -709,6 +709,7 @@ extern "C" int omh_conv_cl_bf16(const omh_conv_args* args, omh_stream_t stream) 
                          a.stride_hw == 1 && a.stride_t == 1 && !a.up2 && a.pad_h == 1 && a.pad_w == 1 &&
                          a.Hout == a.Hin && a.Wout == a.Win && (a.Cin & 31) == 0 && a.split_n == 0 && a.Wout >= 3;
         if (kw3) {
+            if (a.Cout <= 32) return a.out_f32 ? launch_kw3<true, 8, 1, 1>(a, M, s) : launch_kw3<false, 8, 1, 1>(a, M, s);
             if (narrow) return a.out_f32 ? launch_kw3<true, 8, 1>(a, M, s) : launch_kw3<false, 8, 1>(a, M, s);
             return a.out_f32 ? launch_kw3<true, 4, 2>(a, M, s) : launch_kw3<false, 4, 2>(a, M, s);
         }

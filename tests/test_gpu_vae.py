@@ -32,6 +32,8 @@ def _bf(x):
     dict(Cin=32, Cout=96, T=3, H=17, W=20, KT=1, KH=3, KW=3),     # 1020 voxels = exactly two 510-voxel kw-shared tiles
     dict(Cin=32, Cout=64, T=1, H=1, W=3, KT=3, KH=3, KW=3),       # one image row of three voxels: every voxel is an edge
     dict(Cin=384, Cout=384, T=1, H=9, W=29, KT=3, KH=3, KW=3),    # 12 channel blocks per tap pair, 254-voxel tiles
+    dict(Cin=96, Cout=3, T=2, H=14, W=19, KT=3, KH=3, KW=3),      # the decoder head: kw-shared kernel with a 32-column tile
+    dict(Cin=32, Cout=32, T=1, H=8, W=70, KT=1, KH=3, KW=3),
 ])
 @pytest.mark.parametrize("tile", ["small", "wide", "wide-nokw3"])
 def test_conv_cl_matches_torch(ops, cfg, tile, monkeypatch):
