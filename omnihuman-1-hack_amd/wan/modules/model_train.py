@@ -65,8 +65,28 @@ def _wgrad(dy, x, xT=None):
     return out
 
 
-def _bgrad(dy):
-    out = torch.zeros(dy.shape[1], dtype=torch.float32, device=dy.device)
+class _ZeroArena:
+    """One zero-filled fp32 buffer per block backward, carved into the ~20 small accumulators (bias, norm-gain and
+    modulation gradients) that the atomics-based kernels add into: one fill launch instead of twenty."""
+
+    def __init__(self, n, device):
+        self.buf = torch.zeros(n, dtype=torch.float32, device=device)
+        self.pos = 0
+
+    def take(self, *shape):
+        n = 1
+        for s_ in shape:
+            n *= s_
+        n_al = (n + 63) // 64 * 64                              # keep every slice 256-byte aligned
+        if self.pos + n_al > self.buf.numel():                  # undersized estimate: fall back to a fresh buffer
+            return torch.zeros(*shape, dtype=torch.float32, device=self.buf.device)
+        out = self.buf[self.pos:self.pos + n].view(*shape)
+        self.pos += n_al
+        return out
+
+
+def _bgrad(dy, arena=None):
+    out = arena.take(dy.shape[1]) if arena is not None else torch.zeros(dy.shape[1], dtype=torch.float32, device=dy.device)
     return ops.colsum_accum(dy, out)
 
 
@@ -207,7 +227,8 @@ def _block_backward(model, blk, idx, st, x0, dx):
     frozen_ffn = getattr(model, "reference_ffn_freeze", True) and idx > 10
     seq_lens, ctx_lens = fc.seq_lens_host, fc.ctx_lens_host
     Lc = fc.Lc
-    d_eb = torch.zeros(B, 6, d, dtype=torch.float32, device=dev)     # grads of e = modulation + e0
+    arena = _ZeroArena(B * six + 2 * six + 16 * d + 2 * blk.ffn[0].out_features + 4096, dev)
+    d_eb = arena.take(B, 6, d)                                        # grads of e = modulation + e0
     g = {}
 
     def ln_fwd(xin, shift_i, scale_i):
@@ -293,49 +314,48 @@ def _block_backward(model, blk, idx, st, x0, dx):
     # ---- FFN branch: x3 = x2 + y3 * g5
     dy3 = resid_bwd(y3, 5)
     if not frozen_ffn:
-        g["ffn.2.weight"], g["ffn.2.bias"] = _wgrad(dy3, u), _bgrad(dy3)
+        g["ffn.2.weight"], g["ffn.2.bias"] = _wgrad(dy3, u), _bgrad(dy3, arena)
         du = ops.gemm(dy3, _wT(blk, "ffn2", w2), epilogue=EPI_BF16)       # [R, ffn]
         du_pre = ops.gelu_tanh_bwd(du, u_pre)
-        g["ffn.0.weight"], g["ffn.0.bias"] = _wgrad(du_pre, h2), _bgrad(du_pre)
+        g["ffn.0.weight"], g["ffn.0.bias"] = _wgrad(du_pre, h2), _bgrad(du_pre, arena)
         dh2 = _dgrad(du_pre, _wT(blk, "ffn0", w1))
         ln_bwd(x2, dh2, 3, 4)
         del du, du_pre, dh2
     del dy3, u, u_pre, y3, h2
     # ---- cross-attention branch: x2 = x1 + y2
     dy2 = resid_bwd(None, None)
-    g["cross_attn.o.weight"], g["cross_attn.o.bias"] = _wgrad(dy2, oc), _bgrad(dy2)
+    g["cross_attn.o.weight"], g["cross_attn.o.bias"] = _wgrad(dy2, oc), _bgrad(dy2, arena)
     doc = ops.gemm(dy2, _wT(ca, "o", woc), epilogue=EPI_BF16)
     if _FUSED_ATTN_BWD:
         dqc, dkc, dvc = ops.flash_attn_bwd(qc, kc, vc, oc, doc, lse_ca, fc.ctx_lens32, B, N, S, Lc, D ** -0.5)
     else:
         dqc, dkc, dvc = _attn_bwd(qc, kc, vc, doc, ctx_lens, B, S, Lc, N, D)
     dqc_pre = torch.empty(R, d, dtype=torch.bfloat16, device=dev)
-    dnq = torch.zeros(d, dtype=torch.float32, device=dev) if ca.qk_norm else None
+    dnq = arena.take(d) if ca.qk_norm else None
     ops.rmsnorm_rope_bwd_raw(ptr(qc_pre), d, ptr(dqc), d, ptr(dqc_pre), d, ptr(dnq) if dnq is not None else None, R, d,
                              ptr(ca._norm_w("norm_q")) if ca.qk_norm else None, ca.eps, int(ca.qk_norm), None, None,
                              0, D, None, 0)
     if dnq is not None:
         g["cross_attn.norm_q.weight"] = dnq
-    g["cross_attn.q.weight"], g["cross_attn.q.bias"] = _wgrad(dqc_pre, h3), _bgrad(dqc_pre)
+    g["cross_attn.q.weight"], g["cross_attn.q.bias"] = _wgrad(dqc_pre, h3), _bgrad(dqc_pre, arena)
     dh3 = _dgrad(dqc_pre, _wT(ca, "q", wqc))
     Rc = B * Lc
     dkc_pre = torch.empty(Rc, d, dtype=torch.bfloat16, device=dev)
-    dnk = torch.zeros(d, dtype=torch.float32, device=dev) if ca.qk_norm else None
+    dnk = arena.take(d) if ca.qk_norm else None
     ops.rmsnorm_rope_bwd_raw(ptr(kc_pre), d, ptr(dkc), d, ptr(dkc_pre), d, ptr(dnk) if dnk is not None else None, Rc, d,
                              ptr(ca._norm_w("norm_k")) if ca.qk_norm else None, ca.eps, int(ca.qk_norm), None, None,
                              0, D, None, 0)
     if dnk is not None:
         g["cross_attn.norm_k.weight"] = dnk
     ctx2T = ops.transpose_bf16(ctx2)
-    g["cross_attn.k.weight"], g["cross_attn.k.bias"] = _wgrad(dkc_pre, ctx2, ctx2T), _bgrad(dkc_pre)
+    g["cross_attn.k.weight"], g["cross_attn.k.bias"] = _wgrad(dkc_pre, ctx2, ctx2T), _bgrad(dkc_pre, arena)
     dvc_b = ops.cast_bf16(dvc)
-    g["cross_attn.v.weight"], g["cross_attn.v.bias"] = _wgrad(dvc_b, ctx2, ctx2T), _bgrad(dvc_b)
+    g["cross_attn.v.weight"], g["cross_attn.v.bias"] = _wgrad(dvc_b, ctx2, ctx2T), _bgrad(dvc_b, arena)
     dctx = st.d_ctx.view(Rc, d)
     _dgrad(dkc_pre, _wT(ca, "k", wkc), out=dctx, accumulate=True)
     _dgrad(dvc_b, _wT(ca, "v", wvc), out=dctx, accumulate=True)
     if blk.cross_attn_norm:
-        dw3 = torch.zeros(d, dtype=torch.float32, device=dev)
-        db3 = torch.zeros(d, dtype=torch.float32, device=dev)
+        dw3, db3 = arena.take(d), arena.take(d)
         ops.layernorm_modulate_bwd_raw(ptr(x1), ptr(dh3), ptr(dx), R, d, blk.norm3.eps, 0.0, ptr(w3), None, 0,
                                        ptr(dw3), ptr(db3), 0, R)
         g["norm3.weight"], g["norm3.bias"] = dw3, db3
@@ -344,7 +364,7 @@ def _block_backward(model, blk, idx, st, x0, dx):
     del dy2, doc, dqc, dkc, dvc, dqc_pre, dkc_pre, dvc_b, dh3, qc, kc, vc, oc, qc_pre, kc_pre, y2, h3
     # ---- self-attention branch: x1 = x0 + y1 * g2
     dy1 = resid_bwd(y1, 2)
-    g["self_attn.o.weight"], g["self_attn.o.bias"] = _wgrad(dy1, o), _bgrad(dy1)
+    g["self_attn.o.weight"], g["self_attn.o.bias"] = _wgrad(dy1, o), _bgrad(dy1, arena)
     do = ops.gemm(dy1, _wT(sa, "o", wo), epilogue=EPI_BF16)
     if _FUSED_ATTN_BWD:
         dq, dk, dv = ops.flash_attn_bwd(q, k, v, o, do, lse_sa, fc.seq_lens32, B, N, S, S, D ** -0.5)
@@ -352,7 +372,7 @@ def _block_backward(model, blk, idx, st, x0, dx):
         dq, dk, dv = _attn_bwd(q, k, v, do, seq_lens, B, S, S, N, D)
     dqk_pre = torch.empty(R, 2 * d, dtype=torch.bfloat16, device=dev)
     for off, dyy, w, nm in ((0, dq, nq, "norm_q"), (d, dk, nk, "norm_k")):
-        dnw = torch.zeros(d, dtype=torch.float32, device=dev) if sa.qk_norm else None
+        dnw = arena.take(d) if sa.qk_norm else None
         ops.rmsnorm_rope_bwd_raw(ptr(qk_pre, off), 2 * d, ptr(dyy), d, ptr(dqk_pre, off), 2 * d,
                                  ptr(dnw) if dnw is not None else None, R, d, ptr(w) if w is not None else None,
                                  sa.eps, int(sa.qk_norm), ptr(fc.rope_cos), ptr(fc.rope_sin), fc.rope_cos.shape[0],
@@ -360,16 +380,16 @@ def _block_backward(model, blk, idx, st, x0, dx):
         if dnw is not None:
             g[f"self_attn.{nm}.weight"] = dnw
     h1T = ops.transpose_bf16(h1)
-    dwqk, dbqk = _wgrad(dqk_pre, h1, h1T), _bgrad(dqk_pre)
+    dwqk, dbqk = _wgrad(dqk_pre, h1, h1T), _bgrad(dqk_pre, arena)
     g["self_attn.q.weight"], g["self_attn.k.weight"] = dwqk[:d], dwqk[d:]
     g["self_attn.q.bias"], g["self_attn.k.bias"] = dbqk[:d], dbqk[d:]
     dv_b = ops.cast_bf16(dv)
-    g["self_attn.v.weight"], g["self_attn.v.bias"] = _wgrad(dv_b, h1, h1T), _bgrad(dv_b)
+    g["self_attn.v.weight"], g["self_attn.v.bias"] = _wgrad(dv_b, h1, h1T), _bgrad(dv_b, arena)
     dh1 = _dgrad(dqk_pre, _wT(sa, "qk", wqk))
     _dgrad(dv_b, _wT(sa, "v", wv), out=dh1, accumulate=True)
     ln_bwd(x0, dh1, 0, 1)
     # ---- modulation / e0
-    dmod = torch.zeros(six, dtype=torch.float32, device=dev)
+    dmod = arena.take(six)
     ops.colsum_accum(d_eb.view(B, six), dmod)
     g["modulation"] = dmod
     _axpy_rows(st.d_e0.view(B, six), d_eb.view(B, six))
