@@ -98,7 +98,7 @@ class WanI2V:
     def generate(self, input_prompt, img, max_area=720 * 1280, frame_num=81, shift=5.0, sample_solver="unipc",
                  sampling_steps=40, guide_scale=5.0, n_prompt="", seed=-1, offload_model=True,
                  context: Optional[List[torch.Tensor]] = None, context_null: Optional[List[torch.Tensor]] = None,
-                 clip_fea: Optional[torch.Tensor] = None, return_latent: bool = False):
+                 clip_fea: Optional[torch.Tensor] = None, return_latent: bool = False, batched_cfg: bool = True):
         r"""image2video.py:129-347.  ``img``: PIL image or float tensor [3, H, W] in [0, 1].  Returns the video
         ``[3, N, H, W]`` on rank 0 (else None).  (The reference hard-codes 21 latent / 81 pixel frames in the
         noise and mask shapes, :196-203; here they follow ``frame_num`` and coincide at the default 81.)"""
@@ -158,12 +158,23 @@ class WanI2V:
             sample_scheduler.set_begin_index(0)
             latent = noise
             # text/image embedding and per-block cross-attention K/V (text and image tokens): once per sample
-            arg_c = self.model.encode_context([context[0]], clip_fea=clip_context)
-            arg_null = self.model.encode_context(context_null, clip_fea=clip_context)
+            # cond / uncond as one forward on a batch of two where the operands stay below the kernels' 2 GiB limit
+            # (see WanT2V.generate); bit-identical to two calls
+            batched = batched_cfg and 2 * (max_seq_len + 128) * getattr(self.model, "ffn_dim", 0) * 2 < 0x7fffffff
+            if batched:
+                both = self.model.encode_context([context[0], context_null[0]],
+                                                 clip_fea=torch.cat([clip_context, clip_context]))
+            else:
+                arg_c = self.model.encode_context([context[0]], clip_fea=clip_context)
+                arg_null = self.model.encode_context(context_null, clip_fea=clip_context)
             for t in timesteps:
-                timestep = torch.stack([t]).to(self.device)
-                cond = self.model([latent], t=timestep, context=arg_c, seq_len=max_seq_len, y=[y])[0]
-                uncond = self.model([latent], t=timestep, context=arg_null, seq_len=max_seq_len, y=[y])[0]
+                if batched:
+                    cond, uncond = self.model([latent, latent], t=torch.stack([t, t]).to(self.device), context=both,
+                                              seq_len=max_seq_len, y=[y, y])
+                else:
+                    timestep = torch.stack([t]).to(self.device)
+                    cond = self.model([latent], t=timestep, context=arg_c, seq_len=max_seq_len, y=[y])[0]
+                    uncond = self.model([latent], t=timestep, context=arg_null, seq_len=max_seq_len, y=[y])[0]
                 latent = sample_scheduler.step_cfg(cond, uncond, guide_scale, latent)
             x0 = [latent]
             videos = None

@@ -70,7 +70,7 @@ class WanT2V:
     def generate(self, input_prompt, size=(720, 512), frame_num=81, shift=5.0, sample_solver="unipc",
                  sampling_steps=50, guide_scale=5.0, n_prompt="", seed=-1, offload_model=True,
                  context: Optional[List[torch.Tensor]] = None, context_null: Optional[List[torch.Tensor]] = None,
-                 return_latent: bool = False):
+                 return_latent: bool = False, batched_cfg: bool = True):
         r"""text2video.py:112-269.  Returns the video ``[3, N, H, W]`` on rank 0 (else None)."""
         F = frame_num
         target_shape = (self.vae.model.z_dim, (F - 1) // self.vae_stride[0] + 1, size[1] // self.vae_stride[1],
@@ -106,12 +106,22 @@ class WanT2V:
             sample_scheduler.set_begin_index(0)
             latents = noise
             # text embedding + per-block cross-attention K/V do not depend on (x, t): once per sample, not 100x
-            if hasattr(self.model, "encode_context"):
+            # The conditional and unconditional forwards of a step share x and t: run them as ONE forward on a
+            # batch of two (same kernels on twice the rows, bit-identical outputs) unless that would push a GEMM
+            # operand past the kernels' 2 GiB limit (14B at 720p); ``batched_cfg=False`` keeps two calls.
+            batched = batched_cfg and 2 * (seq_len + 128) * getattr(self.model, "ffn_dim", 0) * 2 < 0x7fffffff
+            if batched:
+                both = self.model.encode_context([context[0], context_null[0]])
+            else:
                 context, context_null = self.model.encode_context(context), self.model.encode_context(context_null)
             for t in timesteps:
-                timestep = torch.stack([t])
-                cond = self.model(latents, t=timestep, context=context, seq_len=seq_len)[0]
-                uncond = self.model(latents, t=timestep, context=context_null, seq_len=seq_len)[0]
+                if batched:
+                    cond, uncond = self.model([latents[0], latents[0]], t=torch.stack([t, t]), context=both,
+                                              seq_len=seq_len)
+                else:
+                    timestep = torch.stack([t])
+                    cond = self.model(latents, t=timestep, context=context, seq_len=seq_len)[0]
+                    uncond = self.model(latents, t=timestep, context=context_null, seq_len=seq_len)[0]
                 # noise_pred = uncond + g (cond - uncond); latents = scheduler.step(noise_pred, t, latents)
                 latents = [sample_scheduler.step_cfg(cond, uncond, guide_scale, latents[0])]
             x0 = latents

@@ -94,6 +94,10 @@ def test_wan_t2v_generate_tiny_matches_oracle(solver):
         return (O.dit_forward(sd, ocfg, [x], tt, ctx, 24)[0], O.dit_forward(sd, ocfg, [x], tt, ctx0, 24)[0])
     ref = SO.sample_loop(vel, noise, 4, 3.0, 4.0, solver=solver)
     assert rel_rms(lat, ref) < 2.5e-2          # 8 bf16 forwards chained through the sampler (TOL_TINY per forward)
+    # cond + uncond as one forward on a batch of two (the default) = two separate forwards, bit for bit
+    lat2 = pipe.generate("", size=(64, 48), frame_num=5, shift=3.0, sample_solver=solver, sampling_steps=4,
+                         guide_scale=4.0, seed=11, context=ctx, context_null=ctx0, return_latent=True, batched_cfg=False)
+    assert torch.equal(lat, lat2)
     vid = pipe.generate("", size=(64, 48), frame_num=5, shift=3.0, sample_solver=solver, sampling_steps=2,
                         guide_scale=4.0, seed=11, context=ctx, context_null=ctx0)
     assert vid.shape == (3, 5, 48, 64) and bool(torch.isfinite(vid).all()) and float(vid.abs().max()) <= 1.0
@@ -132,6 +136,7 @@ def test_wan_i2v_generate_tiny_matches_oracle():
               context_null=ctx0)
     lat = pipe.generate("", img, return_latent=True, **kw)
     assert clip.seen == [(3, 1, 40, 60)]
+    assert torch.equal(lat, pipe.generate("", img, return_latent=True, batched_cfg=False, **kw))
     # ---- the same thing on the oracle
     aspect = 40 / 60
     lat_h = round(np.sqrt(48 * 64 * aspect) // 8 // 2 * 2)
