@@ -268,6 +268,10 @@ def main():
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-single-frame", action="store_true")
+    ap.add_argument("--cfg", choices=["batched", "two"], default="two",
+                    help="cond+uncond of a step as two batch-1 forwards (default: one roofline launch = one clip's "
+                         "self-attention, comparable across rounds) or as one batch-2 forward as WanT2V.generate does "
+                         "(bit-identical; measured 560.0 vs 561.6 ms per step at S = 32760, 16.2 vs 22.6 ms at S = 1560)")
     ap.add_argument("--only-train", action="store_true", help="profiling aid: run just the training leg")
     args = ap.parse_args()
 
@@ -309,19 +313,26 @@ def main():
     ctx_null = torch.randn(40, 4096, device=device, generator=g)   # negative prompt ~40 tokens
     guide, shift, n_sampling = 5.0, 5.0, 50
 
+    # --cfg batched: cond and uncond forward of a step as ONE forward on a batch of two (what WanT2V.generate does;
+    # bit-identical to two calls, pipeline tests)
+    nb = 2 if args.cfg == "batched" else 1
     timer = KernelTimer(ops, "flash_attn_raw", lambda *a, **k: a[7] == a[8] and a[7] == seq_len)  # Lq == Lk == S
     # secondary in-situ timings: the widest GEMM (FFN up-projection + GELU) and the HBM-bound LN+modulate pass
-    gemm_timer = KernelTimer(ops, "gemm_raw", lambda *a, **k: a[3] == seq_len and a[4] == 8960 and a[5] == 1536)
-    ln_timer = KernelTimer(ops, "layernorm_modulate_raw", lambda *a, **k: a[2] == seq_len and a[3] == 1536)
+    gemm_timer = KernelTimer(ops, "gemm_raw", lambda *a, **k: a[3] == nb * seq_len and a[4] == 8960 and a[5] == 1536)
+    ln_timer = KernelTimer(ops, "layernorm_modulate_raw", lambda *a, **k: a[2] == nb * seq_len and a[3] == 1536)
 
     # as WanT2V.generate does: what depends on the prompt alone is computed once per sample, not per forward
     st_c, st_u = model.encode_context([ctx]), model.encode_context([ctx_null])
+    st_cu = model.encode_context([ctx, ctx_null]) if nb == 2 else None
 
     def run_steps(n, sched, x):
         for i in range(n):
             t = sched.timesteps[sched.step_index or 0].reshape(1).to(device)
-            c = model([x], t, st_c, seq_len)[0]
-            u = model([x], t, st_u, seq_len)[0]
+            if nb == 2:
+                c, u = model([x, x], torch.cat([t, t]), st_cu, seq_len)
+            else:
+                c = model([x], t, st_c, seq_len)[0]
+                u = model([x], t, st_u, seq_len)[0]
             x = sched.step_cfg(c, u, guide, x)
         return x
 
@@ -359,7 +370,7 @@ def main():
     steps_per_s = world * args.steps / elapsed
     fwd_flops = dit_forward_flops(seq_len)
     attn_ms = timer.avg_ms()
-    attn_flops = 4.0 * seq_len * seq_len * 1536
+    attn_flops = 4.0 * seq_len * seq_len * 1536 * nb             # one launch covers the batch
     roofline = None
     if attn_ms:
         ach = attn_flops / (attn_ms * 1e-3) / 1e12
@@ -370,7 +381,9 @@ def main():
                 traffic = json.load(open(tj)).get("flash_attn_fwd_d128_pp_kernel")
             except Exception:
                 traffic = None
-        roofline = {"kernel": "flash_attn_fwd_d128_pp_kernel (self-attention, Lq=Lk=%d, 12 heads, D=128)" % seq_len,
+        if traffic is not None:
+            traffic = traffic * nb                                 # measured per batch element (tools/pmc_attn.sh)
+        roofline = {"kernel": "flash_attn_fwd_d128_pp_kernel (self-attention, Lq=Lk=%d, 12 heads, D=128, batch %d)" % (seq_len, nb),
                     "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "launches_timed": len(timer.pairs), "avg_launch_ms": round(attn_ms, 4),
@@ -379,12 +392,12 @@ def main():
     secondary = {}
     g_ms, l_ms = gemm_timer.avg_ms(), ln_timer.avg_ms()
     if g_ms:      # [S,1536] x [1536,8960] + bias + GELU-tanh, bf16 out
-        gf = 2.0 * seq_len * 8960 * 1536
+        gf = 2.0 * nb * seq_len * 8960 * 1536
         secondary["ffn_up_gemm_gelu"] = {"avg_launch_ms": round(g_ms, 4), "tflops": round(gf / g_ms / 1e9, 1),
                                         "mfma_frac": round(gf / g_ms / 1e9 / PEAK_BF16_TFLOPS, 4),
                                         "launches_timed": len(gemm_timer.pairs)}
     if l_ms:      # LayerNorm + adaLN modulate: fp32 in, bf16 out = 6 bytes per element
-        lb = 6.0 * seq_len * 1536
+        lb = 6.0 * nb * seq_len * 1536
         secondary["layernorm_modulate"] = {"avg_launch_ms": round(l_ms, 4), "hbm_GBps": round(lb / l_ms / 1e6, 1),
                                           "hbm_frac_of_8TBps": round(lb / l_ms / 1e6 / 8000.0, 4),
                                           "launches_timed": len(ln_timer.pairs)}
@@ -425,7 +438,8 @@ def main():
             "data": "synthetic", "config": {
                 "workload": f"Wan2.1-T2V-1.3B 50-step flow-matching sample, {args.frames}-frame 480x832 "
                             f"(latent {list(shape)}, S={seq_len}), CFG step = cond+uncond DiT forward + fused "
-                            f"CFG/UniPC update, one clip per GPU",
+                            f"CFG/UniPC update, one clip per GPU"
+                            + (" (cond+uncond as one batch-2 forward)" if nb == 2 else " (two batch-1 forwards)"),
                 "weights": "random-init (xavier) Wan2.1-T2V-1.3B architecture",
                 "context_tokens": [int(ctx.shape[0]), int(ctx_null.shape[0])]},
             "dit": {"forward_tflop": round(fwd_flops / 1e12, 2),
