@@ -284,6 +284,11 @@ int omh_colsum_accum(const void* x, int32_t is_bf16, int64_t ld, float* out, int
 /* GELU-tanh on bf16 (model.py:273) and its backward dx = dy * gelu'(x_pre). */
 int omh_gelu_tanh_bf16(const void* x, void* y, int64_t n, omh_stream_t stream);
 int omh_gelu_tanh_bwd_bf16(const void* dy, const void* x_pre, void* dx, int64_t n, omh_stream_t stream);
+
+/* exact (erf) GELU, the activation of the i2v image-embedding MLP (model.py:366), forward and backward — the
+ * training step of the i2v backbone: y = 0.5 x (1 + erf(x/sqrt 2)); dx = dy (Phi(x) + x phi(x)).  bf16, n elements. */
+int omh_gelu_erf_bf16(const void* x_bf16, void* y_bf16, int64_t n, omh_stream_t stream);
+int omh_gelu_erf_bwd_bf16(const void* dy_bf16, const void* x_pre_bf16, void* dx_bf16, int64_t n, omh_stream_t stream);
 /* Gated residual (model.py:296,328): xo = xi + y*gate; gate = gate_const + gate0[c] + gate1[b*stride + c].
  * bwd: dy = bf16(dx*gate); dgate[b*dgate_stride + c] += sum_rows dx*y (skipped when y or dgate is NULL). */
 int omh_gated_residual_fwd(const float* xi, const void* y_bf16, float* xo, int64_t rows, int32_t dim,

@@ -109,6 +109,8 @@ _SIGS = {
     "omh_colsum_accum": (i32, [vp, i32, i64, vp, i64, i32, vp]),
     "omh_gelu_tanh_bf16": (i32, [vp, vp, i64, vp]),
     "omh_gelu_tanh_bwd_bf16": (i32, [vp, vp, vp, i64, vp]),
+    "omh_gelu_erf_bf16": (i32, [vp, vp, i64, vp]),
+    "omh_gelu_erf_bwd_bf16": (i32, [vp, vp, vp, i64, vp]),
     "omh_gated_residual_fwd": (i32, [vp, vp, vp, i64, i32, f32, vp, vp, i64, i64, vp]),
     "omh_gated_residual_bwd": (i32, [vp, vp, vp, vp, i64, i64, i32, f32, vp, vp, i64, i64, vp]),
     "omh_layernorm_modulate_bwd": (i32, [vp, vp, vp, i64, i32, f32, f32, vp, vp, i64, vp, vp, i64, i64, vp]),

@@ -456,6 +456,43 @@ extern "C" int omh_colsum_accum(const void* x, int32_t is_bf16, int64_t ld, floa
     return omh_launch_status();
 }
 
+// exact (erf) GELU of the i2v image-embedding MLP (model.py:366): forward and derivative
+//   d/dz [ z Phi(z) ] = Phi(z) + z phi(z),  Phi(z) = 0.5 (1 + erf(z / sqrt 2)),  phi(z) = exp(-z^2/2) / sqrt(2 pi)
+__global__ __launch_bounds__(256)
+void gelu_erf_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float z = bf2f(x[i]);
+        y[i] = f2bf(0.5f * z * (1.0f + erff(z * 0.7071067811865476f)));
+    }
+}
+__global__ __launch_bounds__(256)
+void gelu_erf_bwd_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ xpre, uint16_t* __restrict__ dx,
+                         int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float z = bf2f(xpre[i]);
+        const float g = 0.5f * (1.0f + erff(z * 0.7071067811865476f)) + z * 0.3989422804014327f * expf(-0.5f * z * z);
+        dx[i] = f2bf(bf2f(dy[i]) * g);
+    }
+}
+
+extern "C" int omh_gelu_erf_bf16(const void* x, void* y, int64_t n, omh_stream_t stream) {
+    if (!x || !y || n <= 0) return OMH_E_BADARG;
+    omh_clear_status();
+    hipLaunchKernelGGL(gelu_erf_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)x, (uint16_t*)y, n);
+    return omh_launch_status();
+}
+
+extern "C" int omh_gelu_erf_bwd_bf16(const void* dy, const void* x_pre, void* dx, int64_t n, omh_stream_t stream) {
+    if (!dy || !x_pre || !dx || n <= 0) return OMH_E_BADARG;
+    omh_clear_status();
+    hipLaunchKernelGGL(gelu_erf_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)dy, (const uint16_t*)x_pre, (uint16_t*)dx, n);
+    return omh_launch_status();
+}
+
 extern "C" int omh_gelu_tanh_bf16(const void* x, void* y, int64_t n, omh_stream_t stream) {
     if (!x || !y || n <= 0) return OMH_E_BADARG;
     omh_clear_status();

@@ -349,6 +349,22 @@ def gelu_tanh_bwd(dy, x_pre, out=None):
     return out
 
 
+def gelu_erf(x, out=None):
+    _dev(x)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    out = torch.empty_like(x) if out is None else out
+    check(lib.omh_gelu_erf_bf16(_p(x), _p(out), x.numel(), _stream()), "omh_gelu_erf_bf16")
+    return out
+
+
+def gelu_erf_bwd(dy, x_pre, out=None):
+    _dev(dy, x_pre)
+    assert dy.dtype == x_pre.dtype == torch.bfloat16 and dy.is_contiguous() and x_pre.is_contiguous()
+    out = torch.empty_like(dy) if out is None else out
+    check(lib.omh_gelu_erf_bwd_bf16(_p(dy), _p(x_pre), _p(out), dy.numel(), _stream()), "omh_gelu_erf_bwd_bf16")
+    return out
+
+
 def gated_residual_fwd_raw(xi, y, xo, rows, dim, gate_const, gate0, gate1, gate1_stride, rows_per_batch):
     check(lib.omh_gated_residual_fwd(xi, y, xo, rows, dim, gate_const, gate0, gate1, gate1_stride, rows_per_batch,
                                      _stream()), "omh_gated_residual_fwd")

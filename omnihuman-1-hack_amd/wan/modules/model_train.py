@@ -23,8 +23,10 @@ the reference computes the FFN on the CPU under ``no_grad`` and adds
 upstream *through that FFN* — receive no gradient; only the gate ``e[5]`` does.
 ``model.reference_ffn_freeze = False`` turns the quirk off (full gradients).
 
-The attention backward is un-fused (scores materialised per head): sized for the
-single-frame training clips of config 3 (S = 1560), not for S = 32 760.
+The attention backward is the fused kernel pair of csrc/attention_bwd.hip (sized for the single-frame training
+clips of config 3, S = 1560); ``OMH_ATTN_BWD=unfused`` keeps the first implementation (scores materialised per head
+through the GEMM kernel) for A/B runs.  The i2v backbone trains too: the image-token branch of the cross-attention
+(k_img / v_img / norm_k_img) and img_emb (LayerNorm, Linear, GELU(erf), Linear, LayerNorm on the CLIP tokens).
 """
 import math
 import os
@@ -55,14 +57,26 @@ def _wT(mod, key, weight_bf16):
     return mod._packed.get("T:" + key, (weight_bf16,), lambda: ops.transpose_bf16(weight_bf16))
 
 
-def _wgrad(dy, x, xT=None):
-    """dW[N, K] = dy[R, N]^T @ x[R, K]  (fp32), both bf16 row-major; xT = cached transpose of x."""
+def _wgrad(dy, x, xT=None, out=None):
+    """dW[N, K] = dy[R, N]^T @ x[R, K]  (fp32), both bf16 row-major; xT = cached transpose of x; with ``out`` the
+    product is ADDED to it (a weight used twice in the block)."""
     dyT = ops.transpose_bf16(dy)
     xT = ops.transpose_bf16(x) if xT is None else xT
     N, K, Rp = dyT.shape[0], xT.shape[0], dyT.shape[1]
-    out = torch.empty(N, K, dtype=torch.float32, device=dy.device)
-    ops.gemm_raw(ptr(dyT), ptr(xT), ptr(out), N, K, Rp, Rp, Rp, K, EPI_F32)
+    acc = out is not None
+    if out is None:
+        out = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+    ops.gemm_raw(ptr(dyT), ptr(xT), ptr(out), N, K, Rp, Rp, Rp, K, EPI_ACC if acc else EPI_F32)
     return out
+
+
+def _dgrad_ctx(dy, wT, d_ctx, first, L):
+    """d_ctx[b, first:first+L, :] += dy[b*L:(b+1)*L, :] @ W  for every sample b (the context gradient of a K / V
+    projection that reads a slice of the context rows): one batched GEMM into the strided destination."""
+    B, Lc, d = d_ctx.shape
+    N = dy.shape[1]
+    ops.gemm_raw(ptr(dy), ptr(wT), ptr(d_ctx, first * d), L, d, N, dy.stride(0), wT.stride(0), d, EPI_ACC, batch=B,
+                 strideA=L * dy.stride(0), strideB=0, strideC=Lc * d)
 
 
 class _ZeroArena:
@@ -221,12 +235,12 @@ def _block_backward(model, blk, idx, st, x0, dx):
     mod = blk.modulation.detach().float().contiguous()
     e0 = fc.e0
     six = 6 * d
-    i2v = hasattr(ca, "k_img")
-    if i2v:
-        raise NotImplementedError("training backward for the i2v cross-attention is not built")
+    i2v = hasattr(ca, "k_img")                                        # model.py:189-230: extra attention over the 257 image tokens
+    n_img = 257 if i2v else 0
     frozen_ffn = getattr(model, "reference_ffn_freeze", True) and idx > 10
     seq_lens, ctx_lens = fc.seq_lens_host, fc.ctx_lens_host
     Lc = fc.Lc
+    Lt = Lc - n_img                                                   # text tokens
     arena = _ZeroArena(B * six + 2 * six + 16 * d + 2 * blk.ffn[0].out_features + 4096, dev)
     d_eb = arena.take(B, 6, d)                                        # grads of e = modulation + e0
     g = {}
@@ -292,15 +306,27 @@ def _block_backward(model, blk, idx, st, x0, dx):
     wqc, bqc = ca._w("q")
     qc_pre = lin(h3, wqc, bqc, EPI_F32)
     qc = ops.rmsnorm_rope(qc_pre, ca._norm_w("norm_q"), ca.eps, do_norm=ca.qk_norm)
-    ctx2 = fc.ctx.view(B * Lc, d)
+    ctx2 = fc.ctx.view(B * Lc, d) if not i2v else fc.ctx[:, n_img:].contiguous().view(B * Lt, d)
     wkc, bkc = ca._w("k")
     wvc, bvc = ca._w("v")
     kc_pre = lin(ctx2, wkc, bkc, EPI_F32)
     kc = ops.rmsnorm_rope(kc_pre, ca._norm_w("norm_k"), ca.eps, do_norm=ca.qk_norm)
     vc = lin(ctx2, wvc, bvc)
-    oc, lse_ca = _attn_fwd(qc, kc, vc, fc.ctx_lens32, B, S, Lc, N, D, want_lse=True)
+    oc, lse_ca = _attn_fwd(qc, kc, vc, fc.ctx_lens32, B, S, Lt, N, D, want_lse=True)
     woc, boc = ca._w("o")
-    y2 = lin(oc, woc, boc)
+    if i2v:
+        ctxi = fc.ctx[:, :n_img].contiguous().view(B * n_img, d)
+        wki, bki = ca._w("k_img")
+        wvi, bvi = ca._w("v_img")
+        ki_pre = lin(ctxi, wki, bki, EPI_F32)
+        ki = ops.rmsnorm_rope(ki_pre, ca._norm_w("norm_k_img"), ca.eps, do_norm=ca.qk_norm)
+        vi = lin(ctxi, wvi, bvi)
+        oi, lse_ci = _attn_fwd(qc, ki, vi, None, B, S, n_img, N, D, want_lse=True)
+        y2f = lin(oc, woc, boc, EPI_F32)                              # o(o_text + o_img): two products into one fp32 sum
+        ops.gemm(oi, woc, out=y2f, epilogue=EPI_ACC)
+        y2 = ops.cast_bf16(y2f)
+    else:
+        y2 = lin(oc, woc, boc)
     x2 = resid_fwd(x1, y2, None)
     # FFN
     h2 = ln_fwd(x2, 3, 4)
@@ -327,9 +353,28 @@ def _block_backward(model, blk, idx, st, x0, dx):
     g["cross_attn.o.weight"], g["cross_attn.o.bias"] = _wgrad(dy2, oc), _bgrad(dy2, arena)
     doc = ops.gemm(dy2, _wT(ca, "o", woc), epilogue=EPI_BF16)
     if _FUSED_ATTN_BWD:
-        dqc, dkc, dvc = ops.flash_attn_bwd(qc, kc, vc, oc, doc, lse_ca, fc.ctx_lens32, B, N, S, Lc, D ** -0.5)
+        dqc, dkc, dvc = ops.flash_attn_bwd(qc, kc, vc, oc, doc, lse_ca, fc.ctx_lens32, B, N, S, Lt, D ** -0.5)
     else:
-        dqc, dkc, dvc = _attn_bwd(qc, kc, vc, doc, ctx_lens, B, S, Lc, N, D)
+        dqc, dkc, dvc = _attn_bwd(qc, kc, vc, doc, ctx_lens, B, S, Lt, N, D)
+    if i2v:                                                           # the image-token branch: same q, same dO
+        _wgrad(dy2, oi, out=g["cross_attn.o.weight"])
+        dqi, dki, dvi = ops.flash_attn_bwd(qc, ki, vi, oi, doc, lse_ci, None, B, N, S, n_img, D ** -0.5)
+        ops.colsum_accum(dqi.view(1, R * d), dqc.view(R * d))         # dq = dq_text + dq_img
+        Ri = B * n_img
+        dki_pre = torch.empty(Ri, d, dtype=torch.bfloat16, device=dev)
+        dnki = arena.take(d) if ca.qk_norm else None
+        ops.rmsnorm_rope_bwd_raw(ptr(ki_pre), d, ptr(dki), d, ptr(dki_pre), d, ptr(dnki) if dnki is not None else None,
+                                 Ri, d, ptr(ca._norm_w("norm_k_img")) if ca.qk_norm else None, ca.eps, int(ca.qk_norm),
+                                 None, None, 0, D, None, 0)
+        if dnki is not None:
+            g["cross_attn.norm_k_img.weight"] = dnki
+        ctxiT = ops.transpose_bf16(ctxi)
+        g["cross_attn.k_img.weight"], g["cross_attn.k_img.bias"] = _wgrad(dki_pre, ctxi, ctxiT), _bgrad(dki_pre, arena)
+        dvi_b = ops.cast_bf16(dvi)
+        g["cross_attn.v_img.weight"], g["cross_attn.v_img.bias"] = _wgrad(dvi_b, ctxi, ctxiT), _bgrad(dvi_b, arena)
+        _dgrad_ctx(dki_pre, _wT(ca, "k_img", wki), st.d_ctx, 0, n_img)
+        _dgrad_ctx(dvi_b, _wT(ca, "v_img", wvi), st.d_ctx, 0, n_img)
+        del dqi, dki, dvi, dki_pre, dvi_b, ki, vi, oi, ki_pre, ctxi, ctxiT
     dqc_pre = torch.empty(R, d, dtype=torch.bfloat16, device=dev)
     dnq = arena.take(d) if ca.qk_norm else None
     ops.rmsnorm_rope_bwd_raw(ptr(qc_pre), d, ptr(dqc), d, ptr(dqc_pre), d, ptr(dnq) if dnq is not None else None, R, d,
@@ -339,7 +384,7 @@ def _block_backward(model, blk, idx, st, x0, dx):
         g["cross_attn.norm_q.weight"] = dnq
     g["cross_attn.q.weight"], g["cross_attn.q.bias"] = _wgrad(dqc_pre, h3), _bgrad(dqc_pre, arena)
     dh3 = _dgrad(dqc_pre, _wT(ca, "q", wqc))
-    Rc = B * Lc
+    Rc = B * Lt
     dkc_pre = torch.empty(Rc, d, dtype=torch.bfloat16, device=dev)
     dnk = arena.take(d) if ca.qk_norm else None
     ops.rmsnorm_rope_bwd_raw(ptr(kc_pre), d, ptr(dkc), d, ptr(dkc_pre), d, ptr(dnk) if dnk is not None else None, Rc, d,
@@ -351,9 +396,8 @@ def _block_backward(model, blk, idx, st, x0, dx):
     g["cross_attn.k.weight"], g["cross_attn.k.bias"] = _wgrad(dkc_pre, ctx2, ctx2T), _bgrad(dkc_pre, arena)
     dvc_b = ops.cast_bf16(dvc)
     g["cross_attn.v.weight"], g["cross_attn.v.bias"] = _wgrad(dvc_b, ctx2, ctx2T), _bgrad(dvc_b, arena)
-    dctx = st.d_ctx.view(Rc, d)
-    _dgrad(dkc_pre, _wT(ca, "k", wkc), out=dctx, accumulate=True)
-    _dgrad(dvc_b, _wT(ca, "v", wvc), out=dctx, accumulate=True)
+    _dgrad_ctx(dkc_pre, _wT(ca, "k", wkc), st.d_ctx, n_img, Lt)
+    _dgrad_ctx(dvc_b, _wT(ca, "v", wvc), st.d_ctx, n_img, Lt)
     if blk.cross_attn_norm:
         dw3, db3 = arena.take(d), arena.take(d)
         ops.layernorm_modulate_bwd_raw(ptr(x1), ptr(dh3), ptr(dx), R, d, blk.norm3.eps, 0.0, ptr(w3), None, 0,
@@ -457,9 +501,44 @@ _EMBED_MODULES = ("patch_embedding", "text_embedding", "time_embedding", "time_p
 
 def _embed_params(model):
     out = []
-    for m in _EMBED_MODULES:
+    for m in _EMBED_MODULES + (("img_emb",) if hasattr(model, "img_emb") else ()):
         out += [(f"{m}.{n}", p) for n, p in getattr(model, m).named_parameters()]
     return out
+
+
+def _img_emb_backward(model, clip_fea, d_img, g):
+    """Backward of MLPProj (model.py:362-374: LayerNorm, Linear, GELU(erf), Linear, LayerNorm) on the CLIP tokens:
+    recompute keeping the pre-activations, then the chain rule.  d_img fp32 [B*257, dim] = gradient of its output."""
+    proj = model.img_emb.proj
+    ln0, l1, l3, ln4 = proj[0], proj[1], proj[3], proj[4]
+    dev = d_img.device
+    x = clip_fea.to(device=dev, dtype=torch.float32).contiguous().view(-1, clip_fea.shape[-1])
+    rows, cin = x.shape
+    dim = l3.weight.shape[0]
+    f = lambda t_: t_.detach().float().contiguous()
+    w0, b0, w4, b4 = f(ln0.weight), f(ln0.bias), f(ln4.weight), f(ln4.bias)
+    h0 = ops.layernorm_modulate(x, ln0.eps, 0.0, mul0=w0, add0=b0)
+    w1, w3 = ops.cast_bf16(f(l1.weight)), ops.cast_bf16(f(l3.weight))
+    z1 = ops.gemm(h0, w1, bias=f(l1.bias), epilogue=EPI_BF16)
+    g1 = ops.gelu_erf(z1)
+    z3 = ops.gemm(g1, w3, bias=f(l3.bias), epilogue=EPI_F32)
+    # LayerNorm 4 (affine): dz3, dw4, db4
+    dz3 = torch.zeros(rows, dim, dtype=torch.float32, device=dev)
+    dw4, db4 = torch.zeros(dim, dtype=torch.float32, device=dev), torch.zeros(dim, dtype=torch.float32, device=dev)
+    ops.layernorm_modulate_bwd_raw(ptr(z3), ptr(d_img), ptr(dz3), rows, dim, ln4.eps, 0.0, ptr(w4), None, 0, ptr(dw4),
+                                   ptr(db4), 0, rows)
+    dz3b = ops.cast_bf16(dz3)
+    g["img_emb.proj.4.weight"], g["img_emb.proj.4.bias"] = dw4, db4
+    g["img_emb.proj.3.weight"], g["img_emb.proj.3.bias"] = _wgrad(dz3b, g1), _bgrad(dz3b)
+    dg1 = ops.gemm(dz3b, ops.transpose_bf16(w3), epilogue=EPI_BF16)
+    dz1 = ops.gelu_erf_bwd(dg1, z1)
+    g["img_emb.proj.1.weight"], g["img_emb.proj.1.bias"] = _wgrad(dz1, h0), _bgrad(dz1)
+    dh0 = _dgrad(dz1, ops.transpose_bf16(w1))
+    dx = torch.zeros(rows, cin, dtype=torch.float32, device=dev)      # (gradient w.r.t. the CLIP tokens: not needed)
+    dw0, db0 = torch.zeros(cin, dtype=torch.float32, device=dev), torch.zeros(cin, dtype=torch.float32, device=dev)
+    ops.layernorm_modulate_bwd_raw(ptr(x), ptr(dh0), ptr(dx), rows, cin, ln0.eps, 0.0, ptr(w0), None, 0, ptr(dw0),
+                                   ptr(db0), 0, rows)
+    g["img_emb.proj.0.weight"], g["img_emb.proj.0.bias"] = dw0, db0
 
 
 class _EmbedFn(torch.autograd.Function):
@@ -475,13 +554,13 @@ class _EmbedFn(torch.autograd.Function):
         st.d_e = torch.zeros(B, d, dtype=torch.float32, device=dev)
         st.d_ctx = torch.zeros(B, fc.Lc, d, dtype=torch.float32, device=dev)
         ctx.model, ctx.st = model, st
-        ctx.inputs = (x_list, t, context, seq_len, y)
+        ctx.inputs = (x_list, t, context, seq_len, y, clip_fea)
         return xs
 
     @staticmethod
     def backward(ctx, dxs):
         model, st = ctx.model, ctx.st
-        x_list, t, context, seq_len, y = ctx.inputs
+        x_list, t, context, seq_len, y, clip_fea = ctx.inputs
         fc = st.fc
         B, d = fc.B, fc.dim
         dev = dxs.device
@@ -538,6 +617,9 @@ class _EmbedFn(torch.autograd.Function):
             dgl = ops.gemm(dctx_b, ops.transpose_bf16(w2), epilogue=EPI_BF16)
             dpre = ops.gelu_tanh_bwd(dgl, pre)
             g["text_embedding.0.weight"], g["text_embedding.0.bias"] = _wgrad(dpre, cin), _bgrad(dpre)
+            # ---- image embedding (i2v): the first n_img context rows came from img_emb(clip_fea)
+            if n_img and clip_fea is not None:
+                _img_emb_backward(model, clip_fea, st.d_ctx[:, :n_img].contiguous().view(B * n_img, d), g)
         out = []
         for n, p in _embed_params(model):
             gg = g.get(n) if p.requires_grad else None
@@ -548,8 +630,6 @@ class _EmbedFn(torch.autograd.Function):
 def forward_train(model, x, t, context, seq_len, clip_fea=None, y=None):
     """WanModel.forward with autograd enabled: same outputs as the inference path, attached to a
     graph of hand-written nodes (see module docstring)."""
-    if clip_fea is not None or model.model_type != "t2v":
-        raise NotImplementedError("training backward is built for the t2v model (BASELINE config 3)")
     st = _State()
     x_list = list(x) if not isinstance(x, (list, tuple)) else list(x)
     eparams = [p for _, p in _embed_params(model)]

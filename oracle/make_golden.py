@@ -122,6 +122,32 @@ def golden_omnihuman():
     print("omnihuman: audio", tuple(a.shape), "pose feat", tuple(pf.shape), "reference process_pose:", pose_err or "ran")
 
 
+def golden_train_i2v():
+    """Gradients of the REAL reference i2v backbone (tiny, L=2): loss = mse(out[0], v_teacher) as the trainer forms
+    it, with CLIP tokens and the conditioning channels y — pins the image branch of the cross-attention
+    (k_img / v_img / norm_k_img) and img_emb for the training backward."""
+    os.makedirs(OUT, exist_ok=True)
+    cfg, tag, xs, ctx, tt, seq_len, ys, clip = tiny_case("i2v", 2)
+    sd = O.synth_state_dict(cfg, tag)
+    ref = ref_import.build_reference_dit(cfg, sd)
+    ref.requires_grad_(True)
+    with torch.enable_grad():
+        v_teacher = torch.from_numpy(detgen.normalish(f"{tag}/vt", (16, 2, 6, 8)))
+        out = ref(xs, torch.tensor([1000.0, 1000.0]), ctx, seq_len, clip_fea=clip, y=ys)
+        loss = torch.nn.functional.mse_loss(out[0], v_teacher)
+        loss.backward()
+    grads = {"loss": np.float32(loss.item())}
+    params = dict(ref.named_parameters())
+    for name in ("blocks.0.cross_attn.k_img.weight", "blocks.1.cross_attn.v_img.bias", "blocks.0.cross_attn.norm_k_img.weight",
+                 "blocks.1.cross_attn.q.weight", "blocks.0.cross_attn.k.weight", "img_emb.proj.0.weight", "img_emb.proj.0.bias",
+                 "img_emb.proj.1.weight", "img_emb.proj.3.bias", "img_emb.proj.4.weight", "patch_embedding.weight",
+                 "text_embedding.2.weight", "blocks.0.self_attn.v.weight"):
+        g = params[name].grad.numpy()
+        grads[name] = g if g.size <= 100000 else g[:16]            # large matrices: their first 16 rows
+    np.savez_compressed(os.path.join(OUT, "dit_train_i2v_L2.npz"), **grads)
+    print("i2v train loss", loss.item(), {k: float(np.abs(v).mean()) for k, v in grads.items() if k != "loss"})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_grad_enabled(False)
@@ -221,6 +247,10 @@ def main():
                             coarse=out[:, 0, ::6, ::8].numpy())
         print("1.3B", float(out.abs().mean()))
 
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "train_i2v":
+    golden_train_i2v()
+    sys.exit(0)
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "omnihuman":
     torch.set_grad_enabled(False)
