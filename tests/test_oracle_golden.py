@@ -148,3 +148,24 @@ def test_omnihuman_adapters_match_reference_vectors():
         x = o.step(v, x)
         assert np.array_equal(x.numpy(), g["dpm_traj"][k])
     assert OH.annealed_cfg(0, 50, 7.5) == 7.5 and abs(OH.annealed_cfg(25, 50, 7.5) - 4.25) < 1e-12
+
+
+def test_i2v_training_gradients_match_reference_vectors():
+    """The autograd oracle on the i2v backbone (CLIP tokens through img_emb, image-token attention branch, 36 input
+    channels) against gradients produced by the real reference (oracle/make_golden.py train_i2v)."""
+    from oracle import detgen, make_golden, wan_dit_oracle as O
+    g = _g("dit_train_i2v_L2.npz")
+    cfg, tag, xs, ctx, tt, seq_len, ys, clip = make_golden.tiny_case("i2v", 2)
+    sd = O.synth_state_dict(cfg, tag)
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = O.dit_forward_autograd(osd, cfg, xs, torch.tensor([1000.0, 1000.0]), ctx, seq_len, clip_fea=clip, y=ys)
+    vt = torch.from_numpy(detgen.normalish(f"{tag}/vt", (16, 2, 6, 8)))
+    loss = torch.nn.functional.mse_loss(out[0], vt)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * float(g["loss"])
+    for name in g.files:
+        if name == "loss":
+            continue
+        a = osd[name].grad
+        a = a if a.numel() <= 100000 else a[:16]
+        assert rel_rms(a, torch.from_numpy(g[name])) < 1e-5, name
