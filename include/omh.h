@@ -77,6 +77,19 @@ typedef struct omh_gemm_args {
 
 int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream);
 
+/* bf16 GEMM with both operands K-MAJOR (row-major [K, *]):  C[m][n] (+)= sum_k A[k][m] * B[k][n],  fp32 C.
+ * The weight gradient of every nn.Linear in the training step — dW[out][in] = sum_r dy[r][out] x[r][in], what
+ * autograd computes for model.py's Linears under distilled_trainer.py:289-301 — on dy and x as the backward
+ * produces them (no transposed copies).  M, N, lda, ldb multiples of 8; K arbitrary; accumulate != 0 adds to C. */
+typedef struct omh_gemm_tn_args {
+    const void* A; const void* B; float* C;
+    int32_t M, N, K;
+    int32_t lda, ldb, ldc;
+    int32_t accumulate;
+} omh_gemm_tn_args;
+
+int omh_gemm_bf16_tn(const omh_gemm_tn_args* args, omh_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Flash attention forward, head_dim 128, bf16, non-causal, key-length mask.
  * Replaces flash_attn.flash_attn_varlen_func as called from

@@ -52,6 +52,11 @@ class GemmArgs(C.Structure):
                 ("gate1_stride", i64), ("gate_rows", i32), ("gate_const", f32)]
 
 
+class GemmTnArgs(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("M", i32), ("N", i32), ("K", i32),
+                ("lda", i32), ("ldb", i32), ("ldc", i32), ("accumulate", i32)]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [("q", vp), ("k", vp), ("vt", vp), ("o", vp),
                 ("k_lens", vp),
@@ -89,6 +94,7 @@ _SIGS = {
     "omh_abi_version": (i32, []),
     "omh_build_arch": (C.c_char_p, []),
     "omh_gemm_bf16": (i32, [C.POINTER(GemmArgs), vp]),
+    "omh_gemm_bf16_tn": (i32, [C.POINTER(GemmTnArgs), vp]),
     "omh_flash_attn_fwd_d128": (i32, [C.POINTER(AttnArgs), vp]),
     "omh_flash_attn_bwd_d128": (i32, [C.POINTER(AttnBwdArgs), vp]),
     "omh_layernorm_modulate": (i32, [vp, vp, i64, i32, f32, f32, vp, vp, i64, vp, vp, i64, i64, vp]),

@@ -64,6 +64,23 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, b
     return out
 
 
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """out[M, N] (+)= a[K, M]^T @ b[K, N]  (fp32): both operands row-major with the contraction index on the ROWS
+    (weight gradient dW = dy^T x without transposed copies).  a, b bf16, row stride free (multiple of 8)."""
+    _dev(a, b, out)
+    assert a.dtype == b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0]
+    assert a.stride(1) == 1 and b.stride(1) == 1
+    K, M = a.shape
+    N = b.shape[1]
+    if out is None:
+        assert not accumulate
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    assert out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1
+    args = _lib.GemmTnArgs(_p(a), _p(b), _p(out), M, N, K, a.stride(0), b.stride(0), out.stride(0), int(accumulate))
+    check(lib.omh_gemm_bf16_tn(C.byref(args), _stream()), "omh_gemm_bf16_tn")
+    return out
+
+
 def flash_attn_raw(q, k, vt, o, k_lens, B, H, Lq, Lk, q_bs, q_rs, k_bs, k_rs, vt_bs, o_bs, o_rs, ldv, scale,
                    lse=None):
     a = AttnArgs(q, k, vt, o, k_lens, B, H, Lq, Lk, q_bs, q_rs, k_bs, k_rs, vt_bs, o_bs, o_rs, ldv, scale, lse)

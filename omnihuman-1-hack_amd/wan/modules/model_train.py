@@ -58,8 +58,11 @@ def _wT(mod, key, weight_bf16):
 
 
 def _wgrad(dy, x, xT=None, out=None):
-    """dW[N, K] = dy[R, N]^T @ x[R, K]  (fp32), both bf16 row-major; xT = cached transpose of x; with ``out`` the
-    product is ADDED to it (a weight used twice in the block)."""
+    """dW[N, K] = dy[R, N]^T @ x[R, K]  (fp32) on dy and x as they are (row-major bf16): the k-major GEMM of
+    csrc/gemm_tn.hip — no transposed copies.  With ``out`` the product is ADDED to it (a weight used twice in the
+    block).  ``xT`` is ignored (kept for the OMH_WGRAD=nt path: two transposes + the NT kernel, for A/B timing)."""
+    if _WGRAD_TN:
+        return ops.gemm_tn(dy, x, out=out, accumulate=out is not None)
     dyT = ops.transpose_bf16(dy)
     xT = ops.transpose_bf16(x) if xT is None else xT
     N, K, Rp = dyT.shape[0], xT.shape[0], dyT.shape[1]
@@ -145,6 +148,7 @@ def _attn_fwd(q, k, v, klens32, B, Lq, Lk, H, D, want_lse=False):
 # launches per sample) for A/B timing and as a second opinion in the tests; the default is the fused kernel pair
 # of csrc/attention_bwd.hip (3 launches + 3 transposes per call, whole batch at once).
 _FUSED_ATTN_BWD = os.environ.get("OMH_ATTN_BWD", "fused") != "unfused"
+_WGRAD_TN = os.environ.get("OMH_WGRAD", "tn") != "nt"
 
 
 def _attn_bwd(q, k, v, do, klens, B, Lq, Lk, H, D):
@@ -368,7 +372,7 @@ def _block_backward(model, blk, idx, st, x0, dx):
                                  None, None, 0, D, None, 0)
         if dnki is not None:
             g["cross_attn.norm_k_img.weight"] = dnki
-        ctxiT = ops.transpose_bf16(ctxi)
+        ctxiT = None if _WGRAD_TN else ops.transpose_bf16(ctxi)
         g["cross_attn.k_img.weight"], g["cross_attn.k_img.bias"] = _wgrad(dki_pre, ctxi, ctxiT), _bgrad(dki_pre, arena)
         dvi_b = ops.cast_bf16(dvi)
         g["cross_attn.v_img.weight"], g["cross_attn.v_img.bias"] = _wgrad(dvi_b, ctxi, ctxiT), _bgrad(dvi_b, arena)
@@ -392,7 +396,7 @@ def _block_backward(model, blk, idx, st, x0, dx):
                              0, D, None, 0)
     if dnk is not None:
         g["cross_attn.norm_k.weight"] = dnk
-    ctx2T = ops.transpose_bf16(ctx2)
+    ctx2T = None if _WGRAD_TN else ops.transpose_bf16(ctx2)
     g["cross_attn.k.weight"], g["cross_attn.k.bias"] = _wgrad(dkc_pre, ctx2, ctx2T), _bgrad(dkc_pre, arena)
     dvc_b = ops.cast_bf16(dvc)
     g["cross_attn.v.weight"], g["cross_attn.v.bias"] = _wgrad(dvc_b, ctx2, ctx2T), _bgrad(dvc_b, arena)
@@ -423,7 +427,7 @@ def _block_backward(model, blk, idx, st, x0, dx):
                                  D, ptr(fc.grid32), S)
         if dnw is not None:
             g[f"self_attn.{nm}.weight"] = dnw
-    h1T = ops.transpose_bf16(h1)
+    h1T = None if _WGRAD_TN else ops.transpose_bf16(h1)
     dwqk, dbqk = _wgrad(dqk_pre, h1, h1T), _bgrad(dqk_pre, arena)
     g["self_attn.q.weight"], g["self_attn.k.weight"] = dwqk[:d], dwqk[d:]
     g["self_attn.q.bias"], g["self_attn.k.bias"] = dbqk[:d], dbqk[d:]

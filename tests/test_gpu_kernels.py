@@ -276,3 +276,28 @@ def test_flash_attention_backward(ops, B, H, Lq, Lk, klens):
     # repeatable bit for bit (no atomics)
     dq2, dk2, dv2 = ops.flash_attn_bwd(q, k, v, o, do, lse, kl, B, H, Lq, Lk, scale)
     assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
+
+
+@pytest.mark.parametrize("M,N,K,pad", [(128, 128, 64, 0), (256, 256, 200, 0), (1536, 1536, 1560, 0), (8960, 1536, 777, 0),
+                                        (1536, 3072, 333, 64), (72, 200, 130, 8), (3072, 1536, 6240, 0)])
+@pytest.mark.parametrize("tile", ["big", "small", "small-split3", "big-split8"])
+def test_gemm_tn(ops, M, N, K, pad, tile, monkeypatch):
+    """omh_gemm_bf16_tn — C = A^T B with both operands k-major (the weight gradient on dy and x as they are):
+    against fp32 matmul on the same bf16 inputs; ragged M / N / K tails, strided rows, both tile configurations,
+    accumulation, and an asymmetric pattern that a transposed or permuted fragment gather would scramble."""
+    monkeypatch.setenv("OMH_GEMM_TN_TILE", tile.split("-")[0])
+    monkeypatch.setenv("OMH_GEMM_TN_SPLIT", tile.split("split")[1] if "split" in tile else "1")    # split K: fp32 atomics
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a_full = torch.randn(K, M + pad, device="cuda", generator=g).bfloat16()
+    b_full = torch.randn(K, N + pad, device="cuda", generator=g).bfloat16()
+    a, b = a_full[:, :M], b_full[:, :N]
+    ref = a.float().t() @ b.float()
+    c = ops.gemm_tn(a, b)
+    assert rel_rms(c, ref) < 2e-5
+    c2 = ops.gemm_tn(a, b, out=c.clone(), accumulate=True)
+    assert rel_rms(c2, 2 * ref) < 2e-5
+    # selector test: A = one-hot rows picks single rows of B (exact), position dependent
+    sel = torch.zeros(K, M, device="cuda", dtype=torch.bfloat16)
+    idx = (torch.arange(M, device="cuda") * 7 + 3) % K
+    sel[idx, torch.arange(M, device="cuda")] = 1.0
+    assert torch.equal(ops.gemm_tn(sel, b), b.float()[idx])
