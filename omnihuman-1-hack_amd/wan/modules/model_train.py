@@ -583,9 +583,12 @@ class _EmbedFn(torch.autograd.Function):
                 n = st.lens[b]
                 tok = ops.patchify(u.to(device=dev, dtype=torch.float32).contiguous(), model.patch_size, Kp)
                 dxb = ops.cast_bf16(dxs[b, :n].contiguous())
-                dxT, tokT = ops.transpose_bf16(dxb), ops.transpose_bf16(tok)
-                ops.gemm_raw(ptr(dxT), ptr(tokT), ptr(dW), d, Kp, dxT.shape[1], dxT.shape[1], tokT.shape[1], Kp,
-                             EPI_ACC)
+                if _WGRAD_TN:
+                    ops.gemm_tn(dxb, tok, out=dW, accumulate=True)
+                else:
+                    dxT, tokT = ops.transpose_bf16(dxb), ops.transpose_bf16(tok)
+                    ops.gemm_raw(ptr(dxT), ptr(tokT), ptr(dW), d, Kp, dxT.shape[1], dxT.shape[1], tokT.shape[1], Kp,
+                                 EPI_ACC)
                 ops.colsum_accum(dxs[b, :n], db)
             g["patch_embedding.weight"] = dW[:, :kin].contiguous()
             g["patch_embedding.bias"] = db
