@@ -123,10 +123,23 @@ def test_rms_silu_softmax_layout(ops):
     assert torch.allclose(out[:, 2:5], ref2, atol=1e-6) and float(out[:, :2].abs().max()) == 0
 
 
+@pytest.mark.parametrize("window", ["default", "one-chunk", "two-chunks"])
 @pytest.mark.parametrize("dim", [32, 96])
-def test_vae_decode_encode_match_oracle(dim):
+def test_vae_decode_encode_match_oracle(dim, window, monkeypatch):
+    """``window``: size of the sliding history window of every conv input buffer.  The default (8 chunks) never
+    reaches its end on a 9-frame clip; "one-chunk" makes the buffer exactly [history | chunk], so the history is
+    copied back before every chunk (incl. the overlapping T = 1, hist = 2 case), "two-chunks" wraps every other one."""
     from oracle import wan_vae_oracle as V, detgen
     vae_mod = importlib.import_module("omnihuman-1-hack_amd.wan.modules.vae")
+    if window != "default":
+        orig_slot = vae_mod._ConvState.slot
+        chunks = 1 if window == "one-chunk" else 2
+
+        def small_slot(self, T, H, W, device):
+            # budget of exactly hist + chunks * T frames for this layer
+            monkeypatch.setattr(vae_mod._ConvState, "_WINDOW_BYTES", (self.hist + chunks * max(T, 1)) * H * W * self.Cin * 2)
+            return orig_slot(self, T, H, W, device)
+        monkeypatch.setattr(vae_mod._ConvState, "slot", small_slot)
     cfg = V.VAEConfig(dim=dim)
     sd = V.synth_state_dict(cfg, f"vae{dim}")
     vae = vae_mod.WanVAE(vae_pth=None, device="cuda", dim=dim)
