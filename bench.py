@@ -129,6 +129,36 @@ def cpu_baseline(model, latent, t, ctx, seq_len, budget_s=60.0):
             "tflops": dit_forward_flops(seq_len) / 30 / t_blk / 1e12}
 
 
+def vae_cpu_baseline(device):
+    """CPU oracle of the VAE decode next to the GPU number: the first two latent frames (5 pixel frames: the first
+    chunk and one steady-state chunk) at a QUARTER of the benchmark's area ([16,2,30,52] -> 240x416; the conv cost is
+    linear in H*W), extrapolated to the 81-frame 480x832 decode; the same sample is a parity check
+    of the HIP decode (kw-shared conv kernels, sliding-window buffers) against the oracle."""
+    from oracle import wan_vae_oracle as V
+    vae_mod = importlib.import_module(PKG + ".wan.modules.vae")
+    torch.manual_seed(4321)
+    vae = vae_mod.WanVAE(vae_pth=None, device=device)
+    sd = {k: v.detach().float().cpu() for k, v in vae.model.state_dict().items()}
+    cfg = V.VAEConfig(dim=96)
+    z = torch.randn(16, 2, 30, 52, generator=torch.Generator().manual_seed(5))
+    cores = min(os.cpu_count() or 1, 32)                             # conv3d on CPU slows down past ~32 threads
+    torch.set_num_threads(cores)                                     # (measured 32/64/128/256: 1.9/2.7/5.9/38 s)
+    t0 = time.time()
+    V.vae_decode(sd, cfg, z[:, :1])
+    t_first = time.time() - t0
+    t0 = time.time()
+    ref = V.vae_decode(sd, cfg, z)
+    t_two = time.time() - t0
+    steady = max(t_two - t_first, 1e-6)
+    full_s = 4.0 * (t_first + 20 * steady)                           # x4 area, 1 first + 20 steady-state chunks
+    out = vae.decode([z.to(device)])[0].float().cpu()
+    parity = float((out - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-30))
+    return {"value": 81.0 / full_s, "unit": "frames/s (81-frame 480x832 decode)", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 VAE decode of latent [16,2,30,52] -> 5 frames 240x416 (first chunk {t_first:.1f}s, "
+                      f"steady-state chunk {steady:.1f}s), extrapolated x4 area x (1 + 20 chunks)",
+            "parity_rel_rms_5_frames_240x416": parity}
+
+
 def single_frame_bench(model, device, iters=20):
     """BASELINE config 1 on the GPU: the CFG teacher pair of generate.py:205-229 — two DiT forwards on one
     [16,1,60,104] latent (S = 1560, t = 999) + v = u + 7.5 (c - u) — as eager launches and as hipGraph replays."""
@@ -421,6 +451,11 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(model, latent, torch.tensor([999.0]), ctx, seq_len)
+        if not args.no_vae:
+            try:
+                cpu["vae"] = vae_cpu_baseline(device)
+            except Exception as e:
+                cpu["vae"] = {"value": None, "error": repr(e)[:200]}
 
     train = None
     if not args.no_train:
