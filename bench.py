@@ -298,8 +298,10 @@ def main():
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-single-frame", action="store_true")
-    ap.add_argument("--cfg", choices=["batched", "two"], default="two",
-                    help="cond+uncond of a step as two batch-1 forwards (default: one roofline launch = one clip's "
+    ap.add_argument("--cfg", choices=["batched", "two", "split"], default="two",
+                    help="split: ranks (2i, 2i+1) share ONE clip, one CFG branch each + one all-gather per step "
+                         "(parallel.CFGPairSplit, SURVEY.md 8e; needs an even --gpus; value = clips in flight x steps/s). "
+                         "cond+uncond of a step as two batch-1 forwards (default: one roofline launch = one clip's "
                          "self-attention, comparable across rounds) or as one batch-2 forward as WanT2V.generate does "
                          "(bit-identical; measured 560.0 vs 561.6 ms per step at S = 32760, 16.2 vs 22.6 ms at S = 1560)")
     ap.add_argument("--only-train", action="store_true", help="profiling aid: run just the training leg")
@@ -310,6 +312,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if os.environ.get("OMH_DIST_BACKEND", "nccl") != "nccl":   # validation mode: ranks may share a GPU (gloo)
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -322,7 +326,10 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=device)
+            if os.environ.get("OMH_DIST_BACKEND", "nccl") == "nccl":
+                dist.init_process_group("nccl", device_id=device)
+            else:                                               # gloo: several ranks on one GPU (validation only)
+                dist.init_process_group(os.environ["OMH_DIST_BACKEND"])
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -337,7 +344,14 @@ def main():
     lat_t = (args.frames - 1) // 4 + 1
     shape = (16, lat_t, 60, 104)
     seq_len = lat_t * 30 * 52
-    g = torch.Generator(device=device).manual_seed(100 + rank)
+    split = None
+    if args.cfg == "split":
+        if dist is None or world % 2:
+            raise SystemExit("--cfg split pairs ranks (2i, 2i+1): launch with an even --gpus")
+        par = importlib.import_module(PKG + ".parallel")
+        groups = [dist.new_group([r, r + 1]) for r in range(0, world, 2)]      # every rank creates every group
+        split = par.CFGPairSplit(groups[rank // 2])
+    g = torch.Generator(device=device).manual_seed(100 + (rank // 2 if split else rank))   # a pair shares its clip
     latent = torch.randn(shape, device=device, generator=g)
     ctx = torch.randn(120, 4096, device=device, generator=g)       # prompt ~120 tokens
     ctx_null = torch.randn(40, 4096, device=device, generator=g)   # negative prompt ~40 tokens
@@ -358,7 +372,9 @@ def main():
     def run_steps(n, sched, x):
         for i in range(n):
             t = sched.timesteps[sched.step_index or 0].reshape(1).to(device)
-            if nb == 2:
+            if split is not None:
+                c, u = split.exchange(model([x], t, st_c if split.runs_conditional else st_u, seq_len)[0])
+            elif nb == 2:
                 c, u = model([x, x], torch.cat([t, t]), st_cu, seq_len)
             else:
                 c = model([x], t, st_c, seq_len)[0]
@@ -397,7 +413,9 @@ def main():
     assert torch.isfinite(x).all(), "non-finite latent after the timed steps"
 
     ms_per_step = elapsed * 1e3 / args.steps
-    steps_per_s = world * args.steps / elapsed
+    clips_in_flight = world // 2 if split is not None else world
+    fwd_per_gpu_step = 1 if split is not None else 2
+    steps_per_s = clips_in_flight * args.steps / elapsed
     fwd_flops = dit_forward_flops(seq_len)
     attn_ms = timer.avg_ms()
     attn_flops = 4.0 * seq_len * seq_len * 1536 * nb             # one launch covers the batch
@@ -473,13 +491,16 @@ def main():
             "data": "synthetic", "config": {
                 "workload": f"Wan2.1-T2V-1.3B 50-step flow-matching sample, {args.frames}-frame 480x832 "
                             f"(latent {list(shape)}, S={seq_len}), CFG step = cond+uncond DiT forward + fused "
-                            f"CFG/UniPC update, one clip per GPU"
-                            + (" (cond+uncond as one batch-2 forward)" if nb == 2 else " (two batch-1 forwards)"),
+                            f"CFG/UniPC update, "
+                            + ("one clip per PAIR of GPUs (one CFG branch per rank, one all-gather per step)"
+                               if split is not None else "one clip per GPU"
+                               + (" (cond+uncond as one batch-2 forward)" if nb == 2 else " (two batch-1 forwards)")),
                 "weights": "random-init (xavier) Wan2.1-T2V-1.3B architecture",
                 "context_tokens": [int(ctx.shape[0]), int(ctx_null.shape[0])]},
             "dit": {"forward_tflop": round(fwd_flops / 1e12, 2),
-                    "achieved_tflops_per_gpu": round(2 * fwd_flops / (ms_per_step * 1e-3) / 1e12, 1),
-                    "mfma_roofline_frac": round(2 * fwd_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                    "achieved_tflops_per_gpu": round(fwd_per_gpu_step * fwd_flops / (ms_per_step * 1e-3) / 1e12, 1),
+                    "mfma_roofline_frac": round(fwd_per_gpu_step * fwd_flops / (ms_per_step * 1e-3) / 1e12
+                                                / PEAK_BF16_TFLOPS, 4),
                     "kernels": secondary},
             "single_frame": single, "vae": vae, "train": train, "roofline": roofline, "cpu_baseline": cpu,
         }

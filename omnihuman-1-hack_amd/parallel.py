@@ -112,3 +112,49 @@ class BucketedGradAllReduce:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+
+
+class CFGPairSplit:
+    """One clip on TWO GPUs: the conditional and the unconditional forward of a denoising step are
+    independent (text2video.py:238-241), so group rank 0 runs the conditional one, group rank 1 the unconditional
+    one, and the two velocity predictions (one ``[16,T,H/8,W/8]`` fp32 latent each — 8.4 MB at 81 frames 480x832)
+    are exchanged with ONE all-gather per step.  Both ranks then apply the same fused CFG + sampler update, so the
+    latents stay bit-identical on both without a broadcast.  The all-gather is the only collective of the path.
+
+    ``group`` must hold exactly two ranks (default: the world).  ``sync_seed`` makes the two ranks draw the same
+    initial noise when the caller asked for a random seed."""
+
+    def __init__(self, group: Optional["dist.ProcessGroup"] = None):
+        if not dist.is_initialized():
+            raise RuntimeError("CFGPairSplit needs an initialised torch.distributed process group")
+        self.group = group
+        if dist.get_world_size(group) != 2:
+            raise ValueError(f"a CFG pair is split over exactly 2 ranks, the group has {dist.get_world_size(group)}")
+        self.index = dist.get_rank(group)                  # 0: conditional branch, 1: unconditional branch
+        self._buf = None
+
+    @property
+    def runs_conditional(self) -> bool:
+        return self.index == 0
+
+    def sync_seed(self, seed: int) -> int:
+        box = [seed]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                                   group=self.group)
+        return int(box[0])
+
+    def exchange(self, mine: torch.Tensor):
+        """``mine``: this rank's prediction.  Returns ``(cond, uncond)``, identical on both ranks."""
+        mine = mine.contiguous()
+        if self._buf is None or self._buf.shape[1:] != mine.shape or self._buf.dtype != mine.dtype \
+                or self._buf.device != mine.device:
+            self._buf = torch.empty((2,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+        if mine.is_cuda and dist.get_backend(self.group) == "gloo":
+            # gloo has no device all-gather: stage through the host (the 2-processes-on-one-GPU test; RCCL is the
+            # production backend and gathers device to device)
+            host = torch.empty(self._buf.shape, dtype=mine.dtype)
+            dist.all_gather([host[0], host[1]], mine.cpu(), group=self.group)
+            self._buf.copy_(host)
+        else:
+            dist.all_gather([self._buf[0], self._buf[1]], mine, group=self.group)
+        return self._buf[0], self._buf[1]

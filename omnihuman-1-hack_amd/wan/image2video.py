@@ -98,10 +98,12 @@ class WanI2V:
     def generate(self, input_prompt, img, max_area=720 * 1280, frame_num=81, shift=5.0, sample_solver="unipc",
                  sampling_steps=40, guide_scale=5.0, n_prompt="", seed=-1, offload_model=True,
                  context: Optional[List[torch.Tensor]] = None, context_null: Optional[List[torch.Tensor]] = None,
-                 clip_fea: Optional[torch.Tensor] = None, return_latent: bool = False, batched_cfg: bool = True):
+                 clip_fea: Optional[torch.Tensor] = None, return_latent: bool = False, batched_cfg: bool = True,
+                 cfg_split=None):
         r"""image2video.py:129-347.  ``img``: PIL image or float tensor [3, H, W] in [0, 1].  Returns the video
         ``[3, N, H, W]`` on rank 0 (else None).  (The reference hard-codes 21 latent / 81 pixel frames in the
-        noise and mask shapes, :196-203; here they follow ``frame_num`` and coincide at the default 81.)"""
+        noise and mask shapes, :196-203; here they follow ``frame_num`` and coincide at the default 81.)
+        ``cfg_split``: a ``parallel.CFGPairSplit`` — the two CFG branches of this clip on two GPUs (see WanT2V)."""
         img = _to_tensor(img).sub_(0.5).div_(0.5).to(self.device)
         F = frame_num
         T_lat = (F - 1) // self.vae_stride[0] + 1
@@ -117,6 +119,8 @@ class WanI2V:
         max_seq_len = int(math.ceil(max_seq_len / self.sp_size)) * self.sp_size
 
         seed = seed if seed >= 0 else random.randint(0, sys.maxsize)
+        if cfg_split is not None:
+            seed = cfg_split.sync_seed(seed)
         seed_g = torch.Generator(device=self.device)
         seed_g.manual_seed(seed)
         noise = torch.randn(16, T_lat, lat_h, lat_w, dtype=torch.float32, generator=seed_g, device=self.device)
@@ -161,14 +165,21 @@ class WanI2V:
             # cond / uncond as one forward on a batch of two where the operands stay below the kernels' 2 GiB limit
             # (see WanT2V.generate); bit-identical to two calls
             batched = batched_cfg and 2 * (max_seq_len + 128) * getattr(self.model, "ffn_dim", 0) * 2 < 0x7fffffff
-            if batched:
+            if cfg_split is not None:
+                batched = False
+                mine = self.model.encode_context([context[0]] if cfg_split.runs_conditional else context_null,
+                                                 clip_fea=clip_context)
+            elif batched:
                 both = self.model.encode_context([context[0], context_null[0]],
                                                  clip_fea=torch.cat([clip_context, clip_context]))
             else:
                 arg_c = self.model.encode_context([context[0]], clip_fea=clip_context)
                 arg_null = self.model.encode_context(context_null, clip_fea=clip_context)
             for t in timesteps:
-                if batched:
+                if cfg_split is not None:
+                    cond, uncond = cfg_split.exchange(self.model(
+                        [latent], t=torch.stack([t]).to(self.device), context=mine, seq_len=max_seq_len, y=[y])[0])
+                elif batched:
                     cond, uncond = self.model([latent, latent], t=torch.stack([t, t]).to(self.device), context=both,
                                               seq_len=max_seq_len, y=[y, y])
                 else:

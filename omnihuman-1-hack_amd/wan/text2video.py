@@ -70,8 +70,11 @@ class WanT2V:
     def generate(self, input_prompt, size=(720, 512), frame_num=81, shift=5.0, sample_solver="unipc",
                  sampling_steps=50, guide_scale=5.0, n_prompt="", seed=-1, offload_model=True,
                  context: Optional[List[torch.Tensor]] = None, context_null: Optional[List[torch.Tensor]] = None,
-                 return_latent: bool = False, batched_cfg: bool = True):
-        r"""text2video.py:112-269.  Returns the video ``[3, N, H, W]`` on rank 0 (else None)."""
+                 return_latent: bool = False, batched_cfg: bool = True, cfg_split=None):
+        r"""text2video.py:112-269.  Returns the video ``[3, N, H, W]`` on rank 0 (else None).
+
+        ``cfg_split``: a ``parallel.CFGPairSplit`` — this clip's two CFG branches run on two GPUs, one all-gather
+        of the velocity predictions per step; every rank of the pair passes the same arguments."""
         F = frame_num
         target_shape = (self.vae.model.z_dim, (F - 1) // self.vae_stride[0] + 1, size[1] // self.vae_stride[1],
                         size[0] // self.vae_stride[2])
@@ -80,6 +83,8 @@ class WanT2V:
         if n_prompt == "":
             n_prompt = self.sample_neg_prompt
         seed = seed if seed >= 0 else random.randint(0, sys.maxsize)
+        if cfg_split is not None:
+            seed = cfg_split.sync_seed(seed)
         seed_g = torch.Generator(device=self.device)
         seed_g.manual_seed(seed)
         if context is None:
@@ -110,12 +115,18 @@ class WanT2V:
             # batch of two (same kernels on twice the rows, bit-identical outputs) unless that would push a GEMM
             # operand past the kernels' 2 GiB limit (14B at 720p); ``batched_cfg=False`` keeps two calls.
             batched = batched_cfg and 2 * (seq_len + 128) * getattr(self.model, "ffn_dim", 0) * 2 < 0x7fffffff
-            if batched:
+            if cfg_split is not None:
+                batched = False
+                mine = self.model.encode_context(context if cfg_split.runs_conditional else context_null)
+            elif batched:
                 both = self.model.encode_context([context[0], context_null[0]])
             else:
                 context, context_null = self.model.encode_context(context), self.model.encode_context(context_null)
             for t in timesteps:
-                if batched:
+                if cfg_split is not None:
+                    cond, uncond = cfg_split.exchange(
+                        self.model(latents, t=torch.stack([t]), context=mine, seq_len=seq_len)[0])
+                elif batched:
                     cond, uncond = self.model([latents[0], latents[0]], t=torch.stack([t, t]), context=both,
                                               seq_len=seq_len)
                 else:

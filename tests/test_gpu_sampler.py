@@ -160,3 +160,67 @@ def test_wan_i2v_generate_tiny_matches_oracle():
     assert rel_rms(lat, ref) < 3e-2                 # bf16 VAE encoder feeding 6 chained bf16 forwards
     vid = pipe.generate("", img, sample_solver="dpm++", **kw)
     assert vid.shape == (3, 5, h, w) and bool(torch.isfinite(vid).all()) and float(vid.abs().max()) <= 1.0
+
+
+def _tiny_t2v(rank=0):
+    from oracle import detgen, wan_dit_oracle as O
+    wan = importlib.import_module(PKG + ".wan")
+    cfgs = importlib.import_module(PKG + ".wan.configs")
+    t2v = importlib.import_module(PKG + ".wan.text2video")
+    vae_mod = importlib.import_module(PKG + ".wan.modules.vae")
+    kw = dict(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64, text_len=32, freq_dim=64)
+    model = wan.modules.model.WanModel(**kw)
+    model.load_state_dict(O.synth_state_dict(O.DiTConfig(**kw), "t2vgen"))
+    vae = vae_mod.WanVAE(vae_pth=None, device="cuda", dim=16)
+    pipe = t2v.WanT2V(cfgs.t2v_1_3B, checkpoint_dir="", model=model, vae=vae, rank=rank)
+    args = dict(size=(64, 48), frame_num=5, shift=3.0, sampling_steps=4, guide_scale=4.0, return_latent=True,
+                context=[torch.from_numpy(detgen.normalish("t2vgen/c", (9, 64)))],
+                context_null=[torch.from_numpy(detgen.normalish("t2vgen/n", (21, 64)))])
+    return pipe, args
+
+
+def _cfg_split_worker(rank, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        par = importlib.import_module(PKG + ".parallel")
+        pipe, args = _tiny_t2v(rank)
+        split = par.CFGPairSplit()
+        out = {}
+        for solver in ("unipc", "dpm++"):
+            got = pipe.generate("", seed=11, sample_solver=solver, cfg_split=split, **args)
+            assert (got is None) == (rank != 0)
+            if got is not None:
+                out[solver] = got.cpu().numpy()
+        q.put((rank, "ok", out))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()[-1500:], None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cfg_pair_split_over_two_processes_equals_single_gpu():
+    """one clip's conditional / unconditional forwards on two ranks, one all-gather per step
+    (parallel.CFGPairSplit), = the single-GPU generate() bit for bit.  The two processes share cuda:0 over gloo
+    (RCCL refuses two ranks on one device; the collective is staged through the host there)."""
+    import socket
+    import torch.multiprocessing as mp
+    pipe, args = _tiny_t2v()
+    ref = {s: pipe.generate("", seed=11, sample_solver=s, batched_cfg=False, **args).cpu().numpy()
+           for s in ("unipc", "dpm++")}
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cfg_split_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    assert [r[1] for r in res] == ["ok", "ok"], res
+    for s in ("unipc", "dpm++"):
+        assert np.array_equal(res[0][2][s], ref[s]), s

@@ -1,5 +1,6 @@
 """CPU, world_size 2 over gloo: the data-parallel gradient reducer of the training step
-(omnihuman-1-hack_amd/parallel.py) — bucketing, overlap hooks, unused parameters, no_sync."""
+(omnihuman-1-hack_amd/parallel.py) — bucketing, overlap hooks, unused parameters, no_sync — and the exchange step
+of a CFG pair split over two ranks."""
 import importlib.util
 import os
 import socket
@@ -79,3 +80,49 @@ def test_bucketed_grad_allreduce_gloo_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def _cfg_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        par = _load_parallel()
+        if world != 2:
+            with pytest.raises(ValueError):
+                par.CFGPairSplit()
+            q.put((rank, "ok"))
+            return
+        split = par.CFGPairSplit()
+        assert split.runs_conditional == (rank == 0)
+        assert split.sync_seed(1000 + rank) == 1000                      # both ranks draw rank 0's noise
+        # a toy "denoising loop": each rank evaluates only its branch, both apply the same update
+        x = torch.linspace(-1, 1, 16 * 2 * 6 * 8).reshape(16, 2, 6, 8)
+        branch = (lambda v: torch.sin(v) * 0.5) if split.runs_conditional else (lambda v: torch.cos(v) * 0.25)
+        ref = x.clone()
+        for _ in range(3):
+            cond, uncond = split.exchange(branch(x))
+            x = x - 0.1 * (uncond + 4.0 * (cond - uncond))
+            c, u = torch.sin(ref) * 0.5, torch.cos(ref) * 0.25
+            ref = ref - 0.1 * (u + 4.0 * (c - u))
+        assert torch.equal(x, ref)                                        # = the single-process loop, bit for bit
+        cond, _ = split.exchange(torch.full((3,), float(rank)))           # a new shape re-allocates the buffer
+        assert cond.shape == (3,) and float(cond[0]) == 0.0
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_cfg_pair_split_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cfg_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
