@@ -1,0 +1,165 @@
+"""The hot path at BASELINE.json's FULL sizes (Wan2.1-T2V-1.3B, 81 frames 480x832: S = 32 760 tokens, latent
+[16,21,60,104]) where the CPU oracle takes minutes per block: checked through properties that do not depend on the
+size — sampled rows against the oracle's arithmetic, exact homogeneity / row-permutation equivariance of the GEMM,
+softmax rows summing to one, key-permutation invariance, batch / padding invariance of the DiT forward, temporal
+causality of the chunked VAE — plus the sampler update on the full latent against the oracle."""
+import importlib
+import math
+
+import pytest
+import torch
+
+from conftest import rel_rms
+
+pytestmark = pytest.mark.gpu
+PKG = "omnihuman-1-hack_amd"
+S_FULL = 21 * 30 * 52                                  # 32 760
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+def _vt(v, B, Lk, H, D):
+    Lp = (Lk + 63) // 64 * 64
+    vt = torch.zeros(B, H * D, Lp, dtype=torch.bfloat16, device="cuda")
+    vt[:, :, :Lk] = v.reshape(B, Lk, H * D).transpose(1, 2)
+    return vt
+
+
+def test_self_attention_full_size(ops, monkeypatch):
+    """One self-attention launch of the benchmark (12 heads x 32 760 x 32 760, D = 128; attention.py:96-127)."""
+    monkeypatch.setenv("OMH_ATTN_KERNEL", "pp")          # what the dispatch picks at this size; pinned for property (4)
+    torch.manual_seed(5)
+    B, H, L, D = 1, 12, S_FULL, 128
+    q = _bf(torch.randn(B, L, H, D, device="cuda"))
+    k = _bf(torch.randn(B, L, H, D, device="cuda"))
+    v = _bf(torch.randn(B, L, H, D, device="cuda"))
+    out = ops.flash_attn(q, k, _vt(v, B, L, H, D), None)
+    assert out.shape == (B, L, H, D) and bool(torch.isfinite(out.float()).all())
+    # (1) sampled query rows (first / last tiles and random ones) of three heads against softmax(q k^T / sqrt(D)) v
+    rows = torch.tensor([0, 1, 31, 255, 256, 16383, L - 257, L - 2, L - 1] +
+                        torch.randint(0, L, (40,), generator=torch.Generator().manual_seed(1)).tolist(), device="cuda")
+    for h in (0, 5, 11):
+        s = (q[0, rows, h].float() @ k[0, :, h].float().t()) * D ** -0.5
+        ref = torch.softmax(s, -1) @ v[0, :, h].float()
+        got = out[0, rows, h].float()
+        assert rel_rms(got, ref) < 8e-3 and float((got - ref).abs().max()) < 3e-2, h
+    # (2) rows of P sum to one: with V = 1 the output is 1 for every query (bf16 rounding of P only)
+    ones = torch.ones_like(v)
+    o1 = ops.flash_attn(q, k, _vt(ones, B, L, H, D), None).float()
+    assert float((o1 - 1.0).abs().max()) < 8e-3
+    # (3) keys are a set: permuting (k, v) rows together changes only the summation order
+    perm = torch.randperm(L, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+    o2 = ops.flash_attn(q, k[:, perm].contiguous(), _vt(v[:, perm].contiguous(), B, L, H, D), None)
+    assert rel_rms(o2.float(), out.float()) < 6e-3
+    # (4) queries are independent: a launch on a slice of the queries returns the same rows, bit for bit
+    o3 = ops.flash_attn(q[:, 4096:8192].contiguous(), k, _vt(v, B, L, H, D), None)
+    assert torch.equal(o3, out[:, 4096:8192])
+
+
+@pytest.mark.parametrize("N,K,epi", [(8960, 1536, "gelu"), (1536, 8960, "f32"), (3072, 1536, "f32")])
+def test_gemm_full_size(ops, N, K, epi):
+    """The DiT's linear layers at M = S = 32 760 (model.py:176-178,253-258): sampled rows against fp32 arithmetic on
+    the same bf16 operands, and two exact properties of fp32-accumulated products."""
+    torch.manual_seed(N + K)
+    M = S_FULL
+    a = _bf(torch.randn(M, K, device="cuda"))
+    w = _bf(torch.randn(N, K, device="cuda") / math.sqrt(K))
+    bias = torch.randn(N, device="cuda")
+    rows = torch.tensor([0, 255, 256, M - 1] + torch.randint(0, M, (60,), generator=torch.Generator().manual_seed(3)).tolist(),
+                        device="cuda")
+    ref = a[rows].float() @ w.float().t() + bias
+    if epi == "gelu":
+        out = ops.gemm(a, w, bias=bias, epilogue=ops.EPI_GELU_BF16)
+        assert rel_rms(out[rows].float(), torch.nn.functional.gelu(ref, approximate="tanh")) < 5e-3
+        return
+    out = ops.gemm(a, w, bias=bias, epilogue=ops.EPI_F32)
+    assert rel_rms(out[rows], ref) < 2e-5
+    # homogeneity: scaling A by a power of two scales every partial sum exactly
+    out2 = ops.gemm(_bf(a.float() * 4.0), w, epilogue=ops.EPI_F32)
+    plain = ops.gemm(a, w, epilogue=ops.EPI_F32)
+    assert torch.equal(out2, plain * 4.0)
+    # a row of C depends on its own row of A only, and on no other row's position in the tile
+    perm = torch.randperm(M, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
+    assert torch.equal(ops.gemm(a[perm].contiguous(), w, epilogue=ops.EPI_F32), plain[perm])
+
+
+@pytest.fixture(scope="module")
+def wan_1_3b():
+    model_mod = importlib.import_module(PKG + ".wan.modules.model")
+    cfgs = importlib.import_module(PKG + ".wan.configs")
+    torch.manual_seed(1234)
+    with torch.device("cuda"):
+        m = model_mod.WanModel(**cfgs.dit_kwargs(cfgs.t2v_1_3B))
+        torch.nn.init.xavier_uniform_(m.head.head.weight)      # zero-init in the reference (model.py:612)
+    return m.eval().requires_grad_(False)
+
+
+def test_dit_forward_full_size_invariances(wan_1_3b):
+    """WanModel.forward on the benchmark's latent [16,21,60,104] (model.py:502-563): a sample's output depends
+    neither on the batch it is in nor on the padded sequence length."""
+    model = wan_1_3b
+    g = torch.Generator(device="cuda").manual_seed(8)
+    x = torch.randn(16, 21, 60, 104, device="cuda", generator=g)
+    x2 = torch.randn(16, 21, 60, 104, device="cuda", generator=g)
+    ctx = torch.randn(120, 4096, device="cuda", generator=g)
+    ctx2 = torch.randn(40, 4096, device="cuda", generator=g)
+    t = torch.tensor([875.0], device="cuda")
+    with torch.no_grad():
+        one = model([x], t, [ctx], S_FULL)[0]
+        assert one.shape == (16, 21, 60, 104) and one.dtype == torch.float32 and bool(torch.isfinite(one).all())
+        assert float(one.abs().mean()) > 1e-3
+        again = model([x], t, [ctx], S_FULL)[0]
+        assert torch.equal(one, again)                                         # repeatable bit for bit
+        pair = model([x, x2], torch.cat([t, t]), [ctx, ctx2], S_FULL)
+        assert torch.equal(pair[0], one)                                       # batch of two = two batches of one
+        other = model([x2], t, [ctx2], S_FULL)[0]
+        assert torch.equal(pair[1], other)
+        padded = model([x], t, [ctx], S_FULL + 520)[0]                         # seq_len > S: zero rows, masked keys
+        assert rel_rms(padded, one) < 2e-3
+        assert rel_rms(other, one) > 0.1                                       # and the inputs do matter
+
+
+def test_sampler_step_full_size_matches_oracle():
+    """Fused CFG + UniPC update on the full latent against the oracle scheduler (fm_solvers_unipc.py:279-739)."""
+    from oracle import sampler_oracle as SO
+    sched_mod = importlib.import_module(PKG + ".wan.utils.fm_solvers_unipc")
+    g = torch.Generator().manual_seed(3)
+    shape = (16, 21, 60, 104)
+    x0 = torch.randn(shape, generator=g)
+    preds = [(torch.randn(shape, generator=g), torch.randn(shape, generator=g)) for _ in range(4)]
+    it = iter(preds)
+    ref = SO.sample_loop(lambda x, t: next(it), x0, 4, 5.0, 5.0, solver="unipc")
+    s = sched_mod.FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+    s.set_timesteps(4, device="cuda", shift=5.0)
+    s.set_begin_index(0)
+    x = x0.cuda()
+    for c, u in preds:
+        x = s.step_cfg(c.cuda(), u.cuda(), 5.0, x)
+    assert rel_rms(x, ref) < 1e-5
+
+
+def test_vae_full_size_temporal_causality(monkeypatch):
+    """Chunked causal decode / encode at 480x832 (vae.py:516-568): frame chunks see only the past, so a prefix of
+    the clip decodes (encodes) to the same leading frames as the whole clip — through the sliding-window history.
+    The conv tile family is pinned: the dispatch moves the latent-resolution convs from the 128x128 kernel to the
+    wide one once 4 latent frames are batched (another summation order: prefix and whole clip then differ by
+    bf16 rounding noise, 1.4 % after 30 layers, each as close to the oracle as the other —
+    tools/vae_causality_probe2.py)."""
+    monkeypatch.setenv("OMH_CONV_TILE", "wide")
+    vae_mod = importlib.import_module(PKG + ".wan.modules.vae")
+    torch.manual_seed(4321)
+    vae = vae_mod.WanVAE(vae_pth=None, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(6)
+    z = torch.randn(16, 4, 60, 104, device="cuda", generator=g)
+    full = vae.decode([z])[0]
+    assert full.shape == (3, 13, 480, 832) and bool(torch.isfinite(full).all()) and float(full.abs().max()) <= 1.0
+    head = vae.decode([z[:, :2].contiguous()])[0]
+    assert head.shape == (3, 5, 480, 832)
+    assert torch.equal(head, full[:, :5])
+    video = full.clamp(-1, 1)
+    mu = vae.encode([video])[0]
+    assert mu.shape == (16, 4, 60, 104) and bool(torch.isfinite(mu).all())
+    mu_head = vae.encode([video[:, :5].contiguous()])[0]
+    assert torch.equal(mu_head, mu[:, :2])
