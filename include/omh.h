@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OMH_ABI_VERSION 1
+#define OMH_ABI_VERSION 2
 
 #define OMH_E_BADARG   (-1)   /* null pointer / non-positive size             */
 #define OMH_E_ALIGN    (-2)   /* pointer or leading dimension not aligned     */
@@ -73,6 +73,10 @@ typedef struct omh_gemm_args {
        either pointer may be NULL (treated as 0).                                 */
     const float* gate0; const float* gate1;
     int64_t gate1_stride; int32_t gate_rows; float gate_const;
+    /* != 0: B is K-MAJOR, [K,N] bf16 row-major (ldb >= N, N a multiple of 8):  C = epi(sum_k A[m][k] B[k][n]).
+       The input gradient of an nn.Linear, dx = dy W, on the weight as stored [out,in] (autograd of the Linears
+       above under distilled_trainer.py:289-301) — no transposed weight copy.  Epilogues BF16 / F32 / F32_ACCUM. */
+    int32_t b_kmajor;
 } omh_gemm_args;
 
 int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream);

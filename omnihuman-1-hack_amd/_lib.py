@@ -49,7 +49,8 @@ class GemmArgs(C.Structure):
                 ("epilogue", i32), ("bias_mode", i32),
                 ("bias", vp),
                 ("gate0", vp), ("gate1", vp),
-                ("gate1_stride", i64), ("gate_rows", i32), ("gate_const", f32)]
+                ("gate1_stride", i64), ("gate_rows", i32), ("gate_const", f32),
+                ("b_kmajor", i32)]
 
 
 class GemmTnArgs(C.Structure):
@@ -147,5 +148,5 @@ def check(rc: int, what: str):
         raise OmhError(f"{what} failed: {_ERR.get(rc, 'hipError ' + str(rc))}")
 
 
-if lib.omh_abi_version() != 1:  # pragma: no cover
+if lib.omh_abi_version() != 2:  # pragma: no cover
     raise OmhError("libomh.so ABI version mismatch")

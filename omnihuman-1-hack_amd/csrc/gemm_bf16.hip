@@ -31,6 +31,9 @@
 namespace {
 
 constexpr int BK = 64;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((address_space(3))) bf16x4_t* lds_bf4_ptr;
+typedef __attribute__((address_space(3))) unsigned char* lds_u8_ptr;
 
 struct GemmGeom { int tiles_m, tiles_n, group_m; };
 
@@ -39,11 +42,21 @@ __device__ __forceinline__ uint32_t lds_slot_addr(int row, int slot) {
 }
 
 // WM x WN waves, each owning MT x NT 32x32 MFMA tiles; STAGES-deep LDS ring
-template <int EPI, int WM, int WN, int MT, int NT, int STAGES>
+// BKM: B is K-MAJOR ([K, N] row-major: dx = dy W with W as stored, the dgrad of every nn.Linear).  Its tile is then
+// staged as [64 k][BN n] and the fragments (lane = row n, 8 consecutive k) are gathered with ds_read_b64_tr_b16,
+// exactly as in gemm_tn.hip (which documents the addressing); everything else is shared.  Measured (tools/
+// gemm_nn_probe.py): 15-30 % slower than the row-major-B kernel on the same product (6240 x 1536 x 8960: 233 vs 182 us)
+// and all of it is the transposing read — with plain ds_read_b64 at the same addresses the two kernels tie.  The
+// 256x256 tile already spends 384 of every 512 MFMA clocks on LDS reads; ds_read_b64_tr_b16 moves half the bytes
+// of a ds_read_b128 in the same LDS time, which pushes the LDS pipe past the matrix pipe.  A weight transpose
+// costs 10-18 us once per step, so the training step keeps transposed weight copies (OMH_DGRAD=nn selects this).
+template <int EPI, int WM, int WN, int MT, int NT, int STAGES, bool BKM = false>
 __global__ __launch_bounds__(64 * WM * WN, 2)
 void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+    constexpr int SLB = BN / 8, ROWB = BN * 2;                     // k-major B tile: 16-byte slots per k row, pitch
+    static_assert(!BKM || (BK * SLB / THREADS == 4 && BM * 8 / THREADS == 4), "k-major B: 4 chunks per thread");
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int CA = BM * 8 / THREADS, CB = BN * 8 / THREADS;     // 16-byte chunks per thread and stage
     static_assert(CA == CB && (CA == 4 || CA == 2), "staging code assumes 2 or 4 chunks per operand per thread");
@@ -70,16 +83,39 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
         (void*)A, 0, (int)((((int64_t)p.M - 1) * p.lda + p.K) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)B, 0, (int)((((int64_t)p.N - 1) * p.ldb + p.K) * 2), 0x00020000);
-    uint32_t voff_a[4], voff_b[4];
-    int lslot[4];
+        (void*)B, 0, BKM ? (int)((((int64_t)p.K - 1) * p.ldb + p.N) * 2) : (int)((((int64_t)p.N - 1) * p.ldb + p.K) * 2),
+        0x00020000);
+    uint32_t voff_a[4], voff_b[4];          // fixed extents: a template-dependent extent loses hipcc's host stub
+    int lslot[4], krow_b[4];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int c = tid + THREADS * j;
         const int row = c >> 3;
         lslot[j] = (c & 7) ^ ((row >> 1) & 7);
         voff_a[j] = (m0 + row < p.M) ? (uint32_t)((((int64_t)(m0 + row)) * p.lda + lslot[j] * 8) * 2) : 0x80000000u;
-        voff_b[j] = (n0 + row < p.N) ? (uint32_t)((((int64_t)(n0 + row)) * p.ldb + lslot[j] * 8) * 2) : 0x80000000u;
+        if (BKM) {      // chunk c = (k row c / SLB, physical slot c % SLB), fetched from logical slot ^ ((row & 3) << 2)
+            krow_b[j] = c / SLB;
+            const int lb = (c % SLB) ^ ((krow_b[j] & 3) << 2);
+            voff_b[j] = (n0 + lb * 8 < p.N) ? (uint32_t)(((int64_t)krow_b[j] * p.ldb + n0 + lb * 8) * 2) : 0x80000000u;
+        } else {
+            krow_b[j] = 0;
+            voff_b[j] = (n0 + row < p.N) ? (uint32_t)((((int64_t)(n0 + row)) * p.ldb + lslot[j] * 8) * 2) : 0x80000000u;
+        }
+    }
+    const uint32_t kstep_b = (uint32_t)(BK * p.ldb * 2);
+    // k-major B fragment gather addresses (gemm_tn.hip): 16-lane group gq, i = lane & 15, e = i >> 2, q = i & 3
+    uint32_t fb[NT][2];
+    {
+        const int gq = lane >> 4, l15 = lane & 15, fe = l15 >> 2, fq = l15 & 3;
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const int row = 8 * (gq >> 1) + 4 * part + fe;            // + 16 KK per k group
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int l = ((wn * NT + i) * 32 + 16 * (gq & 1) + 4 * fq) >> 3;
+                fb[i][part] = (uint32_t)(row * ROWB + ((l ^ (fe << 2)) << 4) + (fq & 1) * 8);
+            }
+        }
     }
     // wave-uniform LDS byte offset of this wave's 1 KiB piece of chunk group j
     const int wave_lds = __builtin_amdgcn_readfirstlane(wave) * 1024;
@@ -107,7 +143,13 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
         unsigned char* xb_ = xa_ + A_BYTES;                                                    \
         _Pragma("unroll") for (int j_ = 0; j_ < NCH; ++j_) {                                   \
             GEMM_DMA1(rsrc_a, voff_a, j_, xa_)                                                 \
-            GEMM_DMA1(rsrc_b, voff_b, j_, xb_)                                                 \
+            if (BKM) {                                                                         \
+                const uint32_t ob_ = (k0_ + krow_b[j_] < p.K) ? voff_b[j_] + (uint32_t)(KT_) * kstep_b : 0x80000000u; \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(xb_ + wave_lds + j_ * THREADS * 16), 16, \
+                                                         ob_, 0, 0, 0);                        \
+            } else {                                                                           \
+                GEMM_DMA1(rsrc_b, voff_b, j_, xb_)                                             \
+            }                                                                                  \
         }                                                                                      \
     }
 
@@ -120,8 +162,17 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
     {                                                                                          \
         const unsigned char* xa_ = smem + (STAGE) * STAGE_BYTES;                               \
         const unsigned char* xb_ = xa_ + A_BYTES;                                              \
-        _Pragma("unroll") for (int i_ = 0; i_ < NT; ++i_)                                      \
-            WF[i_] = *(const bf16x8*)(xb_ + lds_slot_addr((wn * NT + i_) * 32 + li, 2 * (KK) + lh)); \
+        _Pragma("unroll") for (int i_ = 0; i_ < NT; ++i_) {                                    \
+            if (BKM) {                                                                  \
+                const bf16x4_t lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                 \
+                    (lds_bf4_ptr)((lds_u8_ptr)xb_ + fb[i_][0] + (KK) * 16 * ROWB));            \
+                const bf16x4_t hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                 \
+                    (lds_bf4_ptr)((lds_u8_ptr)xb_ + fb[i_][1] + (KK) * 16 * ROWB));            \
+                WF[i_] = __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7);            \
+            } else {                                                                           \
+                WF[i_] = *(const bf16x8*)(xb_ + lds_slot_addr((wn * NT + i_) * 32 + li, 2 * (KK) + lh)); \
+            }                                                                                  \
+        }                                                                                      \
         _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                      \
             XF[i_] = *(const bf16x8*)(xa_ + lds_slot_addr((wm * MT + i_) * 32 + li, 2 * (KK) + lh)); \
     }
@@ -131,7 +182,11 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
             acc[im_][in_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[in_], XF[im_], acc[im_][in_], 0, 0, 0);
     // one MFMA, then one LDS read, ... so the reads hide under the matrix pipe
 #define GEMM_INTERLEAVE()                                                                      \
-    _Pragma("unroll") for (int s_ = 0; s_ < MT + NT; ++s_) {                                   \
+    _Pragma("unroll") for (int s_ = 0; s_ < NT; ++s_) {       /* B fragments: two transposing reads each if BKM */ \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
+        __builtin_amdgcn_sched_group_barrier(0x100, BKM ? 2 : 1, 0);                           \
+    }                                                                                          \
+    _Pragma("unroll") for (int s_ = 0; s_ < MT; ++s_) {                                        \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                     \
     }                                                                                          \
@@ -292,11 +347,11 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
     }
 }
 
-template <int EPI, int WM, int WN, int MT, int NT, int STAGES>
+template <int EPI, int WM, int WN, int MT, int NT, int STAGES, bool BKM = false>
 int launch_cfg(const omh_gemm_args& a, hipStream_t s) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     constexpr int LDS = STAGES * (BM + BN) * BK * 2;
-    auto kern = gemm_bf16_nt_kernel<EPI, WM, WN, MT, NT, STAGES>;
+    auto kern = gemm_bf16_nt_kernel<EPI, WM, WN, MT, NT, STAGES, BKM>;
     static bool attr_set = false;            // > 64 KiB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -316,7 +371,7 @@ int launch_cfg(const omh_gemm_args& a, hipStream_t s) {
     return omh_launch_status();
 }
 
-template <int EPI>
+template <int EPI, bool BKM = false>
 int launch(const omh_gemm_args& a, hipStream_t s) {
     // Tile configuration by estimated time = sum over the rounds the tiles take on the chip, with per-round times
     // measured on MI355X (tools/gemm_tile_probe.py; k = K / 1536; a round is "light" when few workgroups share the
@@ -332,14 +387,15 @@ int launch(const omh_gemm_args& a, hipStream_t s) {
     const int64_t mid_tiles = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
     const char* force = getenv("OMH_GEMM_TILE");               // "big" / "small" / "tiny": test / benchmarking override
     if (force) {
-        if (force[0] == 'b') return launch_cfg<EPI, 2, 4, 4, 2, 2>(a, s);
-        if (force[0] == 't') return launch_cfg<EPI, 2, 2, 1, 1, 2>(a, s);
-        return launch_cfg<EPI, 2, 2, 2, 2, 2>(a, s);
+        if (force[0] == 'b') return launch_cfg<EPI, 2, 4, 4, 2, 2, BKM>(a, s);
+        if (force[0] == 't' && !BKM) return launch_cfg<EPI, 2, 2, 1, 1, 2>(a, s);
+        return launch_cfg<EPI, 2, 2, 2, 2, 2, BKM>(a, s);
     }
+    if (BKM && mid_tiles < 256) return launch_cfg<EPI, 2, 2, 2, 2, 2, BKM>(a, s);   // no 64x64 k-major variant
     if (mid_tiles < 256) return launch_cfg<EPI, 2, 2, 1, 1, 2>(a, s);
     static const char* rule = getenv("OMH_GEMM_RULE");         // "old": the former rule, for A/B timing on one box
     if (rule && rule[0] == 'o')
-        return big_tiles >= 256 ? launch_cfg<EPI, 2, 4, 4, 2, 2>(a, s) : launch_cfg<EPI, 2, 2, 2, 2, 2>(a, s);
+        return big_tiles >= 256 ? launch_cfg<EPI, 2, 4, 4, 2, 2, BKM>(a, s) : launch_cfg<EPI, 2, 2, 2, 2, 2, BKM>(a, s);
     const float k = (float)a.K * (1.0f / 1536.0f);
     auto cost = [](int64_t tiles, int64_t slots, int64_t light_max, float light, float heavy) {
         const int64_t full = tiles / slots, last = tiles % slots;
@@ -347,8 +403,8 @@ int launch(const omh_gemm_args& a, hipStream_t s) {
     };
     const float cost_big = cost(big_tiles, 256, 192, 9.0f + 27.5f * k, 9.0f + 32.0f * k);
     const float cost_small = cost(mid_tiles, 512, 160, 4.0f + 15.5f * k, 5.0f + 21.0f * k);
-    if (cost_big <= cost_small) return launch_cfg<EPI, 2, 4, 4, 2, 2>(a, s);
-    return launch_cfg<EPI, 2, 2, 2, 2, 2>(a, s);
+    if (cost_big <= cost_small) return launch_cfg<EPI, 2, 4, 4, 2, 2, BKM>(a, s);
+    return launch_cfg<EPI, 2, 2, 2, 2, 2, BKM>(a, s);
 }
 
 }  // namespace
@@ -358,6 +414,20 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
     const omh_gemm_args& a = *args;
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.batch <= 0) return OMH_E_BADARG;
     if ((a.K & 7) || (a.lda & 7) || (a.ldb & 7)) return OMH_E_ALIGN;
+    if (a.b_kmajor) {                       // B = [K, N] row-major: dx = dy W on the weight as stored
+        if ((a.N & 7) || a.ldb < a.N) return OMH_E_ALIGN;
+        if (((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15) || ((uintptr_t)a.C & 15)) return OMH_E_ALIGN;
+        if ((a.strideA & 7) || (a.strideB & 7) || (a.strideC & 3)) return OMH_E_ALIGN;
+        if (((int64_t)a.M + 128) * a.lda * 2 >= 0x7fffffffLL || ((int64_t)a.K + 64) * a.ldb * 2 >= 0x7fffffffLL)
+            return OMH_E_SHAPE;
+        hipStream_t s = (hipStream_t)stream;
+        switch (a.epilogue) {
+            case OMH_EPI_BF16:      return launch<OMH_EPI_BF16, true>(a, s);
+            case OMH_EPI_F32:       return launch<OMH_EPI_F32, true>(a, s);
+            case OMH_EPI_F32_ACCUM: return launch<OMH_EPI_F32_ACCUM, true>(a, s);
+            default: return OMH_E_SHAPE;     // the backward needs no other epilogue on a k-major B
+        }
+    }
     if (((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15) || ((uintptr_t)a.C & 15)) return OMH_E_ALIGN;
     if ((a.strideA & 7) || (a.strideB & 7) || (a.strideC & 3)) return OMH_E_ALIGN;
     if (a.epilogue == OMH_EPI_RESID && a.gate1 && a.gate_rows <= 0) return OMH_E_BADARG;

@@ -41,26 +41,27 @@ def ptr(t: torch.Tensor, elem_off: int = 0):
 
 def gemm_raw(A, B, Cp, M, N, K, lda, ldb, ldc, epilogue, bias=None, bias_mode=BIAS_NONE, batch=1,
              strideA=0, strideB=0, strideC=0, gate0=None, gate1=None, gate1_stride=0, gate_rows=1,
-             gate_const=0.0):
-    """C[m][n] = epi(sum_k A[m][k] B[n][k]); all pointers are c_void_p."""
+             gate_const=0.0, b_kmajor=False):
+    """C[m][n] = epi(sum_k A[m][k] B[n][k])  (b_kmajor: B[k][n], [K, N] row-major); all pointers are c_void_p."""
     a = GemmArgs(A, B, Cp, M, N, K, lda, ldb, ldc, batch, strideA, strideB, strideC, epilogue, bias_mode, bias,
-                 gate0, gate1, gate1_stride, gate_rows, gate_const)
+                 gate0, gate1, gate1_stride, gate_rows, gate_const, int(b_kmajor))
     check(lib.omh_gemm_bf16(C.byref(a), _stream()), "omh_gemm_bf16")
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
-         epilogue: int = EPI_BF16):
-    """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias[N]); a, w bf16 contiguous."""
+         epilogue: int = EPI_BF16, b_kmajor: bool = False):
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias[N]); a, w bf16 contiguous.  ``b_kmajor``: w is [K,N] and
+    out = epi(a @ w + bias) — the input gradient of a Linear on the weight as stored."""
     _dev(a, w, out, bias)
     assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.dim() == 2 and w.dim() == 2
     M, K = a.shape
-    N = w.shape[0]
-    assert w.shape[1] == K and a.stride(1) == 1 and w.stride(1) == 1
+    N = w.shape[1] if b_kmajor else w.shape[0]
+    assert w.shape[0 if b_kmajor else 1] == K and a.stride(1) == 1 and w.stride(1) == 1
     if out is None:
         odt = torch.bfloat16 if epilogue in (EPI_BF16, EPI_GELU_BF16, EPI_GELU_ERF_BF16) else torch.float32
         out = torch.empty(M, N, dtype=odt, device=a.device)
     gemm_raw(_p(a), _p(w), _p(out), M, N, K, a.stride(0), w.stride(0), out.stride(0), epilogue,
-             bias=_p(bias), bias_mode=BIAS_N if bias is not None else BIAS_NONE)
+             bias=_p(bias), bias_mode=BIAS_N if bias is not None else BIAS_NONE, b_kmajor=b_kmajor)
     return out
 
 

@@ -52,9 +52,23 @@ class _State:
         self.d_e0 = self.d_e = self.d_ctx = None
 
 
+# dgrad products dx = dy W: on a transposed bf16 copy of the weight (one transpose per weight and step, cached per
+# weight version) with the row-major-B kernel.  OMH_DGRAD=nn runs them on the weight as stored ([out, in] = k-major
+# B of omh_gemm_bf16) instead — no copies, but measured slower (146.1 vs 143.7 ms per 4-clip step: the transposing
+# LDS read costs more than the ~250 weight transposes, see gemm_bf16.hip), kept for the tests and for A/B timing.
+_DGRAD_NN = os.environ.get("OMH_DGRAD", "nt") == "nn"
+
+
 def _wT(mod, key, weight_bf16):
-    """Transposed bf16 copy [K, N] of a packed [N, K] weight (B operand of the dgrad GEMM)."""
+    """B operand of the dgrad GEMM for a packed [N, K] weight: its transposed bf16 copy [K, N] (cached per weight
+    version), or with OMH_DGRAD=nn the weight itself (k-major B)."""
+    if _DGRAD_NN:
+        return weight_bf16
     return mod._packed.get("T:" + key, (weight_bf16,), lambda: ops.transpose_bf16(weight_bf16))
+
+
+def _wT_once(weight_bf16):
+    return weight_bf16 if _DGRAD_NN else ops.transpose_bf16(weight_bf16)
 
 
 def _wgrad(dy, x, xT=None, out=None):
@@ -79,7 +93,7 @@ def _dgrad_ctx(dy, wT, d_ctx, first, L):
     B, Lc, d = d_ctx.shape
     N = dy.shape[1]
     ops.gemm_raw(ptr(dy), ptr(wT), ptr(d_ctx, first * d), L, d, N, dy.stride(0), wT.stride(0), d, EPI_ACC, batch=B,
-                 strideA=L * dy.stride(0), strideB=0, strideC=Lc * d)
+                 strideA=L * dy.stride(0), strideB=0, strideC=Lc * d, b_kmajor=_DGRAD_NN)
 
 
 class _ZeroArena:
@@ -108,13 +122,13 @@ def _bgrad(dy, arena=None):
 
 
 def _dgrad(dy, wT, out=None, accumulate=False):
-    """dx[R, K] = dy[R, N] @ W[N, K]  with wT = W^T bf16 [K, Np]; fp32 output."""
+    """dx[R, K] = dy[R, N] @ W[N, K]  with wT from _wT (W itself, or W^T bf16 [K, Np]); fp32 output."""
     R, N = dy.shape
-    K = wT.shape[0]
+    K = wT.shape[1] if _DGRAD_NN else wT.shape[0]
     if out is None:
         out = torch.empty(R, K, dtype=torch.float32, device=dy.device)
     ops.gemm_raw(ptr(dy), ptr(wT), ptr(out), R, K, N, dy.stride(0), wT.stride(0), out.stride(0),
-                 EPI_ACC if accumulate else EPI_F32)
+                 EPI_ACC if accumulate else EPI_F32, b_kmajor=_DGRAD_NN)
     return out
 
 
@@ -345,7 +359,7 @@ def _block_backward(model, blk, idx, st, x0, dx):
     dy3 = resid_bwd(y3, 5)
     if not frozen_ffn:
         g["ffn.2.weight"], g["ffn.2.bias"] = _wgrad(dy3, u), _bgrad(dy3, arena)
-        du = ops.gemm(dy3, _wT(blk, "ffn2", w2), epilogue=EPI_BF16)       # [R, ffn]
+        du = ops.gemm(dy3, _wT(blk, "ffn2", w2), epilogue=EPI_BF16, b_kmajor=_DGRAD_NN)       # [R, ffn]
         du_pre = ops.gelu_tanh_bwd(du, u_pre)
         g["ffn.0.weight"], g["ffn.0.bias"] = _wgrad(du_pre, h2), _bgrad(du_pre, arena)
         dh2 = _dgrad(du_pre, _wT(blk, "ffn0", w1))
@@ -355,7 +369,7 @@ def _block_backward(model, blk, idx, st, x0, dx):
     # ---- cross-attention branch: x2 = x1 + y2
     dy2 = resid_bwd(None, None)
     g["cross_attn.o.weight"], g["cross_attn.o.bias"] = _wgrad(dy2, oc), _bgrad(dy2, arena)
-    doc = ops.gemm(dy2, _wT(ca, "o", woc), epilogue=EPI_BF16)
+    doc = ops.gemm(dy2, _wT(ca, "o", woc), epilogue=EPI_BF16, b_kmajor=_DGRAD_NN)
     if _FUSED_ATTN_BWD:
         dqc, dkc, dvc = ops.flash_attn_bwd(qc, kc, vc, oc, doc, lse_ca, fc.ctx_lens32, B, N, S, Lt, D ** -0.5)
     else:
@@ -413,7 +427,7 @@ def _block_backward(model, blk, idx, st, x0, dx):
     # ---- self-attention branch: x1 = x0 + y1 * g2
     dy1 = resid_bwd(y1, 2)
     g["self_attn.o.weight"], g["self_attn.o.bias"] = _wgrad(dy1, o), _bgrad(dy1, arena)
-    do = ops.gemm(dy1, _wT(sa, "o", wo), epilogue=EPI_BF16)
+    do = ops.gemm(dy1, _wT(sa, "o", wo), epilogue=EPI_BF16, b_kmajor=_DGRAD_NN)
     if _FUSED_ATTN_BWD:
         dq, dk, dv = ops.flash_attn_bwd(q, k, v, o, do, lse_sa, fc.seq_lens32, B, N, S, S, D ** -0.5)
     else:
@@ -534,10 +548,10 @@ def _img_emb_backward(model, clip_fea, d_img, g):
     dz3b = ops.cast_bf16(dz3)
     g["img_emb.proj.4.weight"], g["img_emb.proj.4.bias"] = dw4, db4
     g["img_emb.proj.3.weight"], g["img_emb.proj.3.bias"] = _wgrad(dz3b, g1), _bgrad(dz3b)
-    dg1 = ops.gemm(dz3b, ops.transpose_bf16(w3), epilogue=EPI_BF16)
+    dg1 = ops.gemm(dz3b, _wT_once(w3), epilogue=EPI_BF16, b_kmajor=_DGRAD_NN)
     dz1 = ops.gelu_erf_bwd(dg1, z1)
     g["img_emb.proj.1.weight"], g["img_emb.proj.1.bias"] = _wgrad(dz1, h0), _bgrad(dz1)
-    dh0 = _dgrad(dz1, ops.transpose_bf16(w1))
+    dh0 = _dgrad(dz1, _wT_once(w1))
     dx = torch.zeros(rows, cin, dtype=torch.float32, device=dev)      # (gradient w.r.t. the CLIP tokens: not needed)
     dw0, db0 = torch.zeros(cin, dtype=torch.float32, device=dev), torch.zeros(cin, dtype=torch.float32, device=dev)
     ops.layernorm_modulate_bwd_raw(ptr(x), ptr(dh0), ptr(dx), rows, cin, ln0.eps, 0.0, ptr(w0), None, 0, ptr(dw0),
@@ -621,7 +635,7 @@ class _EmbedFn(torch.autograd.Function):
             dctx = st.d_ctx[:, n_img:].contiguous().view(B * model.text_len, d)
             dctx_b = ops.cast_bf16(dctx)
             g["text_embedding.2.weight"], g["text_embedding.2.bias"] = _wgrad(dctx_b, gl), _bgrad(dctx_b)
-            dgl = ops.gemm(dctx_b, ops.transpose_bf16(w2), epilogue=EPI_BF16)
+            dgl = ops.gemm(dctx_b, _wT_once(w2), epilogue=EPI_BF16, b_kmajor=_DGRAD_NN)
             dpre = ops.gelu_tanh_bwd(dgl, pre)
             g["text_embedding.0.weight"], g["text_embedding.0.bias"] = _wgrad(dpre, cin), _bgrad(dpre)
             # ---- image embedding (i2v): the first n_img context rows came from img_emb(clip_fea)

@@ -301,3 +301,50 @@ def test_gemm_tn(ops, M, N, K, pad, tile, monkeypatch):
     idx = (torch.arange(M, device="cuda") * 7 + 3) % K
     sel[idx, torch.arange(M, device="cuda")] = 1.0
     assert torch.equal(ops.gemm_tn(sel, b), b.float()[idx])
+
+
+@pytest.mark.parametrize("M,N,K,pad", [(128, 128, 64, 0), (300, 200, 72, 0), (1560, 1536, 1536, 0), (6240, 1536, 8960, 0),
+                                        (1000, 8960, 1536, 0), (257, 72, 1000, 24), (512, 5120, 1536, 0)])
+@pytest.mark.parametrize("tile", ["big", "small", "auto"])
+def test_gemm_b_kmajor(ops, M, N, K, pad, tile, monkeypatch):
+    """omh_gemm_bf16 with b_kmajor — C = A B on B = [K, N] row-major (dx = dy W on the weight as stored): against
+    fp32 matmul on the same bf16 inputs; ragged M / N / K tails, a strided B, both tile configurations and the cost
+    rule, the three epilogues the backward uses, a batched strided call, and an exact selector pattern."""
+    if tile != "auto":
+        monkeypatch.setenv("OMH_GEMM_TILE", tile)
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    b_full = (torch.randn(K, N + pad, device="cuda", generator=g) / math.sqrt(K)).bfloat16()
+    b = b_full[:, :N]
+    bias = torch.randn(N, device="cuda", generator=g)
+    ref = a.float() @ b.float()
+    c = ops.gemm(a, b, epilogue=ops.EPI_F32, b_kmajor=True)
+    assert rel_rms(c, ref) < 2e-5
+    cb = ops.gemm(a, b, bias=bias, epilogue=ops.EPI_BF16, b_kmajor=True)
+    assert rel_rms(cb.float(), ref + bias) < 4e-3
+    c2 = ops.gemm(a, b, out=c.clone(), epilogue=ops.EPI_F32_ACCUM, b_kmajor=True)
+    assert rel_rms(c2, 2 * ref) < 2e-5
+    # equals the row-major-B kernel on the transposed copy up to summation order
+    assert rel_rms(c, ops.gemm(a, b.t().contiguous(), epilogue=ops.EPI_F32)) < 2e-6
+    # selector: B = one-hot columns picks single columns of A (exact), position dependent
+    sel = torch.zeros(K, N, device="cuda", dtype=torch.bfloat16)
+    idx = (torch.arange(N, device="cuda") * 5 + 1) % K
+    sel[idx, torch.arange(N, device="cuda")] = 1.0
+    assert torch.equal(ops.gemm(a, sel, epilogue=ops.EPI_F32, b_kmajor=True), a.float()[:, idx])
+    with pytest.raises(ops.OmhError):
+        ops.gemm(a, b, epilogue=ops.EPI_GELU_BF16, b_kmajor=True)
+
+
+def test_gemm_b_kmajor_batched_strided(ops):
+    """The context-gradient call of the training step: per sample b, d_ctx[b, first:first+L] += dy[b] @ W."""
+    g = torch.Generator(device="cuda").manual_seed(9)
+    B, L, Lc, first, d, N = 3, 257, 600, 64, 1536, 1536
+    dy = torch.randn(B * L, N, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, d, device="cuda", generator=g) / math.sqrt(N)).bfloat16()
+    d_ctx = torch.randn(B, Lc, d, device="cuda", generator=g)
+    ref = d_ctx.clone()
+    ref[:, first:first + L] += (dy.float() @ w.float()).view(B, L, d)
+    ops.gemm_raw(ops.ptr(dy), ops.ptr(w), ops.ptr(d_ctx, first * d), L, d, N, N, d, d, ops.EPI_F32_ACCUM, batch=B,
+                 strideA=L * N, strideB=0, strideC=Lc * d, b_kmajor=True)
+    assert rel_rms(d_ctx, ref) < 2e-5
+    assert torch.equal(d_ctx[:, :first], ref[:, :first]) and torch.equal(d_ctx[:, first + L:], ref[:, first + L:])
