@@ -54,6 +54,15 @@ def _worker(rank, world, port, q):
         step()                                                   # second step reuses the flat buffers
         for i, p in enumerate(params):
             assert torch.allclose(p.grad, torch.full_like(p, mean_scale * (i + 1)))
+        # after finish() every p.grad is a view of its bucket's flat buffer (no copy back) ...
+        flat_ptrs = {f.data_ptr(): f.numel() * f.element_size() for f in red._flat if f is not None}
+        for p in params:
+            assert any(b <= p.grad.data_ptr() < b + n for b, n in flat_ptrs.items())
+        # ... and a backward that accumulates into those views (grads not reset) reduces correctly too
+        sum((p * d).sum() for p, d in zip(params, data)).backward()
+        red.finish()
+        for i, p in enumerate(params):
+            assert torch.allclose(p.grad, torch.full_like(p, 2 * mean_scale * (i + 1)))
         with red.no_sync():                                      # accumulation micro-step: local gradients stay local
             for p in params:
                 p.grad = None
