@@ -179,6 +179,35 @@ def _tiny_t2v(rank=0):
     return pipe, args
 
 
+class _ClipStub:
+    """Stands in for CLIP ViT-H (out of scope)."""
+
+    def __init__(self, fea):
+        self.fea = fea
+
+    def visual(self, videos):
+        return self.fea.cuda()
+
+
+def _tiny_i2v(rank=0):
+    from oracle import detgen, make_golden, wan_dit_oracle as O, wan_vae_oracle as V
+    wan = importlib.import_module(PKG + ".wan")
+    cfgs = importlib.import_module(PKG + ".wan.configs")
+    vae_mod = importlib.import_module(PKG + ".wan.modules.vae")
+    ocfg = O.DiTConfig(model_type="i2v", in_dim=36, num_layers=2, **make_golden.TINY)
+    model = wan.modules.model.WanModel(model_type="i2v", in_dim=36, num_layers=2, **make_golden.TINY)
+    model.load_state_dict(O.synth_state_dict(ocfg, "i2vgen"))
+    vae = vae_mod.WanVAE(vae_pth=None, device="cuda", dim=16)
+    vae.model.load_state_dict(V.synth_state_dict(V.VAEConfig(dim=16), "i2vgen/vae"))
+    clip = _ClipStub(torch.from_numpy(detgen.normalish("i2vgen/clip", (1, 257, 1280))))
+    pipe = wan.WanI2V(cfgs.i2v_14B, checkpoint_dir="", model=model, vae=vae, clip=clip, rank=rank)
+    img = torch.from_numpy(detgen.uniform("i2vgen/img", (3, 40, 60), 0.0, 1.0))
+    args = dict(max_area=48 * 64, frame_num=5, shift=3.0, sampling_steps=3, guide_scale=4.0, return_latent=True,
+                context=[torch.from_numpy(detgen.normalish("i2vgen/c", (9, 64)))],
+                context_null=[torch.from_numpy(detgen.normalish("i2vgen/n", (21, 64)))])
+    return pipe, img, args
+
+
 def _cfg_split_worker(rank, port, q):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -193,6 +222,13 @@ def _cfg_split_worker(rank, port, q):
             assert (got is None) == (rank != 0)
             if got is not None:
                 out[solver] = got.cpu().numpy()
+        ipipe, img, iargs = _tiny_i2v(rank)
+        got = ipipe.generate("", img, seed=-1, cfg_split=split, **iargs)       # random seed: rank 0's is shared
+        got2 = ipipe.generate("", img, seed=5, cfg_split=split, **iargs)
+        assert (got is None) == (rank != 0)
+        if got2 is not None:
+            out["i2v"] = got2.cpu().numpy()
+            assert got.shape == got2.shape and bool(torch.isfinite(got).all())
         q.put((rank, "ok", out))
     except Exception:  # pragma: no cover
         import traceback
@@ -203,13 +239,15 @@ def _cfg_split_worker(rank, port, q):
 
 def test_cfg_pair_split_over_two_processes_equals_single_gpu():
     """one clip's conditional / unconditional forwards on two ranks, one all-gather per step
-    (parallel.CFGPairSplit), = the single-GPU generate() bit for bit.  The two processes share cuda:0 over gloo
+    (parallel.CFGPairSplit), = the single-GPU generate() bit for bit — WanT2V with both solvers and WanI2V.  The two processes share cuda:0 over gloo
     (RCCL refuses two ranks on one device; the collective is staged through the host there)."""
     import socket
     import torch.multiprocessing as mp
     pipe, args = _tiny_t2v()
     ref = {s: pipe.generate("", seed=11, sample_solver=s, batched_cfg=False, **args).cpu().numpy()
            for s in ("unipc", "dpm++")}
+    ipipe, img, iargs = _tiny_i2v()
+    ref["i2v"] = ipipe.generate("", img, seed=5, batched_cfg=False, **iargs).cpu().numpy()
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -222,5 +260,5 @@ def test_cfg_pair_split_over_two_processes_equals_single_gpu():
     for p in procs:
         p.join(timeout=60)
     assert [r[1] for r in res] == ["ok", "ok"], res
-    for s in ("unipc", "dpm++"):
+    for s in ("unipc", "dpm++", "i2v"):
         assert np.array_equal(res[0][2][s], ref[s]), s
