@@ -205,7 +205,9 @@ class WanSelfAttention(nn.Module):
         # V^T[b] = Wv h_b^T + bv  ->  [B, dim, Sp]   (pad columns stay zero)
         Sp = _round_up(S, 64)
         wv, bv = self._w("v")
-        vt = torch.zeros(B, d, Sp, dtype=torch.bfloat16, device=h.device)
+        vt = torch.empty(B, d, Sp, dtype=torch.bfloat16, device=h.device)
+        if Sp != S:
+            vt[:, :, S:].zero_()                       # pad columns only (0 x P = 0 needs them finite); the GEMM writes the rest
         ops.gemm_raw(ptr(wv), ptr(h), ptr(vt), d, S, d, d, d, Sp, EPI_BF16, bias=ptr(bv), bias_mode=BIAS_M, batch=B,
                      strideA=0, strideB=S * d, strideC=d * Sp)
         o = torch.empty(R, d, dtype=torch.bfloat16, device=h.device)
@@ -621,12 +623,14 @@ class WanModel(nn.Module):
         wpe, bpe = self._packed.get("patch", (self.patch_embedding.weight, self.patch_embedding.bias), lambda: (
             _bf16(torch.nn.functional.pad(self.patch_embedding.weight.detach().flatten(1).float(), (0, Kp - kin))),
             self.patch_embedding.bias.detach().float().contiguous()))
-        xs = torch.zeros(B, seq_len, d, dtype=torch.float32, device=device)
+        xs = torch.empty(B, seq_len, d, dtype=torch.float32, device=device)
         for b, u in enumerate(x):
             assert u.shape[0] == self.in_dim, f"expected {self.in_dim} input channels, got {u.shape[0]}"
             tok = ops.patchify(u, self.patch_size, Kp)
             ops.gemm_raw(ptr(tok), ptr(wpe), ptr(xs, b * seq_len * d), lens[b], d, Kp, Kp, Kp, d, EPI_F32,
                          bias=ptr(bpe), bias_mode=BIAS_N)
+            if lens[b] < seq_len:
+                xs[b, lens[b]:].zero_()                 # only the padding rows need the fill; the GEMM wrote the rest
         # ---- time embedding (fp32)                                              model.py:526-528
         t = t.to(device=device)
         te0, te2, tp1 = self.time_embedding[0], self.time_embedding[2], self.time_projection[1]
