@@ -306,6 +306,8 @@ void flash_attn_fwd_d128_pp_kernel(const omh_attn_args p, const int q_tiles) {
     const __bf16* __restrict__ K = (const __bf16*)p.k + (int64_t)b * p.k_bs + head * D;
     const __bf16* __restrict__ VT = (const __bf16*)p.vt + (int64_t)b * p.vt_bs + (int64_t)head * D * p.ldv;
 
+    // static priority for the second-dispatched half of the workgroup (the arbitration loser on every segment)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     const int q_row = qt * QB2 + wave * 32 + li;
     const int q_ld = min(q_row, p.Lq - 1);
     bf16x8 qf[8];
