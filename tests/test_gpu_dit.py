@@ -125,6 +125,10 @@ def test_wan_1_3b_single_frame_cfg_pair():
     ref_u = O.dit_forward(sd, cfg, [noise], t, [cneg], 1560)[0]
     assert rel_rms(u, ref_u) < TOL_FULL
     assert rel_rms(v, ref) < 0.2
+    # the same pair as one batch-2 forward (trainer.teacher_cfg_velocity): bit-identical to the two calls
+    trainer = importlib.import_module("omnihuman-1-hack_amd.trainer")
+    vt = trainer.teacher_cfg_velocity(m, noise, t, cpos, cneg, 7.5)
+    assert torch.equal(vt, torch.add(u, c - u, alpha=7.5))
 
 
 def test_tiny_i2v_model_matches_oracle_and_reference_vectors(wan_model_mod):
