@@ -88,6 +88,13 @@ def test_backward_kernels(ops):
     assert torch.equal(ops.transpose_bf16(x)[:, :70], x.t())
     acc = torch.ones(200, device="cuda")
     assert rel_rms(ops.colsum_accum(x, acc), 1 + x.float().sum(0)) < 1e-5
+    # column sums on the shapes of the step (bias gradients), strided rows, odd widths, one row, bf16 and fp32
+    for R, C, ld, dt in [(6240, 1536, 1536, torch.bfloat16), (333, 8960, 8960, torch.bfloat16), (50, 204, 208, torch.float32),
+                         (97, 201, 201, torch.bfloat16), (1, 3072, 3072, torch.float32), (4001, 1536, 3072, torch.bfloat16)]:
+        full = torch.randn(R, ld, device="cuda").to(dt)
+        xs = full[:, :C]
+        acc = torch.full((C,), 2.0, device="cuda")
+        assert rel_rms(ops.colsum_accum(xs, acc), 2 + xs.float().sum(0)) < 2e-5, (R, C, ld, dt)
     # GELU
     xp = torch.randn(64, 64, device="cuda").to(torch.bfloat16)
     dy = torch.randn(64, 64, device="cuda").to(torch.bfloat16)
