@@ -298,6 +298,16 @@ int omh_transpose_bf16(const void* in, void* out, int32_t R, int32_t C, int64_t 
                        int32_t batch, int64_t bs_in, int64_t bs_out, omh_stream_t stream);
 /* out[c] += sum_r x[r][c]  (x bf16 or fp32) — bias gradients. */
 int omh_colsum_accum(const void* x, int32_t is_bf16, int64_t ld, float* out, int64_t R, int32_t C, omh_stream_t stream);
+/* The same for up to OMH_COLSUM_MAX matrices in one launch (all bias gradients of one block backward).
+ * blocks[] is scratch filled by the library. */
+#define OMH_COLSUM_MAX 16
+typedef struct omh_colsum_batch {
+    int32_t n;
+    const void* x[OMH_COLSUM_MAX]; float* out[OMH_COLSUM_MAX];
+    int64_t ld[OMH_COLSUM_MAX]; int64_t R[OMH_COLSUM_MAX];
+    int32_t C[OMH_COLSUM_MAX]; int32_t is_bf16[OMH_COLSUM_MAX]; int32_t blocks[OMH_COLSUM_MAX];
+} omh_colsum_batch;
+int omh_colsum_accum_multi(const omh_colsum_batch* batch, omh_stream_t stream);
 /* GELU-tanh on bf16 (model.py:273) and its backward dx = dy * gelu'(x_pre). */
 int omh_gelu_tanh_bf16(const void* x, void* y, int64_t n, omh_stream_t stream);
 int omh_gelu_tanh_bwd_bf16(const void* dy, const void* x_pre, void* dx, int64_t n, omh_stream_t stream);

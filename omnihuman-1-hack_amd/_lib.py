@@ -53,6 +53,15 @@ class GemmArgs(C.Structure):
                 ("b_kmajor", i32)]
 
 
+COLSUM_MAX = 16
+
+
+class ColsumBatch(C.Structure):
+    _fields_ = [("n", i32), ("x", vp * COLSUM_MAX), ("out", vp * COLSUM_MAX), ("ld", i64 * COLSUM_MAX),
+                ("R", i64 * COLSUM_MAX), ("C", i32 * COLSUM_MAX), ("is_bf16", i32 * COLSUM_MAX),
+                ("blocks", i32 * COLSUM_MAX)]
+
+
 class GemmTnArgs(C.Structure):
     _fields_ = [("A", vp), ("B", vp), ("C", vp), ("M", i32), ("N", i32), ("K", i32),
                 ("lda", i32), ("ldb", i32), ("ldc", i32), ("accumulate", i32)]
@@ -114,6 +123,7 @@ _SIGS = {
     "omh_softmax_rows": (i32, [vp, i64, vp, i64, i64, i32, f32, vp]),
     "omh_transpose_bf16": (i32, [vp, vp, i32, i32, i64, i64, i32, i64, i64, vp]),
     "omh_colsum_accum": (i32, [vp, i32, i64, vp, i64, i32, vp]),
+    "omh_colsum_accum_multi": (i32, [vp, vp]),
     "omh_gelu_tanh_bf16": (i32, [vp, vp, i64, vp]),
     "omh_gelu_tanh_bwd_bf16": (i32, [vp, vp, vp, i64, vp]),
     "omh_gelu_erf_bf16": (i32, [vp, vp, i64, vp]),

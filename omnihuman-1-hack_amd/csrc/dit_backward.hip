@@ -51,6 +51,31 @@ void colsum_kernel(const T* __restrict__ x, int64_t ld, float* __restrict__ out,
     atomicAdd(out + c, s);
 }
 
+// Up to OMH_COLSUM_MAX column sums in ONE launch (the ~10 bias gradients of a block backward: each alone is a
+// 10-15 us latency- and atomics-bound kernel; together they overlap).  Descriptors travel in the kernel arguments.
+__global__ __launch_bounds__(256)
+void colsum_multi_kernel(const omh_colsum_batch b) {
+    int e = 0, local = blockIdx.x;
+#pragma unroll 1
+    while (e + 1 < b.n && local >= b.blocks[e]) { local -= b.blocks[e]; ++e; }
+    const int C = b.C[e];
+    const int col_chunks = (C + 255) / 256;
+    const int c = (local % col_chunks) * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t R = b.R[e], ld = b.ld[e];
+    const int64_t r0 = (int64_t)(local / col_chunks) * 32;
+    const int64_t r1 = min(R, r0 + 32);
+    float s = 0.f;
+    if (b.is_bf16[e]) {
+        const uint16_t* x = (const uint16_t*)b.x[e];
+        for (int64_t r = r0; r < r1; ++r) s += bf2f(x[r * ld + c]);
+    } else {
+        const float* x = (const float*)b.x[e];
+        for (int64_t r = r0; r < r1; ++r) s += x[r * ld + c];
+    }
+    atomicAdd(b.out[e] + c, s);
+}
+
 // ------------------------------------------------------------------ GELU-tanh fwd / bwd (bf16)
 __device__ __forceinline__ float gelu_tanh_grad(float x) {
     const float c = 0.7978845608028654f, a = 0.044715f;
@@ -466,6 +491,21 @@ extern "C" int omh_colsum_accum(const void* x, int32_t is_bf16, int64_t ld, floa
     else
         hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, out, R,
                            C, rpb);
+    return omh_launch_status();
+}
+
+extern "C" int omh_colsum_accum_multi(const omh_colsum_batch* batch, omh_stream_t stream) {
+    if (!batch || batch->n <= 0 || batch->n > OMH_COLSUM_MAX) return OMH_E_BADARG;
+    omh_colsum_batch b = *batch;
+    int64_t total = 0;
+    for (int i = 0; i < b.n; ++i) {
+        if (!b.x[i] || !b.out[i] || b.R[i] <= 0 || b.C[i] <= 0 || b.ld[i] < b.C[i]) return OMH_E_BADARG;
+        b.blocks[i] = (int32_t)(((b.C[i] + 255) / 256) * ((b.R[i] + 31) / 32));
+        total += b.blocks[i];
+    }
+    if (total > 0x7fffffff) return OMH_E_SHAPE;
+    omh_clear_status();
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, b);
     return omh_launch_status();
 }
 

@@ -351,6 +351,21 @@ def colsum_accum(x: torch.Tensor, out: torch.Tensor):
     return out
 
 
+def colsum_accum_multi(pairs):
+    """out_i[c] += sum_r x_i[r][c] for every (x_i, out_i) of ``pairs`` in one launch per 16 entries."""
+    for k in range(0, len(pairs), _lib.COLSUM_MAX):
+        chunk = pairs[k:k + _lib.COLSUM_MAX]
+        b = _lib.ColsumBatch()
+        b.n = len(chunk)
+        for i, (x, out) in enumerate(chunk):
+            _dev(x, out)
+            assert x.dim() == 2 and x.stride(1) == 1 and out.dtype == torch.float32 and out.is_contiguous()
+            b.x[i], b.out[i] = x.data_ptr(), out.data_ptr()
+            b.ld[i], b.R[i], b.C[i] = x.stride(0), x.shape[0], x.shape[1]
+            b.is_bf16[i] = int(x.dtype == torch.bfloat16)
+        check(lib.omh_colsum_accum_multi(C.byref(b), _stream()), "omh_colsum_accum_multi")
+
+
 def gelu_tanh(x, out=None):
     _dev(x)
     assert x.dtype == torch.bfloat16 and x.is_contiguous()

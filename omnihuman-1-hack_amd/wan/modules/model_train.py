@@ -103,6 +103,13 @@ class _ZeroArena:
     def __init__(self, n, device):
         self.buf = torch.zeros(n, dtype=torch.float32, device=device)
         self.pos = 0
+        self.pending = []                                       # deferred column sums: (dy, out) pairs
+
+    def flush(self):
+        """All bias gradients of the block in one launch (each alone is a 10-15 us latency-bound kernel)."""
+        if self.pending:
+            ops.colsum_accum_multi(self.pending)
+            self.pending = []
 
     def take(self, *shape):
         n = 1
@@ -116,8 +123,16 @@ class _ZeroArena:
         return out
 
 
+_BGRAD_MULTI = os.environ.get("OMH_BGRAD", "multi") != "single"      # "single": one launch per bias gradient (A/B timing)
+
+
 def _bgrad(dy, arena=None):
+    """Bias gradient = column sums of dy.  With an arena the sum is deferred to ``arena.flush()`` at the end of the
+    block backward (dy stays referenced until then); the returned accumulator is complete after the flush."""
     out = arena.take(dy.shape[1]) if arena is not None else torch.zeros(dy.shape[1], dtype=torch.float32, device=dy.device)
+    if arena is not None and _BGRAD_MULTI:
+        arena.pending.append((dy, out))
+        return out
     return ops.colsum_accum(dy, out)
 
 
@@ -455,6 +470,7 @@ def _block_backward(model, blk, idx, st, x0, dx):
     ops.colsum_accum(d_eb.view(B, six), dmod)
     g["modulation"] = dmod
     _axpy_rows(st.d_e0.view(B, six), d_eb.view(B, six))
+    arena.flush()
     g["__dx__"] = dx
     return g
 

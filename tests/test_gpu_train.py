@@ -95,6 +95,14 @@ def test_backward_kernels(ops):
         xs = full[:, :C]
         acc = torch.full((C,), 2.0, device="cuda")
         assert rel_rms(ops.colsum_accum(xs, acc), 2 + xs.float().sum(0)) < 2e-5, (R, C, ld, dt)
+    # the same sums batched into one launch per 16 matrices (the bias gradients of a block backward)
+    mats = [torch.randn(R, C, device="cuda").to(dt) for R, C, dt in
+            [(6240, 1536, torch.bfloat16), (6240, 8960, torch.bfloat16), (2048, 3072, torch.float32), (1, 8, torch.bfloat16),
+             (97, 201, torch.bfloat16)] + [(33 + i, 40 + 3 * i, torch.bfloat16) for i in range(14)]]
+    outs = [torch.full((m.shape[1],), 3.0, device="cuda") for m in mats]
+    ops.colsum_accum_multi(list(zip(mats, outs)))                 # 19 entries: two launches
+    for m, o in zip(mats, outs):
+        assert rel_rms(o, 3 + m.float().sum(0)) < 2e-5, tuple(m.shape)
     # GELU
     xp = torch.randn(64, 64, device="cuda").to(torch.bfloat16)
     dy = torch.randn(64, 64, device="cuda").to(torch.bfloat16)
