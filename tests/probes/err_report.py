@@ -1,6 +1,6 @@
 """Prints the measured bf16-vs-fp32-oracle errors behind the tolerances stated in tests/ (GPU)."""
 import importlib, os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import wan_dit_oracle as O, detgen, make_golden
 mod = importlib.import_module("omnihuman-1-hack_amd.wan.modules.model")
 def rel(a, b): return float((a.double().cpu() - b.double()).norm() / b.double().norm())

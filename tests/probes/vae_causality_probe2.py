@@ -1,6 +1,6 @@
 """Is the T=4 decode as close to the oracle as the T<=3 decodes? (quarter area, dim=96)"""
 import importlib, json, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import wan_vae_oracle as V
 vae_mod = importlib.import_module("omnihuman-1-hack_amd.wan.modules.vae")

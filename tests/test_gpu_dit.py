@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 # stated bf16 tolerance"): every GEMM/attention operand is rounded to bf16
 # (2^-9 relative), accumulation and the residual stream stay fp32.  Relative
 # RMS error of the final velocity grows ~sqrt(layers):
-# (measured with tools/err_report.py: 3.5e-3 for the tiny models, 5.0e-3 for Wan2.1-1.3B; bounds = 2x)
+# (measured with tests/probes/err_report.py: 3.5e-3 for the tiny models, 5.0e-3 for Wan2.1-1.3B; bounds = 2x)
 TOL_TINY = 8.0e-3     # 2..13 layers, d=256
 TOL_FULL = 1.2e-2     # 30 layers, d=1536
 

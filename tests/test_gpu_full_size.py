@@ -146,7 +146,7 @@ def test_vae_full_size_temporal_causality(monkeypatch):
     The conv tile family is pinned: the dispatch moves the latent-resolution convs from the 128x128 kernel to the
     wide one once 4 latent frames are batched (another summation order: prefix and whole clip then differ by
     bf16 rounding noise, 1.4 % after 30 layers, each as close to the oracle as the other —
-    tools/vae_causality_probe2.py)."""
+    tests/probes/vae_causality_probe2.py)."""
     monkeypatch.setenv("OMH_CONV_TILE", "wide")
     vae_mod = importlib.import_module(PKG + ".wan.modules.vae")
     torch.manual_seed(4321)
