@@ -60,6 +60,36 @@ def test_no_cpu_fallback(omh, ops, wan_model_mod):
                 assert "oracle" not in re.sub(r'""".*?"""', "", open(src).read(), flags=re.S).replace("# oracle", "")
 
 
+def test_oracle_is_test_infrastructure_only():
+    """Nothing outside tests/, __graft_entry__.smoke() and bench.py's CPU-baseline functions imports oracle/:
+    every source file of the package and every measurement script under tools/ is free of such imports, and
+    bench.py imports it only inside cpu_baseline / vae_cpu_baseline."""
+    import ast
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def oracle_imports(path):
+        hits = []
+        for node in ast.walk(ast.parse(open(path).read())):
+            if isinstance(node, ast.ImportFrom) and (node.module or "").split(".")[0] == "oracle":
+                hits.append(node.lineno)
+            if isinstance(node, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in node.names):
+                hits.append(node.lineno)
+        return hits
+
+    files = glob.glob(os.path.join(root, "omnihuman-1-hack_amd", "**", "*.py"), recursive=True) + \
+        glob.glob(os.path.join(root, "tools", "**", "*.py"), recursive=True)
+    assert files
+    for f in files:
+        assert not oracle_imports(f), f
+    tree = ast.parse(open(os.path.join(root, "bench.py")).read())
+    for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
+        inside = [n for n in ast.walk(fn) if isinstance(n, ast.ImportFrom) and (n.module or "").split(".")[0] == "oracle"]
+        assert not inside or fn.name in ("cpu_baseline", "vae_cpu_baseline"), fn.name
+    top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom)) and "oracle" in ast.dump(n)]
+    assert not top
+
+
 def test_state_dict_contract(wan_model_mod):
     """Same parameter names / shapes as the reference WanModel."""
     from oracle import wan_dit_oracle as O
