@@ -205,3 +205,36 @@ def test_training_step_full_size_properties():
         assert rel_rms(b, a) < 1e-4, n                                # run to run: atomics order only
         assert rel_rms(c, 4.0 * a) < 1e-4, n                          # homogeneity
     assert all(bool(torch.isfinite(v).all()) for v in g1.values() if v is not None)
+
+
+def test_omnihuman_full_size_sampling(wan_1_3b):
+    """BASELINE config 4 at its real size: OmniHumanWanT2V on the 1.3B backbone, 49 frames 480x832 (13 latent frames
+    + the reference latent frame concatenated along T: S = 21 840), wav2vec-sized audio and 308-keypoint pose heat
+    maps (omnihuman_wan_t2v.py:313-438).  Two annealed-CFG steps: finite, and the condition tokens matter."""
+    omni = importlib.import_module(PKG + ".omnihuman_wan_t2v")
+    vae_mod = importlib.import_module(PKG + ".wan.modules.vae")
+    torch.manual_seed(4321)
+    vae = vae_mod.WanVAE(vae_pth=None, device="cuda")
+
+    class T2V:
+        model, text_encoder = wan_1_3b, None
+
+    T2V.vae = vae
+    m = omni.OmniHumanWanT2V(dict(num_frames=49, num_keypoints=308, model_dim=1536, audio_dim=1024), device_id=0, wan_t2v=T2V)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    audio = torch.randn(1, 49, 1024, device="cuda", generator=g)
+    pose = torch.rand(1, 308, 49, 64, 64, device="cuda", generator=g)
+    ref_img = torch.rand(3, 1, 480, 832, device="cuda", generator=g) * 2 - 1
+    kw = dict(reference_image=ref_img, num_inference_steps=2, cfg_scale=7.5, return_latent=True,
+              text_context=torch.randn(120, 4096, device="cuda", generator=g),
+              text_context_null=torch.randn(40, 4096, device="cuda", generator=g),
+              noise=torch.randn(16, 13, 60, 104, device="cuda", generator=g))
+    cond = m.prepare_conditions(audio=audio, pose=pose, reference_image=ref_img, text_context=kw["text_context"])
+    assert tuple(cond["tokens"].shape) == (1, 2 * 48 + 49, 1536) and tuple(cond["reference"].shape) == (16, 1, 60, 104)
+    lat = m(audio=audio, pose=pose, **kw)
+    assert tuple(lat.shape) == (16, 13, 60, 104) and bool(torch.isfinite(lat).all())
+    assert torch.equal(lat, m(audio=audio, pose=pose, **kw))                    # repeatable bit for bit
+    plain = m(**kw)
+    assert rel_rms(lat, plain) > 1e-3                                           # audio / pose tokens reach the sample
+    video = vae.decode([lat])[0]
+    assert tuple(video.shape) == (3, 49, 480, 832) and bool(torch.isfinite(video).all())
