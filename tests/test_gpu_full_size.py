@@ -238,3 +238,26 @@ def test_omnihuman_full_size_sampling(wan_1_3b):
     assert rel_rms(lat, plain) > 1e-3                                           # audio / pose tokens reach the sample
     video = vae.decode([lat])[0]
     assert tuple(video.shape) == (3, 49, 480, 832) and bool(torch.isfinite(video).all())
+
+
+def test_wan_t2v_generate_full_size(wan_1_3b):
+    """BASELINE config 2 end to end at its real size, shortened to two sampling steps: WanT2V.generate on the 1.3B
+    backbone, 81 frames 480x832 (text2video.py:112-269) — the batch-2 CFG forward equals two forwards bit for bit,
+    the seed decides the sample, the decoded video is finite and in range."""
+    cfgs = importlib.import_module(PKG + ".wan.configs")
+    t2v = importlib.import_module(PKG + ".wan.text2video")
+    vae_mod = importlib.import_module(PKG + ".wan.modules.vae")
+    torch.manual_seed(4321)
+    vae = vae_mod.WanVAE(vae_pth=None, device="cuda")
+    pipe = t2v.WanT2V(cfgs.t2v_1_3B, checkpoint_dir="", model=wan_1_3b, vae=vae)
+    g = torch.Generator().manual_seed(5)
+    kw = dict(size=(832, 480), frame_num=81, shift=5.0, sampling_steps=2, guide_scale=5.0,
+              context=[torch.randn(120, 4096, generator=g)], context_null=[torch.randn(40, 4096, generator=g)])
+    for solver in ("unipc", "dpm++"):
+        lat = pipe.generate("", seed=3, sample_solver=solver, return_latent=True, **kw)
+        assert tuple(lat.shape) == (16, 21, 60, 104) and bool(torch.isfinite(lat).all())
+        assert torch.equal(lat, pipe.generate("", seed=3, sample_solver=solver, return_latent=True, batched_cfg=False, **kw))
+    other = pipe.generate("", seed=4, sample_solver="dpm++", return_latent=True, **kw)
+    assert rel_rms(other, lat) > 0.1
+    video = pipe.generate("", seed=3, **kw)
+    assert tuple(video.shape) == (3, 81, 480, 832) and bool(torch.isfinite(video).all()) and float(video.abs().max()) <= 1.0
