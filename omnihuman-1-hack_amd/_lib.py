@@ -21,14 +21,25 @@ class OmhError(RuntimeError):
     pass
 
 
+ABI_VERSION = 2          # == OMH_ABI_VERSION of include/omh.h; checked against the loaded library below
+
+
 def _load():
-    if not os.path.exists(_LIB_PATH):
-        # build in-tree on first use (hipcc cross-compiles without a GPU)
+    if not os.environ.get("OMH_LIB"):
+        # (re)build in-tree whenever the sources changed (hipcc cross-compiles without a GPU).  build() is a hash
+        # check when nothing changed, takes a file lock so that the ranks of one torchrun do not race, and swaps
+        # the library in atomically.  Without hipcc (a box that only received the prebuilt .so) a stale or missing
+        # library is an error, not something to paper over.
         import importlib.util
         spec = importlib.util.spec_from_file_location("_omh_build", os.path.join(_HERE, "build.py"))
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
-        mod.build(verbose=False)
+        if mod.have_hipcc():
+            mod.build(verbose=False)
+        elif not os.path.exists(_LIB_PATH):
+            raise OmhError(f"{_LIB_PATH} is missing and hipcc is not available to build it")
+        elif not mod.up_to_date():
+            raise OmhError(f"{_LIB_PATH} does not match csrc/ (stale build) and hipcc is not available to rebuild it")
     try:
         return C.CDLL(_LIB_PATH)
     except OSError as e:  # pragma: no cover
@@ -158,5 +169,5 @@ def check(rc: int, what: str):
         raise OmhError(f"{what} failed: {_ERR.get(rc, 'hipError ' + str(rc))}")
 
 
-if lib.omh_abi_version() != 2:  # pragma: no cover
-    raise OmhError("libomh.so ABI version mismatch")
+if lib.omh_abi_version() != ABI_VERSION:  # pragma: no cover
+    raise OmhError(f"libomh.so reports ABI version {lib.omh_abi_version()}, this binding was written for {ABI_VERSION}")

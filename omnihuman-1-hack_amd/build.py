@@ -40,7 +40,32 @@ def _digest():
     for f in _sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
             [os.path.join(INCLUDE, "omh.h")]:
         with open(f, "rb") as fh:
-            h.update(f.encode())
+            h.update(os.path.basename(f).encode())     # not the path: the tree is copied to the GPU box
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def up_to_date() -> bool:
+    """True when libomh.so exists and its stamp equals the digest of the sources as they are now."""
+    stamp = os.path.join(LIBDIR, "libomh.sha256")
+    return os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == _digest()
+
+
+def have_hipcc() -> bool:
+    try:
+        _hipcc()
+        return True
+    except RuntimeError:
+        return False
+
+
+def _obj_digest(src):
+    """Digest of ONE translation unit: its source, the shared headers and the flags (so that editing one .hip
+    file recompiles one object, not nine)."""
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in [src] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
+            [os.path.join(INCLUDE, "omh.h")]:
+        with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
 
@@ -48,28 +73,42 @@ def _digest():
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     stamp = os.path.join(LIBDIR, "libomh.sha256")
-    dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+    if not force and up_to_date():
         return LIB
-    hipcc = _hipcc()
-    objs = []
+    # one builder at a time (torchrun starts N ranks that all import the package): the others wait on the lock and
+    # then find the library up to date
+    import fcntl
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        dig = _digest()
+        if not force and up_to_date():
+            return LIB
+        hipcc = _hipcc()
 
-    def compile_one(src):
-        obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        def compile_one(src):
+            obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
+            ostamp = obj + ".sha256"
+            od = _obj_digest(src)
+            if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read().strip() == od:
+                return obj
+            cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+            if verbose:
+                print("[omh build]", " ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+            with open(ostamp, "w") as fh:
+                fh.write(od)
+            return obj
+
+        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+            objs = list(ex.map(compile_one, _sources()))
+        tmp = LIB + ".tmp"
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp]
         if verbose:
             print("[omh build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-        return obj
-
-    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
-        objs = list(ex.map(compile_one, _sources()))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
-    if verbose:
-        print("[omh build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
-    with open(stamp, "w") as fh:
-        fh.write(dig)
+        os.replace(tmp, LIB)                     # atomic: a concurrent dlopen never sees a half-written file
+        with open(stamp, "w") as fh:
+            fh.write(dig)
     return LIB
 
 

@@ -93,12 +93,22 @@ class GraphedTrainingStep:
     The parameters' ``.grad`` tensors are allocated by the captured backward and *rewritten* by every replay, so
     they are never zeroed or set to None between steps (``optimizer.zero_grad`` must not be called).  With a
     ``reducer`` (parallel.BucketedGradAllReduce) its per-gradient hooks are silenced during capture/replay and
-    every bucket is all-reduced after the replay."""
+    every bucket is all-reduced after the replay.  The reducer's ``finish()`` leaves every ``p.grad`` pointing at
+    a slice of its reduced flat bucket, while a replay keeps writing to the captured addresses — so ``__call__``
+    re-points ``p.grad`` at the captured tensors after every replay, and the reducer packs them afresh.
+
+    A replay OVERWRITES the gradients (the captured backward starts from ``grad = None``), so micro-batch
+    accumulation (distilled_trainer.py:289-301 with ``--gradient_accumulation_steps`` > 1) cannot be expressed by
+    replaying this graph several times: it is refused here; use ``trainer.training_step`` eagerly (with
+    ``reducer.no_sync()`` around the non-final micro-steps) for that."""
 
     def __init__(self, model, example_batch, optimizer=None, reducer=None, num_train_timesteps: int = 1000,
                  gradient_accumulation_steps: int = 1, loss_scale: float = 1.0, reference_loss_quirk: bool = True,
                  warmup: int = 1):
         from . import trainer
+        if gradient_accumulation_steps != 1:
+            raise ValueError("GraphedTrainingStep replays overwrite .grad and step the optimizer on every call; "
+                             "gradient_accumulation_steps must be 1 (accumulate with the eager training_step)")
         dev = next(model.parameters()).device
         self.model, self.optimizer, self.reducer = model, optimizer, reducer
         self.accum = gradient_accumulation_steps
@@ -121,13 +131,18 @@ class GraphedTrainingStep:
             with torch.cuda.graph(self.graph):
                 self.loss = fb()
         # the captured backward left its results in .grad; keep the tensors alive at these addresses
-        self.grads = [p.grad for p in model.parameters()]
+        self.params = list(model.parameters())
+        self.grads = [p.grad for p in self.params]
 
     def __call__(self, batch) -> torch.Tensor:
         for dst, src in zip(self.batch, batch):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         self.graph.replay()
+        # the replay wrote to the captured gradient tensors; a previous reducer.finish() may have left p.grad
+        # pointing at a slice of its flat bucket (parallel.py) — that would be last step's data
+        for p, g in zip(self.params, self.grads):
+            p.grad = g
         if self.reducer is not None:
             self.reducer.finish()              # nothing was launched by hooks: all buckets go now
         if self.optimizer is not None:

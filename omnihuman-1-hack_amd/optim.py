@@ -15,7 +15,7 @@ class AdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
         loss = closure() if closure is not None else None
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
             by_step = {}
             keep = []                                       # keeps .contiguous() copies alive until the launch
@@ -28,7 +28,9 @@ class AdamW(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                st["step"] += 1
+                # a state dict saved by torch.optim.AdamW (the 'optimizer' entry of the reference's checkpoints,
+                # distilled_trainer.py:153-178) holds the step as a 0-d tensor: normalise to a Python int
+                st["step"] = int(st["step"]) + 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 keep.append(g)
                 touched.append(p)
@@ -40,9 +42,12 @@ class AdamW(torch.optim.Optimizer):
                 # the pointer table is re-uploaded only when an address changed (never under a graphed step,
                 # whose gradients live at fixed addresses): no host-to-device copy in the steady state
                 cache = self.__dict__.setdefault("_tables", {})
-                ent = cache.get(dev)
+                # keyed per parameter group and device; parameters that joined later (a different step count) get
+                # their own table instead of evicting the main one every step
+                key = (gi, dev, len(rows))
+                ent = cache.get(key)
                 if ent is None or ent[0] != rows:
-                    ent = cache[dev] = (rows, torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=False))
+                    ent = cache[key] = (rows, torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=False))
                 table = ent[1]
                 ops.adamw_multi(table, len(rows), group["lr"], b1, b2, group["eps"], group["weight_decay"], step,
                                 grad_scale)

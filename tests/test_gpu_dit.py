@@ -14,6 +14,10 @@ pytestmark = pytest.mark.gpu
 # (measured with tests/probes/err_report.py: 3.5e-3 for the tiny models, 5.0e-3 for Wan2.1-1.3B; bounds = 2x)
 TOL_TINY = 8.0e-3     # 2..13 layers, d=256
 TOL_FULL = 1.2e-2     # 30 layers, d=1536
+# guided velocity v = u + 7.5 (c - u) of config 1: the errors of the two forwards enter with weights 7.5 and 6.5
+# while |v| stays O(|u|) when c ~ u, so its relative error is ~ sqrt(7.5^2 + 6.5^2) = 9.9 x the forward's.
+# Measured on MI355X (round 2): see the [measured] line this test prints; bound = 2 x measured.
+TOL_CFG = 0.2
 
 
 def _inputs(cfg, grids, ctx_lens, tag):
@@ -124,7 +128,21 @@ def test_wan_1_3b_single_frame_cfg_pair():
     # individual forwards at TOL_FULL and the guided velocity at a looser bound
     ref_u = O.dit_forward(sd, cfg, [noise], t, [cneg], 1560)[0]
     assert rel_rms(u, ref_u) < TOL_FULL
-    assert rel_rms(v, ref) < 0.2
+    # ... and the unconditional forward straight against the REAL reference's output on these inputs (64 probe
+    # elements, a coarse grid, the mean: tests/golden/dit_wan1_3b_c1.npz written by oracle/make_golden.py from the
+    # imported reference WanModel) — no oracle in between
+    import os
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dit_wan1_3b_c1.npz"))
+    uc = u.cpu()
+    probe = uc.flatten()[torch.from_numpy(g["probe_idx"])]
+    assert rel_rms(probe, torch.from_numpy(g["probe"])) < TOL_FULL
+    assert rel_rms(uc[:, 0, ::6, ::8], torch.from_numpy(g["coarse"])) < TOL_FULL
+    assert abs(float(uc.double().mean()) - float(g["mean"])) < 2e-3 * float(g["abs_mean"])
+    assert abs(float(uc.double().abs().mean()) - float(g["abs_mean"])) < 2e-3 * float(g["abs_mean"])
+    e_v = rel_rms(v, ref)
+    print(f"[measured] 1.3B forward rel-RMS {rel_rms(u, ref_u):.3e}, guided velocity rel-RMS {e_v:.3e}")
+    assert e_v < TOL_CFG
     # the same pair as one batch-2 forward (trainer.teacher_cfg_velocity): bit-identical to the two calls
     trainer = importlib.import_module("omnihuman-1-hack_amd.trainer")
     vt = trainer.teacher_cfg_velocity(m, noise, t, cpos, cneg, 7.5)

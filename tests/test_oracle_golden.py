@@ -94,6 +94,24 @@ def test_dpmpp_matches_reference_vectors():
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/seaweed_apt"), reason="reference tree not present")
+def test_oracle_1_3b_forward_matches_reference_probes():
+    """BASELINE config 1 at its real size: the oracle's Wan2.1-T2V-1.3B forward (30 layers, d = 1536, S = 1560) on
+    c1/noise + c1/neg, t = 999, against 64 probe elements, the mean / abs-mean and a coarse grid of the REAL
+    reference's output on the same inputs (oracle/make_golden.py, `dit_wan1_3b_c1.npz`; ~10 s on 8 cores)."""
+    from oracle import detgen
+    g = np.load(os.path.join(GOLD, "dit_wan1_3b_c1.npz"))
+    cfg = O.DiTConfig.wan_t2v_1_3b()
+    sd = O.synth_state_dict(cfg, "wan1.3b")
+    noise = torch.from_numpy(detgen.normalish("c1/noise", (16, 1, 60, 104)))
+    cneg = torch.from_numpy(detgen.normalish("c1/neg", (37, 4096)))
+    with torch.no_grad():
+        out = O.dit_forward(sd, cfg, [noise], torch.tensor([999.]), [cneg], 1560)[0]
+    assert np.abs(out.flatten()[torch.from_numpy(g["probe_idx"])].numpy() - g["probe"]).max() < 2e-4
+    assert np.abs(out[:, 0, ::6, ::8].numpy() - g["coarse"]).max() < 2e-4
+    assert abs(float(out.double().mean()) - float(g["mean"])) < 1e-5
+    assert abs(float(out.double().abs().mean()) - float(g["abs_mean"])) < 1e-5
+
+
 def test_oracle_against_live_reference():
     from oracle import detgen, ref_import, wan_dit_oracle as O, wan_vae_oracle as V
     cfg = O.DiTConfig(dim=128, ffn_dim=256, num_heads=1, num_layers=3, text_dim=32, text_len=16, freq_dim=32)
