@@ -218,28 +218,53 @@ def single_frame_bench(model, device, iters=20):
     return res
 
 
-def train_bench(model, device, world, dist, steps=4, warmup=2):
+def train_step_flops(S=1560, ffn_freeze=True, d=1536, f=8960, L=30, Lc=512):
+    """Algorithmic work of ONE clip's training step (multiply-add = 2; backward = 2 x forward; the reference's
+    per-block checkpoint, model.py:544-548, recomputes each block once).  With the reference's FFN quirk
+    (model.py:317-324: blocks > 10 run their FFN under no_grad) the FFN of blocks 11..L-1 is computed once in the
+    forward and never again: no recompute, no input gradient, no weight gradient."""
+    ffn = 4 * S * d * f
+    blk = 8 * S * d * d + 4 * S * S * d + (4 * S * d * d + 4 * Lc * d * d) + 4 * S * Lc * d + ffn
+    fwd = dit_forward_flops(S, d=d, f=f, L=L, Lc=Lc)
+    rest = fwd - L * blk
+    frozen = max(0, L - 11) if ffn_freeze else 0
+    return (L - frozen) * 4 * blk + frozen * (4 * (blk - ffn) + ffn) + 3 * rest
+
+
+def train_bench(model, device, world, dist, steps=4, warmup=2, bsz=4, ffn_freeze=True, loss_quirk=True):
     """BASELINE config 3: the distilled_trainer.py student step on a batch of [16,1,60,104] clips per GPU
     (forward + per-block recompute + backward on the HIP kernels, bucketed RCCL gradient all-reduce
-    overlapped with the backward, fused AdamW).  Returns clips/s over all ranks."""
+    overlapped with the backward, fused AdamW).  Returns clips/s over all ranks.
+
+    ``ffn_freeze`` / ``loss_quirk``: the reference's two bug-compatible behaviours (FFN of blocks > 10 without
+    gradient, model.py:317-324; loss on sample 0 broadcast against the batch, distilled_trainer.py:285-289).  With
+    the loss quirk only clip 0 carries gradient, so "clips/s" there is the reference's number, not a measure of
+    learning throughput: the un-quirked leg is reported beside it."""
     trainer = importlib.import_module(PKG + ".trainer")
     optim = importlib.import_module(PKG + ".optim")
     par = importlib.import_module(PKG + ".parallel")
     model.train().requires_grad_(True)
+    old_freeze = model.reference_ffn_freeze
+    model.reference_ffn_freeze = bool(ffn_freeze)
     opt = optim.AdamW(model.parameters(), lr=5e-6, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
     red = par.BucketedGradAllReduce(model.parameters(), bucket_mb=256.0, force=bool(dist and world == 1)) if dist else None
     g = torch.Generator(device=device).manual_seed(7 + int(os.environ.get("RANK", 0)))
-    # clips per GPU and step: BASELINE config 3 is "a batch of [16,1,60,104] clips" (distilled_trainer.py --batch_size;
-    # SURVEY 8(d) lists B in {1, 4}); 4 by default, 1 (the reference's argparse default) via OMH_TRAIN_BATCH=1
-    bsz = int(os.environ.get("OMH_TRAIN_BATCH", "4"))
     batch = (torch.randn(bsz, 16, 1, 60, 104, device=device, generator=g),
              torch.randn(bsz, 512, 4096, device=device, generator=g),
              torch.randn(bsz, 16, 1, 60, 104, device=device, generator=g))
+    exposed = []                                            # (event before finish(), event after) per timed step
 
-    def one_eager():
-        loss = trainer.forward_backward(batch, model, num_train_timesteps=1000)
+    def one_eager(timed=False):
+        loss = trainer.forward_backward(batch, model, num_train_timesteps=1000, reference_loss_quirk=loss_quirk)
         if red is not None:
-            red.finish()
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                red.finish()
+                e1.record()
+                exposed.append((e0, e1))
+            else:
+                red.finish()
         opt.step()
         opt.zero_grad(set_to_none=True)
         return loss
@@ -252,8 +277,9 @@ def train_bench(model, device, world, dist, steps=4, warmup=2):
     if os.environ.get("OMH_TRAIN_GRAPH", "0") == "1":
         graphs = importlib.import_module(PKG + ".graphs")
         try:
-            gstep = graphs.GraphedTrainingStep(model, batch, optimizer=opt, reducer=red, num_train_timesteps=1000)
-            one, mode = (lambda: gstep(batch)), "hipGraph replay of fwd+recompute+bwd, then all-reduce + AdamW"
+            gstep = graphs.GraphedTrainingStep(model, batch, optimizer=opt, reducer=red, num_train_timesteps=1000,
+                                               reference_loss_quirk=loss_quirk)
+            one, mode = (lambda timed=False: gstep(batch)), "hipGraph replay of fwd+recompute+bwd, then all-reduce + AdamW"
         except Exception as e:          # keep the leg alive on a capture failure, and say so
             mode = f"eager launches (hipGraph capture failed: {repr(e)[:160]})"
             for p in model.parameters():
@@ -267,7 +293,7 @@ def train_bench(model, device, world, dist, steps=4, warmup=2):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss = one()
+        loss = one(True)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -277,15 +303,46 @@ def train_bench(model, device, world, dist, steps=4, warmup=2):
         tt = torch.tensor([el], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
+    grad_bytes = sum(st["exp_avg"].numel() * 4 for st in opt.state.values() if "exp_avg" in st)   # tensors that got a gradient
+    exposed_ms = (sum(a.elapsed_time(b) for a, b in exposed) / len(exposed)) if exposed else None
     if red is not None:
         red.remove()
+    # give the weights and flags back as they were found (the optimizer stepped lr = 5e-6 a few times)
+    model.reference_ffn_freeze = old_freeze
     model.eval().requires_grad_(False)
+    del opt
+    fl = train_step_flops(1560, ffn_freeze)
     fwd = dit_forward_flops(1560)
+    reducer_ran = red is not None
     return {"clips_per_s": round(world * bsz * steps / el, 3), "ms_per_step": round(el * 1e3 / steps, 2),
             "clips_per_gpu_step": bsz, "steps": steps, "finite_loss": bool(math.isfinite(float(loss))),
-            "launch_mode": mode,
-            "work": "fwd + per-block recompute + bwd (reference FFN-freeze quirk on) + grad all-reduce + AdamW",
-            "achieved_tflops_per_gpu_at_4x_fwd": round(4 * fwd * bsz * steps / el / 1e12, 1)}
+            "launch_mode": mode, "reference_ffn_freeze": bool(ffn_freeze), "reference_loss_quirk": bool(loss_quirk),
+            "work": "fwd + per-block recompute + bwd"
+                    + (" (FFN of blocks > 10 forward-only: the reference's quirk)" if ffn_freeze else " (all parameters trained)")
+                    + (f" + bucketed gradient all-reduce over {world} rank(s) [{dist.get_backend()}]" if reducer_ran
+                       else " + NO gradient all-reduce (single process, no process group)") + " + fused AdamW",
+            "rccl_world_size": int(dist.get_world_size()) if dist else 1,
+            "grad_bytes": int(grad_bytes),
+            "allreduce_exposed_ms": None if exposed_ms is None else round(exposed_ms, 3),
+            "algorithmic_tflop_per_clip": round(fl / 1e12, 2),
+            "algorithmic_over_forward": round(fl / fwd, 2),
+            "achieved_tflops_per_gpu": round(fl * bsz * steps / el / 1e12, 1),
+            "mfma_roofline_frac": round(fl * bsz * steps / el / 1e12 / PEAK_BF16_TFLOPS, 4)}
+
+
+def train_legs(model, device, world, dist):
+    """The training legs of the line: B = 4 (primary, comparable across rounds) and B = 1 with the reference's
+    quirks, and B = 4 with both quirks off (every clip and every parameter trained).  OMH_TRAIN_BATCH overrides
+    the primary batch size."""
+    bsz = int(os.environ.get("OMH_TRAIN_BATCH", "4"))
+    out = train_bench(model, device, world, dist, bsz=bsz)
+    try:
+        if bsz != 1:
+            out["batch_1"] = train_bench(model, device, world, dist, bsz=1)
+        out["no_reference_quirks"] = train_bench(model, device, world, dist, bsz=bsz, ffn_freeze=False, loss_quirk=False)
+    except Exception as e:
+        out["extra_legs_error"] = repr(e)[:300]
+    return out
 
 
 def main():
@@ -389,7 +446,7 @@ def main():
         return s
 
     if args.only_train:
-        print(json.dumps({"train": train_bench(model, device, world, dist)}), flush=True)
+        print(json.dumps({"train": train_legs(model, device, world, dist)}), flush=True)
         return
     sched = fresh_sched()
     x = run_steps(args.warmup, sched, latent)
@@ -417,6 +474,11 @@ def main():
     fwd_per_gpu_step = 1 if split is not None else 2
     steps_per_s = clips_in_flight * args.steps / elapsed
     fwd_flops = dit_forward_flops(seq_len)
+    # what the kernels really execute per forward: cross-attention over the un-padded context (mean of the two
+    # branches), no per-forward text embedding / context K,V projections (cached per sample)
+    lc_eff = 0.5 * (ctx.shape[0] + ctx_null.shape[0])
+    executed_flops = fwd_flops - 30 * (4 * 512 * 1536 * 1536 + 4 * seq_len * (512 - lc_eff) * 1536) \
+        - 2 * 512 * (4096 * 1536 + 1536 * 1536)
     attn_ms = timer.avg_ms()
     attn_flops = 4.0 * seq_len * seq_len * 1536 * nb             # one launch covers the batch
     roofline = None
@@ -454,7 +516,7 @@ def main():
     if not args.no_vae:
         try:
             vae_bench = importlib.import_module(PKG + ".wan.modules.vae").bench_decode
-            vae = vae_bench(x, device)
+            vae = vae_bench(x, device, iters=3)
         except (ImportError, AttributeError, NotImplementedError) as e:
             vae = {"frames_per_s": None, "note": f"VAE path not built: {e}"}
 
@@ -478,7 +540,7 @@ def main():
     train = None
     if not args.no_train:
         try:
-            train = train_bench(model, device, world, dist)
+            train = train_legs(model, device, world, dist)
         except Exception as e:  # the headline line must survive a failure of this extra leg
             train = {"clips_per_s": None, "error": repr(e)[:300]}
 
@@ -498,6 +560,13 @@ def main():
                 "weights": "random-init (xavier) Wan2.1-T2V-1.3B architecture",
                 "context_tokens": [int(ctx.shape[0]), int(ctx_null.shape[0])]},
             "dit": {"forward_tflop": round(fwd_flops / 1e12, 2),
+                    "forward_tflop_note": "BASELINE.md section 3 formula with Lc = 512 context tokens (the reference "
+                                          "pads the text to 512 and projects K/V of the context in every forward); "
+                                          "this path masks the pad tokens and computes the context projections once "
+                                          "per sample (encode_context), so it executes "
+                                          f"{executed_flops / 1e12:.2f} TFLOP per forward "
+                                          f"({100 * (1 - executed_flops / fwd_flops):.2f} % less)",
+                    "executed_tflops_per_gpu": round(fwd_per_gpu_step * executed_flops / (ms_per_step * 1e-3) / 1e12, 1),
                     "achieved_tflops_per_gpu": round(fwd_per_gpu_step * fwd_flops / (ms_per_step * 1e-3) / 1e12, 1),
                     "mfma_roofline_frac": round(fwd_per_gpu_step * fwd_flops / (ms_per_step * 1e-3) / 1e12
                                                 / PEAK_BF16_TFLOPS, 4),

@@ -648,7 +648,7 @@ extern "C" int omh_dense_f32_bwd(const float* x, const float* W, const float* dy
         hipLaunchKernelGGL(dense_f32_bwd_w_kernel, dim3((unsigned)(((int64_t)N * K + 255) / 256)), dim3(256), 0,
                            (hipStream_t)stream, x, dy, dW_accum, db_accum, B, N, K, act_in);
     if (dx) {
-        if (!dx_accumulate) (void)hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * K, (hipStream_t)stream);
+        if (!dx_accumulate) omh_zero_f32(dx, 1, (int64_t)B * K, (int64_t)B * K, (hipStream_t)stream);
         const int n_chunk = 64;
         dim3 grid((unsigned)(((int64_t)B * K + 255) / 256), (unsigned)((N + n_chunk - 1) / n_chunk));
         hipLaunchKernelGGL(dense_f32_bwd_x_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, W, dy, dx, B, N, K,

@@ -215,8 +215,7 @@ int launch_tn(const omh_gemm_tn_args& a, hipStream_t s) {
     g.splits = (nk + g.ksteps_per_split - 1) / g.ksteps_per_split;
     omh_clear_status();
     if (g.splits > 1 && !ACCUM) {                                    // partial sums are added: start from zero
-        if (a.ldc == a.N) (void)hipMemsetAsync(a.C, 0, sizeof(float) * (size_t)a.M * a.N, s);
-        else (void)hipMemset2DAsync(a.C, sizeof(float) * a.ldc, 0, sizeof(float) * a.N, a.M, s);
+        omh_zero_f32(a.C, a.M, a.N, a.ldc, s);          // a kernel, not a memset node: omh_common.h
     }
     hipLaunchKernelGGL(kern, dim3(tiles, g.splits), dim3(64 * WM * WN), LDS, s, a, g);
     return omh_launch_status();

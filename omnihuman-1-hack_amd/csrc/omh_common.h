@@ -74,6 +74,24 @@ __device__ __forceinline__ void tile_of(int wid, int tiles_m, int tiles_n, int& 
     tn = in_g / gsz;
 }
 
+// Zero fill of rows x cols fp32 (row pitch ld) as a KERNEL.  Not hipMemsetAsync: under hipGraph stream capture a
+// memset node recorded through this library was replayed out of stream order on ROCm 7 (round-2 finding: the
+// input-gradient scratch of omh_dense_f32_bwd lives in recycled graph-pool memory, the memset ran early, a later
+// kernel of the graph reused the block, and the atomics then added onto that kernel's data — every replay after
+// the first returned wrong time-embedding gradients).  A kernel node keeps its place.
+__global__ __launch_bounds__(256) static void omh_zero_f32_kernel(float* __restrict__ p, int64_t rows, int64_t cols,
+                                                                  int64_t ld) {
+    const int64_t n = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        p[(i / cols) * ld + (i % cols)] = 0.f;
+}
+static inline void omh_zero_f32(float* p, int64_t rows, int64_t cols, int64_t ld, hipStream_t s) {
+    const int64_t n = rows * cols;
+    int64_t g = (n + 255) / 256;
+    g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
+    hipLaunchKernelGGL(omh_zero_f32_kernel, dim3((unsigned)g), dim3(256), 0, s, p, rows, cols, ld);
+}
+
 // hipGetLastError() reports the last error of ANY earlier runtime call on this
 // thread (e.g. a probe made by the host framework): clear it before a launch
 // so the status returned after the launch belongs to that launch only.

@@ -576,7 +576,7 @@ def bench_decode(latent, device, iters=1):
     frames = out.shape[1]
     area = (z.shape[2] * z.shape[3]) / (60 * 104)
     flops = (4.29 + (z.shape[1] - 1) * 13.49) * 1e12 * area
-    res = {"frames_per_s": round(frames / dt, 2), "decode_s": round(dt, 3), "frames": int(frames),
+    res = {"frames_per_s": round(frames / dt, 2), "decode_s": round(dt, 3), "frames": int(frames), "repeats": iters,
            "conv_tflops": round(flops / dt / 1e12, 1), "mfma_roofline_frac": round(flops / dt / 2.5e15, 4),
            "finite": bool(torch.isfinite(out).all()), "weights": "random-init"}
     vae.encode([out[:, :5]])                   # warm-up

@@ -93,12 +93,11 @@ def test_dpmpp_matches_reference_vectors():
     assert torch.allclose(o1.step(v, x), x - v, atol=1e-6)
 
 
-@pytest.mark.skipif(not os.path.isdir("/root/reference/seaweed_apt"), reason="reference tree not present")
 def test_oracle_1_3b_forward_matches_reference_probes():
     """BASELINE config 1 at its real size: the oracle's Wan2.1-T2V-1.3B forward (30 layers, d = 1536, S = 1560) on
     c1/noise + c1/neg, t = 999, against 64 probe elements, the mean / abs-mean and a coarse grid of the REAL
     reference's output on the same inputs (oracle/make_golden.py, `dit_wan1_3b_c1.npz`; ~10 s on 8 cores)."""
-    from oracle import detgen
+    from oracle import detgen, wan_dit_oracle as O
     g = np.load(os.path.join(GOLD, "dit_wan1_3b_c1.npz"))
     cfg = O.DiTConfig.wan_t2v_1_3b()
     sd = O.synth_state_dict(cfg, "wan1.3b")
@@ -112,6 +111,7 @@ def test_oracle_1_3b_forward_matches_reference_probes():
     assert abs(float(out.double().abs().mean()) - float(g["abs_mean"])) < 1e-5
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/seaweed_apt"), reason="reference tree not present")
 def test_oracle_against_live_reference():
     from oracle import detgen, ref_import, wan_dit_oracle as O, wan_vae_oracle as V
     cfg = O.DiTConfig(dim=128, ffn_dim=256, num_heads=1, num_layers=3, text_dim=32, text_len=16, freq_dim=32)
