@@ -31,13 +31,24 @@ def _hipcc():
     raise RuntimeError("hipcc not found: the gfx950 kernel library cannot be built")
 
 
+def _generate():
+    """Generated instruction streams: csrc/gen_*.py -> csrc/*_asm.inc (rewritten only when the text changes)."""
+    gen = os.path.join(CSRC, "gen_attn_w64.py")
+    out = os.path.join(CSRC, "attention_w64_asm.inc")
+    if os.path.exists(gen):
+        txt = subprocess.run([sys.executable, gen], check=True, capture_output=True, text=True).stdout
+        if not os.path.exists(out) or open(out).read() != txt:
+            with open(out, "w") as fh:
+                fh.write(txt)
+
+
 def _sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
 def _digest():
     h = hashlib.sha256(" ".join(FLAGS).encode())
-    for f in _sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
+    for f in _sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))) + \
             [os.path.join(INCLUDE, "omh.h")]:
         with open(f, "rb") as fh:
             h.update(os.path.basename(f).encode())     # not the path: the tree is copied to the GPU box
@@ -63,7 +74,9 @@ def _obj_digest(src):
     """Digest of ONE translation unit: its source, the shared headers and the flags (so that editing one .hip
     file recompiles one object, not nine)."""
     h = hashlib.sha256(" ".join(FLAGS).encode())
-    for f in [src] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
+    stem = os.path.basename(src)[:-4]
+    for f in [src] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)
+                            if f.endswith(".h") or (f.endswith(".inc") and f.startswith(stem))) + \
             [os.path.join(INCLUDE, "omh.h")]:
         with open(f, "rb") as fh:
             h.update(fh.read())
@@ -73,6 +86,8 @@ def _obj_digest(src):
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     stamp = os.path.join(LIBDIR, "libomh.sha256")
+    if have_hipcc():
+        _generate()
     if not force and up_to_date():
         return LIB
     # one builder at a time (torchrun starts N ranks that all import the package): the others wait on the lock and

@@ -547,6 +547,9 @@ void flash_attn_fwd_d128_pp_kernel(const omh_attn_args p, const int q_tiles) {
 
 }  // namespace
 
+// attention_w64.hip: 4 waves x 64 query rows, asm-owned register file (long sequences)
+int omh_launch_attn_w64(const omh_attn_args& a, hipStream_t stream);
+
 extern "C" int omh_flash_attn_fwd_d128(const omh_attn_args* args, omh_stream_t stream) {
     if (!args || !args->q || !args->k || !args->vt || !args->o) return OMH_E_BADARG;
     const omh_attn_args& a = *args;
@@ -558,11 +561,18 @@ extern "C" int omh_flash_attn_fwd_d128(const omh_attn_args* args, omh_stream_t s
         return OMH_E_ALIGN;
     if (a.ldv < ((a.Lk + KB - 1) / KB) * KB) return OMH_E_SHAPE;
     // long sequences that fill the chip with 256-row workgroups take the ping-pong kernel
-    const char* force = getenv("OMH_ATTN_KERNEL");                 // "pp" / "base": test / benchmarking override
+    const char* force = getenv("OMH_ATTN_KERNEL");                 // "w64" / "pp" / "base": test / benchmarking override
     const int q_tiles2 = (a.Lq + QB2 - 1) / QB2;
-    const bool pp = force ? (force[0] == 'p') : ((int64_t)q_tiles2 * a.H * a.B >= 512 && a.Lk >= 1024);
+    const bool big = (int64_t)q_tiles2 * a.H * a.B >= 512 && a.Lk >= 1024;
+    // 32-bit buffer offsets inside one (batch, head) slice
+    const bool fits32 = ((int64_t)a.Lq * a.q_rs * 2 < 0x7fffffffLL) && ((int64_t)a.Lk * a.k_rs * 2 < 0x7fffffffLL) &&
+                        ((int64_t)a.Lq * a.o_rs * 2 < 0x7fffffffLL) && ((int64_t)D * a.ldv * 2 < 0x7fffffffLL);
+    const bool w64 = force ? (force[0] == 'w' && fits32) : false;
+    const bool pp = force ? (force[0] == 'p') : big;
     omh_clear_status();
-    if (pp) {
+    if (w64) {
+        omh_launch_attn_w64(a, (hipStream_t)stream);
+    } else if (pp) {
         hipLaunchKernelGGL(flash_attn_fwd_d128_pp_kernel, dim3(q_tiles2 * a.H * a.B), dim3(512), 0,
                            (hipStream_t)stream, a, q_tiles2);
     } else {

@@ -47,6 +47,10 @@ def S(st, qb, kb):  return 32 + st * 64 + (qb * 2 + kb) * 16
 def MI(qb):         return 160 + qb * 16
 def P(qb, kb, a):   return 192 + ((qb * 2 + kb) * 2 + a) * 4
 
+KA = list(range(12, 20))            # K fragment LDS addresses per kk (computed in the prologue)
+VA = list(range(20, 24))            # V^T fragment LDS addresses per (kb, a)
+# scratch SGPRs (named in the clobber list): s92 / s93 DMA offsets, s94 tile counter, s95 K tile stride, s[96:97] exec
+
 M_RUN = [224, 225]
 L_A = [226, 227]
 L_B = [228, 229]
@@ -124,8 +128,8 @@ def qk_phase(e, nxt, kslot, cur, with_softmax, dma_lines, first_tile_c_zero=Fals
 
     def kread(kk):
         st = kk % 3
-        return [f"ds_read_b128 {ar(KR(st, 0), 4)}, %[ka{kk}] offset:{kbase}",
-                f"ds_read_b128 {ar(KR(st, 1), 4)}, %[ka{kk}] offset:{kbase + 8192}"]
+        return [f"ds_read_b128 {ar(KR(st, 0), 4)}, {vr(KA[kk])} offset:{kbase}",
+                f"ds_read_b128 {ar(KR(st, 1), 4)}, {vr(KA[kk])} offset:{kbase + 8192}"]
 
     # MFMA list: per kk: (kb0,qb0) (kb0,qb1) (kb1,qb0) (kb1,qb1)
     mf = []
@@ -234,7 +238,7 @@ def pv_phase(e, cur, vslot, tail_valu):
 
     def vread(i):
         kb, a, db = i >> 3, (i >> 2) & 1, i & 3
-        return f"ds_read_b128 {ar(VR(i % 4), 4)}, %[va{2 * kb + a}] offset:{vbase + db * 4096}"
+        return f"ds_read_b128 {ar(VR(i % 4), 4)}, {vr(VA[2 * kb + a])} offset:{vbase + db * 4096}"
 
     pre = [vread(0), vread(1), vread(2)]
     issued = 3
@@ -262,18 +266,18 @@ def dma_lines(kslot, vslot):
     for j in range(4):
         out.append(f"s_add_u32 m0, %[ldsw], {kslot * 16384 + j * 4096}")
         if j == 0:
-            out.append("s_mov_b32 %[st0], %[skn]")
+            out.append("s_mov_b32 s92, %[skn]")
         else:
-            out.append("s_add_u32 %[st0], %[st0], %[skp]")
-        out.append("buffer_load_dwordx4 %[vok], %[rk], %[st0] offen lds")
+            out.append("s_add_u32 s92, s92, %[skp]")
+        out.append("buffer_load_dwordx4 %[vok], %[rk], s92 offen lds")
     for j in range(4):
         out.append(f"s_add_u32 m0, %[ldsw], {32768 + vslot * 16384 + j * 4096}")
         if j == 0:
-            out.append("s_mov_b32 %[st1], %[svn]")
+            out.append("s_mov_b32 s93, %[svn]")
         else:
-            out.append("s_add_u32 %[st1], %[st1], %[svp]")
-        out.append("buffer_load_dwordx4 %[vov], %[rv], %[st1] offen lds")
-    out.append("s_add_u32 %[skn], %[skn], %[sktile]")
+            out.append("s_add_u32 s93, s93, %[svp]")
+        out.append("buffer_load_dwordx4 %[vov], %[rv], s93 offen lds")
+    out.append("s_add_u32 %[skn], %[skn], s95")
     out.append("s_add_u32 %[svn], %[svn], 128")
     return out
 
@@ -348,6 +352,13 @@ def generate():
             so = "0" if qb == 0 else "%[sq1]"
             e(f"buffer_load_dwordx4 {vr(32 + (qb * 8 + kk) * 4, 4)}, %[voq], %[rq], {so} offen offset:{kk * 32}")
     # constants / state while the loads fly
+    e("s_lshl_b32 s95, %[skp], 2")
+    for kk in range(8):
+        e(f"v_xor_b32 {vr(T0)}, {kk}, %[xh]")
+        e(f"v_lshl_add_u32 {vr(KA[kk])}, {vr(T0)}, 5, %[kab]")
+    for j in range(4):
+        e(f"v_xor_b32 {vr(T0)}, {j}, %[yh]")
+        e(f"v_lshl_add_u32 {vr(VA[j])}, {vr(T0)}, 5, %[vab]")
     e(f"v_mov_b32 {vr(NEGINF)}, 0xff800000")
     for qb in range(2):
         e(f"v_mov_b32 {vr(M_RUN[qb])}, 0")
@@ -364,11 +375,11 @@ def generate():
     for j in range(4):
         e(f"s_add_u32 m0, %[ldsw], {16384 + j * 4096}")
         if j == 0:
-            e("s_mov_b32 %[st0], %[skn]")
+            e("s_mov_b32 s92, %[skn]")
         else:
-            e("s_add_u32 %[st0], %[st0], %[skp]")
-        e("buffer_load_dwordx4 %[vok], %[rk], %[st0] offen lds")
-    e("s_add_u32 %[skn], %[skn], %[sktile]")                  # -> tile 2
+            e("s_add_u32 s92, s92, %[skp]")
+        e("buffer_load_dwordx4 %[vok], %[rk], s92 offen lds")
+    e("s_add_u32 %[skn], %[skn], s95")                  # -> tile 2
     # Q: wait for the 16 loads (the 12 DMAs behind them stay in flight): vmcnt counts in order
     e("s_waitcnt vmcnt(12)")
     for i in range(64):
@@ -395,7 +406,7 @@ def generate():
     for ln in rowmax_lines(0):
         e(ln)
     check_and_rescale(e, 0, "first", first=True)
-    e("s_mov_b32 %[st2], 0")                                   # t
+    e("s_mov_b32 s94, 0")                                   # t
 
     # ---------------- main loop, two tiles per trip
     LOOP, LAST = lab("loop"), [lab("last0"), lab("last1")]
@@ -419,7 +430,7 @@ def generate():
         # phase 2: P.V of tile t ; row sums of tile t, then row max of tile t+1 (its MFMAs are >= 16 MFMAs back)
         pv_phase(e, cur=cur, vslot=p, tail_valu=rowsum_lines(cur) + rowmax_lines(nxt))
         check_and_rescale(e, nxt, f"b{p}")
-        e("s_add_u32 %[st2], %[st2], 1")
+        e("s_add_u32 s94, s94, 1")
 
     def last(p):
         e("s_waitcnt vmcnt(0)")
@@ -429,7 +440,7 @@ def generate():
 
     e.label(LOOP)
     for p in range(2):
-        e("s_cmp_eq_u32 %[st2], %[slast]")
+        e("s_cmp_eq_u32 s94, %[slast]")
         e(f"s_cbranch_scc1 {LAST[p]}")
         body(p)
     e(f"s_branch {LOOP}")
@@ -470,26 +481,23 @@ def generate():
                 if g & 1:
                     e("s_nop 0")
     # log-sum-exp (natural log) for the backward: lanes of the lower half-wave, when requested
-    NOLSE = lab("nolse")
-    e("s_cmp_eq_u32 %[slse], 0")
-    e(f"s_cbranch_scc1 {NOLSE}")
+    # (no lse requested: the descriptor %[rl] has zero records and the two stores are dropped by the hardware)
     for qb in range(2):
         e(f"v_log_f32 {vr(T0 + qb)}, {vr(L_A[qb])}")
     e("s_nop 0")
     for qb in range(2):
         e(f"v_add_f32 {vr(T0 + qb)}, {vr(T0 + qb)}, {vr(M_RUN[qb])}")
         e(f"v_mul_f32 {vr(T0 + qb)}, 0x3f317218, {vr(T0 + qb)}")
-    e("s_mov_b64 %[sx], exec")
+    e("s_mov_b64 s[96:97], exec")
     e("s_mov_b64 exec, 0xffffffff")
     e(f"buffer_store_dword {vr(T0)}, %[vol], %[rl], 0 offen")
     e(f"buffer_store_dword {vr(T1)}, %[vol], %[rl], 0 offen offset:128")
-    e("s_mov_b64 exec, %[sx]")
-    e.label(NOLSE)
+    e("s_mov_b64 exec, s[96:97]")
     e("s_waitcnt vmcnt(0)")
     return e
 
 
-CLOBBER_V = range(32, 256)
+CLOBBER_V = range(12, 256)
 CLOBBER_A = range(0, 256)
 
 
@@ -500,7 +508,7 @@ def main():
     body = e.text().split("\n")
     print(" \\\n".join(body))
     print("")
-    clob = ['"memory"', '"vcc"', '"scc"'] + [f'"v{i}"' for i in CLOBBER_V] + [f'"a{i}"' for i in CLOBBER_A]
+    clob = ['"memory"', '"vcc"', '"scc"', '"s92"', '"s93"', '"s94"', '"s95"', '"s96"', '"s97"'] + [f'"v{i}"' for i in CLOBBER_V] + [f'"a{i}"' for i in CLOBBER_A]
     print("#define OMH_ATTN_W64_CLOBBERS \\")
     rows = [", ".join(clob[i:i + 12]) for i in range(0, len(clob), 12)]
     print(", \\\n    ".join(rows).join(["    ", ""]))
