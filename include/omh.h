@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OMH_ABI_VERSION 2
+#define OMH_ABI_VERSION 3
 
 #define OMH_E_BADARG   (-1)   /* null pointer / non-positive size             */
 #define OMH_E_ALIGN    (-2)   /* pointer or leading dimension not aligned     */
@@ -115,6 +115,11 @@ typedef struct omh_attn_args {
     int32_t ldv;
     float scale;                  /* softmax scale, 1/sqrt(128) in the reference  */
     float* lse;                   /* optional [B,H,Lq] fp32 log-sum-exp (natural log) for backward; may be NULL */
+    /* != 0: q already carries the factor scale*log2(e) (folded into the producing norm kernel, see
+       omh_rmsnorm_rope_bf16 out_scale: one rounding to bf16 instead of two); `scale` is then only documentation.
+       0: the long-sequence kernel multiplies q by scale*log2(e) itself and re-rounds it to bf16 (a 2^-9 relative
+       perturbation of q); the short-sequence kernels apply the factor to the fp32 scores.                        */
+    int32_t q_prescaled;
 } omh_attn_args;
 
 int omh_flash_attn_fwd_d128(const omh_attn_args* args, omh_stream_t stream);
@@ -178,11 +183,15 @@ int omh_rmsnorm_rope(const float* x, int64_t ldx, void* y_bf16, int64_t rows, in
                      int32_t head_dim, const int32_t* grid, int32_t seq_len, omh_stream_t stream);
 
 /* Same with a bf16 input [rows, ldx] (the inference path keeps the q|k projection in bf16: half the
- * HBM traffic of this HBM-bound step; the training recompute uses the fp32 form above). */
+ * HBM traffic of this HBM-bound step; the training recompute uses the fp32 form above).  out_scale multiplies the
+ * result in fp32 before the rounding to bf16: the self-attention q is produced with out_scale =
+ * head_dim^-0.5 * log2(e) (attention.py:96-127 softmax_scale), so that the attention kernel's exponentials need no
+ * per-score multiply (omh_attn_args.q_prescaled). */
 int omh_rmsnorm_rope_bf16(const void* x_bf16, int64_t ldx, void* y_bf16, int64_t rows, int32_t dim,
                           const float* weight, float eps, int32_t do_norm,
                           const float* rope_cos, const float* rope_sin, int32_t rope_len,
-                          int32_t head_dim, const int32_t* grid, int32_t seq_len, omh_stream_t stream);
+                          int32_t head_dim, const int32_t* grid, int32_t seq_len, float out_scale,
+                          omh_stream_t stream);
 
 /* fp32 -> bf16 cast (round to nearest even) of a contiguous buffer. */
 int omh_cast_f32_bf16(const float* x, void* y_bf16, int64_t n, omh_stream_t stream);

@@ -21,7 +21,7 @@ class OmhError(RuntimeError):
     pass
 
 
-ABI_VERSION = 2          # == OMH_ABI_VERSION of include/omh.h; checked against the loaded library below
+ABI_VERSION = 3          # == OMH_ABI_VERSION of include/omh.h; checked against the loaded library below
 
 
 def _load():
@@ -84,7 +84,7 @@ class AttnArgs(C.Structure):
                 ("B", i32), ("H", i32), ("Lq", i32), ("Lk", i32),
                 ("q_bs", i64), ("q_rs", i64), ("k_bs", i64), ("k_rs", i64),
                 ("vt_bs", i64), ("o_bs", i64), ("o_rs", i64),
-                ("ldv", i32), ("scale", f32), ("lse", vp)]
+                ("ldv", i32), ("scale", f32), ("lse", vp), ("q_prescaled", i32)]
 
 
 class AttnBwdArgs(C.Structure):
@@ -120,7 +120,7 @@ _SIGS = {
     "omh_flash_attn_bwd_d128": (i32, [C.POINTER(AttnBwdArgs), vp]),
     "omh_layernorm_modulate": (i32, [vp, vp, i64, i32, f32, f32, vp, vp, i64, vp, vp, i64, i64, vp]),
     "omh_rmsnorm_rope": (i32, [vp, i64, vp, i64, i32, vp, f32, i32, vp, vp, i32, i32, vp, i32, vp]),
-    "omh_rmsnorm_rope_bf16": (i32, [vp, i64, vp, i64, i32, vp, f32, i32, vp, vp, i32, i32, vp, i32, vp]),
+    "omh_rmsnorm_rope_bf16": (i32, [vp, i64, vp, i64, i32, vp, f32, i32, vp, vp, i32, i32, vp, i32, f32, vp]),
     "omh_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
     "omh_patchify": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "omh_unpatchify": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),

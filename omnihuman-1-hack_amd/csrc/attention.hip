@@ -142,7 +142,7 @@ void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
-    const float sc = p.scale * 1.4426950408889634f;   // scores -> log2 domain
+    const float sc = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;   // scores -> log2 domain
 
     if (n_tiles > 0) {
         OMH_GLOAD(0)
@@ -358,7 +358,7 @@ void flash_attn_fwd_d128_pp_kernel(const omh_attn_args p, const int q_tiles) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
-    const float sc = p.scale * 1.4426950408889634f;
+    const float sc = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
     bf16x8 pf[2][2];
     float alpha_keep = 1.0f;
 
@@ -567,8 +567,10 @@ extern "C" int omh_flash_attn_fwd_d128(const omh_attn_args* args, omh_stream_t s
     // 32-bit buffer offsets inside one (batch, head) slice
     const bool fits32 = ((int64_t)a.Lq * a.q_rs * 2 < 0x7fffffffLL) && ((int64_t)a.Lk * a.k_rs * 2 < 0x7fffffffLL) &&
                         ((int64_t)a.Lq * a.o_rs * 2 < 0x7fffffffLL) && ((int64_t)D * a.ldv * 2 < 0x7fffffffLL);
-    const bool w64 = force ? (force[0] == 'w' && fits32) : false;
-    const bool pp = force ? (force[0] == 'p') : big;
+    // long sequences that fill the chip with 256-row workgroups: the 4 x 64 kernel (attention_w64.hip); "pp" keeps
+    // the 8-wave kernel it replaced selectable for A/B timing
+    const bool w64 = force ? (force[0] == 'w' && fits32) : (big && fits32);
+    const bool pp = force ? (force[0] == 'p') : (big && !w64);
     omh_clear_status();
     if (w64) {
         omh_launch_attn_w64(a, (hipStream_t)stream);

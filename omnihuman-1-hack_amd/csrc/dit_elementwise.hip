@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256)
 void rmsnorm_rope_kernel(const void* __restrict__ xv, int64_t ldx, uint16_t* __restrict__ y, int64_t rows,
                          int dim, const float* __restrict__ weight, float eps, int do_norm,
                          const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
-                         int rope_len, int head_dim, const int* __restrict__ grid, int seq_len) {
+                         int rope_len, int head_dim, const int* __restrict__ grid, int seq_len, float out_scale) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -101,7 +101,8 @@ void rmsnorm_rope_kernel(const void* __restrict__ xv, int64_t ldx, uint16_t* __r
             q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
         }
     }
-    const float rinv = do_norm ? rsqrtf(wave_sum(q) / dim + eps) : 1.0f;
+    // out_scale rides on the normalisation factor: one fp32 multiply per element either way (1.0f is exact)
+    const float rinv = (do_norm ? rsqrtf(wave_sum(q) / dim + eps) : 1.0f) * out_scale;
 
     // token position for RoPE
     bool rot = false;
@@ -296,7 +297,7 @@ template <bool IN_BF16>
 static int rmsnorm_rope_launch(const void* x, int64_t ldx, void* y, int64_t rows, int32_t dim, const float* weight,
                                float eps, int32_t do_norm, const float* rope_cos, const float* rope_sin,
                                int32_t rope_len, int32_t head_dim, const int32_t* grid, int32_t seq_len,
-                               omh_stream_t stream) {
+                               float out_scale, omh_stream_t stream) {
     if (!x || !y || rows <= 0 || dim <= 0) return OMH_E_BADARG;
     if ((dim & 3) || dim > MAXV_GENERIC * 256 || (ldx & 3)) return OMH_E_SHAPE;
     if (rope_cos && (!rope_sin || !grid || seq_len <= 0 || head_dim <= 0 || (head_dim & 3) || dim % head_dim))
@@ -307,7 +308,7 @@ static int rmsnorm_rope_launch(const void* x, int64_t ldx, void* y, int64_t rows
                                : (dim <= 20 * 256 ? rmsnorm_rope_kernel<20, IN_BF16> : rmsnorm_rope_kernel<MAXV_GENERIC, IN_BF16>);
     hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        x, ldx, (uint16_t*)y, rows, dim, weight, eps, do_norm, rope_cos, rope_sin, rope_len,
-                       head_dim, grid, seq_len);
+                       head_dim, grid, seq_len, out_scale);
     return omh_launch_status();
 }
 
@@ -316,15 +317,15 @@ extern "C" int omh_rmsnorm_rope(const float* x, int64_t ldx, void* y, int64_t ro
                                 const float* rope_sin, int32_t rope_len, int32_t head_dim, const int32_t* grid,
                                 int32_t seq_len, omh_stream_t stream) {
     return rmsnorm_rope_launch<false>(x, ldx, y, rows, dim, weight, eps, do_norm, rope_cos, rope_sin, rope_len,
-                                      head_dim, grid, seq_len, stream);
+                                      head_dim, grid, seq_len, 1.0f, stream);
 }
 
 extern "C" int omh_rmsnorm_rope_bf16(const void* x_bf16, int64_t ldx, void* y, int64_t rows, int32_t dim,
                                      const float* weight, float eps, int32_t do_norm, const float* rope_cos,
                                      const float* rope_sin, int32_t rope_len, int32_t head_dim,
-                                     const int32_t* grid, int32_t seq_len, omh_stream_t stream) {
+                                     const int32_t* grid, int32_t seq_len, float out_scale, omh_stream_t stream) {
     return rmsnorm_rope_launch<true>(x_bf16, ldx, y, rows, dim, weight, eps, do_norm, rope_cos, rope_sin, rope_len,
-                                     head_dim, grid, seq_len, stream);
+                                     head_dim, grid, seq_len, out_scale, stream);
 }
 
 extern "C" int omh_cast_f32_bf16(const float* x, void* y, int64_t n, omh_stream_t stream) {

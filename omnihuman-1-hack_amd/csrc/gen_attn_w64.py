@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Generator of the instruction stream of ``flash_attn_fwd_d128_w64_kernel`` (attention_w64.hip).
+"""Generator of the instruction streams of ``flash_attn_fwd_d128_w64_kernel<V>`` (attention_w64.hip).
 
 The long-sequence attention kernel of round 2: 4 waves x 64 query rows per workgroup, ONE wave per SIMD owning
 the whole 512-entry register file.  hipcc cannot be made to keep 128 accumulators + 64 operand registers in the
 accumulator half without shuffling them through v_accvgpr_read/write (round 1, DESIGN.md 4.4 last row: 744 TF), so
-the main loop is written out instruction by instruction here, with a fixed register map, and pasted into the
+the kernel body is written out instruction by instruction here, with a fixed register map, and pasted into the
 kernel as one ``asm volatile`` block (``attention_w64_asm.inc``).  The surrounding HIP code computes addresses
 and descriptors only.
 
@@ -16,27 +16,41 @@ between lanes; K [64][128] / V^T [128][64] bf16 tiles, 16-byte-slot XOR swizzle,
   * two 32-query blocks per wave share every K / V^T fragment read: 0.5 ds_read_b128 per MFMA instead of 1;
   * O (128 regs) and the pre-scaled Q fragments (64 regs) live in AGPRs, K / V^T fragment rings too — the arch
     VGPRs hold two score sets (128), the packed P (32) and the softmax state;
-  * Q is multiplied by scale*log2(e) once (bf16), and the running max enters the scores through the MFMA's C
-    operand (16 registers per query block holding -m): p = exp2(S) needs NO per-element subtract / fma;
+  * q carries scale*log2(e) (folded into the norm kernel, or applied in the prologue here), and the running max
+    enters the scores through the MFMA's C operand (16 registers per query block holding -m): p = exp2(S) needs NO
+    per-element subtract / fma;
   * the running max is only moved when a row's new maximum exceeds it by more than THR = 4 (factor 16 in P):
     the rescale of O (AGPR round trip) is a rare slow path, never on the hot path;
   * per tile: phase 1 = K(t+1).Q^T (32 MFMA) || exp2 + bf16 packing of tile t (96 VALU) || K fragment reads,
     phase 2 = V^T(t).P^T(t) (32 MFMA) || row sums of tile t + row max of tile t+1 (~100 VALU) || V^T fragment reads;
     <= 4.2 non-MFMA issues per MFMA (the budget is 5: MI355X_MICROARCH.md, one wave per SIMD).
 
-Register map (asm-owned; inputs stay in the compiler's operand registers v0..v31 / SGPRs):
+Variants (selected at launch, OMH_W64_VARIANT; kept side by side for A/B timing on one box):
+  V0  K / V^T rings of two 16 KiB slots each, all LDS-DMA issued at the head of phase 1, every phase starts by
+      reading its own first fragments;
+  V1  = V0 with the eight DMA pieces spread over phase 1 and the first three V^T fragments of phase 2 read under
+      the last MFMAs of phase 1;
+  V2  = V1 with a K ring of THREE slots filled three tiles ahead, so that the first K fragments of the next tile are
+      read under the last MFMAs of phase 2 (no phase starts by waiting for the LDS).
+
+Register map (asm-owned; the thirteen per-lane inputs stay in the compiler's operand registers v0..v11):
   a[0:127]    O^T accumulators   [qb][db] 16 each
   a[128:191]  Q fragments        [qb][kk] 4 each (bf16x8)
   a[192:215]  K fragment ring    3 stages x [kb] x 4
   a[216:231]  V^T fragment ring  4 stages x 4
-  v[32:95]    score set 0        [qb][kb] 16 each          v[96:159] score set 1
+  v[12:19]    K fragment LDS addresses (per kk)      v[20:23]  V^T fragment LDS addresses (per kb, a)
+  v[32:95]    score set 0        [qb][kb] 16 each    v[96:159] score set 1
   v[160:191]  MI = -m_run        [qb] 16 copies (MFMA C operand)
   v[192:223]  P packed bf16      [qb][kb][a] 4 each
   v[224:255]  state / temporaries
+  s92 s93 DMA source offsets, s94 tile counter, s95 K tile stride, s[96:97] exec save, s98 K read-slot offset,
+  s99 K DMA-slot offset, s91 address step of the K ring
 """
 import sys
 
 THR = "4.0"                      # inline constant: rescale when a row max exceeds the running max by > 4 (log2 units)
+KSLOT = 16384
+
 
 # ---------------------------------------------------------------- register map
 def O(qb, db):      return (qb * 4 + db) * 16
@@ -47,10 +61,9 @@ def S(st, qb, kb):  return 32 + st * 64 + (qb * 2 + kb) * 16
 def MI(qb):         return 160 + qb * 16
 def P(qb, kb, a):   return 192 + ((qb * 2 + kb) * 2 + a) * 4
 
-KA = list(range(12, 20))            # K fragment LDS addresses per kk (computed in the prologue)
-VA = list(range(20, 24))            # V^T fragment LDS addresses per (kb, a)
-# scratch SGPRs (named in the clobber list): s92 / s93 DMA offsets, s94 tile counter, s95 K tile stride, s[96:97] exec
 
+KA = list(range(12, 20))
+VA = list(range(20, 24))
 M_RUN = [224, 225]
 L_A = [226, 227]
 L_B = [228, 229]
@@ -60,7 +73,7 @@ T0, T1, T2, T3 = 234, 235, 236, 237
 NEGINF = 238
 VLIM = 239
 INV = [240, 241]
-E0 = 242                          # 242..249 epilogue scratch (8)
+E0 = 242                          # 242..249 scratch (8)
 
 
 def vr(lo, n=1):   return f"v{lo}" if n == 1 else f"v[{lo}:{lo + n - 1}]"
@@ -68,141 +81,126 @@ def ar(lo, n=1):   return f"a{lo}" if n == 1 else f"a[{lo}:{lo + n - 1}]"
 
 
 class Emit:
-    def __init__(self):
-        self.lines = []
+    def __init__(self, tag):
+        self.lines, self.tag = [], tag
 
     def __call__(self, s):
         self.lines.append(s)
+
+    def lab(self, name):
+        return f".Lw64v{self.tag}_{name}_%="
 
     def label(self, name):
         self.lines.append(f"{name}:")
 
     def text(self):
-        out = []
-        for ln in self.lines:
-            out.append('    "%s\\n\\t"' % ln)
-        return "\n".join(out)
+        return "\n".join('    "%s\\n\\t"' % ln for ln in self.lines)
 
 
-def lab(name):
-    return f".Lw64_{name}_%="
+# ---------------------------------------------------------------- op lists and the LDS wait tracker
+# op = ("m", text, [tags needed])  MFMA   |  ("r", tag, text)  ds_read   |  ("x", text)  anything else
+def linearize(e, ops, pending):
+    """Emit `ops` in order; before an MFMA that needs ds_read results, emit the s_waitcnt lgkmcnt that makes exactly
+    those reads complete (LDS returns in order).  `pending` = tags of reads issued earlier and not yet waited for,
+    oldest first.  Returns the pending list at the end."""
+    pending = list(pending)
+    for op in ops:
+        if op[0] == "r":
+            e(op[2])
+            pending.append(op[1])
+        elif op[0] == "m":
+            need = [t for t in op[2] if t in pending]
+            if need:
+                last = max(pending.index(t) for t in need)
+                allowed = len(pending) - last - 1
+                assert allowed <= 15
+                e(f"s_waitcnt lgkmcnt({allowed})")
+                pending = pending[last + 1:]
+            e(op[1])
+        else:
+            e(op[1])
+    return pending
 
 
-# ---------------------------------------------------------------- phase building blocks
-def interleave(e, mfmas, fillers_per_gap, pre=None):
-    """mfmas: list of (wait_or_None, text).  fillers_per_gap: list (len == len(mfmas)) of lists of filler lines issued
-    AFTER the MFMA of that gap.  pre: lines before the first MFMA."""
-    for ln in pre or []:
-        e(ln)
-    for (wait, txt), fill in zip(mfmas, fillers_per_gap):
-        if wait is not None:
-            e(wait)
-        e(txt)
-        for ln in fill:
-            e(ln)
+def weave(mfmas, plans, pre=()):
+    """mfmas: list of ("m", ...) ops; plans: lists (one entry per gap) of lists of ops issued after that MFMA."""
+    ops = list(pre)
+    for g, m in enumerate(mfmas):
+        ops.append(m)
+        for pl in plans:
+            ops.extend(pl[g])
+    return ops
 
 
-def spread(items, gaps, start=0, end=None, per_gap_cap=None):
-    """Distribute `items` (ordered) over gaps[start:end] as evenly as possible; returns list of lists."""
+def spread(items, gaps, start=0, end=None):
+    """Distribute `items` (ordered) over gaps[start:end] as evenly as possible; returns a per-gap list of lists."""
     end = gaps if end is None else end
     n = end - start
     out = [[] for _ in range(gaps)]
-    if not items:
-        return out
     for i, it in enumerate(items):
-        g = start + min(n - 1, (i * n) // len(items))
-        out[g].append(it)
+        out[start + min(n - 1, (i * n) // len(items))].append(it)
     return out
 
 
-def merge(*plans):
-    gaps = len(plans[0])
-    return [sum((p[g] for p in plans), []) for g in range(gaps)]
+def X(lines):
+    return [("x", ln) for ln in lines]
 
 
-def qk_phase(e, nxt, kslot, cur, with_softmax, dma_lines, first_tile_c_zero=False):
-    """K(t+1).Q^T -> score set `nxt` (C = MI, i.e. scores - m_run), K fragments from ring slot `kslot`;
-    under it: exp2 + bf16 packing of score set `cur` (if with_softmax) and the LDS-DMA issue of the next tiles."""
-    kbase = kslot * 16384
-    reads = []                      # (line) in issue order: step kk -> 2 reads (kb 0, 1)
+# ---------------------------------------------------------------- pieces
+def kread_ops(kk, kbase):
+    st = kk % 3
+    return [("r", f"K{kk}.0", f"ds_read_b128 {ar(KR(st, 0), 4)}, {vr(KA[kk])} offset:{kbase}"),
+            ("r", f"K{kk}.1", f"ds_read_b128 {ar(KR(st, 1), 4)}, {vr(KA[kk])} offset:{kbase + 8192}")]
 
-    def kread(kk):
-        st = kk % 3
-        return [f"ds_read_b128 {ar(KR(st, 0), 4)}, {vr(KA[kk])} offset:{kbase}",
-                f"ds_read_b128 {ar(KR(st, 1), 4)}, {vr(KA[kk])} offset:{kbase + 8192}"]
 
-    # MFMA list: per kk: (kb0,qb0) (kb0,qb1) (kb1,qb0) (kb1,qb1)
+def vread_op(i, vbase):
+    kb, a, db = i >> 3, (i >> 2) & 1, i & 3
+    return ("r", f"V{i}", f"ds_read_b128 {ar(VR(i % 4), 4)}, {vr(VA[2 * kb + a])} offset:{vbase + db * 4096}")
+
+
+def qk_mfmas(nxt, c_zero=False):
+    """32 MFMAs of K.Q^T into score set nxt (C = MI = -m_run on the first k step), + the fragment reads that ride
+    behind them (steps kk+2, after the 2nd MFMA of step kk)."""
     mf = []
-    outstanding = 0                 # ds_reads issued and not yet known complete, in order
-    # reads for kk = 0, 1 go in front
-    pre = kread(0) + kread(1)
-    issued = 4                      # reads issued so far
-    fill_reads = [[] for _ in range(32)]
     for kk in range(8):
-        for j, (kb, qb) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
-            g = kk * 4 + j
-            st = kk % 3
-            c = vr(MI(qb), 16) if kk == 0 else vr(S(nxt, qb, kb), 16)
-            if kk == 0 and first_tile_c_zero:
-                c = "0"
-            txt = f"v_mfma_f32_32x32x16_bf16 {vr(S(nxt, qb, kb), 16)}, {ar(KR(st, kb), 4)}, {ar(Q(qb, kk), 4)}, {c}"
-            wait = None
-            if j == 0 or j == 2:
-                # need read index (2kk + kb) complete: outstanding allowed = issued - (2kk + kb + 1)
-                need = 2 * kk + kb + 1
-                wait = f"s_waitcnt lgkmcnt({issued - need})"
-            mf.append((wait, txt))
-            # after the LAST MFMA using stage (kk % 3) ... the ring has 3 stages: stage of kk+2 == stage of kk-1, free
-            # once step kk-1's MFMAs are issued; issue the reads of step kk+2 after the 2nd MFMA of step kk
-            if j == 1 and kk + 2 < 8:
-                fill_reads[g] = kread(kk + 2)
-                issued += 2
-    # softmax of the current tile: 64 exp (in place) + 32 cvt
-    valu = []
-    if with_softmax:
-        for qb in range(2):
-            for kb in range(2):
-                base = S(cur, qb, kb)
-                for a in range(2):
-                    for eidx in range(4):
-                        r0 = base + 8 * a + 2 * eidx
-                        valu.append(f"v_exp_f32 {vr(r0)}, {vr(r0)}")
-                        valu.append(f"v_exp_f32 {vr(r0 + 1)}, {vr(r0 + 1)}")
-                # packing trails the exponentials by one (qb, kb) block: no trans -> use adjacency
-                for a in range(2):
-                    for eidx in range(4):
-                        r0 = base + 8 * a + 2 * eidx
-                        valu.append(("cvt", f"v_cvt_pk_bf16_f32 {vr(P(qb, kb, a) + eidx)}, {vr(r0)}, {vr(r0 + 1)}"))
-        # reorder: keep each block's cvts a few instructions behind its exps (they are: 16 exps precede them)
-        valu = [v[1] if isinstance(v, tuple) else v for v in valu]
-    plan_valu = spread(valu, 32, 2, 32)
-    plan_dma = spread(dma_lines, 32, 0, 6)
-    interleave(e, mf, merge(plan_dma, fill_reads, plan_valu), pre=pre)
+        for kb, qb in ((0, 0), (0, 1), (1, 0), (1, 1)):
+            c = ("0" if c_zero else vr(MI(qb), 16)) if kk == 0 else vr(S(nxt, qb, kb), 16)
+            mf.append(("m", f"v_mfma_f32_32x32x16_bf16 {vr(S(nxt, qb, kb), 16)}, {ar(KR(kk % 3, kb), 4)}, "
+                            f"{ar(Q(qb, kk), 4)}, {c}", [f"K{kk}.{kb}"]))
+    return mf
 
 
-def softmax_only(e, cur):
+def qk_read_plan(kbase, first=2):
+    plan = [[] for _ in range(32)]
+    for kk in range(8):
+        if first <= kk + 2 < 8:
+            plan[kk * 4 + 1] = kread_ops(kk + 2, kbase)
+    return plan
+
+
+def softmax_lines(cur):
+    """exp2 in place + bf16 packing of score set cur: 64 + 32 VALU; a block's packing trails its exponentials."""
+    out = []
     for qb in range(2):
         for kb in range(2):
             base = S(cur, qb, kb)
-            for r in range(16):
-                e(f"v_exp_f32 {vr(base + r)}, {vr(base + r)}")
+            out += [f"v_exp_f32 {vr(base + r)}, {vr(base + r)}" for r in range(16)]
             for a in range(2):
                 for eidx in range(4):
                     r0 = base + 8 * a + 2 * eidx
-                    e(f"v_cvt_pk_bf16_f32 {vr(P(qb, kb, a) + eidx)}, {vr(r0)}, {vr(r0 + 1)}")
+                    out.append(f"v_cvt_pk_bf16_f32 {vr(P(qb, kb, a) + eidx)}, {vr(r0)}, {vr(r0 + 1)}")
+    return out
 
 
 def rowsum_lines(cur):
-    out = []
-    for qb in range(2):
+    a, b = [], []
+    for qb, dst in ((0, a), (1, b)):
         regs = [S(cur, qb, kb) + r for kb in range(2) for r in range(16)]
         for i, r in enumerate(regs):
             acc = L_A[qb] if i % 2 == 0 else L_B[qb]
-            out.append(f"v_add_f32 {vr(acc)}, {vr(acc)}, {vr(r)}")
-    # interleave the two query blocks so that dependent adds are 4 apart
-    a, b = out[:32], out[32:]
+            dst.append(f"v_add_f32 {vr(acc)}, {vr(acc)}, {vr(r)}")
     mixed = []
-    for i in range(0, 32, 2):
+    for i in range(0, 32, 2):                                   # dependent adds end up 4 apart
         mixed += [a[i], a[i + 1], b[i], b[i + 1]]
     return mixed
 
@@ -231,58 +229,25 @@ def rowmax_lines(nxt):
     return out
 
 
-def pv_phase(e, cur, vslot, tail_valu):
-    """O^T += V^T(t) P^T(t): 16 fragment steps x 2 query blocks; V^T fragments from ring slot `vslot` (ring of 4,
-    read 3 steps ahead); `tail_valu` lines are spread under the MFMAs."""
-    vbase = 32768 + vslot * 16384
-
-    def vread(i):
-        kb, a, db = i >> 3, (i >> 2) & 1, i & 3
-        return f"ds_read_b128 {ar(VR(i % 4), 4)}, {vr(VA[2 * kb + a])} offset:{vbase + db * 4096}"
-
-    pre = [vread(0), vread(1), vread(2)]
-    issued = 3
-    mf, fill_reads = [], [[] for _ in range(32)]
+def pv_mfmas(cur):
+    mf = []
     for i in range(16):
         kb, a, db = i >> 3, (i >> 2) & 1, i & 3
         for qb in range(2):
-            g = 2 * i + qb
-            wait = f"s_waitcnt lgkmcnt({issued - (i + 1)})" if qb == 0 else None
-            mf.append((wait, f"v_mfma_f32_32x32x16_bf16 {ar(O(qb, db), 16)}, {ar(VR(i % 4), 4)}, "
-                             f"{vr(P(qb, kb, a), 4)}, {ar(O(qb, db), 16)}"))
-            # stage (i+3)%4 == (i-1)%4 is free once step i-1's MFMAs are issued: read step i+3 after the 1st MFMA of step i
-            if qb == 0 and i + 3 < 16:
-                fill_reads[g] = [vread(i + 3)]
-                issued += 1
-    plan = spread(tail_valu, 32, 1, 32)
-    interleave(e, mf, merge(fill_reads, plan), pre=pre)
+            mf.append(("m", f"v_mfma_f32_32x32x16_bf16 {ar(O(qb, db), 16)}, {ar(VR(i % 4), 4)}, "
+                            f"{vr(P(qb, kb, a), 4)}, {ar(O(qb, db), 16)}", [f"V{i}"]))
+    return mf
 
 
-def dma_lines(kslot, vslot):
-    """LDS-DMA of K(next-next) -> K ring slot kslot and V^T(next) -> V ring slot vslot: 4 + 4 pieces of 1 KiB per wave.
-    Source offsets: per-lane voffset + running scalar offsets (%[skn] / %[svn] hold the tile base, pieces add a
-    multiple of the piece stride held in %[skp] / %[svp])."""
-    out = []
-    for j in range(4):
-        out.append(f"s_add_u32 m0, %[ldsw], {kslot * 16384 + j * 4096}")
-        if j == 0:
-            out.append("s_mov_b32 s92, %[skn]")
-        else:
-            out.append("s_add_u32 s92, s92, %[skp]")
-        out.append("buffer_load_dwordx4 %[vok], %[rk], s92 offen lds")
-    for j in range(4):
-        out.append(f"s_add_u32 m0, %[ldsw], {32768 + vslot * 16384 + j * 4096}")
-        if j == 0:
-            out.append("s_mov_b32 s93, %[svn]")
-        else:
-            out.append("s_add_u32 s93, s93, %[svp]")
-        out.append("buffer_load_dwordx4 %[vov], %[rv], s93 offen lds")
-    out.append("s_add_u32 %[skn], %[skn], s95")
-    out.append("s_add_u32 %[svn], %[svn], 128")
-    return out
+def pv_read_plan(vbase, first=3):
+    plan = [[] for _ in range(32)]
+    for i in range(16):
+        if first <= i + 3 < 16:
+            plan[2 * i] = [vread_op(i + 3, vbase)]
+    return plan
 
 
-def mask_block(e, st, tag):
+def mask_block(e, st):
     """Scores of set `st` whose key index >= klen -> -inf.  %[srem] = klen - 64 * tile (1..63 when the block runs)."""
     e(f"v_lshlrev_b32 {vr(VLIM)}, 3, %[lh]")
     e(f"v_sub_u32 {vr(VLIM)}, %[srem], {vr(VLIM)}")           # rem - 8 h : mask register r when c(r) >= vlim
@@ -298,7 +263,7 @@ def mask_block(e, st, tag):
 def slow_path(e, st, qb, first):
     """Move the running max of query block qb: delta = first ? rowmax : max(rowmax, 0) (rowmax is relative to the
     running max already), then O, l, the pending scores of set `st` and -m (MI) follow."""
-    d, al, t = T0, T1, T2
+    d, al = T0, T1
     if first:
         e(f"v_mov_b32 {vr(d)}, {vr(MXA[qb])}")
     else:
@@ -332,9 +297,8 @@ def slow_path(e, st, qb, first):
 
 
 def check_and_rescale(e, st, tag, first=False):
-    """After the row max of set `st` is in MXA: per query block, branch to the rescale when needed."""
     for qb in range(2):
-        skip = lab(f"nores_{tag}_{qb}")
+        skip = e.lab(f"nores_{tag}_{qb}")
         if not first:
             e(f"v_cmp_lt_f32 vcc, {THR}, {vr(MXA[qb])}")
             e(f"s_cbranch_vccz {skip}")
@@ -343,19 +307,56 @@ def check_and_rescale(e, st, tag, first=False):
             e.label(skip)
 
 
+def rotate(sreg, nslots):
+    return [f"s_add_u32 {sreg}, {sreg}, {KSLOT}", f"s_cmp_eq_u32 {sreg}, {nslots * KSLOT}", f"s_cselect_b32 {sreg}, 0, {sreg}"]
+
+
 # ---------------------------------------------------------------- whole stream
-def generate():
-    e = Emit()
-    # ---------------- prologue: Q fragments -> pre-scaled bf16 -> AGPRs
+def generate(variant):
+    dma_spread = variant >= 1
+    vpre = variant >= 1
+    k3 = variant >= 2
+    # LDS map: two-slot rings: K [0, 32K) | V^T [32K, 64K).  Three-slot K ring: V^T [0, 32K) | K [32K, 80K) — the K
+    # addresses carry the ring base and slot in the address registers, so every ds_read offset stays below 64 KiB
+    VBASE = 0 if k3 else 2 * KSLOT
+    KBASE = 2 * KSLOT if k3 else 0
+    e = Emit(variant)
+
+    def k_dma(slot_expr, advance=True):
+        """4 pieces of K(next) -> K ring slot; slot_expr: literal byte offset or an SGPR name."""
+        out = [f"s_add_u32 m0, %[ldsw], {slot_expr}"]
+        if KBASE:
+            out.append(f"s_add_u32 m0, m0, {KBASE}")
+        for j in range(4):
+            if j:
+                out.append("s_add_u32 m0, m0, 4096")
+            out.append("s_mov_b32 s92, %[skn]" if j == 0 else "s_add_u32 s92, s92, %[skp]")
+            out.append("buffer_load_dwordx4 %[vok], %[rk], s92 offen lds")
+        if advance:
+            out.append("s_add_u32 %[skn], %[skn], s95")
+        return out
+
+    def v_dma(slot):
+        out = [f"s_add_u32 m0, %[ldsw], {VBASE + slot * KSLOT}"]
+        for j in range(4):
+            if j:
+                out.append("s_add_u32 m0, m0, 4096")
+            out.append("s_mov_b32 s93, %[svn]" if j == 0 else "s_add_u32 s93, s93, %[svp]")
+            out.append("buffer_load_dwordx4 %[vov], %[rv], s93 offen lds")
+        out.append("s_add_u32 %[svn], %[svn], 128")
+        return out
+
+    # ---------------- prologue: Q fragments -> (pre-scaled) bf16 -> AGPRs
     for qb in range(2):
         for kk in range(8):
             so = "0" if qb == 0 else "%[sq1]"
             e(f"buffer_load_dwordx4 {vr(32 + (qb * 8 + kk) * 4, 4)}, %[voq], %[rq], {so} offen offset:{kk * 32}")
-    # constants / state while the loads fly
     e("s_lshl_b32 s95, %[skp], 2")
     for kk in range(8):
         e(f"v_xor_b32 {vr(T0)}, {kk}, %[xh]")
         e(f"v_lshl_add_u32 {vr(KA[kk])}, {vr(T0)}, 5, %[kab]")
+        if KBASE:
+            e(f"v_add_u32 {vr(KA[kk])}, {KBASE}, {vr(KA[kk])}")
     for j in range(4):
         e(f"v_xor_b32 {vr(T0)}, {j}, %[yh]")
         e(f"v_lshl_add_u32 {vr(VA[j])}, {vr(T0)}, 5, %[vab]")
@@ -368,20 +369,12 @@ def generate():
             e(f"v_mov_b32 {vr(MI(qb) + r)}, 0")
     for i in range(128):
         e(f"v_accvgpr_write_b32 {ar(i)}, 0")
-    # first tiles' DMA: K(0) -> K slot 0, V(0) -> V slot 0 ; then K(1) -> K slot 1 (V slot unused: point it at slot 1)
-    for ln in dma_lines(0, 0):
+    # first tiles: K(0), V(0), K(1) (and K(2) with the three-slot ring)
+    n_dma = 0
+    for ln in k_dma(0) + v_dma(0) + k_dma(KSLOT) + (k_dma(2 * KSLOT) if k3 else []):
         e(ln)
-    # dma_lines advanced %[skn] to tile 1 and %[svn] to tile 1; issue K(1) only
-    for j in range(4):
-        e(f"s_add_u32 m0, %[ldsw], {16384 + j * 4096}")
-        if j == 0:
-            e("s_mov_b32 s92, %[skn]")
-        else:
-            e("s_add_u32 s92, s92, %[skp]")
-        e("buffer_load_dwordx4 %[vok], %[rk], s92 offen lds")
-    e("s_add_u32 %[skn], %[skn], s95")                  # -> tile 2
-    # Q: wait for the 16 loads (the 12 DMAs behind them stay in flight): vmcnt counts in order
-    e("s_waitcnt vmcnt(12)")
+        n_dma += ln.startswith("buffer_load")
+    e(f"s_waitcnt vmcnt({n_dma})")                              # the 16 Q loads (issued first) have landed
     for i in range(64):
         src = 32 + i
         e(f"v_lshlrev_b32 {vr(T0)}, 16, {vr(src)}")
@@ -393,50 +386,95 @@ def generate():
     e("s_waitcnt vmcnt(0)")
     e("s_barrier")
     e("s_nop 7")
-    # ---------------- scores of tile 0 -> set 0 (C = 0), no softmax under it
-    qk_phase(e, nxt=0, kslot=0, cur=1, with_softmax=False, dma_lines=[], first_tile_c_zero=True)
+    # ---------------- scores of tile 0 -> set 0 (C = 0)
+    ops = weave(qk_mfmas(0, c_zero=True), [qk_read_plan(0)], pre=kread_ops(0, 0) + kread_ops(1, 0))
+    pending = linearize(e, ops, [])
+    assert not pending
+    if k3:
+        # K ring bookkeeping: tile t reads slot (t+1) % 3 and refills slot t % 3; the address registers now move to slot 1
+        e(f"s_mov_b32 s98, {KSLOT}")                            # slot offset the K addresses point at
+        e("s_mov_b32 s99, 0")                                   # slot offset the next K DMA fills
+        for kk in range(8):
+            e(f"v_add_u32 {vr(KA[kk])}, {KSLOT}, {vr(KA[kk])}")
+        for op in kread_ops(0, 0) + kread_ops(1, 0):
+            e(op[2])
+        pending = ["K0.0", "K0.1", "K1.0", "K1.1"]
     e("s_nop 7")
     e("s_nop 7")                                               # MFMA write of the scores -> VALU
-    # mask (only when tile 0 is partial), row max, forced first placement of the running max
-    nomask0 = lab("nomask_first")
+    nomask0 = e.lab("nomask_first")
     e("s_cmp_ge_i32 %[srem], 64")
     e(f"s_cbranch_scc1 {nomask0}")
-    mask_block(e, 0, "first")
+    mask_block(e, 0)
     e.label(nomask0)
     for ln in rowmax_lines(0):
         e(ln)
     check_and_rescale(e, 0, "first", first=True)
-    e("s_mov_b32 s94, 0")                                   # t
+    e("s_mov_b32 s94, 0")                                      # t
+    LOOP_PENDING = list(pending)
 
-    # ---------------- main loop, two tiles per trip
-    LOOP, LAST = lab("loop"), [lab("last0"), lab("last1")]
-    EPI = lab("epi")
+    LOOP, LAST, EPI = e.lab("loop"), [e.lab("last0"), e.lab("last1")], e.lab("epi")
 
     def body(p):
         cur, nxt = p, p ^ 1
         e("s_waitcnt vmcnt(0)")
         e("s_barrier")
-        # phase 1: K(t+1).Q^T -> set nxt from K slot (t+1)&1 = nxt ; DMA K(t+2) -> K slot p, V(t+1) -> V slot nxt
-        qk_phase(e, nxt=nxt, kslot=nxt, cur=cur, with_softmax=True, dma_lines=dma_lines(p, nxt))
-        # between the phases: mask the new scores if tile t+1 is the last one and partial
+        if k3:
+            dma = k_dma("s99") + v_dma(nxt)
+            kbase = 0                                          # the address registers carry the slot
+        else:
+            dma = k_dma(p * KSLOT) + v_dma(nxt)
+            kbase = nxt * KSLOT
+        vbase = VBASE + p * KSLOT
+        # ---- phase 1
+        mf1 = qk_mfmas(nxt)
+        plans = [qk_read_plan(kbase)]
+        plans.append(spread(X(dma), 32, 0, 30) if dma_spread else spread(X(dma), 32, 0, 6))
+        plans.append(spread(X(softmax_lines(cur)), 32, 2, 32))
+        pre = [] if k3 else kread_ops(0, kbase) + kread_ops(1, kbase)
+        if vpre:
+            vp = [[] for _ in range(32)]
+            vp[29], vp[30], vp[31] = [vread_op(0, vbase)], [vread_op(1, vbase)], [vread_op(2, vbase)]
+            plans.append(vp)
+        ops1 = weave(mf1, plans, pre=pre)
+        pend = linearize(e, ops1, LOOP_PENDING)
+        # ---- between the phases: mask the new scores if tile t+1 is the last one and partial
         e("s_sub_u32 %[srem], %[srem], 64")                    # keys left from tile t+1 on
-        nomask = lab(f"nomask_{p}")
+        nomask = e.lab(f"nomask_{p}")
         e("s_cmp_ge_i32 %[srem], 64")
         e(f"s_cbranch_scc1 {nomask}")
         e("s_nop 7")
         e("s_nop 7")
-        mask_block(e, nxt, f"b{p}")
+        mask_block(e, nxt)
         e.label(nomask)
-        # phase 2: P.V of tile t ; row sums of tile t, then row max of tile t+1 (its MFMAs are >= 16 MFMAs back)
-        pv_phase(e, cur=cur, vslot=p, tail_valu=rowsum_lines(cur) + rowmax_lines(nxt))
+        # ---- phase 2
+        mf2 = pv_mfmas(cur)
+        plans = [pv_read_plan(vbase)]
+        tail = rowsum_lines(cur) + rowmax_lines(nxt)
+        if k3:
+            # the K addresses step to the next slot once the reads of phase 1 are all issued; the first fragments of
+            # the next tile's K are read under the last MFMAs
+            step = ["s_mov_b32 s91, s98"] + rotate("s98", 3) + ["s_sub_u32 s91, s98, s91"] + rotate("s99", 3)
+            step += [f"v_add_u32 {vr(KA[kk])}, s91, {vr(KA[kk])}" for kk in range(8)]
+            plans.append(spread(X(step), 32, 0, 12))
+            kp = [[] for _ in range(32)]
+            kp[27], kp[29] = kread_ops(0, 0), kread_ops(1, 0)
+            plans.append(kp)
+        plans.append(spread(X(tail), 32, 1, 32))
+        pre = [] if vpre else [vread_op(0, vbase), vread_op(1, vbase), vread_op(2, vbase)]
+        pend = linearize(e, weave(mf2, plans, pre=pre), pend)
+        assert pend == LOOP_PENDING, (pend, LOOP_PENDING)
         check_and_rescale(e, nxt, f"b{p}")
         e("s_add_u32 s94, s94, 1")
 
     def last(p):
         e("s_waitcnt vmcnt(0)")
         e("s_barrier")
-        softmax_only(e, p)
-        pv_phase(e, cur=p, vslot=p, tail_valu=rowsum_lines(p))
+        vbase = VBASE + p * KSLOT
+        for ln in softmax_lines(p):
+            e(ln)
+        ops2 = weave(pv_mfmas(p), [pv_read_plan(vbase), spread(X(rowsum_lines(p)), 32, 1, 32)],
+                     pre=[vread_op(0, vbase), vread_op(1, vbase), vread_op(2, vbase)])
+        linearize(e, ops2, LOOP_PENDING)
 
     e.label(LOOP)
     for p in range(2):
@@ -452,6 +490,7 @@ def generate():
     e.label(EPI)
 
     # ---------------- epilogue: l = sum over both half-waves, O / l -> bf16 -> global
+    e("s_waitcnt lgkmcnt(0)")
     e("s_nop 7")
     e("s_nop 7")
     e("s_nop 7")
@@ -478,10 +517,8 @@ def generate():
                 e(f"v_cvt_pk_bf16_f32 {vr(tmp[0])}, {vr(tmp[0])}, {vr(tmp[1])}")
                 e(f"v_cvt_pk_bf16_f32 {vr(tmp[1])}, {vr(tmp[2])}, {vr(tmp[3])}")
                 e(f"buffer_store_dwordx2 {vr(tmp[0], 2)}, %[voo], %[ro], {so} offen offset:{db * 64 + g * 16}")
-                if g & 1:
-                    e("s_nop 0")
-    # log-sum-exp (natural log) for the backward: lanes of the lower half-wave, when requested
-    # (no lse requested: the descriptor %[rl] has zero records and the two stores are dropped by the hardware)
+    # log-sum-exp (natural log) for the backward, lower half-wave.  No lse requested: the descriptor %[rl] has zero
+    # records and the two stores are dropped by the hardware
     for qb in range(2):
         e(f"v_log_f32 {vr(T0 + qb)}, {vr(L_A[qb])}")
     e("s_nop 0")
@@ -497,23 +534,29 @@ def generate():
     return e
 
 
+N_VARIANTS = 3
+LDS_BYTES = {0: 4 * KSLOT, 1: 4 * KSLOT, 2: 5 * KSLOT}
 CLOBBER_V = range(12, 256)
 CLOBBER_A = range(0, 256)
+CLOBBER_S = range(91, 100)
 
 
 def main():
-    e = generate()
     print("// GENERATED by gen_attn_w64.py — do not edit; edit the generator.")
-    print("#define OMH_ATTN_W64_ASM \\")
-    body = e.text().split("\n")
-    print(" \\\n".join(body))
-    print("")
-    clob = ['"memory"', '"vcc"', '"scc"', '"s92"', '"s93"', '"s94"', '"s95"', '"s96"', '"s97"'] + [f'"v{i}"' for i in CLOBBER_V] + [f'"a{i}"' for i in CLOBBER_A]
+    for v in range(N_VARIANTS):
+        e = generate(v)
+        print(f"#define OMH_ATTN_W64_ASM_V{v} \\")
+        print(" \\\n".join(e.text().split("\n")))
+        print("")
+        print(f"#define OMH_ATTN_W64_LDS_V{v} {LDS_BYTES[v]}")
+        n_mfma = sum("v_mfma" in ln for ln in e.lines)
+        print(f"// variant {v}: {len(e.lines)} lines, {n_mfma} MFMA")
+    clob = ['"memory"', '"vcc"', '"scc"'] + [f'"s{i}"' for i in CLOBBER_S] + [f'"v{i}"' for i in CLOBBER_V] + \
+           [f'"a{i}"' for i in CLOBBER_A]
     print("#define OMH_ATTN_W64_CLOBBERS \\")
     rows = [", ".join(clob[i:i + 12]) for i in range(0, len(clob), 12)]
-    print(", \\\n    ".join(rows).join(["    ", ""]))
-    n_mfma = sum("v_mfma" in ln for ln in e.lines)
-    print(f"// {len(e.lines)} lines, {n_mfma} MFMA")
+    print("    " + ", \\\n    ".join(rows))
+    print(f"#define OMH_ATTN_W64_VARIANTS {N_VARIANTS}")
 
 
 if __name__ == "__main__":

@@ -83,8 +83,9 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
 
 
 def flash_attn_raw(q, k, vt, o, k_lens, B, H, Lq, Lk, q_bs, q_rs, k_bs, k_rs, vt_bs, o_bs, o_rs, ldv, scale,
-                   lse=None):
-    a = AttnArgs(q, k, vt, o, k_lens, B, H, Lq, Lk, q_bs, q_rs, k_bs, k_rs, vt_bs, o_bs, o_rs, ldv, scale, lse)
+                   lse=None, q_prescaled=0):
+    a = AttnArgs(q, k, vt, o, k_lens, B, H, Lq, Lk, q_bs, q_rs, k_bs, k_rs, vt_bs, o_bs, o_rs, ldv, scale, lse,
+                 int(q_prescaled))
     check(lib.omh_flash_attn_fwd_d128(C.byref(a), _stream()), "omh_flash_attn_fwd_d128")
 
 
@@ -167,9 +168,9 @@ def rmsnorm_rope_raw(x, ldx, y, rows, dim, weight, eps, do_norm, rope_cos, rope_
 
 
 def rmsnorm_rope_bf16_raw(x, ldx, y, rows, dim, weight, eps, do_norm, rope_cos, rope_sin, rope_len, head_dim, grid,
-                          seq_len):
+                          seq_len, out_scale=1.0):
     check(lib.omh_rmsnorm_rope_bf16(x, ldx, y, rows, dim, weight, eps, do_norm, rope_cos, rope_sin, rope_len,
-                                    head_dim, grid, seq_len, _stream()), "omh_rmsnorm_rope_bf16")
+                                    head_dim, grid, seq_len, float(out_scale), _stream()), "omh_rmsnorm_rope_bf16")
 
 
 def rmsnorm_rope(x: torch.Tensor, weight: Optional[torch.Tensor], eps: float, do_norm: bool = True,

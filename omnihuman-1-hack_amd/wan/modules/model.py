@@ -196,11 +196,14 @@ class WanSelfAttention(nn.Module):
         ops.gemm_raw(ptr(h), ptr(wqk), ptr(qk), R, 2 * d, d, d, d, 2 * d, EPI_BF16, bias=ptr(bqk), bias_mode=BIAS_N)
         q = torch.empty(R, d, dtype=torch.bfloat16, device=h.device)
         k = torch.empty(R, d, dtype=torch.bfloat16, device=h.device)
-        for dst, off, nm in ((q, 0, "norm_q"), (k, d, "norm_k")):
+        # q leaves the norm kernel already multiplied by softmax_scale * log2(e) (attention.py:96-127), in fp32
+        # before its one rounding to bf16: the attention kernel's exponentials then need no per-score multiply
+        q_scale = D ** -0.5 * 1.4426950408889634
+        for dst, off, nm, osc in ((q, 0, "norm_q", q_scale), (k, d, "norm_k", 1.0)):
             w = self._norm_w(nm)
             ops.rmsnorm_rope_bf16_raw(ptr(qk, off), 2 * d, ptr(dst), R, d, ptr(w) if w is not None else None,
                                       self.eps, int(self.qk_norm), ptr(fc.rope_cos), ptr(fc.rope_sin),
-                                      fc.rope_cos.shape[0], D, ptr(fc.grid32), S)
+                                      fc.rope_cos.shape[0], D, ptr(fc.grid32), S, out_scale=osc)
         del qk
         # V^T[b] = Wv h_b^T + bv  ->  [B, dim, Sp]   (pad columns stay zero)
         Sp = _round_up(S, 64)
@@ -212,7 +215,7 @@ class WanSelfAttention(nn.Module):
                      strideA=0, strideB=S * d, strideC=d * Sp)
         o = torch.empty(R, d, dtype=torch.bfloat16, device=h.device)
         ops.flash_attn_raw(ptr(q), ptr(k), ptr(vt), ptr(o), ptr(fc.seq_lens32), B, N, S, S, S * d, d, S * d, d,
-                           d * Sp, S * d, d, Sp, D ** -0.5)
+                           d * Sp, S * d, d, Sp, D ** -0.5, q_prescaled=1)
         return o
 
     def forward(self, x, seq_lens, grid_sizes, freqs, _fc: Optional["_FwdCtx"] = None):

@@ -16,7 +16,10 @@ def vt_of(v, Lk):
     return vt
 
 
-def run(kind, q, k, vt, k_lens=None, lse=False):
+LOG2E = 1.4426950408889634
+
+
+def run(kind, q, k, vt, k_lens=None, lse=False, pre=1):
     os.environ["OMH_ATTN_KERNEL"] = kind
     B, Lq, H, _ = q.shape
     Lk = k.shape[1]
@@ -24,7 +27,7 @@ def run(kind, q, k, vt, k_lens=None, lse=False):
     l = torch.full((B, H, Lq), float("nan"), dtype=torch.float32, device="cuda") if lse else None
     ops.flash_attn_raw(ops._p(q), ops._p(k), ops._p(vt), ops._p(out), ops._p(k_lens), B, H, Lq, Lk, q.stride(0),
                        q.stride(1), k.stride(0), k.stride(1), vt.stride(0), out.stride(0), out.stride(1), vt.stride(1),
-                       D ** -0.5, lse=ops._p(l) if lse else None)
+                       D ** -0.5, lse=ops._p(l) if lse else None, q_prescaled=pre)
     torch.cuda.synchronize()
     return out, l
 
@@ -36,16 +39,17 @@ def check():
              (1, 3, 300, 200, None, 1.0), (2, 2, 777, 1000, [1000, 333], 1.0), (1, 2, 512, 4096, None, 1.0),
              (1, 2, 512, 2048, None, 4.0), (1, 1, 64, 100, [37], 1.0), (1, 12, 1560, 1560, None, 1.0)]
     for (B, H, Lq, Lk, kl, amp) in cases:
-        q = (torch.randn(B, Lq, H, D, device="cuda") * amp).to(torch.bfloat16)
+        # q as the norm kernel hands it over: already multiplied by scale * log2(e), rounded once
+        q = (torch.randn(B, Lq, H, D, device="cuda") * amp * (D ** -0.5 * LOG2E)).to(torch.bfloat16)
         k = (torch.randn(B, Lk, H, D, device="cuda") * amp).to(torch.bfloat16)
         v = torch.randn(B, Lk, H, D, device="cuda").to(torch.bfloat16)
         if amp > 1:                      # spike: one key row aligned with one query row far down the sequence (forces a late rescale)
-            k[:, Lk - 70] = q[:, 5] * 1.0
+            k[:, Lk - 70] = (q[:, 5].float() / (D ** -0.5 * LOG2E)).to(torch.bfloat16)
         vt = vt_of(v, Lk)
         kls = None if kl is None else torch.tensor(kl, dtype=torch.int32, device="cuda")
         got, lse = run("w64", q, k, vt, kls, lse=True)
         base, lse_b = run("base", q, k, vt, kls, lse=True)
-        s = torch.einsum("bqhd,bkhd->bhqk", q.float(), k.float()) * D ** -0.5
+        s = torch.einsum("bqhd,bkhd->bhqk", q.float(), k.float()) / LOG2E        # natural-log domain
         if kl is not None:
             for b_, n in enumerate(kl):
                 s[b_, :, :, n:] = float("-inf")
@@ -63,6 +67,17 @@ def check():
         got2, _ = run("w64", q, k, vt, kls)
         if not torch.equal(got2, got):
             print("   NOT bit-repeatable"); ok = False
+        # the un-prescaled entry (the kernel multiplies q by scale*log2e and re-rounds it): looser, error ~ |scores| 2^-9
+        qu = (q.float() / (D ** -0.5 * LOG2E)).to(torch.bfloat16)
+        got3, _ = run("w64", qu, k, vt, kls, pre=0)
+        s3 = torch.einsum("bqhd,bkhd->bhqk", qu.float(), k.float()) * D ** -0.5
+        if kl is not None:
+            for b_, n in enumerate(kl):
+                s3[b_, :, :, n:] = float("-inf")
+        ref3 = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s3, -1), v.float())
+        e3 = rr(got3, ref3)
+        print(f"   un-prescaled q: rel {e3:.3e}")
+        ok &= e3 < 8e-3 * amp
     print("CHECK", "PASS" if ok else "FAIL", flush=True)
     return ok
 
