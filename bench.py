@@ -488,12 +488,14 @@ def main():
         tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tj):
             try:
-                traffic = json.load(open(tj)).get("flash_attn_fwd_d128_pp_kernel")
+                traffic = json.load(open(tj)).get(kname)
             except Exception:
                 traffic = None
         if traffic is not None:
             traffic = traffic * nb                                 # measured per batch element (tools/pmc_attn.sh)
-        roofline = {"kernel": "flash_attn_fwd_d128_pp_kernel (self-attention, Lq=Lk=%d, 12 heads, D=128, batch %d)" % (seq_len, nb),
+        kname = {"pp": "flash_attn_fwd_d128_pp_kernel", "base": "flash_attn_fwd_d128_kernel"}.get(
+            os.environ.get("OMH_ATTN_KERNEL", ""), "flash_attn_fwd_d128_w64_v2_kernel")
+        roofline = {"kernel": "%s (self-attention, Lq=Lk=%d, 12 heads, D=128, batch %d)" % (kname, seq_len, nb),
                     "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "launches_timed": len(timer.pairs), "avg_launch_ms": round(attn_ms, 4),

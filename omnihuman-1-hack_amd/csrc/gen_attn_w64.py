@@ -313,9 +313,13 @@ def rotate(sreg, nslots):
 
 # ---------------------------------------------------------------- whole stream
 def generate(variant):
-    dma_spread = variant >= 1
-    vpre = variant >= 1
-    k3 = variant >= 2
+    base = min(variant, 2)
+    dma_spread = base >= 1
+    vpre = base >= 1
+    k3 = base >= 2
+    # timing-only ablations of V2 (wrong results): 3 = no LDS-DMA in the loop, 4 = v_exp -> v_mov, 5 = no barrier,
+    # 6 = no ds_reads in the loop bodies
+    abl = variant if variant >= 3 else 0
     # LDS map: two-slot rings: K [0, 32K) | V^T [32K, 64K).  Three-slot K ring: V^T [0, 32K) | K [32K, 80K) — the K
     # addresses carry the ring base and slot in the address registers, so every ds_read offset stays below 64 KiB
     VBASE = 0 if k3 else 2 * KSLOT
@@ -417,7 +421,8 @@ def generate(variant):
     def body(p):
         cur, nxt = p, p ^ 1
         e("s_waitcnt vmcnt(0)")
-        e("s_barrier")
+        if abl != 5:
+            e("s_barrier")
         if k3:
             dma = k_dma("s99") + v_dma(nxt)
             kbase = 0                                          # the address registers carry the slot
@@ -425,6 +430,8 @@ def generate(variant):
             dma = k_dma(p * KSLOT) + v_dma(nxt)
             kbase = nxt * KSLOT
         vbase = VBASE + p * KSLOT
+        if abl == 3:
+            dma = []
         # ---- phase 1
         mf1 = qk_mfmas(nxt)
         plans = [qk_read_plan(kbase)]
@@ -436,6 +443,7 @@ def generate(variant):
             vp[29], vp[30], vp[31] = [vread_op(0, vbase)], [vread_op(1, vbase)], [vread_op(2, vbase)]
             plans.append(vp)
         ops1 = weave(mf1, plans, pre=pre)
+        mark = len(e.lines)
         pend = linearize(e, ops1, LOOP_PENDING)
         # ---- between the phases: mask the new scores if tile t+1 is the last one and partial
         e("s_sub_u32 %[srem], %[srem], 64")                    # keys left from tile t+1 on
@@ -463,6 +471,10 @@ def generate(variant):
         pre = [] if vpre else [vread_op(0, vbase), vread_op(1, vbase), vread_op(2, vbase)]
         pend = linearize(e, weave(mf2, plans, pre=pre), pend)
         assert pend == LOOP_PENDING, (pend, LOOP_PENDING)
+        if abl == 4:
+            e.lines[mark:] = [ln.replace("v_exp_f32", "v_mov_b32") for ln in e.lines[mark:]]
+        if abl == 6:
+            e.lines[mark:] = [ln for ln in e.lines[mark:] if not ln.startswith(("ds_read", "s_waitcnt lgkmcnt"))]
         check_and_rescale(e, nxt, f"b{p}")
         e("s_add_u32 s94, s94, 1")
 
@@ -534,8 +546,8 @@ def generate(variant):
     return e
 
 
-N_VARIANTS = 3
-LDS_BYTES = {0: 4 * KSLOT, 1: 4 * KSLOT, 2: 5 * KSLOT}
+N_VARIANTS = 3        # 3..6 are the timing-only ablations (set 7 and add the kernels in attention_w64.hip to time them)
+LDS_BYTES = {0: 4 * KSLOT, 1: 4 * KSLOT, 2: 5 * KSLOT, 3: 5 * KSLOT, 4: 5 * KSLOT, 5: 5 * KSLOT, 6: 5 * KSLOT}
 CLOBBER_V = range(12, 256)
 CLOBBER_A = range(0, 256)
 CLOBBER_S = range(91, 100)

@@ -116,8 +116,11 @@ def test_dit_forward_full_size_invariances(wan_1_3b):
         assert torch.equal(pair[0], one)                                       # batch of two = two batches of one
         other = model([x2], t, [ctx2], S_FULL)[0]
         assert torch.equal(pair[1], other)
-        padded = model([x], t, [ctx], S_FULL + 520)[0]                         # seq_len > S: zero rows, masked keys
-        assert rel_rms(padded, one) < 2e-3
+        # seq_len > S: zero rows, masked keys.  Not bit-identical: M changes, so some GEMMs take another tile
+        # configuration (another fp32 summation order, bf16 roundings flip and propagate through 30 layers).
+        # Measured 2.4e-3 (round 2) between the two evaluations, each of which sits 5e-3 from the fp32 oracle.
+        padded = model([x], t, [ctx], S_FULL + 520)[0]
+        assert rel_rms(padded, one) < 4e-3
         assert rel_rms(other, one) > 0.1                                       # and the inputs do matter
 
 

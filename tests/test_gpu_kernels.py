@@ -88,7 +88,7 @@ def _attn_ref(q, k, v, k_lens, scale):
 @pytest.mark.parametrize("B,H,Lq,Lk,klens", [
     (1, 1, 128, 64, None), (2, 2, 200, 200, [200, 77]), (1, 12, 1560, 1560, [1560]),
     (2, 3, 130, 512, [37, 512]), (1, 2, 64, 320, [257]), (2, 1, 100, 64, [0, 5])])
-@pytest.mark.parametrize("kernel", ["base", "pp"])
+@pytest.mark.parametrize("kernel", ["base", "pp", "w64"])
 def test_flash_attention(ops, B, H, Lq, Lk, klens, kernel, monkeypatch):
     monkeypatch.setenv("OMH_ATTN_KERNEL", kernel)      # both kernels on every shape (ragged rows/keys, empty rows)
     torch.manual_seed(Lq + Lk)
@@ -126,7 +126,7 @@ def test_flash_attention_long_sequence_dispatch(ops):
     assert float((out.float() - ref).abs().max()) < 3e-2
 
 
-@pytest.mark.parametrize("kernel", ["base", "pp"])
+@pytest.mark.parametrize("kernel", ["base", "pp", "w64"])
 def test_flash_attention_peaked_rows(ops, kernel, monkeypatch):
     """Forces large online-softmax rescales: one key dominates late in the sequence."""
     monkeypatch.setenv("OMH_ATTN_KERNEL", kernel)
@@ -141,6 +141,49 @@ def test_flash_attention_peaked_rows(ops, kernel, monkeypatch):
     out = ops.flash_attn(q, k, vt, None)
     ref = _attn_ref(q, k, v, None, D ** -0.5)
     assert rel_rms(out.float(), ref) < 8e-3
+
+
+@pytest.mark.parametrize("variant", ["0", "1", "2"])
+def test_flash_attention_w64_prescaled_q_lse_and_late_rescale(ops, variant, monkeypatch):
+    """The asm-owned 4 x 64 long-sequence kernel (csrc/attention_w64.hip, every stream variant) as the model drives
+    it: q already multiplied by softmax_scale * log2(e) by the norm kernel (omh_attn_args.q_prescaled), log-sum-exp
+    requested, ragged rows and keys, masked keys, and a key that dominates LATE in the sequence with large scores so
+    that the deferred running-max update (rescale of the AGPR accumulators) runs after hundreds of tiles.  Against
+    fp32 softmax attention on the same bf16 operands, and bit for bit against itself."""
+    monkeypatch.setenv("OMH_ATTN_KERNEL", "w64")
+    monkeypatch.setenv("OMH_W64_VARIANT", variant)
+    D, LOG2E = 128, 1.4426950408889634
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for (B, H, Lq, Lk, klens, amp) in ((1, 2, 300, 200, None, 1.0), (2, 2, 777, 1000, [1000, 333], 1.0),
+                                       (1, 2, 512, 4096, None, 4.0), (1, 1, 64, 100, [37], 1.0)):
+        q = _bf(torch.randn(B, Lq, H, D, device="cuda", generator=g) * amp * (D ** -0.5 * LOG2E))
+        k = _bf(torch.randn(B, Lk, H, D, device="cuda", generator=g) * amp)
+        v = _bf(torch.randn(B, Lk, H, D, device="cuda", generator=g))
+        if amp > 1:
+            k[:, Lk - 70] = _bf(q[:, 5].float() / (D ** -0.5 * LOG2E))       # score ~ 16 |q|^2 / sqrt(128) at tile 62
+        Lp = (Lk + 63) // 64 * 64
+        vt = torch.zeros(B, H * D, Lp, dtype=torch.bfloat16, device="cuda")
+        vt[:, :, :Lk] = v.reshape(B, Lk, H * D).transpose(1, 2)
+        kl = None if klens is None else torch.tensor(klens, dtype=torch.int32, device="cuda")
+
+        def run():
+            out = torch.full((B, Lq, H, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+            lse = torch.full((B, H, Lq), float("nan"), dtype=torch.float32, device="cuda")
+            ops.flash_attn_raw(ops.ptr(q), ops.ptr(k), ops.ptr(vt), ops.ptr(out), ops.ptr(kl) if kl is not None else None,
+                               B, H, Lq, Lk, q.stride(0), q.stride(1), k.stride(0), k.stride(1), vt.stride(0),
+                               out.stride(0), out.stride(1), vt.stride(1), D ** -0.5, lse=ops.ptr(lse), q_prescaled=1)
+            return out, lse
+        out, lse = run()
+        s = torch.einsum("bqhd,bkhd->bhqk", q.float(), k.float()) / LOG2E              # natural-log scores
+        if klens is not None:
+            for b_, n in enumerate(klens):
+                s[b_, :, :, n:] = float("-inf")
+        ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), v.float())
+        assert torch.isfinite(out.float()).all()
+        assert rel_rms(out.float(), ref) < 8e-3 and float((out.float() - ref).abs().max()) < 3e-2
+        assert float((lse - torch.logsumexp(s, -1)).abs().max()) < 5e-3
+        out2, lse2 = run()
+        assert torch.equal(out, out2) and torch.equal(lse, lse2)
 
 
 def test_layernorm_modulate(ops):
@@ -206,7 +249,7 @@ def test_patchify_unpatchify_dense_sinusoid(ops):
     assert torch.equal(ops.cast_bf16(c), c.to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("kernel", ["base", "pp"])
+@pytest.mark.parametrize("kernel", ["base", "pp", "w64"])
 def test_flash_attention_is_bitwise_repeatable(ops, kernel, monkeypatch):
     """Same inputs, same bits, every launch.  The base kernel once took its row max through an inline-asm v_max3
     that hipcc's hazard recognizer does not see: issued right behind the last K.Q^T MFMA it sometimes read scores
