@@ -367,6 +367,33 @@ int omh_adamw_multi(const int64_t* table, int32_t n_tensors, float lr, float bet
 /* EMA of the weights, ema = decay*ema + (1-decay)*p (distilled_trainer.py:319-334). */
 int omh_ema_update(float* ema, const float* p, int64_t n, float decay, omh_stream_t stream);
 
+/* ========================================================================
+ * Prompt-side encoders (run once per prompt): the umT5 text encoder of seaweed_apt/wan/modules/t5.py:272-322 and
+ * the CLIP vision tower of seaweed_apt/wan/modules/clip.py:209-301.  Their Linear layers run on omh_gemm_bf16;
+ * attention (head_dim 64 / 80, <= 512 keys) is two batched omh_gemm_bf16 calls around omh_softmax_bias_rows.
+ * ====================================================================== */
+
+/* nn.Embedding lookup (t5.py:306): out[r][:] = table[ids[r]][:], fp32; ids int64 on the device, clamped to the table. */
+int omh_gather_rows_f32(const float* table, const int64_t* ids, float* out, int64_t rows, int32_t dim, int64_t vocab,
+                        omh_stream_t stream);
+/* T5LayerNorm (t5.py:55-69): y = weight * x * rsqrt(mean(x^2) + eps); either result pointer may be NULL. */
+int omh_rmsnorm_f32(const float* x, const float* weight, float eps, float* y_f32, void* y_bf16, int64_t rows,
+                    int32_t dim, omh_stream_t stream);
+/* nn.LayerNorm with affine, fp32 in and out (clip.py:47-50; the pre_norm of the embedded tokens, clip.py:288-289). */
+int omh_layernorm_f32(const float* x, const float* weight, const float* bias, float eps, float* y, int64_t rows,
+                      int32_t dim, omh_stream_t stream);
+/* Softmax rows with T5's additive attention terms (t5.py:101-113; also clip.py:82 with bucket = table = NULL):
+ *   y[h*L + i][j] = bf16( softmax_j( x[h*L + i][j] * scale + table[bucket[i*L + j]][h] ) ),  j < klen;
+ * keys j >= klen get weight 0 (the reference fills finfo.min), columns L..ldy-1 are zeroed.  x fp32 [H*L, ldx],
+ * bucket int32 [L, L] (relative-position bucket of (i, j), t5.py:244-268, computed on the host), table fp32 [nb, H]. */
+int omh_softmax_bias_rows(const float* x, int64_t ldx, void* y_bf16, int64_t ldy, int32_t H, int32_t L, float scale,
+                          const int32_t* bucket, const float* table, int32_t klen, omh_stream_t stream);
+/* out = a * b, bf16, n even: the gated product of T5FeedForward (t5.py:137). */
+int omh_mul_bf16(const void* a_bf16, const void* b_bf16, void* out_bf16, int64_t n, omh_stream_t stream);
+/* ViT token assembly (clip.py:280-287): out[b][0] = cls + pos[0], out[b][1+i] = tok[b][i] + pos[1+i]; fp32. */
+int omh_vit_embed(const float* tok, const float* cls, const float* pos, float* out, int32_t B, int32_t n, int32_t dim,
+                  omh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

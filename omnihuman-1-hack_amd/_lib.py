@@ -150,6 +150,12 @@ _SIGS = {
     "omh_adamw_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
     "omh_adamw_multi": (i32, [vp, i32, f32, f32, f32, f32, f32, i32, f32, vp]),
     "omh_ema_update": (i32, [vp, vp, i64, f32, vp]),
+    "omh_gather_rows_f32": (i32, [vp, vp, vp, i64, i32, i64, vp]),
+    "omh_rmsnorm_f32": (i32, [vp, vp, f32, vp, vp, i64, i32, vp]),
+    "omh_layernorm_f32": (i32, [vp, vp, vp, f32, vp, i64, i32, vp]),
+    "omh_softmax_bias_rows": (i32, [vp, i64, vp, i64, i32, i32, f32, vp, vp, i32, vp]),
+    "omh_mul_bf16": (i32, [vp, vp, vp, i64, vp]),
+    "omh_vit_embed": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "omh_cfg_unipc_step": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, i32, f32, f32, f32, f32, f32,
                                  f32, f32, vp]),
 }

@@ -469,3 +469,63 @@ def ema_update(ema, p, decay):
     _dev(ema, p)
     assert ema.dtype == p.dtype == torch.float32 and ema.is_contiguous() and p.is_contiguous()
     check(lib.omh_ema_update(_p(ema), _p(p), p.numel(), decay, _stream()), "omh_ema_update")
+
+
+# ----------------------------------------------------------------------------- prompt-side encoders (t5.py / clip.py)
+def gather_rows(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    """nn.Embedding lookup: table fp32 [V, dim], ids int64 [...] -> fp32 [..., dim]."""
+    _dev(table, ids)
+    assert table.dtype == torch.float32 and table.is_contiguous() and ids.dtype == torch.int64
+    idc = ids.contiguous()
+    out = torch.empty(*ids.shape, table.shape[1], dtype=torch.float32, device=table.device)
+    check(lib.omh_gather_rows_f32(_p(table), _p(idc), _p(out), idc.numel(), table.shape[1], table.shape[0], _stream()),
+          "omh_gather_rows_f32")
+    return out
+
+
+def rmsnorm_f32(x: torch.Tensor, weight: torch.Tensor, eps: float, want_f32=True, want_bf16=True):
+    """T5LayerNorm: returns (fp32 result or None, bf16 result or None)."""
+    _dev(x, weight)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    yf = torch.empty_like(x) if want_f32 else None
+    yb = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    check(lib.omh_rmsnorm_f32(_p(x), _p(weight), eps, _p(yf), _p(yb), x.numel() // x.shape[-1], x.shape[-1], _stream()),
+          "omh_rmsnorm_f32")
+    return yf, yb
+
+
+def layernorm_f32(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float) -> torch.Tensor:
+    _dev(x, weight, bias)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    y = torch.empty_like(x)
+    check(lib.omh_layernorm_f32(_p(x), _p(weight), _p(bias), eps, _p(y), x.numel() // x.shape[-1], x.shape[-1], _stream()),
+          "omh_layernorm_f32")
+    return y
+
+
+def softmax_bias_rows(x: torch.Tensor, H: int, L: int, scale: float, bucket=None, table=None, klen=None, ldy=None):
+    """x fp32 [H*L, ldx] scores -> bf16 [H*L, ldy] probabilities (include/omh.h)."""
+    _dev(x, bucket, table)
+    assert x.dtype == torch.float32 and x.stride(1) == 1 and x.shape[0] == H * L
+    ldy = ldy or x.shape[1]
+    y = torch.empty(H * L, ldy, dtype=torch.bfloat16, device=x.device)
+    check(lib.omh_softmax_bias_rows(_p(x), x.stride(0), _p(y), ldy, H, L, scale, _p(bucket), _p(table),
+                                    L if klen is None else int(klen), _stream()), "omh_softmax_bias_rows")
+    return y
+
+
+def mul_bf16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    _dev(a, b)
+    assert a.dtype == b.dtype == torch.bfloat16 and a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+    out = torch.empty_like(a)
+    check(lib.omh_mul_bf16(_p(a), _p(b), _p(out), a.numel(), _stream()), "omh_mul_bf16")
+    return out
+
+
+def vit_embed(tok: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+    """tok fp32 [B, n, dim], cls [dim], pos [n+1, dim] -> fp32 [B, n+1, dim]."""
+    _dev(tok, cls, pos)
+    B, n, d = tok.shape
+    out = torch.empty(B, n + 1, d, dtype=torch.float32, device=tok.device)
+    check(lib.omh_vit_embed(_p(tok), _p(cls), _p(pos), _p(out), B, n, d, _stream()), "omh_vit_embed")
+    return out

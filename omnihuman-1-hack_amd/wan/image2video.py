@@ -2,12 +2,12 @@
 (seaweed_apt/wan/image2video.py:29-347) on the gfx950 DiT / VAE / sampler.
 
 Same constructor arguments, attributes and ``generate(...)`` signature.  The
-umT5 text encoder and the CLIP ViT-H image encoder are outside this path
-(one-off per prompt / per image, their outputs
-are *inputs* here): ``text_encoder`` is a callable ``(list[str], device) ->
-list[Tensor[L, 4096]]``, ``clip`` an object with ``visual(list[Tensor[3,1,H,W]])
--> Tensor[1, 257, 1280]``; or pass ``context= / context_null= / clip_fea=`` to
-``generate``.
+umT5 text encoder and the CLIP ViT-H image encoder (``wan/modules/t5.py``,
+``wan/modules/clip.py``; image2video.py:74-92) are built from ``checkpoint_dir``
+when their checkpoint files are there; otherwise ``text_encoder`` may be any
+callable ``(list[str], device) -> list[Tensor[L, 4096]]`` and ``clip`` any
+object with ``visual(list[Tensor[3,1,H,W]]) -> Tensor[1, 257, 1280]``, or pass
+``context= / context_null= / clip_fea=`` to ``generate``.
 
 What this pipeline does on the device (image2video.py:186-331): VAE-encode the
 conditioning clip (first frame = the bicubic-resized image, the rest zeros),
@@ -71,6 +71,19 @@ class WanI2V:
         self.t5_cpu = t5_cpu
         self.num_train_timesteps = config.num_train_timesteps
         self.param_dtype = config.param_dtype
+        if text_encoder is None:
+            ck = os.path.join(checkpoint_dir or "", config.t5_checkpoint)
+            if checkpoint_dir and os.path.exists(ck):                  # image2video.py:74-81
+                from .modules.t5 import T5EncoderModel
+                text_encoder = T5EncoderModel(text_len=config.text_len, dtype=config.t5_dtype, device=self.device,
+                                              checkpoint_path=ck,
+                                              tokenizer_path=os.path.join(checkpoint_dir, config.t5_tokenizer))
+        if clip is None:
+            ck = os.path.join(checkpoint_dir or "", config.clip_checkpoint)
+            if checkpoint_dir and os.path.exists(ck):                  # image2video.py:87-92
+                from .modules.clip import CLIPModel
+                clip = CLIPModel(dtype=config.clip_dtype, device=self.device, checkpoint_path=ck,
+                                 tokenizer_path=os.path.join(checkpoint_dir, config.clip_tokenizer))
         self.text_encoder = text_encoder
         self.clip = clip
         self.vae_stride = config.vae_stride

@@ -3,10 +3,10 @@
 
 Same constructor arguments, attributes (``model, vae, text_encoder, vae_stride,
 patch_size, num_train_timesteps, sample_neg_prompt, device, param_dtype``) and
-``generate(...)`` signature.  The umT5 text encoder is outside this path
-(a one-off per prompt whose output is an *input* here):
-a ``text_encoder`` callable ``(list[str], device) -> list[Tensor[L, 4096]]`` can
-be plugged in, or pre-computed contexts passed to ``generate``.
+``generate(...)`` signature.  The umT5 text encoder (``wan/modules/t5.py``, text2video.py:64-70) is built from
+``checkpoint_dir`` when its checkpoint file is there (and ``disable_load_t5`` is not set); any callable
+``text_encoder(list[str], device) -> list[Tensor[L, 4096]]`` can be plugged in instead, or pre-computed contexts
+passed to ``generate``.
 
 What changes under the hood (text2video.py:231-259): the two CFG forwards run
 on the HIP DiT, the CFG combine + UniPC update is one fused kernel
@@ -44,7 +44,14 @@ class WanT2V:
         self.t5_cpu = t5_cpu
         self.num_train_timesteps = config.num_train_timesteps
         self.param_dtype = config.param_dtype
-        self.text_encoder = text_encoder          # out of scope here; see module docstring
+        if text_encoder is None and not disable_load_t5:
+            ck = os.path.join(checkpoint_dir or "", config.t5_checkpoint)
+            if checkpoint_dir and os.path.exists(ck):                  # text2video.py:64-70
+                from .modules.t5 import T5EncoderModel
+                text_encoder = T5EncoderModel(text_len=config.text_len, dtype=config.t5_dtype, device=self.device,
+                                              checkpoint_path=ck,
+                                              tokenizer_path=os.path.join(checkpoint_dir, config.t5_tokenizer))
+        self.text_encoder = text_encoder
         self.vae_stride = config.vae_stride
         self.patch_size = config.patch_size
         if vae is None:

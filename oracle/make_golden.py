@@ -248,6 +248,44 @@ def main():
         print("1.3B", float(out.abs().mean()))
 
 
+def encoder_cases():
+    """Shared by the generator and the tests: tiny umT5 / ViT configurations and their inputs."""
+    from oracle import encoders_oracle as E
+    tc, vc = E.T5Config.tiny(), E.ViTConfig.tiny()
+    ids = torch.from_numpy((detgen.uniform("golden/enc/ids", (2, 24), 0.0, 1.0) * tc.vocab).astype(np.int64)).clamp_(0, tc.vocab - 1)
+    mask = torch.ones(2, 24, dtype=torch.long)
+    mask[1, 15:] = 0
+    img = torch.from_numpy(detgen.normalish("golden/enc/img", (2, 3, vc.image_size, vc.image_size)))
+    return tc, vc, ids, mask, img
+
+
+def golden_encoders():
+    """umT5 encoder (with the repository's cut-down block) and the CLIP vision tower of the REAL reference at a small
+    width -> tests/golden/encoders_t5_clip.npz."""
+    from oracle import encoders_oracle as E
+    t5, clip = ref_import.load_reference_encoders()
+    tc, vc, ids, mask, img = encoder_cases()
+    enc = t5.T5Encoder(vocab=tc.vocab, dim=tc.dim, dim_attn=tc.dim_attn, dim_ffn=tc.dim_ffn, num_heads=tc.num_heads,
+                       num_layers=tc.num_layers, num_buckets=tc.num_buckets, shared_pos=tc.shared_pos, dropout=0.1).eval()
+    enc.load_state_dict(E.t5_state_dict(tc, "golden/t5"), strict=True)
+    t5_out = enc(ids, mask).float()
+    vit = clip.VisionTransformer(image_size=vc.image_size, patch_size=vc.patch_size, dim=vc.dim, mlp_ratio=vc.mlp_ratio,
+                                 out_dim=32, num_heads=vc.num_heads, num_layers=vc.num_layers, pool_type="token",
+                                 pre_norm=True, post_norm=False, activation="gelu", norm_eps=vc.norm_eps).eval()
+    vit.load_state_dict(E.vit_state_dict(vc, "golden/vit"), strict=True)
+    vit_out = vit(img, use_31_block=True).float()
+    bk = t5.T5RelativeEmbedding(32, 4, bidirectional=True)._relative_position_bucket(
+        torch.arange(40)[None, :] - torch.arange(40)[:, None])
+    np.savez_compressed(os.path.join(OUT, "encoders_t5_clip.npz"), t5=t5_out.numpy(), vit=vit_out.numpy(),
+                        buckets=bk.numpy().astype(np.int16))
+    print("encoders", float(t5_out.abs().mean()), float(vit_out.abs().mean()))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "encoders":
+    torch.set_grad_enabled(False)
+    golden_encoders()
+    sys.exit(0)
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "train_i2v":
     golden_train_i2v()
     sys.exit(0)

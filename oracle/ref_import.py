@@ -216,3 +216,54 @@ def load_reference_omnihuman():
         os.chdir(cwd)
     _CACHE["omni"] = mod
     return mod
+
+
+def load_reference_encoders():
+    """(t5_module, clip_module) = the reference's ``wan.modules.t5`` / ``wan.modules.clip``, imported in place.
+    Shims: ``ftfy`` (text cleaning of the tokenizer wrapper — tokenisation is outside this path) and
+    ``torchvision.transforms`` (only ``Normalize`` is ever called, clip.py:537) are stubbed; ``t5.py:487`` evaluates
+    ``torch.cuda.current_device()`` in a default argument at class-definition time, so that call is answered with 0
+    during the import; ``flash_attention`` in clip.py is rebound to the masked SDPA used for model.py."""
+    if "enc" in _CACHE:
+        return _CACHE["enc"]
+    load_reference()
+    if not hasattr(sys.modules.get("wan.modules.t5"), "T5Encoder"):
+        sys.modules.pop("wan.modules.t5", None)                       # load_reference_omnihuman registers a stub
+    f = types.ModuleType("ftfy")
+    f.fix_text = lambda s: s
+    sys.modules.setdefault("ftfy", f)
+    tv, tvt = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms")
+
+    class _Compose:
+        def __init__(self, ts):
+            self.transforms = list(ts)
+
+    class _Normalize:
+        def __init__(self, mean, std):
+            self.mean, self.std = torch.tensor(mean).view(1, 3, 1, 1), torch.tensor(std).view(1, 3, 1, 1)
+
+        def __call__(self, x):
+            return (x - self.mean.to(x)) / self.std.to(x)
+
+    tvt.Compose, tvt.Normalize = _Compose, _Normalize
+    tvt.Resize = tvt.ToTensor = lambda *a, **k: None
+    tvt.InterpolationMode = types.SimpleNamespace(BICUBIC="bicubic")
+    tv.transforms = tvt
+    import importlib.machinery
+    for m_ in (f, tv, tvt):                                          # transformers probes find_spec() on its imports
+        m_.__spec__ = importlib.machinery.ModuleSpec(m_.__name__, None)
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.transforms", tvt)
+    cwd = os.getcwd()
+    os.chdir(tempfile.mkdtemp(prefix="omh_ref_"))
+    cd = torch.cuda.current_device
+    torch.cuda.current_device = lambda: 0
+    try:
+        t5 = importlib.import_module("wan.modules.t5")
+        clip = importlib.import_module("wan.modules.clip")
+    finally:
+        torch.cuda.current_device = cd
+        os.chdir(cwd)
+    clip.flash_attention = _masked_sdpa
+    _CACHE["enc"] = (t5, clip)
+    return t5, clip

@@ -187,3 +187,26 @@ def test_i2v_training_gradients_match_reference_vectors():
         a = osd[name].grad
         a = a if a.numel() <= 100000 else a[:16]
         assert rel_rms(a, torch.from_numpy(g[name])) < 1e-5, name
+
+
+def test_encoder_oracles_match_reference_vectors():
+    """umT5 encoder (with the repository's cut-down block, t5.py:166-176) and the CLIP vision tower
+    (use_31_block, clip.py:275-301) of the oracle against outputs of the REAL reference modules at a small width
+    (oracle/make_golden.py encoders), and the relative-position buckets against the reference's own function."""
+    from oracle import encoders_oracle as E, make_golden
+    g = _g("encoders_t5_clip.npz")
+    tc, vc, ids, mask, img = make_golden.encoder_cases()
+    with torch.no_grad():
+        t5 = E.t5_encode(E.t5_state_dict(tc, "golden/t5"), tc, ids, mask)
+        vit = E.vit_forward(E.vit_state_dict(vc, "golden/vit"), vc, img)
+    assert np.abs(t5.numpy() - g["t5"]).max() < 2e-5
+    assert np.abs(vit.numpy() - g["vit"]).max() < 5e-5
+    assert np.array_equal(E.t5_relative_buckets(40, 40, 32).numpy(), g["buckets"].astype(np.int64))
+    # the upstream block (attention residual on the un-normalised stream + gated feed-forward) is a different function
+    with torch.no_grad():
+        up = E.t5_encode(E.t5_state_dict(tc, "golden/t5"), tc, ids, mask, reference_block_quirk=False)
+    assert rel_rms(up, t5) > 0.05
+    # padded positions do not influence the valid ones
+    with torch.no_grad():
+        short = E.t5_encode(E.t5_state_dict(tc, "golden/t5"), tc, ids[1:, :15], mask[1:, :15])
+    assert float((short[0] - t5[1, :15]).abs().max()) < 1e-5
