@@ -277,6 +277,9 @@ int omh_rms_silu_cl(const void* x_bf16, const float* gamma, void* y_bf16, int64_
  * guider (Omnihuman/omnihuman_wan_t2v.py:37-45,149-157), whose convolutions run on omh_conv_cl_bf16.
  * A negative NaN becomes +0 as well (torch.relu would keep it): inputs here are finite conv outputs. */
 int omh_relu_bf16(void* x_bf16, int64_t n, omh_stream_t stream);
+/* Its backward for the training step of the pose guider (omnihuman_wan_t2v.py:453-488 through :149-157):
+ * g = y > 0 ? dy : 0 with y the ReLU's output; bf16, n % 8 == 0. */
+int omh_relu_bwd_bf16(const void* dy_bf16, const void* y_bf16, void* g_bf16, int64_t n, omh_stream_t stream);
 
 /* Layout/precision converts at the VAE boundary (vae.py:547-553, 535-540, 661):
  *   nchw_to_cl : y[t][h][w][c] = bf16( x[c][t0+t][h][w] * mul[c] + add[c] ), c < C; channels C..Cp-1 zero

@@ -129,6 +129,7 @@ _SIGS = {
     "omh_conv_cl_bf16": (i32, [C.POINTER(ConvArgs), vp]),
     "omh_rms_silu_cl": (i32, [vp, vp, vp, i64, i32, i32, vp]),
     "omh_relu_bf16": (i32, [vp, i64, vp]),
+    "omh_relu_bwd_bf16": (i32, [vp, vp, vp, i64, vp]),
     "omh_nchw_to_cl": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp]),
     "omh_cl_to_nchw": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, f32, f32, i32, i32, vp]),
     "omh_softmax_rows": (i32, [vp, i64, vp, i64, i64, i32, f32, vp]),

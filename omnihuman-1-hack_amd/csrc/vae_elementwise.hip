@@ -137,7 +137,36 @@ __global__ __launch_bounds__(256) void relu_bf16_kernel(uint4* __restrict__ x, i
     }
 }
 
+// backward of ReLU on bf16: g = y > 0 ? dy : 0 (y = the ReLU's OUTPUT), 8 elements per lane and trip
+__global__ __launch_bounds__(256) void relu_bwd_bf16_kernel(const uint4* __restrict__ dy, const uint4* __restrict__ y,
+                                                            uint4* __restrict__ g, int64_t nvec) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        uint4 d = dy[i];
+        const uint4 yy = y[i];
+        uint32_t* w = (uint32_t*)&d;
+        const uint32_t* q = (const uint32_t*)&yy;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint32_t u = w[e];
+            const uint32_t lo = q[e] & 0xffffu, hi = q[e] >> 16;
+            if (lo == 0 || (lo & 0x8000u)) u &= 0xffff0000u;           // y <= 0 (or -0): no gradient
+            if (hi == 0 || (hi & 0x8000u)) u &= 0x0000ffffu;
+            w[e] = u;
+        }
+        g[i] = d;
+    }
+}
+
 }  // namespace
+
+extern "C" int omh_relu_bwd_bf16(const void* dy, const void* y, void* g, int64_t n, omh_stream_t stream) {
+    if (!dy || !y || !g || n <= 0) return OMH_E_BADARG;
+    if ((n & 7) || ((uintptr_t)dy & 15) || ((uintptr_t)y & 15) || ((uintptr_t)g & 15)) return OMH_E_ALIGN;
+    omh_clear_status();
+    hipLaunchKernelGGL(relu_bwd_bf16_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)dy, (const uint4*)y, (uint4*)g, n / 8);
+    return omh_launch_status();
+}
 
 extern "C" int omh_relu_bf16(void* x, int64_t n, omh_stream_t stream) {
     if (!x || n <= 0) return OMH_E_BADARG;

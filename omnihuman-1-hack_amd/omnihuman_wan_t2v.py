@@ -35,14 +35,35 @@ def _ru(a, b):
 
 
 # ----------------------------------------------------------------------------- kernels behind the adapters
+# Each adapter layer is an autograd node whose forward AND backward run on libomh.so (the training step of
+# omnihuman_wan_t2v.py:453-488 back-propagates the flow-matching loss through the DiT's cross-attention into the
+# condition tokens and from there into these layers); under torch.no_grad() they are plain kernel launches.
+class _DenseFn(torch.autograd.Function):
+    """y = act_in(x) W^T + b, fp32 (omh_dense_f32 / omh_dense_f32_bwd); act_in: 0 none, 1 SiLU."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act_in):
+        x2 = x.reshape(-1, x.shape[-1]).float().contiguous()
+        wf = w.detach().float().contiguous()
+        y = ops.dense_f32(x2, wf, b.detach().float().contiguous(), act_in, 0)
+        ctx.save_for_backward(x2, wf)
+        ctx.act_in, ctx.shape, ctx.wdt = act_in, x.shape, w.dtype
+        return y.view(*x.shape[:-1], -1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wf = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1]).float().contiguous()
+        dW, db = torch.zeros_like(wf), torch.zeros(wf.shape[0], dtype=torch.float32, device=wf.device)
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        ops.dense_f32_bwd(x2, wf, dy2, dW=dW, db=db, dx=dx, act_in=ctx.act_in)
+        return (None if dx is None else dx.view(ctx.shape)), dW.to(ctx.wdt), db.to(ctx.wdt), None
+
+
 def _mlp_silu(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
     """Linear -> SiLU -> Linear on [..., K] fp32 (omnihuman_wan_t2v.py:30-34)."""
     l0, l2 = seq[0], seq[2]
-    shp = x.shape
-    h = ops.dense_f32(x.reshape(-1, shp[-1]).float().contiguous(), l0.weight.detach().float().contiguous(),
-                      l0.bias.detach().float().contiguous(), 0, 0)
-    y = ops.dense_f32(h, l2.weight.detach().float().contiguous(), l2.bias.detach().float().contiguous(), 1, 0)
-    return y.view(*shp[:-1], -1)
+    return _DenseFn.apply(_DenseFn.apply(x, l0.weight, l0.bias, 0), l2.weight, l2.bias, 1)
 
 
 def _pack_conv(conv: nn.Conv3d, cin_p: int) -> torch.Tensor:
@@ -54,7 +75,7 @@ def _pack_conv(conv: nn.Conv3d, cin_p: int) -> torch.Tensor:
     return ops.cast_bf16(wp.reshape(co, -1).contiguous())
 
 
-def _conv3d_relu(x_cl: torch.Tensor, conv: nn.Conv3d, stride_hw: int) -> torch.Tensor:
+def _conv3d_relu_fwd(x_cl: torch.Tensor, conv: nn.Conv3d, stride_hw: int) -> torch.Tensor:
     """x_cl bf16 [T, H, W, Cp] -> ReLU(Conv3d(k=3, padding=1, stride (1, s, s))) as bf16 [T, H', W', Cout_p].
     Output channels are padded to a multiple of 8 (zero weights, zero bias) so the result feeds the next layer."""
     T, H, W, Cp = x_cl.shape
@@ -72,6 +93,91 @@ def _conv3d_relu(x_cl: torch.Tensor, conv: nn.Conv3d, stride_hw: int) -> torch.T
     return ops.relu_bf16_(y)
 
 
+def _conv3d_relu_bwd(x_cl, y, dy, conv: nn.Conv3d, s: int, need_dx: bool):
+    """Backward of ``_conv3d_relu_fwd``: (dx_cl or None, dW [Cout, Cin, 3, 3, 3] fp32, db [Cout] fp32).
+
+    With g = dy where y > 0 (``omh_relu_bwd_bf16``) scattered onto the INPUT grid at (t, s*ho, s*wo) (zeros elsewhere):
+      * bias:   column sums of g (``omh_colsum_accum``);
+      * weight: dW[co, tap, ci] = sum_voxels g[v, co] x_pad[v + offset(tap), ci] — with g and the zero-padded input on
+        the same (H+2, W+2) row pitch a tap is a constant row offset, so each of the 27 taps is one ``omh_gemm_bf16_tn``
+        over the voxels (the contraction index on the rows of both operands, no transposes);
+      * input:  the transposed convolution = a stride-1 "same" convolution of the scattered g with the kernel
+        flipped along t, h, w and in/out channels swapped — the forward's own implicit-GEMM kernel."""
+    T, H, W, Cp = x_cl.shape
+    _, Ho, Wo, Cop = y.shape
+    co, ci = conv.out_channels, conv.in_channels
+    dev = x_cl.device
+    g = ops.relu_bwd_bf16(dy.contiguous(), y)
+    db = torch.zeros(Cop, dtype=torch.float32, device=dev)
+    ops.colsum_accum(g.view(-1, Cop), db)
+    P = (H + 2) * (W + 2)
+    G = torch.zeros(T, H + 2, W + 2, Cop, dtype=torch.bfloat16, device=dev)
+    G[:, 0:s * Ho:s, 0:s * Wo:s] = g                                     # scatter (data movement only)
+    tail = 2 * (W + 2) + 8
+    xflat = torch.zeros((T + 2) * P + tail, Cp, dtype=torch.bfloat16, device=dev)
+    xflat[:(T + 2) * P].view(T + 2, H + 2, W + 2, Cp)[1:T + 1, 1:H + 1, 1:W + 1] = x_cl
+    dWp = torch.empty(Cop, 27, Cp, dtype=torch.float32, device=dev)
+    Gf = G.view(T * P, Cop)
+    for kt in range(3):
+        for kh in range(3):
+            for kw in range(3):
+                off = kt * P + kh * (W + 2) + kw
+                ops.gemm_tn(Gf, xflat[off:off + T * P], out=dWp[:, (kt * 3 + kh) * 3 + kw, :])
+    dW = dWp[:co, :, :ci].reshape(co, 3, 3, 3, ci).permute(0, 4, 1, 2, 3).contiguous()
+    dx = None
+    if need_dx:
+        w = conv.weight.detach().float()                                 # [co, ci, kt, kh, kw]
+        wf = torch.zeros(Cp, 3, 3, 3, Cop, dtype=torch.float32, device=dev)
+        wf[:ci, :, :, :, :co] = w.flip(2, 3, 4).permute(1, 2, 3, 4, 0)
+        buf = torch.zeros(T + 2, H, W, Cop, dtype=torch.bfloat16, device=dev)
+        buf[1:T + 1] = G[:, :H, :W]
+        dx = ops.conv_cl(buf, ops.cast_bf16(wf.reshape(Cp, -1).contiguous()), None, T, H, W, Cp, 3, 3, 3, stride_t=1,
+                         stride_hw=1, pad_h=1, pad_w=1)
+    return dx, dW, db[:co].contiguous()
+
+
+class _Conv3dReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_cl, weight, bias, conv, stride_hw):
+        y = _conv3d_relu_fwd(x_cl, conv, stride_hw)
+        ctx.save_for_backward(x_cl, y)
+        ctx.conv, ctx.s = conv, stride_hw
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_cl, y = ctx.saved_tensors
+        dx, dW, db = _conv3d_relu_bwd(x_cl, y, dy, ctx.conv, ctx.s, ctx.needs_input_grad[0])
+        return dx, dW.to(ctx.conv.weight.dtype), db.to(ctx.conv.bias.dtype), None, None
+
+
+def _conv3d_relu(x_cl: torch.Tensor, conv: nn.Conv3d, stride_hw: int) -> torch.Tensor:
+    return _Conv3dReluFn.apply(x_cl, conv.weight, conv.bias, conv, stride_hw)
+
+
+class _LinearBf16Fn(torch.autograd.Function):
+    """y = x W^T + b on the bf16 MFMA GEMM (fp32 result); backward: dx = dy W (k-major B), dW = dy^T x (TN GEMM)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        a = ops.cast_bf16(x.float().contiguous())
+        wb = ops.cast_bf16(w.detach().float().contiguous())
+        ctx.save_for_backward(a, wb)
+        ctx.wdt = w.dtype
+        return ops.gemm(a, wb, bias=b.detach().float().contiguous(), epilogue=ops.EPI_F32)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, wb = ctx.saved_tensors
+        dyf = dy.float().contiguous()
+        dyb = ops.cast_bf16(dyf)
+        db = torch.zeros(wb.shape[0], dtype=torch.float32, device=dy.device)
+        ops.colsum_accum(dyf, db)
+        dW = ops.gemm_tn(dyb, a)                                          # [N, K] = dy^T x
+        dx = ops.gemm(dyb, wb, epilogue=ops.EPI_F32, b_kmajor=True) if ctx.needs_input_grad[0] else None
+        return dx, dW.to(ctx.wdt), db.to(ctx.wdt)
+
+
 def _pose_stack(convs, pose: torch.Tensor) -> torch.Tensor:
     """pose fp32 [K, T, H, W] -> fp32 [T, C', h, w] through the three conv+ReLU layers."""
     K, T, H, W = pose.shape
@@ -83,9 +189,7 @@ def _pose_stack(convs, pose: torch.Tensor) -> torch.Tensor:
 
 def _linear_bf16(lin: nn.Linear, x: torch.Tensor) -> torch.Tensor:
     """x fp32 [R, K] -> fp32 [R, N] on the bf16 MFMA GEMM (K % 8 == 0)."""
-    a = ops.cast_bf16(x.float().contiguous())
-    w = ops.cast_bf16(lin.weight.detach().float().contiguous())
-    return ops.gemm(a, w, bias=lin.bias.detach().float().contiguous(), epilogue=ops.EPI_F32)
+    return _LinearBf16Fn.apply(x, lin.weight, lin.bias)
 
 
 class _Adapters:
@@ -116,7 +220,7 @@ class _Adapters:
                          pose_tokens: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         """[B, Ne, model_dim] cross-attention tokens: audio pairs (frame t, then t+1), then pose, each
         ``condition_projector(token + temporal_embed[frame])`` (oracle/omnihuman_oracle.py:condition_tokens)."""
-        te = self.temporal_embed.detach()[0].float()
+        te = self.temporal_embed[0].float()          # (element-wise adds on O(100) tokens: host-side glue in torch)
         d = te.shape[1]
         toks = []
         if audio_tokens is not None:
@@ -132,9 +236,7 @@ class _Adapters:
             return None
         t = torch.cat(toks, dim=1).contiguous()
         cp = self.condition_projector
-        y = ops.dense_f32(t.view(-1, d), cp.weight.detach().float().contiguous(),
-                          cp.bias.detach().float().contiguous(), 0, 0)
-        return y.view(t.shape)
+        return _DenseFn.apply(t, cp.weight, cp.bias, 0)
 
 
 class OmniConditionsModule(_Adapters, nn.Module):
@@ -314,16 +416,39 @@ class OmniHumanWanT2V(_Adapters, nn.Module):
             lat = self.scheduler.step_cfg(c, u, current_cfg, lat)
         return lat if return_latent else vae.decode([lat])[0]
 
-    def training_step(self, frames: torch.Tensor, conditions: Dict[str, torch.Tensor], t: torch.Tensor) -> torch.Tensor:
-        """:440-480 — flow-matching loss of the text-conditioned backbone (autograd through the hand-written
-        backward of wan/modules/model_train.py).  Condition tokens have no backward: text only."""
-        if conditions.get("tokens") is not None or conditions.get("audio") is not None or conditions.get("pose") is not None:
-            raise NotImplementedError("training with audio / pose condition tokens: no backward is built for them")
-        noise = torch.randn_like(frames)
+    def training_step(self, frames: torch.Tensor, conditions: Dict[str, torch.Tensor], t: torch.Tensor,
+                      noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """:453-488 — the flow-matching loss ``mean((pred - frames)^2 (1 - t))`` of the conditioned backbone on
+        ``noisy = (1 - t) frames + t noise``, differentiable end to end: autograd runs through the hand-written
+        backward of the DiT (wan/modules/model_train.py), out of its cross-attention into the condition tokens, and
+        through ``condition_projector`` / ``temporal_embed`` into the audio MLP and the pose Conv3d stack + ``pose_fc``
+        (every layer's backward on libomh.so, see ``_DenseFn`` / ``_Conv3dReluFn`` / ``_LinearBf16Fn``).
+
+        ``conditions``: ``text`` [L, 4096] (required: WanModel cannot embed ``None``), and any of
+        ``tokens`` [B, Ne, dim] (ready condition tokens, e.g. from ``prepare_conditions``),
+        ``audio`` / ``pose`` (adapter outputs, turned into tokens here, gradients reach the projector and the
+        temporal embedding), ``audio_features`` [B, T, audio_dim] / ``pose_heatmaps`` [B, K, T, H, W] (raw inputs:
+        the adapters run here and are trained).  ``noise`` fixes the draw (tests)."""
+        frames = frames.to(self.device).float()
+        t = t.to(self.device).float()
+        if noise is None:
+            noise = torch.randn_like(frames)
         tt = t.view(-1, 1, 1, 1, 1)
-        noisy = (1 - tt) * frames + tt * noise
+        noisy = (1 - tt) * frames + tt * noise.to(self.device)
         ctx = conditions.get("text")
-        pred = self.wan_t2v.model(noisy, t, context=[ctx] * frames.shape[0] if ctx is not None else None,
-                                  seq_len=self._compute_seq_len(noisy.shape))
+        if ctx is None:
+            raise ValueError("text conditioning is required (omnihuman_wan_t2v.py:476-482 passes [None] otherwise, "
+                             "which WanModel cannot embed)")
+        audio, pose = conditions.get("audio"), conditions.get("pose")
+        if conditions.get("audio_features") is not None:
+            audio = self.process_audio(conditions["audio_features"].to(self.device))
+        if conditions.get("pose_heatmaps") is not None:
+            pose = self.process_pose(conditions["pose_heatmaps"].to(self.device))
+        tokens = conditions.get("tokens")
+        if tokens is None:
+            tokens = self.condition_tokens(audio, pose)
+        B = frames.shape[0]
+        pred = self.wan_t2v.model(noisy, t, context=[ctx.to(self.device)] * B,
+                                  seq_len=self._compute_seq_len(noisy.shape), extra_conditions=tokens)
         pred = torch.stack(pred)
         return torch.mean((pred - frames) ** 2 * (1 - tt))

@@ -293,6 +293,15 @@ def relu_bf16_(x):
     return x
 
 
+def relu_bwd_bf16(dy, y):
+    """g = y > 0 ? dy : 0 (y = the ReLU's output); contiguous bf16, numel % 8 == 0."""
+    _dev(dy, y)
+    assert dy.dtype == y.dtype == torch.bfloat16 and dy.is_contiguous() and y.is_contiguous() and dy.shape == y.shape
+    g = torch.empty_like(dy)
+    check(lib.omh_relu_bwd_bf16(_p(dy), _p(y), _p(g), dy.numel(), _stream()), "omh_relu_bwd_bf16")
+    return g
+
+
 def nchw_to_cl(x, T, t0, Cp, mul=None, add=None, out=None):
     """x fp32 [C, Ttot, H, W] frames [t0, t0+T) -> bf16 [T, H, W, Cp]."""
     _dev(x, mul, add, out)

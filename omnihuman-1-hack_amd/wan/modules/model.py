@@ -602,10 +602,8 @@ class WanModel(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             if isinstance(context, ContextState):
                 raise ValueError("a ContextState is an inference-time cache: pass the raw context when training")
-            if extra_conditions is not None:
-                raise NotImplementedError("extra_conditions are an inference-time input (no backward is built for them)")
             from .model_train import forward_train
-            return forward_train(self, x, t, context, seq_len, clip_fea, y)
+            return forward_train(self, x, t, context, seq_len, clip_fea, y, extra_conditions)
         with torch.no_grad():
             return self._forward_infer(x, t, context, seq_len, clip_fea, y, extra_conditions)
 

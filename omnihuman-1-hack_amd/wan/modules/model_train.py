@@ -578,9 +578,11 @@ def _img_emb_backward(model, clip_fea, d_img, g):
 class _EmbedFn(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, model, st, x_list, t, context, seq_len, clip_fea, y, *params):
+    def forward(ctx, model, st, x_list, t, context, seq_len, clip_fea, y, extra_tokens, *params):
         with torch.no_grad():
-            xs, e, fc, grids, lens, ctx_lens = model._embed(x_list, t, context, seq_len, clip_fea, y)
+            xs, e, fc, grids, lens, ctx_lens = model._embed(x_list, t, context, seq_len, clip_fea, y, extra_tokens)
+        ctx.n_extra = 0 if extra_tokens is None else int(extra_tokens.shape[1])
+        ctx.extra_dtype = None if extra_tokens is None else extra_tokens.dtype
         st.fc, st.e, st.grids, st.lens = fc, e, grids, lens
         B, d = fc.B, fc.dim
         dev = xs.device
@@ -661,16 +663,23 @@ class _EmbedFn(torch.autograd.Function):
         for n, p in _embed_params(model):
             gg = g.get(n) if p.requires_grad else None
             out.append(None if gg is None else gg.view(p.shape).to(p.dtype))
-        return (None, None, None, None, None, None, None, None, *out)
+        # condition tokens of the OmniHuman adapters (omnihuman_wan_t2v.py:453-488): they sit in front of the text
+        # in the context, so their gradient is the leading rows of the context gradient
+        d_extra = None
+        if ctx.n_extra and ctx.needs_input_grad[8]:
+            d_extra = st.d_ctx[:, :ctx.n_extra].contiguous().to(ctx.extra_dtype)
+        return (None, None, None, None, None, None, None, None, d_extra, *out)
 
 
-def forward_train(model, x, t, context, seq_len, clip_fea=None, y=None):
+def forward_train(model, x, t, context, seq_len, clip_fea=None, y=None, extra_conditions=None):
     """WanModel.forward with autograd enabled: same outputs as the inference path, attached to a
-    graph of hand-written nodes (see module docstring)."""
+    graph of hand-written nodes (see module docstring).  ``extra_conditions``: [B, Ne, dim] condition tokens (or a
+    dict holding them under 'tokens') that receive a gradient like any other input."""
     st = _State()
     x_list = list(x) if not isinstance(x, (list, tuple)) else list(x)
     eparams = [p for _, p in _embed_params(model)]
-    xs = _EmbedFn.apply(model, st, x_list, t, list(context), seq_len, clip_fea, y, *eparams)
+    tok = extra_conditions.get("tokens") if isinstance(extra_conditions, dict) else extra_conditions
+    xs = _EmbedFn.apply(model, st, x_list, t, list(context), seq_len, clip_fea, y, tok, *eparams)
     if not xs.requires_grad:
         xs.requires_grad_(True)          # keeps the chain alive when the embed parameters are frozen
     for i, blk in enumerate(model.blocks):

@@ -356,12 +356,12 @@ def dit_forward(sd, cfg: DiTConfig, x_list: Sequence[torch.Tensor], t: torch.Ten
 
 
 def dit_forward_autograd(sd, cfg: DiTConfig, x_list, t, context_list, seq_len, reference_ffn_freeze=True,
-                         clip_fea=None, y=None):
+                         clip_fea=None, y=None, extra_tokens=None):
     """The same forward with autograd enabled (``sd`` tensors with requires_grad): the oracle of the
     training step (distilled_trainer.py:268-301).  ``reference_ffn_freeze`` reproduces the reference's
     block_idx > 10 FFN quirk (model.py:317-324).  ``clip_fea`` / ``y``: the i2v backbone."""
     x, e, e0, ctx, context_lens, seq_lens, grid_sizes = embed_inputs(sd, cfg, x_list, t, context_list, seq_len,
-                                                                     clip_fea, y)
+                                                                     clip_fea, y, extra_tokens)
     angles = rope_table(cfg.dim // cfg.num_heads)
     for i in range(cfg.num_layers):
         x = attention_block(sd, i, cfg, x, e0, seq_lens, grid_sizes, angles, ctx, context_lens,

@@ -128,3 +128,34 @@ def test_clip_vit_h_width_two_layers():
     with torch.no_grad():
         ref = E.vit_forward(sd, cfg, E.clip_preprocess([vid]))
     assert out.shape == (1, 257, 1280) and rel_rms(out, ref) < TOL
+
+
+def test_wan_t2v_generate_from_a_prompt_string():
+    """text2video.py:112-269 end to end FROM STRINGS: prompt and negative prompt through ``T5EncoderModel`` (a small
+    umT5 whose width matches the small DiT's text_dim, a stand-in tokenizer), the DiT, the sampler and the VAE — equal,
+    bit for bit, to generate() fed the encoder's embeddings as ``context=`` / ``context_null=``."""
+    from oracle import encoders_oracle as E
+    samp = importlib.import_module("test_gpu_sampler")
+    t5 = importlib.import_module(PKG + ".wan.modules.t5")
+    pipe, args = samp._tiny_t2v()
+    tcfg = E.T5Config(vocab=300, dim=64, dim_attn=128, dim_ffn=160, num_heads=2, num_layers=2, num_buckets=32)
+    enc_model = _t5(tcfg, E.t5_state_dict(tcfg, "e2e/t5"))
+
+    def tokenizer(texts, text_len=32):
+        ids = torch.zeros(len(texts), text_len, dtype=torch.int64)
+        mask = torch.zeros(len(texts), text_len, dtype=torch.int64)
+        for i, t in enumerate(texts):
+            toks = [3 + (ord(c) * 7) % 290 for c in t][:text_len - 1] + [1]          # "eos" = 1
+            ids[i, :len(toks)] = torch.tensor(toks)
+            mask[i, :len(toks)] = 1
+        return ids, mask
+    pipe.text_encoder = t5.T5EncoderModel(32, device="cuda", model=enc_model, tokenizer=tokenizer)
+    kw = {k: v for k, v in args.items() if k not in ("context", "context_null")}
+    prompt, neg = "a cat walks on the beach", "blurry, static"
+    vid = pipe.generate(prompt, n_prompt=neg, seed=3, **kw)
+    ctx, ctx0 = pipe.text_encoder([prompt], "cuda"), pipe.text_encoder([neg], "cuda")
+    assert ctx[0].shape == (len(prompt) + 1, 64) and ctx0[0].shape == (len(neg) + 1, 64)
+    vid2 = pipe.generate("", seed=3, context=ctx, context_null=ctx0, **kw)
+    assert vid.shape == vid2.shape and bool(torch.isfinite(vid).all()) and torch.equal(vid, vid2)
+    vid3 = pipe.generate("a dog", n_prompt=neg, seed=3, **kw)
+    assert not torch.equal(vid3, vid)                                   # the prompt reaches the video
