@@ -59,3 +59,106 @@ def training_step(batch, distilled_model, num_train_timesteps=1000, gradient_acc
     loss = forward_backward(batch, distilled_model, num_train_timesteps, gradient_accumulation_steps, loss_scale,
                             reference_loss_quirk)
     return loss.item() * gradient_accumulation_steps
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Checkpoint save / resume in the trainers' formats (seaweed_apt/distilled_trainer.py:153-178, 199-231): the
+# ``accelerator.save_state`` directory layout (model.safetensors, optimizer.bin, scaler.pt, random_states_<rank>.pkl)
+# next to the reference's manual fallback file (pytorch_model.bin = {'model', 'optimizer', 'scaler', 'step',
+# 'epoch'}), and the EMA weights as a plain state dict (ema_model_step_<n>.pt / ema_model_epoch_<n>.pt /
+# ema_model_final.pt, read back by eval_ema.py:43-47 and wan_inference.py:59-63).  Host-side I/O only.
+def save_checkpoint(checkpoint_dir, model, optimizer=None, scaler_state=None, step: int = 0, epoch: int = 0, rank: int = 0,
+                    is_main_process: bool = True):
+    """Write ``checkpoint_dir`` so that either loader finds what it expects.  Every rank writes its RNG states
+    (as accelerate does); the main process writes the rest."""
+    import os
+    import pickle
+    import random
+    import numpy as np
+    os.makedirs(checkpoint_dir, exist_ok=True)
+    states = {"step": int(step), "random_state": random.getstate(), "numpy_random_seed": np.random.get_state(),
+              "torch_manual_seed": torch.get_rng_state()}
+    if torch.cuda.is_available():
+        states["torch_cuda_manual_seed"] = torch.cuda.get_rng_state_all()
+    with open(os.path.join(checkpoint_dir, f"random_states_{rank}.pkl"), "wb") as fh:
+        pickle.dump(states, fh)
+    if not is_main_process:
+        return checkpoint_dir
+    sd = {k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}
+    try:
+        from safetensors.torch import save_file
+        save_file(sd, os.path.join(checkpoint_dir, "model.safetensors"), metadata={"format": "pt"})
+    except ImportError:                                       # accelerate's own fallback name
+        torch.save(sd, os.path.join(checkpoint_dir, "pytorch_model.bin.model"))
+    opt_sd = optimizer.state_dict() if optimizer is not None else None
+    if opt_sd is not None:
+        torch.save(opt_sd, os.path.join(checkpoint_dir, "optimizer.bin"))
+    if scaler_state is not None:
+        torch.save(scaler_state, os.path.join(checkpoint_dir, "scaler.pt"))
+    torch.save({"model": sd, "optimizer": opt_sd, "scaler": scaler_state, "step": int(step), "epoch": int(epoch)},
+               os.path.join(checkpoint_dir, "pytorch_model.bin"))
+    return checkpoint_dir
+
+
+def load_checkpoint(checkpoint_dir, model, optimizer=None, rank: int = 0, restore_rng: bool = True):
+    """Resume from a directory written by ``save_checkpoint``, by ``accelerator.save_state`` or by the reference's
+    manual fallback.  Returns ``{'step', 'epoch', 'scaler'}`` (what the files hold of them).  A torch.optim.AdamW
+    state (tensor ``step`` entries) loads into ``optim.AdamW`` as is."""
+    import os
+    import pickle
+    import random
+    import numpy as np
+    info = {"step": 0, "epoch": 0, "scaler": None}
+    manual = os.path.join(checkpoint_dir, "pytorch_model.bin")
+    st_path = os.path.join(checkpoint_dir, "model.safetensors")
+    blob = None
+    if os.path.exists(manual):
+        blob = torch.load(manual, map_location="cpu", weights_only=False)
+        if not (isinstance(blob, dict) and "model" in blob):     # accelerate's pytorch_model.bin is the bare state dict
+            blob = {"model": blob}
+    if os.path.exists(st_path):
+        from safetensors.torch import load_file
+        model.load_state_dict(load_file(st_path))
+    elif blob is not None:
+        model.load_state_dict(blob["model"])
+    else:
+        raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {checkpoint_dir}")
+    if optimizer is not None:
+        opt_path = os.path.join(checkpoint_dir, "optimizer.bin")
+        opt_sd = torch.load(opt_path, map_location="cpu", weights_only=False) if os.path.exists(opt_path) else \
+            (blob or {}).get("optimizer")
+        if opt_sd is not None:
+            optimizer.load_state_dict(opt_sd)
+    sc = os.path.join(checkpoint_dir, "scaler.pt")
+    info["scaler"] = torch.load(sc, map_location="cpu", weights_only=False) if os.path.exists(sc) else (blob or {}).get("scaler")
+    if blob is not None:
+        info["step"], info["epoch"] = int(blob.get("step", 0)), int(blob.get("epoch", 0))
+    rs = os.path.join(checkpoint_dir, f"random_states_{rank}.pkl")
+    if os.path.exists(rs):
+        with open(rs, "rb") as fh:
+            states = pickle.load(fh)
+        info["step"] = int(states.get("step", info["step"]))
+        if restore_rng:
+            random.setstate(states["random_state"])
+            np.random.set_state(states["numpy_random_seed"])
+            torch.set_rng_state(states["torch_manual_seed"])
+            if torch.cuda.is_available() and "torch_cuda_manual_seed" in states:
+                try:
+                    torch.cuda.set_rng_state_all(states["torch_cuda_manual_seed"])
+                except (RuntimeError, IndexError):                # saved on a different number of devices
+                    pass
+    # parameters were rewritten: the packed bf16 copies are keyed on the parameters' versions (load_state_dict's copy_
+    # bumps them), nothing else to invalidate
+    return info
+
+
+def save_ema(path, ema_model):
+    """distilled_trainer.py:175-178, 223-231: the EMA weights as a bare state dict."""
+    torch.save({k: v.detach().cpu() for k, v in ema_model.state_dict().items()}, path)
+    return path
+
+
+def load_ema(path, model):
+    """eval_ema.py:43-47 / wan_inference.py:59-63."""
+    model.load_state_dict(torch.load(path, map_location="cpu", weights_only=False))
+    return model

@@ -1,5 +1,6 @@
 """Training step (distilled_trainer.py:241-316 semantics) on the HIP path:
 loss and gradients against the reference's golden gradients and the autograd oracle."""
+import importlib
 import os
 
 import numpy as np
@@ -283,3 +284,73 @@ def test_i2v_training_gradients(wan_model_mod):
         if err > (TOL_GRAD if og.dim() > 1 else 1e-1):
             bad.append((name, err))
     assert not bad, bad[:10]
+
+
+def test_checkpoint_save_resume_in_the_trainers_formats(wan_model_mod, tmp_path):
+    """distilled_trainer.py:153-178: save after two steps, resume into fresh objects, continue — the resumed run
+    reaches the weights of the uninterrupted one (to the gradients' fp32-atomics noise), through the accelerate
+    layout, through the reference's manual pytorch_model.bin alone, and with a torch.optim.AdamW optimizer state."""
+    import os
+    trainer = importlib.import_module("omnihuman-1-hack_amd.trainer")
+    optim = importlib.import_module("omnihuman-1-hack_amd.optim")
+    cfg, sd, m, noise, vt, cl = _setup(wan_model_mod, True)
+    batch = (noise.cuda(), torch.stack([c for c in cl]).cuda() if cl[0].shape == cl[1].shape else None, vt.cuda())
+    if batch[1] is None:
+        L = max(c.shape[0] for c in cl)
+        ctx = torch.zeros(len(cl), L, cl[0].shape[1])
+        for i, c in enumerate(cl):
+            ctx[i, :c.shape[0]] = c
+        batch = (noise.cuda(), ctx.cuda(), vt.cuda())
+
+    def fresh():
+        from oracle import make_golden
+        mm = wan_model_mod.WanModel(num_layers=13, **make_golden.TINY)
+        mm.load_state_dict(sd)
+        mm = mm.cuda().train()
+        return mm, optim.AdamW(mm.parameters(), lr=1e-3, weight_decay=0.01)
+
+    def steps(mm, oo, n):
+        for _ in range(n):
+            trainer.training_step(batch, mm)
+            oo.step()
+            oo.zero_grad(set_to_none=True)
+
+    m_a, o_a = fresh()
+    steps(m_a, o_a, 2)
+    ck = trainer.save_checkpoint(str(tmp_path / "checkpoint_2"), m_a, o_a, step=2, epoch=0)
+    assert {"model.safetensors", "optimizer.bin", "pytorch_model.bin", "random_states_0.pkl"} <= set(os.listdir(ck))
+    ema = trainer.save_ema(str(tmp_path / "ema_model_step_2.pt"), m_a)
+    steps(m_a, o_a, 2)
+    # (1) resume from the accelerate layout
+    m_b, o_b = fresh()
+    info = trainer.load_checkpoint(ck, m_b, o_b)
+    assert info["step"] == 2 and info["epoch"] == 0
+    steps(m_b, o_b, 2)
+    for (n, a), (_, b) in zip(m_a.named_parameters(), m_b.named_parameters()):
+        assert rel_rms(b.detach(), a.detach()) < 1e-3, n
+    assert int(o_b.state[next(iter(m_b.parameters()))]["step"]) == 4
+    # (2) the reference's manual fallback file alone
+    os.remove(os.path.join(ck, "model.safetensors"))
+    os.remove(os.path.join(ck, "optimizer.bin"))
+    m_c, o_c = fresh()
+    assert trainer.load_checkpoint(ck, m_c, o_c)["step"] == 2
+    steps(m_c, o_c, 2)
+    for (n, a), (_, c) in zip(m_a.named_parameters(), m_c.named_parameters()):
+        assert rel_rms(c.detach(), a.detach()) < 1e-3, n
+    # (3) an optimizer state written by torch.optim.AdamW (tensor step counts) loads into the fused optimizer
+    m_d, _ = fresh()
+    t_opt = torch.optim.AdamW(m_d.parameters(), lr=1e-3, weight_decay=0.01)
+    trainer.training_step(batch, m_d)
+    t_opt.step()
+    blob = {"model": m_d.state_dict(), "optimizer": t_opt.state_dict(), "scaler": None, "step": 1, "epoch": 0}
+    d2 = tmp_path / "checkpoint_torch"
+    d2.mkdir()
+    torch.save(blob, str(d2 / "pytorch_model.bin"))
+    m_e, o_e = fresh()
+    trainer.load_checkpoint(str(d2), m_e, o_e)
+    steps(m_e, o_e, 1)
+    assert int(o_e.state[next(iter(m_e.parameters()))]["step"]) == 2
+    # EMA file round trip (eval_ema.py:43-47)
+    m_f, _ = fresh()
+    trainer.load_ema(ema, m_f)
+    assert all(torch.isfinite(p).all() for p in m_f.parameters())
