@@ -120,9 +120,15 @@ typedef struct omh_attn_args {
        0: the long-sequence kernel multiplies q by scale*log2(e) itself and re-rounds it to bf16 (a 2^-9 relative
        perturbation of q); the short-sequence kernels apply the factor to the fp32 scores.                        */
     int32_t q_prescaled;
+    /* Optional scratch for the long-sequence kernel's split-KV tail (omh_flash_attn_workspace_bytes() bytes, 16-byte
+       aligned, contents irrelevant): when the number of 256-query tiles is a multiple of the 256 CUs plus a small
+       remainder, the remainder is split over the keys instead of costing a whole extra round.  NULL: no split. */
+    void* workspace; int64_t workspace_bytes;
 } omh_attn_args;
 
 int omh_flash_attn_fwd_d128(const omh_attn_args* args, omh_stream_t stream);
+/* Scratch size omh_flash_attn_fwd_d128 can use for these shapes (0: none needed). */
+int64_t omh_flash_attn_workspace_bytes(const omh_attn_args* args);
 
 /* ------------------------------------------------------------------------
  * Flash attention backward, head_dim 128 (training step: the autograd of

@@ -84,7 +84,7 @@ class AttnArgs(C.Structure):
                 ("B", i32), ("H", i32), ("Lq", i32), ("Lk", i32),
                 ("q_bs", i64), ("q_rs", i64), ("k_bs", i64), ("k_rs", i64),
                 ("vt_bs", i64), ("o_bs", i64), ("o_rs", i64),
-                ("ldv", i32), ("scale", f32), ("lse", vp), ("q_prescaled", i32)]
+                ("ldv", i32), ("scale", f32), ("lse", vp), ("q_prescaled", i32), ("workspace", vp), ("workspace_bytes", i64)]
 
 
 class AttnBwdArgs(C.Structure):
@@ -117,6 +117,7 @@ _SIGS = {
     "omh_gemm_bf16": (i32, [C.POINTER(GemmArgs), vp]),
     "omh_gemm_bf16_tn": (i32, [C.POINTER(GemmTnArgs), vp]),
     "omh_flash_attn_fwd_d128": (i32, [C.POINTER(AttnArgs), vp]),
+    "omh_flash_attn_workspace_bytes": (i64, [C.POINTER(AttnArgs)]),
     "omh_flash_attn_bwd_d128": (i32, [C.POINTER(AttnBwdArgs), vp]),
     "omh_layernorm_modulate": (i32, [vp, vp, i64, i32, f32, f32, vp, vp, i64, vp, vp, i64, i64, vp]),
     "omh_rmsnorm_rope": (i32, [vp, i64, vp, i64, i32, vp, f32, i32, vp, vp, i32, i32, vp, i32, vp]),

@@ -31,7 +31,8 @@ Variants (selected at launch, OMH_W64_VARIANT; kept side by side for A/B timing 
   V1  = V0 with the eight DMA pieces spread over phase 1 and the first three V^T fragments of phase 2 read under
       the last MFMAs of phase 1;
   V2  = V1 with a K ring of THREE slots filled three tiles ahead, so that the first K fragments of the next tile are
-      read under the last MFMAs of phase 2 (no phase starts by waiting for the LDS).
+      read under the last MFMAs of phase 2 (no phase starts by waiting for the LDS);
+  V3  = V2 storing its normalised result in fp32: the split-KV workers of the tail (attention_w64.hip).
 
 Register map (asm-owned; the thirteen per-lane inputs stay in the compiler's operand registers v0..v11):
   a[0:127]    O^T accumulators   [qb][db] 16 each
@@ -317,9 +318,13 @@ def generate(variant):
     dma_spread = base >= 1
     vpre = base >= 1
     k3 = base >= 2
-    # timing-only ablations of V2 (wrong results): 3 = no LDS-DMA in the loop, 4 = v_exp -> v_mov, 5 = no barrier,
-    # 6 = no ds_reads in the loop bodies
-    abl = variant if variant >= 3 else 0
+    # (timing-only ablations of V2 measured in round 2, profiles/r02_attention_w64_ablations.json: no LDS-DMA in the
+    # loop -5.9 %, v_exp -> v_mov -3.4 %, no barrier -0.2 %, no ds_reads -8.1 %: nothing dominates)
+    abl = 0
+    # variant 3 = variant 2 with the "partial" epilogue of the split-KV tail workers: the normalised output is stored
+    # in fp32 (one [256, 128] slab per worker) instead of bf16; with the log-sum-exp stored next to it a combine
+    # pass weights the workers' results (attention_w64.hip)
+    partial = variant == 3
     # LDS map: two-slot rings: K [0, 32K) | V^T [32K, 64K).  Three-slot K ring: V^T [0, 32K) | K [32K, 80K) — the K
     # addresses carry the ring base and slot in the address registers, so every ds_read offset stays below 64 KiB
     VBASE = 0 if k3 else 2 * KSLOT
@@ -421,8 +426,7 @@ def generate(variant):
     def body(p):
         cur, nxt = p, p ^ 1
         e("s_waitcnt vmcnt(0)")
-        if abl != 5:
-            e("s_barrier")
+        e("s_barrier")
         if k3:
             dma = k_dma("s99") + v_dma(nxt)
             kbase = 0                                          # the address registers carry the slot
@@ -430,8 +434,6 @@ def generate(variant):
             dma = k_dma(p * KSLOT) + v_dma(nxt)
             kbase = nxt * KSLOT
         vbase = VBASE + p * KSLOT
-        if abl == 3:
-            dma = []
         # ---- phase 1
         mf1 = qk_mfmas(nxt)
         plans = [qk_read_plan(kbase)]
@@ -471,10 +473,6 @@ def generate(variant):
         pre = [] if vpre else [vread_op(0, vbase), vread_op(1, vbase), vread_op(2, vbase)]
         pend = linearize(e, weave(mf2, plans, pre=pre), pend)
         assert pend == LOOP_PENDING, (pend, LOOP_PENDING)
-        if abl == 4:
-            e.lines[mark:] = [ln.replace("v_exp_f32", "v_mov_b32") for ln in e.lines[mark:]]
-        if abl == 6:
-            e.lines[mark:] = [ln for ln in e.lines[mark:] if not ln.startswith(("ds_read", "s_waitcnt lgkmcnt"))]
         check_and_rescale(e, nxt, f"b{p}")
         e("s_add_u32 s94, s94, 1")
 
@@ -526,6 +524,10 @@ def generate(variant):
                     e(f"v_accvgpr_read_b32 {vr(t_)}, {ar(a_)}")
                 for t_ in tmp:
                     e(f"v_mul_f32 {vr(t_)}, {vr(t_)}, {vr(INV[qb])}")
+                if partial:
+                    e(f"buffer_store_dwordx4 {vr(tmp[0], 4)}, %[voo], %[ro], {so} offen offset:{db * 128 + g * 32}")
+                    e("s_nop 1")
+                    continue
                 e(f"v_cvt_pk_bf16_f32 {vr(tmp[0])}, {vr(tmp[0])}, {vr(tmp[1])}")
                 e(f"v_cvt_pk_bf16_f32 {vr(tmp[1])}, {vr(tmp[2])}, {vr(tmp[3])}")
                 e(f"buffer_store_dwordx2 {vr(tmp[0], 2)}, %[voo], %[ro], {so} offen offset:{db * 64 + g * 16}")
@@ -546,8 +548,8 @@ def generate(variant):
     return e
 
 
-N_VARIANTS = 3        # 3..6 are the timing-only ablations (set 7 and add the kernels in attention_w64.hip to time them)
-LDS_BYTES = {0: 4 * KSLOT, 1: 4 * KSLOT, 2: 5 * KSLOT, 3: 5 * KSLOT, 4: 5 * KSLOT, 5: 5 * KSLOT, 6: 5 * KSLOT}
+N_VARIANTS = 4
+LDS_BYTES = {0: 4 * KSLOT, 1: 4 * KSLOT, 2: 5 * KSLOT, 3: 5 * KSLOT}
 CLOBBER_V = range(12, 256)
 CLOBBER_A = range(0, 256)
 CLOBBER_S = range(91, 100)

@@ -85,7 +85,12 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
 def flash_attn_raw(q, k, vt, o, k_lens, B, H, Lq, Lk, q_bs, q_rs, k_bs, k_rs, vt_bs, o_bs, o_rs, ldv, scale,
                    lse=None, q_prescaled=0):
     a = AttnArgs(q, k, vt, o, k_lens, B, H, Lq, Lk, q_bs, q_rs, k_bs, k_rs, vt_bs, o_bs, o_rs, ldv, scale, lse,
-                 int(q_prescaled))
+                 int(q_prescaled), None, 0)
+    need = lib.omh_flash_attn_workspace_bytes(C.byref(a))          # split-KV tail of the long-sequence kernel
+    ws = None
+    if need > 0:
+        ws = torch.empty(need, dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()))
+        a.workspace, a.workspace_bytes = ws.data_ptr(), need
     check(lib.omh_flash_attn_fwd_d128(C.byref(a), _stream()), "omh_flash_attn_fwd_d128")
 
 

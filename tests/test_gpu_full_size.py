@@ -264,3 +264,38 @@ def test_wan_t2v_generate_full_size(wan_1_3b):
     assert rel_rms(other, lat) > 0.1
     video = pipe.generate("", seed=3, **kw)
     assert tuple(video.shape) == (3, 81, 480, 832) and bool(torch.isfinite(video).all()) and float(video.abs().max()) <= 1.0
+
+
+def test_self_attention_split_kv_tail_config4(ops, monkeypatch):
+    """BASELINE config 4's self-attention (S = 21 840, 12 heads): 1 032 tiles of 256 queries = 4 x 256 CUs + 8, so the
+    last 8 tiles are split over the keys into 16 workers each (fp32 partial results + log-sum-exp, combined by a second
+    small kernel: attention_w64.hip).  The tail rows against fp32 arithmetic, the log-sum-exp of split and unsplit
+    rows, and everything outside the tail bit for bit against the unsplit launch."""
+    torch.manual_seed(9)
+    B, H, L, D = 1, 12, 21 * 2 * 30 * 52 // 3, 128                      # 21 840 = (13 + 1) latent frames x 1 560
+    assert L == 21840
+    q = _bf(torch.randn(B, L, H, D, device="cuda"))
+    k = _bf(torch.randn(B, L, H, D, device="cuda"))
+    v = _bf(torch.randn(B, L, H, D, device="cuda"))
+    vt = _vt(v, B, L, H, D)
+
+    def run(split):
+        monkeypatch.setenv("OMH_W64_SPLIT", split)
+        out = torch.empty(B, L, H, D, dtype=torch.bfloat16, device="cuda")
+        lse = torch.empty(B, H, L, dtype=torch.float32, device="cuda")
+        ops.flash_attn_raw(ops.ptr(q), ops.ptr(k), ops.ptr(vt), ops.ptr(out), None, B, H, L, L, q.stride(0), q.stride(1),
+                           k.stride(0), k.stride(1), vt.stride(0), out.stride(0), out.stride(1), vt.stride(1), D ** -0.5,
+                           lse=ops.ptr(lse))
+        return out, lse
+    out, lse = run("1")
+    ref_o, ref_l = run("0")
+    assert torch.equal(out[:, :, :11], ref_o[:, :, :11]) and torch.equal(out[:, :19968, 11], ref_o[:, :19968, 11])
+    assert not torch.equal(out[:, 19968:, 11], ref_o[:, 19968:, 11])      # the tail did go through the split path
+    rows = torch.tensor([19968, 19969, 20223, 20224, 21000, L - 257, L - 2, L - 1], device="cuda")
+    s = (q[0, rows, 11].float() @ k[0, :, 11].float().t()) * D ** -0.5
+    ref = torch.softmax(s, -1) @ v[0, :, 11].float()
+    got = out[0, rows, 11].float()
+    assert rel_rms(got, ref) < 8e-3 and float((got - ref).abs().max()) < 3e-2
+    assert float((lse[0, 11, rows] - torch.logsumexp(s, -1)).abs().max()) < 5e-3
+    assert float((lse - ref_l).abs().max()) < 5e-3
+    assert torch.equal(run("1")[0], out)                                   # repeatable
