@@ -484,6 +484,8 @@ def main():
     roofline = None
     if attn_ms:
         ach = attn_flops / (attn_ms * 1e-3) / 1e12
+        kname = {"pp": "flash_attn_fwd_d128_pp_kernel", "base": "flash_attn_fwd_d128_kernel"}.get(
+            os.environ.get("OMH_ATTN_KERNEL", ""), "flash_attn_fwd_d128_w64_v2_kernel")
         traffic = None
         tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tj):
@@ -493,8 +495,6 @@ def main():
                 traffic = None
         if traffic is not None:
             traffic = traffic * nb                                 # measured per batch element (tools/pmc_attn.sh)
-        kname = {"pp": "flash_attn_fwd_d128_pp_kernel", "base": "flash_attn_fwd_d128_kernel"}.get(
-            os.environ.get("OMH_ATTN_KERNEL", ""), "flash_attn_fwd_d128_w64_v2_kernel")
         roofline = {"kernel": "%s (self-attention, Lq=Lk=%d, 12 heads, D=128, batch %d)" % (kname, seq_len, nb),
                     "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,

@@ -16,8 +16,9 @@ TOL_TINY = 8.0e-3     # 2..13 layers, d=256
 TOL_FULL = 1.2e-2     # 30 layers, d=1536
 # guided velocity v = u + 7.5 (c - u) of config 1: the errors of the two forwards enter with weights 7.5 and 6.5
 # while |v| stays O(|u|) when c ~ u, so its relative error is ~ sqrt(7.5^2 + 6.5^2) = 9.9 x the forward's.
-# Measured on MI355X (round 2): see the [measured] line this test prints; bound = 2 x measured.
-TOL_CFG = 0.2
+# Measured on MI355X (round 2): forward 4.99e-3, guided velocity 9.5e-3 (c and u share most of their rounding
+# noise, so the amplification is 1.9 x rather than the worst-case 9.9 x); bound = 2 x measured.
+TOL_CFG = 2.0e-2
 
 
 def _inputs(cfg, grids, ctx_lens, tag):
