@@ -33,13 +33,13 @@ def _hipcc():
 
 def _generate():
     """Generated instruction streams: csrc/gen_*.py -> csrc/*_asm.inc (rewritten only when the text changes)."""
-    gen = os.path.join(CSRC, "gen_attn_w64.py")
-    out = os.path.join(CSRC, "attention_w64_asm.inc")
-    if os.path.exists(gen):
-        txt = subprocess.run([sys.executable, gen], check=True, capture_output=True, text=True).stdout
-        if not os.path.exists(out) or open(out).read() != txt:
-            with open(out, "w") as fh:
-                fh.write(txt)
+    for gname, oname in (("gen_attn_w64.py", "attention_w64_asm.inc"), ("gen_gemm_w64.py", "gemm_w64_asm.inc")):
+        gen, out = os.path.join(CSRC, gname), os.path.join(CSRC, oname)
+        if os.path.exists(gen):
+            txt = subprocess.run([sys.executable, gen], check=True, capture_output=True, text=True).stdout
+            if not os.path.exists(out) or open(out).read() != txt:
+                with open(out, "w") as fh:
+                    fh.write(txt)
 
 
 def _sources():

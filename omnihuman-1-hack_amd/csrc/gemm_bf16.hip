@@ -409,6 +409,10 @@ int launch(const omh_gemm_args& a, hipStream_t s) {
 
 }  // namespace
 
+// gemm_w64.hip: 256 x 384 tile, one wave per SIMD, generated k loop
+bool omh_gemm_w64_takes(const omh_gemm_args& a);
+int omh_launch_gemm_w64(const omh_gemm_args& a, hipStream_t stream);
+
 extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
     if (!args || !args->A || !args->B || !args->C) return OMH_E_BADARG;
     const omh_gemm_args& a = *args;
@@ -435,6 +439,21 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
     if (((int64_t)a.M + 128) * a.lda * 2 >= 0x7fffffffLL || ((int64_t)a.N + 128) * a.ldb * 2 >= 0x7fffffffLL)
         return OMH_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
+    {
+        // OMH_GEMM_KERNEL = "w64": the 256 x 384 stream kernel wherever it applies; "8w": never; unset: where it
+        // applies AND fills the chip (>= 256 tiles, last round of tiles at least 3/4 full or >= 4 rounds)
+        const char* gk = getenv("OMH_GEMM_KERNEL");
+        const bool force = gk && gk[0] == 'w', never = gk && gk[0] == '8';
+        if (!never && omh_gemm_w64_takes(a)) {
+            const int64_t tiles = (int64_t)((a.M + 255) / 256) * ((a.N + 383) / 384);
+            const int64_t rounds = (tiles + 255) / 256;
+            if (force || (tiles >= 256 && (rounds >= 4 || tiles * 4 >= rounds * 256 * 3))) {
+                omh_clear_status();
+                omh_launch_gemm_w64(a, s);
+                return omh_launch_status();
+            }
+        }
+    }
     switch (a.epilogue) {
         case OMH_EPI_BF16:      return launch<OMH_EPI_BF16>(a, s);
         case OMH_EPI_F32:       return launch<OMH_EPI_F32>(a, s);

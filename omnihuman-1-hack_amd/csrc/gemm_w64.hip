@@ -1,0 +1,127 @@
+// bf16 GEMM C = A B^T on a 256(m) x 384(n) x 64 workgroup tile: 4 waves, one per SIMD, 384 accumulators per wave, the
+// k loop a generated instruction stream (gen_gemm_w64.py -> gemm_w64_asm.inc; read its header).  Same contract as
+// gemm_bf16.hip's omh_gemm_bf16 for the shapes it takes (see omh_gemm_w64_takes); this file only computes
+// descriptors and per-lane offsets.
+#include "omh_common.h"
+#include "gemm_w64_asm.inc"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int TM = 256, TN = 384, BK = 64;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, int64_t bytes) {
+    const uint32_t n = bytes <= 0 ? 0u : (bytes > 0xffffffffLL ? 0xffffffffu : (uint32_t)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)n, 0x00020000);
+}
+
+enum { K_F32 = 0, K_BF16 = 1, K_GELU = 2, K_RESID = 3 };
+
+__device__ __forceinline__ uint64_t pack2(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
+
+template <int KIND>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int tiles_n) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[163840];     // 2 stages x (X 32 KiB | W 48 KiB)
+    constexpr int ES = (KIND == K_BF16 || KIND == K_GELU) ? 2 : 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int wid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int tm, tn;
+    tile_of(wid, tiles_m, tiles_n, tm, tn, 8);
+    const int m0 = tm * TM, n0 = tn * TN;
+
+    typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+    const int x3 = (r >> 1) & 7;
+    uint32_t xh = (uint32_t)(x3 >> 1);
+    const uint32_t hb = (uint32_t)((h ^ (x3 & 1)) << 4);
+    uint32_t xab = lds0 + (uint32_t)(wm * 16384 + r * 128) + hb;
+    uint32_t wab = lds0 + 32768u + (uint32_t)(wn * 24576 + r * 128) + hb;
+    // LDS-DMA: a 1 KiB piece = 8 rows x 8 slots; lane -> (row lane >> 3, physical slot lane & 7), fetched from the
+    // logical slot (lane & 7) ^ ((row >> 1) & 7) with (row >> 1) & 7 = 4 (piece & 1) + (lane >> 4)
+    const int pr = lane >> 3, ps = lane & 7;
+    uint32_t vox0 = (uint32_t)((pr * p.lda + ((ps ^ (lane >> 4)) * 8)) * 2);
+    uint32_t vox1 = (uint32_t)((pr * p.lda + ((ps ^ ((lane >> 4) + 4)) * 8)) * 2);
+    uint32_t vow0 = (uint32_t)((pr * p.ldb + ((ps ^ (lane >> 4)) * 8)) * 2);
+    uint32_t vow1 = (uint32_t)((pr * p.ldb + ((ps ^ ((lane >> 4) + 4)) * 8)) * 2);
+    // epilogue: after the permlane widening lane (r, h) holds, per tile (i, j) and run p, the 8 columns
+    // 32 i + 16 p + 8 h ... of row 32 j + r of the wave's 128 x 192 patch
+    const int mw = m0 + wm * 128, nw = n0 + wn * 192;
+    uint32_t voc = (uint32_t)(((int64_t)(mw + r) * p.ldc + 8 * h) * ES);
+    uint32_t vrow = (uint32_t)(mw + r), vcl = (uint32_t)(lane * 4), vh = (uint32_t)(h * 32);
+
+    const __amdgpu_buffer_rsrc_t ra = rsrc_of(p.A, (((int64_t)p.M - 1) * p.lda + p.K) * 2);
+    const __amdgpu_buffer_rsrc_t rb = rsrc_of(p.B, (((int64_t)p.N - 1) * p.ldb + p.K) * 2);
+    const __amdgpu_buffer_rsrc_t rc = rsrc_of(p.C, (((int64_t)p.M - 1) * p.ldc + p.N) * ES);
+    const __amdgpu_buffer_rsrc_t rbias = rsrc_of(p.bias, (p.bias && p.bias_mode == OMH_BIAS_N) ? (int64_t)p.N * 4 : 0);
+    const __amdgpu_buffer_rsrc_t rg0 = rsrc_of(p.gate0, (KIND == K_RESID && p.gate0) ? (int64_t)p.N * 4 : 0);
+    const bool has_g1 = KIND == K_RESID && p.gate1 != nullptr;
+    const int grows = has_g1 ? p.gate_rows : 1;
+    const int nb = has_g1 ? (p.M + grows - 1) / grows : 1;
+    const __amdgpu_buffer_rsrc_t rg1 = rsrc_of(p.gate1, has_g1 ? ((int64_t)(nb - 1) * p.gate1_stride + p.N) * 4 : 0);
+    const int blo = has_g1 ? mw / grows : 0;                                // batch index of the patch's first row
+    const uint32_t mb = has_g1 ? (uint32_t)((blo + 1) * grows) : 0xffffffffu;   // rows from here on: batch blo + 1
+
+    const uint64_t p0 = pack2(lds0 + (uint32_t)w * 8192u, lds0 + (uint32_t)w * 12288u);
+    const uint64_t p1 = pack2((uint32_t)(((int64_t)(m0 + w * 64) * p.lda) * 2), (uint32_t)(((int64_t)(n0 + w * 96) * p.ldb) * 2));
+    const uint64_t p2 = pack2((uint32_t)(8 * p.lda * 2), (uint32_t)(8 * p.ldb * 2));
+    const uint64_t p3 = pack2((uint32_t)(p.K / BK), (uint32_t)(nw * ES));
+    const uint64_t p4 = pack2((uint32_t)(32 * p.ldc * ES), (uint32_t)p.N);
+    const uint64_t p5 = pack2(mb, (uint32_t)(((int64_t)blo * p.gate1_stride + nw) * 4));
+    const uint64_t p6 = pack2((uint32_t)(p.gate1_stride * 4), __float_as_uint(p.gate_const));
+    const uint64_t p7 = pack2((uint32_t)(nw * 4), lds0 + (uint32_t)w * 4096u);
+
+#define OMH_GW64_RUN(ASM)                                                                                              \
+    asm volatile(ASM                                                                                                   \
+                 : [xab] "+v"(xab), [wab] "+v"(wab), [xh] "+v"(xh), [vox0] "+v"(vox0), [vox1] "+v"(vox1),              \
+                   [vow0] "+v"(vow0), [vow1] "+v"(vow1), [voc] "+v"(voc), [vrow] "+v"(vrow), [vcl] "+v"(vcl),          \
+                   [vh] "+v"(vh)                                                                                       \
+                 : [ra] "s"(ra), [rb] "s"(rb), [rc] "s"(rc), [rbias] "s"(rbias), [rg0] "s"(rg0), [rg1] "s"(rg1),       \
+                   [p0] "s"(p0), [p1] "s"(p1), [p2] "s"(p2), [p3] "s"(p3), [p4] "s"(p4), [p5] "s"(p5), [p6] "s"(p6),   \
+                   [p7] "s"(p7)                                                                                        \
+                 : OMH_GEMM_W64_CLOBBERS)
+    if (KIND == K_F32) OMH_GW64_RUN(OMH_GEMM_W64_ASM_F32);
+    else if (KIND == K_BF16) OMH_GW64_RUN(OMH_GEMM_W64_ASM_BF16);
+    else if (KIND == K_GELU) OMH_GW64_RUN(OMH_GEMM_W64_ASM_GELU);
+    else OMH_GW64_RUN(OMH_GEMM_W64_ASM_RESID);
+#undef OMH_GW64_RUN
+}
+
+template <int KIND>
+int launch_w64(const omh_gemm_args& a, hipStream_t stream) {
+    const int tiles_m = (a.M + TM - 1) / TM, tiles_n = (a.N + TN - 1) / TN;
+    hipLaunchKernelGGL(gemm_bf16_nt_w64_kernel<KIND>, dim3(tiles_m * tiles_n), dim3(256), 0, stream, a, tiles_m, tiles_n);
+    return 0;
+}
+
+}  // namespace
+
+// The shapes the stream kernel takes (everything else stays on gemm_bf16.hip's kernels): one batch, row-major B,
+// K % 64 == 0, N % 8 == 0, M >= 256, epilogues F32 / BF16 / GELU_BF16 / RESID with an [N] bias or none, RESID's per-row
+// gate changing at most once inside a wave's 128 rows (gate_rows >= 128), 32-bit byte offsets everywhere.
+bool omh_gemm_w64_takes(const omh_gemm_args& a) {
+    const bool bf16_out = a.epilogue == OMH_EPI_BF16 || a.epilogue == OMH_EPI_GELU_BF16;
+    if (!(bf16_out || a.epilogue == OMH_EPI_F32 || a.epilogue == OMH_EPI_RESID)) return false;
+    if (a.bias && a.bias_mode == OMH_BIAS_M) return false;
+    if (a.epilogue == OMH_EPI_RESID && a.gate1 && (a.gate_rows < 128 || a.gate1_stride * 4 >= 0x7fffffffLL ||
+                                                   ((int64_t)(a.M / a.gate_rows) * a.gate1_stride + a.N) * 4 >= 0x7fffffffLL))
+        return false;
+    const int es = bf16_out ? 2 : 4;
+    return a.batch == 1 && !a.b_kmajor && (a.K % BK) == 0 && a.K >= 2 * BK && (a.N % 8) == 0 && a.M >= TM &&
+           (a.ldc % (16 / es)) == 0 && (((uintptr_t)a.C) & 15) == 0 && (a.lda & 7) == 0 && (a.ldb & 7) == 0 &&
+           (((uintptr_t)a.A) & 15) == 0 && (((uintptr_t)a.B) & 15) == 0 &&
+           ((int64_t)a.M + TM) * a.lda * 2 < 0x7fffffffLL && ((int64_t)a.N + TN) * a.ldb * 2 < 0x7fffffffLL &&
+           ((int64_t)a.M + TM) * a.ldc * es < 0xffffffffLL;
+}
+
+int omh_launch_gemm_w64(const omh_gemm_args& a, hipStream_t stream) {
+    switch (a.epilogue) {
+        case OMH_EPI_F32:       return launch_w64<K_F32>(a, stream);
+        case OMH_EPI_BF16:      return launch_w64<K_BF16>(a, stream);
+        case OMH_EPI_GELU_BF16: return launch_w64<K_GELU>(a, stream);
+        default:                return launch_w64<K_RESID>(a, stream);
+    }
+}

@@ -1,39 +1,48 @@
 #!/usr/bin/env python3
-"""Generator of the instruction stream of ``gemm_bf16_nt_w64_kernel`` (gemm_w64.hip): C = A B^T for the large DiT
-GEMMs on a 256(m) x 384(n) x 64 workgroup tile — 4 waves, ONE per SIMD, each owning a 128 x 192 patch with 384
-fp32 accumulators (256 in AGPRs + 128 in arch VGPRs).
+"""Generator of the instruction streams of ``gemm_bf16_nt_w64_kernel<EPI>`` (gemm_w64.hip): C = epi(A B^T) for the
+large DiT GEMMs on a 256(m) x 384(n) x 64 workgroup tile — 4 waves, ONE per SIMD, each owning a 128 x 192 patch with
+384 fp32 accumulators (256 in AGPRs + 128 in arch VGPRs).
 
 Why: the 8-wave 256 x 256 kernel (gemm_bf16.hip) is bound by the L2 -> LDS fill stream (22 B/clk/CU);
 what is left is bytes per flop, and a 256 x 384 tile moves 17 % fewer (153.6 flop per staged byte against 128).  It
 does not fit two waves per SIMD (192 accumulators + fragments per wave > 256), and a compiler-scheduled one-wave
 variant lost to its own LDS-DMA issue stalls in round 1 — hence a generated stream, as for the attention kernel
-(gen_attn_w64.py): fixed register map, exact lgkmcnt waits, the 20 DMA pieces of a k-step spread between the MFMAs.
+(gen_attn_w64.py): fixed register map, exact lgkmcnt waits, the 20 DMA pieces of a k step spread between the MFMAs.
 
     python gen_gemm_w64.py > gemm_w64_asm.inc
 
-Layout (as gemm_bf16.hip): operand tiles [rows][64] bf16 in LDS, 16-byte-slot XOR swizzle ((row >> 1) & 7) applied on
+Main loop (as gemm_bf16.hip): operand tiles [rows][64] bf16 in LDS, 16-byte-slot XOR swizzle ((row >> 1) & 7) applied on
 the LDS-DMA source address and on the ds_read_b128; weights (B, n) in the MFMA A slot, activations (A, m) in the B
 slot, so a lane ends up with 4 consecutive n of one row m.  Two stages of 80 KiB (X tile 32 KiB | W tile 48 KiB).
 
+Epilogues (one stream per kind): "f32" C = acc + bias, "bf16" C = bf16(acc + bias), "gelu" C = bf16(gelu_tanh(acc +
+bias)), "resid" C fp32 += (acc + bias) * gate[m, n] (model.py:296,313,328).  A lane's four register quads of an
+accumulator tile are widened to two runs of 8 consecutive n with v_permlane32_swap (cdna_hip_programming.md T21), so
+every global access is 16 / 32 contiguous bytes per lane; the per-column vectors (bias, gate, bias*gate) are built
+once per wave in LDS (free after the k loop) and read back as ds_read_b128; columns >= N are masked with EXEC, rows
+>= M are dropped by the buffer descriptors.
+
 Register map: a[0:255] accumulator tiles 0..15, v[128:255] tiles 16..23 (tile = 4 i + j, i = n tile, j = m tile);
-v[32:71] / v[72:111] fragment buffers (6 W fragments + 4 X fragments of one 16-wide k group each);
-v[12:19] X fragment addresses [stage][kk], v[20:27] W fragment addresses; s80.. scratch.
+k loop: v[32:71] / v[72:111] fragment buffers, v[12:19] X fragment addresses [stage][kk], v[20:27] W addresses;
+epilogue: v[32:47] tile values, v[48:79] column vectors, v[80:127] prefetched C rows, v12..v31 misc;
+s[60:75] unpacked scalar arguments, s[80:91] scratch.
 """
 import sys
 
 NI, NJ = 6, 4                   # n tiles (weights) x m tiles (activations) per wave
 STAGE = 81920
 WOFF = 32768                    # W tile behind the X tile inside a stage
+KINDS = ("f32", "bf16", "gelu", "resid")
+
+# fixed scalar registers (unpacked from the 64-bit operand pairs in the prologue)
+S_LDX, S_LDW, S_SXB, S_SWB, S_SXS, S_SWS, S_NK, S_SCB = "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67"
+S_SCJ, S_N, S_MB, S_G1LO, S_G1ST, S_GC, S_COL0, S_REG = "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75"
+S_COLN = "s89"                  # first column of the wave (elements) = S_COL0 / 4
 
 
 def acc(i, j):
     t = i * NJ + j
     return (f"a[{t * 16}:{t * 16 + 15}]") if t < 16 else (f"v[{128 + (t - 16) * 16}:{128 + (t - 16) * 16 + 15}]")
-
-
-def acc_reg(i, j, r):
-    t = i * NJ + j
-    return f"a{t * 16 + r}" if t < 16 else f"v{128 + (t - 16) * 16 + r}"
 
 
 def wfrag(buf, i):   return 32 + buf * 40 + 4 * i
@@ -44,14 +53,14 @@ def vr(lo, n=1):     return f"v{lo}" if n == 1 else f"v[{lo}:{lo + n - 1}]"
 
 
 class Emit:
-    def __init__(self):
-        self.lines = []
+    def __init__(self, tag):
+        self.lines, self.tag = [], tag
 
     def __call__(self, s):
         self.lines.append(s)
 
     def lab(self, name):
-        return f".Lgw64_{name}_%="
+        return f".Lgw64{self.tag}_{name}_%="
 
     def label(self, name):
         self.lines.append(f"{name}:")
@@ -81,7 +90,6 @@ def linearize(e, ops, pending):
 
 
 def frag_reads(stage, kk, buf):
-    """10 ds_read_b128 of one 16-wide k group: 6 W fragments, 4 X fragments."""
     out = []
     for i in range(NI):
         out.append(("r", f"W{buf}.{i}", f"ds_read_b128 {vr(wfrag(buf, i), 4)}, {vr(WA(stage, kk))} offset:{i * 4096}"))
@@ -91,8 +99,6 @@ def frag_reads(stage, kk, buf):
 
 
 def group_mfmas(buf, first=False):
-    """24 MFMAs of one k group, ordered so that consecutive MFMAs never share an accumulator and the W fragments
-    (read first) are needed first."""
     out = []
     for i in range(NI):
         for j in range(NJ):
@@ -104,32 +110,26 @@ def group_mfmas(buf, first=False):
 
 def dma_piece(stage, operand, q):
     """One 1 KiB LDS-DMA piece.  X: wave w fetches rows w*64 + 8 q (q < 8); W: rows w*96 + 8 q (q < 12).
-    s81 / s82: running source offsets of the X / W piece (advanced by the piece stride), s83: LDS piece cursor."""
+    s81 / s82: running source offsets of the X / W piece; s80: k byte offset of the tile being fetched."""
     base = stage * STAGE + (WOFF if operand == "w" else 0)
     vo = ("%[vow1]" if q & 1 else "%[vow0]") if operand == "w" else ("%[vox1]" if q & 1 else "%[vox0]")
     rs = "%[rb]" if operand == "w" else "%[ra]"
     sreg = "s82" if operand == "w" else "s81"
-    lds = "%[ldw]" if operand == "w" else "%[ldx]"
+    lds = S_LDW if operand == "w" else S_LDX
     out = [f"s_add_u32 m0, {lds}, {base + q * 1024}"]
     if q == 0:
-        out.append(f"s_add_u32 {sreg}, {'%[swb]' if operand == 'w' else '%[sxb]'}, s80")     # tile base + k offset
+        out.append(f"s_add_u32 {sreg}, {S_SWB if operand == 'w' else S_SXB}, s80")
     else:
-        out.append(f"s_add_u32 {sreg}, {sreg}, {'%[sws]' if operand == 'w' else '%[sxs]'}")
+        out.append(f"s_add_u32 {sreg}, {sreg}, {S_SWS if operand == 'w' else S_SXS}")
     out.append(f"buffer_load_dwordx4 {vo}, {rs}, {sreg} offen lds")
     return [("x", ln) for ln in out]
 
 
 def all_pieces(stage):
-    out = []
-    for q in range(8):
-        out.append(dma_piece(stage, "x", q))
-    for q in range(12):
-        out.append(dma_piece(stage, "w", q))
-    return out                                              # 20 lists of 3 lines
+    return [dma_piece(stage, "x", q) for q in range(8)] + [dma_piece(stage, "w", q) for q in range(12)]
 
 
 def spread_after(mfmas, extras, start=0, end=None):
-    """Insert the op lists `extras` (each a list of ops) after MFMAs start..end-1, evenly."""
     end = len(mfmas) if end is None else end
     n = end - start
     slots = [[] for _ in mfmas]
@@ -142,23 +142,37 @@ def spread_after(mfmas, extras, start=0, end=None):
     return ops
 
 
-def generate():
-    e = Emit()
-    # ---------------- prologue: fragment addresses
+def with_dma_tail(ops, dm):
+    """Insert the DMA op lists `dm` after every other MFMA from the 13th on."""
+    out, idx, cnt = [], 0, 0
+    for op in ops:
+        out.append(op)
+        if op[0] == "m":
+            cnt += 1
+            if cnt > 12 and idx < len(dm) and (cnt - 12) % 2 == 1:
+                out.extend(dm[idx]); idx += 1
+    while idx < len(dm):
+        out.extend(dm[idx]); idx += 1
+    return out
+
+
+def main_loop(e):
+    # ---------------- prologue: unpack scalars, fragment addresses
+    for k, pair in enumerate(("p0", "p1", "p2", "p3", "p4", "p5", "p6", "p7")):
+        e(f"s_mov_b64 s[{60 + 2 * k}:{61 + 2 * k}], %[{pair}]")
     for kk in range(4):
         e(f"v_xor_b32 v112, {kk}, %[xh]")
         e(f"v_lshl_add_u32 {vr(XA(0, kk))}, v112, 5, %[xab]")
         e(f"v_lshl_add_u32 {vr(WA(0, kk))}, v112, 5, %[wab]")
         e(f"v_add_u32 {vr(XA(1, kk))}, {STAGE}, {vr(XA(0, kk))}")
         e(f"v_add_u32 {vr(WA(1, kk))}, {STAGE}, {vr(WA(0, kk))}")
-    # tile 0 -> stage 0 (all 20 pieces), tile 1 -> stage 1 (first 8 pieces = the X tile; the loop issues the rest)
-    e("s_mov_b32 s80, 0")                                       # k byte offset of the tile being fetched
+    # tile 0 -> stage 0 (all 20 pieces), tile 1 -> stage 1 (the 8 X pieces; the loop issues the 12 W pieces)
+    e("s_mov_b32 s80, 0")
     for ops in all_pieces(0):
         for op in ops:
             e(op[1])
     e("s_mov_b32 s80, 128")
-    p1 = all_pieces(1)
-    for ops in p1[:8]:
+    for ops in all_pieces(1)[:8]:
         for op in ops:
             e(op[1])
     e("s_waitcnt vmcnt(8)")                                     # tile 0 has landed
@@ -168,40 +182,23 @@ def generate():
     LOOP_PENDING = list(pend)
     LOOP, DONE = e.lab("loop"), e.lab("done")
 
-    def body(s, first_step_c_zero=False):
+    def body(s, first=False):
         """One k step on stage s.  Groups 0..2: MFMAs || reads of the next group || the 12 W pieces of tile kt+1
         (into stage s^1).  Then everything in flight is waited for, barrier, and group 3 runs || the 8 X pieces of
         tile kt+2 (into stage s, free now) || reads of group 0 of stage s^1."""
         pend = LOOP_PENDING
-        rest = all_pieces(s ^ 1)[8:]                            # W pieces of tile kt+1
+        rest = all_pieces(s ^ 1)[8:]
         for kk in range(3):
-            mf = group_mfmas(kk & 1, first=False)
+            mf = group_mfmas(kk & 1, first=(first and kk == 0))
             reads = [[r] for r in frag_reads(s, kk + 1, (kk + 1) & 1)]
-            extra = list(reads)
-            ops = spread_after(mf, extra, 0, 14)
+            ops = spread_after(mf, reads, 0, 14)
             if kk < 2:
-                ops2 = []
-                dm = rest[kk * 6:(kk + 1) * 6]
-                # DMA pieces behind the reads: MFMAs 14..23
-                idx = 0
-                cnt = 0
-                for op in ops:
-                    ops2.append(op)
-                    if op[0] == "m":
-                        cnt += 1
-                        if cnt > 12 and idx < len(dm) and (cnt - 12) % 2 == 1:
-                            ops2.extend(dm[idx]); idx += 1
-                while idx < len(dm):
-                    ops2.extend(dm[idx]); idx += 1
-                ops = ops2
+                ops = with_dma_tail(ops, rest[kk * 6:(kk + 1) * 6])
             pend = linearize(e, ops, pend)
         e("s_waitcnt vmcnt(0)")
         e("s_waitcnt lgkmcnt(0)")
-        pend = []
         e("s_barrier")
-        e("s_add_u32 s80, s80, 128")                            # next tile's k offset (tile kt+2)
-        mf = group_mfmas(1)
-        # group 3's fragments (buffer 1) were read during group 2 and are complete (lgkmcnt(0) above)
+        e("s_add_u32 s80, s80, 128")                            # k offset of tile kt+2
         xp = all_pieces(s)[:8]
         reads = [[r] for r in frag_reads(s ^ 1, 0, 0)]
         extras = []
@@ -210,52 +207,13 @@ def generate():
                 extras.append(reads[k])
             if k < len(xp):
                 extras.append(xp[k])
-        ops = spread_after(mf, extras, 0, 22)
-        pend = linearize(e, ops, pend)
+        pend = linearize(e, spread_after(group_mfmas(1), extras, 0, 22), [])
         assert pend == LOOP_PENDING, (pend, LOOP_PENDING)
         e("s_add_u32 s84, s84, 1")
-        e("s_cmp_eq_u32 s84, %[nk]")
+        e(f"s_cmp_eq_u32 s84, {S_NK}")
         e(f"s_cbranch_scc1 {DONE}")
 
-    # first k step: accumulators start from zero (C = 0 on the first MFMA of each tile) — emit a dedicated copy
-    def first_body():
-        pend = LOOP_PENDING
-        rest = all_pieces(1)[8:]
-        for kk in range(3):
-            mf = group_mfmas(kk & 1, first=(kk == 0))
-            reads = [[r] for r in frag_reads(0, kk + 1, (kk + 1) & 1)]
-            ops = spread_after(mf, reads, 0, 14)
-            if kk < 2:
-                dm = rest[kk * 6:(kk + 1) * 6]
-                ops2, idx, cnt = [], 0, 0
-                for op in ops:
-                    ops2.append(op)
-                    if op[0] == "m":
-                        cnt += 1
-                        if cnt > 12 and idx < len(dm) and (cnt - 12) % 2 == 1:
-                            ops2.extend(dm[idx]); idx += 1
-                while idx < len(dm):
-                    ops2.extend(dm[idx]); idx += 1
-                ops = ops2
-            pend = linearize(e, ops, pend)
-        e("s_waitcnt vmcnt(0)")
-        e("s_waitcnt lgkmcnt(0)")
-        e("s_barrier")
-        e("s_add_u32 s80, s80, 128")
-        xp = all_pieces(0)[:8]
-        reads = [[r] for r in frag_reads(1, 0, 0)]
-        extras = []
-        for k in range(8):
-            extras.append(reads[k] if k < len(reads) else [])
-            extras.append(xp[k])
-        extras += [r for r in reads[8:]]
-        pend = linearize(e, spread_after(group_mfmas(1), extras, 0, 22), [])
-        assert pend == LOOP_PENDING
-        e("s_add_u32 s84, s84, 1")
-        e("s_cmp_eq_u32 s84, %[nk]")
-        e(f"s_cbranch_scc1 {DONE}")
-
-    first_body()
+    body(0, first=True)
     e.label(LOOP)
     body(1)
     body(0)
@@ -263,40 +221,186 @@ def generate():
     e.label(DONE)
     e("s_waitcnt vmcnt(0)")
     e("s_waitcnt lgkmcnt(0)")
-    e("s_nop 7")
-    e("s_nop 7")
-    # ---------------- epilogue (fp32 C, no bias): lane holds 4 consecutive n of row m per register quad
-    # voffset %[voc] = row (m tile 0) * ldc * 4 + 16 h; soffset = column base + j * 32 rows; imm = (32 i + 8 q) * 4
-    for j in range(NJ):
-        if j == 0:
-            e("s_mov_b32 s85, %[scb]")
-        else:
-            e("s_add_u32 s85, s85, %[scj]")
-        for i in range(NI):
-            for q in range(4):
-                t = i * NJ + j
-                if t < 16:
-                    src = f"a[{t * 16 + 4 * q}:{t * 16 + 4 * q + 3}]"
-                else:
-                    b = 128 + (t - 16) * 16 + 4 * q
-                    src = f"v[{b}:{b + 3}]"
-                e(f"buffer_store_dwordx4 {src}, %[voc], %[rc], s85 offen offset:{i * 128 + q * 32}")
+    e("s_barrier")                                              # every wave is done with the LDS stages
+    for _ in range(3):
+        e("s_nop 7")                                            # last MFMA results readable by VALU
+
+
+# ---------------------------------------------------------------- epilogues
+T = 32                       # v[32:47] tile values
+GV, BV = 48, 64              # v[48:63] gate runs (GELU: temporaries), v[64:79] bias runs
+CO = 80                      # v[80:127] ring of three prefetched C tiles (resid)
+VSEL, VCOLT = 12, 13         # per-row-block gate vector address, column temporary
+KC = 14                      # v[14:19] GELU constant pairs
+GE = 20                      # v[20:27] GELU temporaries
+NTILES = NI * NJ
+# operand registers of the k loop, dead after it, reused
+VLW, VLR, VCOL = "%[xab]", "%[wab]", "%[xh]"
+
+
+def column_vectors(e, kind):
+    """Per wave: the vectors of its 192 columns in a wave-private LDS region (free after the k loop's last barrier):
+    +0 gate for rows below the batch boundary, +768 bias, +1536 gate for rows from the boundary on.  Lane l handles
+    columns l, l + 64, l + 128; out-of-range columns / absent vectors read 0 through the descriptors."""
+    e(f"v_add_u32 {VLW}, {S_REG}, %[vcl]")                       # region + 4 lane
+    e(f"v_add_u32 {VLR}, {S_REG}, %[vh]")                        # region + 32 h
+    e(f"s_lshr_b32 {S_COLN}, {S_COL0}, 2")
+    e(f"v_lshrrev_b32 {VCOL}, 2, %[vh]")
+    e(f"v_add_u32 {VCOL}, {S_COLN}, {VCOL}")                     # first column of the wave + 8 h
+    for t in range(3):
+        e(f"buffer_load_dword v{48 + t}, %[vcl], %[rbias], {S_COL0} offen offset:{t * 256}")        # bias[n]
+        if kind == "resid":
+            e(f"buffer_load_dword v{52 + t}, %[vcl], %[rg0], {S_COL0} offen offset:{t * 256}")      # gate0[n]
+            e(f"buffer_load_dword v{56 + t}, %[vcl], %[rg1], {S_G1LO} offen offset:{t * 256}")      # gate1[b][n]
+    if kind == "resid":
+        e(f"s_add_u32 s85, {S_G1LO}, {S_G1ST}")
+        for t in range(3):
+            e(f"buffer_load_dword v{60 + t}, %[vcl], %[rg1], s85 offen offset:{t * 256}")           # gate1[b + 1][n]
     e("s_waitcnt vmcnt(0)")
+    for t in range(3):
+        e(f"ds_write_b32 {VLW}, v{48 + t} offset:{768 + t * 256}")
+        if kind == "resid":
+            e(f"v_add_f32 v{52 + t}, {S_GC}, v{52 + t}")                       # gate_const + gate0 (gemm_bf16.hip order)
+            e(f"v_add_f32 v{56 + t}, v{52 + t}, v{56 + t}")
+            e(f"v_add_f32 v{60 + t}, v{52 + t}, v{60 + t}")
+            e(f"ds_write_b32 {VLW}, v{56 + t} offset:{t * 256}")
+            e(f"ds_write_b32 {VLW}, v{60 + t} offset:{1536 + t * 256}")
+    e("s_waitcnt lgkmcnt(0)")
+
+
+def gelu_pairs(e, base):
+    """gelu_tanh (omh_common.h, same operation order => same bits) on v[base:base+7] in place, two elements per packed
+    instruction: x rcp(1 + 2^t), t = (k x) fma(0.044715, x^2, 1).  v[14:15] = 0.044715, v[16:17] = 1, v[18:19] = k."""
+    for p in range(4):
+        x, t, u = base + 2 * p, GE + 2 * p, GV + 2 * p
+        e(f"v_pk_mul_f32 {vr(t, 2)}, {vr(x, 2)}, {vr(x, 2)}")
+        e(f"v_pk_mul_f32 {vr(u, 2)}, {vr(KC + 4, 2)}, {vr(x, 2)}")
+        e(f"v_pk_fma_f32 {vr(t, 2)}, {vr(KC, 2)}, {vr(t, 2)}, {vr(KC + 2, 2)}")
+        e(f"v_pk_mul_f32 {vr(t, 2)}, {vr(u, 2)}, {vr(t, 2)}")
+    for p in range(4):
+        t = GE + 2 * p
+        e(f"v_exp_f32 v{t}, v{t}")
+        e(f"v_exp_f32 v{t + 1}, v{t + 1}")
+    for p in range(4):
+        t = GE + 2 * p
+        e(f"v_pk_add_f32 {vr(t, 2)}, {vr(KC + 2, 2)}, {vr(t, 2)}")
+    for p in range(4):
+        t = GE + 2 * p
+        e(f"v_rcp_f32 v{t}, v{t}")
+        e(f"v_rcp_f32 v{t + 1}, v{t + 1}")
+    e("s_nop 0")
+    for p in range(4):
+        x, t = base + 2 * p, GE + 2 * p
+        e(f"v_pk_mul_f32 {vr(x, 2)}, {vr(x, 2)}, {vr(t, 2)}")
+
+
+def c_loads(e, n, es):
+    """The four 16-byte pieces per lane of tile n's C values -> ring slot n % 3; s88 = soffset of tile n's row block."""
+    i = n % NI
+    for p in range(2):
+        for q in range(2):
+            e(f"buffer_load_dwordx4 {vr(CO + (n % 3) * 16 + p * 8 + q * 4, 4)}, %[voc], %[rc], s88 offen "
+              f"offset:{(i * 32 + 16 * p) * es + q * 16}")
+
+
+def epilogue(e, kind):
+    out_bf16 = kind in ("bf16", "gelu")
+    resid = kind == "resid"
+    es = 2 if out_bf16 else 4
+    column_vectors(e, kind)
+    if kind == "gelu":
+        for r_, val in ((KC, "0x3d372713"), (KC + 1, "0x3d372713"), (KC + 2, "1.0"), (KC + 3, "1.0"),
+                        (KC + 4, "0xc0135761"), (KC + 5, "0xc0135761")):
+            e(f"v_mov_b32 v{r_}, {val}")
+    # tiles in the order n = 6 j + i (row block j, column tile i)
+    e(f"s_mov_b32 s85, {S_SCB}")                                 # store soffset: row block of the tile being written
+    e(f"s_mov_b32 s88, {S_SCB}")                                 # load soffset: row block of the tile being fetched
+    if resid:
+        c_loads(e, 0, es)
+        c_loads(e, 1, es)
+    for n in range(NTILES):
+        j, i = divmod(n, NI)
+        t = i * NJ + j
+        if i == 0:
+            if j:
+                e(f"s_add_u32 s85, s85, {S_SCJ}")
+                e("v_add_u32 %[vrow], 32, %[vrow]")
+            if resid:
+                e(f"v_cmp_le_u32 vcc, {S_MB}, %[vrow]")
+                e(f"v_add_u32 v{VCOLT}, 1536, {VLR}")
+                e(f"v_cndmask_b32 v{VSEL}, {VLR}, v{VCOLT}, vcc")
+        if resid and n + 2 < NTILES:
+            if (n + 2) % NI == 0:
+                e(f"s_add_u32 s88, s88, {S_SCJ}")
+            c_loads(e, n + 2, es)
+        for p in range(2):
+            col = (i * 32 + 16 * p) * 4
+            if resid:
+                e(f"ds_read_b128 {vr(GV + p * 8, 4)}, v{VSEL} offset:{col}")
+                e(f"ds_read_b128 {vr(GV + p * 8 + 4, 4)}, v{VSEL} offset:{col + 16}")
+            e(f"ds_read_b128 {vr(BV + p * 8, 4)}, {VLR} offset:{768 + col}")
+            e(f"ds_read_b128 {vr(BV + p * 8 + 4, 4)}, {VLR} offset:{768 + col + 16}")
+        for r_ in range(16):
+            if t < 16:
+                e(f"v_accvgpr_read_b32 v{T + r_}, a{t * 16 + r_}")
+            else:
+                e(f"v_mov_b32 v{T + r_}, v{128 + (t - 16) * 16 + r_}")
+        e("s_nop 1")
+        for q0 in (0, 2):                                        # quads (0,1), (2,3) -> two runs of 8 consecutive n
+            for r_ in range(4):
+                e(f"v_permlane32_swap_b32 v{T + 4 * q0 + r_}, v{T + 4 * (q0 + 1) + r_}")
+        e("s_waitcnt lgkmcnt(0)")
+        if resid:
+            # in issue order behind tile n's loads: S(n-2) L(n+1) S(n-1) L(n+2), four instructions each
+            behind = 4 * ((n >= 2) + (n + 1 < NTILES) + (n >= 1) + (n + 2 < NTILES))
+            e(f"s_waitcnt vmcnt({behind})")
+        for p in range(2):
+            v0 = T + 8 * p
+            e(f"v_add_u32 v{VCOLT}, {i * 32 + 16 * p}, {VCOL}")
+            e(f"v_cmp_gt_u32 vcc, {S_N}, v{VCOLT}")
+            e("s_and_saveexec_b64 s[86:87], vcc")
+            for r_ in range(0, 8, 2):
+                e(f"v_pk_add_f32 {vr(v0 + r_, 2)}, {vr(v0 + r_, 2)}, {vr(BV + p * 8 + r_, 2)}")
+            if resid:
+                for r_ in range(0, 8, 2):
+                    e(f"v_pk_mul_f32 {vr(v0 + r_, 2)}, {vr(v0 + r_, 2)}, {vr(GV + p * 8 + r_, 2)}")
+                for r_ in range(0, 8, 2):
+                    e(f"v_pk_add_f32 {vr(v0 + r_, 2)}, {vr(CO + (n % 3) * 16 + p * 8 + r_, 2)}, {vr(v0 + r_, 2)}")
+            if kind == "gelu":
+                gelu_pairs(e, v0)
+            off = (i * 32 + 16 * p) * es
+            if out_bf16:
+                for r_ in range(4):
+                    e(f"v_cvt_pk_bf16_f32 v{v0 + r_}, v{v0 + 2 * r_}, v{v0 + 2 * r_ + 1}")
+                e(f"buffer_store_dwordx4 {vr(v0, 4)}, %[voc], %[rc], s85 offen offset:{off}")
+            else:
+                e(f"buffer_store_dwordx4 {vr(v0, 4)}, %[voc], %[rc], s85 offen offset:{off}")
+                e(f"buffer_store_dwordx4 {vr(v0 + 4, 4)}, %[voc], %[rc], s85 offen offset:{off + 16}")
+            e("s_nop 1")
+            e("s_mov_b64 exec, s[86:87]")
+    e("s_waitcnt vmcnt(0)")
+
+
+def generate(kind):
+    e = Emit(kind)
+    main_loop(e)
+    epilogue(e, kind)
     return e
 
 
 def main():
-    e = generate()
     print("// GENERATED by gen_gemm_w64.py — do not edit; edit the generator.")
-    print("#define OMH_GEMM_W64_ASM \\")
-    print(" \\\n".join(e.text().split("\n")))
-    print("")
-    clob = ['"memory"', '"vcc"', '"scc"'] + [f'"s{i}"' for i in range(80, 86)] + [f'"v{i}"' for i in range(12, 256)] + \
+    for kind in KINDS:
+        e = generate(kind)
+        print(f"#define OMH_GEMM_W64_ASM_{kind.upper()} \\")
+        print(" \\\n".join(e.text().split("\n")))
+        print("")
+        print(f"// {kind}: {len(e.lines)} lines, {sum('v_mfma' in ln for ln in e.lines)} MFMA")
+    clob = ['"memory"', '"vcc"', '"scc"'] + [f'"s{i}"' for i in range(60, 92)] + [f'"v{i}"' for i in range(12, 256)] + \
            [f'"a{i}"' for i in range(256)]
     print("#define OMH_GEMM_W64_CLOBBERS \\")
     rows = [", ".join(clob[i:i + 12]) for i in range(0, len(clob), 12)]
     print("    " + ", \\\n    ".join(rows))
-    print(f"// {len(e.lines)} lines, {sum('v_mfma' in ln for ln in e.lines)} MFMA")
 
 
 if __name__ == "__main__":
