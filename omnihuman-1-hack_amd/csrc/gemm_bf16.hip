@@ -443,7 +443,7 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
         // OMH_GEMM_KERNEL = "w64": the 256 x 384 stream kernel wherever it applies; "8w": never; unset: where it
         // applies AND fills the chip (>= 256 tiles, last round of tiles at least 3/4 full or >= 4 rounds)
         const char* gk = getenv("OMH_GEMM_KERNEL");
-        const bool force = gk && gk[0] == 'w', never = gk && gk[0] == '8';
+        const bool force = gk && gk[0] == 'w', never = (gk && gk[0] == '8') || (!force && getenv("OMH_GEMM_TILE"));
         if (!never && omh_gemm_w64_takes(a)) {
             const int64_t tiles = (int64_t)((a.M + 255) / 256) * ((a.N + 383) / 384);
             const int64_t rounds = (tiles + 255) / 256;

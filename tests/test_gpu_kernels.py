@@ -73,6 +73,58 @@ def test_gemm_resid_gate_and_batch(ops, tile, monkeypatch):
     assert float(vt[:, :, S:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("M,N,K,gate_rows", [(256, 384, 128, 256), (1000, 776, 192, 300), (2000, 1536, 256, 500),
+                                             (4100, 1160, 1536, 2050), (32760, 1536, 128, 16380)])
+def test_gemm_w64_stream_kernel(ops, M, N, K, gate_rows, monkeypatch):
+    """The 256 x 384 one-wave-per-SIMD stream kernel (gemm_w64.hip): each epilogue against fp32 torch AND bit for bit
+    against the 8-wave kernel (same k order, same epilogue arithmetic) — ragged M and N, the N % 384 tail masked by
+    EXEC, a strided gate table whose batch boundary falls inside a wave's 128 rows."""
+    torch.manual_seed(M + N)
+    a = _bf(torch.randn(M, K, device="cuda"))
+    w = _bf(torch.randn(N, K, device="cuda") / math.sqrt(K))
+    bias = torch.randn(N, device="cuda")
+    nb = (M + gate_rows - 1) // gate_rows
+    mod = torch.randn(6, N, device="cuda")
+    e0 = torch.randn(nb, 6, N, device="cuda")
+    x0 = torch.randn(M, N, device="cuda")
+    ref = a.float() @ w.float().t() + bias
+
+    def run(kernel):
+        monkeypatch.setenv("OMH_GEMM_KERNEL", kernel)
+        x = x0.clone()
+        ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(x), M, N, K, K, K, N, ops.EPI_RESID, bias=ops.ptr(bias),
+                     bias_mode=ops.BIAS_N, gate0=ops.ptr(mod, 2 * N), gate1=ops.ptr(e0, 2 * N), gate1_stride=6 * N,
+                     gate_rows=gate_rows, gate_const=0.5)
+        x1 = x0.clone()
+        ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(x1), M, N, K, K, K, N, ops.EPI_RESID, gate_const=1.0)
+        return (ops.gemm(a, w, bias=bias, epilogue=ops.EPI_F32), ops.gemm(a, w, epilogue=ops.EPI_F32),
+                ops.gemm(a, w, bias=bias, epilogue=ops.EPI_BF16), ops.gemm(a, w, bias=bias, epilogue=ops.EPI_GELU_BF16), x, x1)
+
+    got, old = run("w64"), run("8w")
+    for g, o in zip(got, old):
+        assert torch.equal(g, o)
+    assert rel_rms(got[0], ref) < 2e-5
+    assert rel_rms(got[1], ref - bias) < 2e-5
+    assert rel_rms(got[2].float(), ref) < 4e-3
+    assert rel_rms(got[3].float(), torch.nn.functional.gelu(ref, approximate="tanh")) < 5e-3
+    gate = (0.5 + mod[2][None] + e0[:, 2]).repeat_interleave(gate_rows, 0)[:M]
+    assert rel_rms(got[4], x0 + ref * gate) < 1e-5
+    assert rel_rms(got[5], x0 + ref - bias) < 1e-5
+
+
+def test_gemm_w64_is_the_default_on_the_large_shapes(ops, monkeypatch):
+    """Unset OMH_GEMM_KERNEL: >= 256 tiles of 256 x 384 -> the stream kernel; its output is that of the forced call and
+    (the kernels agree bit for bit) of the 8-wave kernel."""
+    monkeypatch.delenv("OMH_GEMM_KERNEL", raising=False)
+    monkeypatch.delenv("OMH_GEMM_TILE", raising=False)
+    M, N, K = 32760, 1536, 256
+    a = _bf(torch.randn(M, K, device="cuda"))
+    w = _bf(torch.randn(N, K, device="cuda") / math.sqrt(K))
+    d = ops.gemm(a, w)
+    monkeypatch.setenv("OMH_GEMM_KERNEL", "8w")
+    assert torch.equal(d, ops.gemm(a, w))
+
+
 def _attn_ref(q, k, v, k_lens, scale):
     B, Lq, H, D = q.shape
     out = torch.zeros(B, Lq, H, D, device=q.device)
