@@ -17,8 +17,30 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, int64_t
 
 enum { K_F32 = 0, K_BF16 = 1, K_GELU = 2, K_RESID = 3 };
 
-__device__ __forceinline__ uint64_t pack2(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
+// two wave-uniform 32-bit scalars in one SGPR pair (inline asm takes at most 30 operands)
+__device__ __forceinline__ uint64_t pack2(uint32_t lo, uint32_t hi) {
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)lo) |
+           ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32);
+}
 
+struct W64Tile { uint32_t sxb, swb; int m0, n0; };
+
+// Tile `idx` of this launch: XCD-contiguous work order (xcd_remap) walking 8 m-tiles x all n-tiles (tile_of), and the
+// byte offsets of this WAVE's first X / W rows (wave w stages X rows 64 w .. and W rows 96 w ..).
+__device__ __forceinline__ W64Tile w64_tile(const omh_gemm_args& p, int idx, int tiles_m, int tiles_n, int w) {
+    const int wid = xcd_remap(idx, tiles_m * tiles_n);
+    int tm, tn;
+    tile_of(wid, tiles_m, tiles_n, tm, tn, 8);
+    W64Tile t;
+    t.m0 = tm * TM; t.n0 = tn * TN;
+    t.sxb = (uint32_t)(((int64_t)(t.m0 + w * 64) * p.lda) * 2);
+    t.swb = (uint32_t)(((int64_t)(t.n0 + w * 96) * p.ldb) * 2);
+    return t;
+}
+
+// Persistent: workgroup b computes tiles b, b + gridDim.x, ...  The prologue DMA of tile t + 1 is issued from inside
+// tile t's stream, just before its epilogue (the LDS stages are free then), so it lands under the epilogue and the
+// epilogue's stores drain under tile t + 1's k loop.
 template <int KIND>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int tiles_n) {
@@ -28,30 +50,26 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int wid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    int tm, tn;
-    tile_of(wid, tiles_m, tiles_n, tm, tn, 8);
-    const int m0 = tm * TM, n0 = tn * TN;
+    const int total = tiles_m * tiles_n;
 
     typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
     const int x3 = (r >> 1) & 7;
-    uint32_t xh = (uint32_t)(x3 >> 1);
+    const uint32_t xh = (uint32_t)(x3 >> 1);
     const uint32_t hb = (uint32_t)((h ^ (x3 & 1)) << 4);
-    uint32_t xab = lds0 + (uint32_t)(wm * 16384 + r * 128) + hb;
-    uint32_t wab = lds0 + 32768u + (uint32_t)(wn * 24576 + r * 128) + hb;
+    const uint32_t xab = lds0 + (uint32_t)(wm * 16384 + r * 128) + hb;
+    const uint32_t wab = lds0 + 32768u + (uint32_t)(wn * 24576 + r * 128) + hb;
     // LDS-DMA: a 1 KiB piece = 8 rows x 8 slots; lane -> (row lane >> 3, physical slot lane & 7), fetched from the
     // logical slot (lane & 7) ^ ((row >> 1) & 7) with (row >> 1) & 7 = 4 (piece & 1) + (lane >> 4)
     const int pr = lane >> 3, ps = lane & 7;
-    uint32_t vox0 = (uint32_t)((pr * p.lda + ((ps ^ (lane >> 4)) * 8)) * 2);
-    uint32_t vox1 = (uint32_t)((pr * p.lda + ((ps ^ ((lane >> 4) + 4)) * 8)) * 2);
-    uint32_t vow0 = (uint32_t)((pr * p.ldb + ((ps ^ (lane >> 4)) * 8)) * 2);
-    uint32_t vow1 = (uint32_t)((pr * p.ldb + ((ps ^ ((lane >> 4) + 4)) * 8)) * 2);
+    const uint32_t vox0 = (uint32_t)((pr * p.lda + ((ps ^ (lane >> 4)) * 8)) * 2);
+    const uint32_t vox1 = (uint32_t)((pr * p.lda + ((ps ^ ((lane >> 4) + 4)) * 8)) * 2);
+    const uint32_t vow0 = (uint32_t)((pr * p.ldb + ((ps ^ (lane >> 4)) * 8)) * 2);
+    const uint32_t vow1 = (uint32_t)((pr * p.ldb + ((ps ^ ((lane >> 4) + 4)) * 8)) * 2);
     // epilogue: after the permlane widening lane (r, h) holds, per tile (i, j) and run p, the 8 columns
-    // 32 i + 16 p + 8 h ... of row 32 j + r of the wave's 128 x 192 patch
-    const int mw = m0 + wm * 128, nw = n0 + wn * 192;
-    uint32_t voc = (uint32_t)(((int64_t)(mw + r) * p.ldc + 8 * h) * ES);
-    uint32_t vrow = (uint32_t)(mw + r), vcl = (uint32_t)(lane * 4), vh = (uint32_t)(h * 32);
+    // 32 i + 16 p + 8 h ... of row 32 j + r of the wave's 128 x 192 patch; the tile's origin goes in the soffset
+    const uint32_t voc = (uint32_t)(((int64_t)(wm * 128 + r) * p.ldc + 8 * h) * ES);
+    const uint32_t vlane = (uint32_t)lane;
 
     const __amdgpu_buffer_rsrc_t ra = rsrc_of(p.A, (((int64_t)p.M - 1) * p.lda + p.K) * 2);
     const __amdgpu_buffer_rsrc_t rb = rsrc_of(p.B, (((int64_t)p.N - 1) * p.ldb + p.K) * 2);
@@ -62,38 +80,72 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
     const int grows = has_g1 ? p.gate_rows : 1;
     const int nb = has_g1 ? (p.M + grows - 1) / grows : 1;
     const __amdgpu_buffer_rsrc_t rg1 = rsrc_of(p.gate1, has_g1 ? ((int64_t)(nb - 1) * p.gate1_stride + p.N) * 4 : 0);
-    const int blo = has_g1 ? mw / grows : 0;                                // batch index of the patch's first row
-    const uint32_t mb = has_g1 ? (uint32_t)((blo + 1) * grows) : 0xffffffffu;   // rows from here on: batch blo + 1
 
     const uint64_t p0 = pack2(lds0 + (uint32_t)w * 8192u, lds0 + (uint32_t)w * 12288u);
-    const uint64_t p1 = pack2((uint32_t)(((int64_t)(m0 + w * 64) * p.lda) * 2), (uint32_t)(((int64_t)(n0 + w * 96) * p.ldb) * 2));
     const uint64_t p2 = pack2((uint32_t)(8 * p.lda * 2), (uint32_t)(8 * p.ldb * 2));
-    const uint64_t p3 = pack2((uint32_t)(p.K / BK), (uint32_t)(nw * ES));
     const uint64_t p4 = pack2((uint32_t)(32 * p.ldc * ES), (uint32_t)p.N);
-    const uint64_t p5 = pack2(mb, (uint32_t)(((int64_t)blo * p.gate1_stride + nw) * 4));
     const uint64_t p6 = pack2((uint32_t)(p.gate1_stride * 4), __float_as_uint(p.gate_const));
-    const uint64_t p7 = pack2((uint32_t)(nw * 4), lds0 + (uint32_t)w * 4096u);
+    const uint32_t nk = (uint32_t)(p.K / BK);
+    const uint32_t region = lds0 + 114688u + (uint32_t)w * 4096u;           // column vectors: stage 1's W region
 
+    int idx = blockIdx.x;
+    W64Tile t = w64_tile(p, idx, tiles_m, tiles_n, w);
+    {
+        const uint64_t p8 = pack2(t.sxb, t.swb);
+        asm volatile(OMH_GEMM_W64_ASM_PRO
+                     :
+                     : [vox0] "v"(vox0), [vox1] "v"(vox1), [vow0] "v"(vow0), [vow1] "v"(vow1), [ra] "s"(ra), [rb] "s"(rb),
+                       [p0] "{s[60:61]}"(p0), [p2] "{s[64:65]}"(p2), [p8] "{s[76:77]}"(p8)
+                     : "memory", "scc", "s80", "s81", "s82");
+    }
+#pragma nounroll
+    while (true) {
+        const int nidx = idx + (int)gridDim.x;
+        const bool has_next = nidx < total;
+        const W64Tile tn = w64_tile(p, has_next ? nidx : idx, tiles_m, tiles_n, w);
+        const int mw = t.m0 + wm * 128, nw = t.n0 + wn * 192;
+        const int blo = has_g1 ? mw / grows : 0;                            // batch index of the patch's first row
+        // rows of the wave's patch from here on take the gate of batch blo + 1
+        const uint32_t mb = has_g1 ? (uint32_t)((blo + 1) * grows - mw) : 0xffffffffu;
+        const uint64_t p1 = pack2(t.sxb, t.swb);
+        const uint64_t p3 = pack2(nk, (uint32_t)(((int64_t)t.m0 * p.ldc + nw) * ES));
+        const uint64_t p5 = pack2(mb, (uint32_t)(((int64_t)blo * p.gate1_stride + nw) * 4));
+        const uint64_t p7 = pack2((uint32_t)(nw * 4), region);
+        const uint64_t p8 = pack2(tn.sxb, tn.swb);
+        const uint64_t p9 = pack2(has_next ? 1u : 0u, 0u);
 #define OMH_GW64_RUN(ASM)                                                                                              \
     asm volatile(ASM                                                                                                   \
-                 : [xab] "+v"(xab), [wab] "+v"(wab), [xh] "+v"(xh), [vox0] "+v"(vox0), [vox1] "+v"(vox1),              \
-                   [vow0] "+v"(vow0), [vow1] "+v"(vow1), [voc] "+v"(voc), [vrow] "+v"(vrow), [vcl] "+v"(vcl),          \
-                   [vh] "+v"(vh)                                                                                       \
-                 : [ra] "s"(ra), [rb] "s"(rb), [rc] "s"(rc), [rbias] "s"(rbias), [rg0] "s"(rg0), [rg1] "s"(rg1),       \
-                   [p0] "s"(p0), [p1] "s"(p1), [p2] "s"(p2), [p3] "s"(p3), [p4] "s"(p4), [p5] "s"(p5), [p6] "s"(p6),   \
-                   [p7] "s"(p7)                                                                                        \
+                 :                                                                                                     \
+                 : [xab] "v"(xab), [wab] "v"(wab), [xh] "v"(xh), [vox0] "v"(vox0), [vox1] "v"(vox1), [vow0] "v"(vow0),  \
+                   [vow1] "v"(vow1), [voc] "v"(voc), [vlane] "v"(vlane), [ra] "s"(ra), [rb] "s"(rb), [rc] "s"(rc),      \
+                   [rbias] "s"(rbias), [rg0] "s"(rg0), [rg1] "s"(rg1), [p0] "{s[60:61]}"(p0), [p1] "{s[62:63]}"(p1),   \
+                   [p2] "{s[64:65]}"(p2), [p3] "{s[66:67]}"(p3), [p4] "{s[68:69]}"(p4), [p5] "{s[70:71]}"(p5),          \
+                   [p6] "{s[72:73]}"(p6), [p7] "{s[74:75]}"(p7), [p8] "{s[76:77]}"(p8), [p9] "{s[78:79]}"(p9)           \
                  : OMH_GEMM_W64_CLOBBERS)
-    if (KIND == K_F32) OMH_GW64_RUN(OMH_GEMM_W64_ASM_F32);
-    else if (KIND == K_BF16) OMH_GW64_RUN(OMH_GEMM_W64_ASM_BF16);
-    else if (KIND == K_GELU) OMH_GW64_RUN(OMH_GEMM_W64_ASM_GELU);
-    else OMH_GW64_RUN(OMH_GEMM_W64_ASM_RESID);
+        if (KIND == K_F32) OMH_GW64_RUN(OMH_GEMM_W64_ASM_F32);
+        else if (KIND == K_BF16) OMH_GW64_RUN(OMH_GEMM_W64_ASM_BF16);
+        else if (KIND == K_GELU) OMH_GW64_RUN(OMH_GEMM_W64_ASM_GELU);
+        else OMH_GW64_RUN(OMH_GEMM_W64_ASM_RESID);
 #undef OMH_GW64_RUN
+        if (!has_next) break;
+        idx = nidx;
+        t = tn;
+    }
 }
 
 template <int KIND>
 int launch_w64(const omh_gemm_args& a, hipStream_t stream) {
     const int tiles_m = (a.M + TM - 1) / TM, tiles_n = (a.N + TN - 1) / TN;
-    hipLaunchKernelGGL(gemm_bf16_nt_w64_kernel<KIND>, dim3(tiles_m * tiles_n), dim3(256), 0, stream, a, tiles_m, tiles_n);
+    const int total = tiles_m * tiles_n;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        ncu -= ncu % 8;                                                   // whole XCD rounds keep xcd_remap's chunks aligned
+        if (ncu < 8) ncu = 256;
+    }
+    hipLaunchKernelGGL(gemm_bf16_nt_w64_kernel<KIND>, dim3(total < ncu ? total : ncu), dim3(256), 0, stream, a, tiles_m, tiles_n);
     return 0;
 }
 

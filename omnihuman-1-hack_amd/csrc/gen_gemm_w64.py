@@ -37,7 +37,9 @@ KINDS = ("f32", "bf16", "gelu", "resid")
 # fixed scalar registers (unpacked from the 64-bit operand pairs in the prologue)
 S_LDX, S_LDW, S_SXB, S_SWB, S_SXS, S_SWS, S_NK, S_SCB = "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67"
 S_SCJ, S_N, S_MB, S_G1LO, S_G1ST, S_GC, S_COL0, S_REG = "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75"
+S_NXB, S_NWB, S_NEXT = "s76", "s77", "s78"      # next tile of this workgroup: X / W source offsets, != 0 if there is one
 S_COLN = "s89"                  # first column of the wave (elements) = S_COL0 / 4
+NPAIRS = 10                     # p0..p9 -> s[60:79]
 
 
 def acc(i, j):
@@ -108,7 +110,7 @@ def group_mfmas(buf, first=False):
     return out
 
 
-def dma_piece(stage, operand, q):
+def dma_piece(stage, operand, q, xb=S_SXB, wb=S_SWB):
     """One 1 KiB LDS-DMA piece.  X: wave w fetches rows w*64 + 8 q (q < 8); W: rows w*96 + 8 q (q < 12).
     s81 / s82: running source offsets of the X / W piece; s80: k byte offset of the tile being fetched."""
     base = stage * STAGE + (WOFF if operand == "w" else 0)
@@ -118,15 +120,32 @@ def dma_piece(stage, operand, q):
     lds = S_LDW if operand == "w" else S_LDX
     out = [f"s_add_u32 m0, {lds}, {base + q * 1024}"]
     if q == 0:
-        out.append(f"s_add_u32 {sreg}, {S_SWB if operand == 'w' else S_SXB}, s80")
+        out.append(f"s_add_u32 {sreg}, {wb if operand == 'w' else xb}, s80")
     else:
         out.append(f"s_add_u32 {sreg}, {sreg}, {S_SWS if operand == 'w' else S_SXS}")
     out.append(f"buffer_load_dwordx4 {vo}, {rs}, {sreg} offen lds")
     return [("x", ln) for ln in out]
 
 
-def all_pieces(stage):
-    return [dma_piece(stage, "x", q) for q in range(8)] + [dma_piece(stage, "w", q) for q in range(12)]
+def all_pieces(stage, xb=S_SXB, wb=S_SWB):
+    return [dma_piece(stage, "x", q, xb, wb) for q in range(8)] + [dma_piece(stage, "w", q, xb, wb) for q in range(12)]
+
+
+def unpack(e, pairs=range(NPAIRS)):
+    """Nothing to emit: gemm_w64.hip binds the packed scalar operands to s[60:79] directly ("{s[60:61]}" ...)."""
+
+
+def tile_prologue(e, xb, wb):
+    """k tile 0 -> stage 0 (all 20 pieces per wave), k tile 1 -> stage 1 (the 8 X pieces; the k loop issues the 12 W
+    pieces): 28 LDS-DMA instructions."""
+    e("s_mov_b32 s80, 0")
+    for ops in all_pieces(0, xb, wb):
+        for op in ops:
+            e(op[1])
+    e("s_mov_b32 s80, 128")
+    for ops in all_pieces(1, xb, wb)[:8]:
+        for op in ops:
+            e(op[1])
 
 
 def spread_after(mfmas, extras, start=0, end=None):
@@ -156,26 +175,19 @@ def with_dma_tail(ops, dm):
     return out
 
 
-def main_loop(e):
-    # ---------------- prologue: unpack scalars, fragment addresses
-    for k, pair in enumerate(("p0", "p1", "p2", "p3", "p4", "p5", "p6", "p7")):
-        e(f"s_mov_b64 s[{60 + 2 * k}:{61 + 2 * k}], %[{pair}]")
+def main_loop(e, epi_vmem):
+    """The k loop of one output tile.  On entry the tile's prologue DMA (tile_prologue) is in flight, followed in issue
+    order by `epi_vmem` stores / loads of the previous tile's epilogue (none for the workgroup's first tile, whose
+    prologue stream ended with its own wait)."""
+    unpack(e)
     for kk in range(4):
         e(f"v_xor_b32 v112, {kk}, %[xh]")
         e(f"v_lshl_add_u32 {vr(XA(0, kk))}, v112, 5, %[xab]")
         e(f"v_lshl_add_u32 {vr(WA(0, kk))}, v112, 5, %[wab]")
         e(f"v_add_u32 {vr(XA(1, kk))}, {STAGE}, {vr(XA(0, kk))}")
         e(f"v_add_u32 {vr(WA(1, kk))}, {STAGE}, {vr(WA(0, kk))}")
-    # tile 0 -> stage 0 (all 20 pieces), tile 1 -> stage 1 (the 8 X pieces; the loop issues the 12 W pieces)
-    e("s_mov_b32 s80, 0")
-    for ops in all_pieces(0):
-        for op in ops:
-            e(op[1])
-    e("s_mov_b32 s80, 128")
-    for ops in all_pieces(1)[:8]:
-        for op in ops:
-            e(op[1])
-    e("s_waitcnt vmcnt(8)")                                     # tile 0 has landed
+    e("s_mov_b32 s80, 128")                                     # k offset of the tile whose W pieces come next
+    e(f"s_waitcnt vmcnt({min(63, 8 + epi_vmem)})")               # k tile 0 has landed (in-order counter)
     e("s_barrier")
     pend = linearize(e, frag_reads(0, 0, 0), [])
     e("s_mov_b32 s84, 0")                                       # k step counter
@@ -234,29 +246,41 @@ VSEL, VCOLT = 12, 13         # per-row-block gate vector address, column tempora
 KC = 14                      # v[14:19] GELU constant pairs
 GE = 20                      # v[20:27] GELU temporaries
 NTILES = NI * NJ
-# operand registers of the k loop, dead after it, reused
-VLW, VLR, VCOL = "%[xab]", "%[wab]", "%[xh]"
+VLW, VLR, VCOL, VROW = "v28", "v29", "v30", "v31"   # LDS write / read addresses, first column + 8 h, row in the wave's patch
+VCL, VH = "v20", "v21"       # 4 lane, 32 h (column_vectors only)
 
 
 def column_vectors(e, kind):
     """Per wave: the vectors of its 192 columns in a wave-private LDS region (free after the k loop's last barrier):
     +0 gate for rows below the batch boundary, +768 bias, +1536 gate for rows from the boundary on.  Lane l handles
     columns l, l + 64, l + 128; out-of-range columns / absent vectors read 0 through the descriptors."""
-    e(f"v_add_u32 {VLW}, {S_REG}, %[vcl]")                       # region + 4 lane
-    e(f"v_add_u32 {VLR}, {S_REG}, %[vh]")                        # region + 32 h
+    e(f"v_lshlrev_b32 {VCL}, 2, %[vlane]")
+    e(f"v_and_b32 {VH}, 32, %[vlane]")
+    e(f"v_and_b32 {VROW}, 31, %[vlane]")
+    e(f"v_add_u32 {VLW}, {S_REG}, {VCL}")                        # region + 4 lane
+    e(f"v_add_u32 {VLR}, {S_REG}, {VH}")                         # region + 32 h
     e(f"s_lshr_b32 {S_COLN}, {S_COL0}, 2")
-    e(f"v_lshrrev_b32 {VCOL}, 2, %[vh]")
+    e(f"v_lshrrev_b32 {VCOL}, 2, {VH}")
     e(f"v_add_u32 {VCOL}, {S_COLN}, {VCOL}")                     # first column of the wave + 8 h
     for t in range(3):
-        e(f"buffer_load_dword v{48 + t}, %[vcl], %[rbias], {S_COL0} offen offset:{t * 256}")        # bias[n]
+        e(f"buffer_load_dword v{48 + t}, {VCL}, %[rbias], {S_COL0} offen offset:{t * 256}")        # bias[n]
         if kind == "resid":
-            e(f"buffer_load_dword v{52 + t}, %[vcl], %[rg0], {S_COL0} offen offset:{t * 256}")      # gate0[n]
-            e(f"buffer_load_dword v{56 + t}, %[vcl], %[rg1], {S_G1LO} offen offset:{t * 256}")      # gate1[b][n]
+            e(f"buffer_load_dword v{52 + t}, {VCL}, %[rg0], {S_COL0} offen offset:{t * 256}")      # gate0[n]
+            e(f"buffer_load_dword v{56 + t}, {VCL}, %[rg1], {S_G1LO} offen offset:{t * 256}")      # gate1[b][n]
     if kind == "resid":
         e(f"s_add_u32 s85, {S_G1LO}, {S_G1ST}")
         for t in range(3):
-            e(f"buffer_load_dword v{60 + t}, %[vcl], %[rg1], s85 offen offset:{t * 256}")           # gate1[b + 1][n]
+            e(f"buffer_load_dword v{60 + t}, {VCL}, %[rg1], s85 offen offset:{t * 256}")           # gate1[b + 1][n]
+    # the workgroup's next tile: its prologue DMA goes out now (the stages are free) and lands under this epilogue
+    NONE, JOIN = e.lab("nonext"), e.lab("join")
+    e(f"s_cmp_eq_u32 {S_NEXT}, 0")
+    e(f"s_cbranch_scc1 {NONE}")
+    tile_prologue(e, S_NXB, S_NWB)
+    e("s_waitcnt vmcnt(28)")                                     # the column vectors (older than the 28 DMA pieces)
+    e(f"s_branch {JOIN}")
+    e.label(NONE)
     e("s_waitcnt vmcnt(0)")
+    e.label(JOIN)
     for t in range(3):
         e(f"ds_write_b32 {VLW}, v{48 + t} offset:{768 + t * 256}")
         if kind == "resid":
@@ -324,9 +348,9 @@ def epilogue(e, kind):
         if i == 0:
             if j:
                 e(f"s_add_u32 s85, s85, {S_SCJ}")
-                e("v_add_u32 %[vrow], 32, %[vrow]")
+                e(f"v_add_u32 {VROW}, 32, {VROW}")
             if resid:
-                e(f"v_cmp_le_u32 vcc, {S_MB}, %[vrow]")
+                e(f"v_cmp_le_u32 vcc, {S_MB}, {VROW}")
                 e(f"v_add_u32 v{VCOLT}, 1536, {VLR}")
                 e(f"v_cndmask_b32 v{VSEL}, {VLR}, v{VCOLT}, vcc")
         if resid and n + 2 < NTILES:
@@ -378,25 +402,35 @@ def epilogue(e, kind):
                 e(f"buffer_store_dwordx4 {vr(v0 + 4, 4)}, %[voc], %[rc], s85 offen offset:{off + 16}")
             e("s_nop 1")
             e("s_mov_b64 exec, s[86:87]")
-    e("s_waitcnt vmcnt(0)")
+
+
+EPI_VMEM = {"f32": 96, "bf16": 48, "gelu": 48, "resid": 192}    # VMEM instructions an epilogue issues after the next tile's DMA
 
 
 def generate(kind):
     e = Emit(kind)
-    main_loop(e)
+    main_loop(e, EPI_VMEM[kind])
     epilogue(e, kind)
+    return e
+
+
+def first_prologue():
+    e = Emit("pro")
+    unpack(e, (0, 2, 8))
+    tile_prologue(e, S_NXB, S_NWB)
+    e("s_waitcnt vmcnt(8)")
     return e
 
 
 def main():
     print("// GENERATED by gen_gemm_w64.py — do not edit; edit the generator.")
-    for kind in KINDS:
-        e = generate(kind)
-        print(f"#define OMH_GEMM_W64_ASM_{kind.upper()} \\")
+    streams = [("PRO", first_prologue())] + [(kind.upper(), generate(kind)) for kind in KINDS]
+    for name, e in streams:
+        print(f"#define OMH_GEMM_W64_ASM_{name} \\")
         print(" \\\n".join(e.text().split("\n")))
         print("")
-        print(f"// {kind}: {len(e.lines)} lines, {sum('v_mfma' in ln for ln in e.lines)} MFMA")
-    clob = ['"memory"', '"vcc"', '"scc"'] + [f'"s{i}"' for i in range(60, 92)] + [f'"v{i}"' for i in range(12, 256)] + \
+        print(f"// {name}: {len(e.lines)} lines, {sum('v_mfma' in ln for ln in e.lines)} MFMA")
+    clob = ['"memory"', '"vcc"', '"scc"'] + [f'"s{i}"' for i in range(80, 92)] + [f'"v{i}"' for i in range(12, 256)] + \
            [f'"a{i}"' for i in range(256)]
     print("#define OMH_GEMM_W64_CLOBBERS \\")
     rows = [", ".join(clob[i:i + 12]) for i in range(0, len(clob), 12)]

@@ -86,7 +86,7 @@ if __name__ == "__main__":
     for shp in ((512, 384, 128, None), (1000, 776, 192, 300), (2000, 1536, 256, 500), (32760, 8960, 1536, 16380), (32760, 1536, 8960, 16380)):
         ok &= check(*shp)
     print("CHECK", "PASS" if ok else "FAIL", flush=True)
-    for M in (32760, 65520):
+    for M in (32760,):
         timeit(M, 1536, 1536, ops.EPI_BF16, "bf16+bias")
         timeit(M, 1536, 1536, ops.EPI_RESID, "resid")
         timeit(M, 8960, 1536, ops.EPI_GELU_BF16, "gelu")
