@@ -152,7 +152,7 @@ int launch_w64(const omh_gemm_args& a, hipStream_t stream) {
 }  // namespace
 
 // The shapes the stream kernel takes (everything else stays on gemm_bf16.hip's kernels): one batch, row-major B,
-// K % 64 == 0, N % 8 == 0, M >= 256, epilogues F32 / BF16 / GELU_BF16 / RESID with an [N] bias or none, RESID's per-row
+// K % 64 == 0, K >= 256, N % 8 == 0, M >= 256, epilogues F32 / BF16 / GELU_BF16 / RESID with an [N] bias or none, RESID's per-row
 // gate changing at most once inside a wave's 128 rows (gate_rows >= 128), 32-bit byte offsets everywhere.
 bool omh_gemm_w64_takes(const omh_gemm_args& a) {
     const bool bf16_out = a.epilogue == OMH_EPI_BF16 || a.epilogue == OMH_EPI_GELU_BF16;
@@ -162,7 +162,7 @@ bool omh_gemm_w64_takes(const omh_gemm_args& a) {
                                                    ((int64_t)(a.M / a.gate_rows) * a.gate1_stride + a.N) * 4 >= 0x7fffffffLL))
         return false;
     const int es = bf16_out ? 2 : 4;
-    return a.batch == 1 && !a.b_kmajor && (a.K % BK) == 0 && a.K >= 2 * BK && (a.N % 8) == 0 && a.M >= TM &&
+    return a.batch == 1 && !a.b_kmajor && (a.K % BK) == 0 && a.K >= 4 * BK && (a.N % 8) == 0 && a.M >= TM &&
            (a.ldc % (16 / es)) == 0 && (((uintptr_t)a.C) & 15) == 0 && (a.lda & 7) == 0 && (a.ldb & 7) == 0 &&
            (((uintptr_t)a.A) & 15) == 0 && (((uintptr_t)a.B) & 15) == 0 &&
            ((int64_t)a.M + TM) * a.lda * 2 < 0x7fffffffLL && ((int64_t)a.N + TN) * a.ldb * 2 < 0x7fffffffLL &&

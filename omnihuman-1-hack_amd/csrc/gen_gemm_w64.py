@@ -190,16 +190,16 @@ def main_loop(e, epi_vmem):
     e(f"s_waitcnt vmcnt({min(63, 8 + epi_vmem)})")               # k tile 0 has landed (in-order counter)
     e("s_barrier")
     pend = linearize(e, frag_reads(0, 0, 0), [])
-    e("s_mov_b32 s84, 0")                                       # k step counter
     LOOP_PENDING = list(pend)
     LOOP, DONE = e.lab("loop"), e.lab("done")
 
-    def body(s, first=False):
-        """One k step on stage s.  Groups 0..2: MFMAs || reads of the next group || the 12 W pieces of tile kt+1
+    def body(s, first=False, mode="full"):
+        """One k step on stage s.  Groups 0..2: MFMAs || reads of the next group || the 12 W pieces of k tile kt+1
         (into stage s^1).  Then everything in flight is waited for, barrier, and group 3 runs || the 8 X pieces of
-        tile kt+2 (into stage s, free now) || reads of group 0 of stage s^1."""
+        k tile kt+2 (into stage s, free now) || reads of group 0 of stage s^1.  mode "nox": the step before the last
+        (no k tile kt+2), "none": the last step (nothing to fetch, nothing to read ahead)."""
         pend = LOOP_PENDING
-        rest = all_pieces(s ^ 1)[8:]
+        rest = all_pieces(s ^ 1)[8:] if mode != "none" else []
         for kk in range(3):
             mf = group_mfmas(kk & 1, first=(first and kk == 0))
             reads = [[r] for r in frag_reads(s, kk + 1, (kk + 1) & 1)]
@@ -207,11 +207,16 @@ def main_loop(e, epi_vmem):
             if kk < 2:
                 ops = with_dma_tail(ops, rest[kk * 6:(kk + 1) * 6])
             pend = linearize(e, ops, pend)
+        if mode == "none":
+            linearize(e, group_mfmas(1), pend)
+            return
         e("s_waitcnt vmcnt(0)")
         e("s_waitcnt lgkmcnt(0)")
         e("s_barrier")
-        e("s_add_u32 s80, s80, 128")                            # k offset of tile kt+2
-        xp = all_pieces(s)[:8]
+        xp = []
+        if mode == "full":
+            e("s_add_u32 s80, s80, 128")                        # k offset of tile kt+2
+            xp = all_pieces(s)[:8]
         reads = [[r] for r in frag_reads(s ^ 1, 0, 0)]
         extras = []
         for k in range(max(len(xp), len(reads))):
@@ -221,15 +226,30 @@ def main_loop(e, epi_vmem):
                 extras.append(xp[k])
         pend = linearize(e, spread_after(group_mfmas(1), extras, 0, 22), [])
         assert pend == LOOP_PENDING, (pend, LOOP_PENDING)
-        e("s_add_u32 s84, s84, 1")
-        e(f"s_cmp_eq_u32 s84, {S_NK}")
-        e(f"s_cbranch_scc1 {DONE}")
 
-    body(0, first=True)
+    def step_check(tail):
+        e(f"s_sub_u32 s83, {S_NK}, s84")                        # k steps left, this one included (>= 2 here)
+        e("s_cmp_eq_u32 s83, 2")
+        e(f"s_cbranch_scc1 {tail}")
+
+    TAIL1, TAIL0 = e.lab("tail1"), e.lab("tail0")
+    body(0, first=True)                                         # k step 0 (K >= 3 k tiles: it is never a tail step)
+    e("s_mov_b32 s84, 1")
     e.label(LOOP)
+    step_check(TAIL1)
     body(1)
+    e("s_add_u32 s84, s84, 1")
+    step_check(TAIL0)
     body(0)
+    e("s_add_u32 s84, s84, 1")
     e(f"s_branch {LOOP}")
+    e.label(TAIL1)
+    body(1, mode="nox")
+    body(0, mode="none")
+    e(f"s_branch {DONE}")
+    e.label(TAIL0)
+    body(0, mode="nox")
+    body(1, mode="none")
     e.label(DONE)
     e("s_waitcnt vmcnt(0)")
     e("s_waitcnt lgkmcnt(0)")

@@ -73,12 +73,13 @@ def test_gemm_resid_gate_and_batch(ops, tile, monkeypatch):
     assert float(vt[:, :, S:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("M,N,K,gate_rows", [(256, 384, 128, 256), (1000, 776, 192, 300), (2000, 1536, 256, 500),
-                                             (4100, 1160, 1536, 2050), (32760, 1536, 128, 16380)])
+@pytest.mark.parametrize("M,N,K,gate_rows", [(256, 384, 256, 256), (1000, 776, 320, 300), (2000, 1536, 384, 500),
+                                             (4100, 1160, 1536, 2050), (32760, 1536, 448, 16380)])
 def test_gemm_w64_stream_kernel(ops, M, N, K, gate_rows, monkeypatch):
     """The 256 x 384 one-wave-per-SIMD stream kernel (gemm_w64.hip): each epilogue against fp32 torch AND bit for bit
     against the 8-wave kernel (same k order, same epilogue arithmetic) — ragged M and N, the N % 384 tail masked by
-    EXEC, a strided gate table whose batch boundary falls inside a wave's 128 rows."""
+    EXEC, a strided gate table whose batch boundary falls inside a wave's 128 rows, even and odd numbers of k steps (the
+    two tail paths of the stream)."""
     torch.manual_seed(M + N)
     a = _bf(torch.randn(M, K, device="cuda"))
     w = _bf(torch.randn(N, K, device="cuda") / math.sqrt(K))
