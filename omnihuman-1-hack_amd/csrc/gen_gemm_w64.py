@@ -27,6 +27,7 @@ k loop: v[32:71] / v[72:111] fragment buffers, v[12:19] X fragment addresses [st
 epilogue: v[32:47] tile values, v[48:79] column vectors, v[80:127] prefetched C rows, v12..v31 misc;
 s[60:75] unpacked scalar arguments, s[80:91] scratch.
 """
+import os
 import sys
 
 NI, NJ = 6, 4                   # n tiles (weights) x m tiles (activations) per wave
@@ -161,14 +162,17 @@ def spread_after(mfmas, extras, start=0, end=None):
     return ops
 
 
-def with_dma_tail(ops, dm):
-    """Insert the DMA op lists `dm` after every other MFMA from the 13th on."""
+SCHED = os.environ.get("OMH_GW64_SCHED", "0")     # experiment knob: where the W pieces of a k step are issued
+
+
+def with_dma_tail(ops, dm, start=12):
+    """Insert the DMA op lists `dm` after every other MFMA from the (start+1)-th on."""
     out, idx, cnt = [], 0, 0
     for op in ops:
         out.append(op)
         if op[0] == "m":
             cnt += 1
-            if cnt > 12 and idx < len(dm) and (cnt - 12) % 2 == 1:
+            if cnt > start and idx < len(dm) and (cnt - start) % 2 == 1:
                 out.extend(dm[idx]); idx += 1
     while idx < len(dm):
         out.extend(dm[idx]); idx += 1
@@ -204,7 +208,15 @@ def main_loop(e, epi_vmem):
             mf = group_mfmas(kk & 1, first=(first and kk == 0))
             reads = [[r] for r in frag_reads(s, kk + 1, (kk + 1) & 1)]
             ops = spread_after(mf, reads, 0, 14)
-            if kk < 2:
+            if SCHED == "1":                                    # all 12 W pieces in group 0
+                if kk == 0:
+                    ops = with_dma_tail(ops, rest, 0)
+            elif SCHED == "2":                                  # 8 in group 0 from the first MFMA, 4 in group 1
+                if kk == 0:
+                    ops = with_dma_tail(ops, rest[:8], 4)
+                elif kk == 1:
+                    ops = with_dma_tail(ops, rest[8:], 0)
+            elif kk < 2:
                 ops = with_dma_tail(ops, rest[kk * 6:(kk + 1) * 6])
             pend = linearize(e, ops, pend)
         if mode == "none":

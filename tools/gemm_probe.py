@@ -8,5 +8,5 @@ w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).to(torch.bfloat16)
 bias = torch.randn(N, device="cuda")
 out = torch.empty(S, N, dtype=torch.bfloat16, device="cuda")
 for _ in range(3):
-    ops.gemm(a, w, out=out, bias=bias, epilogue=ops.EPI_BF16)
+    ops.gemm(a, w, out=out, bias=bias, epilogue=ops.EPI_GELU_BF16 if os.environ.get("EPI", "gelu") == "gelu" else ops.EPI_BF16)
 torch.cuda.synchronize()
