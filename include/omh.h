@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OMH_ABI_VERSION 3
+#define OMH_ABI_VERSION 4
 
 #define OMH_E_BADARG   (-1)   /* null pointer / non-positive size             */
 #define OMH_E_ALIGN    (-2)   /* pointer or leading dimension not aligned     */
@@ -270,6 +270,7 @@ typedef struct omh_conv_args {
     int32_t KT, KH, KW;
     int32_t stride_t, stride_hw, pad_h, pad_w;
     int32_t up2, out_f32, split_n;
+    int32_t resid_f32;            /* != 0: resid is fp32 (the fp32 residual trunk of the VAE executor, ABI v4) */
 } omh_conv_args;
 
 int omh_conv_cl_bf16(const omh_conv_args* args, omh_stream_t stream);
@@ -278,6 +279,10 @@ int omh_conv_cl_bf16(const omh_conv_args* args, omh_stream_t stream);
  *   y[p][c] = act( x[p][c] / max(||x[p]||_2, 1e-12) * sqrt(C) * gamma[c] ),  x,y bf16 [P, C]. */
 int omh_rms_silu_cl(const void* x_bf16, const float* gamma, void* y_bf16, int64_t P, int32_t C,
                     int32_t do_silu, omh_stream_t stream);
+/* The same on an fp32 input (the residual trunk, which the reference keeps in fp32: WanVAE(dtype=torch.float),
+ * vae.py:619-624): statistics and normalisation in fp32, one rounding to bf16 at the convolution's input. */
+int omh_rms_silu_cl_f32in(const float* x_f32, const float* gamma, void* y_bf16, int64_t P, int32_t C,
+                          int32_t do_silu, omh_stream_t stream);
 
 /* In-place ReLU on a bf16 buffer (n % 8 == 0): the nn.ReLU between the Conv3d layers of the OmniHuman pose
  * guider (Omnihuman/omnihuman_wan_t2v.py:37-45,149-157), whose convolutions run on omh_conv_cl_bf16.

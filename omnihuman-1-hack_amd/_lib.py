@@ -21,7 +21,7 @@ class OmhError(RuntimeError):
     pass
 
 
-ABI_VERSION = 3          # == OMH_ABI_VERSION of include/omh.h; checked against the loaded library below
+ABI_VERSION = 4          # == OMH_ABI_VERSION of include/omh.h; checked against the loaded library below
 
 
 def _load():
@@ -105,7 +105,7 @@ class ConvArgs(C.Structure):
                 ("Tout", i32), ("Hout", i32), ("Wout", i32), ("Cout", i32),
                 ("KT", i32), ("KH", i32), ("KW", i32),
                 ("stride_t", i32), ("stride_hw", i32), ("pad_h", i32), ("pad_w", i32),
-                ("up2", i32), ("out_f32", i32), ("split_n", i32)]
+                ("up2", i32), ("out_f32", i32), ("split_n", i32), ("resid_f32", i32)]
 
 
 EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID, EPI_F32_ACCUM, EPI_GELU_ERF_BF16 = 0, 1, 2, 3, 4, 5
@@ -129,6 +129,7 @@ _SIGS = {
     "omh_sinusoidal_embedding": (i32, [vp, vp, i32, i32, vp]),
     "omh_conv_cl_bf16": (i32, [C.POINTER(ConvArgs), vp]),
     "omh_rms_silu_cl": (i32, [vp, vp, vp, i64, i32, i32, vp]),
+    "omh_rms_silu_cl_f32in": (i32, [vp, vp, vp, i64, i32, i32, vp]),
     "omh_relu_bf16": (i32, [vp, i64, vp]),
     "omh_relu_bwd_bf16": (i32, [vp, vp, vp, i64, vp]),
     "omh_nchw_to_cl": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp]),

@@ -164,7 +164,16 @@ void conv_cl_kernel(const omh_conv_args p, const int tiles_m, const int tiles_n)
                     v[e] = acc[im][in][4 * gq + e];
                     if (p.bias && n + e < p.Cout) v[e] += p.bias[n + e];
                 }
-                if (R) {
+                if (R && p.resid_f32) {                             // fp32 residual trunk
+                    const float* Rf = (const float*)p.resid;
+                    if (full) {
+                        const float4 rr = *(const float4*)(Rf + off);
+                        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (n + e < p.Cout) v[e] += Rf[off + e];
+                    }
+                } else if (R) {
                     if (full) {
                         const uint2 rr = *(const uint2*)(R + off);
                         v[0] += bf2f((uint16_t)(rr.x & 0xffff)); v[1] += bf2f((uint16_t)(rr.x >> 16));
@@ -244,7 +253,10 @@ __device__ __forceinline__ void wide_epilogue(const omh_conv_args& p, f32x16 (&a
             }
             rres[ps] = make_uint4(0, 0, 0, 0);
             const bool row_ok = trow + r >= row_lo && trow + r <= row_hi && m >= 0 && m < M;
-            if (!OUT_F32 && R && row_ok && vec_all && n + VEC <= p.Cout) rres[ps] = *(const uint4*)(R + offs[ps]);
+            if (R && row_ok && vec_all && n + VEC <= p.Cout) {
+                if (!OUT_F32 && !p.resid_f32) rres[ps] = *(const uint4*)(R + offs[ps]);                     // 8 bf16
+                else if (OUT_F32 && p.resid_f32) rres[ps] = *(const uint4*)((const float*)p.resid + offs[ps]);   // 4 fp32
+            }
         }
 #pragma unroll
         for (int in = 0; in < NT; ++in)
@@ -272,10 +284,16 @@ __device__ __forceinline__ void wide_epilogue(const omh_conv_args& p, f32x16 (&a
             }
             const int64_t off = offs[ps];
             if (R) {
-                if (full && !OUT_F32) {
-                    const uint32_t rw[4] = {rres[ps].x, rres[ps].y, rres[ps].z, rres[ps].w};
+                const uint32_t rw[4] = {rres[ps].x, rres[ps].y, rres[ps].z, rres[ps].w};
+                if (full && !OUT_F32 && !p.resid_f32) {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) v[e] += bf2f((uint16_t)((rw[(e >> 1) & 3] >> (16 * (e & 1))) & 0xffff));
+                } else if (full && OUT_F32 && p.resid_f32) {           // fp32 residual trunk -> fp32 trunk
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] += __uint_as_float(rw[e & 3]);
+                } else if (p.resid_f32) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) if (n + e < p.Cout) v[e] += ((const float*)p.resid)[off + e];
                 } else {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) if (n + e < p.Cout) v[e] += bf2f(R[off + e]);

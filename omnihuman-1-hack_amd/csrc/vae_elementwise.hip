@@ -7,28 +7,37 @@ namespace {
 
 // One voxel (C channels, bf16) is handled by G consecutive lanes, 8 channels
 // (16 bytes) per lane per pass.
-template <int G>
+template <int G, bool XF32>
 __global__ __launch_bounds__(256)
-void rms_silu_kernel(const uint16_t* __restrict__ x, const float* __restrict__ gamma, uint16_t* __restrict__ y,
+void rms_silu_kernel(const void* __restrict__ xv, const float* __restrict__ gamma, uint16_t* __restrict__ y,
                      int64_t P, int C, int do_silu) {
     const int lane_g = threadIdx.x % G;
     const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     if (p >= P) return;            // whole group exits together (G divides the wave)
-    const int nch = C >> 3;        // 16-byte chunks per voxel
+    const int nch = C >> 3;        // 8-channel chunks per voxel
     constexpr int MAXC = 4;        // chunks per lane  -> C <= 8*G*MAXC
-    uint4 v[MAXC];
+    float v[MAXC][8];
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const int c = lane_g + G * i;
         if (c < nch) {
-            v[i] = *(const uint4*)(x + p * C + c * 8);
-            const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+            if (XF32) {
+                const float4 a = *(const float4*)((const float*)xv + p * C + c * 8);
+                const float4 b = *(const float4*)((const float*)xv + p * C + c * 8 + 4);
+                v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w;
+                v[i][4] = b.x; v[i][5] = b.y; v[i][6] = b.z; v[i][7] = b.w;
+            } else {
+                const uint4 u = *(const uint4*)((const uint16_t*)xv + p * C + c * 8);
+                const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float a = bf2f((uint16_t)(w[e] & 0xffff)), b = bf2f((uint16_t)(w[e] >> 16));
-                ss += a * a + b * b;
+                for (int e = 0; e < 4; ++e) {
+                    v[i][2 * e] = bf2f((uint16_t)(w[e] & 0xffff));
+                    v[i][2 * e + 1] = bf2f((uint16_t)(w[e] >> 16));
+                }
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ss += v[i][2 * e] * v[i][2 * e] + v[i][2 * e + 1] * v[i][2 * e + 1];
         }
     }
 #pragma unroll
@@ -38,12 +47,11 @@ void rms_silu_kernel(const uint16_t* __restrict__ x, const float* __restrict__ g
     for (int i = 0; i < MAXC; ++i) {
         const int c = lane_g + G * i;
         if (c < nch) {
-            const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
             uint32_t o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float a = bf2f((uint16_t)(w[e] & 0xffff)) * inv * gamma[c * 8 + 2 * e];
-                float b = bf2f((uint16_t)(w[e] >> 16)) * inv * gamma[c * 8 + 2 * e + 1];
+                float a = v[i][2 * e] * inv * gamma[c * 8 + 2 * e];
+                float b = v[i][2 * e + 1] * inv * gamma[c * 8 + 2 * e + 1];
                 if (do_silu) { a = silu(a); b = silu(b); }
                 o[e] = pack_bf2(a, b);
             }
@@ -177,8 +185,9 @@ extern "C" int omh_relu_bf16(void* x, int64_t n, omh_stream_t stream) {
     return omh_launch_status();
 }
 
-extern "C" int omh_rms_silu_cl(const void* x, const float* gamma, void* y, int64_t P, int32_t C, int32_t do_silu,
-                               omh_stream_t stream) {
+template <bool XF32>
+static int rms_silu_launch(const void* x, const float* gamma, void* y, int64_t P, int32_t C, int32_t do_silu,
+                           omh_stream_t stream) {
     if (!x || !gamma || !y || P <= 0 || C <= 0) return OMH_E_BADARG;
     if ((C & 7) || C > 8 * 64 * 4) return OMH_E_SHAPE;
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return OMH_E_ALIGN;
@@ -187,16 +196,26 @@ extern "C" int omh_rms_silu_cl(const void* x, const float* gamma, void* y, int64
     omh_clear_status();
     // lanes per voxel: enough that each lane holds <= 4 chunks, rounded to a power of two
     if (nch <= 16) {
-        hipLaunchKernelGGL(rms_silu_kernel<4>, dim3((unsigned)((P * 4 + 255) / 256)), dim3(256), 0, s,
-                           (const uint16_t*)x, gamma, (uint16_t*)y, P, C, do_silu);
+        hipLaunchKernelGGL((rms_silu_kernel<4, XF32>), dim3((unsigned)((P * 4 + 255) / 256)), dim3(256), 0, s,
+                           x, gamma, (uint16_t*)y, P, C, do_silu);
     } else if (nch <= 64) {
-        hipLaunchKernelGGL(rms_silu_kernel<16>, dim3((unsigned)((P * 16 + 255) / 256)), dim3(256), 0, s,
-                           (const uint16_t*)x, gamma, (uint16_t*)y, P, C, do_silu);
+        hipLaunchKernelGGL((rms_silu_kernel<16, XF32>), dim3((unsigned)((P * 16 + 255) / 256)), dim3(256), 0, s,
+                           x, gamma, (uint16_t*)y, P, C, do_silu);
     } else {
-        hipLaunchKernelGGL(rms_silu_kernel<64>, dim3((unsigned)((P * 64 + 255) / 256)), dim3(256), 0, s,
-                           (const uint16_t*)x, gamma, (uint16_t*)y, P, C, do_silu);
+        hipLaunchKernelGGL((rms_silu_kernel<64, XF32>), dim3((unsigned)((P * 64 + 255) / 256)), dim3(256), 0, s,
+                           x, gamma, (uint16_t*)y, P, C, do_silu);
     }
     return omh_launch_status();
+}
+
+extern "C" int omh_rms_silu_cl(const void* x, const float* gamma, void* y, int64_t P, int32_t C, int32_t do_silu,
+                               omh_stream_t stream) {
+    return rms_silu_launch<false>(x, gamma, y, P, C, do_silu, stream);
+}
+
+extern "C" int omh_rms_silu_cl_f32in(const float* x, const float* gamma, void* y, int64_t P, int32_t C,
+                                     int32_t do_silu, omh_stream_t stream) {
+    return rms_silu_launch<true>(x, gamma, y, P, C, do_silu, stream);
 }
 
 extern "C" int omh_nchw_to_cl(const float* x, void* y, int32_t C, int32_t T, int32_t H, int32_t W, int32_t Cp,

@@ -270,23 +270,26 @@ def conv_cl(x, w, bias, Tout, Hout, Wout, Cout, KT, KH, KW, stride_t=1, stride_h
     if out is None:
         out = torch.empty(Tout * f, Hout, Wout, cch, dtype=torch.float32 if out_f32 else torch.bfloat16,
                           device=x.device)
-    assert out.is_contiguous() and (resid is None or (resid.is_contiguous() and resid.dtype == torch.bfloat16))
+    assert out.is_contiguous() and (resid is None or (resid.is_contiguous() and
+                                                      resid.dtype in (torch.bfloat16, torch.float32)))
     a = _lib.ConvArgs(_p(x), _p(w), _p(bias), _p(resid), _p(out), Tin, Hin, Win, Cin, Tout, Hout, Wout, Cout,
-                      KT, KH, KW, stride_t, stride_hw, pad_h, pad_w, int(up2), int(out_f32), split_n)
+                      KT, KH, KW, stride_t, stride_hw, pad_h, pad_w, int(up2), int(out_f32), split_n,
+                      int(resid is not None and resid.dtype == torch.float32))
     check(lib.omh_conv_cl_bf16(C.byref(a), _stream()), "omh_conv_cl_bf16")
     return out
 
 
 def rms_silu_cl(x, gamma, out=None, do_silu=True):
-    """x bf16 [..., C] channels-last -> bf16, per-voxel RMS norm (* gamma) then SiLU."""
+    """x bf16 or fp32 [..., C] channels-last -> bf16, per-voxel RMS norm (* gamma) then SiLU."""
     _dev(x, gamma, out)
-    assert x.dtype == torch.bfloat16 and x.is_contiguous() and gamma.dtype == torch.float32
+    assert x.dtype in (torch.bfloat16, torch.float32) and x.is_contiguous() and gamma.dtype == torch.float32
     Cc = x.shape[-1]
     if out is None:
-        out = torch.empty_like(x)
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
     assert out.is_contiguous() and out.dtype == torch.bfloat16
-    check(lib.omh_rms_silu_cl(_p(x), _p(gamma), _p(out), x.numel() // Cc, Cc, int(do_silu), _stream()),
-          "omh_rms_silu_cl")
+    fn, name = ((lib.omh_rms_silu_cl, "omh_rms_silu_cl") if x.dtype == torch.bfloat16 else
+                (lib.omh_rms_silu_cl_f32in, "omh_rms_silu_cl_f32in"))
+    check(fn(_p(x), _p(gamma), _p(out), x.numel() // Cc, Cc, int(do_silu), _stream()), name)
     return out
 
 

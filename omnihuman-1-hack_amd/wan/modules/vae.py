@@ -288,11 +288,27 @@ def _gamma(norm: RMS_norm):
     return norm.gamma.detach().float().reshape(-1).contiguous()
 
 
+# The residual trunk (the tensor that runs from block to block: conv1's output, every ResidualBlock / AttentionBlock /
+# Resample output) is kept in fp32, as the reference's VAE does throughout (WanVAE(dtype=torch.float), vae.py:619-624):
+# RMS statistics are then taken from unrounded values and the skip path is never rounded, so the 2^-9 of a bf16
+# rounding per block no longer accumulates over the ~20 blocks of a decode.  Convolution INPUTS are bf16 (the MFMA
+# operand type), rounded once from the fp32 trunk.  OMH_VAE_TRUNK=bf16 restores the round-1 executor (A/B, tests).
+_TRUNK_F32 = os.environ.get("OMH_VAE_TRUNK", "f32") != "bf16"
+
+
+def _fill(slot, x):
+    """Write trunk tensor x into a convolution's bf16 input slot."""
+    if x.dtype == torch.float32 and x.shape[-1] == slot.shape[-1]:
+        ops.cast_bf16(x.contiguous(), out=slot)
+    else:
+        slot.copy_(x)
+
+
 def _conv_on(st: _Stream, key, module, x, **run_kw):
-    """Feed tensor x (bf16 [T,H,W,C]) to a conv that has no fused producer."""
+    """Feed tensor x ([T,H,W,C], bf16 or the fp32 trunk) to a conv that has no fused producer."""
     cs = st.conv(key, module)
     T, H, W, _ = x.shape
-    cs.slot(T, H, W, x.device).copy_(x)
+    _fill(cs.slot(T, H, W, x.device), x)
     return cs.run(**run_kw)
 
 
@@ -301,13 +317,13 @@ def _res_block(st, key, blk: ResidualBlock, x):
     T, H, W, _ = x.shape
     h = x
     if not isinstance(blk.shortcut, nn.Identity):
-        h = _conv_on(st, key + ".shortcut", blk.shortcut, x)
+        h = _conv_on(st, key + ".shortcut", blk.shortcut, x, out_f32=_TRUNK_F32)
     ca = st.conv(key + ".residual.2", blk.residual[2])
     ops.rms_silu_cl(x, _gamma(blk.residual[0]), out=ca.slot(T, H, W, x.device))
-    y = ca.run()
+    y = ca.run()                                    # inside the block: bf16 (rounded once, feeds one norm + conv)
     cb = st.conv(key + ".residual.6", blk.residual[6])
     ops.rms_silu_cl(y, _gamma(blk.residual[3]), out=cb.slot(T, H, W, x.device))
-    return cb.run(resid=h)
+    return cb.run(resid=h, out_f32=_TRUNK_F32)
 
 
 def _attention(st, key, blk: AttentionBlock, x):
@@ -339,7 +355,7 @@ def _attention(st, key, blk: AttentionBlock, x):
     del s, p
     cs = st.conv(key + ".proj", blk.proj)
     cs.slot(T, H, W, dev).copy_(o.view(T, H, W, Cc))
-    return cs.run(resid=x)
+    return cs.run(resid=x, out_f32=_TRUNK_F32)
 
 
 def _resample(st, key, rs: Resample, x):
@@ -352,12 +368,12 @@ def _resample(st, key, rs: Resample, x):
             else:
                 x = _conv_on(st, key + ".time_conv", rs.time_conv, x, split_n=Cc)    # [2T, H, W, C]
         cs = st.conv(key + ".resample.1", rs.resample[1], up2=True)
-        cs.slot(x.shape[0], H, W, x.device).copy_(x)
-        return cs.run()
+        _fill(cs.slot(x.shape[0], H, W, x.device), x)
+        return cs.run(out_f32=_TRUNK_F32)
     if rs.mode in ("downsample2d", "downsample3d"):
         cs = st.conv(key + ".resample.1", rs.resample[1], stride_hw=2, pad=(0, 0))
-        cs.slot(T, H, W, x.device).copy_(x)
-        x = cs.run()
+        _fill(cs.slot(T, H, W, x.device), x)
+        x = cs.run(out_f32=_TRUNK_F32)
         if rs.mode == "downsample3d":
             tc = st.conv(key + ".time_conv", rs.time_conv)
             if key not in st.seen:
@@ -365,8 +381,8 @@ def _resample(st, key, rs: Resample, x):
                 tc.slot(x.shape[0], x.shape[1], x.shape[2], x.device)
                 tc.set_history(x[-1])
             else:
-                tc.slot(x.shape[0], x.shape[1], x.shape[2], x.device).copy_(x)
-                x = tc.run()
+                _fill(tc.slot(x.shape[0], x.shape[1], x.shape[2], x.device), x)
+                x = tc.run(out_f32=_TRUNK_F32)
         return x
     return x
 
@@ -455,7 +471,7 @@ class WanVAE_(nn.Module):
             t0, tn = (0, 1) if i == 0 else (1 + 4 * (i - 1), 4)
             c1 = st.conv("encoder.conv1", enc.conv1)
             ops.nchw_to_cl(vid, tn, t0, c1.Cin, out=c1.slot(tn, H, W, dev))
-            h = c1.run()
+            h = c1.run(out_f32=_TRUNK_F32)
             rows.append(_run_sequential(st, "encoder.downsamples", enc.downsamples, h, stop=n_tail))
         h = torch.cat(rows, dim=0) if len(rows) > 1 else rows[0]                   # [n_chunks, h, w, C]
         h = _run_sequential(st, "encoder.downsamples", enc.downsamples, h, start=n_tail)
@@ -503,7 +519,7 @@ class WanVAE_(nn.Module):
         n_front = _first_resample(dec.upsamples)
         c1 = st.conv("decoder.conv1", dec.conv1)
         c1.slot(Tl, h, w, dev).copy_(x_all)
-        y_all = c1.run()
+        y_all = c1.run(out_f32=_TRUNK_F32)
         y_all = _run_sequential(st, "decoder.middle", dec.middle, y_all)
         y_all = _run_sequential(st, "decoder.upsamples", dec.upsamples, y_all, stop=n_front)
         for i in range(Tl):

@@ -329,5 +329,6 @@ def test_vae_81_frames_against_oracle_quarter_area():
     assert mu.shape == ref_mu.shape == (16, 21, 30, 52)
     e_enc = rel_rms(mu, ref_mu)
     print(f"[measured] VAE 81 frames 240x416: decode rel-RMS {e_dec:.3e} (last chunk {e_last:.3e}), encode rel-RMS {e_enc:.3e}")
-    # measured on MI355X (round 2): decode 1.25e-2 (last chunk 1.24e-2: no drift), encode 3.8e-3; bounds = 2 x
-    assert e_dec < 2.5e-2 and e_last < 2.5e-2 and e_enc < 8e-3
+    # measured on MI355X (round 2, fp32 residual trunk): decode 1.03e-2 (last chunk 1.03e-2: no drift), encode 3.4e-3
+    # (bf16 trunk of round 1: 1.25e-2 / 3.8e-3); bounds = 2 x
+    assert e_dec < 2.1e-2 and e_last < 2.1e-2 and e_enc < 7e-3

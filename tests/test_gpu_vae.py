@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 # The reference runs the VAE in fp32; this build stores activations in bf16 and
 # multiplies in bf16 MFMA with fp32 accumulation.  Through the ~35 conv layers of
 # the decoder the relative RMS error of the output video stays below:
-TOL_VAE = 3.0e-2
+TOL_VAE = 2.0e-2          # measured with the fp32 residual trunk: 9.1e-3 decode / 5.4e-3 encode at 240x416 (x 2)
 
 
 def _bf(x):
@@ -58,6 +58,11 @@ def test_conv_cl_matches_torch(ops, cfg, tile, monkeypatch):
     # bf16 output (the layout every inner layer uses): same values, one bf16 rounding
     yb = ops.conv_cl(x, wp, bias, T, H, W, Cout, KT, KH, KW, pad_h=KH // 2, pad_w=KW // 2, resid=resid)
     assert yb.dtype == torch.bfloat16 and torch.equal(yb, y.to(torch.bfloat16))
+    # fp32 residual -> fp32 output: the residual trunk of the VAE executor (omh_conv_args.resid_f32)
+    rf = torch.randn(T, H, W, Cout, device="cuda")
+    yf = ops.conv_cl(x, wp, bias, T, H, W, Cout, KT, KH, KW, pad_h=KH // 2, pad_w=KW // 2, resid=rf, out_f32=True)
+    assert rel_rms(yf, ref - resid.float() + rf) < 2e-5
+    assert float((yf - rf - (y - resid.float())).abs().max()) < 1e-5        # same accumulators, only the residual differs
 
 
 @pytest.mark.parametrize("tile", ["small", "wide"])
@@ -106,6 +111,10 @@ def test_rms_silu_softmax_layout(ops):
         g = torch.rand(C, device="cuda") + 0.5
         ref = torch.nn.functional.silu(torch.nn.functional.normalize(x.float(), dim=1) * C ** 0.5 * g)
         assert rel_rms(ops.rms_silu_cl(x, g).float(), ref) < 4e-3
+        xf = torch.randn(77, C, device="cuda") * 2                # fp32 input (the residual trunk): omh_rms_silu_cl_f32in
+        reff = torch.nn.functional.silu(torch.nn.functional.normalize(xf, dim=1) * C ** 0.5 * g)
+        assert rel_rms(ops.rms_silu_cl(xf, g).float(), reff) < 3e-3
+        assert torch.equal(ops.rms_silu_cl(x.float(), g), ops.rms_silu_cl(x, g))      # same values in, same bits out
     s = torch.randn(50, 333, device="cuda") * 3
     p = torch.zeros(50, 336, dtype=torch.bfloat16, device="cuda")
     ops.softmax_rows(s, p, 333, 0.7)
