@@ -294,6 +294,7 @@ def _gamma(norm: RMS_norm):
 # rounding per block no longer accumulates over the ~20 blocks of a decode.  Convolution INPUTS are bf16 (the MFMA
 # operand type), rounded once from the fp32 trunk.  OMH_VAE_TRUNK=bf16 restores the round-1 executor (A/B, tests).
 _TRUNK_F32 = os.environ.get("OMH_VAE_TRUNK", "f32") != "bf16"
+_GROUP = max(1, int(os.environ.get("OMH_VAE_GROUP", "5")))      # latent frames per step at the decoder's 2h x 2w stage
 
 
 def _fill(slot, x):
@@ -522,11 +523,23 @@ class WanVAE_(nn.Module):
         y_all = c1.run(out_f32=_TRUNK_F32)
         y_all = _run_sequential(st, "decoder.middle", dec.middle, y_all)
         y_all = _run_sequential(st, "decoder.upsamples", dec.upsamples, y_all, stop=n_front)
-        for i in range(Tl):
-            y = _run_sequential(st, "decoder.upsamples", dec.upsamples, y_all[i:i + 1], start=n_front)
-            y = _head(st, "decoder.head", dec.head, y, out_f32=True)            # fp32 [t, 8h, 8w, 3]
-            ops.cl_to_nchw(y, out, t_pix, 3, lo=lo, hi=hi)
-            t_pix += y.shape[0]
+        # From the first Resample to just past the second one (the 2h x 2w stage: 49 920 voxels per latent frame at
+        # 480x832 — 195 workgroups of 256 rows on 256 CUs) the latent frames go _GROUP at a time, the first one
+        # alone (its chunk skips the temporal upsamples); the full-resolution rest takes one latent frame's 4 frames
+        # per step as the reference.  Causal convolutions over [history | frames]: same values either way.
+        res_idx = [i for i, layer in enumerate(dec.upsamples) if isinstance(layer, Resample)]
+        n_mid = res_idx[1] + 1 if len(res_idx) > 1 else len(dec.upsamples)
+        i = 0
+        while i < Tl:
+            g = 1 if i == 0 else min(_GROUP, Tl - i)
+            ymid = _run_sequential(st, "decoder.upsamples", dec.upsamples, y_all[i:i + g], start=n_front, stop=n_mid)
+            per = ymid.shape[0] // g
+            for j in range(g):
+                y = _run_sequential(st, "decoder.upsamples", dec.upsamples, ymid[j * per:(j + 1) * per], start=n_mid)
+                y = _head(st, "decoder.head", dec.head, y, out_f32=True)        # fp32 [t, 8h, 8w, 3]
+                ops.cl_to_nchw(y, out, t_pix, 3, lo=lo, hi=hi)
+                t_pix += y.shape[0]
+            i += g
         assert t_pix == T_out
         return out.unsqueeze(0)
 

@@ -14,7 +14,7 @@ def child():
     sd = V.synth_state_dict(cfg, "vae96wide")
     vae = vae_mod.WanVAE(vae_pth=None, device="cuda", dim=96)
     vae.model.load_state_dict(sd)
-    z = torch.from_numpy(detgen.normalish("vae/zwide", (16, 2, 30, 52)))
+    z = torch.from_numpy(detgen.normalish("vae/zwide", (16, 4, 16, 24)))
     ref = V.vae_decode(sd, cfg, z)
     out = vae.decode([z.cuda()])[0]
     vid = ref.clamp(-1, 1)
@@ -29,5 +29,6 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         child()
     else:
-        for mode in ("bf16", "f32"):
-            subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, OMH_VAE_TRUNK=mode), check=False)
+        for mode, grp in (("bf16", "1"), ("f32", "1"), ("f32", "2"), ("f32", "4"), ("f32", "5")):
+            print("== trunk", mode, "group", grp, flush=True)
+            subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, OMH_VAE_TRUNK=mode, OMH_VAE_GROUP=grp), check=False)
