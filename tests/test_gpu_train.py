@@ -14,7 +14,11 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 # bf16 forward + bf16 backward operands, fp32 accumulation: per-tensor relative RMS error of a
 # parameter gradient after 13 blocks of back-propagation.
-TOL_GRAD = 6e-2
+# measured on MI355X (round 2, printed by the tests): matrices <= 1.01e-2 against the reference's own gradients and
+# against the autograd oracle (t2v 13 layers, both freeze settings, i2v); 1-D parameters (bias / gain gradients: long
+# sums with heavy cancellation) <= 4.5e-2.  Bounds = 2 x measured.
+TOL_GRAD = 2e-2
+TOL_GRAD_1D = 9e-2
 
 
 def _setup(wan_model_mod, freeze=True):
@@ -41,11 +45,15 @@ def test_training_step_matches_reference_gradients(wan_model_mod):
     assert abs(loss.item() - float(g["loss"])) < 2e-2 * float(g["loss"])
     loss.backward()
     params = dict(m.named_parameters())
+    worst = {1: 0.0, 2: 0.0}
     for name in g.files:
         if name in params:
             got = params[name].grad
             assert got is not None, name
-            assert rel_rms(got, torch.from_numpy(g[name])) < TOL_GRAD, name
+            e = rel_rms(got, torch.from_numpy(g[name]))
+            worst[min(got.dim(), 2)] = max(worst[min(got.dim(), 2)], e)
+            assert e < (TOL_GRAD if got.dim() > 1 else TOL_GRAD_1D), (name, e)
+    print(f"[measured] reference golden gradients (t2v, 13 layers): worst matrix {worst[2]:.3e}, worst 1-D {worst[1]:.3e}")
     # the reference's block_idx > 10 quirk: those FFN weights get no gradient at all (model.py:317-324)
     first = int(g["ffn_grad_none_from"])
     for i in range(13):
@@ -67,6 +75,7 @@ def test_all_gradients_match_autograd_oracle(wan_model_mod, freeze):
     lg.backward()
     assert abs(lg.item() - lo.item()) < 2e-2 * lo.item()
     bad = []
+    worst = {1: 0.0, 2: 0.0}
     norms = sorted(float(v.grad.norm()) for v in osd.values() if v.grad is not None and float(v.grad.abs().max()) > 0)
     floor = 1e-2 * norms[len(norms) // 2]      # near-null gradients (e.g. the cross-attention K bias, to which the
     for name, p in m.named_parameters():       # softmax is invariant) are compared on the absolute scale instead
@@ -75,10 +84,12 @@ def test_all_gradients_match_autograd_oracle(wan_model_mod, freeze):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
             continue
         err = float((p.grad.double().cpu() - og.double()).norm() / max(float(og.double().norm()), floor))
+        worst[min(og.dim(), 2)] = max(worst[min(og.dim(), 2)], err)
         # matrices: TOL_GRAD; 1-D parameters (bias / gain gradients are long sums with heavy cancellation, so the
-        # same bf16 operand noise is a larger fraction of the result): 1e-1
-        if err > (TOL_GRAD if og.dim() > 1 else 1e-1):
+        # same bf16 operand noise is a larger fraction of the result): TOL_GRAD_1D
+        if err > (TOL_GRAD if og.dim() > 1 else TOL_GRAD_1D):
             bad.append((name, err))
+    print(f"[measured] all gradients vs autograd oracle (freeze={freeze}): worst matrix {worst[2]:.3e}, worst 1-D {worst[1]:.3e}")
     assert not bad, bad[:10]
 
 
@@ -274,6 +285,7 @@ def test_i2v_training_gradients(wan_model_mod):
     norms = sorted(float(v.grad.norm()) for v in osd.values() if v.grad is not None and float(v.grad.abs().max()) > 0)
     floor = 1e-2 * norms[len(norms) // 2]
     bad = []
+    worst = {1: 0.0, 2: 0.0}
     for name, p in m.named_parameters():
         og = osd[name].grad
         if og is None or float(og.abs().max()) == 0.0:
@@ -281,8 +293,10 @@ def test_i2v_training_gradients(wan_model_mod):
             continue
         assert p.grad is not None, name
         err = float((p.grad.double().cpu() - og.double()).norm() / max(float(og.double().norm()), floor))
-        if err > (TOL_GRAD if og.dim() > 1 else 1e-1):
+        worst[min(og.dim(), 2)] = max(worst[min(og.dim(), 2)], err)
+        if err > (TOL_GRAD if og.dim() > 1 else TOL_GRAD_1D):
             bad.append((name, err))
+    print(f"[measured] i2v gradients vs autograd oracle: worst matrix {worst[2]:.3e}, worst 1-D {worst[1]:.3e}")
     assert not bad, bad[:10]
 
 
