@@ -331,6 +331,19 @@ void rmsnorm_rope_bwd_kernel(const float* __restrict__ x, int64_t ldx, const flo
             if (s < gf * gh * gw) { rot = true; pf = s / (gh * gw); ph = (s / gw) % gh; pw = s % gw; }
         }
         float sxg = 0.f;
+        // as in rmsnorm_rope_kernel: with head_dim | 256 a lane's vectors all use the same two table entries
+        const bool same_pairs = rot && (256 % head_dim) == 0;
+        float cs2[2] = {1.f, 1.f}, sn2[2] = {0.f, 0.f};
+        if (same_pairs) {
+            const int p0 = ((4 * lane) % head_dim) >> 1;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int pc = p0 + e;
+                const int pos = pc < cf ? pf : (pc < cf + c3 ? ph : pw);
+                const int idx = min(pos, rope_len - 1) * hc + pc;
+                cs2[e] = rope_cos[idx]; sn2[e] = rope_sin[idx];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
@@ -343,7 +356,7 @@ void rmsnorm_rope_bwd_kernel(const float* __restrict__ x, int64_t ldx, const flo
                         const int pc = p0 + e;
                         const int pos = pc < cf ? pf : (pc < cf + c3 ? ph : pw);
                         const int idx = min(pos, rope_len - 1) * hc + pc;
-                        const float cs = rope_cos[idx], sn = rope_sin[idx];
+                        const float cs = same_pairs ? cs2[e] : rope_cos[idx], sn = same_pairs ? sn2[e] : rope_sin[idx];
                         float& re = e == 0 ? t.x : t.z;
                         float& im = e == 0 ? t.y : t.w;
                         const float nr = re * cs + im * sn;          // rotate by -theta
