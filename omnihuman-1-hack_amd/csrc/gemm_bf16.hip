@@ -371,6 +371,19 @@ int launch_cfg(const omh_gemm_args& a, hipStream_t s) {
     return omh_launch_status();
 }
 
+// Estimated time (us) of the 256x256 and the 128x128 tile configurations on `a` (see launch() below for the model).
+static float round_cost(int64_t tiles, int64_t slots, int64_t light_max, float light, float heavy) {
+    const int64_t full = tiles / slots, last = tiles % slots;
+    return (float)full * heavy + (last == 0 ? 0.0f : (last <= light_max ? light : heavy));
+}
+static void tile_costs(const omh_gemm_args& a, float& cost_big, float& cost_small) {
+    const int64_t big_tiles = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) * a.batch;
+    const int64_t mid_tiles = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
+    const float k = (float)a.K * (1.0f / 1536.0f);
+    cost_big = round_cost(big_tiles, 256, 192, 9.0f + 27.5f * k, 9.0f + 32.0f * k);
+    cost_small = round_cost(mid_tiles, 512, 160, 4.0f + 15.5f * k, 5.0f + 21.0f * k);
+}
+
 template <int EPI, bool BKM = false>
 int launch(const omh_gemm_args& a, hipStream_t s) {
     // Tile configuration by estimated time = sum over the rounds the tiles take on the chip, with per-round times
@@ -396,13 +409,8 @@ int launch(const omh_gemm_args& a, hipStream_t s) {
     static const char* rule = getenv("OMH_GEMM_RULE");         // "old": the former rule, for A/B timing on one box
     if (rule && rule[0] == 'o')
         return big_tiles >= 256 ? launch_cfg<EPI, 2, 4, 4, 2, 2, BKM>(a, s) : launch_cfg<EPI, 2, 2, 2, 2, 2, BKM>(a, s);
-    const float k = (float)a.K * (1.0f / 1536.0f);
-    auto cost = [](int64_t tiles, int64_t slots, int64_t light_max, float light, float heavy) {
-        const int64_t full = tiles / slots, last = tiles % slots;
-        return (float)full * heavy + (last == 0 ? 0.0f : (last <= light_max ? light : heavy));
-    };
-    const float cost_big = cost(big_tiles, 256, 192, 9.0f + 27.5f * k, 9.0f + 32.0f * k);
-    const float cost_small = cost(mid_tiles, 512, 160, 4.0f + 15.5f * k, 5.0f + 21.0f * k);
+    float cost_big, cost_small;
+    tile_costs(a, cost_big, cost_small);
     if (cost_big <= cost_small) return launch_cfg<EPI, 2, 4, 4, 2, 2, BKM>(a, s);
     return launch_cfg<EPI, 2, 2, 2, 2, 2, BKM>(a, s);
 }
@@ -459,9 +467,19 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
         if (!never && omh_gemm_w64_takes(a)) {
             // (a ragged last tile column stays in this kernel, masked: handing N % 384 = 128 columns of the FFN's 8960
             // to the 8-wave kernel as a second launch measured 778 us against 757 us)
+            // Rounds of 256 persistent workgroups at 10 + 47 K/1536 us per tile (57 us at K = 1536; a last round of
+            // <= 128 tiles 0.8 of that) against the 8-wave kernels' model — whose full rounds at large K cost
+            // 8 + 36 K/1536 us when compared here (tools/gemm_dispatch_probe.py: 15 shapes of the training step, config 4,
+            // config 5 and the teacher pair); at least half a round of tiles.
             const int64_t tiles = (int64_t)((a.M + 255) / 256) * ((a.N + 383) / 384);
-            const int64_t rounds = (tiles + 255) / 256;
-            if (force || (tiles >= 256 && (rounds >= 4 || tiles * 4 >= rounds * 256 * 3))) {
+            const float kk = (float)a.K * (1.0f / 1536.0f);
+            float cost_big, cost_small;
+            tile_costs(a, cost_big, cost_small);
+            const int64_t big_tiles = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256);
+            cost_big = round_cost(big_tiles, 256, 192, 9.0f + 27.5f * kk, 8.0f + 36.0f * kk);
+            const float tw = 10.0f + 47.0f * kk;
+            const float cost_w64 = round_cost(tiles, 256, 128, 0.8f * tw, tw);
+            if (force || (tiles >= 128 && cost_w64 < fminf(cost_big, cost_small))) {
                 omh_clear_status();
                 omh_launch_gemm_w64(a, s);
                 return omh_launch_status();
