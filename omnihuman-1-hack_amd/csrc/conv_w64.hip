@@ -1,0 +1,179 @@
+// The VAE's 3x3(x3) "same" convolutions (vae.py:17-36 under the ResidualBlocks of :186-220) on one wave per SIMD: 4 waves,
+// each a 128(voxels) x 96(couts) patch, three LDS stages, the stage loop and the epilogue a generated instruction
+// stream (gen_conv_w64.py -> conv_w64_asm.inc; read its header).  Same contract and the same values, bit for bit, as
+// vae_conv.hip's conv_cl_kw3_kernel for the layers it takes (omh_conv_w64_takes); this file computes the per-lane
+// address table, the descriptors and the scalar arguments.
+#include "omh_common.h"
+#include "conv_w64_asm.inc"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int STAGE = 53312, A_OFF = 64;                  // [64 pad | A slab | B tile | 2 KiB sink], 3 stages
+enum { CFG_P = 0, CFG_Q = 1 };                            // 512 x 96 (Cout = 96) / 256 x 192 (Cout % 192 == 0)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, int64_t bytes) {
+    const uint32_t n = bytes <= 0 ? 0u : (bytes > 0xffffffffLL ? 0xffffffffu : (uint32_t)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)n, 0x00020000);
+}
+__device__ __forceinline__ uint64_t pack2(uint32_t lo, uint32_t hi) {
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)lo) |
+           ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32);
+}
+__device__ __forceinline__ uint32_t a3_addr(int row, int slot) {      // [rows][32 ch]: 64-byte rows, 4 slots
+    return (uint32_t)(row * 64 + ((slot ^ ((row >> 2) & 3)) << 4));
+}
+
+template <int CFG, bool OUT_F32>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void conv_cl_w64_kernel(const omh_conv_args p, const int tiles_m, const int tiles_n) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * STAGE];
+    constexpr int WBM = CFG == CFG_P ? 512 : 256, WBN = CFG == CFG_P ? 96 : 192, VM = WBM - 2;
+    constexpr int A_BYTES = WBM * 64;
+    constexpr int NA = CFG == CFG_P ? 8 : 4, NB = CFG == CFG_P ? 5 : 9;
+    constexpr int ES = OUT_F32 ? 4 : 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = CFG == CFG_P ? w : (w >> 1), wn = CFG == CFG_P ? 0 : (w & 1);
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int wid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int tm, tn;
+    tile_of(wid, tiles_m, tiles_n, tm, tn);
+    const int M = p.Tout * p.Hout * p.Wout;
+    const int vbase = tm * VM - 1;                                    // voxel of slab row 0 / tile row 0
+    const int n0 = tn * WBN;
+    const int K = p.KT * 9 * p.Cin;
+    const int HW = p.Hin * p.Win;
+
+    typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+    uint32_t* tab = (uint32_t*)smem + tid * 44;                       // this lane's table (gen_conv_w64.py's v[12:55])
+
+    // A staging: piece q of this wave = slab rows 16 (first + q) .. +15; lane -> row lane >> 2, physical 16-byte slot
+    // lane & 3, fetched from the logical slot (lane & 3) ^ ((row >> 2) & 3) = channels 8 slot .. +7 of the block
+    const int a_first = (CFG == CFG_P ? 8 : 4) * w;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        uint32_t off2 = 0, ay = (uint32_t)-16384;
+        if (q < NA) {
+            const int row = (a_first + q) * 16 + (lane >> 2);
+            const int ls = (lane & 3) ^ ((row >> 2) & 3);
+            const int v = vbase + row;
+            const bool ok = v >= 0 && v < M;
+            const int vc = min(max(v, 0), M - 1);
+            const int xo = vc % p.Wout, yo = (vc / p.Wout) % p.Hout, to = vc / (p.Wout * p.Hout);
+            off2 = (uint32_t)(((to * HW + xo) * p.Cin + ls * 8) * 2);
+            ay = ok ? (uint32_t)(yo - p.pad_h) : (uint32_t)-16384;   // rows outside the volume never pass the bounds test
+        }
+        tab[q] = off2;
+        tab[8 + q] = ay;
+    }
+    // B staging: 16-byte chunk c of the tile -> cout row c / 12, physical slot c % 12; logical slot = tap kw (slot >> 2)
+    // and 8-channel group (slot & 3).  P: 18 pieces, wave w takes 4 w .. 4 w + 3 and 16 + w (w < 2; the others' fifth
+    // piece goes to the sink with an out-of-range source); Q: 36 pieces, 9 per wave.
+    uint32_t blast_rel;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        uint32_t woff = 0x80000000u;
+        if (q < NB) {
+            int pb = CFG == CFG_P ? (q < 4 ? 4 * w + q : (w < 2 ? 16 + w : -1)) : 9 * w + q;
+            if (pb >= 0) {
+                const int c = pb * 64 + lane;
+                const int row = c / 12, ps = c - row * 12;
+                const int ls = ps ^ ((row >> 2) & 3);
+                const int kw = ls >> 2, c8 = ls & 3;
+                if (row < WBN && n0 + row < p.Cout) woff = (uint32_t)((((int64_t)(n0 + row)) * K + kw * p.Cin + c8 * 8) * 2);
+            }
+        }
+        tab[16 + q] = woff;
+    }
+    if (CFG == CFG_P) blast_rel = w < 2 ? (uint32_t)(A_OFF + A_BYTES + (16 + w) * 1024) : (uint32_t)(A_OFF + A_BYTES + 18432 + (w - 2) * 1024);
+    else blast_rel = (uint32_t)(A_OFF + A_BYTES + (9 * w + 8) * 1024);
+    // fragment addresses (buffer 0): voxel tile j adds 2048, cout tile i adds 6144, tap kw of the weights adds 64
+    {
+        const int r = wm * 128 + li;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+                tab[25 + 2 * kw + half] = lds0 + A_OFF + a3_addr(r + kw - 1, 2 * half + lh);
+        const int row = wn * 96 + li;
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+            tab[31 + half] = lds0 + A_OFF + A_BYTES + (uint32_t)(row * 192) + (uint32_t)((((2 * half + lh) ^ ((row >> 2) & 3))) << 4);
+    }
+    uint32_t rowmask = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int t = wm * 128 + 32 * j + li;
+        const int v = vbase + t;
+        const int xo = (v >= 0 && v < M) ? v % p.Wout : 1;
+        tab[33 + j] = xo == 0 ? 0u : 0xffffffffu;                     // no x - 1 neighbour
+        tab[37 + j] = xo == p.Wout - 1 ? 0u : 0xffffffffu;            // no x + 1 neighbour
+        if (t >= 1 && t <= WBM - 2) rowmask |= 1u << j;               // rows 0 and WBM - 1 of a tile are dropped
+    }
+    tab[41] = (uint32_t)(((int64_t)(vbase + wm * 128 + li) * p.Cout + n0 + wn * 96 + 8 * lh) * ES);   // < 0: outside the descriptor
+    tab[42] = rowmask;
+    tab[43] = 0;
+    const uint32_t vtab = lds0 + (uint32_t)tid * 176u;
+
+    const __amdgpu_buffer_rsrc_t rx = rsrc_of(p.x, (int64_t)p.Tin * HW * p.Cin * 2);
+    const __amdgpu_buffer_rsrc_t rw = rsrc_of(p.w, (int64_t)p.Cout * K * 2);
+    const __amdgpu_buffer_rsrc_t ry = rsrc_of(p.y, (int64_t)M * p.Cout * ES);
+    const __amdgpu_buffer_rsrc_t rres = rsrc_of(p.resid, p.resid ? (int64_t)M * p.Cout * ES : 0);
+    const int col0 = n0 + wn * 96;
+    const __amdgpu_buffer_rsrc_t rbias = rsrc_of(p.bias ? p.bias + col0 : nullptr, p.bias ? (int64_t)(p.Cout - col0) * 4 : 0);
+
+    const int cblocks = p.Cin >> 5;
+    const uint64_t p0 = pack2(lds0 + A_OFF + (uint32_t)(a_first * 1024),
+                              lds0 + A_OFF + A_BYTES + (uint32_t)((CFG == CFG_P ? 4 : 9) * w * 1024));
+    const uint64_t p1 = pack2((uint32_t)(p.Win * p.Cin * 2), (uint32_t)p.Hin);
+    const uint64_t p2 = pack2((uint32_t)cblocks, (uint32_t)(p.KT * 3 * cblocks));
+    const uint64_t p3 = pack2((uint32_t)(HW * p.Cin * 2), (uint32_t)(64 - p.Cin * 2));
+    const uint64_t p4 = pack2((uint32_t)(4 * p.Cin + 64), lds0 + blast_rel);
+    const uint64_t p5 = pack2((uint32_t)(32 * p.Cout * ES), 0u);
+    const uint64_t p6 = pack2(0u, 0u);
+
+#define OMH_CW64_RUN(ASM)                                                                                              \
+    asm volatile(ASM                                                                                                   \
+                 :                                                                                                     \
+                 : [vtab] "v"(vtab), [rx] "s"(rx), [rw] "s"(rw), [ry] "s"(ry), [rres] "s"(rres), [rbias] "s"(rbias),   \
+                   [p0] "{s[60:61]}"(p0), [p1] "{s[62:63]}"(p1), [p2] "{s[64:65]}"(p2), [p3] "{s[66:67]}"(p3),          \
+                   [p4] "{s[68:69]}"(p4), [p5] "{s[70:71]}"(p5), [p6] "{s[72:73]}"(p6)                                  \
+                 : OMH_CONV_W64_CLOBBERS)
+    if (CFG == CFG_P) { if (OUT_F32) OMH_CW64_RUN(OMH_CONV_W64_ASM_P_F32); else OMH_CW64_RUN(OMH_CONV_W64_ASM_P_BF16); }
+    else { if (OUT_F32) OMH_CW64_RUN(OMH_CONV_W64_ASM_Q_F32); else OMH_CW64_RUN(OMH_CONV_W64_ASM_Q_BF16); }
+#undef OMH_CW64_RUN
+}
+
+template <int CFG, bool OUT_F32>
+int launch_cw64(const omh_conv_args& a, int64_t M, hipStream_t s) {
+    constexpr int WBM = CFG == CFG_P ? 512 : 256, WBN = CFG == CFG_P ? 96 : 192;
+    const int tiles_m = (int)((M + WBM - 3) / (WBM - 2)), tiles_n = a.Cout / WBN;
+    omh_clear_status();
+    hipLaunchKernelGGL((conv_cl_w64_kernel<CFG, OUT_F32>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n);
+    return omh_launch_status();
+}
+
+}  // namespace
+
+// 3x3 taps in (h, w), 1 or 3 in t, stride 1, "same" padding, no folded upsample / frame interleave, Cin % 32 == 0,
+// Cout = 96 or a multiple of 192, at least 3 stages, the residual (if any) in the output's type, 32-bit byte offsets.
+bool omh_conv_w64_takes(const omh_conv_args& a) {
+    const int64_t M = (int64_t)a.Tout * a.Hout * a.Wout;
+    const int es = a.out_f32 ? 4 : 2;
+    return a.KW == 3 && a.KH == 3 && (a.KT == 3 || a.KT == 1) && a.stride_hw == 1 && a.stride_t == 1 && !a.up2 &&
+           a.pad_h == 1 && a.pad_w == 1 && a.Hout == a.Hin && a.Wout == a.Win && (a.Cin & 31) == 0 && a.split_n == 0 &&
+           a.Wout >= 3 && (a.Cout == 96 || a.Cout % 192 == 0) && a.KT * 3 * (a.Cin >> 5) >= 3 &&
+           (!a.resid || (a.resid_f32 != 0) == (a.out_f32 != 0)) && (((uintptr_t)a.resid) & 15) == 0 &&
+           (((uintptr_t)a.bias) & 15) == 0 && (int64_t)a.Win * a.Cin * 2 < (1 << 24) && a.Hin < 16384 &&
+           (M + 1024) * a.Cout * es < 0x7fffffffLL && (int64_t)a.Tin * a.Hin * a.Win * a.Cin * 2 < 0x7fffffffLL &&
+           (int64_t)a.Cout * a.KT * 9 * a.Cin * 2 < 0x7fffffffLL;
+}
+
+int omh_launch_conv_w64(const omh_conv_args& a, hipStream_t s) {
+    const int64_t M = (int64_t)a.Tout * a.Hout * a.Wout;
+    if (a.Cout == 96) return a.out_f32 ? launch_cw64<CFG_P, true>(a, M, s) : launch_cw64<CFG_P, false>(a, M, s);
+    return a.out_f32 ? launch_cw64<CFG_Q, true>(a, M, s) : launch_cw64<CFG_Q, false>(a, M, s);
+}

@@ -1,0 +1,385 @@
+#!/usr/bin/env python3
+"""Generator of the instruction streams of ``conv_cl_w64_kernel`` (conv_w64.hip): the kw-shared 3x3(x3) "same"
+convolution of the VAE's residual blocks (vae.py:17-36 under :186-220) as ONE wave per SIMD — 4 waves, each a
+128(voxels) x 96(couts) patch = 4 x 3 MFMA tiles, the 192 fp32 accumulators in AGPRs — on the same staging scheme as
+``conv_cl_kw3_kernel`` (vae_conv.hip: a stage = one (kt, kh) tap pair x one 32-channel block for all three kw taps;
+A slab [WBM voxels][32 ch] fetched once, B tile [WBN couts][3 x 32]), with THREE stages in LDS.
+
+Why: the 8-wave kernel has 36 MFMAs per wave between two barriers and waits for a stage's DMA one stage after issuing
+it; it runs at 0.30 of the MFMA peak although its bytes per flop allow > 0.8.  Here a stage is 72 MFMAs per wave,
+its 13 LDS-DMA pieces per wave are issued TWO stages ahead, spread between the MFMAs, and the fragment reads carry
+exact lgkmcnt waits (gen_gemm_w64.py has the same design for the GEMM).
+
+    python gen_conv_w64.py > conv_w64_asm.inc
+
+Two tile configurations share the per-wave code: P = 512 x 96 (4 waves stacked along the voxels; NA = 8 A pieces and
+NB = 5 B pieces per wave and stage), Q = 256 x 192 (2 x 2 waves; NA = 4, NB = 9).  Stage layout (53 312 bytes):
+[64 pad | A slab | B tile | 2 KiB sink for the disabled pieces]; output row j of a strip reads slab rows j-1, j, j+1
+(the pad is row -1 of the slab), rows 0 and WBM-1 of a tile are computed and dropped (tiles advance by WBM-2 voxels),
+the x neighbours of an image row's end voxels are zeroed with per-lane AND words.  Per-lane constants come from a
+table the C++ prologue writes to LDS (44 dwords per lane: inline asm takes 30 operands).
+
+Accumulation order per output element = conv_cl_kw3_kernel's (stages in (kt, kh, channel block) order, groups kw-major,
+one v_mfma_f32_32x32x16_bf16 per 16 channels), the epilogue adds bias then residual as wide_epilogue does: the two
+kernels agree bit for bit.
+
+Register map: a[0:191] accumulators (tile = 4 i + j, i = cout tile, j = voxel tile); v[12:55] the lane table
+(a_off2[8] a_y[8] w_off[9] xaddr[kw][half] waddr[half] edge0[4] edge2[4] voc rowmask); v[56:83] / v[84:111] fragment
+buffers (3 W + 4 X quads); v[112:119] DMA temporaries; epilogue: v[56:71] tile values, v[120:167] bias runs,
+v[168:215] ring of three residual tiles.  s[60:73] scalar arguments, s[80:99] state and scratch.
+"""
+import sys
+
+NI, NJ = 3, 4
+STAGE = 53312
+NSTAGES = 3
+KINDS = ("bf16", "f32")
+CONFIGS = {"P": (8, 5), "Q": (4, 9)}
+
+# scalar arguments (pairs bound to s[60:73] by conv_w64.hip)
+S_LDSA0, S_LDSB0, S_ROWB, S_HIN, S_CBLK, S_NS, S_FRAME = "s60", "s61", "s62", "s63", "s64", "s65", "s66"
+S_CWRAPA, S_CWRAPW, S_BLAST, S_JSTEP, S_SPARE0, S_SPARE1, S_SPARE2 = "s67", "s68", "s69", "s70", "s71", "s72", "s73"
+# state: s80 LDS offset of the buffer being FETCHED, s81 / s82 source offsets of the A / B stage being fetched,
+# s83 channel block, s84 kh, s85 loop counter, s[86:87] exec save, s89 compute buffer
+# index, s90 / s91 piece bases, s92..s95 temporaries, s97 / s98 stage step constants
+A_OFF2, A_Y, W_OFF, XADDR, WADDR, EDGE0, EDGE2, VOC, ROWMASK = 12, 20, 28, 37, 43, 45, 49, 53, 54
+FRAG = (56, 84)
+TMP = 112
+T = 56
+BIASV = 120
+RING = 168
+
+
+def vr(lo, n=1):
+    return f"v{lo}" if n == 1 else f"v[{lo}:{lo + n - 1}]"
+
+
+def acc(i, j):
+    t = i * NJ + j
+    return f"a[{t * 16}:{t * 16 + 15}]"
+
+
+def wfrag(buf, i):
+    return FRAG[buf] + 4 * i
+
+
+def xfrag(buf, j):
+    return FRAG[buf] + 12 + 4 * j
+
+
+class Emit:
+    def __init__(self, tag):
+        self.lines, self.tag = [], tag
+
+    def __call__(self, s):
+        self.lines.append(s)
+
+    def lab(self, name):
+        return f".Lcw64{self.tag}_{name}_%="
+
+    def label(self, name):
+        self.lines.append(f"{name}:")
+
+    def text(self):
+        return "\n".join('    "%s\\n\\t"' % ln for ln in self.lines)
+
+
+def linearize(e, ops, pending):
+    """ops: ("r", tag, text) LDS read; ("m", text, [tags]) instruction that needs those reads landed; ("x", text)."""
+    pending = list(pending)
+    for op in ops:
+        if op[0] == "r":
+            e(op[2])
+            pending.append(op[1])
+        elif op[0] == "m":
+            need = [t for t in op[2] if t in pending]
+            if need:
+                last = max(pending.index(t) for t in need)
+                allowed = len(pending) - last - 1
+                assert allowed <= 15, allowed
+                e(f"s_waitcnt lgkmcnt({allowed})")
+                pending = pending[last + 1:]
+            e(op[1])
+        else:
+            e(op[1])
+    return pending
+
+
+def frag_reads(G, buf):
+    """The 3 W + 4 X fragment reads of group G (tap kw = G >> 1, 16-channel half G & 1) from the buffer the address
+    registers point at."""
+    kw, half = G >> 1, G & 1
+    out = []
+    for i in range(NI):
+        out.append(("r", f"W{buf}.{i}", f"ds_read_b128 {vr(wfrag(buf, i), 4)}, {vr(WADDR + half)} offset:{kw * 64 + i * 6144}"))
+    for j in range(NJ):
+        out.append(("r", f"X{buf}.{j}", f"ds_read_b128 {vr(xfrag(buf, j), 4)}, {vr(XADDR + 2 * kw + half)} offset:{j * 2048}"))
+    return out
+
+
+def group_ops(G, buf, first=False):
+    """MFMAs of group G, voxel tile major; the dx = -1 / +1 taps first AND the voxel fragment with the lane's edge
+    word (an image row's end voxels have no such neighbour)."""
+    kw = G >> 1
+    out = []
+    for j in range(NJ):
+        if kw != 1:
+            m = (EDGE0 if kw == 0 else EDGE2) + j
+            for r_ in range(4):
+                out.append(("m", f"v_and_b32 v{xfrag(buf, j) + r_}, v{m}, v{xfrag(buf, j) + r_}", [f"X{buf}.{j}"]))
+            out.append(("x", "s_nop 1"))
+        for i in range(NI):
+            c = "0" if first else acc(i, j)
+            out.append(("m", f"v_mfma_f32_32x32x16_bf16 {acc(i, j)}, {vr(wfrag(buf, i), 4)}, {vr(xfrag(buf, j), 4)}, {c}",
+                        [f"W{buf}.{i}", f"X{buf}.{j}"]))
+    return out
+
+
+def dma_pieces(NA, NB):
+    """The 13 LDS-DMA pieces of the stage (s83 channel block, s84 kh, offsets s81 / s82) into the buffer at s80; then
+    the scalar state moves on to the next stage.  Returns a list of op lists."""
+    out = [[("x", f"s_add_u32 s90, s80, {S_LDSA0}"), ("x", f"s_add_u32 s91, s80, {S_LDSB0}")]]
+    for q in range(NA):
+        t = TMP + (q & 3)
+        out.append([("x", f"v_add_u32 v{t}, s84, v{A_Y + q}"),                       # input row of the tap
+                    ("x", f"v_cmp_gt_u32 vcc, {S_HIN}, v{t}"),                      # inside the image (unsigned)
+                    ("x", f"v_mad_u32_u24 v{t}, v{t}, {S_ROWB}, v{A_OFF2 + q}"),
+                    ("x", f"v_cndmask_b32 v{t}, v{TMP + 4}, v{t}, vcc"),            # outside: beyond the descriptor -> zeros
+                    ("x", f"s_add_u32 m0, s90, {q * 1024}"),
+                    ("x", f"buffer_load_dwordx4 v{t}, %[rx], s81 offen lds")])
+    for q in range(NB):
+        m0 = f"s_add_u32 m0, s80, {S_BLAST}" if q == NB - 1 else f"s_add_u32 m0, s91, {q * 1024}"
+        out.append([("x", m0), ("x", f"buffer_load_dwordx4 v{W_OFF + q}, %[rw], s82 offen lds")])
+    out.append([("x", "s_add_u32 s83, s83, 1"),
+                ("x", f"s_cmp_eq_u32 s83, {S_CBLK}"),                               # last channel block of the tap pair
+                ("x", "s_cselect_b32 s83, 0, s83"),
+                ("x", f"s_cselect_b32 s92, {S_CWRAPA}, 64"),
+                ("x", f"s_cselect_b32 s93, {S_CWRAPW}, 64"),
+                ("x", "s_cselect_b32 s94, 1, 0"),
+                ("x", "s_add_u32 s81, s81, s92"),
+                ("x", "s_add_u32 s82, s82, s93"),
+                ("x", "s_add_u32 s84, s84, s94"),
+                ("x", "s_cmp_eq_u32 s84, 3"),                                       # next frame tap
+                ("x", "s_cselect_b32 s84, 0, s84"),
+                ("x", f"s_cselect_b32 s92, {S_FRAME}, 0"),
+                ("x", "s_add_u32 s81, s81, s92"),
+                ("x", f"s_add_u32 s80, s80, {STAGE}"),
+                ("x", f"s_cmp_eq_u32 s80, {NSTAGES * STAGE}"),
+                ("x", "s_cselect_b32 s80, 0, s80")])
+    return out
+
+
+def spread(mops, extras, lo=0, hi=None):
+    """Insert the op lists `extras` evenly after the MFMAs (not the ANDs) of `mops`, MFMA index in [lo, hi)."""
+    idx = [k for k, op in enumerate(mops) if op[0] == "m" and "v_mfma" in op[1]]
+    hi = len(idx) if hi is None else hi
+    n = hi - lo
+    slots = {}
+    for k, ex in enumerate(extras):
+        pos = idx[lo + min(n - 1, (k * n) // max(1, len(extras)))]
+        slots.setdefault(pos, []).extend(ex)
+    out = []
+    for k, op in enumerate(mops):
+        out.append(op)
+        out.extend(slots.get(k, []))
+    return out
+
+
+def advance(e):
+    """Fragment addresses to the next buffer (s89 = index of the buffer they point at)."""
+    e("s_add_u32 s89, s89, 1")
+    e(f"s_cmp_eq_u32 s89, {NSTAGES}")
+    e("s_cselect_b32 s89, 0, s89")
+    e("s_cselect_b32 s92, s98, s97")                             # back to buffer 0 / one stage up
+    for r_ in range(XADDR, XADDR + 8):
+        e(f"v_add_u32 v{r_}, s92, v{r_}")
+
+
+def main_loop(e, NA, NB):
+    NP = NA + NB
+    # the lane table, written to LDS by the C++ prologue
+    for k in range(11):
+        e(f"ds_read_b128 {vr(12 + 4 * k, 4)}, %[vtab] offset:{16 * k}")
+    e(f"v_mov_b32 v{TMP + 4}, 0x80000000")                        # an offset outside every descriptor
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_barrier")                                               # the stages overwrite the table
+    for s_, v_ in (("s80", 0), ("s81", 0), ("s82", 0), ("s83", 0), ("s84", 0), ("s89", 0), ("s97", STAGE),
+                   ("s98", (-(NSTAGES - 1) * STAGE) & 0xffffffff)):
+        e(f"s_mov_b32 {s_}, {v_}")
+    pieces = dma_pieces(NA, NB)
+    for _ in range(2):                                           # stages 0 and 1
+        for ops in pieces:
+            for op in ops:
+                e(op[1])
+    e(f"s_waitcnt vmcnt({NP})")                                  # stage 0 has landed
+    e("s_barrier")
+    LOOP_PENDING = linearize(e, frag_reads(0, 0), [])
+    e(f"s_sub_u32 s85, {S_NS}, 2")                               # steps that fetch a stage two ahead (>= 1)
+
+    def body(mode, first=False):
+        """One stage = 6 groups of 12 MFMAs.  Groups 0..4: MFMAs || reads of the next group || (mode "full") the 13
+        DMA pieces of the stage two ahead.  Then: the NEXT stage has landed (counted vmcnt), barrier (every wave has
+        read this stage), addresses advance, group 5 || reads of the next stage's group 0.  mode "last": the final
+        stage, nothing to wait for or read ahead."""
+        pend = LOOP_PENDING
+        dm = pieces if mode == "full" else []
+        per = [dm[0:4], dm[4:7], dm[7:10], dm[10:13], dm[13:]] if dm else [[]] * 5
+        for G in range(5):
+            mo = group_ops(G, G & 1, first=(first and G == 0))
+            reads = [[r] for r in frag_reads(G + 1, (G + 1) & 1)]
+            ops = spread(mo, reads, 0, 8)
+            ops = spread_keep(ops, per[G])
+            pend = linearize(e, ops, pend)
+        if mode == "last":
+            linearize(e, group_ops(5, 1), pend)
+            return
+        e(f"s_waitcnt vmcnt({NP if mode == 'full' else 0})")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_barrier")
+        advance(e)
+        reads = [[r] for r in frag_reads(0, 0)]
+        pend = linearize(e, spread(group_ops(5, 1), reads, 0, 10), [])
+        assert pend == LOOP_PENDING, (pend, LOOP_PENDING)
+
+    LOOP = e.lab("loop")
+    REST = e.lab("rest")
+    body("full", first=True)
+    e("s_sub_u32 s85, s85, 1")
+    e("s_cmp_eq_u32 s85, 0")
+    e(f"s_cbranch_scc1 {REST}")
+    e.label(LOOP)
+    body("full")
+    e("s_sub_u32 s85, s85, 1")
+    e("s_cmp_lg_u32 s85, 0")
+    e(f"s_cbranch_scc1 {LOOP}")
+    e.label(REST)
+    body("nodma")
+    body("last")
+    for _ in range(3):
+        e("s_nop 7")                                             # last MFMA results readable by VALU
+
+
+def spread_keep(ops, extras):
+    """Insert op lists `extras` after MFMAs 2, 5, 8, 11 ... of an already interleaved op list."""
+    if not extras:
+        return ops
+    idx = [k for k, op in enumerate(ops) if op[0] == "m" and "v_mfma" in op[1]]
+    n = len(idx)
+    slots = {}
+    for k, ex in enumerate(extras):
+        pos = idx[min(n - 1, 1 + (k * n) // len(extras))]
+        slots.setdefault(pos, []).extend(ex)
+    out = []
+    for k, op in enumerate(ops):
+        out.append(op)
+        out.extend(slots.get(k, []))
+    return out
+
+
+# ---------------------------------------------------------------- epilogue
+NTILES = NI * NJ
+
+
+def res_loads(e, n, kind):
+    """Residual values of tile n = 3 j + i -> ring slot n % 3 (v117 = the lane's offset in its row block: the row block
+    goes in the VGPR, not in the soffset, because the range check sees only voffset + inst_offset and tile 0's lane of
+    row -1 must be out of range for j = 0 ONLY)."""
+    i = n % NI
+    es = 2 if kind == "bf16" else 4
+    for p in range(2):
+        if kind == "bf16":
+            e(f"buffer_load_dwordx4 {vr(RING + (n % 3) * 16 + p * 4, 4)}, v117, %[rres], 0 offen offset:{(i * 32 + 16 * p) * es}")
+        else:
+            for q in range(2):
+                e(f"buffer_load_dwordx4 {vr(RING + (n % 3) * 16 + p * 8 + q * 4, 4)}, v117, %[rres], 0 offen "
+                  f"offset:{(i * 32 + 16 * p) * es + q * 16}")
+
+
+def epilogue(e, kind):
+    """y = acc + bias (+ residual), bf16 or fp32 (wide_epilogue's order).  After the permlane widening lane (r, h)
+    holds, per tile (i, j) and run p, the 8 couts 32 i + 16 p + 8 h .. of voxel row 32 j + r of the wave's patch."""
+    es = 2 if kind == "bf16" else 4
+    per_tile = 2 if kind == "bf16" else 4                        # VMEM instructions per tile, loads and stores alike
+    e("v_mbcnt_lo_u32_b32 v112, -1, 0")
+    e("v_mbcnt_hi_u32_b32 v112, -1, v112")                       # lane
+    e("v_lshrrev_b32 v112, 5, v112")
+    e("v_lshlrev_b32 v112, 5, v112")                             # 32 h bytes = 8 h floats
+    for i in range(NI):
+        for p in range(2):
+            for q in range(2):
+                e(f"buffer_load_dwordx4 {vr(BIASV + (2 * i + p) * 8 + 4 * q, 4)}, v112, %[rbias], 0 offen "
+                  f"offset:{(32 * i + 16 * p) * 4 + 16 * q}")
+    e(f"v_mov_b32 v116, v{VOC}")                                 # store offset of the lane's row in row block j
+    e(f"v_mov_b32 v117, v{VOC}")                                 # the same for the residual loads, two tiles ahead
+    res_loads(e, 0, kind)
+    res_loads(e, 1, kind)
+    for n in range(NTILES):
+        j, i = divmod(n, NI)
+        t = i * NJ + j
+        if i == 0 and j:
+            e(f"v_add_u32 v116, {S_JSTEP}, v116")
+        if n + 2 < NTILES:
+            if (n + 2) % NI == 0:
+                e(f"v_add_u32 v117, {S_JSTEP}, v117")
+            res_loads(e, n + 2, kind)
+        for r_ in range(16):
+            e(f"v_accvgpr_read_b32 v{T + r_}, a{t * 16 + r_}")
+        e("s_nop 1")
+        for q0 in (0, 2):                                        # quads (0,1), (2,3) -> two runs of 8 consecutive couts
+            for r_ in range(4):
+                e(f"v_permlane32_swap_b32 v{T + 4 * q0 + r_}, v{T + 4 * (q0 + 1) + r_}")
+        # in issue order behind tile n's loads: S(n-2) L(n+1) S(n-1) L(n+2)  (the 12 bias loads are older)
+        behind = per_tile * ((n >= 2) + (n + 1 < NTILES) + (n >= 1) + (n + 2 < NTILES))
+        e(f"s_waitcnt vmcnt({behind})")
+        e(f"v_bfe_u32 v113, v{ROWMASK}, {j}, 1")                  # this lane's row of the strip is an output row
+        e("v_cmp_ne_u32 vcc, 0, v113")
+        e("s_and_saveexec_b64 s[86:87], vcc")
+        for p in range(2):
+            v0 = T + 8 * p
+            b0 = BIASV + (2 * i + p) * 8
+            r0 = RING + (n % 3) * 16 + (p * 4 if kind == "bf16" else p * 8)
+            for r_ in range(0, 8, 2):
+                e(f"v_pk_add_f32 {vr(v0 + r_, 2)}, {vr(v0 + r_, 2)}, {vr(b0 + r_, 2)}")
+            if kind == "bf16":
+                for r_ in range(4):                              # residual bf16 pairs -> fp32, added after the bias
+                    e(f"v_lshlrev_b32 v114, 16, v{r0 + r_}")
+                    e(f"v_and_b32 v115, 0xffff0000, v{r0 + r_}")
+                    e(f"v_pk_add_f32 {vr(v0 + 2 * r_, 2)}, {vr(v0 + 2 * r_, 2)}, v[114:115]")
+                for r_ in range(4):
+                    e(f"v_cvt_pk_bf16_f32 v{v0 + r_}, v{v0 + 2 * r_}, v{v0 + 2 * r_ + 1}")
+                e(f"buffer_store_dwordx4 {vr(v0, 4)}, v116, %[ry], 0 offen offset:{(i * 32 + 16 * p) * es}")
+            else:
+                for r_ in range(0, 8, 2):
+                    e(f"v_pk_add_f32 {vr(v0 + r_, 2)}, {vr(v0 + r_, 2)}, {vr(r0 + r_, 2)}")
+                e(f"buffer_store_dwordx4 {vr(v0, 4)}, v116, %[ry], 0 offen offset:{(i * 32 + 16 * p) * es}")
+                e(f"buffer_store_dwordx4 {vr(v0 + 4, 4)}, v116, %[ry], 0 offen offset:{(i * 32 + 16 * p) * es + 16}")
+        e("s_nop 1")
+        e("s_mov_b64 exec, s[86:87]")
+
+
+def generate(cfg, kind):
+    e = Emit(cfg + kind)
+    NA, NB = CONFIGS[cfg]
+    main_loop(e, NA, NB)
+    epilogue(e, kind)
+    return e
+
+
+def main():
+    print("// GENERATED by gen_conv_w64.py — do not edit; edit the generator.")
+    for cfg in CONFIGS:
+        for kind in KINDS:
+            e = generate(cfg, kind)
+            print(f"#define OMH_CONV_W64_ASM_{cfg}_{kind.upper()} \\")
+            print(" \\\n".join(e.text().split("\n")))
+            print("")
+            print(f"// {cfg} {kind}: {len(e.lines)} lines, {sum('v_mfma' in ln for ln in e.lines)} MFMA")
+    clob = ['"memory"', '"vcc"', '"scc"'] + [f'"s{i}"' for i in range(80, 100)] + [f'"v{i}"' for i in range(12, 256)] + \
+           [f'"a{i}"' for i in range(256)]
+    print("#define OMH_CONV_W64_CLOBBERS \\")
+    rows = [", ".join(clob[i:i + 12]) for i in range(0, len(clob), 12)]
+    print("    " + ", \\\n    ".join(rows))
+
+
+if __name__ == "__main__":
+    main()

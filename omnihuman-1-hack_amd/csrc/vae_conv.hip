@@ -696,6 +696,10 @@ int launch_kw3(const omh_conv_args& a, int64_t M, hipStream_t s) {
 
 }  // namespace
 
+// conv_w64.hip: the kw-shared convolution on one wave per SIMD, generated stage loop
+bool omh_conv_w64_takes(const omh_conv_args& a);
+int omh_launch_conv_w64(const omh_conv_args& a, hipStream_t s);
+
 extern "C" int omh_conv_cl_bf16(const omh_conv_args* args, omh_stream_t stream) {
     if (!args || !args->x || !args->w || !args->y) return OMH_E_BADARG;
     const omh_conv_args& a = *args;
@@ -719,6 +723,15 @@ extern "C" int omh_conv_cl_bf16(const omh_conv_args* args, omh_stream_t stream) 
     if (force && force[0] == 'w') wide = true;
     if (force && force[0] == 's') wide = false;
     if (((uintptr_t)a.resid & 15) || ((uintptr_t)a.bias & 3)) wide = false;
+    {
+        // the residual-block convolutions: the one-wave-per-SIMD stream kernel (same values as the kw-shared 8-wave
+        // kernel).  OMH_CONV_TILE=w64 forces it wherever it applies, wide / small exclude it, OMH_CONV_W64=0 turns it off.
+        const char* w64e = getenv("OMH_CONV_W64");
+        const bool w64_forced = force && force[0] == 'w' && force[1] == '6';
+        const bool w64_ok = !(w64e && w64e[0] == '0') && (w64_forced || (!force && wide));
+        if (w64_ok && omh_conv_w64_takes(a)) return omh_launch_conv_w64(a, (hipStream_t)stream);
+        if (w64_forced) wide = true;                                  // not taken: the wide kernels
+    }
     if (wide) {
         hipStream_t s = (hipStream_t)stream;
         // 3x3 "same" convolutions with stride 1 at >= 32 channels: the kw-shared kernel (3x less voxel traffic)

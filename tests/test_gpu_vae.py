@@ -35,10 +35,11 @@ def _bf(x):
     dict(Cin=96, Cout=3, T=2, H=14, W=19, KT=3, KH=3, KW=3),      # the decoder head: kw-shared kernel with a 32-column tile
     dict(Cin=32, Cout=32, T=1, H=8, W=70, KT=1, KH=3, KW=3),
 ])
-@pytest.mark.parametrize("tile", ["small", "wide", "wide-nokw3"])
+@pytest.mark.parametrize("tile", ["small", "wide", "wide-nokw3", "w64"])
 def test_conv_cl_matches_torch(ops, cfg, tile, monkeypatch):
     # every tile configuration on every shape: 128x128; wide tiles with the kw-shared kernel where it applies
-    # (3x3 taps, stride 1, Cin % 32 == 0); wide tiles without it
+    # (3x3 taps, stride 1, Cin % 32 == 0); wide tiles without it; the one-wave-per-SIMD stream kernel where IT applies
+    # (kw-shared shapes with Cout = 96 or a multiple of 192), the wide kernels elsewhere
     monkeypatch.setenv("OMH_CONV_TILE", tile.split("-")[0])
     monkeypatch.setenv("OMH_CONV_KW3", "0" if tile.endswith("nokw3") else "1")
     torch.manual_seed(cfg["Cin"] + cfg["Cout"])
@@ -63,6 +64,38 @@ def test_conv_cl_matches_torch(ops, cfg, tile, monkeypatch):
     yf = ops.conv_cl(x, wp, bias, T, H, W, Cout, KT, KH, KW, pad_h=KH // 2, pad_w=KW // 2, resid=rf, out_f32=True)
     assert rel_rms(yf, ref - resid.float() + rf) < 2e-5
     assert float((yf - rf - (y - resid.float())).abs().max()) < 1e-5        # same accumulators, only the residual differs
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(Cin=96, Cout=96, T=2, H=12, W=20, KT=3),        # P (512 x 96): one ragged tile, 27 stages
+    dict(Cin=96, Cout=96, T=3, H=24, W=27, KT=3),        # P: 1944 voxels = 3.8 tiles of 510
+    dict(Cin=32, Cout=96, T=3, H=17, W=20, KT=1),        # P: exactly two tiles, the minimum of 3 stages
+    dict(Cin=192, Cout=192, T=1, H=20, W=31, KT=3),      # Q (256 x 192)
+    dict(Cin=64, Cout=384, T=2, H=11, W=13, KT=3),       # Q: two cout tiles
+    dict(Cin=384, Cout=384, T=1, H=9, W=29, KT=3),       # Q: 12 channel blocks per tap pair
+    dict(Cin=96, Cout=192, T=4, H=30, W=52, KT=3),       # Q: 6240 voxels, 25 tiles (the decoder's first stage)
+])
+def test_conv_cl_w64_equals_the_kw_shared_kernel(ops, cfg, monkeypatch):
+    """conv_w64.hip's stream kernel against conv_cl_kw3_kernel on the same inputs: same accumulation order, same
+    epilogue arithmetic -> torch.equal, for bf16 / fp32 outputs with and without bias and residual."""
+    torch.manual_seed(cfg["Cin"] + cfg["Cout"] + cfg["H"])
+    Cin, Cout, T, H, W, KT = (cfg[k] for k in ("Cin", "Cout", "T", "H", "W", "KT"))
+    x = _bf(torch.randn(KT - 1 + T, H, W, Cin, device="cuda"))
+    wp = _bf(torch.randn(Cout, KT * 9 * Cin, device="cuda") / (Cin * KT * 9) ** 0.5)
+    bias = torch.randn(Cout, device="cuda")
+    rb, rf = _bf(torch.randn(T, H, W, Cout, device="cuda")), torch.randn(T, H, W, Cout, device="cuda")
+
+    def run(tile):
+        monkeypatch.setenv("OMH_CONV_TILE", tile)
+        kw = dict(pad_h=1, pad_w=1)
+        return (ops.conv_cl(x, wp, bias, T, H, W, Cout, KT, 3, 3, resid=rb, **kw),
+                ops.conv_cl(x, wp, None, T, H, W, Cout, KT, 3, 3, **kw),
+                ops.conv_cl(x, wp, bias, T, H, W, Cout, KT, 3, 3, resid=rf, out_f32=True, **kw),
+                ops.conv_cl(x, wp, bias, T, H, W, Cout, KT, 3, 3, out_f32=True, **kw))
+
+    got, ref = run("w64"), run("wide")
+    for g, r in zip(got, ref):
+        assert torch.isfinite(g.float()).all() and torch.equal(g, r)
 
 
 @pytest.mark.parametrize("tile", ["small", "wide"])
