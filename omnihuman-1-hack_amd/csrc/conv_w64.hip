@@ -27,6 +27,15 @@ __device__ __forceinline__ uint32_t a3_addr(int row, int slot) {      // [rows][
     return (uint32_t)(row * 64 + ((slot ^ SWZ(row)) << 4));
 }
 
+// v / d and v % d for 0 <= v < 2^24 through the float reciprocal (one correction step): the lane table needs ~40 of
+// them per tile, and the compiler's exact 32-bit division is ~35 instructions each
+__device__ __forceinline__ void divmod24(int v, int d, float rcp, int& q, int& r) {
+    q = (int)((float)v * rcp);
+    r = v - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) { ++q; r -= d; }
+}
+
 template <int CFG, bool OUT_F32>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void conv_cl_w64_kernel(const omh_conv_args p, const int tiles_m, const int tiles_n) {
@@ -49,6 +58,8 @@ void conv_cl_w64_kernel(const omh_conv_args p, const int tiles_m, const int tile
     const int K = p.KT * 9 * p.Cin;
     const int HW = p.Hin * p.Win;
 
+    const float rcp_w = 1.0f / (float)p.Wout, rcp_h = 1.0f / (float)p.Hout;
+
     typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
     uint32_t* tab = (uint32_t*)smem + tid * 44;                       // this lane's table (gen_conv_w64.py's v[12:55])
@@ -65,7 +76,9 @@ void conv_cl_w64_kernel(const omh_conv_args p, const int tiles_m, const int tile
             const int v = vbase + row;
             const bool ok = v >= 0 && v < M;
             const int vc = min(max(v, 0), M - 1);
-            const int xo = vc % p.Wout, yo = (vc / p.Wout) % p.Hout, to = vc / (p.Wout * p.Hout);
+            int xo, yo, to, vy;
+            divmod24(vc, p.Wout, rcp_w, vy, xo);
+            divmod24(vy, p.Hout, rcp_h, to, yo);
             off2 = (uint32_t)(((to * HW + xo) * p.Cin + ls * 8) * 2);
             ay = ok ? (uint32_t)(yo - p.pad_h) : (uint32_t)-16384;   // rows outside the volume never pass the bounds test
         }
@@ -111,7 +124,8 @@ void conv_cl_w64_kernel(const omh_conv_args p, const int tiles_m, const int tile
     for (int j = 0; j < 4; ++j) {
         const int t = wm * 128 + 32 * j + li;
         const int v = vbase + t;
-        const int xo = (v >= 0 && v < M) ? v % p.Wout : 1;
+        int xo = 1, vy;
+        if (v >= 0 && v < M) divmod24(v, p.Wout, rcp_w, vy, xo);
         tab[33 + j] = xo == 0 ? 0u : 0xffffffffu;                     // no x - 1 neighbour
         tab[37 + j] = xo == p.Wout - 1 ? 0u : 0xffffffffu;            // no x + 1 neighbour
         if (t >= 1 && t <= WBM - 2) rowmask |= 1u << j;               // rows 0 and WBM - 1 of a tile are dropped
@@ -170,7 +184,7 @@ bool omh_conv_w64_takes(const omh_conv_args& a) {
            a.pad_h == 1 && a.pad_w == 1 && a.Hout == a.Hin && a.Wout == a.Win && (a.Cin & 31) == 0 && a.split_n == 0 &&
            a.Wout >= 3 && (a.Cout == 96 || a.Cout % 192 == 0) && a.KT * 3 * (a.Cin >> 5) >= 3 &&
            (!a.resid || (a.resid_f32 != 0) == (a.out_f32 != 0)) && (((uintptr_t)a.resid) & 15) == 0 &&
-           (((uintptr_t)a.bias) & 15) == 0 && (int64_t)a.Win * a.Cin * 2 < (1 << 24) && a.Hin < 16384 &&
+           (((uintptr_t)a.bias) & 15) == 0 && (int64_t)a.Win * a.Cin * 2 < (1 << 24) && a.Hin < 16384 && M < (1 << 24) &&
            (M + 1024) * a.Cout * es < 0x7fffffffLL && (int64_t)a.Tin * a.Hin * a.Win * a.Cin * 2 < 0x7fffffffLL &&
            (int64_t)a.Cout * a.KT * 9 * a.Cin * 2 < 0x7fffffffLL;
 }

@@ -28,9 +28,11 @@ Register map: a[0:191] accumulators (tile = 4 i + j, i = cout tile, j = voxel ti
 buffers (3 W + 4 X quads); v[112:119] DMA temporaries; epilogue: v[56:71] tile values, v[120:167] bias runs,
 v[168:215] ring of three residual tiles.  s[60:73] scalar arguments, s[80:99] state and scratch.
 """
+import os
 import sys
 
 NI, NJ = 3, 4
+ABL = os.environ.get("OMH_CW64_ABL", "")     # timing-only ablations (wrong results): "dma", "and", "bar", "reads"
 STAGE = 53312
 NSTAGES = 3
 KINDS = ("bf16", "f32")
@@ -123,7 +125,7 @@ def group_ops(G, buf, first=False):
     kw = G >> 1
     out = []
     for j in range(NJ):
-        if kw != 1:
+        if kw != 1 and ABL != "and":
             m = (EDGE0 if kw == 0 else EDGE2) + j
             for r_ in range(4):
                 out.append(("m", f"v_and_b32 v{xfrag(buf, j) + r_}, v{m}, v{xfrag(buf, j) + r_}", [f"X{buf}.{j}"]))
@@ -222,20 +224,21 @@ def main_loop(e, NA, NB):
         read this stage), addresses advance, group 5 || reads of the next stage's group 0.  mode "last": the final
         stage, nothing to wait for or read ahead."""
         pend = LOOP_PENDING
-        dm = pieces if mode == "full" else []
+        dm = pieces if (mode == "full" and ABL != "dma") else []
         per = [dm[0:4], dm[4:7], dm[7:10], dm[10:13], dm[13:]] if dm else [[]] * 5
         for G in range(5):
             mo = group_ops(G, G & 1, first=(first and G == 0))
-            reads = [[r] for r in frag_reads(G + 1, (G + 1) & 1)]
+            reads = [[r] for r in frag_reads(G + 1, (G + 1) & 1)] if ABL != "reads" else []
             ops = spread(mo, reads, 0, 8)
             ops = spread_keep(ops, per[G])
             pend = linearize(e, ops, pend)
         if mode == "last":
             linearize(e, group_ops(5, 1), pend)
             return
-        e(f"s_waitcnt vmcnt({NP if mode == 'full' else 0})")
+        e(f"s_waitcnt vmcnt({NP if (mode == 'full' and ABL != 'dma') else 0})")
         e("s_waitcnt lgkmcnt(0)")
-        e("s_barrier")
+        if ABL != "bar":
+            e("s_barrier")
         advance(e)
         reads = [[r] for r in frag_reads(0, 0)]
         pend = linearize(e, spread(group_ops(5, 1), reads, 0, 10), [])
