@@ -2,7 +2,7 @@
 the wide-tile decode ([16,2,30,52] -> 5 frames 240x416) and a 9-frame encode, and time of the full 81-frame 480x832
 decode / encode.  Each mode in its own process (the switch is read at import)."""
 import importlib, os, subprocess, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def child():
