@@ -377,22 +377,38 @@ def main():
     if world > 1 or os.environ.get("OMH_FORCE_DIST"):      # OMH_FORCE_DIST: exercise the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL prints a version banner on stdout at communicator creation: keep stdout clean for the
-        # single JSON line by pointing fd 1 at stderr until the first collective has run
+        if world == 1:                                          # OMH_FORCE_DIST without a launcher: a one-rank group
+            for k_, v_ in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_PORT", "29533")):
+                os.environ.setdefault(k_, v_)
+        # RCCL prints a version banner on stdout whenever it creates a communicator (process-group init, and again
+        # lazily for the reducer's streams): fd 1 points at stderr for the whole run, the ONE JSON line is written
+        # to the saved descriptor at the end (emit()).
         sys.stdout.flush()
         saved_fd = os.dup(1)
         os.dup2(2, 1)
-        try:
-            if os.environ.get("OMH_DIST_BACKEND", "nccl") == "nccl":
-                dist.init_process_group("nccl", device_id=device)
-            else:                                               # gloo: several ranks on one GPU (validation only)
-                dist.init_process_group(os.environ["OMH_DIST_BACKEND"])
-            dist.barrier()
-            torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
+        if os.environ.get("OMH_DIST_BACKEND", "nccl") == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:                                               # gloo: several ranks on one GPU (validation only)
+            dist.init_process_group(os.environ["OMH_DIST_BACKEND"])
+        dist.barrier()
+        torch.cuda.synchronize()
+    else:
+        saved_fd = None
+
+    def emit(line):
+        """The one stdout line of the run (after every collective, so nothing of RCCL's can follow it)."""
+        sys.stdout.flush()
+        if saved_fd is not None:
+            if dist.is_initialized():
+                dist.barrier()
+                torch.cuda.synchronize()
+                dist.destroy_process_group()
+            import ctypes
+            ctypes.CDLL(None).fflush(None)                      # RCCL's banner sits in the C stdio buffer: out with it, to stderr
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
+        if line is not None:
+            print(line, flush=True)
 
     ops = importlib.import_module(PKG + ".ops")
     sched_mod = importlib.import_module(PKG + ".wan.utils.fm_solvers_unipc")
@@ -446,7 +462,8 @@ def main():
         return s
 
     if args.only_train:
-        print(json.dumps({"train": train_legs(model, device, world, dist)}), flush=True)
+        res_ = {"train": train_legs(model, device, world, dist)}
+        emit(json.dumps(res_) if rank == 0 else None)
         return
     sched = fresh_sched()
     x = run_steps(args.warmup, sched, latent)
@@ -575,9 +592,9 @@ def main():
                     "kernels": secondary},
             "single_frame": single, "vae": vae, "train": train, "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
-    if dist:
-        dist.destroy_process_group()
+        emit(json.dumps(out))
+    else:
+        emit(None)
 
 
 if __name__ == "__main__":
