@@ -28,9 +28,12 @@ def _vt(v, B, Lk, H, D):
     return vt
 
 
-def test_self_attention_full_size(ops, monkeypatch):
-    """One self-attention launch of the benchmark (12 heads x 32 760 x 32 760, D = 128; attention.py:96-127)."""
-    monkeypatch.setenv("OMH_ATTN_KERNEL", "pp")          # what the dispatch picks at this size; pinned for property (4)
+@pytest.mark.parametrize("kernel", ["w64", "pp"])
+def test_self_attention_full_size(ops, kernel, monkeypatch):
+    """One self-attention launch of the benchmark (12 heads x 32 760 x 32 760, D = 128; attention.py:96-127): the
+    generated stream kernel the dispatch picks at this size ("w64") and round 1's 8-wave kernel ("pp"); pinned so that
+    the query slice of property (4) runs the same kernel."""
+    monkeypatch.setenv("OMH_ATTN_KERNEL", kernel)
     torch.manual_seed(5)
     B, H, L, D = 1, 12, S_FULL, 128
     q = _bf(torch.randn(B, L, H, D, device="cuda"))
@@ -300,6 +303,26 @@ def test_self_attention_split_kv_tail_config4(ops, monkeypatch):
     assert float((lse[0, 11, rows] - torch.logsumexp(s, -1)).abs().max()) < 5e-3
     assert float((lse - ref_l).abs().max()) < 5e-3
     assert torch.equal(run("1")[0], out)                                   # repeatable
+
+
+@pytest.mark.parametrize("C,T,H,W", [(96, 4, 480, 832), (192, 4, 240, 416), (384, 5, 120, 208)])
+def test_vae_convolutions_full_size_stream_kernel_equals_8_wave_kernel(ops, C, T, H, W, monkeypatch):
+    """The decoder's residual-block convolutions at their real sizes (3 132 / 1 573 / 983 x 2 tiles): the stream kernel
+    (conv_w64.hip) returns the 8-wave kw-shared kernel's values bit for bit, fp32 trunk and bf16 outputs alike."""
+    torch.manual_seed(C)
+    x = _bf(torch.randn(2 + T, H, W, C, device="cuda"))
+    wp = _bf(torch.randn(C, 27 * C, device="cuda") / (27 * C) ** 0.5)
+    bias = torch.randn(C, device="cuda")
+    rf = torch.randn(T, H, W, C, device="cuda")
+
+    def run(tile):
+        monkeypatch.setenv("OMH_CONV_TILE", tile)
+        return (ops.conv_cl(x, wp, bias, T, H, W, C, 3, 3, 3, pad_h=1, pad_w=1),
+                ops.conv_cl(x, wp, bias, T, H, W, C, 3, 3, 3, pad_h=1, pad_w=1, resid=rf, out_f32=True))
+
+    got, ref = run("w64"), run("wide")
+    for g, r in zip(got, ref):
+        assert bool(torch.isfinite(g.float()).all()) and torch.equal(g, r)
 
 
 def test_vae_81_frames_against_oracle_quarter_area():
