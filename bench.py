@@ -331,14 +331,16 @@ def train_bench(model, device, world, dist, steps=4, warmup=2, bsz=4, ffn_freeze
 
 
 def train_legs(model, device, world, dist):
-    """The training legs of the line: B = 4 (primary, comparable across rounds) and B = 1 with the reference's
-    quirks, and B = 4 with both quirks off (every clip and every parameter trained).  OMH_TRAIN_BATCH overrides
+    """The training legs of the line: B = 4 (primary, comparable across rounds), B = 1 (the reference's default
+    --batch_size) and B = 16 with the reference's quirks, and B = 4 with both quirks off (every clip and every parameter trained).  OMH_TRAIN_BATCH overrides
     the primary batch size."""
     bsz = int(os.environ.get("OMH_TRAIN_BATCH", "4"))
     out = train_bench(model, device, world, dist, bsz=bsz)
     try:
         if bsz != 1:
             out["batch_1"] = train_bench(model, device, world, dist, bsz=1)
+        if bsz != 16:                                           # what 288 GB allow: the GEMMs leave the tile-quantised regime
+            out["batch_16"] = train_bench(model, device, world, dist, bsz=16)
         out["no_reference_quirks"] = train_bench(model, device, world, dist, bsz=bsz, ffn_freeze=False, loss_quirk=False)
     except Exception as e:
         out["extra_legs_error"] = repr(e)[:300]
