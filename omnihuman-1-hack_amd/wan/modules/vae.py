@@ -471,12 +471,17 @@ class WanVAE_(nn.Module):
         # or all together, so that tail runs once over all n_chunks frames.
         n_tail = _last_resample(enc.downsamples)
         rows = []
-        for i in range(n_chunks):
-            t0, tn = (0, 1) if i == 0 else (1 + 4 * (i - 1), 4)
+        i = 0
+        while i < n_chunks:
+            # the first frame alone (its chunk bypasses the temporal downsamples, vae.py:146-148), then _GROUP2 chunks
+            # of 4 frames per step (causal convolutions over [history | frames]: same values as chunk by chunk)
+            g = 1 if i == 0 else min(_GROUP2, n_chunks - i)
+            t0, tn = (0, 1) if i == 0 else (1 + 4 * (i - 1), 4 * g)
             c1 = st.conv("encoder.conv1", enc.conv1)
             ops.nchw_to_cl(vid, tn, t0, c1.Cin, out=c1.slot(tn, H, W, dev))
             h = c1.run(out_f32=_TRUNK_F32)
             rows.append(_run_sequential(st, "encoder.downsamples", enc.downsamples, h, stop=n_tail))
+            i += g
         h = torch.cat(rows, dim=0) if len(rows) > 1 else rows[0]                   # [n_chunks, h, w, C]
         h = _run_sequential(st, "encoder.downsamples", enc.downsamples, h, start=n_tail)
         h = _run_sequential(st, "encoder.middle", enc.middle, h)

@@ -29,6 +29,6 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         child()
     else:
-        for g2 in ("1", "2", "3"):
+        for g2 in ("1", "2"):
             print("== group2", g2, flush=True)
             subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, OMH_VAE_GROUP2=g2), check=False)
