@@ -137,6 +137,46 @@ def group_ops(G, buf, first=False):
     return out
 
 
+def and_ops(G, buf, j):
+    """The four ANDs of voxel fragment j of group G with the lane's edge word ([] for the centre tap)."""
+    kw = G >> 1
+    if kw == 1 or ABL == "and":
+        return []
+    m = (EDGE0 if kw == 0 else EDGE2) + j
+    return [("m", f"v_and_b32 v{xfrag(buf, j) + r_}, v{m}, v{xfrag(buf, j) + r_}", [f"X{buf}.{j}"]) for r_ in range(4)]
+
+
+def group_sched(G, buf, first, reads_next, dma_instrs, ands_next):
+    """Group G as 12 MFMA slots (voxel tile major) with everything else dealt into the gaps behind them, a few
+    instructions per gap (one wave per SIMD: whatever stalls the wave's issue for longer than an MFMA's 32 cycles is a
+    bubble in the matrix pipe): the next group's 7 fragment reads in gaps 0..6, this group's edge ANDs of fragment
+    j >= 1 in the gaps of fragment j - 1, the next group's ANDs of fragment 0 in gaps 9 / 10, the DMA instructions
+    spread over all gaps."""
+    gaps = [[] for _ in range(NJ * NI)]
+    for k, r in enumerate(reads_next):
+        gaps[k].append(r)
+    for j in range(1, NJ):
+        a = and_ops(G, buf, j)
+        gaps[NI * (j - 1)] += a[:2]
+        gaps[NI * (j - 1) + 1] += a[2:]
+    gaps[9] += ands_next[:2]
+    gaps[10] += ands_next[2:]
+    n = len(dma_instrs)
+    for t, ins in enumerate(dma_instrs):
+        gaps[min(NJ * NI - 1, (t * NJ * NI) // n)].append(ins)
+    out = []
+    for j in range(NJ):
+        for i in range(NI):
+            c = "0" if first else acc(i, j)
+            out.append(("m", f"v_mfma_f32_32x32x16_bf16 {acc(i, j)}, {vr(wfrag(buf, i), 4)}, {vr(xfrag(buf, j), 4)}, {c}",
+                        [f"W{buf}.{i}", f"X{buf}.{j}"]))
+            out += gaps[NI * j + i]
+    return out
+
+
+SCHED = os.environ.get("OMH_CW64_SCHED", "fine")      # "coarse": round-2's first schedule (whole pieces after an MFMA)
+
+
 def dma_pieces(NA, NB):
     """The 13 LDS-DMA pieces of the stage (s83 channel block, s84 kh, offsets s81 / s82) into the buffer at s80; then
     the scalar state moves on to the next stage.  Returns a list of op lists."""
@@ -215,7 +255,10 @@ def main_loop(e, NA, NB):
                 e(op[1])
     e(f"s_waitcnt vmcnt({NP})")                                  # stage 0 has landed
     e("s_barrier")
-    LOOP_PENDING = linearize(e, frag_reads(0, 0), [])
+    if SCHED == "fine":
+        LOOP_PENDING = linearize(e, frag_reads(0, 0) + and_ops(0, 0, 0), [])
+    else:
+        LOOP_PENDING = linearize(e, frag_reads(0, 0), [])
     e(f"s_sub_u32 s85, {S_NS}, 2")                               # steps that fetch a stage two ahead (>= 1)
 
     def body(mode, first=False):
@@ -227,21 +270,26 @@ def main_loop(e, NA, NB):
         dm = pieces if (mode == "full" and ABL != "dma") else []
         per = [dm[0:4], dm[4:7], dm[7:10], dm[10:13], dm[13:]] if dm else [[]] * 5
         for G in range(5):
-            mo = group_ops(G, G & 1, first=(first and G == 0))
-            reads = [[r] for r in frag_reads(G + 1, (G + 1) & 1)] if ABL != "reads" else []
-            ops = spread(mo, reads, 0, 8)
-            ops = spread_keep(ops, per[G])
+            reads = frag_reads(G + 1, (G + 1) & 1) if ABL != "reads" else []
+            if SCHED == "fine":
+                flat = [op for piece in per[G] for op in piece]
+                ops = group_sched(G, G & 1, first and G == 0, reads, flat, and_ops(G + 1, (G + 1) & 1, 0))
+            else:
+                ops = spread(group_ops(G, G & 1, first=(first and G == 0)), [[r] for r in reads], 0, 8)
+                ops = spread_keep(ops, per[G])
             pend = linearize(e, ops, pend)
         if mode == "last":
-            linearize(e, group_ops(5, 1), pend)
+            linearize(e, group_sched(5, 1, False, [], [], []) if SCHED == "fine" else group_ops(5, 1), pend)
             return
         e(f"s_waitcnt vmcnt({NP if (mode == 'full' and ABL != 'dma') else 0})")
         e("s_waitcnt lgkmcnt(0)")
         if ABL != "bar":
             e("s_barrier")
         advance(e)
-        reads = [[r] for r in frag_reads(0, 0)]
-        pend = linearize(e, spread(group_ops(5, 1), reads, 0, 10), [])
+        if SCHED == "fine":
+            pend = linearize(e, group_sched(5, 1, False, frag_reads(0, 0), [], and_ops(0, 0, 0)), [])
+        else:
+            pend = linearize(e, spread(group_ops(5, 1), [[r] for r in frag_reads(0, 0)], 0, 10), [])
         assert pend == LOOP_PENDING, (pend, LOOP_PENDING)
 
     LOOP = e.lab("loop")
