@@ -211,7 +211,19 @@ def single_frame_bench(model, device, iters=20):
     except Exception as e:
         tb = None
         res["batched_error"] = repr(e)[:200]
-    best = min(v for v in (te, tg, tb) if v)
+    tbg = None
+    if tb:                                                      # ... and that forward as one hipGraph replay
+        try:
+            gb = graphs.GraphedForward(model, x2, t2, st_cu, 1560)
+
+            def batched_graphed():
+                c, u = gb(x2, t2)
+                return torch.add(u, c - u, alpha=7.5)
+            tbg, vbg = timed(batched_graphed)
+            res.update({"batched_hipgraph_ms": round(tbg * 1e3, 3), "batched_hipgraph_equals_batched": bool(torch.equal(vbg, vb))})
+        except Exception as e:
+            res["batched_hipgraph_error"] = repr(e)[:200]
+    best = min(v for v in (te, tg, tb, tbg) if v)
     fl = 2 * dit_forward_flops(1560)
     res.update({"pairs_per_s": round(1 / best, 2), "achieved_tflops": round(fl / best / 1e12, 1),
                 "mfma_roofline_frac": round(fl / best / 1e12 / PEAK_BF16_TFLOPS, 4)})
