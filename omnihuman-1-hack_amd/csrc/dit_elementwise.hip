@@ -15,6 +15,10 @@ namespace {
 constexpr int MAXV_GENERIC = 32;   // float4 chunks per lane -> dim <= 8192 (specialised: 6 = 1536, 20 = 5120)
 
 // ------------------------------------------------------------------ LayerNorm + modulate
+// A wave takes LN_RPW consecutive rows: the modulation vectors (up to four [dim] fp32 vectors, 24 floats per lane each at
+// dim = 1536) are fetched once per wave and batch element instead of once per row — per row they were twice the
+// loads of x itself — and the next row's x is requested before the current row's reductions.
+constexpr int LN_RPW = 4;
 template <int MAXV>
 __global__ __launch_bounds__(256)
 void layernorm_modulate_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t rows, int dim,
@@ -23,51 +27,76 @@ void layernorm_modulate_kernel(const float* __restrict__ x, uint16_t* __restrict
                                const float* __restrict__ add0, const float* __restrict__ add1,
                                int64_t add1_stride, int64_t rows_per_batch) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_RPW;
+    if (row0 >= rows) return;
     const int nv = dim >> 2;
-    const float4* xr = (const float4*)(x + row * dim);
-    float4 v[MAXV];
-    float s = 0.f;
+    float4 mu[MAXV], ad[MAXV], v[MAXV], nx[MAXV];
+    int64_t have = -1;                                            // batch element whose vectors are in mu / ad
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + 64 * i;
-        if (c < nv) {
-            v[i] = xr[c];
-            s += v[i].x + v[i].y + v[i].z + v[i].w;
-        }
+        if (c < nv) nx[i] = ((const float4*)(x + row0 * dim))[c];
     }
-    const float mean = wave_sum(s) / dim;
-    float q = 0.f;
+    for (int r = 0; r < LN_RPW; ++r) {
+        const int64_t row = row0 + r;
+        if (row >= rows) break;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) {
-            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
-            q += a * a + b * b + cc * cc + d * d;
+        for (int i = 0; i < MAXV; ++i) v[i] = nx[i];
+        if (r + 1 < LN_RPW && row + 1 < rows) {
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nv) nx[i] = ((const float4*)(x + (row + 1) * dim))[c];
+            }
         }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / dim + eps);
-    const int64_t bidx = row / rows_per_batch;
-    const float4* m0 = (const float4*)mul0;
-    const float4* m1 = mul1 ? (const float4*)(mul1 + bidx * mul1_stride) : nullptr;
-    const float4* a0 = (const float4*)add0;
-    const float4* a1 = add1 ? (const float4*)(add1 + bidx * add1_stride) : nullptr;
-    uint2* yr = (uint2*)(y + row * dim);
+        const int64_t bidx = row / rows_per_batch;
+        if (bidx != have) {                                       // wave-uniform
+            have = bidx;
+            const float4* m0 = (const float4*)mul0;
+            const float4* m1 = mul1 ? (const float4*)(mul1 + bidx * mul1_stride) : nullptr;
+            const float4* a0 = (const float4*)add0;
+            const float4* a1 = add1 ? (const float4*)(add1 + bidx * add1_stride) : nullptr;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) {
-            float4 mu = make_float4(mul_const, mul_const, mul_const, mul_const);
-            float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0) { const float4 t = m0[c]; mu.x += t.x; mu.y += t.y; mu.z += t.z; mu.w += t.w; }
-            if (m1) { const float4 t = m1[c]; mu.x += t.x; mu.y += t.y; mu.z += t.z; mu.w += t.w; }
-            if (a0) { const float4 t = a0[c]; ad.x += t.x; ad.y += t.y; ad.z += t.z; ad.w += t.w; }
-            if (a1) { const float4 t = a1[c]; ad.x += t.x; ad.y += t.y; ad.z += t.z; ad.w += t.w; }
-            uint2 o;
-            o.x = pack_bf2((v[i].x - mean) * rstd * mu.x + ad.x, (v[i].y - mean) * rstd * mu.y + ad.y);
-            o.y = pack_bf2((v[i].z - mean) * rstd * mu.z + ad.z, (v[i].w - mean) * rstd * mu.w + ad.w);
-            yr[c] = o;
+            for (int i = 0; i < MAXV; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nv) {
+                    float4 m = make_float4(mul_const, mul_const, mul_const, mul_const);
+                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (m0) { const float4 t = m0[c]; m.x += t.x; m.y += t.y; m.z += t.z; m.w += t.w; }
+                    if (m1) { const float4 t = m1[c]; m.x += t.x; m.y += t.y; m.z += t.z; m.w += t.w; }
+                    if (a0) { const float4 t = a0[c]; a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
+                    if (a1) { const float4 t = a1[c]; a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
+                    mu[i] = m; ad[i] = a;
+                }
+            }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) s += v[i].x + v[i].y + v[i].z + v[i].w;
+        }
+        const float mean = wave_sum(s) / dim;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+                q += a * a + b * b + cc * cc + d * d;
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / dim + eps);
+        uint2* yr = (uint2*)(y + row * dim);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                uint2 o;
+                o.x = pack_bf2((v[i].x - mean) * rstd * mu[i].x + ad[i].x, (v[i].y - mean) * rstd * mu[i].y + ad[i].y);
+                o.y = pack_bf2((v[i].z - mean) * rstd * mu[i].z + ad[i].z, (v[i].w - mean) * rstd * mu[i].w + ad[i].w);
+                yr[c] = o;
+            }
         }
     }
 }
@@ -302,7 +331,7 @@ extern "C" int omh_layernorm_modulate(const float* x, void* y, int64_t rows, int
     omh_clear_status();
     auto kern = dim <= 6 * 256 ? layernorm_modulate_kernel<6>
                                : (dim <= 20 * 256 ? layernorm_modulate_kernel<20> : layernorm_modulate_kernel<MAXV_GENERIC>);
-    hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+    hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 4 * LN_RPW - 1) / (4 * LN_RPW))), dim3(256), 0,
                        (hipStream_t)stream, x, (uint16_t*)y, rows, dim, eps, mul_const, mul0, mul1, mul1_stride,
                        add0, add1, add1_stride, rows_per_batch);
     return omh_launch_status();

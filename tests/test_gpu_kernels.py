@@ -241,16 +241,19 @@ def test_flash_attention_w64_prescaled_q_lse_and_late_rescale(ops, variant, monk
 
 def test_layernorm_modulate(ops):
     torch.manual_seed(2)
+    # a wave takes 4 consecutive rows: batch boundaries inside them (50 % 4 = 2; 7 rows per batch), a ragged last wave
+    for B, S, d in ((2, 50, 1536), (3, 7, 1536), (1, 1, 256)):
+        x = torch.randn(B * S, d, device="cuda") * 3 + 0.5
+        mod = torch.randn(6, d, device="cuda")
+        e0 = torch.randn(B, 6, d, device="cuda")
+        y = torch.empty(B * S, d, dtype=torch.bfloat16, device="cuda")
+        ops.layernorm_modulate_raw(ops.ptr(x), ops.ptr(y), B * S, d, 1e-6, 1.0, ops.ptr(mod, d), ops.ptr(e0, d), 6 * d,
+                                   ops.ptr(mod, 0), ops.ptr(e0, 0), 6 * d, S)
+        xh = torch.nn.functional.layer_norm(x, (d,), eps=1e-6)
+        ref = xh * (1 + (mod[1][None] + e0[:, 1]).repeat_interleave(S, 0)) + (mod[0][None] + e0[:, 0]).repeat_interleave(S, 0)
+        assert rel_rms(y.float(), ref) < 4e-3
     B, S, d = 2, 50, 1536
     x = torch.randn(B * S, d, device="cuda") * 3 + 0.5
-    mod = torch.randn(6, d, device="cuda")
-    e0 = torch.randn(B, 6, d, device="cuda")
-    y = torch.empty(B * S, d, dtype=torch.bfloat16, device="cuda")
-    ops.layernorm_modulate_raw(ops.ptr(x), ops.ptr(y), B * S, d, 1e-6, 1.0, ops.ptr(mod, d), ops.ptr(e0, d), 6 * d,
-                               ops.ptr(mod, 0), ops.ptr(e0, 0), 6 * d, S)
-    xh = torch.nn.functional.layer_norm(x, (d,), eps=1e-6)
-    ref = xh * (1 + (mod[1][None] + e0[:, 1]).repeat_interleave(S, 0)) + (mod[0][None] + e0[:, 0]).repeat_interleave(S, 0)
-    assert rel_rms(y.float(), ref) < 4e-3
     w, b = torch.randn(d, device="cuda"), torch.randn(d, device="cuda")
     y2 = ops.layernorm_modulate(x, 1e-6, 0.0, mul0=w, add0=b)
     assert rel_rms(y2.float(), torch.nn.functional.layer_norm(x, (d,), w, b, 1e-6)) < 4e-3

@@ -24,6 +24,7 @@ def t(fn, n=20):
 f1 = lambda: ops.rmsnorm_rope_bf16_raw(ops.ptr(qk), 2 * d, ops.ptr(out), S, d, ops.ptr(w), 1e-6, 1, ops.ptr(cos), ops.ptr(sin), 1024, D, ops.ptr(grid), S, out_scale=0.1275)
 us = t(f1)
 print(f"rmsnorm_rope bf16 (q of q|k): {us:.1f} us  {S * d * 4 / us / 1e6:.2f} TB/s")
-f2 = lambda: ops.layernorm_modulate(x, 1e-6, 0.0)
+e1 = torch.randn(1, 6, d, device="cuda")
+f2 = lambda: ops.layernorm_modulate(x, 1e-6, 1.0, mul1=e1[:, 1], add1=e1[:, 0], rows_per_batch=S)     # as the DiT block calls it
 us = t(f2)
 print(f"layernorm_modulate: {us:.1f} us  {S * d * 6 / us / 1e6:.2f} TB/s")
