@@ -49,7 +49,8 @@ FRAG = (56, 84)
 TMP = 112
 T = 56
 BIASV = 120
-RING = 168
+RING_SLOTS = (168, 184, 200, 216, 232, 72, 88)    # residual tiles in flight: v[168:247] and the dead fragment buffers
+RING_DEPTH = int(os.environ.get("OMH_CW64_RING", len(RING_SLOTS)))
 
 
 def vr(lo, n=1):
@@ -331,19 +332,21 @@ def spread_keep(ops, extras):
 NTILES = NI * NJ
 
 
-def res_loads(e, n, kind):
-    """Residual values of tile n = 3 j + i -> ring slot n % 3 (v117 = the lane's offset in its row block: the row block
+def res_loads(e, n, kind, issued):
+    """Residual values of tile n = 3 j + i -> ring slot n % RING_DEPTH (v117 = the lane's offset in its row block: the row block
     goes in the VGPR, not in the soffset, because the range check sees only voffset + inst_offset and tile 0's lane of
     row -1 must be out of range for j = 0 ONLY)."""
     i = n % NI
     es = 2 if kind == "bf16" else 4
     for p in range(2):
         if kind == "bf16":
-            e(f"buffer_load_dwordx4 {vr(RING + (n % 3) * 16 + p * 4, 4)}, v117, %[rres], 0 offen offset:{(i * 32 + 16 * p) * es}")
+            e(f"buffer_load_dwordx4 {vr(RING_SLOTS[n % RING_DEPTH] + p * 4, 4)}, v117, %[rres], 0 offen offset:{(i * 32 + 16 * p) * es}")
+            issued.append(("L", n))
         else:
             for q in range(2):
-                e(f"buffer_load_dwordx4 {vr(RING + (n % 3) * 16 + p * 8 + q * 4, 4)}, v117, %[rres], 0 offen "
+                e(f"buffer_load_dwordx4 {vr(RING_SLOTS[n % RING_DEPTH] + p * 8 + q * 4, 4)}, v117, %[rres], 0 offen "
                   f"offset:{(i * 32 + 16 * p) * es + q * 16}")
+                issued.append(("L", n))
 
 
 def epilogue(e, kind):
@@ -362,33 +365,38 @@ def epilogue(e, kind):
                   f"offset:{(32 * i + 16 * p) * 4 + 16 * q}")
     e(f"v_mov_b32 v116, v{VOC}")                                 # store offset of the lane's row in row block j
     e(f"v_mov_b32 v117, v{VOC}")                                 # the same for the residual loads, two tiles ahead
-    res_loads(e, 0, kind)
-    res_loads(e, 1, kind)
+    issued = []                                                  # VMEM instructions in issue order (the bias loads are older)
+    D = RING_DEPTH - 1                                           # tiles requested ahead: per-CU read bandwidth = bytes in flight / latency
+
+    def request(n):
+        if n < NTILES:
+            if n and n % NI == 0:
+                e(f"v_add_u32 v117, {S_JSTEP}, v117")
+            res_loads(e, n, kind, issued)
+
+    for n in range(D):
+        request(n)
     for n in range(NTILES):
         j, i = divmod(n, NI)
         t = i * NJ + j
         if i == 0 and j:
             e(f"v_add_u32 v116, {S_JSTEP}, v116")
-        if n + 2 < NTILES:
-            if (n + 2) % NI == 0:
-                e(f"v_add_u32 v117, {S_JSTEP}, v117")
-            res_loads(e, n + 2, kind)
+        request(n + D)
         for r_ in range(16):
             e(f"v_accvgpr_read_b32 v{T + r_}, a{t * 16 + r_}")
         e("s_nop 1")
         for q0 in (0, 2):                                        # quads (0,1), (2,3) -> two runs of 8 consecutive couts
             for r_ in range(4):
                 e(f"v_permlane32_swap_b32 v{T + 4 * q0 + r_}, v{T + 4 * (q0 + 1) + r_}")
-        # in issue order behind tile n's loads: S(n-2) L(n+1) S(n-1) L(n+2)  (the 12 bias loads are older)
-        behind = per_tile * ((n >= 2) + (n + 1 < NTILES) + (n >= 1) + (n + 2 < NTILES))
-        e(f"s_waitcnt vmcnt({behind})")
+        last = max(k for k, tag in enumerate(issued) if tag == ("L", n))
+        e(f"s_waitcnt vmcnt({min(63, len(issued) - last - 1)})")     # in-order counter: tile n's residual has landed
         e(f"v_bfe_u32 v113, v{ROWMASK}, {j}, 1")                  # this lane's row of the strip is an output row
         e("v_cmp_ne_u32 vcc, 0, v113")
         e("s_and_saveexec_b64 s[86:87], vcc")
         for p in range(2):
             v0 = T + 8 * p
             b0 = BIASV + (2 * i + p) * 8
-            r0 = RING + (n % 3) * 16 + (p * 4 if kind == "bf16" else p * 8)
+            r0 = RING_SLOTS[n % RING_DEPTH] + (p * 4 if kind == "bf16" else p * 8)
             for r_ in range(0, 8, 2):
                 e(f"v_pk_add_f32 {vr(v0 + r_, 2)}, {vr(v0 + r_, 2)}, {vr(b0 + r_, 2)}")
             if kind == "bf16":
@@ -399,11 +407,13 @@ def epilogue(e, kind):
                 for r_ in range(4):
                     e(f"v_cvt_pk_bf16_f32 v{v0 + r_}, v{v0 + 2 * r_}, v{v0 + 2 * r_ + 1}")
                 e(f"buffer_store_dwordx4 {vr(v0, 4)}, v116, %[ry], 0 offen offset:{(i * 32 + 16 * p) * es}")
+                issued.append(("S", n))
             else:
                 for r_ in range(0, 8, 2):
                     e(f"v_pk_add_f32 {vr(v0 + r_, 2)}, {vr(v0 + r_, 2)}, {vr(r0 + r_, 2)}")
                 e(f"buffer_store_dwordx4 {vr(v0, 4)}, v116, %[ry], 0 offen offset:{(i * 32 + 16 * p) * es}")
                 e(f"buffer_store_dwordx4 {vr(v0 + 4, 4)}, v116, %[ry], 0 offen offset:{(i * 32 + 16 * p) * es + 16}")
+                issued += [("S", n), ("S", n)]
         e("s_nop 1")
         e("s_mov_b64 exec, s[86:87]")
 
