@@ -436,13 +436,111 @@ def epilogue(e, kind):
             e("s_mov_b64 exec, s[86:87]")
 
 
+def epilogue_resid(e):
+    """C fp32 += (acc + bias) * gate.  The old C values are what the epilogue waits for (786 KB per tile and CU): the
+    more of them are in flight the better, and registers are the limit.  The 8 accumulator tiles that live in
+    v[128:255] therefore go first — each frees 16 registers when it has been read — and from then on up to 11 tiles
+    of old values are in flight instead of 3 (ring slots: v[80:127] + the freed accumulator registers)."""
+    es = 4
+    depth = int(os.environ.get("OMH_GW64_RING", "11"))
+    # experiment knob, off: a second permlane level gives a lane 16 CONSECUTIVE columns (64 B per lane, full 128-B lines
+    # per row and instruction pair) — measured 197 -> 202 us on the o-projection: the epilogue is not bound by request count
+    W16 = os.environ.get("OMH_GW64_WIDE16", "0") == "1"
+    column_vectors(e, "resid")
+    VLR_, VCOL_, VOC_ = VLR, VCOL, "%[voc]"
+    if W16:
+        e(f"v_add_u32 v24, {VLR}, {VH}")                         # vector region + 64 h bytes
+        e(f"v_add_u32 v25, {VH}, %[voc]")                        # row offset + 16 h columns
+        e(f"v_lshrrev_b32 v26, 2, {VH}")
+        e(f"v_add_u32 v26, v26, {VCOL}")                         # first column of the wave + 16 h
+        VLR_, VCOL_, VOC_ = "v24", "v26", "v25"
+    seq = [(4 + m // 4, m % 4) for m in range(8)] + [(t // NJ, t % NJ) for t in range(16)]
+    free = [CO, CO + 16, CO + 32][:min(3, depth)]
+    slot_of, issued, nxt = {}, [], [0]
+
+    def request():
+        """Old C values of the next tiles in processing order, while a ring slot is free."""
+        while nxt[0] < NTILES and free:
+            k = nxt[0]
+            i, j = seq[k]
+            sl = free.pop(0)
+            slot_of[k] = sl
+            e(f"s_mul_i32 s88, {S_SCJ}, {j}")
+            e(f"s_add_u32 s88, s88, {S_SCB}")
+            for p in range(2):
+                for q in range(2):
+                    off = (i * 32) * es + p * 32 + q * 16 if W16 else (i * 32 + 16 * p) * es + q * 16
+                    e(f"buffer_load_dwordx4 {vr(sl + p * 8 + q * 4, 4)}, {VOC_}, %[rc], s88 offen offset:{off}")
+                    issued.append(("L", k))
+            nxt[0] += 1
+
+    request()
+    for k, (i, j) in enumerate(seq):
+        t = i * NJ + j
+        # row block j: store soffset, gate vector set of this lane's row
+        e(f"s_mul_i32 s85, {S_SCJ}, {j}")
+        e(f"s_add_u32 s85, s85, {S_SCB}")
+        e(f"v_add_u32 v{VCOLT}, {32 * j}, {VROW}")
+        e(f"v_cmp_le_u32 vcc, {S_MB}, v{VCOLT}")
+        e(f"v_add_u32 v{VCOLT}, 1536, {VLR_}")
+        e(f"v_cndmask_b32 v{VSEL}, {VLR_}, v{VCOLT}, vcc")
+        for p in range(2):
+            col = (i * 32) * 4 + p * 32 if W16 else (i * 32 + 16 * p) * 4
+            e(f"ds_read_b128 {vr(GV + p * 8, 4)}, v{VSEL} offset:{col}")
+            e(f"ds_read_b128 {vr(GV + p * 8 + 4, 4)}, v{VSEL} offset:{col + 16}")
+            e(f"ds_read_b128 {vr(BV + p * 8, 4)}, {VLR_} offset:{768 + col}")
+            e(f"ds_read_b128 {vr(BV + p * 8 + 4, 4)}, {VLR_} offset:{768 + col + 16}")
+        for r_ in range(16):
+            if t < 16:
+                e(f"v_accvgpr_read_b32 v{T + r_}, a{t * 16 + r_}")
+            else:
+                e(f"v_mov_b32 v{T + r_}, v{128 + (t - 16) * 16 + r_}")
+        if t >= 16 and len(slot_of) + len(free) - k < depth:      # the accumulator tile's registers join the ring
+            free.append(128 + (t - 16) * 16)
+        e("s_nop 1")
+        for q0 in (0, 2):                                        # quads (0,1), (2,3) -> two runs of 8 consecutive n
+            for r_ in range(4):
+                e(f"v_permlane32_swap_b32 v{T + 4 * q0 + r_}, v{T + 4 * (q0 + 1) + r_}")
+        if W16:                                                  # ... and the two runs -> 16 consecutive n per lane
+            e("s_nop 1")
+            for r_ in range(8):
+                e(f"v_permlane32_swap_b32 v{T + r_}, v{T + 8 + r_}")
+        request()
+        e("s_waitcnt lgkmcnt(0)")
+        last = max(x for x, tag in enumerate(issued) if tag == ("L", k))
+        e(f"s_waitcnt vmcnt({min(63, len(issued) - last - 1)})")     # in-order counter: tile k's old values have landed
+        sl = slot_of[k]
+        for p in range(2):
+            v0 = T + 8 * p
+            e(f"v_add_u32 v{VCOLT}, {i * 32 + (8 if W16 else 16) * p}, {VCOL_}")
+            e(f"v_cmp_gt_u32 vcc, {S_N}, v{VCOLT}")
+            e("s_and_saveexec_b64 s[86:87], vcc")
+            for r_ in range(0, 8, 2):
+                e(f"v_pk_add_f32 {vr(v0 + r_, 2)}, {vr(v0 + r_, 2)}, {vr(BV + p * 8 + r_, 2)}")
+            for r_ in range(0, 8, 2):
+                e(f"v_pk_mul_f32 {vr(v0 + r_, 2)}, {vr(v0 + r_, 2)}, {vr(GV + p * 8 + r_, 2)}")
+            for r_ in range(0, 8, 2):
+                e(f"v_pk_add_f32 {vr(v0 + r_, 2)}, {vr(sl + p * 8 + r_, 2)}, {vr(v0 + r_, 2)}")
+            off = (i * 32) * es + p * 32 if W16 else (i * 32 + 16 * p) * es
+            e(f"buffer_store_dwordx4 {vr(v0, 4)}, {VOC_}, %[rc], s85 offen offset:{off}")
+            e(f"buffer_store_dwordx4 {vr(v0 + 4, 4)}, {VOC_}, %[rc], s85 offen offset:{off + 16}")
+            issued += [("S", k), ("S", k)]
+            e("s_nop 1")
+            e("s_mov_b64 exec, s[86:87]")
+        free.append(sl)
+    assert nxt[0] == NTILES
+
+
 EPI_VMEM = {"f32": 96, "bf16": 48, "gelu": 48, "resid": 192}    # VMEM instructions an epilogue issues after the next tile's DMA
 
 
 def generate(kind):
     e = Emit(kind)
     main_loop(e, EPI_VMEM[kind])
-    epilogue(e, kind)
+    if kind == "resid":
+        epilogue_resid(e)
+    else:
+        epilogue(e, kind)
     return e
 
 
