@@ -113,6 +113,39 @@ def test_gemm_w64_stream_kernel(ops, M, N, K, gate_rows, monkeypatch):
     assert rel_rms(got[5], x0 + ref - bias) < 1e-5
 
 
+def test_gemm_w64_random_shapes_equal_the_8_wave_kernel(ops, monkeypatch):
+    """Seeded sweep: 20 random (M, N, K, epilogue, bias, gate layout) within the stream kernel's domain, whole outputs
+    bit for bit against the 8-wave kernels (one to a few tiles per workgroup of the persistent grid, ragged M and N,
+    odd and even numbers of k steps)."""
+    import random
+    rng = random.Random(7)
+    for case in range(20):
+        M, N, K = rng.randint(256, 5000), 8 * rng.randint(12, 300), 64 * rng.randint(4, 20)
+        epi = rng.choice((ops.EPI_F32, ops.EPI_BF16, ops.EPI_GELU_BF16, ops.EPI_RESID))
+        torch.manual_seed(case)
+        a = _bf(torch.randn(M, K, device="cuda"))
+        w = _bf(torch.randn(N, K, device="cuda") / math.sqrt(K))
+        bias = torch.randn(N, device="cuda") if rng.random() < 0.7 else None
+        gate_rows = rng.randint(128, M)
+        nb = (M + gate_rows - 1) // gate_rows
+        g0 = torch.randn(N, device="cuda") if rng.random() < 0.5 else None
+        g1 = torch.randn(nb, 3, N, device="cuda") if rng.random() < 0.7 else None
+        x0 = torch.randn(M, N, device="cuda")
+        outs = {}
+        for kernel in ("w64", "8w"):
+            monkeypatch.setenv("OMH_GEMM_KERNEL", kernel)
+            out = x0.clone() if epi == ops.EPI_RESID else torch.empty(
+                M, N, device="cuda", dtype=torch.float32 if epi == ops.EPI_F32 else torch.bfloat16)
+            ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(out), M, N, K, K, K, N, epi,
+                         bias=ops.ptr(bias) if bias is not None else None,
+                         bias_mode=ops.BIAS_N if bias is not None else ops.BIAS_NONE,
+                         gate0=ops.ptr(g0) if (g0 is not None and epi == ops.EPI_RESID) else None,
+                         gate1=ops.ptr(g1, N) if (g1 is not None and epi == ops.EPI_RESID) else None,
+                         gate1_stride=3 * N, gate_rows=gate_rows, gate_const=0.25)
+            outs[kernel] = out
+        assert torch.equal(outs["w64"], outs["8w"]), (case, M, N, K, epi)
+
+
 def test_gemm_w64_is_the_default_on_the_large_shapes(ops, monkeypatch):
     """Unset OMH_GEMM_KERNEL: >= 256 tiles of 256 x 384 -> the stream kernel; its output is that of the forced call and
     (the kernels agree bit for bit) of the 8-wave kernel."""

@@ -98,6 +98,29 @@ def test_conv_cl_w64_equals_the_kw_shared_kernel(ops, cfg, monkeypatch):
         assert torch.isfinite(g.float()).all() and torch.equal(g, r)
 
 
+def test_conv_cl_w64_random_shapes_equal_the_kw_shared_kernel(ops, monkeypatch):
+    """Seeded sweep: 24 random (Cin, Cout, T, H, W, KT) within the stream kernel's domain — image rows as short as 3
+    voxels, volumes smaller than one tile, ragged last tiles, 1 to 4 channel blocks — bit for bit against the 8-wave
+    kernel, bf16 and fp32-trunk outputs."""
+    import random
+    rng = random.Random(20260929)
+    for case in range(24):
+        Cin, Cout = rng.choice((32, 64, 96, 128)), rng.choice((96, 192, 384))
+        T, H, W, KT = rng.randint(1, 3), rng.randint(1, 40), rng.randint(3, 40), rng.choice((1, 3))
+        torch.manual_seed(case)
+        x = _bf(torch.randn(KT - 1 + T, H, W, Cin, device="cuda"))
+        wp = _bf(torch.randn(Cout, KT * 9 * Cin, device="cuda") / (Cin * KT * 9) ** 0.5)
+        bias = torch.randn(Cout, device="cuda")
+        rf = torch.randn(T, H, W, Cout, device="cuda")
+        out = {}
+        for tile in ("w64", "wide"):
+            monkeypatch.setenv("OMH_CONV_TILE", tile)
+            out[tile] = (ops.conv_cl(x, wp, bias, T, H, W, Cout, KT, 3, 3, pad_h=1, pad_w=1, resid=_bf(rf)),
+                         ops.conv_cl(x, wp, bias, T, H, W, Cout, KT, 3, 3, pad_h=1, pad_w=1, resid=rf, out_f32=True))
+        for g, r in zip(out["w64"], out["wide"]):
+            assert torch.equal(g, r), (case, Cin, Cout, T, H, W, KT)
+
+
 @pytest.mark.parametrize("tile", ["small", "wide"])
 def test_conv_cl_upsample_downsample_stride_split(ops, tile, monkeypatch):
     monkeypatch.setenv("OMH_CONV_TILE", tile)
