@@ -92,6 +92,35 @@ def _wgrad_join(dev):
         torch.cuda.current_stream(dev).wait_stream(_side[dev])
 
 
+def _prepack(model, blk, idx, transposes):
+    """Build block ``idx``'s bf16 weight copies (and, for the backward, their transposes) on the side stream while the
+    main stream computes the neighbouring block: after an optimizer step every copy is stale, and the ~20 small cast /
+    transpose kernels per block (93 MB written) otherwise sit between the block's GEMMs on the main stream.  The
+    caller's next use of the block is ordered behind them by _wgrad_join."""
+    from . import model as _model_mod
+    if not _WGRAD_STREAM or _model_mod._Packed.always_rebuild:     # (under hipGraph capture the packs are graph nodes)
+        return
+    dev = blk.modulation.device
+    main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+    side.wait_stream(main)
+    sa, ca = blk.self_attn, blk.cross_attn
+    frozen_ffn = getattr(model, "reference_ffn_freeze", True) and idx > 10
+    with torch.cuda.stream(side), torch.no_grad():
+        wqk, _ = sa._w_qk()
+        packs = {"qk": (sa, wqk), "v": (sa, sa._w("v")[0]), "o": (sa, sa._w("o")[0]),
+                 "q": (ca, ca._w("q")[0]), "k": (ca, ca._w("k")[0]), "v_": (ca, ca._w("v")[0]), "o_": (ca, ca._w("o")[0])}
+        if hasattr(ca, "k_img"):
+            packs["k_img"] = (ca, ca._w("k_img")[0])
+            packs["v_img"] = (ca, ca._w("v_img")[0])
+        w1, w2 = blk._ffn_w(0)[0], blk._ffn_w(2)[0]
+        if transposes:
+            for key, (mod, w) in packs.items():
+                _wT(mod, key.rstrip("_"), w)
+            if not frozen_ffn:
+                _wT(blk, "ffn2", w2)
+                _wT(blk, "ffn0", w1)
+
+
 def _wgrad(dy, x, xT=None, out=None):
     """dW[N, K] = dy[R, N]^T @ x[R, K]  (fp32) on dy and x as they are (row-major bf16): the k-major GEMM of
     csrc/gemm_tn.hip — no transposed copies.  With ``out`` the product is ADDED to it (a weight used twice in the
@@ -267,6 +296,9 @@ class _BlockFn(torch.autograd.Function):
     def forward(ctx, x, model, st, idx, *params):
         block = model.blocks[idx]
         fc = st.fc
+        _wgrad_join(x.device)                                     # this block's packs (prefetched by the previous one)
+        if idx + 1 < len(model.blocks):
+            _prepack(model, model.blocks[idx + 1], idx + 1, False)
         with torch.no_grad():
             x_out = x.detach().clone()
             seq_lens = fc.seq_lens32.long()
@@ -282,6 +314,8 @@ class _BlockFn(torch.autograd.Function):
         model, st, idx = ctx.model, ctx.st, ctx.idx
         blk = model.blocks[idx]
         names = [n for n, _ in blk.named_parameters()]
+        if idx > 0:
+            _prepack(model, model.blocks[idx - 1], idx - 1, True)
         with torch.no_grad():
             grads = _block_backward(model, blk, idx, st, x0, dx_out.float().contiguous().clone())
         out = []
