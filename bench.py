@@ -348,6 +348,8 @@ def train_legs(model, device, world, dist):
     the primary batch size."""
     bsz = int(os.environ.get("OMH_TRAIN_BATCH", "4"))
     out = train_bench(model, device, world, dist, bsz=bsz)
+    if os.environ.get("OMH_TRAIN_LEGS", "all") == "primary":      # (tests: the primary leg only)
+        return out
     try:
         if bsz != 1:
             out["batch_1"] = train_bench(model, device, world, dist, bsz=1)
@@ -357,6 +359,36 @@ def train_legs(model, device, world, dist):
     except Exception as e:
         out["extra_legs_error"] = repr(e)[:300]
     return out
+
+
+def self_launch(n):
+    """Re-run this command line under ``python -m torch.distributed.run --nproc-per-node n`` (one process per GPU,
+    RCCL over xGMI; rendezvous on 127.0.0.1 at a free port) and print the ONE JSON line its rank 0 produced.
+    Everything else the ranks or the launcher write goes to stderr.  Returns the exit code."""
+    import socket
+    import subprocess
+    if os.environ.get("OMH_DIST_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < n:
+        sys.stderr.write(f"bench.py --gpus {n}: only {torch.cuda.device_count()} HIP device(s) visible; RCCL needs one "
+                         "GPU per rank (OMH_DIST_BACKEND=gloo lets ranks share a GPU for validation runs)\n")
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL's peer mappings need it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    for ln in r.stdout.splitlines():
+        if not ln.startswith('{"metric"'):
+            sys.stderr.write(ln + "\n")
+    if r.returncode != 0 or len(lines) != 1:
+        sys.stderr.write(f"bench.py --gpus {n}: launcher exit code {r.returncode}, {len(lines)} result line(s)\n")
+        return r.returncode or 1
+    print(lines[0], flush=True)
+    return 0
 
 
 def main():
@@ -378,12 +410,23 @@ def main():
     ap.add_argument("--only-train", action="store_true", help="profiling aid: run just the training leg")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, as the reference's
+        # `accelerate launch`, seaweed_apt/train.sh:3 / distilled_trainer.py:384) and pass rank 0's line through
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    if os.environ.get("OMH_DIST_BACKEND", "nccl") != "nccl":   # validation mode: ranks may share a GPU (gloo)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: the two must agree "
+                         "(n_gpus on the line is the number of ranks that ran)")
+    shared_gpu = os.environ.get("OMH_DIST_BACKEND", "nccl") != "nccl"      # validation mode: ranks may share a GPU (gloo)
+    if not shared_gpu and world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py --gpus {world}: only {torch.cuda.device_count()} HIP device(s) visible; RCCL needs "
+                         "one GPU per rank (OMH_DIST_BACKEND=gloo lets ranks share a GPU for validation runs)")
+    if shared_gpu:
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -517,11 +560,12 @@ def main():
         ach = attn_flops / (attn_ms * 1e-3) / 1e12
         kname = {"pp": "flash_attn_fwd_d128_pp_kernel", "base": "flash_attn_fwd_d128_kernel"}.get(
             os.environ.get("OMH_ATTN_KERNEL", ""), "flash_attn_fwd_d128_w64_v2_kernel")
-        traffic = None
+        traffic = tsrc = None
         tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tj):
             try:
-                traffic = json.load(open(tj)).get(kname)
+                tjd = json.load(open(tj))
+                traffic, tsrc = tjd.get(kname), tjd.get("_source", {}).get(kname)
             except Exception:
                 traffic = None
         if traffic is not None:
@@ -529,6 +573,10 @@ def main():
         roofline = {"kernel": "%s (self-attention, Lq=Lk=%d, 12 heads, D=128, batch %d)" % (kname, seq_len, nb),
                     "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": None if traffic is None else
+                    "NOT a counter of this run: HBM-side bytes per launch of this kernel from separate rocprofv3 --pmc "
+                    "passes (2 x FETCH_SIZE + WRITE_SIZE, tools/pmc_attn.sh), recorded in profiles/traffic_latest.json "
+                    "(" + str(tsrc) + ")",
                     "launches_timed": len(timer.pairs), "avg_launch_ms": round(attn_ms, 4),
                     "algorithmic_flops_per_launch": attn_flops}
 

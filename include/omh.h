@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OMH_ABI_VERSION 4
+#define OMH_ABI_VERSION 5
 
 #define OMH_E_BADARG   (-1)   /* null pointer / non-positive size             */
 #define OMH_E_ALIGN    (-2)   /* pointer or leading dimension not aligned     */
@@ -56,7 +56,8 @@ enum {
     OMH_EPI_GELU_BF16 = 2,  /* C bf16  = gelu_tanh(acc + bias)   (model.py:273)   */
     OMH_EPI_RESID     = 3,  /* C fp32 += (acc + bias) * gate     (model.py:296,313,328) */
     OMH_EPI_F32_ACCUM = 4,  /* C fp32 += acc + bias               (used by backward) */
-    OMH_EPI_GELU_ERF_BF16 = 5 /* C bf16 = gelu_erf(acc + bias)    (i2v MLPProj, model.py:369) */
+    OMH_EPI_GELU_ERF_BF16 = 5, /* C bf16 = gelu_erf(acc + bias)   (i2v MLPProj, model.py:369) */
+    OMH_EPI_GELU_BWD_BF16 = 6  /* C bf16 = acc * gelu_tanh'(aux)   (backward of model.py:273 fused into the dgrad GEMM) */
 };
 enum { OMH_BIAS_NONE = 0, OMH_BIAS_N = 1, OMH_BIAS_M = 2 };
 
@@ -77,6 +78,15 @@ typedef struct omh_gemm_args {
        The input gradient of an nn.Linear, dx = dy W, on the weight as stored [out,in] (autograd of the Linears
        above under distilled_trainer.py:289-301) — no transposed weight copy.  Epilogues BF16 / F32 / F32_ACCUM. */
     int32_t b_kmajor;
+    /* ABI v5 — fused epilogues of the training step (autograd of model.py:296,313,328,273 under
+       distilled_trainer.py:289-301), batch == 1, the gemm_bf16.hip kernels:
+       c_in : OMH_EPI_RESID reads the old residual from c_in (layout of C) instead of C: the out-of-place
+              x_out = x_in + (acc + bias) * gate that keeps x_in for the backward.  NULL: in place.
+       aux  : bf16 [M, >= N], row pitch ldaux (multiple of 8), 16-byte aligned.
+              OMH_EPI_RESID          OUT  aux = bf16(acc + bias): the branch output the gate gradient needs
+              OMH_EPI_GELU_BF16      OUT  aux = bf16(acc + bias): the pre-activation the GELU backward needs
+              OMH_EPI_GELU_BWD_BF16  IN   the forward's pre-activation                                        */
+    const float* c_in; void* aux; int32_t ldaux;
 } omh_gemm_args;
 
 int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream);
@@ -148,12 +158,18 @@ typedef struct omh_attn_bwd_args {
     const void* q; const void* k; const void* v; const void* o; const void* dout;
     const void* qt; const void* dot; const void* kt;
     const float* lse; float* delta;
-    float* dq; float* dk; float* dv;
+    void* dq; void* dk; void* dv;          /* fp32, or bf16 with out_bf16 */
     const int32_t* k_lens;
     int32_t B, H, Lq, Lk;
     int64_t q_bs, q_rs, k_bs, k_rs, o_bs, o_rs, dq_bs, dq_rs, dk_bs, dk_rs, qt_bs, kt_bs;
     int32_t ldq, ldk;
     float scale;
+    /* ABI v5.  q_prescaled != 0: q (and qt) carry the factor scale*log2(e) as in the forward call
+       (omh_attn_args.q_prescaled): P is recomputed from the very operands the forward used; dq is still the gradient
+       with respect to the UNSCALED normalised q (what omh_rmsnorm_rope_bwd expects), dk = dS^T q' / log2(e).
+       out_bf16 != 0: dq / dk / dv are bf16 (strides in bf16 elements, multiples of 4) — the operand type of the
+       weight-gradient GEMMs that follow, no cast pass. */
+    int32_t q_prescaled, out_bf16;
 } omh_attn_bwd_args;
 
 int omh_flash_attn_bwd_d128(const omh_attn_bwd_args* args, omh_stream_t stream);
@@ -357,6 +373,14 @@ int omh_rmsnorm_rope_bwd(const float* x, int64_t ldx, const float* dy, int64_t l
                          float* dweight, int64_t rows, int32_t dim, const float* weight, float eps, int32_t do_norm,
                          const float* rope_cos, const float* rope_sin, int32_t rope_len, int32_t head_dim,
                          const int32_t* grid, int32_t seq_len, omh_stream_t stream);
+/* The same with x and / or dy in bf16 (x_bf16 / dy_bf16 != 0; strides in elements, multiples of 4): the backward of
+ * omh_rmsnorm_rope_bf16 on the very bf16 projection the forward normalised (model.py:144-145 under
+ * distilled_trainer.py:289-301), fed by omh_flash_attn_bwd_d128 with out_bf16.  dy is the gradient of the UNSCALED
+ * output (out_scale not applied).  dx may alias dy (a row is read whole before it is written). */
+int omh_rmsnorm_rope_bwd_t(const void* x, int32_t x_bf16, int64_t ldx, const void* dy, int32_t dy_bf16, int64_t lddy,
+                           void* dx_bf16, int64_t lddx, float* dweight, int64_t rows, int32_t dim, const float* weight,
+                           float eps, int32_t do_norm, const float* rope_cos, const float* rope_sin, int32_t rope_len,
+                           int32_t head_dim, const int32_t* grid, int32_t seq_len, omh_stream_t stream);
 /* dS = P * (dP - sum_j P*dP) * scale per row (softmax backward of the unfused attention backward). */
 int omh_softmax_bwd_rows(const void* p_bf16, int64_t ldp, const float* dp, int64_t lddp, void* ds_bf16, int64_t ldds,
                          int64_t R, int32_t L, float scale, omh_stream_t stream);
@@ -378,6 +402,13 @@ int omh_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, floa
  * {param ptr, grad ptr, exp_avg ptr, exp_avg_sq ptr, numel}; all tensors share `step`. */
 int omh_adamw_multi(const int64_t* table, int32_t n_tensors, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int32_t step, float grad_scale, omh_stream_t stream);
+/* bf16 operand copies of the fp32 master weights, all in ONE launch (they go stale with every optimizer step,
+ * distilled_trainer.py:376-380: the reference's autocast re-casts every weight on every use).  table: DEVICE array of
+ * n_entries x 9 int64 {src fp32 [rows, cols] contiguous, dst, dstT, rows, cols, ld_dst, ld_dstT, first_tile, kind};
+ * kind 0: dst bf16 [rows, ld_dst] = bf16(src) and dstT bf16 [cols, ld_dstT] = its transpose (either may be 0), one
+ * workgroup per 64 x 64 tile; kind 1: dst fp32 = src, one workgroup per 4096 elements.  first_tile = prefix sum of the
+ * entries' workgroup counts (ascending), total_tiles = their sum. */
+int omh_pack_weights_multi(const int64_t* table, int32_t n_entries, int64_t total_tiles, omh_stream_t stream);
 /* EMA of the weights, ema = decay*ema + (1-decay)*p (distilled_trainer.py:319-334). */
 int omh_ema_update(float* ema, const float* p, int64_t n, float decay, omh_stream_t stream);
 

@@ -21,7 +21,7 @@ class OmhError(RuntimeError):
     pass
 
 
-ABI_VERSION = 4          # == OMH_ABI_VERSION of include/omh.h; checked against the loaded library below
+ABI_VERSION = 5          # == OMH_ABI_VERSION of include/omh.h; checked against the loaded library below
 
 
 def _load():
@@ -61,7 +61,8 @@ class GemmArgs(C.Structure):
                 ("bias", vp),
                 ("gate0", vp), ("gate1", vp),
                 ("gate1_stride", i64), ("gate_rows", i32), ("gate_const", f32),
-                ("b_kmajor", i32)]
+                ("b_kmajor", i32),
+                ("c_in", vp), ("aux", vp), ("ldaux", i32)]
 
 
 COLSUM_MAX = 16
@@ -96,7 +97,7 @@ class AttnBwdArgs(C.Structure):
                 ("B", i32), ("H", i32), ("Lq", i32), ("Lk", i32),
                 ("q_bs", i64), ("q_rs", i64), ("k_bs", i64), ("k_rs", i64), ("o_bs", i64), ("o_rs", i64),
                 ("dq_bs", i64), ("dq_rs", i64), ("dk_bs", i64), ("dk_rs", i64), ("qt_bs", i64), ("kt_bs", i64),
-                ("ldq", i32), ("ldk", i32), ("scale", f32)]
+                ("ldq", i32), ("ldk", i32), ("scale", f32), ("q_prescaled", i32), ("out_bf16", i32)]
 
 
 class ConvArgs(C.Structure):
@@ -108,7 +109,7 @@ class ConvArgs(C.Structure):
                 ("up2", i32), ("out_f32", i32), ("split_n", i32), ("resid_f32", i32)]
 
 
-EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID, EPI_F32_ACCUM, EPI_GELU_ERF_BF16 = 0, 1, 2, 3, 4, 5
+EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID, EPI_F32_ACCUM, EPI_GELU_ERF_BF16, EPI_GELU_BWD_BF16 = 0, 1, 2, 3, 4, 5, 6
 BIAS_NONE, BIAS_N, BIAS_M = 0, 1, 2
 
 _SIGS = {
@@ -147,12 +148,15 @@ _SIGS = {
     "omh_layernorm_modulate_bwd": (i32, [vp, vp, vp, i64, i32, f32, f32, vp, vp, i64, vp, vp, i64, i64, vp]),
     "omh_rmsnorm_rope_bwd": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, i32, vp, f32, i32, vp, vp, i32, i32, vp, i32,
                                    vp]),
+    "omh_rmsnorm_rope_bwd_t": (i32, [vp, i32, i64, vp, i32, i64, vp, i64, vp, i64, i32, vp, f32, i32, vp, vp, i32, i32,
+                                     vp, i32, vp]),
     "omh_softmax_bwd_rows": (i32, [vp, i64, vp, i64, vp, i64, i64, i32, f32, vp]),
     "omh_unpatchify_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "omh_dense_f32_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "omh_adamw_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
     "omh_adamw_multi": (i32, [vp, i32, f32, f32, f32, f32, f32, i32, f32, vp]),
     "omh_ema_update": (i32, [vp, vp, i64, f32, vp]),
+    "omh_pack_weights_multi": (i32, [vp, i32, i64, vp]),
     "omh_gather_rows_f32": (i32, [vp, vp, vp, i64, i32, i64, vp]),
     "omh_rmsnorm_f32": (i32, [vp, vp, f32, vp, vp, i64, i32, vp]),
     "omh_layernorm_f32": (i32, [vp, vp, vp, f32, vp, i64, i32, vp]),

@@ -121,7 +121,10 @@ void attn_bwd_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dv[i][r] = 0.f; dk[i][r] = 0.f; }
-    const float sc = p.scale * LOG2E;
+    // q_prescaled: q / qt already carry scale * log2(e) (the forward's operands): scores are in the log2 domain as
+    // they come, and dK = dS^T q' / log2(e)
+    const float sc = p.q_prescaled ? 1.0f : p.scale * LOG2E;
+    const float ds_scale = p.q_prescaled ? (1.0f / LOG2E) : p.scale;
     const int qrow_l = swap_bits23(li);
 
     // global -> register prefetch one tile ahead: the loads of tile t+1 fly while tile t is computed.  Loads are
@@ -192,7 +195,7 @@ void attn_bwd_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks) {
                 dl[8 * a + e] = dl_s[16 * a + 8 * lh + e];
             }
         bf16x8 pf[2], dsf[2];
-        p_and_ds(s, dp, lv, dl, ok, sc, p.scale, pf, dsf);
+        p_and_ds(s, dp, lv, dl, ok, sc, ds_scale, pf, dsf);
         // dV^T += dO^T P ,  dK^T += Q^T dS   ([d][key], lane = key)
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -205,16 +208,30 @@ void attn_bwd_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks) {
             }
     }
     if (key < p.Lk) {
-        float* DK = p.dk + (int64_t)b * p.dk_bs + (int64_t)key * p.dk_rs + head * D;
-        float* DV = p.dv + (int64_t)b * p.dk_bs + (int64_t)key * p.dk_rs + head * D;
+        const int64_t eo = (int64_t)b * p.dk_bs + (int64_t)key * p.dk_rs + head * D;
+        if (p.out_bf16) {
+            uint16_t* DK = (uint16_t*)p.dk + eo;
+            uint16_t* DV = (uint16_t*)p.dv + eo;
 #pragma unroll
-        for (int db = 0; db < 4; ++db)
+            for (int db = 0; db < 4; ++db)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d0 = db * 32 + g * 8 + lh * 4;
-                *(float4*)(DK + d0) = make_float4(dk[db][4 * g], dk[db][4 * g + 1], dk[db][4 * g + 2], dk[db][4 * g + 3]);
-                *(float4*)(DV + d0) = make_float4(dv[db][4 * g], dv[db][4 * g + 1], dv[db][4 * g + 2], dv[db][4 * g + 3]);
-            }
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = db * 32 + g * 8 + lh * 4;
+                    *(uint2*)(DK + d0) = make_uint2(pack_bf2(dk[db][4 * g], dk[db][4 * g + 1]), pack_bf2(dk[db][4 * g + 2], dk[db][4 * g + 3]));
+                    *(uint2*)(DV + d0) = make_uint2(pack_bf2(dv[db][4 * g], dv[db][4 * g + 1]), pack_bf2(dv[db][4 * g + 2], dv[db][4 * g + 3]));
+                }
+        } else {
+            float* DK = (float*)p.dk + eo;
+            float* DV = (float*)p.dv + eo;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = db * 32 + g * 8 + lh * 4;
+                    *(float4*)(DK + d0) = make_float4(dk[db][4 * g], dk[db][4 * g + 1], dk[db][4 * g + 2], dk[db][4 * g + 3]);
+                    *(float4*)(DV + d0) = make_float4(dv[db][4 * g], dv[db][4 * g + 1], dv[db][4 * g + 2], dv[db][4 * g + 3]);
+                }
+        }
     }
 }
 
@@ -255,7 +272,7 @@ void attn_bwd_dq_kernel(const omh_attn_bwd_args p, const int q_blocks) {
         const float l = p.lse[row_i];
         l2 = (l > -INFINITY) ? l * LOG2E : INFINITY;
     }
-    const float sc = p.scale * LOG2E;
+    const float sc = p.q_prescaled ? 1.0f : p.scale * LOG2E;      // (dq stays the gradient of the UNSCALED q: x scale)
     const int krow_l = swap_bits23(li);
 
     // ---- pass 1: delta_i = sum_j P_ij dP_ij (this lane's query; its two half-lanes hold different keys)
@@ -348,13 +365,24 @@ void attn_bwd_dq_kernel(const omh_attn_bwd_args p, const int q_blocks) {
             }
     }
     if (q_ok) {
-        float* DQ = p.dq + (int64_t)b * p.dq_bs + (int64_t)q_row * p.dq_rs + head * D;
+        const int64_t eo = (int64_t)b * p.dq_bs + (int64_t)q_row * p.dq_rs + head * D;
+        if (p.out_bf16) {
+            uint16_t* DQ = (uint16_t*)p.dq + eo;
 #pragma unroll
-        for (int db = 0; db < 4; ++db)
+            for (int db = 0; db < 4; ++db)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *(float4*)(DQ + db * 32 + g * 8 + lh * 4) =
-                    make_float4(dq[db][4 * g], dq[db][4 * g + 1], dq[db][4 * g + 2], dq[db][4 * g + 3]);
+                for (int g = 0; g < 4; ++g)
+                    *(uint2*)(DQ + db * 32 + g * 8 + lh * 4) =
+                        make_uint2(pack_bf2(dq[db][4 * g], dq[db][4 * g + 1]), pack_bf2(dq[db][4 * g + 2], dq[db][4 * g + 3]));
+        } else {
+            float* DQ = (float*)p.dq + eo;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *(float4*)(DQ + db * 32 + g * 8 + lh * 4) =
+                        make_float4(dq[db][4 * g], dq[db][4 * g + 1], dq[db][4 * g + 2], dq[db][4 * g + 3]);
+        }
     }
 }
 

@@ -77,12 +77,6 @@ void colsum_multi_kernel(const omh_colsum_batch b) {
 }
 
 // ------------------------------------------------------------------ GELU-tanh fwd / bwd (bf16)
-__device__ __forceinline__ float gelu_tanh_grad(float x) {
-    const float c = 0.7978845608028654f, a = 0.044715f;
-    const float u = c * (x + a * x * x * x);
-    const float t = 1.0f - 2.0f / (1.0f + __expf(2.0f * u));          // tanh(u)
-    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * a * x * x);
-}
 
 __global__ __launch_bounds__(256)
 void gelu_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int64_t n) {
@@ -282,9 +276,18 @@ void layernorm_modulate_bwd_kernel(const float* __restrict__ x, const float* __r
 // ------------------------------------------------------------------ RMSNorm (+RoPE) backward
 // forward: y = rope( x * r * w ), r = rsqrt(mean(x^2)+eps).  g = unrope(dy);
 // dw[c] += g*x*r ; dx = r*(g*w) - x * r^3 * mean(x * g*w)   -> bf16
-template <int NV>
+// 4 consecutive elements of a row as fp32, from an fp32 or a bf16 tensor
+template <typename T> __device__ __forceinline__ float4 ld4(const T* row, int c);
+template <> __device__ __forceinline__ float4 ld4<float>(const float* row, int c) { return ((const float4*)row)[c]; }
+template <> __device__ __forceinline__ float4 ld4<uint16_t>(const uint16_t* row, int c) {
+    const uint2 u = ((const uint2*)row)[c];
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+
+template <int NV, typename XT, typename GT>
 __global__ __launch_bounds__(256)
-void rmsnorm_rope_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy,
+void rmsnorm_rope_bwd_kernel(const XT* __restrict__ x, int64_t ldx, const GT* __restrict__ dy, int64_t lddy,
                              uint16_t* __restrict__ dx, int64_t lddx, float* __restrict__ dw, int64_t rows, int dim,
                              const float* __restrict__ weight, float eps, int do_norm,
                              const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, int rope_len,
@@ -306,8 +309,8 @@ void rmsnorm_rope_bwd_kernel(const float* __restrict__ x, int64_t ldx, const flo
     for (int rr = 0; rr < RPW; ++rr) {
         const int64_t row = row0 + rr;
         if (row >= rows) break;
-        const float4* xr = (const float4*)(x + row * ldx);
-        const float4* gr = (const float4*)(dy + row * lddy);
+        const XT* xr = x + row * ldx;
+        const GT* gr = dy + row * lddy;
         float4 v[NV], g[NV];
         float q = 0.f;
         // both operands of the row are requested before the first reduction: with ~6 waves per CU at S = 1560 the
@@ -315,7 +318,7 @@ void rmsnorm_rope_bwd_kernel(const float* __restrict__ x, int64_t ldx, const flo
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
-            if (c < nv) { v[i] = xr[c]; g[i] = gr[c]; }
+            if (c < nv) { v[i] = ld4<XT>(xr, c); g[i] = ld4<GT>(gr, c); }
         }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -615,22 +618,45 @@ extern "C" int omh_layernorm_modulate_bwd(const float* x, const float* dy, float
     return omh_launch_status();
 }
 
+template <typename XT, typename GT>
+static int rmsnorm_rope_bwd_launch(const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx_bf16, int64_t lddx,
+                                   float* dweight, int64_t rows, int32_t dim, const float* weight, float eps,
+                                   int32_t do_norm, const float* rope_cos, const float* rope_sin, int32_t rope_len,
+                                   int32_t head_dim, const int32_t* grid, int32_t seq_len, omh_stream_t stream) {
+    if (!x || !dy || !dx_bf16 || rows <= 0 || dim <= 0) return OMH_E_BADARG;
+    if ((dim & 3) || dim > MAXV * 256 || (ldx & 3) || (lddy & 3) || (lddx & 3)) return OMH_E_SHAPE;
+    if (rope_cos && (!rope_sin || !grid || seq_len <= 0 || head_dim <= 0)) return OMH_E_BADARG;
+    omh_clear_status();
+    auto kern = dim <= 6 * 256 ? rmsnorm_rope_bwd_kernel<6, XT, GT>
+                               : (dim <= 20 * 256 ? rmsnorm_rope_bwd_kernel<20, XT, GT> : rmsnorm_rope_bwd_kernel<MAXV, XT, GT>);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 4 * RPW - 1) / (4 * RPW))), dim3(256), dim * sizeof(float),
+                       (hipStream_t)stream, (const XT*)x, ldx, (const GT*)dy, lddy, (uint16_t*)dx_bf16, lddx, dweight, rows,
+                       dim, weight, eps, do_norm, rope_cos, rope_sin, rope_len, head_dim, grid, seq_len);
+    return omh_launch_status();
+}
+
 extern "C" int omh_rmsnorm_rope_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, void* dx_bf16,
                                     int64_t lddx, float* dweight, int64_t rows, int32_t dim, const float* weight,
                                     float eps, int32_t do_norm, const float* rope_cos, const float* rope_sin,
                                     int32_t rope_len, int32_t head_dim, const int32_t* grid, int32_t seq_len,
                                     omh_stream_t stream) {
-    if (!x || !dy || !dx_bf16 || rows <= 0 || dim <= 0) return OMH_E_BADARG;
-    if ((dim & 3) || dim > MAXV * 256 || (ldx & 3) || (lddy & 3) || (lddx & 3)) return OMH_E_SHAPE;
-    if (rope_cos && (!rope_sin || !grid || seq_len <= 0 || head_dim <= 0)) return OMH_E_BADARG;
-    omh_clear_status();
-    auto kern = dim <= 6 * 256 ? rmsnorm_rope_bwd_kernel<6>
-                               : (dim <= 20 * 256 ? rmsnorm_rope_bwd_kernel<20> : rmsnorm_rope_bwd_kernel<MAXV>);
-    hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 4 * RPW - 1) / (4 * RPW))), dim3(256), dim * sizeof(float),
-                       (hipStream_t)stream, x, ldx, dy, lddy, (uint16_t*)dx_bf16, lddx, dweight, rows, dim, weight, eps,
-                       do_norm, rope_cos,
-                       rope_sin, rope_len, head_dim, grid, seq_len);
-    return omh_launch_status();
+    return rmsnorm_rope_bwd_launch<float, float>(x, ldx, dy, lddy, dx_bf16, lddx, dweight, rows, dim, weight, eps, do_norm,
+                                                 rope_cos, rope_sin, rope_len, head_dim, grid, seq_len, stream);
+}
+
+extern "C" int omh_rmsnorm_rope_bwd_t(const void* x, int32_t x_bf16, int64_t ldx, const void* dy, int32_t dy_bf16,
+                                      int64_t lddy, void* dx_bf16, int64_t lddx, float* dweight, int64_t rows, int32_t dim,
+                                      const float* weight, float eps, int32_t do_norm, const float* rope_cos,
+                                      const float* rope_sin, int32_t rope_len, int32_t head_dim, const int32_t* grid,
+                                      int32_t seq_len, omh_stream_t stream) {
+#define OMH_RRB(XT, GT)                                                                                               \
+    return rmsnorm_rope_bwd_launch<XT, GT>(x, ldx, dy, lddy, dx_bf16, lddx, dweight, rows, dim, weight, eps, do_norm,  \
+                                           rope_cos, rope_sin, rope_len, head_dim, grid, seq_len, stream)
+    if (x_bf16 && dy_bf16) OMH_RRB(uint16_t, uint16_t);
+    if (x_bf16) OMH_RRB(uint16_t, float);
+    if (dy_bf16) OMH_RRB(float, uint16_t);
+    OMH_RRB(float, float);
+#undef OMH_RRB
 }
 
 extern "C" int omh_softmax_bwd_rows(const void* p_bf16, int64_t ldp, const float* dp, int64_t lddp, void* ds_bf16,

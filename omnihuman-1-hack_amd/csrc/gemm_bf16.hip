@@ -236,7 +236,8 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
     // every global access is a 16-byte vector with LPR consecutive lanes covering one contiguous
     // row segment — full 128/256-byte lines for stores and for the residual read-modify-write.
     // All LDS reads of the main loop completed before its last barrier, so no extra barrier here.
-    constexpr bool OUT_BF16 = (EPI == OMH_EPI_BF16 || EPI == OMH_EPI_GELU_BF16 || EPI == OMH_EPI_GELU_ERF_BF16);
+    constexpr bool OUT_BF16 = (EPI == OMH_EPI_BF16 || EPI == OMH_EPI_GELU_BF16 || EPI == OMH_EPI_GELU_ERF_BF16 ||
+                               EPI == OMH_EPI_GELU_BWD_BF16);
     constexpr int PITCH = NT * 32 + 4;                 // floats
     constexpr int VEC = OUT_BF16 ? 8 : 4;              // elements per 16-byte global access
     constexpr int LPR = NT * 32 / VEC;                 // lanes per row
@@ -246,6 +247,13 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
     float* ep = (float*)smem + wave * (32 * PITCH);
     float* Cf = (float*)p.C + zb * p.strideC;
     uint16_t* Ch = (uint16_t*)p.C + zb * p.strideC;
+    // ABI v5 (batch == 1): out-of-place residual input, bf16 aux tensor (OUT: acc + bias of RESID / GELU; IN: the
+    // pre-activation of GELU_BWD)
+    const float* Cin = (EPI == OMH_EPI_RESID && p.c_in) ? p.c_in + zb * p.strideC : Cf;
+    uint16_t* Ax = (uint16_t*)p.aux;
+    constexpr bool AUX_OUT = (EPI == OMH_EPI_RESID || EPI == OMH_EPI_GELU_BF16);
+    constexpr bool AUX_IN = (EPI == OMH_EPI_GELU_BWD_BF16);
+    const bool aux_vec = Ax && (p.ldaux % 8) == 0 && (((uintptr_t)Ax) & 15) == 0;
     const int rr = lane / LPR, cc = (lane % LPR) * VEC;
     const int n = n0 + wn * NT * 32 + cc;
     const bool n_any = n < p.N;
@@ -270,7 +278,15 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
 #pragma unroll
             for (int ps = 0; ps < PASSES; ++ps) {
                 const int m = mrow + ps * RPP + rr;
-                cold[ps] = (m < p.M) ? *(const float4*)(Cf + (int64_t)m * p.ldc + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                cold[ps] = (m < p.M) ? *(const float4*)(Cin + (int64_t)m * p.ldc + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        uint4 apre[AUX_IN ? PASSES : 1];                            // GELU_BWD: the pre-activations of this strip
+        if (AUX_IN && vec_ok && aux_vec) {
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int m = mrow + ps * RPP + rr;
+                apre[ps] = (m < p.M) ? *(const uint4*)(Ax + (int64_t)m * p.ldaux + n) : make_uint4(0u, 0u, 0u, 0u);
             }
         }
 #pragma unroll
@@ -294,6 +310,37 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
             if (m >= p.M || !n_any) continue;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) v[e] += bn[e];
+            if (AUX_OUT && Ax) {                                       // bf16(acc + bias) on the side
+                uint16_t* ap = Ax + (int64_t)m * p.ldaux + n;
+                if (vec_ok && aux_vec) {
+                    if (VEC == 8) {
+                        uint4 pk;
+                        pk.x = pack_bf2(v[0], v[1]);
+                        pk.y = pack_bf2(v[2], v[3]);
+                        pk.z = pack_bf2(v[4 % VEC], v[5 % VEC]);
+                        pk.w = pack_bf2(v[6 % VEC], v[7 % VEC]);
+                        *(uint4*)ap = pk;
+                    } else {
+                        *(uint2*)ap = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) if (n + e < p.N) ap[e] = f2bf(v[e]);
+                }
+            }
+            if (AUX_IN) {                                              // dx = dy * gelu_tanh'(pre-activation)
+                if (vec_ok && aux_vec) {
+                    const uint4 a4 = apre[AUX_IN ? ps : 0];
+                    const uint32_t w_[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e)
+                        v[e] *= gelu_tanh_grad(__uint_as_float((e & 1) ? (w_[(e >> 1) & 3] & 0xffff0000u) : (w_[(e >> 1) & 3] << 16)));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e)
+                        if (n + e < p.N) v[e] *= gelu_tanh_grad(bf2f(Ax[(int64_t)m * p.ldaux + n + e]));
+                }
+            }
             if (EPI == OMH_EPI_GELU_BF16) {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) v[e] = gelu_tanh(v[e]);
@@ -339,7 +386,7 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
                     *(float4*)(Cf + off) = o;
                 } else {
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) if (n + e < p.N) Cf[off + e] += v[e];
+                    for (int e = 0; e < VEC; ++e) if (n + e < p.N) Cf[off + e] = Cin[off + e] + v[e];
                 }
             }
         }
@@ -429,6 +476,7 @@ static int launch_8w(const omh_gemm_args& a, hipStream_t s) {
         case OMH_EPI_RESID:     return launch<OMH_EPI_RESID>(a, s);
         case OMH_EPI_F32_ACCUM: return launch<OMH_EPI_F32_ACCUM>(a, s);
         case OMH_EPI_GELU_ERF_BF16: return launch<OMH_EPI_GELU_ERF_BF16>(a, s);
+        case OMH_EPI_GELU_BWD_BF16: return launch<OMH_EPI_GELU_BWD_BF16>(a, s);
         default: return OMH_E_BADARG;
     }
 }
@@ -455,6 +503,16 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
     if (((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15) || ((uintptr_t)a.C & 15)) return OMH_E_ALIGN;
     if ((a.strideA & 7) || (a.strideB & 7) || (a.strideC & 3)) return OMH_E_ALIGN;
     if (a.epilogue == OMH_EPI_RESID && a.gate1 && a.gate_rows <= 0) return OMH_E_BADARG;
+    const bool v5 = a.aux || a.c_in || a.epilogue == OMH_EPI_GELU_BWD_BF16;        // fused training epilogues
+    if (v5) {
+        if (a.batch != 1) return OMH_E_SHAPE;
+        if (a.epilogue == OMH_EPI_GELU_BWD_BF16 && !a.aux) return OMH_E_BADARG;
+        if (a.aux && a.epilogue != OMH_EPI_RESID && a.epilogue != OMH_EPI_GELU_BF16 && a.epilogue != OMH_EPI_GELU_BWD_BF16)
+            return OMH_E_BADARG;
+        if (a.c_in && a.epilogue != OMH_EPI_RESID) return OMH_E_BADARG;
+        if (a.aux && (a.ldaux < a.N || (a.ldaux & 7) || ((uintptr_t)a.aux & 15))) return OMH_E_ALIGN;
+        if (a.c_in && ((uintptr_t)a.c_in & 15)) return OMH_E_ALIGN;
+    }
     // 32-bit buffer offsets: each operand (one batch element) must stay below 2 GiB
     if (((int64_t)a.M + 128) * a.lda * 2 >= 0x7fffffffLL || ((int64_t)a.N + 128) * a.ldb * 2 >= 0x7fffffffLL)
         return OMH_E_SHAPE;
@@ -463,7 +521,7 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
         // OMH_GEMM_KERNEL = "w64": the 256 x 384 stream kernel wherever it applies; "8w": never; unset: where it
         // applies AND fills the chip (>= 256 tiles, last round of tiles at least 3/4 full or >= 4 rounds)
         const char* gk = getenv("OMH_GEMM_KERNEL");
-        const bool force = gk && gk[0] == 'w', never = (gk && gk[0] == '8') || (!force && getenv("OMH_GEMM_TILE"));
+        const bool force = gk && gk[0] == 'w', never = v5 || (gk && gk[0] == '8') || (!force && getenv("OMH_GEMM_TILE"));
         if (!never && omh_gemm_w64_takes(a)) {
             // (a ragged last tile column stays in this kernel, masked: handing N % 384 = 128 columns of the FFN's 8960
             // to the 8-wave kernel as a second launch measured 778 us against 757 us)

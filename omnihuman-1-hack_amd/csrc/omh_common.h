@@ -42,6 +42,13 @@ __device__ __forceinline__ float gelu_tanh(float x) {
     const float t = k * x * fmaf(0.044715f, x2, 1.0f);
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
 }
+// d/dx gelu_tanh(x) = 0.5 (1 + t) + 0.5 x (1 - t^2) c (1 + 3 a x^2),  t = tanh(c (x + a x^3))
+__device__ __forceinline__ float gelu_tanh_grad(float x) {
+    const float c = 0.7978845608028654f, a = 0.044715f;
+    const float u = c * (x + a * x * x * x);
+    const float t = 1.0f - 2.0f / (1.0f + __expf(2.0f * u));          // tanh(u)
+    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * a * x * x);
+}
 __device__ __forceinline__ float silu(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }

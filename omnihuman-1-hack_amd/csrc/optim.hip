@@ -50,6 +50,87 @@ void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, int64_t n,
         ema[i] = ema[i] * decay + p[i] * (1.0f - decay);
 }
 
+// ---------------------------------------------------------------------------------------------- weight packing
+// After an optimizer step every bf16 operand copy of the fp32 master weights is stale.  The training step used to
+// rebuild them per block with ~20 small cast / transpose launches (11 600 transposes + 8 200 casts per bench run);
+// this is ONE launch for all of them: entry e of the device table = {src fp32 [rows, cols] contiguous, dst bf16
+// [rows, ld_dst] or 0, dstT bf16 [cols, ld_dstT] or 0, rows, cols, ld_dst, ld_dstT, first tile, kind}.
+//   kind 0: dst = bf16(src) and / or dstT = bf16(src)^T, one 64 x 64 tile per workgroup (through LDS);
+//   kind 1: dst fp32 = src (rows = 1: the concatenated biases of fused projections), 4096 elements per workgroup.
+constexpr int PK_COLS = 9;
+
+__global__ __launch_bounds__(256)
+void pack_weights_kernel(const int64_t* __restrict__ table, int n_entries) {
+    __shared__ uint16_t tile[64][66];
+    const int64_t t = blockIdx.x;
+    int lo = 0, hi = n_entries - 1;                               // last entry whose first tile is <= t
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[(int64_t)mid * PK_COLS + 7] <= t) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* e = table + (int64_t)lo * PK_COLS;
+    const float* src = (const float*)e[0];
+    const int64_t rows = e[3], cols = e[4], ld_dst = e[5], ld_t = e[6];
+    const int64_t local = t - e[7];
+    const int tid = threadIdx.x;
+    if (e[8] == 1) {                                              // fp32 copy
+        float* dst = (float*)e[1];
+        const int64_t n = rows * cols, i0 = local * 4096;
+        for (int64_t i = i0 + tid; i < min(n, i0 + 4096); i += 256) dst[i] = src[i];
+        return;
+    }
+    uint16_t* dst = (uint16_t*)e[1];
+    uint16_t* dstT = (uint16_t*)e[2];
+    const int64_t tiles_c = (cols + 63) >> 6;
+    const int64_t r0 = (local / tiles_c) << 6, c0 = (local % tiles_c) << 6;
+    const bool vec = (cols & 3) == 0;
+    const int tr = tid >> 4, tc = (tid & 15) << 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rl = tr + 16 * j;
+        const int64_t r = r0 + rl, c = c0 + tc;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < rows) {
+            if (vec && c + 3 < cols) v = *(const float4*)(src + r * cols + c);
+            else {
+                if (c < cols) v.x = src[r * cols + c];
+                if (c + 1 < cols) v.y = src[r * cols + c + 1];
+                if (c + 2 < cols) v.z = src[r * cols + c + 2];
+                if (c + 3 < cols) v.w = src[r * cols + c + 3];
+            }
+        }
+        const uint32_t lo2 = pack_bf2(v.x, v.y), hi2 = pack_bf2(v.z, v.w);
+        if (dst && r < rows) {
+            if ((ld_dst & 3) == 0 && c + 3 < cols) *(uint2*)(dst + r * ld_dst + c) = make_uint2(lo2, hi2);
+            else {
+                if (c < cols) dst[r * ld_dst + c] = (uint16_t)(lo2 & 0xffff);
+                if (c + 1 < cols) dst[r * ld_dst + c + 1] = (uint16_t)(lo2 >> 16);
+                if (c + 2 < cols) dst[r * ld_dst + c + 2] = (uint16_t)(hi2 & 0xffff);
+                if (c + 3 < cols) dst[r * ld_dst + c + 3] = (uint16_t)(hi2 >> 16);
+            }
+        }
+        *(uint32_t*)&tile[rl][tc] = lo2;
+        *(uint32_t*)&tile[rl][tc + 2] = hi2;
+    }
+    if (!dstT) return;                                            // workgroup-uniform
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int cl = tr + 16 * j;                               // source column = row of the transposed copy
+        const int64_t c = c0 + cl, r = r0 + tc;
+        if (c >= cols) continue;
+        const uint16_t a0 = tile[tc][cl], a1 = tile[tc + 1][cl], a2 = tile[tc + 2][cl], a3 = tile[tc + 3][cl];
+        if ((ld_t & 3) == 0 && r + 3 < rows) {
+            *(uint2*)(dstT + c * ld_t + r) = make_uint2((uint32_t)a0 | ((uint32_t)a1 << 16), (uint32_t)a2 | ((uint32_t)a3 << 16));
+        } else {
+            if (r < rows) dstT[c * ld_t + r] = a0;
+            if (r + 1 < rows) dstT[c * ld_t + r + 1] = a1;
+            if (r + 2 < rows) dstT[c * ld_t + r + 2] = a2;
+            if (r + 3 < rows) dstT[c * ld_t + r + 3] = a3;
+        }
+    }
+}
+
 inline int grid_for(int64_t n) {
     int64_t g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -84,5 +165,13 @@ extern "C" int omh_ema_update(float* ema, const float* p, int64_t n, float decay
     if (!ema || !p || n <= 0) return OMH_E_BADARG;
     omh_clear_status();
     hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, ema, p, n, decay);
+    return omh_launch_status();
+}
+
+extern "C" int omh_pack_weights_multi(const int64_t* table, int32_t n_entries, int64_t total_tiles, omh_stream_t stream) {
+    if (!table || n_entries <= 0 || total_tiles <= 0 || total_tiles > 0x7fffffffLL) return OMH_E_BADARG;
+    omh_clear_status();
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, table,
+                       n_entries);
     return omh_launch_status();
 }

@@ -10,8 +10,8 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (BIAS_M, BIAS_N, BIAS_NONE, EPI_BF16, EPI_F32, EPI_F32_ACCUM, EPI_GELU_BF16, EPI_GELU_ERF_BF16, EPI_RESID,
-                   AttnArgs, GemmArgs, OmhError, check, lib)
+from ._lib import (BIAS_M, BIAS_N, BIAS_NONE, EPI_BF16, EPI_F32, EPI_F32_ACCUM, EPI_GELU_BF16, EPI_GELU_BWD_BF16,
+                   EPI_GELU_ERF_BF16, EPI_RESID, AttnArgs, GemmArgs, OmhError, check, lib)
 
 __all__ = ["gemm", "flash_attn", "layernorm_modulate", "rmsnorm_rope", "cast_bf16", "patchify", "unpatchify",
            "dense_f32", "sinusoidal_embedding", "cfg_unipc_step", "conv_cl", "rms_silu_cl", "nchw_to_cl", "cl_to_nchw",
@@ -41,10 +41,11 @@ def ptr(t: torch.Tensor, elem_off: int = 0):
 
 def gemm_raw(A, B, Cp, M, N, K, lda, ldb, ldc, epilogue, bias=None, bias_mode=BIAS_NONE, batch=1,
              strideA=0, strideB=0, strideC=0, gate0=None, gate1=None, gate1_stride=0, gate_rows=1,
-             gate_const=0.0, b_kmajor=False):
-    """C[m][n] = epi(sum_k A[m][k] B[n][k])  (b_kmajor: B[k][n], [K, N] row-major); all pointers are c_void_p."""
+             gate_const=0.0, b_kmajor=False, c_in=None, aux=None, ldaux=0):
+    """C[m][n] = epi(sum_k A[m][k] B[n][k])  (b_kmajor: B[k][n], [K, N] row-major); all pointers are c_void_p.
+    ``c_in`` / ``aux`` / ``ldaux``: the fused training epilogues of include/omh.h (ABI v5)."""
     a = GemmArgs(A, B, Cp, M, N, K, lda, ldb, ldc, batch, strideA, strideB, strideC, epilogue, bias_mode, bias,
-                 gate0, gate1, gate1_stride, gate_rows, gate_const, int(b_kmajor))
+                 gate0, gate1, gate1_stride, gate_rows, gate_const, int(b_kmajor), c_in, aux, ldaux)
     check(lib.omh_gemm_bf16(C.byref(a), _stream()), "omh_gemm_bf16")
 
 
@@ -114,14 +115,16 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, k_lens: Optio
     return out
 
 
-def flash_attn_bwd(q, k, v, o, dout, lse, k_lens, B, H, Lq, Lk, scale=None):
+def flash_attn_bwd(q, k, v, o, dout, lse, k_lens, B, H, Lq, Lk, scale=None, q_prescaled=False, out=None):
     """Fused attention backward (include/omh.h).  q, o, dout: bf16 [B*Lq, H*128]; k, v: bf16 [B*Lk, H*128]
-    (contiguous); lse fp32 [B, H, Lq] from ``flash_attn_raw(..., lse=)``; k_lens int32 [B] or None.
-    Returns fp32 dq [B*Lq, H*128], dk, dv [B*Lk, H*128]."""
+    (row stride free); lse fp32 [B, H, Lq] from ``flash_attn_raw(..., lse=)``; k_lens int32 [B] or None.
+    Returns fp32 dq [B*Lq, H*128], dk, dv [B*Lk, H*128] — or, with ``out=(dq, dk, dv)`` bf16 2-D tensors (row stride
+    free: e.g. the three column blocks of one [rows, 3*H*128] buffer), writes bf16 gradients there.
+    ``q_prescaled``: q carries scale*log2(e) as in the forward call."""
     _dev(q, k, v, o, dout, lse, k_lens)
     d = H * 128
-    for t in (q, k, v, o, dout):
-        assert t.dtype == torch.bfloat16 and t.is_contiguous() and t.shape[-1] == d
+    for t in (q, k, v, dout):
+        assert t.dtype == torch.bfloat16 and t.stride(-1) == 1 and t.shape[-1] == d
     assert lse.dtype == torch.float32 and lse.is_contiguous() and lse.numel() == B * H * Lq
     dev = q.device
     ldq, ldk = (Lq + 63) // 64 * 64, (Lk + 63) // 64 * 64
@@ -131,17 +134,28 @@ def flash_attn_bwd(q, k, v, o, dout, lse, k_lens, B, H, Lq, Lk, scale=None):
             t[:, :, L:].zero_()
         return t
     qt, dot, kt = padded(Lq, ldq), padded(Lq, ldq), padded(Lk, ldk)
-    transpose_bf16_raw(ptr(q), ptr(qt), Lq, d, d, ldq, batch=B, bs_in=Lq * d, bs_out=d * ldq)
-    transpose_bf16_raw(ptr(dout), ptr(dot), Lq, d, d, ldq, batch=B, bs_in=Lq * d, bs_out=d * ldq)
-    transpose_bf16_raw(ptr(k), ptr(kt), Lk, d, d, ldk, batch=B, bs_in=Lk * d, bs_out=d * ldk)
+    rs = lambda t: t.stride(-2)
+    transpose_bf16_raw(ptr(q), ptr(qt), Lq, d, rs(q), ldq, batch=B, bs_in=Lq * rs(q), bs_out=d * ldq)
+    transpose_bf16_raw(ptr(dout), ptr(dot), Lq, d, rs(dout), ldq, batch=B, bs_in=Lq * rs(dout), bs_out=d * ldq)
+    transpose_bf16_raw(ptr(k), ptr(kt), Lk, d, rs(k), ldk, batch=B, bs_in=Lk * rs(k), bs_out=d * ldk)
     delta = torch.empty(B, H, Lq, dtype=torch.float32, device=dev)
-    dq = torch.empty(B * Lq, d, dtype=torch.float32, device=dev)
-    dk = torch.empty(B * Lk, d, dtype=torch.float32, device=dev)
-    dv = torch.empty(B * Lk, d, dtype=torch.float32, device=dev)
+    if out is None:
+        dq = torch.empty(B * Lq, d, dtype=torch.float32, device=dev)
+        dk = torch.empty(B * Lk, d, dtype=torch.float32, device=dev)
+        dv = torch.empty(B * Lk, d, dtype=torch.float32, device=dev)
+        bf = 0
+    else:
+        dq, dk, dv = out
+        for t in out:
+            assert t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1 and t.shape[1] == d
+        assert dk.stride(0) == dv.stride(0)
+        bf = 1
+    assert rs(k) == rs(v)
     a = _lib.AttnBwdArgs(_p(q), _p(k), _p(v), _p(o), _p(dout), _p(qt), _p(dot), _p(kt), _p(lse), _p(delta),
                          _p(dq), _p(dk), _p(dv), _p(k_lens), B, H, Lq, Lk,
-                         Lq * d, d, Lk * d, d, Lq * d, d, Lq * d, d, Lk * d, d, d * ldq, d * ldk, ldq, ldk,
-                         float(scale if scale is not None else 128 ** -0.5))
+                         Lq * rs(q), rs(q), Lk * rs(k), rs(k), Lq * rs(dout), rs(dout), Lq * dq.stride(0), dq.stride(0),
+                         Lk * dk.stride(0), dk.stride(0), d * ldq, d * ldk, ldq, ldk,
+                         float(scale if scale is not None else 128 ** -0.5), int(q_prescaled), bf)
     check(lib.omh_flash_attn_bwd_d128(C.byref(a), _stream()), "omh_flash_attn_bwd_d128")
     return dq, dk, dv
 
@@ -360,6 +374,23 @@ def transpose_bf16(x: torch.Tensor, pad_to: int = 8):
     return out
 
 
+def transpose_bf16_batched(xt: torch.Tensor, L: int) -> torch.Tensor:
+    """xt bf16 [B, d, ld] (e.g. a V^T buffer of the attention forward) -> its first L columns transposed per batch
+    element, stacked: bf16 [B*L, d]."""
+    _dev(xt)
+    assert xt.dtype == torch.bfloat16 and xt.dim() == 3 and xt.is_contiguous() and L <= xt.shape[2]
+    B, d, ld = xt.shape
+    out = torch.empty(B * L, d, dtype=torch.bfloat16, device=xt.device)
+    transpose_bf16_raw(_p(xt), _p(out), d, L, ld, d, batch=B, bs_in=d * ld, bs_out=L * d)
+    return out
+
+
+def cast_bf16_strided(x: torch.Tensor, out: torch.Tensor):
+    """fp32 contiguous [R, C] -> an existing bf16 [R, C] view with a free row stride (cast kernel + strided copy)."""
+    out.copy_(cast_bf16(x))
+    return out
+
+
 def colsum_accum(x: torch.Tensor, out: torch.Tensor):
     """out[c] += sum_r x[r][c]; x bf16/fp32 [R, C]."""
     _dev(x, out)
@@ -439,6 +470,14 @@ def rmsnorm_rope_bwd_raw(x, ldx, dy, lddy, dx, lddx, dw, rows, dim, weight, eps,
                                    rope_sin, rope_len, head_dim, grid, seq_len, _stream()), "omh_rmsnorm_rope_bwd")
 
 
+def rmsnorm_rope_bwd_t_raw(x, x_bf16, ldx, dy, dy_bf16, lddy, dx, lddx, dw, rows, dim, weight, eps, do_norm, rope_cos,
+                           rope_sin, rope_len, head_dim, grid, seq_len):
+    """omh_rmsnorm_rope_bwd with bf16 or fp32 x / dy (include/omh.h); dx may alias dy."""
+    check(lib.omh_rmsnorm_rope_bwd_t(x, int(x_bf16), ldx, dy, int(dy_bf16), lddy, dx, lddx, dw, rows, dim, weight, eps,
+                                     do_norm, rope_cos, rope_sin, rope_len, head_dim, grid, seq_len, _stream()),
+          "omh_rmsnorm_rope_bwd_t")
+
+
 def softmax_bwd_rows(p, dp, ds, L, scale):
     _dev(p, dp, ds)
     assert p.dtype == torch.bfloat16 and dp.dtype == torch.float32 and ds.dtype == torch.bfloat16
@@ -480,6 +519,14 @@ def adamw_multi(table, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=
     assert table.dtype == torch.int64 and table.is_contiguous()
     check(lib.omh_adamw_multi(_p(table), n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, _stream()),
           "omh_adamw_multi")
+
+
+def pack_weights_multi(table, n_entries, total_tiles):
+    """One launch for every bf16 operand copy (and transposed copy) of the fp32 master weights; ``table``: int64 device
+    tensor [n_entries, 9] (include/omh.h)."""
+    _dev(table)
+    assert table.dtype == torch.int64 and table.is_contiguous() and table.shape == (n_entries, 9)
+    check(lib.omh_pack_weights_multi(_p(table), n_entries, total_tiles, _stream()), "omh_pack_weights_multi")
 
 
 def ema_update(ema, p, decay):

@@ -1,21 +1,43 @@
 """Training-mode forward/backward of WanModel on the gfx950 kernels — the
 student step of seaweed_apt/distilled_trainer.py:241-316 (BASELINE config 3).
 
-The reference gets the backward from autograd over aten ops with one
-``torch.utils.checkpoint`` per block (model.py:544-548).  Here autograd only
-chains three kinds of hand-written nodes — embed -> 30 x block -> head — so
-DDP's bucketed RCCL all-reduce still overlaps with the backward (each block's
-parameter gradients become ready when that block's node finishes):
+The reference gets the backward from autograd over aten ops, with one
+``torch.utils.checkpoint`` per block when ``model.use_checkpoint`` is set
+(model.py:544-553).  Here autograd only chains three kinds of hand-written
+nodes — embed -> 30 x block -> head — so a data-parallel reducer (DDP's, or
+parallel.BucketedGradAllReduce) still overlaps its all-reduce with the
+backward: each block's parameter gradients become ready when that block's
+node finishes.
 
-* forward of a block node = the fused inference block (model.py:279-330 on
-  libomh.so), saving only its input residual stream (per-block checkpointing,
-  as the reference does);
-* backward of a block node = recompute the block with un-fused kernels that
-  keep the intermediates, then the chain rule by hand: every dgrad / wgrad /
-  attention dQ,dK,dV product is ``omh_gemm_bf16`` on transposed bf16 operands,
-  surrounded by the kernels of csrc/dit_backward.hip.  Gradients w.r.t. the
-  time-embedding vector ``e0``, the text context and ``e`` are accumulated in a
-  per-forward state object and consumed by the embed node, which runs last.
+A block node's forward is ``_block_forward``: the kernels and epilogues of the
+inference block (model.py:279-330 on libomh.so; same operands, same roundings,
+bit-identical output), with the residual stream written out of place and the
+few extra tensors the backward needs emitted by the producing kernels' epilogues
+(the branch outputs y = o W^T + b for the gate gradients, the FFN pre-activation
+for GELU').  What happens to those tensors is ``model.use_checkpoint``'s call,
+as in the reference:
+
+* ``use_checkpoint = False`` (model.py:549-553): they are kept — 0.6 GB per
+  block at 4 clips, 18 GB for the 1.3B model, nothing against 288 GB of HBM — and
+  the backward starts straight away;
+* ``use_checkpoint = True`` (model.py:544-548, the reference's 24 GB default):
+  only the block's input is kept and the backward first re-runs
+  ``_block_forward`` — the same kernels on the same input, hence the same
+  values the loss was computed from.
+
+The backward applies the chain rule by hand: every dgrad / wgrad product is an
+MFMA GEMM (``omh_gemm_bf16`` on a transposed weight copy, ``omh_gemm_bf16_tn`` on
+dy and x as they are), the attention backward is the fused kernel pair of
+csrc/attention_bwd.hip on the forward's own (pre-scaled) q, k, v and log-sum-exp,
+GELU' is an epilogue of the FFN dgrad GEMM.  q, k, v share one gradient buffer
+[rows, 3 dim], so their input gradient and their weight gradients are ONE GEMM
+each (K = 3 dim / M = 3 dim); likewise k, v of the cross-attention.  Gradients
+w.r.t. the time-embedding vector ``e0``, the text context and ``e`` are
+accumulated in a per-forward state object and consumed by the embed node.
+
+bf16 operand copies of the weights (and the transposed copies the dgrad GEMMs
+read) are rebuilt by ONE launch per step (``TrainPacks``, omh_pack_weights_multi)
+— after an optimizer step every copy is stale.
 
 Reference quirk kept by default: for ``block_idx > 10``
 the reference computes the FFN on the CPU under ``no_grad`` and adds
@@ -23,10 +45,9 @@ the reference computes the FFN on the CPU under ``no_grad`` and adds
 upstream *through that FFN* — receive no gradient; only the gate ``e[5]`` does.
 ``model.reference_ffn_freeze = False`` turns the quirk off (full gradients).
 
-The attention backward is the fused kernel pair of csrc/attention_bwd.hip (sized for the single-frame training
-clips of config 3, S = 1560); ``OMH_ATTN_BWD=unfused`` keeps the first implementation (scores materialised per head
-through the GEMM kernel) for A/B runs.  The i2v backbone trains too: the image-token branch of the cross-attention
-(k_img / v_img / norm_k_img) and img_emb (LayerNorm, Linear, GELU(erf), Linear, LayerNorm on the CLIP tokens).
+The i2v backbone trains too: the image-token branch of the cross-attention
+(k_img / v_img / norm_k_img) and img_emb (LayerNorm, Linear, GELU(erf), Linear,
+LayerNorm on the CLIP tokens).
 """
 import math
 import os
@@ -37,7 +58,9 @@ from .._backend import ops
 
 ptr = ops.ptr
 EPI_BF16, EPI_F32, EPI_ACC = ops.EPI_BF16, ops.EPI_F32, ops.EPI_F32_ACCUM
+EPI_GELU_BF16, EPI_RESID, EPI_GELU_BWD = ops.EPI_GELU_BF16, ops.EPI_RESID, ops.EPI_GELU_BWD_BF16
 BIAS_N, BIAS_M, BIAS_NONE = ops.BIAS_N, ops.BIAS_M, ops.BIAS_NONE
+LOG2E = 1.4426950408889634
 
 
 def _ru(a, b):
@@ -52,30 +75,96 @@ class _State:
         self.d_e0 = self.d_e = self.d_ctx = None
 
 
-# dgrad products dx = dy W: on a transposed bf16 copy of the weight (one transpose per weight and step, cached per
-# weight version) with the row-major-B kernel.  OMH_DGRAD=nn runs them on the weight as stored ([out, in] = k-major
-# B of omh_gemm_bf16) instead — no copies, but measured slower (146.1 vs 143.7 ms per 4-clip step: the transposing
-# LDS read costs more than the ~250 weight transposes, see gemm_bf16.hip), kept for the tests and for A/B timing.
-_DGRAD_NN = os.environ.get("OMH_DGRAD", "nt") == "nn"
+# ----------------------------------------------------------------------------- bf16 weight copies, one launch per step
+class TrainPacks:
+    """bf16 operand copies of every block's Linear weights for the training step, in persistent buffers, rebuilt by
+    ONE ``omh_pack_weights_multi`` launch whenever a parameter changed (version counters): per block
+      wqkv [3d, d] (+ wqkvT [d, 3d], bqkv fp32 [3d]) · wo, woT · cross wq, wqT · cross wkv [2d, d], wkvT, (i2v: wkvi,
+      wkviT) · cross wo, woT · w1 [f, d], w1T · w2 [d, f], w2T     (T = the transposed copy the dgrad GEMM reads;
+    not built for the FFNs the reference's quirk freezes).  The q | k | v (and cross k | v) weights sit in one buffer
+    so that their input gradient and their weight gradient are one GEMM each."""
+
+    def __init__(self, model):
+        self.sig = None
+        self.table = None
+        self.blocks = []
+        self.key = None
+
+    @staticmethod
+    def of(model):
+        tp = model.__dict__.get("_train_packs")
+        if tp is None:
+            tp = model.__dict__["_train_packs"] = TrainPacks(model)
+        return tp
+
+    def _layout(self, model):
+        dev = model.patch_embedding.weight.device
+        freeze = bool(getattr(model, "reference_ffn_freeze", True))
+        rows, self.blocks, self.params = [], [], []
+        bf = lambda *shape: torch.empty(*shape, dtype=torch.bfloat16, device=dev)
+
+        def entry(src, dst, dstT, r, c, ld_dst, ld_t, kind=0):
+            assert src.dtype == torch.float32 and src.is_contiguous(), "training packs expect fp32 master weights"
+            self.params.append(src)
+            rows.append([src.data_ptr(), dst.data_ptr() if dst is not None else 0,
+                         dstT.data_ptr() if dstT is not None else 0, r, c, ld_dst, ld_t, 0, kind])
+
+        for idx, blk in enumerate(model.blocks):
+            sa, ca = blk.self_attn, blk.cross_attn
+            d, f = blk.dim, blk.ffn_dim
+            P = {}
+            P["wqkv"], P["wqkvT"] = bf(3 * d, d), bf(d, 3 * d)
+            P["bqkv"] = torch.empty(3 * d, dtype=torch.float32, device=dev)
+            for j, lin in enumerate((sa.q, sa.k, sa.v)):
+                entry(lin.weight, P["wqkv"][j * d:], P["wqkvT"][:, j * d:], d, d, d, 3 * d)
+                entry(lin.bias, P["bqkv"][j * d:], None, 1, d, d, 0, kind=1)
+            P["wo"], P["woT"] = bf(d, d), bf(d, d)
+            entry(sa.o.weight, P["wo"], P["woT"], d, d, d, d)
+            P["wq_c"], P["wq_cT"] = bf(d, d), bf(d, d)
+            entry(ca.q.weight, P["wq_c"], P["wq_cT"], d, d, d, d)
+            P["wkv_c"], P["wkv_cT"] = bf(2 * d, d), bf(d, 2 * d)
+            for j, lin in enumerate((ca.k, ca.v)):
+                entry(lin.weight, P["wkv_c"][j * d:], P["wkv_cT"][:, j * d:], d, d, d, 2 * d)
+            if hasattr(ca, "k_img"):
+                P["wkv_i"], P["wkv_iT"] = bf(2 * d, d), bf(d, 2 * d)
+                for j, lin in enumerate((ca.k_img, ca.v_img)):
+                    entry(lin.weight, P["wkv_i"][j * d:], P["wkv_iT"][:, j * d:], d, d, d, 2 * d)
+            P["wo_c"], P["wo_cT"] = bf(d, d), bf(d, d)
+            entry(ca.o.weight, P["wo_c"], P["wo_cT"], d, d, d, d)
+            frozen = freeze and idx > 10
+            P["w1"], P["w2"] = bf(f, d), bf(d, f)
+            P["w1T"], P["w2T"] = (None, None) if frozen else (bf(d, f), bf(f, d))
+            entry(blk.ffn[0].weight, P["w1"], P["w1T"], f, d, d, f)
+            entry(blk.ffn[2].weight, P["w2"], P["w2T"], d, f, f, d)
+            self.blocks.append(P)
+        tile0 = 0
+        for r in rows:
+            r[7] = tile0
+            tile0 += (r[3] * r[4] + 4095) // 4096 if r[8] == 1 else ((r[3] + 63) // 64) * ((r[4] + 63) // 64)
+        self.total_tiles, self.n = tile0, len(rows)
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+
+    def refresh(self, model):
+        """Make the copies current; returns the per-block dicts."""
+        from . import model as _model_mod
+        freeze = bool(getattr(model, "reference_ffn_freeze", True))
+        dev = model.patch_embedding.weight.device
+        if self.table is None or self.key != (freeze, str(dev)) or \
+                any(p.data_ptr() != r for p, r in zip(self.params, self.ptrs)):
+            self._layout(model)
+            self.key, self.ptrs, self.sig = (freeze, str(dev)), [p.data_ptr() for p in self.params], None
+        sig = [p._version for p in self.params]
+        if sig != self.sig or _model_mod._Packed.always_rebuild:   # (under hipGraph capture the launch is a graph node)
+            ops.pack_weights_multi(self.table, self.n, self.total_tiles)
+            self.sig = sig
+        return self.blocks
 
 
-def _wT(mod, key, weight_bf16):
-    """B operand of the dgrad GEMM for a packed [N, K] weight: its transposed bf16 copy [K, N] (cached per weight
-    version), or with OMH_DGRAD=nn the weight itself (k-major B)."""
-    if _DGRAD_NN:
-        return weight_bf16
-    return mod._packed.get("T:" + key, (weight_bf16,), lambda: ops.transpose_bf16(weight_bf16))
-
-
-def _wT_once(weight_bf16):
-    return weight_bf16 if _DGRAD_NN else ops.transpose_bf16(weight_bf16)
-
-
-# The weight-gradient GEMMs of a block run on a second HIP stream (OMH_WGRAD_STREAM=0: on the main one).  At 4 clips per GPU they are
-# tile-poor (1536 x 1536 outputs: 144 tiles with split K) like the dgrad GEMMs they are independent of (150 tiles on 256
-# CUs), so the two fill each other's idle CUs.  The side stream forks from the main one at every call (its inputs are
-# ready there) and joins at the end of the block's backward (_wgrad_join); hipGraph capture follows the fork / join.
-# Measured: 142.7 -> 138.2 ms per step at 4 clips, 428 -> 413 ms at 16, 167 -> 162 ms with every parameter trained.
+# The weight-gradient GEMMs of a block run on a second HIP stream (OMH_WGRAD_STREAM=0: on the main one).  At 4 clips per
+# GPU they are tile-poor like the dgrad GEMMs they are independent of (150 tiles on 256 CUs), so the two fill each
+# other's idle CUs.  The side stream forks from the main one at every call (its inputs are ready there) and joins at
+# the end of the block's backward (_wgrad_join); hipGraph capture follows the fork / join.
+# Measured (round 2): 142.7 -> 138.2 ms per step at 4 clips, 428 -> 413 ms at 16.
 _WGRAD_STREAM = os.environ.get("OMH_WGRAD_STREAM", "1") == "1"
 _side = {}
 
@@ -92,72 +181,24 @@ def _wgrad_join(dev):
         torch.cuda.current_stream(dev).wait_stream(_side[dev])
 
 
-def _prepack(model, blk, idx, transposes):
-    """Build block ``idx``'s bf16 weight copies (and, for the backward, their transposes) on the side stream while the
-    main stream computes the neighbouring block: after an optimizer step every copy is stale, and the ~20 small cast /
-    transpose kernels per block (93 MB written) otherwise sit between the block's GEMMs on the main stream.  The
-    caller's next use of the block is ordered behind them by _wgrad_join."""
-    from . import model as _model_mod
-    if not _WGRAD_STREAM or _model_mod._Packed.always_rebuild:     # (under hipGraph capture the packs are graph nodes)
-        return
-    dev = blk.modulation.device
-    main, side = torch.cuda.current_stream(dev), _side_stream(dev)
-    side.wait_stream(main)
-    sa, ca = blk.self_attn, blk.cross_attn
-    frozen_ffn = getattr(model, "reference_ffn_freeze", True) and idx > 10
-    with torch.cuda.stream(side), torch.no_grad():
-        wqk, _ = sa._w_qk()
-        packs = {"qk": (sa, wqk), "v": (sa, sa._w("v")[0]), "o": (sa, sa._w("o")[0]),
-                 "q": (ca, ca._w("q")[0]), "k": (ca, ca._w("k")[0]), "v_": (ca, ca._w("v")[0]), "o_": (ca, ca._w("o")[0])}
-        if hasattr(ca, "k_img"):
-            packs["k_img"] = (ca, ca._w("k_img")[0])
-            packs["v_img"] = (ca, ca._w("v_img")[0])
-        w1, w2 = blk._ffn_w(0)[0], blk._ffn_w(2)[0]
-        if transposes:
-            for key, (mod, w) in packs.items():
-                _wT(mod, key.rstrip("_"), w)
-            if not frozen_ffn:
-                _wT(blk, "ffn2", w2)
-                _wT(blk, "ffn0", w1)
-
-
-def _wgrad(dy, x, xT=None, out=None):
-    """dW[N, K] = dy[R, N]^T @ x[R, K]  (fp32) on dy and x as they are (row-major bf16): the k-major GEMM of
-    csrc/gemm_tn.hip — no transposed copies.  With ``out`` the product is ADDED to it (a weight used twice in the
-    block).  ``xT`` is ignored (kept for the OMH_WGRAD=nt path: two transposes + the NT kernel, for A/B timing)."""
-    if _WGRAD_TN and _WGRAD_STREAM and _side.get("on"):
+def _wgrad(dy, x, out=None, side=False):
+    """dW[N, K] (+)= dy[R, N]^T @ x[R, K]  (fp32) on dy and x as they are (row-major bf16, row stride free): the
+    k-major GEMM of csrc/gemm_tn.hip — no transposed copies.  With ``out`` the product is ADDED to it (a weight used
+    twice in the block).  ``side``: on the second stream (the caller joins with _wgrad_join before the result is used
+    or handed to autograd)."""
+    if side and _WGRAD_STREAM:
         dev = dy.device
-        main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+        main, sd = torch.cuda.current_stream(dev), _side_stream(dev)
+        acc = out is not None
         if out is None:
             out = torch.empty(dy.shape[1], x.shape[1], dtype=torch.float32, device=dev)
-            acc = False
-        else:
-            acc = True
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
+        sd.wait_stream(main)
+        with torch.cuda.stream(sd):
             ops.gemm_tn(dy, x, out=out, accumulate=acc)
         for t in (dy, x, out):
-            t.record_stream(side)
+            t.record_stream(sd)
         return out
-    if _WGRAD_TN:
-        return ops.gemm_tn(dy, x, out=out, accumulate=out is not None)
-    dyT = ops.transpose_bf16(dy)
-    xT = ops.transpose_bf16(x) if xT is None else xT
-    N, K, Rp = dyT.shape[0], xT.shape[0], dyT.shape[1]
-    acc = out is not None
-    if out is None:
-        out = torch.empty(N, K, dtype=torch.float32, device=dy.device)
-    ops.gemm_raw(ptr(dyT), ptr(xT), ptr(out), N, K, Rp, Rp, Rp, K, EPI_ACC if acc else EPI_F32)
-    return out
-
-
-def _dgrad_ctx(dy, wT, d_ctx, first, L):
-    """d_ctx[b, first:first+L, :] += dy[b*L:(b+1)*L, :] @ W  for every sample b (the context gradient of a K / V
-    projection that reads a slice of the context rows): one batched GEMM into the strided destination."""
-    B, Lc, d = d_ctx.shape
-    N = dy.shape[1]
-    ops.gemm_raw(ptr(dy), ptr(wT), ptr(d_ctx, first * d), L, d, N, dy.stride(0), wT.stride(0), d, EPI_ACC, batch=B,
-                 strideA=L * dy.stride(0), strideB=0, strideC=Lc * d, b_kmajor=_DGRAD_NN)
+    return ops.gemm_tn(dy, x, out=out, accumulate=out is not None)
 
 
 class _ZeroArena:
@@ -187,106 +228,334 @@ class _ZeroArena:
         return out
 
 
-_BGRAD_MULTI = os.environ.get("OMH_BGRAD", "multi") != "single"      # "single": one launch per bias gradient (A/B timing)
-
-
 def _bgrad(dy, arena=None):
     """Bias gradient = column sums of dy.  With an arena the sum is deferred to ``arena.flush()`` at the end of the
     block backward (dy stays referenced until then); the returned accumulator is complete after the flush."""
     out = arena.take(dy.shape[1]) if arena is not None else torch.zeros(dy.shape[1], dtype=torch.float32, device=dy.device)
-    if arena is not None and _BGRAD_MULTI:
+    if arena is not None:
         arena.pending.append((dy, out))
         return out
     return ops.colsum_accum(dy, out)
 
 
-def _dgrad(dy, wT, out=None, accumulate=False):
-    """dx[R, K] = dy[R, N] @ W[N, K]  with wT from _wT (W itself, or W^T bf16 [K, Np]); fp32 output."""
+def _dgrad(dy, wT, out=None, accumulate=False, epilogue=None):
+    """dx[R, K] = dy[R, N] @ W[N, K]  with wT = W^T bf16 [K, N] (row stride free); fp32 output unless ``epilogue``."""
     R, N = dy.shape
-    K = wT.shape[1] if _DGRAD_NN else wT.shape[0]
+    K = wT.shape[0]
+    epi = epilogue if epilogue is not None else (EPI_ACC if accumulate else EPI_F32)
     if out is None:
-        out = torch.empty(R, K, dtype=torch.float32, device=dy.device)
-    ops.gemm_raw(ptr(dy), ptr(wT), ptr(out), R, K, N, dy.stride(0), wT.stride(0), out.stride(0),
-                 EPI_ACC if accumulate else EPI_F32, b_kmajor=_DGRAD_NN)
+        out = torch.empty(R, K, dtype=torch.bfloat16 if epi == EPI_BF16 else torch.float32, device=dy.device)
+    ops.gemm_raw(ptr(dy), ptr(wT), ptr(out), R, K, N, dy.stride(0), wT.stride(0), out.stride(0), epi)
     return out
 
 
-def _axpy_rows(dst2d, src2d):
-    """dst[b] += src[b] for small fp32 [B, n] buffers (colsum kernel with one row)."""
-    for b in range(dst2d.shape[0]):
-        ops.colsum_accum(src2d[b:b + 1], dst2d[b])
+def _wT_once(weight_bf16):
+    return ops.transpose_bf16(weight_bf16)
 
 
-# ----------------------------------------------------------------------------- attention (training)
-def _vt_from_v(v, B, L, d):
-    Lp = _ru(L, 64)
-    vt = torch.empty(B, d, Lp, dtype=torch.bfloat16, device=v.device)
-    if Lp != L:
-        vt[:, :, L:].zero_()                       # pad columns only; the transpose writes the rest
-    ops.transpose_bf16_raw(ptr(v), ptr(vt), L, d, d, Lp, batch=B, bs_in=L * d, bs_out=d * Lp)
-    return vt, Lp
+def _wT(mod, key, weight_bf16):
+    """Transposed bf16 copy [K, N] of a packed [N, K] weight outside the blocks (head), cached per weight version."""
+    return mod._packed.get("T:" + key, (weight_bf16,), lambda: ops.transpose_bf16(weight_bf16))
 
 
-def _attn_fwd(q, k, v, klens32, B, Lq, Lk, H, D, want_lse=False):
-    d = H * D
-    vt, Lp = _vt_from_v(v, B, Lk, d)
-    o = torch.empty(B * Lq, d, dtype=torch.bfloat16, device=q.device)
-    lse = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device) if want_lse else None
-    ops.flash_attn_raw(ptr(q), ptr(k), ptr(vt), ptr(o), ptr(klens32) if klens32 is not None else None, B, H, Lq, Lk,
-                       Lq * d, d, Lk * d, d, d * Lp, Lq * d, d, Lp, D ** -0.5, lse=ptr(lse) if want_lse else None)
-    return (o, lse) if want_lse else o
+_VT_CACHE_MAX = 256
 
 
-# OMH_ATTN_BWD=unfused keeps the first implementation (scores materialised per head through the GEMM kernel, ~14
-# launches per sample) for A/B timing and as a second opinion in the tests; the default is the fused kernel pair
-# of csrc/attention_bwd.hip (3 launches + 3 transposes per call, whole batch at once).
-_FUSED_ATTN_BWD = os.environ.get("OMH_ATTN_BWD", "fused") != "unfused"
-_WGRAD_TN = os.environ.get("OMH_WGRAD", "tn") != "nt"
+def _vt_buffer(model, key, B, d, Lp, L, dev, keep):
+    """V^T [B, d, Lp] bf16 with zeroed pad columns [L, Lp) (0 x P needs them finite).  Kept activations get their own
+    tensor (two forwards may be in flight before a backward); a transient one (use_checkpoint: produced and consumed
+    inside one node) comes from a per-model cache whose pad was zeroed once."""
+    if keep:
+        t = torch.empty(B, d, Lp, dtype=torch.bfloat16, device=dev)
+        if Lp != L:
+            t[:, :, L:].zero_()
+        return t
+    cache = model.__dict__.setdefault("_vt_cache", {})
+    k = (key[1:], B, d, Lp, L, str(dev))
+    t = cache.get(k)
+    if t is None:
+        if len(cache) > _VT_CACHE_MAX:
+            cache.clear()
+        t = cache[k] = torch.zeros(B, d, Lp, dtype=torch.bfloat16, device=dev)
+    return t
 
 
-def _attn_bwd(q, k, v, do, klens, B, Lq, Lk, H, D):
-    """Un-fused attention backward.  q/do bf16 [B*Lq, d]; k/v bf16 [B*Lk, d]; klens python ints.
-    Returns fp32 dq [B*Lq, d], dk, dv [B*Lk, d]."""
-    d = H * D
-    dev = q.device
-    scale = D ** -0.5
-    dq = torch.zeros(B * Lq, d, dtype=torch.float32, device=dev)
-    dk = torch.zeros(B * Lk, d, dtype=torch.float32, device=dev)
-    dv = torch.zeros(B * Lk, d, dtype=torch.float32, device=dev)
-    Sp = _ru(Lq, 8)
-    for b in range(B):
-        L = min(int(klens[b]), Lk)
-        if L <= 0:
-            continue
-        Lp = _ru(L, 8)
-        qb, dob = q[b * Lq:(b + 1) * Lq], do[b * Lq:(b + 1) * Lq]
-        kb, vb = k[b * Lk:b * Lk + L], v[b * Lk:b * Lk + L]
-        sc = torch.empty(H, Lq, Lp, dtype=torch.float32, device=dev)
-        ops.gemm_raw(ptr(qb), ptr(kb), ptr(sc), Lq, L, D, d, d, Lp, EPI_F32, batch=H, strideA=D, strideB=D,
-                     strideC=Lq * Lp)
-        p = torch.zeros(H * Lq, Lp, dtype=torch.bfloat16, device=dev)
-        ops.softmax_rows(sc.view(H * Lq, Lp), p, L, scale)
-        dp = sc                                                    # reuse the score buffer
-        ops.gemm_raw(ptr(dob), ptr(vb), ptr(dp), Lq, L, D, d, d, Lp, EPI_F32, batch=H, strideA=D, strideB=D,
-                     strideC=Lq * Lp)
-        ds = torch.zeros(H * Lq, Lp, dtype=torch.bfloat16, device=dev)
-        ops.softmax_bwd_rows(p, dp.view(H * Lq, Lp), ds, L, scale)
-        # dq_h = dS_h K_h
-        kT = ops.transpose_bf16(kb)                                # [d, Lp]
-        ops.gemm_raw(ptr(ds), ptr(kT), ptr(dq, b * Lq * d), Lq, D, Lp, Lp, Lp, d, EPI_F32, batch=H,
-                     strideA=Lq * Lp, strideB=D * Lp, strideC=D)
-        # dk_h = dS_h^T Q_h ; dv_h = P_h^T dO_h
-        dsT = torch.zeros(H, Lp, Sp, dtype=torch.bfloat16, device=dev)
-        ops.transpose_bf16_raw(ptr(ds), ptr(dsT), Lq, Lp, Lp, Sp, batch=H, bs_in=Lq * Lp, bs_out=Lp * Sp)
-        qT = ops.transpose_bf16(qb)                                # [d, Sp]
-        ops.gemm_raw(ptr(dsT), ptr(qT), ptr(dk, b * Lk * d), L, D, Sp, Sp, Sp, d, EPI_F32, batch=H,
-                     strideA=Lp * Sp, strideB=D * Sp, strideC=D)
-        pT = dsT                                                   # reuse (same shape, fully rewritten below)
-        ops.transpose_bf16_raw(ptr(p), ptr(pT), Lq, Lp, Lp, Sp, batch=H, bs_in=Lq * Lp, bs_out=Lp * Sp)
-        doT = ops.transpose_bf16(dob)
-        ops.gemm_raw(ptr(pT), ptr(doT), ptr(dv, b * Lk * d), L, D, Sp, Sp, Sp, d, EPI_F32, batch=H,
-                     strideA=Lp * Sp, strideB=D * Sp, strideC=D)
-    return dq, dk, dv
+# ----------------------------------------------------------------------------- block forward (training)
+def _block_forward(model, blk, idx, st, x0, P, keep):
+    """The inference block (model.py:279-330 on libomh.so, WanAttentionBlock.forward of this package) with the
+    residual stream out of place and the backward's extra tensors emitted by the producing epilogues.  x0 fp32
+    [B, S, d] is left untouched.  Returns (x3, S) — S holds what ``_block_backward`` reads."""
+    fc = st.fc
+    B, Sq, d = x0.shape
+    R = B * Sq
+    dev = x0.device
+    sa, ca = blk.self_attn, blk.cross_attn
+    N, D = sa.num_heads, sa.head_dim
+    f = blk.ffn_dim
+    mod = blk.modulation.detach()
+    if mod.dtype != torch.float32:
+        mod = mod.float()
+    mod = mod.contiguous()
+    e0 = fc.e0
+    six = 6 * d
+    i2v = hasattr(ca, "k_img")
+    n_img = 257 if i2v else 0
+    frozen_ffn = getattr(model, "reference_ffn_freeze", True) and idx > 10
+    Lc = fc.Lc
+    Lt = Lc - n_img
+    bf = lambda *shape: torch.empty(*shape, dtype=torch.bfloat16, device=dev)
+    S = {"x0": x0}
+
+    def ln_mod(xin, shift_i, scale_i):
+        h = bf(R, d)
+        ops.layernorm_modulate_raw(ptr(xin), ptr(h), R, d, blk.eps, 1.0, ptr(mod, scale_i * d), ptr(e0, scale_i * d), six,
+                                   ptr(mod, shift_i * d), ptr(e0, shift_i * d), six, Sq)
+        return h
+
+    def resid(xin, a, w, b, gate_i, want_y, xout=None):
+        """x_out = x_in + (a w^T + b) * gate  (+ y = bf16(a w^T + b) when the gate gets a gradient)."""
+        xo = torch.empty_like(xin) if xout is None else xout
+        y = bf(R, d) if want_y else None
+        M, K = a.shape
+        kw = dict(c_in=ptr(xin) if xo.data_ptr() != xin.data_ptr() else None, aux=ptr(y) if y is not None else None, ldaux=d)
+        if gate_i is None:
+            ops.gemm_raw(ptr(a), ptr(w), ptr(xo), M, d, K, a.stride(0), w.stride(0), d, EPI_RESID,
+                         bias=ptr(b) if b is not None else None, bias_mode=BIAS_N if b is not None else BIAS_NONE,
+                         gate_const=1.0, **kw)
+        else:
+            ops.gemm_raw(ptr(a), ptr(w), ptr(xo), M, d, K, a.stride(0), w.stride(0), d, EPI_RESID, bias=ptr(b),
+                         bias_mode=BIAS_N, gate0=ptr(mod, gate_i * d), gate1=ptr(e0, gate_i * d), gate1_stride=six,
+                         gate_rows=Sq, gate_const=0.0, **kw)
+        return xo, y
+
+    # ---- self-attention: x1 = x0 + o(attn(LN(x0)(1+e1)+e0)) * e2                                    model.py:292-296
+    h1 = ln_mod(x0, 0, 1)
+    wqkv, bqkv = P["wqkv"], P["bqkv"]
+    qk = bf(R, 2 * d)                                       # q | k projection, bf16 like the inference path
+    ops.gemm_raw(ptr(h1), ptr(wqkv), ptr(qk), R, 2 * d, d, d, d, 2 * d, EPI_BF16, bias=ptr(bqkv), bias_mode=BIAS_N)
+    q, k = bf(R, d), bf(R, d)
+    nq, nk = sa._norm_w("norm_q"), sa._norm_w("norm_k")
+    for dst, off, w, osc in ((q, 0, nq, D ** -0.5 * LOG2E), (k, d, nk, 1.0)):
+        ops.rmsnorm_rope_bf16_raw(ptr(qk, off), 2 * d, ptr(dst), R, d, ptr(w) if w is not None else None, sa.eps,
+                                  int(sa.qk_norm), ptr(fc.rope_cos), ptr(fc.rope_sin), fc.rope_cos.shape[0], D,
+                                  ptr(fc.grid32), Sq, out_scale=osc)
+    Sp = _ru(Sq, 64)
+    vt = _vt_buffer(model, (idx, "sa"), B, d, Sp, Sq, dev, keep)
+    ops.gemm_raw(ptr(wqkv, 2 * d * d), ptr(h1), ptr(vt), d, Sq, d, d, d, Sp, EPI_BF16, bias=ptr(bqkv, 2 * d),
+                 bias_mode=BIAS_M, batch=B, strideA=0, strideB=Sq * d, strideC=d * Sp)
+    o = bf(R, d)
+    lse_sa = torch.empty(B, N, Sq, dtype=torch.float32, device=dev)
+    ops.flash_attn_raw(ptr(q), ptr(k), ptr(vt), ptr(o), ptr(fc.seq_lens32), B, N, Sq, Sq, Sq * d, d, Sq * d, d, d * Sp,
+                       Sq * d, d, Sp, D ** -0.5, lse=ptr(lse_sa), q_prescaled=1)
+    x1, y1 = resid(x0, o, P["wo"], sa.o.bias.detach(), 2, True)
+    S.update(h1=h1, qk=qk, q=q, k=k, vt=vt, o=o, lse_sa=lse_sa, y1=y1, x1=x1)
+    # ---- cross-attention: x2 = x1 + o(attn(norm3(x1), context))                                     model.py:313
+    h3 = bf(R, d)
+    if blk.cross_attn_norm:
+        n3 = blk.norm3
+        w3, b3 = n3.weight.detach().float().contiguous(), n3.bias.detach().float().contiguous()
+        ops.layernorm_modulate_raw(ptr(x1), ptr(h3), R, d, n3.eps, 0.0, ptr(w3), None, 0, ptr(b3), None, 0, R)
+        S.update(w3=w3)
+    else:
+        ops.cast_bf16(x1.view(R, d), out=h3)
+    qcb = ops.gemm(h3, P["wq_c"], bias=ca.q.bias.detach(), epilogue=EPI_BF16)
+    qc = bf(R, d)
+    wnq = ca._norm_w("norm_q")
+    ops.rmsnorm_rope_bf16_raw(ptr(qcb), d, ptr(qc), R, d, ptr(wnq) if wnq is not None else None, ca.eps, int(ca.qk_norm),
+                              None, None, 0, D, None, Sq)
+
+    def ctx_kv(lo, L, wkv, k_lin, v_lin, norm_name, key):
+        """K (normalised bf16 [B*L, d], its fp32 pre-norm) and V ([B*L, d] for the backward, V^T for the forward)
+        of context rows [lo, lo + L) — model.py:176-178 / 216-220 as WanT2VCrossAttention._context_kv computes them."""
+        Lp = _ru(L, 64)
+        kf = torch.empty(B, L, d, dtype=torch.float32, device=dev)
+        ops.gemm_raw(ptr(fc.ctx, lo * d), ptr(wkv), ptr(kf), L, d, d, d, d, d, EPI_F32, bias=ptr(k_lin.bias.detach()),
+                     bias_mode=BIAS_N, batch=B, strideA=Lc * d, strideB=0, strideC=L * d)
+        kn = ops.rmsnorm_rope(kf.view(B * L, d), ca._norm_w(norm_name), ca.eps, do_norm=ca.qk_norm)
+        vtc = _vt_buffer(model, (idx, key), B, d, Lp, L, dev, keep)
+        ops.gemm_raw(ptr(wkv, d * d), ptr(fc.ctx, lo * d), ptr(vtc), d, L, d, d, d, Lp, EPI_BF16,
+                     bias=ptr(v_lin.bias.detach()), bias_mode=BIAS_M, batch=B, strideA=0, strideB=Lc * d, strideC=d * Lp)
+        return kf, kn, vtc, Lp
+
+    kf, kc, vtc, Ltp = ctx_kv(n_img, Lt, P["wkv_c"], ca.k, ca.v, "norm_k", "ca")
+    oc = bf(R, d)
+    lse_ca = torch.empty(B, N, Sq, dtype=torch.float32, device=dev)
+    # the reference passes the (text + 257) lengths here (model.py:223,537); keys are clipped to the text rows
+    ops.flash_attn_raw(ptr(qc), ptr(kc), ptr(vtc), ptr(oc), ptr(fc.ctx_lens32), B, N, Sq, Lt, Sq * d, d, Lt * d, d,
+                       d * Ltp, Sq * d, d, Ltp, D ** -0.5, lse=ptr(lse_ca))
+    x2, _ = resid(x1, oc, P["wo_c"], ca.o.bias.detach(), None, False)
+    S.update(h3=h3, qcb=qcb, qc=qc, kf=kf, kc=kc, vtc=vtc, oc=oc, lse_ca=lse_ca, x2=x2)
+    if i2v:                                                  # model.py:189-230: extra attention over the 257 image tokens
+        kfi, ki, vti, Lip = ctx_kv(0, n_img, P["wkv_i"], ca.k_img, ca.v_img, "norm_k_img", "ci")
+        oi = bf(R, d)
+        lse_ci = torch.empty(B, N, Sq, dtype=torch.float32, device=dev)
+        ops.flash_attn_raw(ptr(qc), ptr(ki), ptr(vti), ptr(oi), None, B, N, Sq, n_img, Sq * d, d, n_img * d, d, d * Lip,
+                           Sq * d, d, Lip, D ** -0.5, lse=ptr(lse_ci))
+        resid(x2, oi, P["wo_c"], None, None, False, xout=x2)          # x2 += o_img Wo^T   (in place)
+        S.update(kfi=kfi, ki=ki, vti=vti, oi=oi, lse_ci=lse_ci)
+    # ---- FFN: x3 = x2 + (W2 gelu(W1 (LN(x2)(1+e4)+e3) + b1) + b2) * e5                               model.py:314-328
+    h2 = ln_mod(x2, 3, 4)
+    u = bf(R, f)
+    u_pre = None if frozen_ffn else bf(R, f)
+    ops.gemm_raw(ptr(h2), ptr(P["w1"]), ptr(u), R, f, d, d, d, f, EPI_GELU_BF16, bias=ptr(blk.ffn[0].bias.detach()),
+                 bias_mode=BIAS_N, aux=ptr(u_pre) if u_pre is not None else None, ldaux=f)
+    x3, y3 = resid(x2, u, P["w2"], blk.ffn[2].bias.detach(), 5, True)
+    S.update(y3=y3)
+    if not frozen_ffn:
+        S.update(h2=h2, u=u, u_pre=u_pre)
+    return x3, S
+
+
+# ----------------------------------------------------------------------------- block backward
+def _block_backward(model, blk, idx, st, S, dx, P):
+    """Back-propagate dx (fp32 [B, S, d], updated in place) through block ``idx`` given its kept tensors ``S``."""
+    fc = st.fc
+    x0 = S["x0"]
+    B, Sq, d = x0.shape
+    R = B * Sq
+    dev = x0.device
+    sa, ca = blk.self_attn, blk.cross_attn
+    N, D = sa.num_heads, sa.head_dim
+    f = blk.ffn_dim
+    eps = blk.eps
+    mod = blk.modulation.detach().float().contiguous()
+    e0 = fc.e0
+    six = 6 * d
+    i2v = hasattr(ca, "k_img")
+    n_img = 257 if i2v else 0
+    frozen_ffn = getattr(model, "reference_ffn_freeze", True) and idx > 10
+    Lc = fc.Lc
+    Lt = Lc - n_img
+    bf = lambda *shape: torch.empty(*shape, dtype=torch.bfloat16, device=dev)
+    arena = _ZeroArena(B * six + 2 * six + 20 * d + 2 * f + 4096, dev)
+    d_eb = arena.take(B, 6, d)                                        # grads of e = modulation + e0
+    g = {}
+
+    def ln_bwd(xin, dh, shift_i, scale_i):
+        ops.layernorm_modulate_bwd_raw(ptr(xin), ptr(dh), ptr(dx), R, d, eps, 1.0, ptr(mod, scale_i * d),
+                                       ptr(e0, scale_i * d), six, ptr(d_eb, scale_i * d), ptr(d_eb, shift_i * d),
+                                       six, Sq)
+
+    def resid_bwd(y, gate_i):
+        dy = bf(R, d)
+        if gate_i is None:
+            ops.gated_residual_bwd_raw(ptr(dx), None, ptr(dy), None, 0, R, d, 1.0, None, None, 0, Sq)
+        else:
+            ops.gated_residual_bwd_raw(ptr(dx), ptr(y), ptr(dy), ptr(d_eb, gate_i * d), six, R, d, 0.0,
+                                       ptr(mod, gate_i * d), ptr(e0, gate_i * d), six, Sq)
+        return dy
+
+    def rms_bwd(x, x_bf16, ldx, dy, lddy, rows, weight, norm_on, rope, name, mod_):
+        """In place on dy (bf16): dy <- gradient of the pre-norm projection; the norm gain's gradient into g[name]."""
+        dnw = arena.take(d) if norm_on else None
+        rc, rs_, rl, gr, sl = (ptr(fc.rope_cos), ptr(fc.rope_sin), fc.rope_cos.shape[0], ptr(fc.grid32), Sq) if rope \
+            else (None, None, 0, None, 0)
+        ops.rmsnorm_rope_bwd_t_raw(x, x_bf16, ldx, dy, True, lddy, dy, lddy, ptr(dnw) if dnw is not None else None, rows,
+                                   d, ptr(weight) if (norm_on and weight is not None) else None, mod_.eps, int(norm_on),
+                                   rc, rs_, rl, D, gr, sl)
+        if dnw is not None:
+            g[name] = dnw
+
+    # ---- FFN branch: x3 = x2 + y3 * g5
+    dy3 = resid_bwd(S["y3"], 5)
+    if not frozen_ffn:
+        u, u_pre, h2 = S["u"], S["u_pre"], S["h2"]
+        g["ffn.2.weight"], g["ffn.2.bias"] = _wgrad(dy3, u, side=True), _bgrad(dy3, arena)
+        du_pre = bf(R, f)                                            # (dy3 W2) * gelu'(u_pre): GELU' in the GEMM's epilogue
+        ops.gemm_raw(ptr(dy3), ptr(P["w2T"]), ptr(du_pre), R, f, d, d, d, f, EPI_GELU_BWD, aux=ptr(u_pre), ldaux=f)
+        g["ffn.0.weight"], g["ffn.0.bias"] = _wgrad(du_pre, h2, side=True), _bgrad(du_pre, arena)
+        dh2 = _dgrad(du_pre, P["w1T"])
+        ln_bwd(S["x2"], dh2, 3, 4)
+        del du_pre, dh2
+    # ---- cross-attention branch: x2 = x1 + y2
+    dy2 = resid_bwd(None, None)
+    oc, qc, kc = S["oc"], S["qc"], S["kc"]
+    g["cross_attn.o.weight"], g["cross_attn.o.bias"] = _wgrad(dy2, oc, side=True), _bgrad(dy2, arena)
+    doc = _dgrad(dy2, P["wo_cT"], epilogue=EPI_BF16)
+    Rc = B * Lt
+    ctx2 = fc.ctx.view(B * Lc, d) if not i2v else fc.ctx[:, n_img:].contiguous().view(Rc, d)
+    vc = ops.transpose_bf16_batched(S["vtc"], Lt)                     # [B*Lt, d]
+    dqc = bf(R, d)
+    dkv = bf(Rc, 2 * d)                                               # dk | dv of the text keys, one buffer
+    if not i2v:
+        ops.flash_attn_bwd(qc, kc, vc, oc, doc, S["lse_ca"], fc.ctx_lens32, B, N, Sq, Lt, D ** -0.5,
+                           out=(dqc, dkv[:, :d], dkv[:, d:]))
+    else:                                                             # the image-token branch: same q, same dO
+        oi, ki = S["oi"], S["ki"]
+        _wgrad(dy2, oi, out=g["cross_attn.o.weight"], side=True)
+        dq32, dk32, dv32 = ops.flash_attn_bwd(qc, kc, vc, oc, doc, S["lse_ca"], fc.ctx_lens32, B, N, Sq, Lt, D ** -0.5)
+        vi = ops.transpose_bf16_batched(S["vti"], n_img)
+        dqi, dki, dvi = ops.flash_attn_bwd(qc, ki, vi, oi, doc, S["lse_ci"], None, B, N, Sq, n_img, D ** -0.5)
+        ops.colsum_accum(dqi.view(1, R * d), dq32.view(R * d))        # dq = dq_text + dq_img
+        ops.cast_bf16(dq32, out=dqc)
+        ops.cast_bf16_strided(dk32, dkv[:, :d])
+        ops.cast_bf16_strided(dv32, dkv[:, d:])
+        Ri = B * n_img
+        ctxi = fc.ctx[:, :n_img].contiguous().view(Ri, d)
+        dkvi = bf(Ri, 2 * d)
+        ops.cast_bf16_strided(dki, dkvi[:, :d])
+        ops.cast_bf16_strided(dvi, dkvi[:, d:])
+        rms_bwd(ptr(S["kfi"]), False, d, ptr(dkvi), 2 * d, Ri, ca._norm_w("norm_k_img"), ca.qk_norm, False,
+                "cross_attn.norm_k_img.weight", ca)
+        dwi, dbi = _wgrad(dkvi, ctxi, side=True), _bgrad(dkvi, arena)
+        g["cross_attn.k_img.weight"], g["cross_attn.v_img.weight"] = dwi[:d], dwi[d:]
+        g["cross_attn.k_img.bias"], g["cross_attn.v_img.bias"] = dbi[:d], dbi[d:]
+        _dgrad_ctx(dkvi, P["wkv_iT"], st.d_ctx, 0, n_img)
+        del dq32, dk32, dv32, dqi, dki, dvi
+    rms_bwd(ptr(S["qcb"]), True, d, ptr(dqc), d, R, ca._norm_w("norm_q"), ca.qk_norm, False, "cross_attn.norm_q.weight", ca)
+    h3 = S["h3"]
+    g["cross_attn.q.weight"], g["cross_attn.q.bias"] = _wgrad(dqc, h3, side=True), _bgrad(dqc, arena)
+    dh3 = _dgrad(dqc, P["wq_cT"])
+    rms_bwd(ptr(S["kf"]), False, d, ptr(dkv), 2 * d, Rc, ca._norm_w("norm_k"), ca.qk_norm, False,
+            "cross_attn.norm_k.weight", ca)
+    dwkv, dbkv = _wgrad(dkv, ctx2, side=True), _bgrad(dkv, arena)      # [2d, d]: k | v in one GEMM
+    g["cross_attn.k.weight"], g["cross_attn.v.weight"] = dwkv[:d], dwkv[d:]
+    g["cross_attn.k.bias"], g["cross_attn.v.bias"] = dbkv[:d], dbkv[d:]
+    _dgrad_ctx(dkv, P["wkv_cT"], st.d_ctx, n_img, Lt)
+    x1 = S["x1"]
+    if blk.cross_attn_norm:
+        dw3, db3 = arena.take(d), arena.take(d)
+        ops.layernorm_modulate_bwd_raw(ptr(x1), ptr(dh3), ptr(dx), R, d, blk.norm3.eps, 0.0, ptr(S["w3"]), None, 0,
+                                       ptr(dw3), ptr(db3), 0, R)
+        g["norm3.weight"], g["norm3.bias"] = dw3, db3
+    else:
+        ops.colsum_accum(dh3.view(1, R * d), dx.view(R * d))          # dx += dh3
+    del dy2, doc, dh3
+    # ---- self-attention branch: x1 = x0 + y1 * g2
+    dy1 = resid_bwd(S["y1"], 2)
+    o, q, k, h1 = S["o"], S["q"], S["k"], S["h1"]
+    g["self_attn.o.weight"], g["self_attn.o.bias"] = _wgrad(dy1, o, side=True), _bgrad(dy1, arena)
+    do = _dgrad(dy1, P["woT"], epilogue=EPI_BF16)
+    v = ops.transpose_bf16_batched(S["vt"], Sq)                       # [B*S, d]
+    dqkv = bf(R, 3 * d)                                               # dq | dk | dv, one buffer
+    ops.flash_attn_bwd(q, k, v, o, do, S["lse_sa"], fc.seq_lens32, B, N, Sq, Sq, D ** -0.5, q_prescaled=True,
+                       out=(dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]))
+    qk = S["qk"]
+    rms_bwd(ptr(qk), True, 2 * d, ptr(dqkv), 3 * d, R, sa._norm_w("norm_q"), sa.qk_norm, True, "self_attn.norm_q.weight", sa)
+    rms_bwd(ptr(qk, d), True, 2 * d, ptr(dqkv, d), 3 * d, R, sa._norm_w("norm_k"), sa.qk_norm, True,
+            "self_attn.norm_k.weight", sa)
+    dwqkv, dbqkv = _wgrad(dqkv, h1, side=True), _bgrad(dqkv, arena)     # [3d, d]: q | k | v in one GEMM
+    for j, nm in enumerate(("q", "k", "v")):
+        g[f"self_attn.{nm}.weight"], g[f"self_attn.{nm}.bias"] = dwqkv[j * d:(j + 1) * d], dbqkv[j * d:(j + 1) * d]
+    dh1 = _dgrad(dqkv, P["wqkvT"])                                      # K = 3d: dq Wq + dk Wk + dv Wv
+    ln_bwd(x0, dh1, 0, 1)
+    # ---- modulation / e0
+    dmod = arena.take(six)
+    ops.colsum_accum(d_eb.view(B, six), dmod)
+    g["modulation"] = dmod
+    ops.colsum_accum(d_eb.view(1, B * six), st.d_e0.view(B * six))      # d_e0 += d_eb
+    arena.flush()
+    g["__dx__"] = dx
+    return g
+
+
+def _dgrad_ctx(dy, wT, d_ctx, first, L):
+    """d_ctx[b, first:first+L, :] += dy[b*L:(b+1)*L, :] @ W  for every sample b (the context gradient of a K | V
+    projection that reads a slice of the context rows): one batched GEMM into the strided destination."""
+    B, Lc, d = d_ctx.shape
+    Nn = dy.shape[1]
+    ops.gemm_raw(ptr(dy), ptr(wT), ptr(d_ctx, first * d), L, d, Nn, dy.stride(0), wT.stride(0), d, EPI_ACC, batch=B,
+                 strideA=L * dy.stride(0), strideB=0, strideC=Lc * d)
 
 
 # ----------------------------------------------------------------------------- block node
@@ -294,18 +563,16 @@ class _BlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, model, st, idx, *params):
-        block = model.blocks[idx]
-        fc = st.fc
-        _wgrad_join(x.device)                                     # this block's packs (prefetched by the previous one)
-        if idx + 1 < len(model.blocks):
-            _prepack(model, model.blocks[idx + 1], idx + 1, False)
+        blk = model.blocks[idx]
+        keep = not getattr(model, "use_checkpoint", True)
         with torch.no_grad():
-            x_out = x.detach().clone()
-            seq_lens = fc.seq_lens32.long()
-            out = block(x_out, fc.e0, seq_lens, fc.grid32.long(), (fc.rope_cos, fc.rope_sin), fc.ctx,
-                        fc.ctx_lens32.long(), block_idx=idx, _fc=fc)
-        ctx.save_for_backward(x.detach())
+            x0 = x.detach()
+            if not (x0.dtype == torch.float32 and x0.is_contiguous()):
+                x0 = x0.float().contiguous()
+            out, S = _block_forward(model, blk, idx, st, x0, st.packs[idx], keep)
         ctx.model, ctx.st, ctx.idx = model, st, idx
+        ctx.kept = S if keep else None
+        ctx.save_for_backward(x0)
         return out
 
     @staticmethod
@@ -313,238 +580,24 @@ class _BlockFn(torch.autograd.Function):
         (x0,) = ctx.saved_tensors
         model, st, idx = ctx.model, ctx.st, ctx.idx
         blk = model.blocks[idx]
-        names = [n for n, _ in blk.named_parameters()]
-        if idx > 0:
-            _prepack(model, model.blocks[idx - 1], idx - 1, True)
+        P = st.packs[idx]
+        dev = x0.device
         with torch.no_grad():
-            grads = _block_backward(model, blk, idx, st, x0, dx_out.float().contiguous().clone())
+            S = ctx.kept
+            ctx.kept = None
+            if S is None:                                    # use_checkpoint: re-run the forward's kernels on its input
+                _, S = _block_forward(model, blk, idx, st, x0, P, False)
+            # the incoming gradient belongs to this node alone (the residual stream has one consumer): updated in place
+            dx = dx_out if (dx_out.dtype == torch.float32 and dx_out.is_contiguous()) else dx_out.float().contiguous()
+            try:
+                grads = _block_backward(model, blk, idx, st, S, dx, P)
+            finally:
+                _wgrad_join(dev)                             # also on an exception: nothing may stay on the side stream
         out = []
-        for n, p in zip(names, blk.parameters()):
-            g = grads.get(n) if p.requires_grad else None
-            out.append(None if g is None else g.view(p.shape).to(p.dtype))
+        for n, p in blk.named_parameters():
+            gg = grads.get(n) if p.requires_grad else None
+            out.append(None if gg is None else gg.view(p.shape).to(p.dtype))
         return (grads["__dx__"], None, None, None, *out)
-
-
-def _block_backward(model, blk, idx, st, x0, dx):
-    """Recompute block ``idx`` from its input x0 (fp32 [B,S,d]) and back-propagate dx (in place)."""
-    _side["on"] = True                                            # weight gradients of this block: second stream (if enabled)
-    fc = st.fc
-    B, S, d = x0.shape
-    R = B * S
-    dev = x0.device
-    sa, ca = blk.self_attn, blk.cross_attn
-    N, D = sa.num_heads, sa.head_dim
-    eps = blk.eps
-    mod = blk.modulation.detach().float().contiguous()
-    e0 = fc.e0
-    six = 6 * d
-    i2v = hasattr(ca, "k_img")                                        # model.py:189-230: extra attention over the 257 image tokens
-    n_img = 257 if i2v else 0
-    frozen_ffn = getattr(model, "reference_ffn_freeze", True) and idx > 10
-    seq_lens, ctx_lens = fc.seq_lens_host, fc.ctx_lens_host
-    Lc = fc.Lc
-    Lt = Lc - n_img                                                   # text tokens
-    arena = _ZeroArena(B * six + 2 * six + 16 * d + 2 * blk.ffn[0].out_features + 4096, dev)
-    d_eb = arena.take(B, 6, d)                                        # grads of e = modulation + e0
-    g = {}
-
-    def ln_fwd(xin, shift_i, scale_i):
-        h = torch.empty(R, d, dtype=torch.bfloat16, device=dev)
-        ops.layernorm_modulate_raw(ptr(xin), ptr(h), R, d, eps, 1.0, ptr(mod, scale_i * d), ptr(e0, scale_i * d), six,
-                                   ptr(mod, shift_i * d), ptr(e0, shift_i * d), six, S)
-        return h
-
-    def ln_bwd(xin, dh, shift_i, scale_i):
-        ops.layernorm_modulate_bwd_raw(ptr(xin), ptr(dh), ptr(dx), R, d, eps, 1.0, ptr(mod, scale_i * d),
-                                       ptr(e0, scale_i * d), six, ptr(d_eb, scale_i * d), ptr(d_eb, shift_i * d),
-                                       six, S)
-
-    def lin(a, w, b, epi=EPI_BF16):
-        return ops.gemm(a, w, bias=b, epilogue=epi)
-
-    def resid_fwd(xin, y, gate_i):
-        xo = torch.empty_like(xin)
-        if gate_i is None:
-            ops.gated_residual_fwd_raw(ptr(xin), ptr(y), ptr(xo), R, d, 1.0, None, None, 0, S)
-        else:
-            ops.gated_residual_fwd_raw(ptr(xin), ptr(y), ptr(xo), R, d, 0.0, ptr(mod, gate_i * d),
-                                       ptr(e0, gate_i * d), six, S)
-        return xo
-
-    def resid_bwd(y, gate_i):
-        dy = torch.empty(R, d, dtype=torch.bfloat16, device=dev)
-        if gate_i is None:
-            ops.gated_residual_bwd_raw(ptr(dx), None, ptr(dy), None, 0, R, d, 1.0, None, None, 0, S)
-        else:
-            ops.gated_residual_bwd_raw(ptr(dx), ptr(y), ptr(dy), ptr(d_eb, gate_i * d), six, R, d, 0.0,
-                                       ptr(mod, gate_i * d), ptr(e0, gate_i * d), six, S)
-        return dy
-
-    # ================= recompute (un-fused, keeps intermediates) =================
-    x0 = x0.contiguous()
-    h1 = ln_fwd(x0, 0, 1)
-    wqk, bqk = sa._w_qk()
-    qk_pre = lin(h1, wqk, bqk, EPI_F32)                                   # [R, 2d] fp32
-    q = torch.empty(R, d, dtype=torch.bfloat16, device=dev)
-    k = torch.empty(R, d, dtype=torch.bfloat16, device=dev)
-    nq, nk = sa._norm_w("norm_q"), sa._norm_w("norm_k")
-    for dst, off, w in ((q, 0, nq), (k, d, nk)):
-        ops.rmsnorm_rope_raw(ptr(qk_pre, off), 2 * d, ptr(dst), R, d, ptr(w) if w is not None else None, sa.eps,
-                             int(sa.qk_norm), ptr(fc.rope_cos), ptr(fc.rope_sin), fc.rope_cos.shape[0], D,
-                             ptr(fc.grid32), S)
-    wv, bv = sa._w("v")
-    v = lin(h1, wv, bv)
-    o, lse_sa = _attn_fwd(q, k, v, fc.seq_lens32, B, S, S, N, D, want_lse=True)
-    wo, bo = sa._w("o")
-    y1 = lin(o, wo, bo)
-    x1 = resid_fwd(x0, y1, 2)
-    # cross attention
-    h3 = torch.empty(R, d, dtype=torch.bfloat16, device=dev)
-    if blk.cross_attn_norm:
-        n3 = blk.norm3
-        w3, b3 = n3.weight.detach().float().contiguous(), n3.bias.detach().float().contiguous()
-        ops.layernorm_modulate_raw(ptr(x1), ptr(h3), R, d, n3.eps, 0.0, ptr(w3), None, 0, ptr(b3), None, 0, R)
-    else:
-        ops.cast_bf16(x1.view(R, d), out=h3)
-    wqc, bqc = ca._w("q")
-    qc_pre = lin(h3, wqc, bqc, EPI_F32)
-    qc = ops.rmsnorm_rope(qc_pre, ca._norm_w("norm_q"), ca.eps, do_norm=ca.qk_norm)
-    ctx2 = fc.ctx.view(B * Lc, d) if not i2v else fc.ctx[:, n_img:].contiguous().view(B * Lt, d)
-    wkc, bkc = ca._w("k")
-    wvc, bvc = ca._w("v")
-    kc_pre = lin(ctx2, wkc, bkc, EPI_F32)
-    kc = ops.rmsnorm_rope(kc_pre, ca._norm_w("norm_k"), ca.eps, do_norm=ca.qk_norm)
-    vc = lin(ctx2, wvc, bvc)
-    oc, lse_ca = _attn_fwd(qc, kc, vc, fc.ctx_lens32, B, S, Lt, N, D, want_lse=True)
-    woc, boc = ca._w("o")
-    if i2v:
-        ctxi = fc.ctx[:, :n_img].contiguous().view(B * n_img, d)
-        wki, bki = ca._w("k_img")
-        wvi, bvi = ca._w("v_img")
-        ki_pre = lin(ctxi, wki, bki, EPI_F32)
-        ki = ops.rmsnorm_rope(ki_pre, ca._norm_w("norm_k_img"), ca.eps, do_norm=ca.qk_norm)
-        vi = lin(ctxi, wvi, bvi)
-        oi, lse_ci = _attn_fwd(qc, ki, vi, None, B, S, n_img, N, D, want_lse=True)
-        y2f = lin(oc, woc, boc, EPI_F32)                              # o(o_text + o_img): two products into one fp32 sum
-        ops.gemm(oi, woc, out=y2f, epilogue=EPI_ACC)
-        y2 = ops.cast_bf16(y2f)
-    else:
-        y2 = lin(oc, woc, boc)
-    x2 = resid_fwd(x1, y2, None)
-    # FFN
-    h2 = ln_fwd(x2, 3, 4)
-    w1, b1 = blk._ffn_w(0)
-    w2, b2 = blk._ffn_w(2)
-    u_pre = lin(h2, w1, b1)
-    u = ops.gelu_tanh(u_pre)
-    y3 = lin(u, w2, b2)
-
-    # ================= backward =================
-    # ---- FFN branch: x3 = x2 + y3 * g5
-    dy3 = resid_bwd(y3, 5)
-    if not frozen_ffn:
-        g["ffn.2.weight"], g["ffn.2.bias"] = _wgrad(dy3, u), _bgrad(dy3, arena)
-        du = ops.gemm(dy3, _wT(blk, "ffn2", w2), epilogue=EPI_BF16, b_kmajor=_DGRAD_NN)       # [R, ffn]
-        du_pre = ops.gelu_tanh_bwd(du, u_pre)
-        g["ffn.0.weight"], g["ffn.0.bias"] = _wgrad(du_pre, h2), _bgrad(du_pre, arena)
-        dh2 = _dgrad(du_pre, _wT(blk, "ffn0", w1))
-        ln_bwd(x2, dh2, 3, 4)
-        del du, du_pre, dh2
-    del dy3, u, u_pre, y3, h2
-    # ---- cross-attention branch: x2 = x1 + y2
-    dy2 = resid_bwd(None, None)
-    g["cross_attn.o.weight"], g["cross_attn.o.bias"] = _wgrad(dy2, oc), _bgrad(dy2, arena)
-    doc = ops.gemm(dy2, _wT(ca, "o", woc), epilogue=EPI_BF16, b_kmajor=_DGRAD_NN)
-    if _FUSED_ATTN_BWD:
-        dqc, dkc, dvc = ops.flash_attn_bwd(qc, kc, vc, oc, doc, lse_ca, fc.ctx_lens32, B, N, S, Lt, D ** -0.5)
-    else:
-        dqc, dkc, dvc = _attn_bwd(qc, kc, vc, doc, ctx_lens, B, S, Lt, N, D)
-    if i2v:                                                           # the image-token branch: same q, same dO
-        _wgrad(dy2, oi, out=g["cross_attn.o.weight"])
-        dqi, dki, dvi = ops.flash_attn_bwd(qc, ki, vi, oi, doc, lse_ci, None, B, N, S, n_img, D ** -0.5)
-        ops.colsum_accum(dqi.view(1, R * d), dqc.view(R * d))         # dq = dq_text + dq_img
-        Ri = B * n_img
-        dki_pre = torch.empty(Ri, d, dtype=torch.bfloat16, device=dev)
-        dnki = arena.take(d) if ca.qk_norm else None
-        ops.rmsnorm_rope_bwd_raw(ptr(ki_pre), d, ptr(dki), d, ptr(dki_pre), d, ptr(dnki) if dnki is not None else None,
-                                 Ri, d, ptr(ca._norm_w("norm_k_img")) if ca.qk_norm else None, ca.eps, int(ca.qk_norm),
-                                 None, None, 0, D, None, 0)
-        if dnki is not None:
-            g["cross_attn.norm_k_img.weight"] = dnki
-        ctxiT = None if _WGRAD_TN else ops.transpose_bf16(ctxi)
-        g["cross_attn.k_img.weight"], g["cross_attn.k_img.bias"] = _wgrad(dki_pre, ctxi, ctxiT), _bgrad(dki_pre, arena)
-        dvi_b = ops.cast_bf16(dvi)
-        g["cross_attn.v_img.weight"], g["cross_attn.v_img.bias"] = _wgrad(dvi_b, ctxi, ctxiT), _bgrad(dvi_b, arena)
-        _dgrad_ctx(dki_pre, _wT(ca, "k_img", wki), st.d_ctx, 0, n_img)
-        _dgrad_ctx(dvi_b, _wT(ca, "v_img", wvi), st.d_ctx, 0, n_img)
-        del dqi, dki, dvi, dki_pre, dvi_b, ki, vi, oi, ki_pre, ctxi, ctxiT
-    dqc_pre = torch.empty(R, d, dtype=torch.bfloat16, device=dev)
-    dnq = arena.take(d) if ca.qk_norm else None
-    ops.rmsnorm_rope_bwd_raw(ptr(qc_pre), d, ptr(dqc), d, ptr(dqc_pre), d, ptr(dnq) if dnq is not None else None, R, d,
-                             ptr(ca._norm_w("norm_q")) if ca.qk_norm else None, ca.eps, int(ca.qk_norm), None, None,
-                             0, D, None, 0)
-    if dnq is not None:
-        g["cross_attn.norm_q.weight"] = dnq
-    g["cross_attn.q.weight"], g["cross_attn.q.bias"] = _wgrad(dqc_pre, h3), _bgrad(dqc_pre, arena)
-    dh3 = _dgrad(dqc_pre, _wT(ca, "q", wqc))
-    Rc = B * Lt
-    dkc_pre = torch.empty(Rc, d, dtype=torch.bfloat16, device=dev)
-    dnk = arena.take(d) if ca.qk_norm else None
-    ops.rmsnorm_rope_bwd_raw(ptr(kc_pre), d, ptr(dkc), d, ptr(dkc_pre), d, ptr(dnk) if dnk is not None else None, Rc, d,
-                             ptr(ca._norm_w("norm_k")) if ca.qk_norm else None, ca.eps, int(ca.qk_norm), None, None,
-                             0, D, None, 0)
-    if dnk is not None:
-        g["cross_attn.norm_k.weight"] = dnk
-    ctx2T = None if _WGRAD_TN else ops.transpose_bf16(ctx2)
-    g["cross_attn.k.weight"], g["cross_attn.k.bias"] = _wgrad(dkc_pre, ctx2, ctx2T), _bgrad(dkc_pre, arena)
-    dvc_b = ops.cast_bf16(dvc)
-    g["cross_attn.v.weight"], g["cross_attn.v.bias"] = _wgrad(dvc_b, ctx2, ctx2T), _bgrad(dvc_b, arena)
-    _dgrad_ctx(dkc_pre, _wT(ca, "k", wkc), st.d_ctx, n_img, Lt)
-    _dgrad_ctx(dvc_b, _wT(ca, "v", wvc), st.d_ctx, n_img, Lt)
-    if blk.cross_attn_norm:
-        dw3, db3 = arena.take(d), arena.take(d)
-        ops.layernorm_modulate_bwd_raw(ptr(x1), ptr(dh3), ptr(dx), R, d, blk.norm3.eps, 0.0, ptr(w3), None, 0,
-                                       ptr(dw3), ptr(db3), 0, R)
-        g["norm3.weight"], g["norm3.bias"] = dw3, db3
-    else:
-        ops.colsum_accum(dh3.view(1, R * d), dx.view(R * d))                  # dx += dh3
-    del dy2, doc, dqc, dkc, dvc, dqc_pre, dkc_pre, dvc_b, dh3, qc, kc, vc, oc, qc_pre, kc_pre, y2, h3
-    # ---- self-attention branch: x1 = x0 + y1 * g2
-    dy1 = resid_bwd(y1, 2)
-    g["self_attn.o.weight"], g["self_attn.o.bias"] = _wgrad(dy1, o), _bgrad(dy1, arena)
-    do = ops.gemm(dy1, _wT(sa, "o", wo), epilogue=EPI_BF16, b_kmajor=_DGRAD_NN)
-    if _FUSED_ATTN_BWD:
-        dq, dk, dv = ops.flash_attn_bwd(q, k, v, o, do, lse_sa, fc.seq_lens32, B, N, S, S, D ** -0.5)
-    else:
-        dq, dk, dv = _attn_bwd(q, k, v, do, seq_lens, B, S, S, N, D)
-    dqk_pre = torch.empty(R, 2 * d, dtype=torch.bfloat16, device=dev)
-    for off, dyy, w, nm in ((0, dq, nq, "norm_q"), (d, dk, nk, "norm_k")):
-        dnw = arena.take(d) if sa.qk_norm else None
-        ops.rmsnorm_rope_bwd_raw(ptr(qk_pre, off), 2 * d, ptr(dyy), d, ptr(dqk_pre, off), 2 * d,
-                                 ptr(dnw) if dnw is not None else None, R, d, ptr(w) if w is not None else None,
-                                 sa.eps, int(sa.qk_norm), ptr(fc.rope_cos), ptr(fc.rope_sin), fc.rope_cos.shape[0],
-                                 D, ptr(fc.grid32), S)
-        if dnw is not None:
-            g[f"self_attn.{nm}.weight"] = dnw
-    h1T = None if _WGRAD_TN else ops.transpose_bf16(h1)
-    dwqk, dbqk = _wgrad(dqk_pre, h1, h1T), _bgrad(dqk_pre, arena)
-    g["self_attn.q.weight"], g["self_attn.k.weight"] = dwqk[:d], dwqk[d:]
-    g["self_attn.q.bias"], g["self_attn.k.bias"] = dbqk[:d], dbqk[d:]
-    dv_b = ops.cast_bf16(dv)
-    g["self_attn.v.weight"], g["self_attn.v.bias"] = _wgrad(dv_b, h1, h1T), _bgrad(dv_b, arena)
-    dh1 = _dgrad(dqk_pre, _wT(sa, "qk", wqk))
-    _dgrad(dv_b, _wT(sa, "v", wv), out=dh1, accumulate=True)
-    ln_bwd(x0, dh1, 0, 1)
-    # ---- modulation / e0
-    dmod = arena.take(six)
-    ops.colsum_accum(d_eb.view(B, six), dmod)
-    g["modulation"] = dmod
-    _axpy_rows(st.d_e0.view(B, six), d_eb.view(B, six))
-    arena.flush()
-    _side["on"] = False
-    _wgrad_join(dev)
-    g["__dx__"] = dx
-    return g
 
 
 # ----------------------------------------------------------------------------- head node
@@ -636,7 +689,7 @@ def _img_emb_backward(model, clip_fea, d_img, g):
     dz3b = ops.cast_bf16(dz3)
     g["img_emb.proj.4.weight"], g["img_emb.proj.4.bias"] = dw4, db4
     g["img_emb.proj.3.weight"], g["img_emb.proj.3.bias"] = _wgrad(dz3b, g1), _bgrad(dz3b)
-    dg1 = ops.gemm(dz3b, _wT_once(w3), epilogue=EPI_BF16, b_kmajor=_DGRAD_NN)
+    dg1 = ops.gemm(dz3b, _wT_once(w3), epilogue=EPI_BF16)
     dz1 = ops.gelu_erf_bwd(dg1, z1)
     g["img_emb.proj.1.weight"], g["img_emb.proj.1.bias"] = _wgrad(dz1, h0), _bgrad(dz1)
     dh0 = _dgrad(dz1, _wT_once(w1))
@@ -687,12 +740,7 @@ class _EmbedFn(torch.autograd.Function):
                 n = st.lens[b]
                 tok = ops.patchify(u.to(device=dev, dtype=torch.float32).contiguous(), model.patch_size, Kp)
                 dxb = ops.cast_bf16(dxs[b, :n].contiguous())
-                if _WGRAD_TN:
-                    ops.gemm_tn(dxb, tok, out=dW, accumulate=True)
-                else:
-                    dxT, tokT = ops.transpose_bf16(dxb), ops.transpose_bf16(tok)
-                    ops.gemm_raw(ptr(dxT), ptr(tokT), ptr(dW), d, Kp, dxT.shape[1], dxT.shape[1], tokT.shape[1], Kp,
-                                 EPI_ACC)
+                ops.gemm_tn(dxb, tok, out=dW, accumulate=True)
                 ops.colsum_accum(dxs[b, :n], db)
             g["patch_embedding.weight"] = dW[:, :kin].contiguous()
             g["patch_embedding.bias"] = db
@@ -725,7 +773,7 @@ class _EmbedFn(torch.autograd.Function):
             dctx = st.d_ctx[:, n_img:].contiguous().view(B * model.text_len, d)
             dctx_b = ops.cast_bf16(dctx)
             g["text_embedding.2.weight"], g["text_embedding.2.bias"] = _wgrad(dctx_b, gl), _bgrad(dctx_b)
-            dgl = ops.gemm(dctx_b, _wT_once(w2), epilogue=EPI_BF16, b_kmajor=_DGRAD_NN)
+            dgl = ops.gemm(dctx_b, _wT_once(w2), epilogue=EPI_BF16)
             dpre = ops.gelu_tanh_bwd(dgl, pre)
             g["text_embedding.0.weight"], g["text_embedding.0.bias"] = _wgrad(dpre, cin), _bgrad(dpre)
             # ---- image embedding (i2v): the first n_img context rows came from img_emb(clip_fea)
@@ -748,6 +796,7 @@ def forward_train(model, x, t, context, seq_len, clip_fea=None, y=None, extra_co
     graph of hand-written nodes (see module docstring).  ``extra_conditions``: [B, Ne, dim] condition tokens (or a
     dict holding them under 'tokens') that receive a gradient like any other input."""
     st = _State()
+    st.packs = TrainPacks.of(model).refresh(model)           # bf16 weight copies: one launch when anything changed
     x_list = list(x) if not isinstance(x, (list, tuple)) else list(x)
     eparams = [p for _, p in _embed_params(model)]
     tok = extra_conditions.get("tokens") if isinstance(extra_conditions, dict) else extra_conditions

@@ -31,3 +31,36 @@ def test_bench_prints_one_json_line(forced_rccl):
     assert d["n_gpus"] == 1 and d["steps"] == 1 and d["value"] > 0 and d["dtype"] == "bf16"
     assert d["roofline"]["bound"] == "mfma" and 0.3 < d["roofline"]["frac"] < 1.0
     assert "workload" in d["config"]
+
+
+def test_bench_gpus_2_launches_itself():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver calls it) must start its own ranks under
+    torch.distributed.run and still print ONE line, with n_gpus = 2 and a two-rank gradient all-reduce in the training
+    leg.  The test box has one GPU, so the two ranks share it over gloo (OMH_DIST_BACKEND=gloo: validation mode)."""
+    env = dict(os.environ)
+    for k in ("OMH_GEMM_KERNEL", "OMH_CONV_TILE", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(OMH_DIST_BACKEND="gloo", OMH_TRAIN_LEGS="primary", OMH_TRAIN_BATCH="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-vae", "--no-single-frame", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["train"]["rccl_world_size"] == 2 and d["train"]["finite_loss"]
+    assert "all-reduce over 2 rank(s)" in d["train"]["work"]
+    assert d["cpu_baseline"] is None                      # rank 0 times the CPU oracle at N = 1 only
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OMH_DIST_BACKEND"):
+        env.pop(k, None)
+    import torch
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not r.stdout.strip()
+    assert "HIP device(s) visible" in r.stderr

@@ -1,0 +1,221 @@
+"""The reference's data-parallel call pattern around the model, on the HIP path:
+
+    distilled_model, optimizer, ... = accelerator.prepare(distilled_model, optimizer, ...)   distilled_trainer.py:79-81
+    scaler = GradScaler()                                                                     :95
+    with autocast(): out = distilled_model(noise, t=..., context=..., seq_len=...); loss = F.mse_loss(out[0], v_teacher)   :268-289
+    scaler.scale(loss).backward()                                                             :301
+
+i.e. the build's ``WanModel`` wrapped in ``torch.nn.parallel.DistributedDataParallel`` (what ``accelerator.prepare`` does
+to the model on a multi-GPU launch), called under the caller's autocast, back-propagated through a ``GradScaler`` with
+the reference's frozen FFNs (model.py:317-324) on.  The gradients DDP averages are compared with the ones this
+build's own reducer (parallel.BucketedGradAllReduce) produces on the same two ranks.
+
+Two ranks share the one GPU of the test box, so the process group is gloo (RCCL refuses two ranks on one device);
+the accelerate test runs one rank on RCCL, where ``Accelerator.prepare`` still wraps the model in DDP.
+
+What the build needs under DDP (recorded by these tests): nothing — no ``find_unused_parameters``: every parameter is
+an input of one of the hand-written autograd nodes, the nodes return ``None`` for the frozen FFN parameters, DDP's
+hook on their accumulators still fires and the bucket slot is zero-filled, so a frozen parameter ends a DDP step with
+a ZERO gradient where the bare model (and this build's reducer) leave ``.grad = None``.
+"""
+import copy
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = "omnihuman-1-hack_amd"
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _tiny_model_and_batch(rank):
+    import importlib
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from oracle import make_golden, wan_dit_oracle as O, detgen
+    model_mod = importlib.import_module(PKG + ".wan.modules.model")
+    cfg, tag, xs, ctx, tt, seq_len, _, _ = make_golden.tiny_case("t2v", 13)
+    sd = O.synth_state_dict(cfg, tag)
+    m = model_mod.WanModel(num_layers=13, **make_golden.TINY)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    m.reference_ffn_freeze = True
+    # every rank its own clips (data parallel): distilled_trainer's batch layout, [B,16,F,H,W] / [B,L,text_dim]
+    noise = torch.from_numpy(detgen.normalish(f"ddp/noise{rank}", (2, 16, 2, 6, 8))).cuda()
+    vt = torch.from_numpy(detgen.normalish(f"ddp/vt{rank}", (2, 16, 2, 6, 8))).cuda()
+    context = torch.from_numpy(detgen.normalish(f"ddp/ctx{rank}", (2, 32, 64))).cuda()
+    return m, noise, context, vt
+
+
+def _reference_step(model, noise, context, vt, scaler=None, autocast_dtype=None):
+    """distilled_trainer.py:256-301 with the reference's names."""
+    import torch.nn.functional as F
+    contexts_list = [context[i] for i in range(context.size(0))]
+    ps = (model.module if hasattr(model, "module") else model).patch_size
+    seq_len = (noise.shape[2] // ps[0]) * (noise.shape[3] // ps[1]) * (noise.shape[4] // ps[2])
+    timestep = torch.ones(noise.shape[0], device=noise.device) * 1000
+    import contextlib
+    import warnings
+    ac = torch.autocast("cuda", dtype=autocast_dtype) if autocast_dtype is not None else contextlib.nullcontext()
+    with ac, warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = model(noise, t=timestep, context=contexts_list, seq_len=seq_len)
+        loss = F.mse_loss(out[0], vt)                      # sample 0 broadcast against the batch: the reference's line
+    (scaler.scale(loss) if scaler is not None else loss).backward()
+    return loss.detach()
+
+
+def _ddp_worker(rank, world, port, q):
+    try:
+        import importlib
+        import torch.distributed as dist
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        par = importlib.import_module(PKG + ".parallel")
+        optim = importlib.import_module(PKG + ".optim")
+        base, noise, context, vt = _tiny_model_and_batch(rank)
+        frozen = {n for n, _ in base.named_parameters() if n.startswith("blocks.") and ".ffn." in n
+                  and int(n.split(".")[1]) > 10}
+        assert len(frozen) == 2 * 4                      # blocks 11, 12: ffn.0 / ffn.2, weight + bias
+
+        # ---- (B) this build's reducer on a bare copy of the model: the averaged gradients to compare with
+        mine = copy.deepcopy(base)
+        red = par.BucketedGradAllReduce(mine.parameters(), bucket_mb=1.0)
+        loss_b = _reference_step(mine, noise, context, vt)
+        red.finish()
+        red.remove()
+        want = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in mine.named_parameters()}
+        assert all(want[n] is None for n in frozen) and sum(v is not None for v in want.values()) == len(want) - len(frozen)
+
+        # ---- (A) the reference's pattern: DDP(model), fp16 autocast as torch.cuda.amp.autocast() gives, GradScaler
+        ddp = DDP(base, device_ids=[0])                 # find_unused_parameters stays False
+        opt = optim.AdamW(ddp.parameters(), lr=1e-4, weight_decay=0.01)
+        scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 12)
+        before = {n: p.detach().clone() for n, p in base.named_parameters()}
+        loss_a = _reference_step(ddp, noise, context, vt, scaler=scaler, autocast_dtype=torch.float16)
+        assert abs(float(loss_a) - float(loss_b)) <= 1e-5 * abs(float(loss_b)), (float(loss_a), float(loss_b))
+        scaler.unscale_(opt)
+        worst = 0.0
+        for n, p in base.named_parameters():
+            if n in frozen:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, n      # DDP zero-fills the unused slot
+                continue
+            assert p.grad is not None and torch.isfinite(p.grad).all(), n
+            e = float((p.grad.double() - want[n].double()).norm() / want[n].double().norm().clamp_min(1e-30))
+            worst = max(worst, e)
+            # same kernels, same data; the loss scale is a power of two (commutes with every bf16 rounding): what is
+            # left is the summation order of the fp32 atomics (bias / gain / split-K sums), 1e-4 run to run
+            assert e < 2e-3, (n, e)
+        # gradients are identical on both ranks after the all-reduce (they ARE the average)
+        probe = base.blocks[3].self_attn.o.weight.grad.detach().clone()
+        other = [torch.empty_like(probe) for _ in range(world)]
+        dist.all_gather(other, probe)
+        assert torch.equal(other[0], other[1])
+        scaler.step(opt)
+        scaler.update()
+        moved = sum(int(not torch.equal(p.detach(), before[n])) for n, p in base.named_parameters())
+        assert moved >= len(before) - len(frozen)
+        # a second iteration: DDP raises here if a parameter of the first one never reported to its reducer
+        opt.zero_grad(set_to_none=True)
+        loss_2 = _reference_step(ddp, noise, context, vt, scaler=scaler, autocast_dtype=torch.float16)
+        scaler.step(opt)
+        scaler.update()
+        assert torch.isfinite(loss_2)
+        # bf16 autocast, no scaler (accelerate's mixed_precision="bf16" path) gives the same forward
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            o1 = ddp(noise, t=torch.ones(2, device="cuda") * 1000, context=[context[0], context[1]], seq_len=24)
+        with torch.no_grad():
+            o2 = base(noise, t=torch.ones(2, device="cuda") * 1000, context=[context[0], context[1]], seq_len=24)
+        assert o1[0].dtype == torch.float32 and torch.equal(o1[0], o2[0])
+        q.put((rank, "ok", worst))
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL " + repr(e) + traceback.format_exc()[-1500:], None))
+
+
+def test_ddp_autocast_gradscaler_two_ranks_match_the_bucketed_reducer():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    assert sorted(r[:2] for r in res) == [(0, "ok"), (1, "ok")], res
+    print(f"[measured] DDP + fp16 autocast + GradScaler vs BucketedGradAllReduce, 2 ranks (gloo, one GPU): worst "
+          f"relative gradient difference {max(r[2] for r in res):.2e}")
+
+
+def _accelerate_worker(port, q):
+    try:
+        import importlib
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                          LOCAL_WORLD_SIZE="1")
+        torch.cuda.set_device(0)
+        from accelerate import Accelerator
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        import torch.nn.functional as F
+        optim = importlib.import_module(PKG + ".optim")
+        base, noise, context, vt = _tiny_model_and_batch(0)
+        bare = copy.deepcopy(base)
+        loss_b = _reference_step(bare, noise, context, vt)
+        want = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in bare.named_parameters()}
+        accelerator = Accelerator(mixed_precision="bf16")              # a one-rank RCCL group: still MULTI_GPU -> DDP
+        opt = optim.AdamW(base.parameters(), lr=1e-4, weight_decay=0.01)
+        model, opt = accelerator.prepare(base, opt)                     # distilled_trainer.py:79-81
+        assert isinstance(model, DDP), type(model)
+        model.train()
+        contexts_list = [context[i] for i in range(context.size(0))]
+        with accelerator.autocast():
+            out = model(noise, t=torch.ones(2, device="cuda") * 1000, context=contexts_list, seq_len=24)
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                loss = F.mse_loss(out[0], vt)
+        accelerator.backward(loss)
+        assert abs(float(loss) - float(loss_b)) <= 1e-5 * abs(float(loss_b))
+        worst = 0.0
+        for n, p in accelerator.unwrap_model(model).named_parameters():
+            if want[n] is None:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+                continue
+            e = float((p.grad.double() - want[n].double()).norm() / want[n].double().norm().clamp_min(1e-30))
+            worst = max(worst, e)
+            assert e < 2e-3, (n, e)
+        opt.step()
+        opt.zero_grad()
+        q.put(("ok", worst))
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put(("FAIL " + repr(e) + traceback.format_exc()[-1500:], None))
+
+
+def test_accelerate_prepare_wraps_the_model_and_trains():
+    pytest.importorskip("accelerate")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_accelerate_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=120)
+    assert res[0] == "ok", res
+    print(f"[measured] Accelerator(mixed_precision='bf16').prepare -> DDP on a one-rank RCCL group: worst relative "
+          f"gradient difference vs the bare model {res[1]:.2e}")

@@ -368,3 +368,178 @@ def test_checkpoint_save_resume_in_the_trainers_formats(wan_model_mod, tmp_path)
     m_f, _ = fresh()
     trainer.load_ema(ema, m_f)
     assert all(torch.isfinite(p).all() for p in m_f.parameters())
+
+
+# ------------------------------------------------------------------------------------------------ round 3: fused epilogues
+def test_gemm_training_epilogues(ops):
+    """ABI v5 epilogues of omh_gemm_bf16 against the un-fused kernels they replace: out-of-place gated residual with
+    the branch output on the side, GELU with the pre-activation on the side, GELU' in the dgrad epilogue."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for M, N, K, S in [(1560, 1536, 1536, 1560), (6240, 1536, 1536, 1560), (333, 264, 136, 111)]:
+        a = (torch.randn(M, K, device="cuda", generator=g) * 0.5).bfloat16()
+        w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).bfloat16()
+        b = torch.randn(N, device="cuda", generator=g)
+        x = torch.randn(M, N, device="cuda", generator=g)
+        g0 = torch.randn(N, device="cuda", generator=g)
+        g1 = torch.randn((M + S - 1) // S, 6 * N, device="cuda", generator=g)
+        # reference: in place, no aux
+        ref = x.clone()
+        ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(ref), M, N, K, K, K, N, ops.EPI_RESID, bias=ops.ptr(b), bias_mode=ops.BIAS_N,
+                     gate0=ops.ptr(g0), gate1=ops.ptr(g1, 2 * N), gate1_stride=6 * N, gate_rows=S, gate_const=0.0)
+        y_ref = ops.gemm(a, w, bias=b, epilogue=ops.EPI_BF16)
+        xin = x.clone()
+        out = torch.full_like(x, 7.0)
+        y = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(out), M, N, K, K, K, N, ops.EPI_RESID, bias=ops.ptr(b), bias_mode=ops.BIAS_N,
+                     gate0=ops.ptr(g0), gate1=ops.ptr(g1, 2 * N), gate1_stride=6 * N, gate_rows=S, gate_const=0.0,
+                     c_in=ops.ptr(xin), aux=ops.ptr(y), ldaux=N)
+        assert torch.equal(out, ref) and torch.equal(xin, x) and torch.equal(y, y_ref), (M, N, K)
+        # GELU + pre-activation
+        u_ref = ops.gemm(a, w, bias=b, epilogue=ops.EPI_GELU_BF16)
+        u = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        pre = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(u), M, N, K, K, K, N, ops.EPI_GELU_BF16, bias=ops.ptr(b), bias_mode=ops.BIAS_N,
+                     aux=ops.ptr(pre), ldaux=N)
+        assert torch.equal(u, u_ref) and torch.equal(pre, y_ref)
+        # GELU' epilogue: (a w^T) * gelu'(pre)  ==  gelu_bwd(bf16(a w^T), pre) up to the one rounding it saves
+        d_un = ops.gelu_tanh_bwd(ops.gemm(a, w, epilogue=ops.EPI_BF16), pre)
+        d_f = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(d_f), M, N, K, K, K, N, ops.EPI_GELU_BWD_BF16, aux=ops.ptr(pre), ldaux=N)
+        xf = pre.float().requires_grad_(True)
+        torch.nn.functional.gelu(xf, approximate="tanh").backward((a.float() @ w.float().t()))
+        assert rel_rms(d_f.float(), xf.grad) < 4e-3 and rel_rms(d_f.float(), d_un.float()) < 6e-3, (M, N, K)
+
+
+def test_attention_backward_prescaled_q_and_bf16_outputs(ops):
+    """omh_flash_attn_bwd_d128 on the forward's pre-scaled q (q' = bf16(q scale log2 e)) with bf16 gradients written
+    into the column blocks of one [rows, 3d] buffer, against the fp32 / plain-q path on the same problem."""
+    torch.manual_seed(9)
+    B, H, Lq, Lk, D = 2, 2, 200, 136, 128
+    d = H * D
+    q = torch.randn(B * Lq, d, device="cuda")
+    k = torch.randn(B * Lk, d, device="cuda").bfloat16()
+    v = torch.randn(B * Lk, d, device="cuda").bfloat16()
+    do = torch.randn(B * Lq, d, device="cuda").bfloat16()
+    klens = torch.tensor([Lk, 77], dtype=torch.int32, device="cuda")
+    scale = D ** -0.5
+    qs = (q * (scale * 1.4426950408889634)).bfloat16()               # what rmsnorm_rope_bf16(out_scale) hands the forward
+    q_plain = (qs.float() / (scale * 1.4426950408889634)).bfloat16()  # a plain q representing (almost) the same values
+
+    def fwd(qq, pres):
+        Lp = (Lk + 63) // 64 * 64
+        vt = torch.zeros(B, d, Lp, device="cuda", dtype=torch.bfloat16)
+        ops.transpose_bf16_raw(ops.ptr(v), ops.ptr(vt), Lk, d, d, Lp, batch=B, bs_in=Lk * d, bs_out=d * Lp)
+        o = torch.empty(B * Lq, d, device="cuda", dtype=torch.bfloat16)
+        lse = torch.empty(B, H, Lq, device="cuda")
+        ops.flash_attn_raw(ops.ptr(qq), ops.ptr(k), ops.ptr(vt), ops.ptr(o), ops.ptr(klens), B, H, Lq, Lk, Lq * d, d, Lk * d,
+                           d, d * Lp, Lq * d, d, Lp, scale, lse=ops.ptr(lse), q_prescaled=int(pres))
+        return o, lse
+    o1, lse1 = fwd(qs, True)
+    o0, lse0 = fwd(q_plain, False)
+    assert rel_rms(o1.float(), o0.float()) < 1e-2
+    dq0, dk0, dv0 = ops.flash_attn_bwd(q_plain, k, v, o0, do, lse0, klens, B, H, Lq, Lk, scale)
+    buf = torch.full((B * Lq, 3 * d), 3.0, device="cuda", dtype=torch.bfloat16)
+    kvb = torch.full((B * Lk, 2 * d), 3.0, device="cuda", dtype=torch.bfloat16)
+    ops.flash_attn_bwd(qs, k, v, o1, do, lse1, klens, B, H, Lq, Lk, scale, q_prescaled=True,
+                       out=(buf[:, d:2 * d], kvb[:, :d], kvb[:, d:]))
+    assert bool((buf[:, :d] == 3.0).all()) and bool((buf[:, 2 * d:] == 3.0).all())
+    for got, want, nm in ((buf[:, d:2 * d], dq0, "dq"), (kvb[:, :d], dk0, "dk"), (kvb[:, d:], dv0, "dv")):
+        e = rel_rms(got.float(), want)
+        assert e < 1.2e-2, (nm, e)          # bf16 rounding of the output + the 2^-9 perturbation of q between the two
+
+
+def test_rmsnorm_rope_bwd_typed_inputs(ops):
+    """omh_rmsnorm_rope_bwd_t: bf16 / fp32 x and dy in every combination, in place on dy, strided column blocks."""
+    from oracle import wan_dit_oracle as O
+    torch.manual_seed(4)
+    B, S, N, D = 2, 9, 2, 128
+    dd = N * D
+    grids = [(1, 3, 3), (1, 2, 4)]
+    ang = O.rope_table(D)
+    cos, sin = torch.cos(ang).float().cuda(), torch.sin(ang).float().cuda()
+    grid = torch.tensor(grids, dtype=torch.int32, device="cuda")
+    w = torch.rand(dd, device="cuda") + 0.5
+    xq = torch.randn(B * S, 2 * dd, device="cuda").bfloat16()          # q | k projection, bf16, row stride 2 dd
+    gq = torch.randn(B * S, 3 * dd, device="cuda").bfloat16()          # dq | dk | dv buffer
+    for x_bf in (True, False):
+        for col in (0, 1):
+            x_in = xq if x_bf else xq.float()
+            xc = xq[:, col * dd:(col + 1) * dd].float().cpu().requires_grad_(True)
+            wc = w.cpu().requires_grad_(True)
+            yq = O.rope_apply(O.rms_norm(xc, wc, 1e-6).view(B, S, N, D), grids, ang)
+            yq.backward(gq[:, col * dd:(col + 1) * dd].float().cpu().view(B, S, N, D))
+            buf = gq.clone()
+            dw = torch.zeros(dd, device="cuda")
+            ops.rmsnorm_rope_bwd_t_raw(ops.ptr(x_in, col * dd), x_bf, 2 * dd, ops.ptr(buf, col * dd), True, 3 * dd,
+                                       ops.ptr(buf, col * dd), 3 * dd, ops.ptr(dw), B * S, dd, ops.ptr(w), 1e-6, 1,
+                                       ops.ptr(cos), ops.ptr(sin), 1024, D, ops.ptr(grid), S)
+            assert rel_rms(buf[:, col * dd:(col + 1) * dd].float(), xc.grad) < 5e-3
+            assert rel_rms(dw, wc.grad) < 1e-4
+            other = [c for c in range(3) if c != col]
+            for c in other:
+                assert torch.equal(buf[:, c * dd:(c + 1) * dd], gq[:, c * dd:(c + 1) * dd])
+
+
+def test_pack_weights_multi(ops):
+    """One launch = bf16 copy + transposed bf16 copy of many fp32 matrices (ragged tiles, row pitches, column blocks of
+    fused buffers) + the fp32 bias copies."""
+    g = torch.Generator(device="cuda").manual_seed(2)
+    shapes = [(1536, 1536), (8960, 1536), (1536, 8960), (64, 1536), (130, 70), (7, 5)]
+    srcs = [torch.randn(r, c, device="cuda", generator=g) for r, c in shapes]
+    bias = torch.randn(5000, device="cuda", generator=g)
+    fused = torch.zeros(2 * 1536, 1536, device="cuda", dtype=torch.bfloat16)
+    fusedT = torch.zeros(1536, 2 * 1536, device="cuda", dtype=torch.bfloat16)
+    rows, outs = [], []
+    for i, s in enumerate(srcs):
+        r, c = s.shape
+        if i == 0:
+            dst, dstT, ld, ldt = fused[1536:], fusedT[:, 1536:], 1536, 3072
+        else:
+            dst = torch.zeros(r, c, device="cuda", dtype=torch.bfloat16)
+            dstT = torch.zeros(c, r + (8 if i == 4 else 0), device="cuda", dtype=torch.bfloat16) if i != 3 else None
+            ld, ldt = c, (dstT.shape[1] if dstT is not None else 0)
+        outs.append((dst, dstT))
+        rows.append([s.data_ptr(), dst.data_ptr(), dstT.data_ptr() if dstT is not None else 0, r, c, ld, ldt, 0, 0])
+    bcopy = torch.zeros(5000, device="cuda")
+    rows.append([bias.data_ptr(), bcopy.data_ptr(), 0, 1, 5000, 5000, 0, 0, 1])
+    t0 = 0
+    for r in rows:
+        r[7] = t0
+        t0 += (r[3] * r[4] + 4095) // 4096 if r[8] == 1 else ((r[3] + 63) // 64) * ((r[4] + 63) // 64)
+    ops.pack_weights_multi(torch.tensor(rows, dtype=torch.int64).cuda(), len(rows), t0)
+    for s, (dst, dstT) in zip(srcs, outs):
+        want = s.bfloat16()
+        assert torch.equal(dst, want)
+        if dstT is not None:
+            assert torch.equal(dstT[:, :s.shape[0]], want.t())
+    assert torch.equal(bcopy, bias) and bool((fused[:1536] == 0).all()) and bool((fusedT[:, :1536] == 0).all())
+
+
+@pytest.mark.parametrize("freeze", [True, False])
+def test_training_forward_equals_inference_and_checkpoint_equals_kept_activations(wan_model_mod, freeze):
+    """(1) the training forward is the inference forward bit for bit (same kernels, same roundings: the loss is taken
+    from the values the backward differentiates); (2) use_checkpoint = False (activations kept, model.py:549-553) and
+    True (block re-run in the backward, model.py:544-548) give the same gradients — both run the same kernels on the
+    same inputs, only fp32 atomic summation order differs."""
+    cfg, sd, m, noise, vt, cl = _setup(wan_model_mod, freeze)
+    args = dict(t=torch.ones(2, device="cuda") * 1000.0, context=[c.cuda() for c in cl], seq_len=24)
+    with torch.no_grad():
+        want = m(list(noise.cuda()), **args)
+    grads = {}
+    for ck in (False, True):
+        m.use_checkpoint = ck
+        for p in m.parameters():
+            p.grad = None
+        out = m(list(noise.cuda()), **args)
+        assert all(torch.equal(a, b) for a, b in zip(out, want)), f"training forward != inference forward (ckpt={ck})"
+        sum(torch.nn.functional.mse_loss(a, b) for a, b in zip(out, vt.cuda())).backward()
+        grads[ck] = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in m.named_parameters()}
+    worst = 0.0
+    for n in grads[True]:
+        a, b = grads[True][n], grads[False][n]
+        assert (a is None) == (b is None), n
+        if a is not None:
+            e = float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+            worst = max(worst, e)
+            assert e < 1e-3, (n, e)
+    print(f"[measured] gradients, re-run block vs kept activations (freeze={freeze}): worst relative difference {worst:.2e}")

@@ -1,8 +1,9 @@
-"""Eight training steps at 4 clips per GPU with the reference's quirks (bench.py's primary training leg) — for
-rocprofv3 --kernel-trace --stats."""
+"""Training steps of bench.py's training leg (reference quirks on) at OMH_TRAIN_BATCH clips per GPU (default 4) —
+for rocprofv3 --kernel-trace --stats (tools/rocprof_train.sh)."""
 import importlib, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 dev = torch.device("cuda", 0)
 model = bench.build_model(dev)
-print(bench.train_bench(model, dev, 1, None, steps=6, warmup=2, bsz=4))
+bsz = int(os.environ.get("OMH_TRAIN_BATCH", "4"))
+print(bench.train_bench(model, dev, 1, None, steps=6, warmup=2, bsz=bsz))
