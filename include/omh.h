@@ -381,6 +381,41 @@ int omh_rmsnorm_rope_bwd_t(const void* x, int32_t x_bf16, int64_t ldx, const voi
                            void* dx_bf16, int64_t lddx, float* dweight, int64_t rows, int32_t dim, const float* weight,
                            float eps, int32_t do_norm, const float* rope_cos, const float* rope_sin, int32_t rope_len,
                            int32_t head_dim, const int32_t* grid, int32_t seq_len, omh_stream_t stream);
+/* Round-3 forms of the two norm backwards (csrc/dit_backward2.hip): a workgroup takes 8 rows of ONE batch element,
+ * per-column parameter sums are combined in a fixed order (registers -> LDS -> one partial per workgroup in
+ * `workspace` -> a second launch adds the partials of a column in workgroup order): no atomics, bit-repeatable.
+ *
+ * omh_layernorm_modulate_bwd2 = omh_layernorm_modulate_bwd (dy fp32 or bf16) and, optionally, the gated-residual
+ * backward of the NEXT branch (omh_gated_residual_bwd) applied to each row of dx as soon as it is final:
+ *   dy_next[r][c] = bf16(dx[r][c] * gate),  gate = gate_const + gate0[c] + gate1[b * gate1_stride + c]
+ *   dgate[b * dgate_stride + c] += sum_rows dx * y_next            (only with y_next and dgate)
+ * workspace: omh_layernorm_modulate_bwd2_workspace(rows, dim, rows_per_batch) floats, 16-byte aligned. */
+typedef struct omh_ln_bwd_args {
+    const float* x; const void* dy; int32_t dy_bf16; float* dx;
+    int64_t rows; int32_t dim; float eps; float mul_const;
+    const float* mul0; const float* mul1; int64_t mul1_stride;
+    float* dmul; float* dadd; int64_t dstride; int64_t rows_per_batch;
+    void* dy_next; const void* y_next; float gate_const; const float* gate0; const float* gate1; int64_t gate1_stride;
+    float* dgate; int64_t dgate_stride;
+    float* workspace; int64_t workspace_floats;
+} omh_ln_bwd_args;
+int64_t omh_layernorm_modulate_bwd2_workspace(int64_t rows, int32_t dim, int64_t rows_per_batch);
+int omh_layernorm_modulate_bwd2(const omh_ln_bwd_args* args, omh_stream_t stream);
+
+/* omh_rmsnorm_rope_bwd_t on n_seg = 1 or 2 column segments of the same rows in one launch (q and k of the
+ * self-attention: segment s reads x + s*seg_x, dy + s*seg_dy, writes dx + s*seg_dx — element offsets — with its own
+ * weight[s] / dweight[s]; with n_seg = 2 the dweight pointers are both set or both NULL).  dx may alias dy.
+ * workspace: omh_rmsnorm_rope_bwd2_workspace(rows, dim, n_seg) floats (only read when a dweight is set). */
+typedef struct omh_rms_bwd_args {
+    const void* x; int32_t x_bf16; int64_t ldx; const void* dy; int32_t dy_bf16; int64_t lddy; void* dx; int64_t lddx;
+    int32_t n_seg; int64_t seg_x, seg_dy, seg_dx;
+    const float* weight[2]; float* dweight[2];
+    int64_t rows; int32_t dim; float eps; int32_t do_norm;
+    const float* rope_cos; const float* rope_sin; int32_t rope_len, head_dim; const int32_t* grid; int32_t seq_len;
+    float* workspace; int64_t workspace_floats;
+} omh_rms_bwd_args;
+int64_t omh_rmsnorm_rope_bwd2_workspace(int64_t rows, int32_t dim, int32_t n_seg);
+int omh_rmsnorm_rope_bwd2(const omh_rms_bwd_args* args, omh_stream_t stream);
 /* dS = P * (dP - sum_j P*dP) * scale per row (softmax backward of the unfused attention backward). */
 int omh_softmax_bwd_rows(const void* p_bf16, int64_t ldp, const float* dp, int64_t lddp, void* ds_bf16, int64_t ldds,
                          int64_t R, int32_t L, float scale, omh_stream_t stream);

@@ -100,6 +100,25 @@ class AttnBwdArgs(C.Structure):
                 ("ldq", i32), ("ldk", i32), ("scale", f32), ("q_prescaled", i32), ("out_bf16", i32)]
 
 
+class LnBwdArgs(C.Structure):
+    _fields_ = [("x", vp), ("dy", vp), ("dy_bf16", i32), ("dx", vp),
+                ("rows", i64), ("dim", i32), ("eps", f32), ("mul_const", f32),
+                ("mul0", vp), ("mul1", vp), ("mul1_stride", i64),
+                ("dmul", vp), ("dadd", vp), ("dstride", i64), ("rows_per_batch", i64),
+                ("dy_next", vp), ("y_next", vp), ("gate_const", f32), ("gate0", vp), ("gate1", vp), ("gate1_stride", i64),
+                ("dgate", vp), ("dgate_stride", i64),
+                ("workspace", vp), ("workspace_floats", i64)]
+
+
+class RmsBwdArgs(C.Structure):
+    _fields_ = [("x", vp), ("x_bf16", i32), ("ldx", i64), ("dy", vp), ("dy_bf16", i32), ("lddy", i64), ("dx", vp), ("lddx", i64),
+                ("n_seg", i32), ("seg_x", i64), ("seg_dy", i64), ("seg_dx", i64),
+                ("weight", vp * 2), ("dweight", vp * 2),
+                ("rows", i64), ("dim", i32), ("eps", f32), ("do_norm", i32),
+                ("rope_cos", vp), ("rope_sin", vp), ("rope_len", i32), ("head_dim", i32), ("grid", vp), ("seq_len", i32),
+                ("workspace", vp), ("workspace_floats", i64)]
+
+
 class ConvArgs(C.Structure):
     _fields_ = [("x", vp), ("w", vp), ("bias", vp), ("resid", vp), ("y", vp),
                 ("Tin", i32), ("Hin", i32), ("Win", i32), ("Cin", i32),
@@ -150,6 +169,10 @@ _SIGS = {
                                    vp]),
     "omh_rmsnorm_rope_bwd_t": (i32, [vp, i32, i64, vp, i32, i64, vp, i64, vp, i64, i32, vp, f32, i32, vp, vp, i32, i32,
                                      vp, i32, vp]),
+    "omh_layernorm_modulate_bwd2_workspace": (i64, [i64, i32, i64]),
+    "omh_layernorm_modulate_bwd2": (i32, [C.POINTER(LnBwdArgs), vp]),
+    "omh_rmsnorm_rope_bwd2_workspace": (i64, [i64, i32, i32]),
+    "omh_rmsnorm_rope_bwd2": (i32, [C.POINTER(RmsBwdArgs), vp]),
     "omh_softmax_bwd_rows": (i32, [vp, i64, vp, i64, vp, i64, i64, i32, f32, vp]),
     "omh_unpatchify_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "omh_dense_f32_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),

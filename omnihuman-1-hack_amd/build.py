@@ -39,8 +39,10 @@ def _generate():
         if os.path.exists(gen):
             txt = subprocess.run([sys.executable, gen], check=True, capture_output=True, text=True).stdout
             if not os.path.exists(out) or open(out).read() != txt:
-                with open(out, "w") as fh:
+                tmp = out + f".tmp{os.getpid()}"
+                with open(tmp, "w") as fh:
                     fh.write(txt)
+                os.replace(tmp, out)             # atomic: a concurrent reader never sees a truncated stream
 
 
 def _sources():
@@ -49,7 +51,10 @@ def _sources():
 
 def _digest():
     h = hashlib.sha256(" ".join(FLAGS).encode())
-    for f in _sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))) + \
+    # (the generators are part of the digest: editing one makes the build stale, and the streams are regenerated
+    # under the build lock — not on every import)
+    for f in _sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)
+                                 if f.endswith((".h", ".inc")) or (f.startswith("gen_") and f.endswith(".py"))) + \
             [os.path.join(INCLUDE, "omh.h")]:
         with open(f, "rb") as fh:
             h.update(os.path.basename(f).encode())     # not the path: the tree is copied to the GPU box
@@ -87,8 +92,6 @@ def _obj_digest(src):
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     stamp = os.path.join(LIBDIR, "libomh.sha256")
-    if have_hipcc():
-        _generate()
     if not force and up_to_date():
         return LIB
     # one builder at a time (torchrun starts N ranks that all import the package): the others wait on the lock and
@@ -96,10 +99,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     import fcntl
     with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
-        dig = _digest()
         if not force and up_to_date():
             return LIB
         hipcc = _hipcc()
+        _generate()
+        dig = _digest()
 
         def compile_one(src):
             obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")

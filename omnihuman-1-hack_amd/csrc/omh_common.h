@@ -43,11 +43,15 @@ __device__ __forceinline__ float gelu_tanh(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
 }
 // d/dx gelu_tanh(x) = 0.5 (1 + t) + 0.5 x (1 - t^2) c (1 + 3 a x^2),  t = tanh(c (x + a x^3))
+// With s = sigmoid(2u) = 1 / (1 + 2^(-2u log2 e)):  0.5 (1 + t) = s  and  0.5 (1 - t^2) = 2 s (1 - s), so
+//   gelu' = s + x * 2 s (1 - s) * c (1 + 3 a x^2)      (raw v_exp_f32 / v_rcp_f32: ~12 VALU, no IEEE division —
+// this runs 128 times per lane in the epilogue of the FFN dgrad GEMM)
 __device__ __forceinline__ float gelu_tanh_grad(float x) {
     const float c = 0.7978845608028654f, a = 0.044715f;
-    const float u = c * (x + a * x * x * x);
-    const float t = 1.0f - 2.0f / (1.0f + __expf(2.0f * u));          // tanh(u)
-    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * a * x * x);
+    const float x2 = x * x;
+    const float k = -2.0f * c * 1.4426950408889634f;                  // -2 c log2(e)
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(k * x * fmaf(a, x2, 1.0f)));
+    return fmaf(x * (2.0f * c) * fmaf(3.0f * a, x2, 1.0f), s * (1.0f - s), s);
 }
 __device__ __forceinline__ float silu(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));

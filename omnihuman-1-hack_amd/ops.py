@@ -478,6 +478,35 @@ def rmsnorm_rope_bwd_t_raw(x, x_bf16, ldx, dy, dy_bf16, lddy, dx, lddx, dw, rows
           "omh_rmsnorm_rope_bwd_t")
 
 
+def layernorm_modulate_bwd2(x, dy, dx, rows, dim, eps, mul_const, mul0, mul1, mul1_stride, dmul, dadd, dstride,
+                            rows_per_batch, dy_next=None, y_next=None, gate_const=1.0, gate0=None, gate1=None,
+                            gate1_stride=0, dgate=None, dgate_stride=0):
+    """Repeatable LayerNorm+modulate backward, optionally fused with the next branch's gated-residual backward
+    (include/omh.h).  x, dx fp32 tensors [rows, dim]; dy fp32 or bf16 tensor; the pointer-like arguments (mul0 ... dgate)
+    are c_void_p / None as for the *_raw ops; dy_next / y_next bf16 tensors or None."""
+    _dev(x, dy, dx, dy_next, y_next)
+    need = lib.omh_layernorm_modulate_bwd2_workspace(rows, dim, rows_per_batch)
+    ws = torch.empty(need, dtype=torch.float32, device=x.device)
+    a = _lib.LnBwdArgs(_p(x), _p(dy), int(dy.dtype == torch.bfloat16), _p(dx), rows, dim, eps, mul_const, mul0, mul1,
+                       mul1_stride, dmul, dadd, dstride, rows_per_batch, _p(dy_next), _p(y_next), gate_const, gate0, gate1,
+                       gate1_stride, dgate, dgate_stride, _p(ws), need)
+    check(lib.omh_layernorm_modulate_bwd2(C.byref(a), _stream()), "omh_layernorm_modulate_bwd2")
+
+
+def rmsnorm_rope_bwd2(x, x_bf16, ldx, dy, dy_bf16, lddy, dx, lddx, rows, dim, eps, do_norm, weights, dweights, device,
+                      n_seg=1, seg_x=0, seg_dy=0, seg_dx=0, rope_cos=None, rope_sin=None, rope_len=0, head_dim=128,
+                      grid=None, seq_len=0):
+    """Repeatable RMSNorm(+RoPE) backward on 1 or 2 column segments (include/omh.h); x / dy / dx and the table
+    pointers are c_void_p; weights / dweights: lists of fp32 tensors or None per segment."""
+    need = lib.omh_rmsnorm_rope_bwd2_workspace(rows, dim, n_seg) if any(d is not None for d in dweights) else 0
+    ws = torch.empty(max(need, 1), dtype=torch.float32, device=device)
+    W = (C.c_void_p * 2)(*[(w.data_ptr() if w is not None else None) for w in (list(weights) + [None])[:2]])
+    DW = (C.c_void_p * 2)(*[(w.data_ptr() if w is not None else None) for w in (list(dweights) + [None])[:2]])
+    a = _lib.RmsBwdArgs(x, int(x_bf16), ldx, dy, int(dy_bf16), lddy, dx, lddx, n_seg, seg_x, seg_dy, seg_dx, W, DW, rows, dim,
+                        eps, int(do_norm), rope_cos, rope_sin, rope_len, head_dim, grid, seq_len, _p(ws), need)
+    check(lib.omh_rmsnorm_rope_bwd2(C.byref(a), _stream()), "omh_rmsnorm_rope_bwd2")
+
+
 def softmax_bwd_rows(p, dp, ds, L, scale):
     _dev(p, dp, ds)
     assert p.dtype == torch.bfloat16 and dp.dtype == torch.float32 and ds.dtype == torch.bfloat16

@@ -431,10 +431,21 @@ def _block_backward(model, blk, idx, st, S, dx, P):
     d_eb = arena.take(B, 6, d)                                        # grads of e = modulation + e0
     g = {}
 
-    def ln_bwd(xin, dh, shift_i, scale_i):
-        ops.layernorm_modulate_bwd_raw(ptr(xin), ptr(dh), ptr(dx), R, d, eps, 1.0, ptr(mod, scale_i * d),
-                                       ptr(e0, scale_i * d), six, ptr(d_eb, scale_i * d), ptr(d_eb, shift_i * d),
-                                       six, Sq)
+    def ln_bwd(xin, dh, shift_i, scale_i, nxt=None):
+        """dx += LN+modulate backward of dh; ``nxt = (y, gate_i)``: also the next branch's gated-residual backward on
+        the finished rows (dy_next = bf16(dx * gate), the gate's gradient) — returns dy_next."""
+        dy_next = bf(R, d) if nxt is not None else None
+        kw = {}
+        if nxt is not None:
+            y, gi = nxt
+            if gi is None:
+                kw = dict(dy_next=dy_next, gate_const=1.0)
+            else:
+                kw = dict(dy_next=dy_next, y_next=y, gate_const=0.0, gate0=ptr(mod, gi * d), gate1=ptr(e0, gi * d),
+                          gate1_stride=six, dgate=ptr(d_eb, gi * d), dgate_stride=six)
+        ops.layernorm_modulate_bwd2(xin, dh, dx, R, d, eps, 1.0, ptr(mod, scale_i * d), ptr(e0, scale_i * d), six,
+                                    ptr(d_eb, scale_i * d), ptr(d_eb, shift_i * d), six, Sq, **kw)
+        return dy_next
 
     def resid_bwd(y, gate_i):
         dy = bf(R, d)
@@ -445,16 +456,17 @@ def _block_backward(model, blk, idx, st, S, dx, P):
                                        ptr(mod, gate_i * d), ptr(e0, gate_i * d), six, Sq)
         return dy
 
-    def rms_bwd(x, x_bf16, ldx, dy, lddy, rows, weight, norm_on, rope, name, mod_):
-        """In place on dy (bf16): dy <- gradient of the pre-norm projection; the norm gain's gradient into g[name]."""
-        dnw = arena.take(d) if norm_on else None
-        rc, rs_, rl, gr, sl = (ptr(fc.rope_cos), ptr(fc.rope_sin), fc.rope_cos.shape[0], ptr(fc.grid32), Sq) if rope \
-            else (None, None, 0, None, 0)
-        ops.rmsnorm_rope_bwd_t_raw(x, x_bf16, ldx, dy, True, lddy, dy, lddy, ptr(dnw) if dnw is not None else None, rows,
-                                   d, ptr(weight) if (norm_on and weight is not None) else None, mod_.eps, int(norm_on),
-                                   rc, rs_, rl, D, gr, sl)
-        if dnw is not None:
-            g[name] = dnw
+    def rms_bwd(x, x_bf16, ldx, dy, lddy, rows, weights, norm_on, rope, names, mod_, n_seg=1, seg_x=0, seg_dy=0):
+        """In place on dy (bf16): dy <- gradient of the pre-norm projection; the norm gains' gradients into g[names]."""
+        dws = [arena.take(d) if norm_on else None for _ in range(n_seg)]
+        rk = dict(rope_cos=ptr(fc.rope_cos), rope_sin=ptr(fc.rope_sin), rope_len=fc.rope_cos.shape[0], grid=ptr(fc.grid32),
+                  seq_len=Sq) if rope else {}
+        ops.rmsnorm_rope_bwd2(x, x_bf16, ldx, dy, True, lddy, dy, lddy, rows, d, mod_.eps, norm_on,
+                              [w if norm_on else None for w in weights], dws, dev, n_seg=n_seg, seg_x=seg_x, seg_dy=seg_dy,
+                              seg_dx=seg_dy, head_dim=D, **rk)
+        for nm, dw in zip(names, dws):
+            if dw is not None:
+                g[nm] = dw
 
     # ---- FFN branch: x3 = x2 + y3 * g5
     dy3 = resid_bwd(S["y3"], 5)
@@ -465,10 +477,11 @@ def _block_backward(model, blk, idx, st, S, dx, P):
         ops.gemm_raw(ptr(dy3), ptr(P["w2T"]), ptr(du_pre), R, f, d, d, d, f, EPI_GELU_BWD, aux=ptr(u_pre), ldaux=f)
         g["ffn.0.weight"], g["ffn.0.bias"] = _wgrad(du_pre, h2, side=True), _bgrad(du_pre, arena)
         dh2 = _dgrad(du_pre, P["w1T"])
-        ln_bwd(S["x2"], dh2, 3, 4)
+        # ---- cross-attention branch: x2 = x1 + y2  (its dy2 = bf16(dx) comes out of the same pass)
+        dy2 = ln_bwd(S["x2"], dh2, 3, 4, nxt=(None, None))
         del du_pre, dh2
-    # ---- cross-attention branch: x2 = x1 + y2
-    dy2 = resid_bwd(None, None)
+    else:
+        dy2 = resid_bwd(None, None)
     oc, qc, kc = S["oc"], S["qc"], S["kc"]
     g["cross_attn.o.weight"], g["cross_attn.o.bias"] = _wgrad(dy2, oc, side=True), _bgrad(dy2, arena)
     doc = _dgrad(dy2, P["wo_cT"], epilogue=EPI_BF16)
@@ -495,34 +508,36 @@ def _block_backward(model, blk, idx, st, S, dx, P):
         dkvi = bf(Ri, 2 * d)
         ops.cast_bf16_strided(dki, dkvi[:, :d])
         ops.cast_bf16_strided(dvi, dkvi[:, d:])
-        rms_bwd(ptr(S["kfi"]), False, d, ptr(dkvi), 2 * d, Ri, ca._norm_w("norm_k_img"), ca.qk_norm, False,
-                "cross_attn.norm_k_img.weight", ca)
+        rms_bwd(ptr(S["kfi"]), False, d, ptr(dkvi), 2 * d, Ri, [ca._norm_w("norm_k_img")], ca.qk_norm, False,
+                ["cross_attn.norm_k_img.weight"], ca)
         dwi, dbi = _wgrad(dkvi, ctxi, side=True), _bgrad(dkvi, arena)
         g["cross_attn.k_img.weight"], g["cross_attn.v_img.weight"] = dwi[:d], dwi[d:]
         g["cross_attn.k_img.bias"], g["cross_attn.v_img.bias"] = dbi[:d], dbi[d:]
         _dgrad_ctx(dkvi, P["wkv_iT"], st.d_ctx, 0, n_img)
         del dq32, dk32, dv32, dqi, dki, dvi
-    rms_bwd(ptr(S["qcb"]), True, d, ptr(dqc), d, R, ca._norm_w("norm_q"), ca.qk_norm, False, "cross_attn.norm_q.weight", ca)
+    rms_bwd(ptr(S["qcb"]), True, d, ptr(dqc), d, R, [ca._norm_w("norm_q")], ca.qk_norm, False, ["cross_attn.norm_q.weight"], ca)
     h3 = S["h3"]
     g["cross_attn.q.weight"], g["cross_attn.q.bias"] = _wgrad(dqc, h3, side=True), _bgrad(dqc, arena)
     dh3 = _dgrad(dqc, P["wq_cT"])
-    rms_bwd(ptr(S["kf"]), False, d, ptr(dkv), 2 * d, Rc, ca._norm_w("norm_k"), ca.qk_norm, False,
-            "cross_attn.norm_k.weight", ca)
+    rms_bwd(ptr(S["kf"]), False, d, ptr(dkv), 2 * d, Rc, [ca._norm_w("norm_k")], ca.qk_norm, False,
+            ["cross_attn.norm_k.weight"], ca)
     dwkv, dbkv = _wgrad(dkv, ctx2, side=True), _bgrad(dkv, arena)      # [2d, d]: k | v in one GEMM
     g["cross_attn.k.weight"], g["cross_attn.v.weight"] = dwkv[:d], dwkv[d:]
     g["cross_attn.k.bias"], g["cross_attn.v.bias"] = dbkv[:d], dbkv[d:]
     _dgrad_ctx(dkv, P["wkv_cT"], st.d_ctx, n_img, Lt)
     x1 = S["x1"]
     if blk.cross_attn_norm:
+        # ---- self-attention branch: x1 = x0 + y1 * g2  (dy1 = bf16(dx * g2) and the gate's gradient: same pass)
         dw3, db3 = arena.take(d), arena.take(d)
-        ops.layernorm_modulate_bwd_raw(ptr(x1), ptr(dh3), ptr(dx), R, d, blk.norm3.eps, 0.0, ptr(S["w3"]), None, 0,
-                                       ptr(dw3), ptr(db3), 0, R)
+        dy1 = bf(R, d)
+        ops.layernorm_modulate_bwd2(x1, dh3, dx, R, d, blk.norm3.eps, 0.0, ptr(S["w3"]), None, 0, ptr(dw3), ptr(db3), 0, Sq,
+                                    dy_next=dy1, y_next=S["y1"], gate_const=0.0, gate0=ptr(mod, 2 * d), gate1=ptr(e0, 2 * d),
+                                    gate1_stride=six, dgate=ptr(d_eb, 2 * d), dgate_stride=six)
         g["norm3.weight"], g["norm3.bias"] = dw3, db3
     else:
         ops.colsum_accum(dh3.view(1, R * d), dx.view(R * d))          # dx += dh3
+        dy1 = resid_bwd(S["y1"], 2)
     del dy2, doc, dh3
-    # ---- self-attention branch: x1 = x0 + y1 * g2
-    dy1 = resid_bwd(S["y1"], 2)
     o, q, k, h1 = S["o"], S["q"], S["k"], S["h1"]
     g["self_attn.o.weight"], g["self_attn.o.bias"] = _wgrad(dy1, o, side=True), _bgrad(dy1, arena)
     do = _dgrad(dy1, P["woT"], epilogue=EPI_BF16)
@@ -531,9 +546,8 @@ def _block_backward(model, blk, idx, st, S, dx, P):
     ops.flash_attn_bwd(q, k, v, o, do, S["lse_sa"], fc.seq_lens32, B, N, Sq, Sq, D ** -0.5, q_prescaled=True,
                        out=(dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]))
     qk = S["qk"]
-    rms_bwd(ptr(qk), True, 2 * d, ptr(dqkv), 3 * d, R, sa._norm_w("norm_q"), sa.qk_norm, True, "self_attn.norm_q.weight", sa)
-    rms_bwd(ptr(qk, d), True, 2 * d, ptr(dqkv, d), 3 * d, R, sa._norm_w("norm_k"), sa.qk_norm, True,
-            "self_attn.norm_k.weight", sa)
+    rms_bwd(ptr(qk), True, 2 * d, ptr(dqkv), 3 * d, R, [sa._norm_w("norm_q"), sa._norm_w("norm_k")], sa.qk_norm, True,
+            ["self_attn.norm_q.weight", "self_attn.norm_k.weight"], sa, n_seg=2, seg_x=d, seg_dy=d)   # q and k: one launch
     dwqkv, dbqkv = _wgrad(dqkv, h1, side=True), _bgrad(dqkv, arena)     # [3d, d]: q | k | v in one GEMM
     for j, nm in enumerate(("q", "k", "v")):
         g[f"self_attn.{nm}.weight"], g[f"self_attn.{nm}.bias"] = dwqkv[j * d:(j + 1) * d], dbqkv[j * d:(j + 1) * d]

@@ -10,8 +10,8 @@ to the model on a multi-GPU launch), called under the caller's autocast, back-pr
 the reference's frozen FFNs (model.py:317-324) on.  The gradients DDP averages are compared with the ones this
 build's own reducer (parallel.BucketedGradAllReduce) produces on the same two ranks.
 
-Two ranks share the one GPU of the test box, so the process group is gloo (RCCL refuses two ranks on one device);
-the accelerate test runs one rank on RCCL, where ``Accelerator.prepare`` still wraps the model in DDP.
+Two ranks share the one GPU of the test box, so the process group is gloo (RCCL refuses two ranks on one device),
+in the accelerate test too (``Accelerator.prepare`` wraps the model in DDP only when there is more than one process).
 
 What the build needs under DDP (recorded by these tests): nothing — no ``find_unused_parameters``: every parameter is
 an input of one of the hand-written autograd nodes, the nodes return ``None`` for the frozen FFN parameters, DDP's
@@ -161,32 +161,43 @@ def test_ddp_autocast_gradscaler_two_ranks_match_the_bucketed_reducer():
           f"relative gradient difference {max(r[2] for r in res):.2e}")
 
 
-def _accelerate_worker(port, q):
+def _accelerate_worker(rank, world, port, q):
     try:
         import importlib
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-                          LOCAL_WORLD_SIZE="1")
+        import torch.distributed as dist
+        # two ranks on the one GPU: gloo is initialised first (accelerate keeps an initialised group), both ranks map to
+        # cuda:0 (accelerate: local_process_index % device_count) and DDP is built without device_ids
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world), ACCELERATE_BYPASS_DEVICE_MAP="true")
         torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
         from accelerate import Accelerator
         from torch.nn.parallel import DistributedDataParallel as DDP
         import torch.nn.functional as F
         optim = importlib.import_module(PKG + ".optim")
-        base, noise, context, vt = _tiny_model_and_batch(0)
+        base, noise, context, vt = _tiny_model_and_batch(rank)
         bare = copy.deepcopy(base)
         loss_b = _reference_step(bare, noise, context, vt)
-        want = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in bare.named_parameters()}
-        accelerator = Accelerator(mixed_precision="bf16")              # a one-rank RCCL group: still MULTI_GPU -> DDP
+        want = {}
+        for n, p in bare.named_parameters():                 # the data-parallel mean of the bare models' gradients
+            if p.grad is not None:
+                gsum = p.grad.detach().clone()
+                dist.all_reduce(gsum)
+                want[n] = gsum / world
+            else:
+                want[n] = None
+        accelerator = Accelerator(mixed_precision="bf16")
+        assert accelerator.num_processes == world and accelerator.device == torch.device("cuda", 0)
         opt = optim.AdamW(base.parameters(), lr=1e-4, weight_decay=0.01)
         model, opt = accelerator.prepare(base, opt)                     # distilled_trainer.py:79-81
         assert isinstance(model, DDP), type(model)
         model.train()
         contexts_list = [context[i] for i in range(context.size(0))]
-        with accelerator.autocast():
+        import warnings
+        with accelerator.autocast(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
             out = model(noise, t=torch.ones(2, device="cuda") * 1000, context=contexts_list, seq_len=24)
-            import warnings
-            with warnings.catch_warnings():
-                warnings.simplefilter("ignore")
-                loss = F.mse_loss(out[0], vt)
+            loss = F.mse_loss(out[0], vt)
         accelerator.backward(loss)
         assert abs(float(loss) - float(loss_b)) <= 1e-5 * abs(float(loss_b))
         worst = 0.0
@@ -199,23 +210,24 @@ def _accelerate_worker(port, q):
             assert e < 2e-3, (n, e)
         opt.step()
         opt.zero_grad()
-        q.put(("ok", worst))
-        import torch.distributed as dist
-        if dist.is_initialized():
-            dist.destroy_process_group()
+        q.put((rank, "ok", worst))
+        dist.destroy_process_group()
     except Exception as e:  # pragma: no cover
         import traceback
-        q.put(("FAIL " + repr(e) + traceback.format_exc()[-1500:], None))
+        q.put((rank, "FAIL " + repr(e) + traceback.format_exc()[-1500:], None))
 
 
 def test_accelerate_prepare_wraps_the_model_and_trains():
     pytest.importorskip("accelerate")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_accelerate_worker, args=(_free_port(), q))
-    p.start()
-    res = q.get(timeout=600)
-    p.join(timeout=120)
-    assert res[0] == "ok", res
-    print(f"[measured] Accelerator(mixed_precision='bf16').prepare -> DDP on a one-rank RCCL group: worst relative "
-          f"gradient difference vs the bare model {res[1]:.2e}")
+    port = _free_port()
+    procs = [ctx.Process(target=_accelerate_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    assert sorted(r[:2] for r in res) == [(0, "ok"), (1, "ok")], res
+    print(f"[measured] Accelerator(mixed_precision='bf16').prepare -> DDP, 2 ranks (gloo, one GPU): worst relative "
+          f"gradient difference vs the mean of the bare models' gradients {max(r[2] for r in res):.2e}")

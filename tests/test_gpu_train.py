@@ -543,3 +543,81 @@ def test_training_forward_equals_inference_and_checkpoint_equals_kept_activation
             worst = max(worst, e)
             assert e < 1e-3, (n, e)
     print(f"[measured] gradients, re-run block vs kept activations (freeze={freeze}): worst relative difference {worst:.2e}")
+
+
+def test_norm_backward_round3_kernels(ops):
+    """omh_layernorm_modulate_bwd2 / omh_rmsnorm_rope_bwd2: against autograd, the fused follow-up (next branch's gated
+    residual backward) against the separate kernel, two column segments in one launch — and bit-repeatable."""
+    torch.manual_seed(11)
+    B, S, d = 3, 37, 256                                   # 37 rows per batch element: ragged last workgroup
+    R = B * S
+    xx = (torch.randn(R, d, device="cuda") * 2 + 0.3).requires_grad_(True)
+    mod = torch.randn(6, d, device="cuda", requires_grad=True)
+    e0 = torch.randn(B, 6, d, device="cuda", requires_grad=True)
+    gy = torch.randn(R, d, device="cuda")
+    dx0 = torch.randn(R, d, device="cuda")
+    e = (mod[None] + e0)
+    y = torch.nn.functional.layer_norm(xx, (d,), eps=1e-6).view(B, S, d) * (1 + e[:, 1:2]) + e[:, 0:1]
+    y.backward(gy.view(B, S, d))
+    ynext = torch.randn(R, d, device="cuda").bfloat16()
+    outs = []
+    for gy_t in (gy, gy.bfloat16()):
+        for rep in range(2):
+            dx = dx0.clone()
+            d_eb = torch.zeros(B, 6, d, device="cuda")
+            dyn = torch.zeros(R, d, device="cuda", dtype=torch.bfloat16)
+            ops.layernorm_modulate_bwd2(xx.detach(), gy_t, dx, R, d, 1e-6, 1.0, ops.ptr(mod.detach(), d),
+                                        ops.ptr(e0.detach(), d), 6 * d, ops.ptr(d_eb, d), ops.ptr(d_eb, 0), 6 * d, S,
+                                        dy_next=dyn, y_next=ynext, gate_const=0.0, gate0=ops.ptr(mod.detach(), 2 * d),
+                                        gate1=ops.ptr(e0.detach(), 2 * d), gate1_stride=6 * d, dgate=ops.ptr(d_eb, 2 * d),
+                                        dgate_stride=6 * d)
+            outs.append((dx, d_eb, dyn))
+        tol = 1e-4 if gy_t.dtype == torch.float32 else 6e-3
+        dx, d_eb, dyn = outs[-1]
+        assert rel_rms(dx - dx0, xx.grad) < tol and rel_rms(d_eb[:, :2], e0.grad[:, :2]) < tol
+        assert torch.equal(outs[-1][0], outs[-2][0]) and torch.equal(outs[-1][1], outs[-2][1])     # bit-repeatable
+        # the fused follow-up == omh_gated_residual_bwd on the finished dx
+        dy_ref = torch.empty(R, d, device="cuda", dtype=torch.bfloat16)
+        dg_ref = torch.zeros(B, 6, d, device="cuda")
+        ops.gated_residual_bwd_raw(ops.ptr(dx), ops.ptr(ynext), ops.ptr(dy_ref), ops.ptr(dg_ref, 2 * d), 6 * d, R, d, 0.0,
+                                   ops.ptr(mod.detach(), 2 * d), ops.ptr(e0.detach(), 2 * d), 6 * d, S)
+        assert torch.equal(dyn, dy_ref) and rel_rms(d_eb[:, 2], dg_ref[:, 2]) < 1e-5
+    # shared parameters (norm3: dstride 0) under per-batch row groups, follow-up without a gate
+    w3 = torch.rand(d, device="cuda") + 0.5
+    xr = xx.detach().clone().requires_grad_(True)
+    wr = w3.clone().requires_grad_(True)
+    br = torch.zeros(d, device="cuda", requires_grad=True)
+    (torch.nn.functional.layer_norm(xr, (d,), wr, br, 1e-6)).backward(gy)
+    dx = dx0.clone()
+    dw, db = torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
+    dyn = torch.zeros(R, d, device="cuda", dtype=torch.bfloat16)
+    ops.layernorm_modulate_bwd2(xx.detach(), gy, dx, R, d, 1e-6, 0.0, ops.ptr(w3), None, 0, ops.ptr(dw), ops.ptr(db), 0, S,
+                                dy_next=dyn, gate_const=1.0)
+    assert rel_rms(dx - dx0, xr.grad) < 1e-4 and rel_rms(dw, wr.grad) < 1e-4 and rel_rms(db, br.grad) < 1e-4
+    assert torch.equal(dyn, dx.bfloat16())
+    # RMSNorm + RoPE backward, q and k segments in one launch == two launches of the typed round-2 kernel
+    from oracle import wan_dit_oracle as O
+    N, D = 2, 128
+    dd = N * D
+    S2 = 9
+    grids = [(1, 3, 3), (1, 2, 4), (1, 1, 5)]
+    ang = O.rope_table(D)
+    cos, sin = torch.cos(ang).float().cuda(), torch.sin(ang).float().cuda()
+    grid = torch.tensor(grids, dtype=torch.int32, device="cuda")
+    wq, wk = torch.rand(dd, device="cuda") + 0.5, torch.rand(dd, device="cuda") + 0.5
+    xq = torch.randn(B * S2, 2 * dd, device="cuda").bfloat16()
+    gq = torch.randn(B * S2, 3 * dd, device="cuda").bfloat16()
+    ref, dws_ref = gq.clone(), []
+    for col, w in ((0, wq), (1, wk)):
+        dw = torch.zeros(dd, device="cuda")
+        ops.rmsnorm_rope_bwd_t_raw(ops.ptr(xq, col * dd), True, 2 * dd, ops.ptr(ref, col * dd), True, 3 * dd,
+                                   ops.ptr(ref, col * dd), 3 * dd, ops.ptr(dw), B * S2, dd, ops.ptr(w), 1e-6, 1,
+                                   ops.ptr(cos), ops.ptr(sin), 1024, D, ops.ptr(grid), S2)
+        dws_ref.append(dw)
+    got = gq.clone()
+    dwq, dwk = torch.zeros(dd, device="cuda"), torch.zeros(dd, device="cuda")
+    ops.rmsnorm_rope_bwd2(ops.ptr(xq), True, 2 * dd, ops.ptr(got), True, 3 * dd, ops.ptr(got), 3 * dd, B * S2, dd, 1e-6, True,
+                          [wq, wk], [dwq, dwk], xq.device, n_seg=2, seg_x=dd, seg_dy=dd, seg_dx=dd, rope_cos=ops.ptr(cos),
+                          rope_sin=ops.ptr(sin), rope_len=1024, head_dim=D, grid=ops.ptr(grid), seq_len=S2)
+    assert torch.equal(got, ref)
+    assert rel_rms(dwq, dws_ref[0]) < 1e-5 and rel_rms(dwk, dws_ref[1]) < 1e-5
