@@ -230,20 +230,22 @@ def single_frame_bench(model, device, iters=20):
     return res
 
 
-def train_step_flops(S=1560, ffn_freeze=True, d=1536, f=8960, L=30, Lc=512):
-    """Algorithmic work of ONE clip's training step (multiply-add = 2; backward = 2 x forward; the reference's
-    per-block checkpoint, model.py:544-548, recomputes each block once).  With the reference's FFN quirk
-    (model.py:317-324: blocks > 10 run their FFN under no_grad) the FFN of blocks 11..L-1 is computed once in the
-    forward and never again: no recompute, no input gradient, no weight gradient."""
+def train_step_flops(S=1560, ffn_freeze=True, checkpoint=True, d=1536, f=8960, L=30, Lc=512):
+    """Algorithmic work of ONE clip's training step (multiply-add = 2; backward = 2 x forward).  ``checkpoint``: the
+    reference's per-block checkpoint (model.use_checkpoint, model.py:544-548) recomputes each block once more in the
+    backward; with the activations kept (model.py:549-553) that pass does not exist and is NOT counted.  With the
+    reference's FFN quirk (model.py:317-324: blocks > 10 run their FFN under no_grad) the FFN of blocks 11..L-1 is
+    computed once in the forward and never again: no recompute, no input gradient, no weight gradient."""
     ffn = 4 * S * d * f
     blk = 8 * S * d * d + 4 * S * S * d + (4 * S * d * d + 4 * Lc * d * d) + 4 * S * Lc * d + ffn
     fwd = dit_forward_flops(S, d=d, f=f, L=L, Lc=Lc)
     rest = fwd - L * blk
     frozen = max(0, L - 11) if ffn_freeze else 0
-    return (L - frozen) * 4 * blk + frozen * (4 * (blk - ffn) + ffn) + 3 * rest
+    passes = 4 if checkpoint else 3                       # forward (+ recompute) + 2 x backward
+    return (L - frozen) * passes * blk + frozen * (passes * (blk - ffn) + ffn) + 3 * rest
 
 
-def train_bench(model, device, world, dist, steps=4, warmup=2, bsz=4, ffn_freeze=True, loss_quirk=True):
+def train_bench(model, device, world, dist, steps=4, warmup=2, bsz=4, ffn_freeze=True, loss_quirk=True, checkpoint=True):
     """BASELINE config 3: the distilled_trainer.py student step on a batch of [16,1,60,104] clips per GPU
     (forward + per-block recompute + backward on the HIP kernels, bucketed RCCL gradient all-reduce
     overlapped with the backward, fused AdamW).  Returns clips/s over all ranks.
@@ -251,13 +253,19 @@ def train_bench(model, device, world, dist, steps=4, warmup=2, bsz=4, ffn_freeze
     ``ffn_freeze`` / ``loss_quirk``: the reference's two bug-compatible behaviours (FFN of blocks > 10 without
     gradient, model.py:317-324; loss on sample 0 broadcast against the batch, distilled_trainer.py:285-289).  With
     the loss quirk only clip 0 carries gradient, so "clips/s" there is the reference's number, not a measure of
-    learning throughput: the un-quirked leg is reported beside it."""
+    learning throughput: the un-quirked leg is reported beside it.
+
+    ``checkpoint``: model.use_checkpoint — True = the reference trainer's default (use_gradient_checkpointing=True,
+    distilled_trainer.py:40,65: every block is re-run in the backward), False = the reference model's other branch
+    (model.py:549-553): activations kept in HBM (0.6 GB per block at 4 clips), no second forward pass.  The work
+    counted for the roofline figure follows the setting (the recompute is only counted where it is executed)."""
     trainer = importlib.import_module(PKG + ".trainer")
     optim = importlib.import_module(PKG + ".optim")
     par = importlib.import_module(PKG + ".parallel")
     model.train().requires_grad_(True)
-    old_freeze = model.reference_ffn_freeze
+    old_freeze, old_ckpt = model.reference_ffn_freeze, model.use_checkpoint
     model.reference_ffn_freeze = bool(ffn_freeze)
+    model.use_checkpoint = bool(checkpoint)
     opt = optim.AdamW(model.parameters(), lr=5e-6, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
     red = par.BucketedGradAllReduce(model.parameters(), bucket_mb=256.0, force=bool(dist and world == 1)) if dist else None
     g = torch.Generator(device=device).manual_seed(7 + int(os.environ.get("RANK", 0)))
@@ -320,16 +328,17 @@ def train_bench(model, device, world, dist, steps=4, warmup=2, bsz=4, ffn_freeze
     if red is not None:
         red.remove()
     # give the weights and flags back as they were found (the optimizer stepped lr = 5e-6 a few times)
-    model.reference_ffn_freeze = old_freeze
+    model.reference_ffn_freeze, model.use_checkpoint = old_freeze, old_ckpt
     model.eval().requires_grad_(False)
     del opt
-    fl = train_step_flops(1560, ffn_freeze)
+    fl = train_step_flops(1560, ffn_freeze, checkpoint)
     fwd = dit_forward_flops(1560)
     reducer_ran = red is not None
     return {"clips_per_s": round(world * bsz * steps / el, 3), "ms_per_step": round(el * 1e3 / steps, 2),
             "clips_per_gpu_step": bsz, "steps": steps, "finite_loss": bool(math.isfinite(float(loss))),
             "launch_mode": mode, "reference_ffn_freeze": bool(ffn_freeze), "reference_loss_quirk": bool(loss_quirk),
-            "work": "fwd + per-block recompute + bwd"
+            "use_checkpoint": bool(checkpoint),
+            "work": ("fwd + per-block recompute + bwd" if checkpoint else "fwd (activations kept in HBM) + bwd")
                     + (" (FFN of blocks > 10 forward-only: the reference's quirk)" if ffn_freeze else " (all parameters trained)")
                     + (f" + bucketed gradient all-reduce over {world} rank(s) [{dist.get_backend()}]" if reducer_ran
                        else " + NO gradient all-reduce (single process, no process group)") + " + fused AdamW",
@@ -343,18 +352,23 @@ def train_bench(model, device, world, dist, steps=4, warmup=2, bsz=4, ffn_freeze
 
 
 def train_legs(model, device, world, dist):
-    """The training legs of the line: B = 4 (primary, comparable across rounds), B = 1 (the reference's default
-    --batch_size) and B = 16 with the reference's quirks, and B = 4 with both quirks off (every clip and every parameter trained).  OMH_TRAIN_BATCH overrides
-    the primary batch size."""
+    """The training legs of the line.  Primary: B = 4 with the reference trainer's settings (quirks on, per-block
+    checkpoint on: comparable across rounds).  Then the same with the activations kept (``kept_activations``: what 288 GB
+    of HBM make the natural setting, at B = 4 and B = 1), B = 1 (the reference's default --batch_size) and B = 16 with the
+    checkpoint, and B = 4 with both quirks off (every clip and every parameter trained).  OMH_TRAIN_BATCH overrides the
+    primary batch size."""
     bsz = int(os.environ.get("OMH_TRAIN_BATCH", "4"))
     out = train_bench(model, device, world, dist, bsz=bsz)
     if os.environ.get("OMH_TRAIN_LEGS", "all") == "primary":      # (tests: the primary leg only)
         return out
     try:
+        out["kept_activations"] = train_bench(model, device, world, dist, bsz=bsz, checkpoint=False)
         if bsz != 1:
             out["batch_1"] = train_bench(model, device, world, dist, bsz=1)
+            out["kept_activations"]["batch_1"] = train_bench(model, device, world, dist, bsz=1, checkpoint=False)
         if bsz != 16:                                           # what 288 GB allow: the GEMMs leave the tile-quantised regime
             out["batch_16"] = train_bench(model, device, world, dist, bsz=16)
+            out["kept_activations"]["batch_16"] = train_bench(model, device, world, dist, bsz=16, checkpoint=False)
         out["no_reference_quirks"] = train_bench(model, device, world, dist, bsz=bsz, ffn_freeze=False, loss_quirk=False)
     except Exception as e:
         out["extra_legs_error"] = repr(e)[:300]

@@ -134,6 +134,11 @@ typedef struct omh_attn_args {
        aligned, contents irrelevant): when the number of 256-query tiles is a multiple of the 256 CUs plus a small
        remainder, the remainder is split over the keys instead of costing a whole extra round.  NULL: no split. */
     void* workspace; int64_t workspace_bytes;
+    /* ABI v5, optional: the output once more in fp32, [B, Lq, H, 128] with o's strides (o_bs, o_rs, in elements),
+       16-byte aligned — the training step keeps it for the backward's delta_i = sum_d dO_id O_id (a bf16 O there
+       leaves a 2^-9 residue in every row sum of dS).  Served by the short-sequence kernel only: a call that sets it
+       does not take the long-sequence kernels. */
+    float* o32;
 } omh_attn_args;
 
 int omh_flash_attn_fwd_d128(const omh_attn_args* args, omh_stream_t stream);
@@ -170,6 +175,11 @@ typedef struct omh_attn_bwd_args {
        out_bf16 != 0: dq / dk / dv are bf16 (strides in bf16 elements, multiples of 4) — the operand type of the
        weight-gradient GEMMs that follow, no cast pass. */
     int32_t q_prescaled, out_bf16;
+    /* o32 != NULL: the forward's fp32 output (omh_attn_args.o32, strides o_bs / o_rs).  Selects the round-3 kernels
+       (csrc/attention_bwd2.hip): delta = rowsum(dO * o32) in the dQ kernel's prologue instead of a first pass over the
+       keys, 64-position tiles staged by LDS-DMA into a double buffer, the transposed operands read from the
+       row-major tiles with ds_read_b64_tr_b16 — qt / dot / kt are not read (may be NULL). */
+    const float* o32;
 } omh_attn_bwd_args;
 
 int omh_flash_attn_bwd_d128(const omh_attn_bwd_args* args, omh_stream_t stream);

@@ -85,7 +85,8 @@ class AttnArgs(C.Structure):
                 ("B", i32), ("H", i32), ("Lq", i32), ("Lk", i32),
                 ("q_bs", i64), ("q_rs", i64), ("k_bs", i64), ("k_rs", i64),
                 ("vt_bs", i64), ("o_bs", i64), ("o_rs", i64),
-                ("ldv", i32), ("scale", f32), ("lse", vp), ("q_prescaled", i32), ("workspace", vp), ("workspace_bytes", i64)]
+                ("ldv", i32), ("scale", f32), ("lse", vp), ("q_prescaled", i32), ("workspace", vp), ("workspace_bytes", i64),
+                ("o32", vp)]
 
 
 class AttnBwdArgs(C.Structure):
@@ -97,7 +98,7 @@ class AttnBwdArgs(C.Structure):
                 ("B", i32), ("H", i32), ("Lq", i32), ("Lk", i32),
                 ("q_bs", i64), ("q_rs", i64), ("k_bs", i64), ("k_rs", i64), ("o_bs", i64), ("o_rs", i64),
                 ("dq_bs", i64), ("dq_rs", i64), ("dk_bs", i64), ("dk_rs", i64), ("qt_bs", i64), ("kt_bs", i64),
-                ("ldq", i32), ("ldk", i32), ("scale", f32), ("q_prescaled", i32), ("out_bf16", i32)]
+                ("ldq", i32), ("ldk", i32), ("scale", f32), ("q_prescaled", i32), ("out_bf16", i32), ("o32", vp)]
 
 
 class LnBwdArgs(C.Structure):

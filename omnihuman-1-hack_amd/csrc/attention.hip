@@ -257,6 +257,16 @@ void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles) {
                 pk.y = pack_bf2(oacc[db][4 * gq + 2] * inv, oacc[db][4 * gq + 3] * inv);
                 *(uint2*)(O + db * 32 + gq * 8 + lh * 4) = pk;
             }
+        if (p.o32) {                                   // the same values before the rounding (training: delta of the backward)
+            float* O32 = p.o32 + (int64_t)b * p.o_bs + (int64_t)q_row * p.o_rs + head * D;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    *(float4*)(O32 + db * 32 + gq * 8 + lh * 4) =
+                        make_float4(oacc[db][4 * gq] * inv, oacc[db][4 * gq + 1] * inv, oacc[db][4 * gq + 2] * inv,
+                                    oacc[db][4 * gq + 3] * inv);
+        }
         if (p.lse && lh == 0) {
             // natural-log LSE of the scaled scores
             const float lse = l_run > 0.f ? (m_run + log2f(l_run)) * 0.6931471805599453f : -INFINITY;
@@ -550,6 +560,25 @@ void flash_attn_fwd_d128_pp_kernel(const omh_attn_args p, const int q_tiles) {
 // attention_w64.hip: 4 waves x 64 query rows, asm-owned register file (long sequences)
 int omh_launch_attn_w64(const omh_attn_args& a, hipStream_t stream);
 
+// Which forward kernel a call takes.  OMH_ATTN_KERNEL = "w64" / "pp" / "base": test / benchmarking override (looked up
+// per call — the tests flip it inside one process; a getenv is ~50 ns against ~3.5 us of launch).
+struct AttnChoice { bool w64, pp; };
+static AttnChoice attn_choice(const omh_attn_args& a) {
+    const char* force = getenv("OMH_ATTN_KERNEL");
+    const int q_tiles2 = (a.Lq + QB2 - 1) / QB2;
+    // long sequences that fill the chip with 256-row workgroups take the 4 x 64 kernel (attention_w64.hip); "pp" keeps
+    // the 8-wave kernel it replaced selectable for A/B timing
+    const bool big = (int64_t)q_tiles2 * a.H * a.B >= 512 && a.Lk >= 1024;
+    // 32-bit buffer offsets inside one (batch, head) slice
+    const bool fits32 = ((int64_t)a.Lq * a.q_rs * 2 < 0x7fffffffLL) && ((int64_t)a.Lk * a.k_rs * 2 < 0x7fffffffLL) &&
+                        ((int64_t)a.Lq * a.o_rs * 2 < 0x7fffffffLL) && ((int64_t)D * a.ldv * 2 < 0x7fffffffLL);
+    AttnChoice c;
+    c.w64 = a.o32 ? false : (force ? (force[0] == 'w' && fits32) : (big && fits32));      // fp32 output: base kernel only
+    c.pp = a.o32 ? false : (force ? (force[0] == 'p') : (big && !c.w64));
+    return c;
+}
+bool omh_attn_takes_w64(const omh_attn_args& a) { return attn_choice(a).w64; }
+
 extern "C" int omh_flash_attn_fwd_d128(const omh_attn_args* args, omh_stream_t stream) {
     if (!args || !args->q || !args->k || !args->vt || !args->o) return OMH_E_BADARG;
     const omh_attn_args& a = *args;
@@ -560,21 +589,14 @@ extern "C" int omh_flash_attn_fwd_d128(const omh_attn_args* args, omh_stream_t s
     if (((uintptr_t)a.q & 15) || ((uintptr_t)a.k & 15) || ((uintptr_t)a.vt & 15) || ((uintptr_t)a.o & 7))
         return OMH_E_ALIGN;
     if (a.ldv < ((a.Lk + KB - 1) / KB) * KB) return OMH_E_SHAPE;
-    // long sequences that fill the chip with 256-row workgroups take the ping-pong kernel
-    const char* force = getenv("OMH_ATTN_KERNEL");                 // "w64" / "pp" / "base": test / benchmarking override
-    const int q_tiles2 = (a.Lq + QB2 - 1) / QB2;
-    const bool big = (int64_t)q_tiles2 * a.H * a.B >= 512 && a.Lk >= 1024;
-    // 32-bit buffer offsets inside one (batch, head) slice
-    const bool fits32 = ((int64_t)a.Lq * a.q_rs * 2 < 0x7fffffffLL) && ((int64_t)a.Lk * a.k_rs * 2 < 0x7fffffffLL) &&
-                        ((int64_t)a.Lq * a.o_rs * 2 < 0x7fffffffLL) && ((int64_t)D * a.ldv * 2 < 0x7fffffffLL);
-    // long sequences that fill the chip with 256-row workgroups: the 4 x 64 kernel (attention_w64.hip); "pp" keeps
-    // the 8-wave kernel it replaced selectable for A/B timing
-    const bool w64 = force ? (force[0] == 'w' && fits32) : (big && fits32);
-    const bool pp = force ? (force[0] == 'p') : (big && !w64);
+    if (a.o32 && (((uintptr_t)a.o32 & 15) || (a.o_rs & 3) || (a.o_bs & 3))) return OMH_E_ALIGN;
+    const AttnChoice ch = attn_choice(a);
+    const bool w64 = ch.w64, pp = ch.pp;
     omh_clear_status();
     if (w64) {
         omh_launch_attn_w64(a, (hipStream_t)stream);
     } else if (pp) {
+        const int q_tiles2 = (a.Lq + QB2 - 1) / QB2;
         hipLaunchKernelGGL(flash_attn_fwd_d128_pp_kernel, dim3(q_tiles2 * a.H * a.B), dim3(512), 0,
                            (hipStream_t)stream, a, q_tiles2);
     } else {

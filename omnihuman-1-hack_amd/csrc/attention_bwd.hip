@@ -388,12 +388,26 @@ void attn_bwd_dq_kernel(const omh_attn_bwd_args p, const int q_blocks) {
 
 }  // namespace
 
+// attention_bwd2.hip: the round-3 kernel pair (needs the forward's fp32 output for delta)
+int omh_launch_attn_bwd2(const omh_attn_bwd_args& a, hipStream_t s);
+
 extern "C" int omh_flash_attn_bwd_d128(const omh_attn_bwd_args* args, omh_stream_t stream) {
     if (!args) return OMH_E_BADARG;
     const omh_attn_bwd_args& a = *args;
-    if (!a.q || !a.k || !a.v || !a.dout || !a.qt || !a.dot || !a.kt || !a.lse || !a.delta || !a.dq || !a.dk ||
-        !a.dv)
-        return OMH_E_BADARG;
+    if (!a.q || !a.k || !a.v || !a.dout || !a.lse || !a.delta || !a.dq || !a.dk || !a.dv) return OMH_E_BADARG;
+    if (a.o32) {
+        if (a.B <= 0 || a.H <= 0 || a.Lq <= 0 || a.Lk <= 0) return OMH_E_BADARG;
+        if ((a.q_rs & 7) || (a.k_rs & 7) || (a.o_rs & 7) || (a.q_bs & 7) || (a.k_bs & 7) || (a.o_bs & 7) || (a.dq_rs & 3) ||
+            (a.dk_rs & 3) || (a.dq_bs & 3) || (a.dk_bs & 3))
+            return OMH_E_ALIGN;
+        if (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.dout | (uintptr_t)a.dq | (uintptr_t)a.dk |
+             (uintptr_t)a.dv) & 15)
+            return OMH_E_ALIGN;
+        omh_clear_status();
+        const int rc = omh_launch_attn_bwd2(a, (hipStream_t)stream);
+        return rc ? rc : omh_launch_status();
+    }
+    if (!a.qt || !a.dot || !a.kt) return OMH_E_BADARG;
     if (a.B <= 0 || a.H <= 0 || a.Lq <= 0 || a.Lk <= 0) return OMH_E_BADARG;
     if ((a.q_rs & 7) || (a.k_rs & 7) || (a.o_rs & 7) || (a.q_bs & 7) || (a.k_bs & 7) || (a.o_bs & 7) || (a.ldq & 7) ||
         (a.ldk & 7) || (a.qt_bs & 7) || (a.kt_bs & 7) || (a.dq_rs & 3) || (a.dk_rs & 3) || (a.dq_bs & 3) || (a.dk_bs & 3))

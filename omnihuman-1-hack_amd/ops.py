@@ -84,9 +84,9 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
 
 
 def flash_attn_raw(q, k, vt, o, k_lens, B, H, Lq, Lk, q_bs, q_rs, k_bs, k_rs, vt_bs, o_bs, o_rs, ldv, scale,
-                   lse=None, q_prescaled=0):
+                   lse=None, q_prescaled=0, o32=None):
     a = AttnArgs(q, k, vt, o, k_lens, B, H, Lq, Lk, q_bs, q_rs, k_bs, k_rs, vt_bs, o_bs, o_rs, ldv, scale, lse,
-                 int(q_prescaled), None, 0)
+                 int(q_prescaled), None, 0, o32)
     need = lib.omh_flash_attn_workspace_bytes(C.byref(a))          # split-KV tail of the long-sequence kernel
     ws = None
     if need > 0:
@@ -115,29 +115,35 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, k_lens: Optio
     return out
 
 
-def flash_attn_bwd(q, k, v, o, dout, lse, k_lens, B, H, Lq, Lk, scale=None, q_prescaled=False, out=None):
-    """Fused attention backward (include/omh.h).  q, o, dout: bf16 [B*Lq, H*128]; k, v: bf16 [B*Lk, H*128]
-    (row stride free); lse fp32 [B, H, Lq] from ``flash_attn_raw(..., lse=)``; k_lens int32 [B] or None.
+def flash_attn_bwd(q, k, v, o, dout, lse, k_lens, B, H, Lq, Lk, scale=None, q_prescaled=False, out=None, o32=None):
+    """Fused attention backward (include/omh.h).  q, dout: bf16 [B*Lq, H*128]; k, v: bf16 [B*Lk, H*128] (row stride
+    free); lse fp32 [B, H, Lq] from ``flash_attn_raw(..., lse=)``; k_lens int32 [B] or None.
     Returns fp32 dq [B*Lq, H*128], dk, dv [B*Lk, H*128] — or, with ``out=(dq, dk, dv)`` bf16 2-D tensors (row stride
     free: e.g. the three column blocks of one [rows, 3*H*128] buffer), writes bf16 gradients there.
-    ``q_prescaled``: q carries scale*log2(e) as in the forward call."""
-    _dev(q, k, v, o, dout, lse, k_lens)
+    ``q_prescaled``: q carries scale*log2(e) as in the forward call.  ``o32``: the forward's fp32 output
+    (``flash_attn_raw(..., o32=)``, fp32 [B*Lq, H*128] contiguous) — selects the round-3 kernels (no transposed copies,
+    delta from dO . o32); without it round 2's kernels run (three transposes + a delta pass over the keys)."""
+    _dev(q, k, v, dout, lse, k_lens, o32)
     d = H * 128
     for t in (q, k, v, dout):
         assert t.dtype == torch.bfloat16 and t.stride(-1) == 1 and t.shape[-1] == d
     assert lse.dtype == torch.float32 and lse.is_contiguous() and lse.numel() == B * H * Lq
     dev = q.device
-    ldq, ldk = (Lq + 63) // 64 * 64, (Lk + 63) // 64 * 64
-    def padded(L, ld):                     # only the pad columns need the zeros (the transpose writes the rest)
-        t = torch.empty(B, d, ld, dtype=torch.bfloat16, device=dev)
-        if ld != L:
-            t[:, :, L:].zero_()
-        return t
-    qt, dot, kt = padded(Lq, ldq), padded(Lq, ldq), padded(Lk, ldk)
     rs = lambda t: t.stride(-2)
-    transpose_bf16_raw(ptr(q), ptr(qt), Lq, d, rs(q), ldq, batch=B, bs_in=Lq * rs(q), bs_out=d * ldq)
-    transpose_bf16_raw(ptr(dout), ptr(dot), Lq, d, rs(dout), ldq, batch=B, bs_in=Lq * rs(dout), bs_out=d * ldq)
-    transpose_bf16_raw(ptr(k), ptr(kt), Lk, d, rs(k), ldk, batch=B, bs_in=Lk * rs(k), bs_out=d * ldk)
+    ldq, ldk = (Lq + 63) // 64 * 64, (Lk + 63) // 64 * 64
+    qt = dot = kt = None
+    if o32 is None:
+        def padded(L, ld):                     # only the pad columns need the zeros (the transpose writes the rest)
+            t = torch.empty(B, d, ld, dtype=torch.bfloat16, device=dev)
+            if ld != L:
+                t[:, :, L:].zero_()
+            return t
+        qt, dot, kt = padded(Lq, ldq), padded(Lq, ldq), padded(Lk, ldk)
+        transpose_bf16_raw(ptr(q), ptr(qt), Lq, d, rs(q), ldq, batch=B, bs_in=Lq * rs(q), bs_out=d * ldq)
+        transpose_bf16_raw(ptr(dout), ptr(dot), Lq, d, rs(dout), ldq, batch=B, bs_in=Lq * rs(dout), bs_out=d * ldq)
+        transpose_bf16_raw(ptr(k), ptr(kt), Lk, d, rs(k), ldk, batch=B, bs_in=Lk * rs(k), bs_out=d * ldk)
+    else:
+        assert o32.dtype == torch.float32 and o32.is_contiguous() and o32.shape[-1] == d and rs(dout) == d
     delta = torch.empty(B, H, Lq, dtype=torch.float32, device=dev)
     if out is None:
         dq = torch.empty(B * Lq, d, dtype=torch.float32, device=dev)
@@ -155,7 +161,7 @@ def flash_attn_bwd(q, k, v, o, dout, lse, k_lens, B, H, Lq, Lk, scale=None, q_pr
                          _p(dq), _p(dk), _p(dv), _p(k_lens), B, H, Lq, Lk,
                          Lq * rs(q), rs(q), Lk * rs(k), rs(k), Lq * rs(dout), rs(dout), Lq * dq.stride(0), dq.stride(0),
                          Lk * dk.stride(0), dk.stride(0), d * ldq, d * ldk, ldq, ldk,
-                         float(scale if scale is not None else 128 ** -0.5), int(q_prescaled), bf)
+                         float(scale if scale is not None else 128 ** -0.5), int(q_prescaled), bf, _p(o32))
     check(lib.omh_flash_attn_bwd_d128(C.byref(a), _stream()), "omh_flash_attn_bwd_d128")
     return dq, dk, dv
 

@@ -166,6 +166,9 @@ class TrainPacks:
 # the end of the block's backward (_wgrad_join); hipGraph capture follows the fork / join.
 # Measured (round 2): 142.7 -> 138.2 ms per step at 4 clips, 428 -> 413 ms at 16.
 _WGRAD_STREAM = os.environ.get("OMH_WGRAD_STREAM", "1") == "1"
+# OMH_ATTN_BWD=v1: round 2's attention-backward kernels (three transposed copies + a delta pass over the keys per
+# call) instead of round 3's (csrc/attention_bwd2.hip, which read the forward's fp32 output) — A/B timing
+_ATTN_BWD2 = os.environ.get("OMH_ATTN_BWD", "v2") != "v1"
 _side = {}
 
 
@@ -345,10 +348,13 @@ def _block_forward(model, blk, idx, st, x0, P, keep):
                  bias_mode=BIAS_M, batch=B, strideA=0, strideB=Sq * d, strideC=d * Sp)
     o = bf(R, d)
     lse_sa = torch.empty(B, N, Sq, dtype=torch.float32, device=dev)
+    f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+    o32_sa = f32(R, d) if _ATTN_BWD2 else None                # the output before its rounding: delta of the backward
     ops.flash_attn_raw(ptr(q), ptr(k), ptr(vt), ptr(o), ptr(fc.seq_lens32), B, N, Sq, Sq, Sq * d, d, Sq * d, d, d * Sp,
-                       Sq * d, d, Sp, D ** -0.5, lse=ptr(lse_sa), q_prescaled=1)
+                       Sq * d, d, Sp, D ** -0.5, lse=ptr(lse_sa), q_prescaled=1,
+                       o32=ptr(o32_sa) if o32_sa is not None else None)
     x1, y1 = resid(x0, o, P["wo"], sa.o.bias.detach(), 2, True)
-    S.update(h1=h1, qk=qk, q=q, k=k, vt=vt, o=o, lse_sa=lse_sa, y1=y1, x1=x1)
+    S.update(h1=h1, qk=qk, q=q, k=k, vt=vt, o=o, lse_sa=lse_sa, y1=y1, x1=x1, o32_sa=o32_sa)
     # ---- cross-attention: x2 = x1 + o(attn(norm3(x1), context))                                     model.py:313
     h3 = bf(R, d)
     if blk.cross_attn_norm:
@@ -380,11 +386,13 @@ def _block_forward(model, blk, idx, st, x0, P, keep):
     kf, kc, vtc, Ltp = ctx_kv(n_img, Lt, P["wkv_c"], ca.k, ca.v, "norm_k", "ca")
     oc = bf(R, d)
     lse_ca = torch.empty(B, N, Sq, dtype=torch.float32, device=dev)
+    o32_ca = f32(R, d) if (_ATTN_BWD2 and not i2v) else None
     # the reference passes the (text + 257) lengths here (model.py:223,537); keys are clipped to the text rows
     ops.flash_attn_raw(ptr(qc), ptr(kc), ptr(vtc), ptr(oc), ptr(fc.ctx_lens32), B, N, Sq, Lt, Sq * d, d, Lt * d, d,
-                       d * Ltp, Sq * d, d, Ltp, D ** -0.5, lse=ptr(lse_ca))
+                       d * Ltp, Sq * d, d, Ltp, D ** -0.5, lse=ptr(lse_ca),
+                       o32=ptr(o32_ca) if o32_ca is not None else None)
     x2, _ = resid(x1, oc, P["wo_c"], ca.o.bias.detach(), None, False)
-    S.update(h3=h3, qcb=qcb, qc=qc, kf=kf, kc=kc, vtc=vtc, oc=oc, lse_ca=lse_ca, x2=x2)
+    S.update(h3=h3, qcb=qcb, qc=qc, kf=kf, kc=kc, vtc=vtc, oc=oc, lse_ca=lse_ca, x2=x2, o32_ca=o32_ca)
     if i2v:                                                  # model.py:189-230: extra attention over the 257 image tokens
         kfi, ki, vti, Lip = ctx_kv(0, n_img, P["wkv_i"], ca.k_img, ca.v_img, "norm_k_img", "ci")
         oi = bf(R, d)
@@ -492,7 +500,7 @@ def _block_backward(model, blk, idx, st, S, dx, P):
     dkv = bf(Rc, 2 * d)                                               # dk | dv of the text keys, one buffer
     if not i2v:
         ops.flash_attn_bwd(qc, kc, vc, oc, doc, S["lse_ca"], fc.ctx_lens32, B, N, Sq, Lt, D ** -0.5,
-                           out=(dqc, dkv[:, :d], dkv[:, d:]))
+                           out=(dqc, dkv[:, :d], dkv[:, d:]), o32=S["o32_ca"])
     else:                                                             # the image-token branch: same q, same dO
         oi, ki = S["oi"], S["ki"]
         _wgrad(dy2, oi, out=g["cross_attn.o.weight"], side=True)
@@ -544,7 +552,7 @@ def _block_backward(model, blk, idx, st, S, dx, P):
     v = ops.transpose_bf16_batched(S["vt"], Sq)                       # [B*S, d]
     dqkv = bf(R, 3 * d)                                               # dq | dk | dv, one buffer
     ops.flash_attn_bwd(q, k, v, o, do, S["lse_sa"], fc.seq_lens32, B, N, Sq, Sq, D ** -0.5, q_prescaled=True,
-                       out=(dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]))
+                       out=(dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]), o32=S["o32_sa"])
     qk = S["qk"]
     rms_bwd(ptr(qk), True, 2 * d, ptr(dqkv), 3 * d, R, [sa._norm_w("norm_q"), sa._norm_w("norm_k")], sa.qk_norm, True,
             ["self_attn.norm_q.weight", "self_attn.norm_k.weight"], sa, n_seg=2, seg_x=d, seg_dy=d)   # q and k: one launch

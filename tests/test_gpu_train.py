@@ -448,6 +448,69 @@ def test_attention_backward_prescaled_q_and_bf16_outputs(ops):
         assert e < 1.2e-2, (nm, e)          # bf16 rounding of the output + the 2^-9 perturbation of q between the two
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,lens", [(2, 2, 200, 136, [136, 77]), (1, 3, 1560, 1560, [1560]), (3, 1, 130, 512, [512, 0, 300]),
+                                            (2, 2, 64, 64, [64, 33]), (1, 1, 257, 70, [70])])
+def test_attention_backward_round3_kernels(ops, B, H, Lq, Lk, lens):
+    """csrc/attention_bwd2.hip (delta from dO . o32, 64-position LDS-DMA tiles, transposed operands gathered with
+    ds_read_b64_tr_b16) against round 2's kernels on the same forward — plain and pre-scaled q, fp32 and bf16 outputs,
+    ragged tiles, a sample without keys, strided column-block outputs — and against autograd through a masked fp32
+    softmax."""
+    torch.manual_seed(B * 1000 + Lq + Lk)
+    D = 128
+    d = H * D
+    scale = D ** -0.5
+    qf32 = torch.randn(B * Lq, d, device="cuda")
+    k = torch.randn(B * Lk, d, device="cuda").bfloat16()
+    v = torch.randn(B * Lk, d, device="cuda").bfloat16()
+    do = torch.randn(B * Lq, d, device="cuda").bfloat16()
+    klens = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    Lp = (Lk + 63) // 64 * 64
+    vt = torch.zeros(B, d, Lp, device="cuda", dtype=torch.bfloat16)
+    ops.transpose_bf16_raw(ops.ptr(v), ops.ptr(vt), Lk, d, d, Lp, batch=B, bs_in=Lk * d, bs_out=d * Lp)
+    for pres in (False, True):
+        q = (qf32 * (scale * 1.4426950408889634)).bfloat16() if pres else qf32.bfloat16()
+        o = torch.empty(B * Lq, d, device="cuda", dtype=torch.bfloat16)
+        o32 = torch.empty(B * Lq, d, device="cuda")
+        lse = torch.empty(B, H, Lq, device="cuda")
+        ops.flash_attn_raw(ops.ptr(q), ops.ptr(k), ops.ptr(vt), ops.ptr(o), ops.ptr(klens), B, H, Lq, Lk, Lq * d, d, Lk * d, d,
+                           d * Lp, Lq * d, d, Lp, scale, lse=ops.ptr(lse), q_prescaled=int(pres), o32=ops.ptr(o32))
+        assert torch.equal(o32.bfloat16(), o)                          # the same values before the rounding
+        dq1, dk1, dv1 = ops.flash_attn_bwd(q, k, v, o, do, lse, klens, B, H, Lq, Lk, scale, q_prescaled=pres)
+        dq2, dk2, dv2 = ops.flash_attn_bwd(q, k, v, o, do, lse, klens, B, H, Lq, Lk, scale, q_prescaled=pres, o32=o32)
+        for a_, b_, nm in ((dq2, dq1, "dq"), (dk2, dk1, "dk"), (dv2, dv1, "dv")):
+            assert torch.isfinite(a_).all()
+            e = rel_rms(a_, b_)
+            assert e < 3e-3, (nm, pres, e)     # same P / dP / dS products; delta from bf16-P vs fp32-P sums differs by ~1e-4
+        # bf16 outputs into column blocks of shared buffers
+        buf = torch.full((B * Lq, 3 * d), 3.0, device="cuda", dtype=torch.bfloat16)
+        kvb = torch.full((B * Lk, 2 * d), 3.0, device="cuda", dtype=torch.bfloat16)
+        ops.flash_attn_bwd(q, k, v, o, do, lse, klens, B, H, Lq, Lk, scale, q_prescaled=pres, o32=o32,
+                           out=(buf[:, d:2 * d], kvb[:, :d], kvb[:, d:]))
+        assert torch.equal(buf[:, d:2 * d], dq2.bfloat16()) and torch.equal(kvb[:, :d], dk2.bfloat16())
+        assert torch.equal(kvb[:, d:], dv2.bfloat16()) and bool((buf[:, :d] == 3.0).all()) and bool((buf[:, 2 * d:] == 3.0).all())
+        again = ops.flash_attn_bwd(q, k, v, o, do, lse, klens, B, H, Lq, Lk, scale, q_prescaled=pres, o32=o32)
+        assert all(torch.equal(x, y) for x, y in zip(again, (dq2, dk2, dv2)))          # bit-repeatable
+    # autograd through a masked fp32 softmax on the bf16 operands (plain q)
+    q = qf32.bfloat16()
+    qa = q.float().view(B, Lq, H, D).transpose(1, 2).requires_grad_(True)
+    ka = k.float().view(B, Lk, H, D).transpose(1, 2).requires_grad_(True)
+    va = v.float().view(B, Lk, H, D).transpose(1, 2).requires_grad_(True)
+    sc_ = (qa @ ka.transpose(-1, -2)) * scale
+    mask = torch.arange(Lk, device="cuda")[None, None, None, :] >= klens.long()[:, None, None, None]
+    pa = torch.softmax(sc_.masked_fill(mask, float("-inf")), -1)
+    pa = torch.nan_to_num(pa, nan=0.0)                              # a sample without keys
+    (pa @ va).backward(do.float().view(B, Lq, H, D).transpose(1, 2))
+    o = torch.empty(B * Lq, d, device="cuda", dtype=torch.bfloat16)
+    o32 = torch.empty(B * Lq, d, device="cuda")
+    lse = torch.empty(B, H, Lq, device="cuda")
+    ops.flash_attn_raw(ops.ptr(q), ops.ptr(k), ops.ptr(vt), ops.ptr(o), ops.ptr(klens), B, H, Lq, Lk, Lq * d, d, Lk * d, d,
+                       d * Lp, Lq * d, d, Lp, scale, lse=ops.ptr(lse), o32=ops.ptr(o32))
+    dq2, dk2, dv2 = ops.flash_attn_bwd(q, k, v, o, do, lse, klens, B, H, Lq, Lk, scale, o32=o32)
+    for got, want, nm in ((dq2, qa.grad, "dq"), (dk2, ka.grad, "dk"), (dv2, va.grad, "dv")):
+        w = want.transpose(1, 2).reshape(got.shape)
+        assert rel_rms(got, w) < 8e-3, (nm, rel_rms(got, w))
+
+
 def test_rmsnorm_rope_bwd_typed_inputs(ops):
     """omh_rmsnorm_rope_bwd_t: bf16 / fp32 x and dy in every combination, in place on dy, strided column blocks."""
     from oracle import wan_dit_oracle as O

@@ -71,6 +71,9 @@ def main():
     dkv = torch.empty(B * 512, 2 * d, device=dev, dtype=torch.bfloat16)
     klc = torch.full((B,), 512, dtype=torch.int32, device=dev)
     res["attn_bwd_cross_us"] = timeit(lambda: ops.flash_attn_bwd(q, kc, vc, None, do, lse, klc, B, H, S, 512, out=(dqkv[:, :d], dkv[:, :d], dkv[:, d:])), 10)
+    o32 = torch.randn(R, d, device=dev)
+    res["attn_bwd2_self_us"] = timeit(lambda: ops.flash_attn_bwd(q, k, v, None, do, lse, kl, B, H, S, S, out=out, o32=o32), 10)
+    res["attn_bwd2_cross_us"] = timeit(lambda: ops.flash_attn_bwd(q, kc, vc, None, do, lse, klc, B, H, S, 512, out=(dqkv[:, :d], dkv[:, :d], dkv[:, d:]), o32=o32), 10)
     res["attn_bwd_self_gflop"] = 10 * S * S * 128 * H * B / 1e9
     print(json.dumps(res, indent=1))
 
