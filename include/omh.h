@@ -104,6 +104,18 @@ typedef struct omh_gemm_tn_args {
 
 int omh_gemm_bf16_tn(const omh_gemm_tn_args* args, omh_stream_t stream);
 
+/* Up to OMH_TN_GROUP_MAX such products in ONE launch: all the weight gradients of one block's backward (q|k|v, o,
+ * cross q, cross k|v, cross o, FFN 1, FFN 2).  Each alone is 144 ... 840 tiles of 128 x 128 over a contraction of 6 240
+ * rows and leaves most of the chip idle or needs a split K with fp32 atomics; together they fill it, every tile runs
+ * its whole K range, and the result is bit-repeatable.  first_tile / total_tiles are scratch filled by the library. */
+#define OMH_TN_GROUP_MAX 12
+typedef struct omh_gemm_tn_group {
+    int32_t n;
+    omh_gemm_tn_args problem[OMH_TN_GROUP_MAX];
+    int32_t first_tile[OMH_TN_GROUP_MAX]; int32_t total_tiles;
+} omh_gemm_tn_group;
+int omh_gemm_bf16_tn_grouped(const omh_gemm_tn_group* group, omh_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Flash attention forward, head_dim 128, bf16, non-causal, key-length mask.
  * Replaces flash_attn.flash_attn_varlen_func as called from

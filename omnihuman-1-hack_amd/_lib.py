@@ -79,6 +79,13 @@ class GemmTnArgs(C.Structure):
                 ("lda", i32), ("ldb", i32), ("ldc", i32), ("accumulate", i32)]
 
 
+TN_GROUP_MAX = 12
+
+
+class GemmTnGroup(C.Structure):
+    _fields_ = [("n", i32), ("problem", GemmTnArgs * TN_GROUP_MAX), ("first_tile", i32 * TN_GROUP_MAX), ("total_tiles", i32)]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [("q", vp), ("k", vp), ("vt", vp), ("o", vp),
                 ("k_lens", vp),
@@ -137,6 +144,7 @@ _SIGS = {
     "omh_build_arch": (C.c_char_p, []),
     "omh_gemm_bf16": (i32, [C.POINTER(GemmArgs), vp]),
     "omh_gemm_bf16_tn": (i32, [C.POINTER(GemmTnArgs), vp]),
+    "omh_gemm_bf16_tn_grouped": (i32, [C.POINTER(GemmTnGroup), vp]),
     "omh_flash_attn_fwd_d128": (i32, [C.POINTER(AttnArgs), vp]),
     "omh_flash_attn_workspace_bytes": (i64, [C.POINTER(AttnArgs)]),
     "omh_flash_attn_bwd_d128": (i32, [C.POINTER(AttnBwdArgs), vp]),

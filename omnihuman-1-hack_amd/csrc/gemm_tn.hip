@@ -27,9 +27,10 @@ typedef __attribute__((address_space(3))) void* lds_vptr;
 
 struct TnGeom { int tiles_m, tiles_n, splits, ksteps_per_split; };
 
-template <bool ACCUM, int WM, int WN, int MT, int NT>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1)
-void gemm_bf16_tn_kernel(const omh_gemm_tn_args p, const TnGeom g) {
+// the body of one output tile (tm, tn) over k-steps [kt0, kt_end); out_mode: 0 store, 1 read-modify-write, 2 atomicAdd
+template <int WM, int WN, int MT, int NT>
+__device__ __forceinline__ void tn_tile(const omh_gemm_tn_args& p, const int tm, const int tn, const int kt0,
+                                        const int kt_end, const int out_mode) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     constexpr int SLA = BM / 8, SLB = BN / 8;                        // 16-byte slots per tile row
@@ -41,9 +42,6 @@ void gemm_bf16_tn_kernel(const omh_gemm_tn_args p, const TnGeom g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int wid = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
-    int tm, tn;
-    tile_of(wid, g.tiles_m, g.tiles_n, tm, tn, 4);                   // 4 m-tiles x all n-tiles per XCD-resident group
     const int m0 = tm * BM, n0 = tn * BN;
 
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
@@ -118,9 +116,7 @@ void gemm_bf16_tn_kernel(const omh_gemm_tn_args p, const TnGeom g) {
     // latency-bound workgroup on half the CUs): blockIdx.y takes k-steps [kt0, nk) and adds its partial sums with
     // fp32 atomics (C zeroed by the launcher).  The summation order then varies from run to run: last-bit
     // differences in dW, like the bias / gain gradients of dit_backward.hip.
-    const int nk_all = (p.K + BK - 1) / BK;
-    const int kt0 = blockIdx.y * g.ksteps_per_split;
-    const int nk = min(nk_all, kt0 + g.ksteps_per_split);
+    const int nk = kt_end;
     if (kt0 >= nk) return;
     TN_DMA(kt0, 0)
     if (kt0 + 1 < nk) TN_DMA(kt0 + 1, 1)
@@ -182,11 +178,44 @@ void gemm_bf16_tn_kernel(const omh_gemm_tn_args p, const TnGeom g) {
                 const int m = m0 + (wm * MT + im) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
                 if (m >= p.M) continue;
                 float* dst = Cb + (int64_t)m * p.ldc + n;
-                if (g.splits > 1) atomicAdd(dst, acc[im][in][r]);
-                else if (ACCUM) *dst += acc[im][in][r];
+                if (out_mode == 2) atomicAdd(dst, acc[im][in][r]);
+                else if (out_mode == 1) *dst += acc[im][in][r];
                 else *dst = acc[im][in][r];
             }
         }
+#undef TN_DMA
+#undef TN_FRAG
+#undef TN_FRAGS
+#undef TN_MFMAS
+#undef TN_INTERLEAVE
+}
+
+template <bool ACCUM, int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1)
+void gemm_bf16_tn_kernel(const omh_gemm_tn_args p, const TnGeom g) {
+    const int wid = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+    int tm, tn;
+    tile_of(wid, g.tiles_m, g.tiles_n, tm, tn, 4);                   // 4 m-tiles x all n-tiles per XCD-resident group
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int kt0 = blockIdx.y * g.ksteps_per_split;
+    tn_tile<WM, WN, MT, NT>(p, tm, tn, kt0, min(nk_all, kt0 + g.ksteps_per_split), g.splits > 1 ? 2 : (ACCUM ? 1 : 0));
+}
+
+// Several independent products in ONE launch (the weight gradients of a block's backward): 128 x 128 tiles, every
+// tile its whole K range — no split K, hence no atomics (bit-repeatable) — the tiles of all problems together fill the
+// chip where each problem alone (144 tiles of 1536 x 1536 on 512 slots) did not.
+__global__ __launch_bounds__(256, 2)
+void gemm_bf16_tn_grouped_kernel(const omh_gemm_tn_group g) {
+    const int wid = xcd_remap(blockIdx.x, g.total_tiles);
+    int e = 0;
+#pragma unroll 1
+    while (e + 1 < g.n && wid >= g.first_tile[e + 1]) ++e;
+    const omh_gemm_tn_args& p = g.problem[e];
+    const int local = wid - g.first_tile[e];
+    const int tiles_m = (p.M + 127) / 128, tiles_n = (p.N + 127) / 128;
+    int tm, tn;
+    tile_of(local, tiles_m, tiles_n, tm, tn, 4);
+    tn_tile<2, 2, 2, 2>(p, tm, tn, 0, (p.K + BK - 1) / BK, p.accumulate ? 1 : 0);
 }
 
 template <bool ACCUM, int WM, int WN, int MT, int NT>
@@ -237,4 +266,30 @@ extern "C" int omh_gemm_bf16_tn(const omh_gemm_tn_args* args, omh_stream_t strea
     const bool big = force ? force[0] == 'b' : big_tiles >= 128;
     if (big) return a.accumulate ? launch_tn<true, 2, 4, 4, 2>(a, s) : launch_tn<false, 2, 4, 4, 2>(a, s);
     return a.accumulate ? launch_tn<true, 2, 2, 2, 2>(a, s) : launch_tn<false, 2, 2, 2, 2>(a, s);
+}
+
+extern "C" int omh_gemm_bf16_tn_grouped(const omh_gemm_tn_group* group, omh_stream_t stream) {
+    if (!group || group->n <= 0 || group->n > OMH_TN_GROUP_MAX) return OMH_E_BADARG;
+    omh_gemm_tn_group g = *group;
+    int64_t total = 0;
+    for (int i = 0; i < g.n; ++i) {
+        const omh_gemm_tn_args& a = g.problem[i];
+        if (!a.A || !a.B || !a.C || a.M <= 0 || a.N <= 0 || a.K <= 0) return OMH_E_BADARG;
+        if ((a.M & 7) || (a.N & 7) || (a.lda & 7) || (a.ldb & 7) || a.lda < a.M || a.ldb < a.N || a.ldc < a.N) return OMH_E_ALIGN;
+        if (((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15) || ((uintptr_t)a.C & 3)) return OMH_E_ALIGN;
+        if (((int64_t)a.K + 64) * a.lda * 2 >= 0x7fffffffLL || ((int64_t)a.K + 64) * a.ldb * 2 >= 0x7fffffffLL) return OMH_E_SHAPE;
+        g.first_tile[i] = (int32_t)total;
+        total += (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    }
+    if (total > 0x7fffffffLL) return OMH_E_SHAPE;
+    g.total_tiles = (int32_t)total;
+    constexpr int LDS = 2 * BK * (128 + 128) * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_tn_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    omh_clear_status();
+    hipLaunchKernelGGL(gemm_bf16_tn_grouped_kernel, dim3((unsigned)total), dim3(256), LDS, (hipStream_t)stream, g);
+    return omh_launch_status();
 }

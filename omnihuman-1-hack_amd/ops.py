@@ -83,6 +83,23 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     return out
 
 
+def gemm_tn_grouped(problems):
+    """``problems``: list of (a [K, M] bf16, b [K, N] bf16, out fp32 [M, N], accumulate) — ``out (+)= a^T @ b`` for all of
+    them in one launch per OMH_TN_GROUP_MAX entries (include/omh.h): no split K, no atomics."""
+    for k0 in range(0, len(problems), _lib.TN_GROUP_MAX):
+        chunk = problems[k0:k0 + _lib.TN_GROUP_MAX]
+        g = _lib.GemmTnGroup()
+        g.n = len(chunk)
+        for i, (a, b, out, acc) in enumerate(chunk):
+            _dev(a, b, out)
+            assert a.dtype == b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0]
+            assert a.stride(1) == 1 and b.stride(1) == 1 and out.dtype == torch.float32 and out.stride(1) == 1
+            assert out.shape == (a.shape[1], b.shape[1])
+            g.problem[i] = _lib.GemmTnArgs(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.shape[1], b.shape[1], a.shape[0],
+                                           a.stride(0), b.stride(0), out.stride(0), int(acc))
+        check(lib.omh_gemm_bf16_tn_grouped(C.byref(g), _stream()), "omh_gemm_bf16_tn_grouped")
+
+
 def flash_attn_raw(q, k, vt, o, k_lens, B, H, Lq, Lk, q_bs, q_rs, k_bs, k_rs, vt_bs, o_bs, o_rs, ldv, scale,
                    lse=None, q_prescaled=0, o32=None):
     a = AttnArgs(q, k, vt, o, k_lens, B, H, Lq, Lk, q_bs, q_rs, k_bs, k_rs, vt_bs, o_bs, o_rs, ldv, scale, lse,

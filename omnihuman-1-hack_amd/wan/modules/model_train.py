@@ -184,24 +184,52 @@ def _wgrad_join(dev):
         torch.cuda.current_stream(dev).wait_stream(_side[dev])
 
 
-def _wgrad(dy, x, out=None, side=False):
+def _wgrad(dy, x, out=None):
     """dW[N, K] (+)= dy[R, N]^T @ x[R, K]  (fp32) on dy and x as they are (row-major bf16, row stride free): the
-    k-major GEMM of csrc/gemm_tn.hip — no transposed copies.  With ``out`` the product is ADDED to it (a weight used
-    twice in the block).  ``side``: on the second stream (the caller joins with _wgrad_join before the result is used
-    or handed to autograd)."""
-    if side and _WGRAD_STREAM:
-        dev = dy.device
-        main, sd = torch.cuda.current_stream(dev), _side_stream(dev)
+    k-major GEMM of csrc/gemm_tn.hip — no transposed copies.  With ``out`` the product is ADDED to it."""
+    return ops.gemm_tn(dy, x, out=out, accumulate=out is not None)
+
+
+class _WgradGroup:
+    """The weight-gradient products of a block's backward, collected and launched a few at a time as ONE grouped GEMM
+    (omh_gemm_bf16_tn_grouped: every tile its whole K range, no split K, no atomics) on the second stream.  Each
+    product alone is tile-poor (1536 x 1536 over 6 240 rows = 144 tiles on 512 slots, 310 TFLOP/s with a 3-way split
+    K and atomics); two or three of them together fill the chip."""
+
+    def __init__(self, dev):
+        self.dev, self.items = dev, []
+
+    def add(self, dy, x, out=None):
         acc = out is not None
         if out is None:
-            out = torch.empty(dy.shape[1], x.shape[1], dtype=torch.float32, device=dev)
-        sd.wait_stream(main)
-        with torch.cuda.stream(sd):
-            ops.gemm_tn(dy, x, out=out, accumulate=acc)
-        for t in (dy, x, out):
-            t.record_stream(sd)
+            out = torch.empty(dy.shape[1], x.shape[1], dtype=torch.float32, device=self.dev)
+        if dy.shape[1] * x.shape[1] >= 256 * 256 * 128:          # >= 128 tiles of 256 x 256 (the FFN weights): fills the
+            self._run([(dy, x, out, acc)], single=True)          # chip alone, on the 8-wave 256 x 256 kernel, at once
+        else:
+            self.items.append((dy, x, out, acc))
         return out
-    return ops.gemm_tn(dy, x, out=out, accumulate=out is not None)
+
+    def _run(self, items, single=False):
+        def go():
+            if single:
+                dy, x, out, acc = items[0]
+                ops.gemm_tn(dy, x, out=out, accumulate=acc)
+            else:
+                ops.gemm_tn_grouped(items)
+        if not _WGRAD_STREAM:
+            return go()
+        main, sd = torch.cuda.current_stream(self.dev), _side_stream(self.dev)
+        sd.wait_stream(main)                                  # the operands were produced on the main stream
+        with torch.cuda.stream(sd):
+            go()
+        for dy, x, out, _ in items:
+            for tt in (dy, x, out):
+                tt.record_stream(sd)
+
+    def launch(self):
+        if self.items:
+            items, self.items = self.items, []
+            self._run(items)
 
 
 class _ZeroArena:
@@ -436,6 +464,7 @@ def _block_backward(model, blk, idx, st, S, dx, P):
     Lt = Lc - n_img
     bf = lambda *shape: torch.empty(*shape, dtype=torch.bfloat16, device=dev)
     arena = _ZeroArena(B * six + 2 * six + 20 * d + 2 * f + 4096, dev)
+    wg = _WgradGroup(dev)
     d_eb = arena.take(B, 6, d)                                        # grads of e = modulation + e0
     g = {}
 
@@ -480,10 +509,11 @@ def _block_backward(model, blk, idx, st, S, dx, P):
     dy3 = resid_bwd(S["y3"], 5)
     if not frozen_ffn:
         u, u_pre, h2 = S["u"], S["u_pre"], S["h2"]
-        g["ffn.2.weight"], g["ffn.2.bias"] = _wgrad(dy3, u, side=True), _bgrad(dy3, arena)
+        g["ffn.2.weight"], g["ffn.2.bias"] = wg.add(dy3, u), _bgrad(dy3, arena)
         du_pre = bf(R, f)                                            # (dy3 W2) * gelu'(u_pre): GELU' in the GEMM's epilogue
         ops.gemm_raw(ptr(dy3), ptr(P["w2T"]), ptr(du_pre), R, f, d, d, d, f, EPI_GELU_BWD, aux=ptr(u_pre), ldaux=f)
-        g["ffn.0.weight"], g["ffn.0.bias"] = _wgrad(du_pre, h2, side=True), _bgrad(du_pre, arena)
+        g["ffn.0.weight"], g["ffn.0.bias"] = wg.add(du_pre, h2), _bgrad(du_pre, arena)
+        wg.launch()                                                  # FFN weight gradients: second stream, from here on
         dh2 = _dgrad(du_pre, P["w1T"])
         # ---- cross-attention branch: x2 = x1 + y2  (its dy2 = bf16(dx) comes out of the same pass)
         dy2 = ln_bwd(S["x2"], dh2, 3, 4, nxt=(None, None))
@@ -491,7 +521,7 @@ def _block_backward(model, blk, idx, st, S, dx, P):
     else:
         dy2 = resid_bwd(None, None)
     oc, qc, kc = S["oc"], S["qc"], S["kc"]
-    g["cross_attn.o.weight"], g["cross_attn.o.bias"] = _wgrad(dy2, oc, side=True), _bgrad(dy2, arena)
+    g["cross_attn.o.weight"], g["cross_attn.o.bias"] = wg.add(dy2, oc), _bgrad(dy2, arena)
     doc = _dgrad(dy2, P["wo_cT"], epilogue=EPI_BF16)
     Rc = B * Lt
     ctx2 = fc.ctx.view(B * Lc, d) if not i2v else fc.ctx[:, n_img:].contiguous().view(Rc, d)
@@ -503,7 +533,8 @@ def _block_backward(model, blk, idx, st, S, dx, P):
                            out=(dqc, dkv[:, :d], dkv[:, d:]), o32=S["o32_ca"])
     else:                                                             # the image-token branch: same q, same dO
         oi, ki = S["oi"], S["ki"]
-        _wgrad(dy2, oi, out=g["cross_attn.o.weight"], side=True)
+        wg.launch()                                                  # (the second product ADDS to the first one's result)
+        wg.add(dy2, oi, out=g["cross_attn.o.weight"])
         dq32, dk32, dv32 = ops.flash_attn_bwd(qc, kc, vc, oc, doc, S["lse_ca"], fc.ctx_lens32, B, N, Sq, Lt, D ** -0.5)
         vi = ops.transpose_bf16_batched(S["vti"], n_img)
         dqi, dki, dvi = ops.flash_attn_bwd(qc, ki, vi, oi, doc, S["lse_ci"], None, B, N, Sq, n_img, D ** -0.5)
@@ -518,18 +549,19 @@ def _block_backward(model, blk, idx, st, S, dx, P):
         ops.cast_bf16_strided(dvi, dkvi[:, d:])
         rms_bwd(ptr(S["kfi"]), False, d, ptr(dkvi), 2 * d, Ri, [ca._norm_w("norm_k_img")], ca.qk_norm, False,
                 ["cross_attn.norm_k_img.weight"], ca)
-        dwi, dbi = _wgrad(dkvi, ctxi, side=True), _bgrad(dkvi, arena)
+        dwi, dbi = wg.add(dkvi, ctxi), _bgrad(dkvi, arena)
         g["cross_attn.k_img.weight"], g["cross_attn.v_img.weight"] = dwi[:d], dwi[d:]
         g["cross_attn.k_img.bias"], g["cross_attn.v_img.bias"] = dbi[:d], dbi[d:]
         _dgrad_ctx(dkvi, P["wkv_iT"], st.d_ctx, 0, n_img)
         del dq32, dk32, dv32, dqi, dki, dvi
     rms_bwd(ptr(S["qcb"]), True, d, ptr(dqc), d, R, [ca._norm_w("norm_q")], ca.qk_norm, False, ["cross_attn.norm_q.weight"], ca)
     h3 = S["h3"]
-    g["cross_attn.q.weight"], g["cross_attn.q.bias"] = _wgrad(dqc, h3, side=True), _bgrad(dqc, arena)
+    g["cross_attn.q.weight"], g["cross_attn.q.bias"] = wg.add(dqc, h3), _bgrad(dqc, arena)
     dh3 = _dgrad(dqc, P["wq_cT"])
     rms_bwd(ptr(S["kf"]), False, d, ptr(dkv), 2 * d, Rc, [ca._norm_w("norm_k")], ca.qk_norm, False,
             ["cross_attn.norm_k.weight"], ca)
-    dwkv, dbkv = _wgrad(dkv, ctx2, side=True), _bgrad(dkv, arena)      # [2d, d]: k | v in one GEMM
+    dwkv, dbkv = wg.add(dkv, ctx2), _bgrad(dkv, arena)                 # [2d, d]: k | v in one GEMM
+    wg.launch()                                                      # the cross-attention's weight gradients
     g["cross_attn.k.weight"], g["cross_attn.v.weight"] = dwkv[:d], dwkv[d:]
     g["cross_attn.k.bias"], g["cross_attn.v.bias"] = dbkv[:d], dbkv[d:]
     _dgrad_ctx(dkv, P["wkv_cT"], st.d_ctx, n_img, Lt)
@@ -547,7 +579,7 @@ def _block_backward(model, blk, idx, st, S, dx, P):
         dy1 = resid_bwd(S["y1"], 2)
     del dy2, doc, dh3
     o, q, k, h1 = S["o"], S["q"], S["k"], S["h1"]
-    g["self_attn.o.weight"], g["self_attn.o.bias"] = _wgrad(dy1, o, side=True), _bgrad(dy1, arena)
+    g["self_attn.o.weight"], g["self_attn.o.bias"] = wg.add(dy1, o), _bgrad(dy1, arena)
     do = _dgrad(dy1, P["woT"], epilogue=EPI_BF16)
     v = ops.transpose_bf16_batched(S["vt"], Sq)                       # [B*S, d]
     dqkv = bf(R, 3 * d)                                               # dq | dk | dv, one buffer
@@ -556,7 +588,8 @@ def _block_backward(model, blk, idx, st, S, dx, P):
     qk = S["qk"]
     rms_bwd(ptr(qk), True, 2 * d, ptr(dqkv), 3 * d, R, [sa._norm_w("norm_q"), sa._norm_w("norm_k")], sa.qk_norm, True,
             ["self_attn.norm_q.weight", "self_attn.norm_k.weight"], sa, n_seg=2, seg_x=d, seg_dy=d)   # q and k: one launch
-    dwqkv, dbqkv = _wgrad(dqkv, h1, side=True), _bgrad(dqkv, arena)     # [3d, d]: q | k | v in one GEMM
+    dwqkv, dbqkv = wg.add(dqkv, h1), _bgrad(dqkv, arena)               # [3d, d]: q | k | v in one GEMM
+    wg.launch()                                                      # the self-attention's weight gradients
     for j, nm in enumerate(("q", "k", "v")):
         g[f"self_attn.{nm}.weight"], g[f"self_attn.{nm}.bias"] = dwqkv[j * d:(j + 1) * d], dbqkv[j * d:(j + 1) * d]
     dh1 = _dgrad(dqkv, P["wqkvT"])                                      # K = 3d: dq Wq + dk Wk + dv Wv
@@ -566,6 +599,7 @@ def _block_backward(model, blk, idx, st, S, dx, P):
     ops.colsum_accum(d_eb.view(B, six), dmod)
     g["modulation"] = dmod
     ops.colsum_accum(d_eb.view(1, B * six), st.d_e0.view(B * six))      # d_e0 += d_eb
+    wg.launch()
     arena.flush()
     g["__dx__"] = dx
     return g

@@ -684,3 +684,31 @@ def test_norm_backward_round3_kernels(ops):
                           rope_sin=ops.ptr(sin), rope_len=1024, head_dim=D, grid=ops.ptr(grid), seq_len=S2)
     assert torch.equal(got, ref)
     assert rel_rms(dwq, dws_ref[0]) < 1e-5 and rel_rms(dwk, dws_ref[1]) < 1e-5
+
+
+def test_gemm_tn_grouped(ops):
+    """omh_gemm_bf16_tn_grouped: several weight-gradient products in one launch == the single-problem kernel on each
+    (ragged tiles, strided operands out of fused buffers, accumulation), and bit-repeatable (no split K, no atomics)."""
+    g = torch.Generator(device="cuda").manual_seed(8)
+    R = 1000
+    dyf = (torch.randn(R, 3 * 256, device="cuda", generator=g) * 0.3).bfloat16()       # dq | dk | dv style buffer
+    xs = [(torch.randn(R, n, device="cuda", generator=g) * 0.3).bfloat16() for n in (256, 136, 520)]
+    probs = [(dyf, xs[0], None), (dyf[:, 256:512], xs[1], None), (dyf[:, :136], xs[2], None), (dyf[:, 512:], xs[0], "acc")]
+    want, items = [], []
+    for dy, x, acc in probs:
+        base = torch.randn(dy.shape[1], x.shape[1], device="cuda", generator=g) if acc else None
+        ref = ops.gemm_tn(dy, x, out=base.clone() if acc else None, accumulate=bool(acc))
+        want.append(ref)
+        out = base.clone() if acc else torch.full((dy.shape[1], x.shape[1]), 7.0, device="cuda")
+        items.append((dy, x, out, bool(acc)))
+    ops.gemm_tn_grouped(items)
+    for (dy, x, out, acc), ref in zip(items, want):
+        assert rel_rms(out, ref) < 2e-6, (tuple(out.shape), rel_rms(out, ref))
+        assert rel_rms(out, (dy.float().t() @ x.float()) + (0 if not acc else ref - dy.float().t() @ x.float())) < 1e-5
+    again = [(dy, x, torch.zeros_like(out), False) for dy, x, out, acc in items[:3]]
+    ops.gemm_tn_grouped(again)
+    for (_, _, o2, _), (_, _, o1, _) in zip(again, items[:3]):
+        assert torch.equal(o2, o1)
+    many = [(dyf[:, :64], xs[0][:, :64], torch.zeros(64, 64, device="cuda"), False) for _ in range(15)]   # > one group
+    ops.gemm_tn_grouped(many)
+    assert all(torch.equal(m_[2], many[0][2]) for m_ in many)
