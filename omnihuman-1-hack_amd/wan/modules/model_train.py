@@ -312,10 +312,12 @@ def _vt_buffer(model, key, B, d, Lp, L, dev, keep):
 
 
 # ----------------------------------------------------------------------------- block forward (training)
-def _block_forward(model, blk, idx, st, x0, P, keep):
+def _block_forward(model, blk, idx, st, x0, P, keep, need=True):
     """The inference block (model.py:279-330 on libomh.so, WanAttentionBlock.forward of this package) with the
     residual stream out of place and the backward's extra tensors emitted by the producing epilogues.  x0 fp32
-    [B, S, d] is left untouched.  Returns (x3, S) — S holds what ``_block_backward`` reads."""
+    [B, S, d] is left untouched.  Returns (x3, S) — S holds what ``_block_backward`` reads.  ``need = False`` (the
+    forward pass under use_checkpoint: the block is run again in the backward): the extras — branch outputs, FFN
+    pre-activation, log-sum-exp, fp32 attention output — are not produced; the values of x3 do not depend on it."""
     fc = st.fc
     B, Sq, d = x0.shape
     R = B * Sq
@@ -346,7 +348,7 @@ def _block_forward(model, blk, idx, st, x0, P, keep):
     def resid(xin, a, w, b, gate_i, want_y, xout=None):
         """x_out = x_in + (a w^T + b) * gate  (+ y = bf16(a w^T + b) when the gate gets a gradient)."""
         xo = torch.empty_like(xin) if xout is None else xout
-        y = bf(R, d) if want_y else None
+        y = bf(R, d) if (want_y and need) else None
         M, K = a.shape
         kw = dict(c_in=ptr(xin) if xo.data_ptr() != xin.data_ptr() else None, aux=ptr(y) if y is not None else None, ldaux=d)
         if gate_i is None:
@@ -375,11 +377,11 @@ def _block_forward(model, blk, idx, st, x0, P, keep):
     ops.gemm_raw(ptr(wqkv, 2 * d * d), ptr(h1), ptr(vt), d, Sq, d, d, d, Sp, EPI_BF16, bias=ptr(bqkv, 2 * d),
                  bias_mode=BIAS_M, batch=B, strideA=0, strideB=Sq * d, strideC=d * Sp)
     o = bf(R, d)
-    lse_sa = torch.empty(B, N, Sq, dtype=torch.float32, device=dev)
     f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
-    o32_sa = f32(R, d) if _ATTN_BWD2 else None                # the output before its rounding: delta of the backward
+    lse_sa = f32(B, N, Sq) if need else None
+    o32_sa = f32(R, d) if (_ATTN_BWD2 and need) else None     # the output before its rounding: delta of the backward
     ops.flash_attn_raw(ptr(q), ptr(k), ptr(vt), ptr(o), ptr(fc.seq_lens32), B, N, Sq, Sq, Sq * d, d, Sq * d, d, d * Sp,
-                       Sq * d, d, Sp, D ** -0.5, lse=ptr(lse_sa), q_prescaled=1,
+                       Sq * d, d, Sp, D ** -0.5, lse=ptr(lse_sa) if need else None, q_prescaled=1,
                        o32=ptr(o32_sa) if o32_sa is not None else None)
     x1, y1 = resid(x0, o, P["wo"], sa.o.bias.detach(), 2, True)
     S.update(h1=h1, qk=qk, q=q, k=k, vt=vt, o=o, lse_sa=lse_sa, y1=y1, x1=x1, o32_sa=o32_sa)
@@ -413,26 +415,26 @@ def _block_forward(model, blk, idx, st, x0, P, keep):
 
     kf, kc, vtc, Ltp = ctx_kv(n_img, Lt, P["wkv_c"], ca.k, ca.v, "norm_k", "ca")
     oc = bf(R, d)
-    lse_ca = torch.empty(B, N, Sq, dtype=torch.float32, device=dev)
-    o32_ca = f32(R, d) if (_ATTN_BWD2 and not i2v) else None
+    lse_ca = f32(B, N, Sq) if need else None
+    o32_ca = f32(R, d) if (_ATTN_BWD2 and need and not i2v) else None
     # the reference passes the (text + 257) lengths here (model.py:223,537); keys are clipped to the text rows
     ops.flash_attn_raw(ptr(qc), ptr(kc), ptr(vtc), ptr(oc), ptr(fc.ctx_lens32), B, N, Sq, Lt, Sq * d, d, Lt * d, d,
-                       d * Ltp, Sq * d, d, Ltp, D ** -0.5, lse=ptr(lse_ca),
+                       d * Ltp, Sq * d, d, Ltp, D ** -0.5, lse=ptr(lse_ca) if need else None,
                        o32=ptr(o32_ca) if o32_ca is not None else None)
     x2, _ = resid(x1, oc, P["wo_c"], ca.o.bias.detach(), None, False)
     S.update(h3=h3, qcb=qcb, qc=qc, kf=kf, kc=kc, vtc=vtc, oc=oc, lse_ca=lse_ca, x2=x2, o32_ca=o32_ca)
     if i2v:                                                  # model.py:189-230: extra attention over the 257 image tokens
         kfi, ki, vti, Lip = ctx_kv(0, n_img, P["wkv_i"], ca.k_img, ca.v_img, "norm_k_img", "ci")
         oi = bf(R, d)
-        lse_ci = torch.empty(B, N, Sq, dtype=torch.float32, device=dev)
+        lse_ci = f32(B, N, Sq) if need else None
         ops.flash_attn_raw(ptr(qc), ptr(ki), ptr(vti), ptr(oi), None, B, N, Sq, n_img, Sq * d, d, n_img * d, d, d * Lip,
-                           Sq * d, d, Lip, D ** -0.5, lse=ptr(lse_ci))
+                           Sq * d, d, Lip, D ** -0.5, lse=ptr(lse_ci) if need else None)
         resid(x2, oi, P["wo_c"], None, None, False, xout=x2)          # x2 += o_img Wo^T   (in place)
         S.update(kfi=kfi, ki=ki, vti=vti, oi=oi, lse_ci=lse_ci)
     # ---- FFN: x3 = x2 + (W2 gelu(W1 (LN(x2)(1+e4)+e3) + b1) + b2) * e5                               model.py:314-328
     h2 = ln_mod(x2, 3, 4)
     u = bf(R, f)
-    u_pre = None if frozen_ffn else bf(R, f)
+    u_pre = None if (frozen_ffn or not need) else bf(R, f)
     ops.gemm_raw(ptr(h2), ptr(P["w1"]), ptr(u), R, f, d, d, d, f, EPI_GELU_BF16, bias=ptr(blk.ffn[0].bias.detach()),
                  bias_mode=BIAS_N, aux=ptr(u_pre) if u_pre is not None else None, ldaux=f)
     x3, y3 = resid(x2, u, P["w2"], blk.ffn[2].bias.detach(), 5, True)
@@ -625,7 +627,7 @@ class _BlockFn(torch.autograd.Function):
             x0 = x.detach()
             if not (x0.dtype == torch.float32 and x0.is_contiguous()):
                 x0 = x0.float().contiguous()
-            out, S = _block_forward(model, blk, idx, st, x0, st.packs[idx], keep)
+            out, S = _block_forward(model, blk, idx, st, x0, st.packs[idx], keep, need=keep)
         ctx.model, ctx.st, ctx.idx = model, st, idx
         ctx.kept = S if keep else None
         ctx.save_for_backward(x0)
