@@ -59,8 +59,9 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
     static_assert(!BKM || (BK * SLB / THREADS == 4 && BM * 8 / THREADS == 4), "k-major B: 4 chunks per thread");
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int CA = BM * 8 / THREADS, CB = BN * 8 / THREADS;     // 16-byte chunks per thread and stage
-    static_assert(CA == CB && (CA == 4 || CA == 2), "staging code assumes 2 or 4 chunks per operand per thread");
-    constexpr int NCH = CA;
+    static_assert(CA * THREADS == BM * 8 && CB * THREADS == BN * 8 && CA >= 2 && CA <= 4 && CB >= 2 && CB <= 4,
+                  "staging code assumes 2..4 whole chunks per operand per thread");
+    constexpr int NCH = CA > CB ? CA : CB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -142,7 +143,8 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
         unsigned char* xa_ = smem + (BUF) * STAGE_BYTES;                                       \
         unsigned char* xb_ = xa_ + A_BYTES;                                                    \
         _Pragma("unroll") for (int j_ = 0; j_ < NCH; ++j_) {                                   \
-            GEMM_DMA1(rsrc_a, voff_a, j_, xa_)                                                 \
+            if (j_ < CA) GEMM_DMA1(rsrc_a, voff_a, j_, xa_)                                    \
+            if (j_ >= CB) continue;                                                            \
             if (BKM) {                                                                         \
                 const uint32_t ob_ = (k0_ + krow_b[j_] < p.K) ? voff_b[j_] + (uint32_t)(KT_) * kstep_b : 0x80000000u; \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(xb_ + wave_lds + j_ * THREADS * 16), 16, \
@@ -197,7 +199,7 @@ void gemm_bf16_nt_kernel(const omh_gemm_args p, const GemmGeom g) {
     // outstanding proves stage kt+1 has landed).  Every shipped configuration uses 2: a deeper ring measured no
     // faster on any of them (the 64x64 tile is L2->LDS-bandwidth bound at ~13 TB/s aggregate, not latency bound,
     // and 64 KiB of LDS per workgroup halves the resident workgroups — DESIGN.md section 4.4).
-    constexpr int PER_STAGE = 2 * NCH;                           // DMA instructions per wave and stage
+    constexpr int PER_STAGE = CA + CB;                           // DMA instructions per wave and stage
 #pragma unroll
     for (int st = 0; st < STAGES; ++st)
         if (st < nk) GEMM_DMA(st, st)
@@ -447,6 +449,7 @@ int launch(const omh_gemm_args& a, hipStream_t s) {
     const int64_t mid_tiles = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
     const char* force = getenv("OMH_GEMM_TILE");               // "big" / "small" / "tiny": test / benchmarking override
     if (force) {
+        if (force[0] == 'm' && !BKM) return launch_cfg<EPI, 2, 4, 3, 2, 2, false>(a, s);      // "mid192"
         if (force[0] == 'b') return launch_cfg<EPI, 2, 4, 4, 2, 2, BKM>(a, s);
         if (force[0] == 't' && !BKM) return launch_cfg<EPI, 2, 2, 1, 1, 2>(a, s);
         return launch_cfg<EPI, 2, 2, 2, 2, 2, BKM>(a, s);
@@ -458,6 +461,14 @@ int launch(const omh_gemm_args& a, hipStream_t s) {
         return big_tiles >= 256 ? launch_cfg<EPI, 2, 4, 4, 2, 2, BKM>(a, s) : launch_cfg<EPI, 2, 2, 2, 2, 2, BKM>(a, s);
     float cost_big, cost_small;
     tile_costs(a, cost_big, cost_small);
+    // 192 x 256 tiles (8 waves, wave tile 96 x 64; round 3): a tile costs 3/4 of a 256 x 256 one, so when the big tiles
+    // leave a round mostly empty (M = 6 240, N = 1 536: 150 tiles on 256 CUs) 198 of these take one round of 0.75
+    if (!BKM) {
+        const int64_t mid192 = (int64_t)((a.M + 191) / 192) * ((a.N + 255) / 256) * a.batch;
+        const float k = (float)a.K * (1.0f / 1536.0f);
+        const float cost_192 = round_cost(mid192, 256, 192, 8.0f + 21.0f * k, 8.0f + 24.5f * k);
+        if (cost_192 < fminf(cost_big, cost_small)) return launch_cfg<EPI, 2, 4, 3, 2, 2, false>(a, s);
+    }
     if (cost_big <= cost_small) return launch_cfg<EPI, 2, 4, 4, 2, 2, BKM>(a, s);
     return launch_cfg<EPI, 2, 2, 2, 2, 2, BKM>(a, s);
 }

@@ -563,7 +563,6 @@ def _block_backward(model, blk, idx, st, S, dx, P):
     rms_bwd(ptr(S["kf"]), False, d, ptr(dkv), 2 * d, Rc, [ca._norm_w("norm_k")], ca.qk_norm, False,
             ["cross_attn.norm_k.weight"], ca)
     dwkv, dbkv = wg.add(dkv, ctx2), _bgrad(dkv, arena)                 # [2d, d]: k | v in one GEMM
-    wg.launch()                                                      # the cross-attention's weight gradients
     g["cross_attn.k.weight"], g["cross_attn.v.weight"] = dwkv[:d], dwkv[d:]
     g["cross_attn.k.bias"], g["cross_attn.v.bias"] = dbkv[:d], dbkv[d:]
     _dgrad_ctx(dkv, P["wkv_cT"], st.d_ctx, n_img, Lt)
@@ -582,6 +581,9 @@ def _block_backward(model, blk, idx, st, S, dx, P):
     del dy2, doc, dh3
     o, q, k, h1 = S["o"], S["q"], S["k"], S["h1"]
     g["self_attn.o.weight"], g["self_attn.o.bias"] = wg.add(dy1, o), _bgrad(dy1, arena)
+    # the cross-attention's weight gradients + the self-attention's o: 3 x 144 full-K tiles + 288 short ones = about one
+    # round of the 512 resident 128 x 128 tiles (with q|k|v's 432 tiles in the same launch it would be 2.2 rounds = 3)
+    wg.launch()
     do = _dgrad(dy1, P["woT"], epilogue=EPI_BF16)
     v = ops.transpose_bf16_batched(S["vt"], Sq)                       # [B*S, d]
     dqkv = bf(R, 3 * d)                                               # dq | dk | dv, one buffer

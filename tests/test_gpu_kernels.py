@@ -16,7 +16,7 @@ def _bf(x):
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 72), (1560, 1536, 1536), (257, 64, 1536),
                                    (64, 8960, 256), (1000, 1536, 8960)])
-@pytest.mark.parametrize("tile", ["big", "small", "tiny"])
+@pytest.mark.parametrize("tile", ["big", "mid192", "small", "tiny"])
 def test_gemm_bf16_f32_bias(ops, M, N, K, tile, monkeypatch):
     monkeypatch.setenv("OMH_GEMM_TILE", tile)          # all three tile configurations on every (ragged) shape
     torch.manual_seed(M * 7 + N)
@@ -44,7 +44,7 @@ def test_gemm_asymmetric_layout(ops):
     assert torch.equal(out, ref)
 
 
-@pytest.mark.parametrize("tile", ["big", "small", "tiny"])
+@pytest.mark.parametrize("tile", ["big", "mid192", "small", "tiny"])
 def test_gemm_resid_gate_and_batch(ops, tile, monkeypatch):
     monkeypatch.setenv("OMH_GEMM_TILE", tile)
     B, S, d, K = 2, 200, 256, 320

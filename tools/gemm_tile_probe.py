@@ -1,48 +1,53 @@
-"""Which tile configuration (256x256 'big', 128x128 'small', 64x64 'tiny') is fastest per GEMM shape of the
-S=1560 regimes (1 and 4 clips, forward / dgrad / wgrad shapes)?  Prints us per launch for each and what the
-library's own dispatch picks.  GPU box only."""
-import importlib, json, math, os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""Tile configurations of omh_gemm_bf16 on the shapes of the training step and the single-frame forward (GPU box):
+    python tools/gemm_tile_probe.py
+For each shape: us per call with the dispatcher's own choice and with every forced configuration."""
+import importlib, json, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 ops = importlib.import_module("omnihuman-1-hack_amd.ops")
 
 
-def t(M, N, K, epi, reps=30):
-    a = torch.randn(M, K, device="cuda").bfloat16()
-    w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).bfloat16()
-    odt = torch.float32 if epi == ops.EPI_F32 else torch.bfloat16
-    out = torch.empty(M, N, dtype=odt, device="cuda")
+def timeit(fn, n=30):
     for _ in range(3):
-        ops.gemm(a, w, out=out, epilogue=epi)
+        fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(reps):
-        ops.gemm(a, w, out=out, epilogue=epi)
+    for _ in range(n):
+        fn()
     e.record()
     torch.cuda.synchronize()
-    return round(s.elapsed_time(e) / reps * 1e3, 1)
+    return s.elapsed_time(e) * 1e3 / n
 
 
-shapes = []
-for M in (1560, 3120, 6240, 12480):
-    for N, K in ((1536, 1536), (3072, 1536), (8960, 1536), (1536, 8960)):
-        shapes.append((M, N, K))
-for R in (1560, 6240):                       # wgrad: [N_out, K_in] over R rows
-    for M, N in ((1536, 1536), (3072, 1536), (8960, 1536), (1536, 8960)):
-        shapes.append((M, N, (R + 7) // 8 * 8))
-shapes += [(512, 1536, 1536), (2048, 1536, 1536), (1536, 512, 1536), (1536, 2048, 1536)]
-res = {}
-for M, N, K in shapes:
-    row = {}
-    for cfg in ("big", "small", "tiny", None):
-        if cfg is None:
-            os.environ.pop("OMH_GEMM_TILE", None)
-        else:
-            os.environ["OMH_GEMM_TILE"] = cfg
-        row[cfg or "auto"] = t(M, N, K, ops.EPI_BF16)
+shapes = [(6240, 1536, 1536, ops.EPI_BF16), (6240, 1536, 1536, ops.EPI_RESID), (6240, 1536, 4608, ops.EPI_F32),
+          (6240, 1536, 8960, ops.EPI_RESID), (6240, 3072, 1536, ops.EPI_BF16), (6240, 8960, 1536, ops.EPI_GELU_BF16),
+          (6240, 8960, 1536, ops.EPI_BF16), (1560, 1536, 1536, ops.EPI_BF16), (1560, 1536, 8960, ops.EPI_RESID),
+          (3120, 1536, 1536, ops.EPI_BF16), (3120, 8960, 1536, ops.EPI_GELU_BF16), (3120, 1536, 8960, ops.EPI_RESID),
+          (24960, 1536, 1536, ops.EPI_BF16), (24960, 1536, 8960, ops.EPI_RESID), (32760, 1536, 1536, ops.EPI_RESID)]
+res = []
+for M, N, K, epi in shapes:
+    a = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()
+    w = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+    b = torch.randn(N, device="cuda")
+    out = torch.zeros(M, N, device="cuda", dtype=torch.float32 if epi in (ops.EPI_F32, ops.EPI_RESID) else torch.bfloat16)
+    kw = dict(gate_const=1.0) if epi == ops.EPI_RESID else {}
+    fn = lambda: ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(out), M, N, K, K, K, N, epi, bias=ops.ptr(b), bias_mode=ops.BIAS_N, **kw)
+    row = {"M": M, "N": N, "K": K, "epi": epi}
     os.environ.pop("OMH_GEMM_TILE", None)
-    best = min(("big", "small", "tiny"), key=lambda c: row[c])
-    row["best"] = best
-    row["auto_loss_pct"] = round(100 * (row["auto"] / row[best] - 1), 1)
-    res[f"{M}x{N}x{K}"] = row
-    print(f"{M}x{N}x{K}", row, flush=True)
+    os.environ.pop("OMH_GEMM_KERNEL", None)
+    row["auto_us"] = round(timeit(fn), 1)
+    for t in ("big", "mid192", "small", "tiny"):
+        os.environ["OMH_GEMM_TILE"] = t
+        row[t + "_us"] = round(timeit(fn), 1)
+    os.environ.pop("OMH_GEMM_TILE", None)
+    os.environ["OMH_GEMM_KERNEL"] = "w64"
+    try:
+        row["w64_us"] = round(timeit(fn), 1)
+    except Exception as e:
+        row["w64_us"] = None
+    os.environ.pop("OMH_GEMM_KERNEL", None)
+    row["auto_tflops"] = round(2 * M * N * K / row["auto_us"] / 1e6, 0)
+    res.append(row)
+    print(json.dumps(row), flush=True)
