@@ -159,6 +159,48 @@ def vae_cpu_baseline(device):
             "parity_rel_rms_5_frames_240x416": parity}
 
 
+def encoders_bench(device):
+    """The prompt-side encoders at full depth: umT5-XXL (24 layers x 4096, bf16 parameters as
+    T5EncoderModel's default, t5.py:465-528) on 512-token prompts and the CLIP ViT-H/14 vision tower (31 of 32 blocks,
+    clip.py:468-542) on one image — random init (no checkpoints in the image), ms per prompt / per image.  They run
+    once per sample, outside the denoising loop."""
+    t5 = importlib.import_module(PKG + ".wan.modules.t5")
+    clip = importlib.import_module(PKG + ".wan.modules.clip")
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, 256384, (2, 512), generator=g)
+    mask = torch.ones(2, 512, dtype=torch.long)
+    mask[0, 120:] = 0
+    mask[1, 40:] = 0
+    enc = t5.T5EncoderModel(512, dtype=torch.bfloat16, device=device, tokenizer=lambda texts: (ids, mask))
+    with torch.no_grad():
+        for blk in enc.model.blocks:                   # T5 does not scale its scores: q is trained small (t5.py:36-39)
+            blk.attn.q.weight.mul_(0.05)
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3 / n, out
+    ms_t5, ctx = timed(lambda: enc(["a", "b"], device), 3)
+    res = {"umt5_xxl": {"ms_per_prompt": round(ms_t5 / 2, 2), "layers": enc.model.num_layers, "tokens": 512,
+                        "parameters": sum(p.numel() for p in enc.model.parameters()), "weights": "random-init bf16",
+                        "finite": bool(all(torch.isfinite(c).all() for c in ctx))}}
+    del enc, ctx
+    torch.cuda.empty_cache()
+    cm = clip.CLIPModel(device=device)
+    vid = torch.rand(3, 1, 480, 832, generator=g) * 2 - 1
+    ms_v, out = timed(lambda: cm.visual([vid.to(device)]), 3)
+    res["clip_vit_h"] = {"ms_per_image": round(ms_v, 2), "blocks_evaluated": cm.model.num_layers - 1,
+                         "parameters": sum(p.numel() for p in cm.model.parameters()), "weights": "random-init",
+                         "finite": bool(torch.isfinite(out).all())}
+    del cm
+    torch.cuda.empty_cache()
+    return res
+
+
 def single_frame_bench(model, device, iters=20):
     """BASELINE config 1 on the GPU: the CFG teacher pair of generate.py:205-229 — two DiT forwards on one
     [16,1,60,104] latent (S = 1560, t = 999) + v = u + 7.5 (c - u) — as eager launches and as hipGraph replays."""
@@ -415,6 +457,7 @@ def main():
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-single-frame", action="store_true")
+    ap.add_argument("--no-encoders", action="store_true")
     ap.add_argument("--cfg", choices=["batched", "two", "split"], default="two",
                     help="split: ranks (2i, 2i+1) share ONE clip, one CFG branch each + one all-gather per step "
                          "(parallel.CFGPairSplit, SURVEY.md 8e; needs an even --gpus; value = clips in flight x steps/s). "
@@ -622,6 +665,13 @@ def main():
         except Exception as e:
             single = {"forwards_per_s": None, "error": repr(e)[:300]}
 
+    encoders = None
+    if not args.no_encoders and rank == 0:
+        try:
+            encoders = encoders_bench(device)
+        except Exception as e:
+            encoders = {"error": repr(e)[:300]}
+
     # before the training leg: that one updates the weights the full-size parity check compares
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -666,7 +716,8 @@ def main():
                     "mfma_roofline_frac": round(fwd_per_gpu_step * fwd_flops / (ms_per_step * 1e-3) / 1e12
                                                 / PEAK_BF16_TFLOPS, 4),
                     "kernels": secondary},
-            "single_frame": single, "vae": vae, "train": train, "roofline": roofline, "cpu_baseline": cpu,
+            "single_frame": single, "vae": vae, "encoders": encoders, "train": train, "roofline": roofline,
+            "cpu_baseline": cpu,
         }
         emit(json.dumps(out))
     else:

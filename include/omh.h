@@ -478,6 +478,9 @@ int omh_ema_update(float* ema, const float* p, int64_t n, float decay, omh_strea
 /* nn.Embedding lookup (t5.py:306): out[r][:] = table[ids[r]][:], fp32; ids int64 on the device, clamped to the table. */
 int omh_gather_rows_f32(const float* table, const int64_t* ids, float* out, int64_t rows, int32_t dim, int64_t vocab,
                         omh_stream_t stream);
+/* The same from a bf16 table (the umT5 checkpoint is bf16: the embedding is never widened to fp32 as a whole). */
+int omh_gather_rows_bf16(const void* table_bf16, const int64_t* ids, float* out, int64_t rows, int32_t dim, int64_t vocab,
+                         omh_stream_t stream);
 /* T5LayerNorm (t5.py:55-69): y = weight * x * rsqrt(mean(x^2) + eps); either result pointer may be NULL. */
 int omh_rmsnorm_f32(const float* x, const float* weight, float eps, float* y_f32, void* y_bf16, int64_t rows,
                     int32_t dim, omh_stream_t stream);

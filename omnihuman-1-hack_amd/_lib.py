@@ -190,6 +190,7 @@ _SIGS = {
     "omh_ema_update": (i32, [vp, vp, i64, f32, vp]),
     "omh_pack_weights_multi": (i32, [vp, i32, i64, vp]),
     "omh_gather_rows_f32": (i32, [vp, vp, vp, i64, i32, i64, vp]),
+    "omh_gather_rows_bf16": (i32, [vp, vp, vp, i64, i32, i64, vp]),
     "omh_rmsnorm_f32": (i32, [vp, vp, f32, vp, vp, i64, i32, vp]),
     "omh_layernorm_f32": (i32, [vp, vp, vp, f32, vp, i64, i32, vp]),
     "omh_softmax_bias_rows": (i32, [vp, i64, vp, i64, i32, i32, f32, vp, vp, i32, vp]),

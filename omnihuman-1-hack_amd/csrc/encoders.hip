@@ -19,6 +19,23 @@ void gather_rows_kernel(const float* __restrict__ table, const int64_t* __restri
     for (int c = threadIdx.x & 63; c < (dim >> 2); c += 64) dst[c] = src[c];
 }
 
+// the same from a bf16 table (umt5-xxl ships as bf16: models_t5_umt5-xxl-enc-bf16.pth, text2video.py:64-70)
+__global__ __launch_bounds__(256)
+void gather_rows_bf16_kernel(const uint16_t* __restrict__ table, const int64_t* __restrict__ ids, float* __restrict__ out,
+                             int64_t rows, int dim, int64_t vocab) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    int64_t id = ids[r];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const uint2* src = (const uint2*)(table + id * dim);
+    float4* dst = (float4*)(out + r * dim);
+    for (int c = threadIdx.x & 63; c < (dim >> 2); c += 64) {
+        const uint2 u = src[c];
+        dst[c] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                             __uint_as_float(u.y & 0xffff0000u));
+    }
+}
+
 // T5LayerNorm (t5.py:55-69): y = w * x * rsqrt(mean(x^2) + eps); fp32 and / or bf16 result
 __global__ __launch_bounds__(256)
 void rmsnorm_f32_kernel(const float* __restrict__ x, const float* __restrict__ w, float eps, float* __restrict__ yf,
@@ -148,6 +165,16 @@ extern "C" int omh_gather_rows_f32(const float* table, const int64_t* ids, float
     omh_clear_status();
     hipLaunchKernelGGL(gather_rows_kernel, dim3(rows4(rows)), dim3(256), 0, (hipStream_t)stream, table, ids, out, rows,
                        dim, vocab);
+    return omh_launch_status();
+}
+
+extern "C" int omh_gather_rows_bf16(const void* table_bf16, const int64_t* ids, float* out, int64_t rows, int32_t dim,
+                                    int64_t vocab, omh_stream_t stream) {
+    if (!table_bf16 || !ids || !out || rows <= 0 || dim <= 0 || vocab <= 0) return OMH_E_BADARG;
+    if ((dim & 3) || ((uintptr_t)table_bf16 & 7) || ((uintptr_t)out & 15)) return OMH_E_ALIGN;
+    omh_clear_status();
+    hipLaunchKernelGGL(gather_rows_bf16_kernel, dim3(rows4(rows)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)table_bf16, ids, out, rows, dim, vocab);
     return omh_launch_status();
 }
 

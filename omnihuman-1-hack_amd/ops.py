@@ -589,13 +589,17 @@ def ema_update(ema, p, decay):
 
 # ----------------------------------------------------------------------------- prompt-side encoders (t5.py / clip.py)
 def gather_rows(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
-    """nn.Embedding lookup: table fp32 [V, dim], ids int64 [...] -> fp32 [..., dim]."""
+    """nn.Embedding lookup: table fp32 or bf16 [V, dim], ids int64 [...] -> fp32 [..., dim].  ids outside [0, V) raise
+    IndexError as nn.Embedding does (one host read-back of a flag: the encoders run once per prompt)."""
     _dev(table, ids)
-    assert table.dtype == torch.float32 and table.is_contiguous() and ids.dtype == torch.int64
+    assert table.dtype in (torch.float32, torch.bfloat16) and table.is_contiguous() and ids.dtype == torch.int64
     idc = ids.contiguous()
+    if idc.numel() and bool(((idc < 0) | (idc >= table.shape[0])).any()):
+        raise IndexError(f"token id outside [0, {table.shape[0]})")
     out = torch.empty(*ids.shape, table.shape[1], dtype=torch.float32, device=table.device)
-    check(lib.omh_gather_rows_f32(_p(table), _p(idc), _p(out), idc.numel(), table.shape[1], table.shape[0], _stream()),
-          "omh_gather_rows_f32")
+    fn, name = (lib.omh_gather_rows_f32, "omh_gather_rows_f32") if table.dtype == torch.float32 else \
+        (lib.omh_gather_rows_bf16, "omh_gather_rows_bf16")
+    check(fn(_p(table), _p(idc), _p(out), idc.numel(), table.shape[1], table.shape[0], _stream()), name)
     return out
 
 

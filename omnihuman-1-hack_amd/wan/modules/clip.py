@@ -96,33 +96,44 @@ class VisionTransformer(nn.Module):
         t = ops.vit_embed(tok, self.cls_embedding.detach().float().reshape(d).contiguous(),
                           self.pos_embedding.detach().float().reshape(n + 1, d).contiguous())
         t = ops.layernorm_f32(t, self.pre_norm.weight.detach().float(), self.pre_norm.bias.detach().float(), self.norm_eps)
-        L = n + 1
-        Lp = _round_up(L, 8)
-        blocks = list(self.transformer)[:-1] if use_31_block else list(self.transformer)
+        hi = self.num_layers - 1 if use_31_block else self.num_layers
         for b in range(B):
-            xb = t[b]                                                  # fp32 [L, d] view, updated in place
-            for li, blk in enumerate(blocks):
-                h = ops.layernorm_modulate(xb, self.norm_eps, 0.0, mul0=blk.norm1.weight.detach().float(),
-                                           add0=blk.norm1.bias.detach().float())
-                wqkv, bqkv = self._lin(blk.attn.to_qkv, (li, "qkv"))
-                qk = ops.gemm(h, wqkv[:2 * d], bias=bqkv[:2 * d].contiguous())     # [L, 2d]: q | k (view(b,s,3,n,d), clip.py:78)
-                q, k = qk[:, :d].contiguous(), qk[:, d:].contiguous()
-                vt = torch.zeros(d, Lp, dtype=torch.bfloat16, device=dev)
-                ops.gemm_raw(ptr(wqkv, 2 * d * d), ptr(h), ptr(vt), d, L, d, d, d, Lp, EPI_BF16,
-                             bias=ptr(bqkv, 2 * d), bias_mode=ops.BIAS_M)
-                o = encoder_attention(q, k, vt, H, Dh, L, Dh ** -0.5)
-                wp, bp = self._lin(blk.attn.proj, (li, "proj"))
-                ops.gemm_raw(ptr(o), ptr(wp), ptr(xb), L, d, d, d, d, d, EPI_RESID, bias=ptr(bp), bias_mode=ops.BIAS_N,
-                             gate_const=1.0)
-                h = ops.layernorm_modulate(xb, self.norm_eps, 0.0, mul0=blk.norm2.weight.detach().float(),
-                                           add0=blk.norm2.bias.detach().float())
-                w1, b1 = self._lin(blk.mlp[0], (li, "fc1"))
-                w2, b2 = self._lin(blk.mlp[2], (li, "fc2"))
-                u = ops.gemm(h, w1, bias=b1, epilogue=EPI_GELU_ERF)
-                m = w1.shape[0]
-                ops.gemm_raw(ptr(u), ptr(w2), ptr(xb), L, d, m, m, m, d, EPI_RESID, bias=ptr(b2), bias_mode=ops.BIAS_N,
-                             gate_const=1.0)
+            self.run_layers(t[b], 0, hi)                               # fp32 [L, d] view, updated in place
         return t
+
+    @torch.no_grad()
+    def run_layers(self, xb: torch.Tensor, lo: int = 0, hi: Optional[int] = None) -> torch.Tensor:
+        """Blocks [lo, hi) of clip.py:130-157 (pre-norm attention + erf-GELU MLP) IN PLACE on one sample's fp32 stream
+        [1 + patches, dim]."""
+        dev = xb.device
+        L, d = xb.shape
+        H = self.num_heads
+        Dh = d // H
+        Lp = _round_up(L, 8)
+        blocks = list(self.transformer)
+        for li in range(lo, len(blocks) if hi is None else hi):
+            blk = blocks[li]
+            h = ops.layernorm_modulate(xb, self.norm_eps, 0.0, mul0=blk.norm1.weight.detach().float(),
+                                       add0=blk.norm1.bias.detach().float())
+            wqkv, bqkv = self._lin(blk.attn.to_qkv, (li, "qkv"))
+            qk = ops.gemm(h, wqkv[:2 * d], bias=bqkv[:2 * d].contiguous())     # [L, 2d]: q | k (view(b,s,3,n,d), clip.py:78)
+            q, k = qk[:, :d].contiguous(), qk[:, d:].contiguous()
+            vt = torch.zeros(d, Lp, dtype=torch.bfloat16, device=dev)
+            ops.gemm_raw(ptr(wqkv, 2 * d * d), ptr(h), ptr(vt), d, L, d, d, d, Lp, EPI_BF16,
+                         bias=ptr(bqkv, 2 * d), bias_mode=ops.BIAS_M)
+            o = encoder_attention(q, k, vt, H, Dh, L, Dh ** -0.5)
+            wp, bp = self._lin(blk.attn.proj, (li, "proj"))
+            ops.gemm_raw(ptr(o), ptr(wp), ptr(xb), L, d, d, d, d, d, EPI_RESID, bias=ptr(bp), bias_mode=ops.BIAS_N,
+                         gate_const=1.0)
+            h = ops.layernorm_modulate(xb, self.norm_eps, 0.0, mul0=blk.norm2.weight.detach().float(),
+                                       add0=blk.norm2.bias.detach().float())
+            w1, b1 = self._lin(blk.mlp[0], (li, "fc1"))
+            w2, b2 = self._lin(blk.mlp[2], (li, "fc2"))
+            u = ops.gemm(h, w1, bias=b1, epilogue=EPI_GELU_ERF)
+            m = w1.shape[0]
+            ops.gemm_raw(ptr(u), ptr(w2), ptr(xb), L, d, m, m, m, d, EPI_RESID, bias=ptr(b2), bias_mode=ops.BIAS_N,
+                         gate_const=1.0)
+        return xb
 
 
 def _pad_cols(w: torch.Tensor, Kp: int) -> torch.Tensor:

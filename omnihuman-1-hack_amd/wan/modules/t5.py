@@ -127,50 +127,72 @@ class T5Encoder(nn.Module):
         return b
 
     @torch.no_grad()
+    def embed(self, ids: torch.Tensor) -> torch.Tensor:
+        """Token embedding (t5.py:306): ids int64 [B, L] -> fp32 [B, L, dim].  A bf16 table is read as it is."""
+        dev = self.token_embedding.weight.device
+        emb = self.token_embedding.weight.detach()
+        if emb.dtype not in (torch.float32, torch.bfloat16):
+            emb = emb.float()
+        return ops.gather_rows(emb.contiguous(), ids.to(dev))
+
+    @torch.no_grad()
+    def run_layers(self, xb: torch.Tensor, klen: int, lo: int = 0, hi: Optional[int] = None) -> torch.Tensor:
+        """Blocks [lo, hi) on ONE sample's fp32 residual stream [L, dim] with ``klen`` unmasked (leading) keys
+        (T5SelfAttention.forward, t5.py:166-176 / the upstream block).  The stream stays fp32 whatever the parameter
+        dtype: the reference casts it to the weights' bf16 in every T5LayerNorm (t5.py:66-68) — this path is the more
+        precise of the two; parameters are used in bf16 (the MFMA operand type) either way."""
+        dev = xb.device
+        L, d = xb.shape
+        H, Dh = self.num_heads, self.dim_attn // self.num_heads
+        Lp = _round_up(L, 8)
+        bucket = self._bucket_table(L, dev)
+        f32 = lambda w: w.detach() if w.dtype == torch.float32 else w.detach().float()
+        xb = xb.contiguous().clone()
+        for li in range(lo, len(self.blocks) if hi is None else hi):
+            blk = self.blocks[li]
+            table = f32((self.pos_embedding if self.shared_pos else blk.pos_embedding).embedding.weight).contiguous()
+            nf, nb_ = ops.rmsnorm_f32(xb, f32(blk.norm1.weight), blk.norm1.eps, want_f32=self.reference_block_quirk,
+                                      want_bf16=True)
+            a = blk.attn
+            wq, wk, wv, wo = (self._w(getattr(a, n), (li, n)) for n in ("q", "k", "v", "o"))
+            q = ops.gemm(nb_, wq)
+            k = ops.gemm(nb_, wk)
+            vt = torch.zeros(self.dim_attn, Lp, dtype=torch.bfloat16, device=dev) if Lp != L else \
+                torch.empty(self.dim_attn, Lp, dtype=torch.bfloat16, device=dev)
+            ops.gemm_raw(ptr(wv), ptr(nb_), ptr(vt), self.dim_attn, L, d, d, d, Lp, EPI_BF16)     # V^T = Wv n^T
+            o = encoder_attention(q, k, vt, H, Dh, L, 1.0, bucket, table, klen)
+            if self.reference_block_quirk:                              # t5.py:166-176: x = norm1(x) + attn(norm1(x))
+                xb = nf
+            ops.gemm_raw(ptr(o), ptr(wo), ptr(xb), L, d, self.dim_attn, self.dim_attn, self.dim_attn, d, EPI_RESID,
+                         gate_const=1.0)
+            if not self.reference_block_quirk:                          # upstream: x += fc2(fc1(h) * gelu(gate(h)))
+                _, h = ops.rmsnorm_f32(xb, f32(blk.norm2.weight), blk.norm2.eps, want_f32=False)
+                f = blk.ffn
+                g = ops.gemm(h, self._w(f.gate[0], (li, "gate")), epilogue=EPI_GELU_BF16)
+                u = ops.gemm(h, self._w(f.fc1, (li, "fc1")))
+                gu = ops.mul_bf16(u, g)
+                ops.gemm_raw(ptr(gu), ptr(self._w(f.fc2, (li, "fc2"))), ptr(xb), L, d, self.dim_ffn, self.dim_ffn,
+                             self.dim_ffn, d, EPI_RESID, gate_const=1.0)
+        return xb
+
+    @torch.no_grad()
     def forward(self, ids: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """ids int64 [B, L], mask [B, L] (1 = token) -> fp32 [B, L, dim] (t5.py:305-322, eval mode)."""
         dev = self.token_embedding.weight.device
         ids = ids.to(dev)
         B, L = ids.shape
-        H, Dh, d = self.num_heads, self.dim_attn // self.num_heads, self.dim
-        Lp = _round_up(L, 8)
-        emb = self.token_embedding.weight.detach()
-        emb = emb if emb.dtype == torch.float32 else emb.float()
-        x = ops.gather_rows(emb.contiguous(), ids)                          # fp32 [B, L, dim]
-        bucket = self._bucket_table(L, dev)
+        x = self.embed(ids)                                                 # fp32 [B, L, dim]
         klens = [L] * B if mask is None else [int(v) for v in mask.to(dev).gt(0).sum(dim=1).tolist()]
         if mask is not None:                                                # the kernel masks keys >= klen: prefix masks only
             m = mask.to(dev).gt(0)
             assert bool((m == (torch.arange(L, device=dev)[None, :] < m.sum(1, keepdim=True))).all()), \
                 "attention masks must be prefixes (tokens first, padding after): tokenizers pad on the right"
-        out = torch.empty(B, L, d, dtype=torch.float32, device=dev)
+        out = torch.empty(B, L, self.dim, dtype=torch.float32, device=dev)
+        nw = self.norm.weight.detach()
+        nw = nw if nw.dtype == torch.float32 else nw.float()
         for b in range(B):
-            xb = x[b].contiguous()
-            for li, blk in enumerate(self.blocks):
-                table = (self.pos_embedding if self.shared_pos else blk.pos_embedding).embedding.weight.detach().float().contiguous()
-                nf, nb_ = ops.rmsnorm_f32(xb, blk.norm1.weight.detach().float(), blk.norm1.eps,
-                                          want_f32=self.reference_block_quirk, want_bf16=True)
-                a = blk.attn
-                wq, wk, wv, wo = (self._w(getattr(a, n), (li, n)) for n in ("q", "k", "v", "o"))
-                q = ops.gemm(nb_, wq)
-                k = ops.gemm(nb_, wk)
-                vt = torch.zeros(self.dim_attn, Lp, dtype=torch.bfloat16, device=dev) if Lp != L else \
-                    torch.empty(self.dim_attn, Lp, dtype=torch.bfloat16, device=dev)
-                ops.gemm_raw(ptr(wv), ptr(nb_), ptr(vt), self.dim_attn, L, d, d, d, Lp, EPI_BF16)     # V^T = Wv n^T
-                o = encoder_attention(q, k, vt, H, Dh, L, 1.0, bucket, table, klens[b])
-                if self.reference_block_quirk:                              # t5.py:166-176: x = norm1(x) + attn(norm1(x))
-                    xb = nf
-                ops.gemm_raw(ptr(o), ptr(wo), ptr(xb), L, d, self.dim_attn, self.dim_attn, self.dim_attn, d, EPI_RESID,
-                             gate_const=1.0)
-                if not self.reference_block_quirk:                          # upstream: x += fc2(fc1(h) * gelu(gate(h)))
-                    _, h = ops.rmsnorm_f32(xb, blk.norm2.weight.detach().float(), blk.norm2.eps, want_f32=False)
-                    f = blk.ffn
-                    g = ops.gemm(h, self._w(f.gate[0], (li, "gate")), epilogue=EPI_GELU_BF16)
-                    u = ops.gemm(h, self._w(f.fc1, (li, "fc1")))
-                    gu = ops.mul_bf16(u, g)
-                    ops.gemm_raw(ptr(gu), ptr(self._w(f.fc2, (li, "fc2"))), ptr(xb), L, d, self.dim_ffn, self.dim_ffn,
-                                 self.dim_ffn, d, EPI_RESID, gate_const=1.0)
-            yf, _ = ops.rmsnorm_f32(xb, self.norm.weight.detach().float(), self.norm.eps, want_bf16=False)
+            xb = self.run_layers(x[b], klens[b])
+            yf, _ = ops.rmsnorm_f32(xb, nw, self.norm.eps, want_bf16=False)
             out[b] = yf
         return out
 
@@ -199,7 +221,9 @@ class T5EncoderModel:
         if shard_fn is not None:
             raise NotImplementedError("FSDP sharding of the text encoder: 9 GB of bf16 weights fit one MI355X")
         if model is None:
-            model = umt5_xxl(encoder_only=True, dtype=torch.float32, device=self.device)
+            # the parameters take the dtype the caller names, as in the reference (t5.py:493-500: bf16 by default,
+            # 11 GB for umT5-XXL): a bf16 weight IS its MFMA operand copy (model._bf16 returns it as it is)
+            model = umt5_xxl(encoder_only=True, dtype=dtype, device=self.device)
             if checkpoint_path is not None:
                 model.load_state_dict(torch.load(checkpoint_path, map_location="cpu"))
         self.model = model.eval().requires_grad_(False).to(self.device)

@@ -19,7 +19,7 @@ def test_bench_prints_one_json_line(forced_rccl):
     if forced_rccl:
         env.update(OMH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-vae",
-                        "--no-single-frame", "--no-train", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                        "--no-single-frame", "--no-train", "--no-cpu-baseline", "--no-encoders"], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -42,8 +42,8 @@ def test_bench_gpus_2_launches_itself():
         env.pop(k, None)
     env.update(OMH_DIST_BACKEND="gloo", OMH_TRAIN_LEGS="primary", OMH_TRAIN_BATCH="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-                        "--no-vae", "--no-single-frame", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
-                       timeout=900)
+                        "--no-vae", "--no-single-frame", "--no-cpu-baseline", "--no-encoders"], env=env, capture_output=True,
+                       text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines

@@ -159,3 +159,103 @@ def test_wan_t2v_generate_from_a_prompt_string():
     assert vid.shape == vid2.shape and bool(torch.isfinite(vid).all()) and torch.equal(vid, vid2)
     vid3 = pipe.generate("a dog", n_prompt=neg, seed=3, **kw)
     assert not torch.equal(vid3, vid)                                   # the prompt reaches the video
+
+
+def test_umt5_xxl_full_depth_random_init():
+    """umT5-XXL as the pipelines build it (t5.py:465-528: 24 layers x 4096, 64 heads, ffn 10 240, vocabulary 256 384;
+    bf16 parameters as T5EncoderModel's default dtype — 11 GB), random init (no checkpoint in the image), through
+    ``T5EncoderModel.__call__``: finite, bit-repeatable, padding stripped; the layer pair 11-12 against the oracle on
+    the hidden state this model hands it; an out-of-range token id raises as nn.Embedding does."""
+    import time
+    from oracle import encoders_oracle as E
+    t5 = importlib.import_module(PKG + ".wan.modules.t5")
+    torch.manual_seed(3)
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, 256384, (2, 512), generator=g)
+    mask = torch.ones(2, 512, dtype=torch.long)
+    mask[0, 37:] = 0
+    mask[1, 200:] = 0
+    enc = t5.T5EncoderModel(512, dtype=torch.bfloat16, device="cuda", tokenizer=lambda texts: (ids, mask))
+    m = enc.model
+    assert m.num_layers == 24 and m.token_embedding.weight.dtype == torch.bfloat16
+    n_par = sum(p.numel() for p in m.parameters())
+    assert 5.6e9 < n_par < 5.8e9, n_par
+    with torch.no_grad():                              # init_weights-like scales: q small (T5 does not scale its scores)
+        for blk in m.blocks:
+            blk.attn.q.weight.mul_(0.05)
+    ctx = enc(["a", "b"], "cuda")
+    assert [tuple(c.shape) for c in ctx] == [(37, 4096), (200, 4096)] and all(torch.isfinite(c).all() for c in ctx)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    again = enc(["a", "b"], "cuda")
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / 2
+    assert all(torch.equal(a, b) for a, b in zip(ctx, again))
+    print(f"[measured] umT5-XXL (24 layers, bf16 weights, 512 tokens): {ms:.1f} ms per prompt")
+    # mid-depth layer pair against the oracle
+    x = m.embed(ids[1:2].cuda())[0]
+    h11 = m.run_layers(x, 200, 0, 11)
+    h13 = m.run_layers(h11, 200, 11, 13)
+    cfg = E.T5Config(num_layers=2)
+    sd = {}
+    for j, li in enumerate((11, 12)):
+        for k_, v in m.blocks[li].state_dict().items():
+            sd[f"blocks.{j}.{k_}"] = v.float().cpu()
+    x_ref = h11.float().cpu()[None]
+    buckets = E.t5_relative_buckets(512, 512, cfg.num_buckets)
+    mk = mask[1:2]
+    with torch.no_grad():
+        for j in range(2):
+            p = f"blocks.{j}."
+            e = sd[p + "pos_embedding.embedding.weight"][buckets].permute(2, 0, 1).unsqueeze(0)
+            x_ref = E.t5_layernorm(x_ref, sd[p + "norm1.weight"])
+            x_ref = x_ref + E.t5_attention(sd, p + "attn.", x_ref, mk, e, cfg.num_heads)
+    assert rel_rms(h13[:200], x_ref[0, :200]) < TOL, rel_rms(h13[:200], x_ref[0, :200])
+    bad = ids.clone()
+    bad[0, 3] = 256384
+    with pytest.raises(IndexError):
+        m.embed(bad.cuda())
+    del enc, m
+    torch.cuda.empty_cache()
+
+
+def test_clip_vit_h_full_depth_random_init():
+    """ViT-H/14 at full depth (clip.py:468-495: 32 blocks x 1280, 31 evaluated) through ``CLIPModel.visual``: finite,
+    bit-repeatable, blocks 15-16 against the oracle on the hidden state this model hands them."""
+    import time
+    from oracle import encoders_oracle as E
+    clip = importlib.import_module(PKG + ".wan.modules.clip")
+    torch.manual_seed(4)
+    cm = clip.CLIPModel(device="cuda")
+    m = cm.model
+    assert m.num_layers == 32 and 6.2e8 < sum(p.numel() for p in m.parameters()) < 6.5e8
+    vid = torch.rand(3, 2, 96, 160, generator=torch.Generator().manual_seed(1)) * 2 - 1
+    out = cm.visual([vid.cuda()])
+    assert out.shape == (2, 257, 1280) and torch.isfinite(out).all()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    again = cm.visual([vid.cuda()])
+    torch.cuda.synchronize()
+    print(f"[measured] CLIP ViT-H/14 (31 of 32 blocks): {(time.perf_counter() - t0) * 1e3 / 2:.1f} ms per image")
+    assert torch.equal(out, again)
+    h = out[0].clone()                                    # any finite stream will do as the blocks' input
+    got = m.run_layers(h.clone(), 15, 17)
+    cfg = E.ViTConfig(num_layers=2)
+    sd = {}
+    for j, li in enumerate((15, 16)):
+        for k_, v in list(m.transformer)[li].state_dict().items():
+            sd[f"transformer.{j}.{k_}"] = v.float().cpu()
+    t = h.float().cpu()[None]
+    n, d = cfg.num_heads, cfg.dim // cfg.num_heads
+    import torch.nn.functional as F
+    with torch.no_grad():
+        for j in range(2):
+            p = f"transformer.{j}."
+            hh = F.layer_norm(t, (cfg.dim,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], cfg.norm_eps)
+            q, k, v = F.linear(hh, sd[p + "attn.to_qkv.weight"], sd[p + "attn.to_qkv.bias"]).view(1, -1, 3, n, d).unbind(2)
+            a = torch.softmax(torch.einsum("binc,bjnc->bnij", q, k) * d ** -0.5, -1)
+            o = torch.einsum("bnij,bjnc->binc", a, v).reshape(1, -1, cfg.dim)
+            t = t + F.linear(o, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+            hh = F.layer_norm(t, (cfg.dim,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], cfg.norm_eps)
+            t = t + F.linear(F.gelu(F.linear(hh, sd[p + "mlp.0.weight"], sd[p + "mlp.0.bias"])), sd[p + "mlp.2.weight"], sd[p + "mlp.2.bias"])
+    assert rel_rms(got, t[0]) < TOL, rel_rms(got, t[0])
