@@ -40,16 +40,21 @@ def process_audio(sd, audio, prefix="audio_processor."):
     return tok
 
 
-def pose_conv_stack(sd, pose, prefix="pose_processor."):
-    """:37-45 / :149-157 — three Conv3d(3x3x3, padding 1) + ReLU, spatial stride 1, 2, 2.  pose [B, K, T, H, W]."""
-    x = F.relu(F.conv3d(pose.float(), sd[prefix + "0.weight"], sd[prefix + "0.bias"], padding=1))
-    x = F.relu(F.conv3d(x, sd[prefix + "2.weight"], sd[prefix + "2.bias"], stride=(1, 2, 2), padding=1))
-    return F.relu(F.conv3d(x, sd[prefix + "4.weight"], sd[prefix + "4.bias"], stride=(1, 2, 2), padding=1))
+def pose_conv_stack(sd, pose, prefix="pose_processor.", gates=None):
+    """:37-45 / :149-157 — three Conv3d(3x3x3, padding 1) + ReLU, spatial stride 1, 2, 2.  pose [B, K, T, H, W].
+    ``gates`` (tests only): three boolean masks of the layers' output shapes that REPLACE the ReLUs' own on/off
+    decisions (y = conv * gate) — the ReLU is discontinuous in its gradient at 0, and a test that wants to compare
+    gradients with a lower-precision forward hands over that forward's decisions."""
+    def act(x, i):
+        return F.relu(x) if gates is None else x * gates[i].to(x.dtype)
+    x = act(F.conv3d(pose.float(), sd[prefix + "0.weight"], sd[prefix + "0.bias"], padding=1), 0)
+    x = act(F.conv3d(x, sd[prefix + "2.weight"], sd[prefix + "2.bias"], stride=(1, 2, 2), padding=1), 1)
+    return act(F.conv3d(x, sd[prefix + "4.weight"], sd[prefix + "4.bias"], stride=(1, 2, 2), padding=1), 2)
 
 
-def process_pose(sd, pose, prefix="pose_processor."):
+def process_pose(sd, pose, prefix="pose_processor.", gates=None):
     """:205-224 with the frame / channel axes in the order the text describes (module docstring)."""
-    x = pose_conv_stack(sd, pose, prefix)                        # [B, C', T, h, w]
+    x = pose_conv_stack(sd, pose, prefix, gates)                 # [B, C', T, h, w]
     x = x.permute(0, 2, 1, 3, 4).flatten(2)                      # [B, T, C'*h*w]
     return F.linear(x, sd["pose_fc.weight"], sd["pose_fc.bias"])
 

@@ -143,7 +143,31 @@ def test_relu_backward_kernel(ops):
     assert torch.equal(got, torch.where(y.float() > 0, dy, torch.zeros_like(dy)))
 
 
-def test_adapter_gradients_match_autograd(omni):
+class _GateSpy:
+    """Records the on/off decisions of the product's three pose Conv3d + ReLU layers (bf16 forward), per sample, so the
+    fp32 oracle can differentiate the SAME piecewise-linear function (test_pose_conv_gradients_with_the_products_relu_
+    gates shows that the 0.1 % of decisions that differ are all of the 5-9 % gradient gap)."""
+
+    def __init__(self, omni, monkeypatch):
+        self.rec, orig = [], omni._conv3d_relu_fwd
+
+        def spy(x_cl, conv, stride_hw):
+            y = orig(x_cl, conv, stride_hw)
+            self.rec.append((conv.out_channels, y.detach()))
+            return y
+        monkeypatch.setattr(omni, "_conv3d_relu_fwd", spy)
+
+    def gates(self, B):
+        assert len(self.rec) >= 3 * B
+        rec = self.rec[-3 * B:]
+        out = []
+        for layer in range(3):
+            out.append(torch.stack([(rec[3 * b + layer][1][..., :rec[3 * b + layer][0]].float() > 0).permute(3, 0, 1, 2).cpu()
+                                    for b in range(B)]))
+        return out
+
+
+def test_adapter_gradients_match_autograd(omni, monkeypatch):
     """Backward of every adapter layer (omh_dense_f32_bwd, the Conv3d dgrad / wgrad on omh_conv_cl_bf16 and
     omh_gemm_bf16_tn, pose_fc on the GEMMs) against autograd through the oracle's fp32 formulas
     (oracle/omnihuman_oracle.py, whose forward is pinned to the reference's OmniConditionsModule)."""
@@ -156,37 +180,92 @@ def test_adapter_gradients_match_autograd(omni):
     wa = torch.from_numpy(detgen.normalish("omni/grad/wa", (2, 4, 512)))
     wp = torch.from_numpy(detgen.normalish("omni/grad/wp", (2, 5, 256)))
     wt = torch.from_numpy(detgen.normalish("omni/grad/wt", (2, 13, 256)))
-    # oracle side
-    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    a = OH.process_audio(osd, audio)
-    p = OH.process_pose(osd, pose, prefix="pose_guider.")
-    tok = OH.condition_tokens(osd, a, p)
-    lo = (a * wa).sum() + (p * wp).sum() + (tok * wt).sum()
-    lo.backward()
-    # product side
+    # product side (its ReLU decisions are recorded for the oracle)
+    spy = _GateSpy(omni, monkeypatch)
     ag = m.process_audio(audio.cuda())
     pg = m.process_pose(pose.cuda())
     tg = m.condition_tokens(ag, pg)
     lg = (ag * wa.cuda()).sum() + (pg * wp.cuda()).sum() + (tg * wt.cuda()).sum()
     lg.backward()
+    # oracle side: the same piecewise-linear pose stack
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    a = OH.process_audio(osd, audio)
+    p = OH.process_pose(osd, pose, prefix="pose_guider.", gates=spy.gates(pose.shape[0]))
+    tok = OH.condition_tokens(osd, a, p)
+    lo = (a * wa).sum() + (p * wp).sum() + (tok * wt).sum()
+    lo.backward()
     assert abs(lg.item() - lo.item()) < 2e-2 * abs(lo.item()) + 1e-2
     bad = []
     for name, prm in m.named_parameters():
         og = osd[name].grad
         assert prm.grad is not None and og is not None, name
         err = rel_rms(prm.grad, og)
-        # fp32 layers: accumulation order only.  Pose Conv3d stack: the bf16 forward (activations within 1.5e-2 of the
-        # fp32 ones) flips ~1 % of the ReLU gates that sit at a pre-activation of ~0, where the gradient is
-        # discontinuous — each flip adds / removes one full contribution, which shows as 5e-2 (last layer) to 9e-2
-        # (first layer) relative RMS on the conv gradients (measured on MI355X); the layers downstream of the ReLUs
+        # fp32 layers: accumulation order only.  Pose Conv3d stack, differentiated at the product's own ReLU decisions
+        # (with the oracle's own they sit 5-9 % apart: 0.1 % of the gates flip in the bf16 forward, see the test above):
+        # bf16 operands, as any matrix gradient of this build (measured 5e-3).  The layers downstream of the ReLUs
         # (pose_fc, projector, temporal embedding) see the forward's bf16 rounding only.
-        tol = 1e-3 if name.startswith("audio_processor") else (1.5e-1 if name.startswith("pose_guider") else 4e-2)
+        tol = 1e-3 if name.startswith("audio_processor") else (2e-2 if name.startswith("pose_guider") else 4e-2)
         if err > tol:
             bad.append((name, err))
     assert not bad, bad
 
 
-def test_omnihuman_training_step_matches_autograd_oracle(omni, wan_model_mod):
+def test_pose_conv_gradients_with_the_products_relu_gates(omni, monkeypatch):
+    """The pose Conv3d gradients sit 5-9 % (relative RMS) from the fp32 autograd oracle (bound 1.5e-1 above).  Claimed
+    cause: the bf16 forward flips ~1 % of the ReLU gates at pre-activations ~ 0, where the gradient is
+    discontinuous.  Proof: hand the oracle the PRODUCT's gate decisions (y = conv * gate instead of ReLU) — the
+    residual must then collapse to the bound of a bf16-operand matrix gradient (2e-2, as for the DiT's weights)."""
+    from oracle import detgen, make_golden, omnihuman_oracle as OH
+    sd = make_golden.omni_state_dict()
+    audio, pose = make_golden.omni_inputs()
+    m = omni.OmniConditionsModule(**make_golden.OMNI_TINY)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    wp = torch.from_numpy(detgen.normalish("omni/grad/wp", (2, 5, 256)))
+    rec = []
+    orig = omni._conv3d_relu_fwd
+
+    def spy(x_cl, conv, stride_hw):
+        y = orig(x_cl, conv, stride_hw)
+        rec.append((conv.out_channels, y.detach()))
+        return y
+    monkeypatch.setattr(omni, "_conv3d_relu_fwd", spy)
+    pg = m.process_pose(pose.cuda())
+    (pg * wp.cuda()).sum().backward()
+    B = pose.shape[0]
+    assert len(rec) == 3 * B                                   # three layers per sample, samples in order
+    gates, flips = [], []
+    for layer in range(3):
+        per = []
+        for b in range(B):
+            co, y = rec[3 * b + layer]                         # bf16 [T, h, w, Cout_p], channels last
+            per.append((y[..., :co].float() > 0).permute(3, 0, 1, 2).cpu())      # [C', T, h, w]
+        gates.append(torch.stack(per))
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    with torch.no_grad():                                      # how many decisions differ from the fp32 forward's own
+        x = pose.float()
+        for layer, (key, st) in enumerate((("0", 1), ("2", 2), ("4", 2))):
+            x = torch.nn.functional.conv3d(x, sd["pose_guider." + key + ".weight"], sd["pose_guider." + key + ".bias"],
+                                           stride=(1, st, st), padding=1)
+            flips.append(float(((x > 0) != gates[layer]).float().mean()))
+            x = torch.relu(x)
+    p_o = OH.process_pose(osd, pose, prefix="pose_guider.", gates=gates)
+    (p_o * wp).sum().backward()
+    worst_gated = 0.0
+    for name, prm in m.named_parameters():
+        if name.startswith("pose_guider"):
+            worst_gated = max(worst_gated, rel_rms(prm.grad, osd[name].grad))
+    # the same comparison with the oracle's own ReLUs, for the record
+    osd2 = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    (OH.process_pose(osd2, pose, prefix="pose_guider.") * wp).sum().backward()
+    worst_relu = max(rel_rms(prm.grad, osd2[name].grad) for name, prm in m.named_parameters() if name.startswith("pose_guider"))
+    print(f"[measured] pose Conv3d gradients vs the fp32 oracle: {worst_relu:.3e} with its own ReLUs, {worst_gated:.3e} with "
+          f"the product's gates; gate decisions that differ per layer: {[f'{f:.2%}' for f in flips]}")
+    assert worst_gated < 2e-2, worst_gated
+    assert worst_relu > 2 * worst_gated                        # ... and the gates ARE what the 5-9 % consisted of
+
+
+def test_omnihuman_training_step_matches_autograd_oracle(omni, wan_model_mod, monkeypatch):
     """OmniHumanWanT2V.training_step (omnihuman_wan_t2v.py:453-488) with audio + pose conditioning: loss and the
     gradients of every adapter parameter and of the DiT against autograd through the oracle (fp32 DiT with the
     condition tokens prepended to the context + fp32 adapters)."""
@@ -202,18 +281,8 @@ def test_omnihuman_training_step_matches_autograd_oracle(omni, wan_model_mod):
     noise = torch.from_numpy(detgen.normalish("omni/tr/noise", (2, 16, 2, 4, 6)))
     ctx = torch.from_numpy(detgen.normalish("omni/ctx", (20, 64)))
     t = torch.tensor([0.3, 0.7])
-    # ---- oracle
-    d_o = {k: v.clone().requires_grad_(True) for k, v in dsd.items()}
-    o_o = {k: v.clone().requires_grad_(True) for k, v in osd.items()}
-    tok = OH.condition_tokens(o_o, OH.process_audio(o_o, audio), OH.process_pose(o_o, pose))
-    tok.retain_grad()
-    tt = t.view(-1, 1, 1, 1, 1)
-    noisy = (1 - tt) * frames + tt * noise
-    pred = torch.stack(O.dit_forward_autograd(d_o, cfg, list(noisy), t, [ctx, ctx], 24, reference_ffn_freeze=True,
-                                              extra_tokens=tok))
-    lo = torch.mean((pred - frames) ** 2 * (1 - tt))
-    lo.backward()
-    # ---- product
+    # ---- product (the pose stack's ReLU decisions are recorded for the oracle)
+    spy = _GateSpy(omni, monkeypatch)
     dit = wan_model_mod.WanModel(num_layers=2, **make_golden.TINY)
     dit.load_state_dict(dsd)
     dit = dit.cuda().train()
@@ -222,21 +291,34 @@ def test_omnihuman_training_step_matches_autograd_oracle(omni, wan_model_mod):
     m.load_state_dict(osd, strict=False)
     loss = m.training_step(frames, {"text": ctx, "audio_features": audio, "pose_heatmaps": pose}, t, noise=noise)
     loss.backward()
+    # ---- oracle
+    d_o = {k: v.clone().requires_grad_(True) for k, v in dsd.items()}
+    o_o = {k: v.clone().requires_grad_(True) for k, v in osd.items()}
+    tok = OH.condition_tokens(o_o, OH.process_audio(o_o, audio), OH.process_pose(o_o, pose, gates=spy.gates(pose.shape[0])))
+    tok.retain_grad()
+    tt = t.view(-1, 1, 1, 1, 1)
+    noisy = (1 - tt) * frames + tt * noise
+    pred = torch.stack(O.dit_forward_autograd(d_o, cfg, list(noisy), t, [ctx, ctx], 24, reference_ffn_freeze=True,
+                                              extra_tokens=tok))
+    lo = torch.mean((pred - frames) ** 2 * (1 - tt))
+    lo.backward()
     assert abs(loss.item() - lo.item()) < 1e-2 * lo.item()
-    bad = []
+    bad, worst = [], 0.0
     for name, prm in m.named_parameters():
         if name.startswith("wan_t2v"):
             continue
         og = o_o[name].grad
         assert prm.grad is not None, name
         err = rel_rms(prm.grad, og)
-        if err > (1.5e-1 if name.startswith("pose_processor") else 8e-2):
+        worst = max(worst, err)
+        if err > 2e-2:                  # through two DiT blocks of bf16 attention + the adapters (measured 8.6e-3)
             bad.append((name, err))
     for name in ("blocks.0.cross_attn.k.weight", "blocks.1.cross_attn.v.weight", "blocks.0.self_attn.q.weight",
                  "patch_embedding.weight"):
         err = rel_rms(dict(dit.named_parameters())[name].grad, d_o[name].grad)
         if err > 6e-2:
             bad.append((name, err))
+    print(f"[measured] OmniHuman training step, adapter gradients vs the autograd oracle (product's ReLU gates): worst {worst:.3e}")
     assert not bad, bad
     # ready tokens that require grad receive theirs
     tok_g = m.condition_tokens(m.process_audio(audio.cuda()), m.process_pose(pose.cuda())).detach().requires_grad_(True)
