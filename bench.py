@@ -75,6 +75,70 @@ class KernelTimer:
         return sum(s.elapsed_time(e) for s, e in self.pairs) / len(self.pairs)
 
 
+class Telemetry:
+    """Shader clock and board power of the GPU this rank runs on, sampled from the amdgpu hwmon files (freq1_input,
+    power1_input) every 50 ms by a host thread while the timed region runs.  The dominant kernels of this path are
+    power-limited: the chip holds ~1.5-1.9 GHz of its 2.4 GHz under them (MI355X_MICROARCH.md, "DVFS give-back"), and the
+    2.5 PFLOP/s the roofline divides by is the 2.4 GHz figure — this object makes that visible in the line."""
+
+    def __init__(self, device_index=0):
+        import glob
+        self.dir = None
+        cands = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+        cands = [d for d in cands if os.path.exists(os.path.join(d, "freq1_input"))]
+        try:                                            # match the PCI address when the runtime tells it
+            bus = torch.cuda.get_device_properties(device_index).pci_bus_id
+            dom = getattr(torch.cuda.get_device_properties(device_index), "pci_domain_id", 0)
+            dev = getattr(torch.cuda.get_device_properties(device_index), "pci_device_id", 0)
+            want = f"{dom:04x}:{bus:02x}:{dev:02x}"
+            for d in cands:
+                if want in os.path.realpath(os.path.join(d, "..", "..")):
+                    self.dir = d
+        except Exception:
+            pass
+        if self.dir is None and len(cands) == 1:
+            self.dir = cands[0]
+        self.samples, self._stop, self._thr = [], False, None
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as fh:
+                return float(fh.read().strip())
+        except Exception:
+            return None
+
+    def start(self):
+        if self.dir is None:
+            return
+        import threading
+        self._stop = False
+
+        def run():
+            while not self._stop:
+                f, p = self._read("freq1_input"), self._read("power1_input")
+                if f is not None:
+                    self.samples.append((f / 1e6, (p or 0.0) / 1e6))
+                time.sleep(0.05)
+        self._thr = threading.Thread(target=run, daemon=True)
+        self._thr.start()
+
+    def stop(self):
+        if self._thr is not None:
+            self._stop = True
+            self._thr.join(timeout=1.0)
+        if not self.samples:
+            return None
+        f = [a for a, _ in self.samples]
+        p = [b for _, b in self.samples]
+        cap = self._read("power1_cap")
+        mean_f = sum(f) / len(f)
+        return {"sclk_mhz_mean": round(mean_f, 0), "sclk_mhz_min": round(min(f), 0), "sclk_mhz_max": round(max(f), 0),
+                "power_w_mean": round(sum(p) / len(p), 0), "power_w_max": round(max(p), 0),
+                "power_cap_w": None if cap is None else round(cap / 1e6, 0), "samples": len(f),
+                "source": "amdgpu hwmon freq1_input / power1_input, 50 ms period, timed region only",
+                "mfma_peak_at_mean_clock_tflops": round(PEAK_BF16_TFLOPS * mean_f / 2400.0, 0)}
+
+
 def build_model(device):
     model_mod = importlib.import_module(PKG + ".wan.modules.model")
     cfgs = importlib.import_module(PKG + ".wan.configs")
@@ -586,9 +650,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = gemm_timer.enabled = ln_timer.enabled = True
+    tele = Telemetry(local_rank)
+    tele.start()
     t0 = time.perf_counter()
     x = run_steps(args.steps, sched, x)
     torch.cuda.synchronize()
+    telemetry = tele.stop()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -629,7 +696,9 @@ def main():
             traffic = traffic * nb                                 # measured per batch element (tools/pmc_attn.sh)
         roofline = {"kernel": "%s (self-attention, Lq=Lk=%d, 12 heads, D=128, batch %d)" % (kname, seq_len, nb),
                     "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                    "frac_of_peak_at_measured_clock": None if not telemetry else
+                    round(ach / telemetry["mfma_peak_at_mean_clock_tflops"], 4), "traffic": traffic,
                     "traffic_source": None if traffic is None else
                     "NOT a counter of this run: HBM-side bytes per launch of this kernel from separate rocprofv3 --pmc "
                     "passes (2 x FETCH_SIZE + WRITE_SIZE, tools/pmc_attn.sh), recorded in profiles/traffic_latest.json "
@@ -715,7 +784,7 @@ def main():
                     "achieved_tflops_per_gpu": round(fwd_per_gpu_step * fwd_flops / (ms_per_step * 1e-3) / 1e12, 1),
                     "mfma_roofline_frac": round(fwd_per_gpu_step * fwd_flops / (ms_per_step * 1e-3) / 1e12
                                                 / PEAK_BF16_TFLOPS, 4),
-                    "kernels": secondary},
+                    "kernels": secondary, "telemetry": telemetry},
             "single_frame": single, "vae": vae, "encoders": encoders, "train": train, "roofline": roofline,
             "cpu_baseline": cpu,
         }

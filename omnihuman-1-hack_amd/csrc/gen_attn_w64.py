@@ -179,13 +179,30 @@ def qk_read_plan(kbase, first=2):
     return plan
 
 
-def softmax_lines(cur):
+# Timing-only ablation builds (tools/attn_abl.sh; wrong numerics by construction, never shipped — the default output of
+# this generator is unchanged).  OMH_ATTN_ABL=1: variant 0 = V2 with every 4th exponential replaced by the 5 FMA-pipe
+# instructions a degree-3 exp2 polynomial costs (floor, subtract, 3 fma; the exponent insertion not even counted),
+# variant 1 = V2 without the per-piece SALU address arithmetic of the LDS-DMA (all four pieces of a tile then fetch the
+# same rows into the same 1 KiB).  OMH_ATTN_ABL=2: variant 1 = V2 with that arithmetic kept but adding zero (same
+# instruction count, same-rows traffic).  Round-3 results (profiles/r03_attention_ablations.json): polynomial share
+# -3.5 % (slower); no-SALU +7.7 %, same-count same-rows +10.3 % — i.e. NOT the SALU slots: with three quarters of every
+# K / V^T tile left stale the operands toggle less and the power-limited chip clocks higher (see the telemetry there).
+ABL = __import__("os").environ.get("OMH_ATTN_ABL", "")
+
+
+def softmax_lines(cur, poly=False):
     """exp2 in place + bf16 packing of score set cur: 64 + 32 VALU; a block's packing trails its exponentials."""
     out = []
     for qb in range(2):
         for kb in range(2):
             base = S(cur, qb, kb)
-            out += [f"v_exp_f32 {vr(base + r)}, {vr(base + r)}" for r in range(16)]
+            for r in range(16):
+                if poly and r % 4 == 3:
+                    x = vr(base + r)
+                    out += [f"v_floor_f32 {vr(T3)}, {x}", f"v_sub_f32 {x}, {x}, {vr(T3)}", f"v_fma_f32 {vr(T3)}, {x}, 0.5, 1.0",
+                            f"v_fma_f32 {vr(T3)}, {x}, {vr(T3)}, 0.5", f"v_fma_f32 {x}, {x}, {vr(T3)}, 1.0"]
+                else:
+                    out.append(f"v_exp_f32 {vr(base + r)}, {vr(base + r)}")
             for a in range(2):
                 for eidx in range(4):
                     r0 = base + 8 * a + 2 * eidx
@@ -314,7 +331,10 @@ def rotate(sreg, nslots):
 
 # ---------------------------------------------------------------- whole stream
 def generate(variant):
-    base = min(variant, 2)
+    abl_poly = ABL == "1" and variant == 0
+    abl_salu = ABL == "1" and variant == 1
+    abl_traffic = ABL == "2" and variant == 1
+    base = 2 if (abl_poly or abl_salu or abl_traffic) else min(variant, 2)
     dma_spread = base >= 1
     vpre = base >= 1
     k3 = base >= 2
@@ -337,9 +357,10 @@ def generate(variant):
         if KBASE:
             out.append(f"s_add_u32 m0, m0, {KBASE}")
         for j in range(4):
-            if j:
-                out.append("s_add_u32 m0, m0, 4096")
-            out.append("s_mov_b32 s92, %[skn]" if j == 0 else "s_add_u32 s92, s92, %[skp]")
+            if j and not abl_salu:
+                out.append("s_add_u32 m0, m0, 0" if abl_traffic else "s_add_u32 m0, m0, 4096")
+            if not (abl_salu and j):
+                out.append("s_mov_b32 s92, %[skn]" if j == 0 else ("s_add_u32 s92, s92, 0" if abl_traffic else "s_add_u32 s92, s92, %[skp]"))
             out.append("buffer_load_dwordx4 %[vok], %[rk], s92 offen lds")
         if advance:
             out.append("s_add_u32 %[skn], %[skn], s95")
@@ -348,9 +369,10 @@ def generate(variant):
     def v_dma(slot):
         out = [f"s_add_u32 m0, %[ldsw], {VBASE + slot * KSLOT}"]
         for j in range(4):
-            if j:
-                out.append("s_add_u32 m0, m0, 4096")
-            out.append("s_mov_b32 s93, %[svn]" if j == 0 else "s_add_u32 s93, s93, %[svp]")
+            if j and not abl_salu:
+                out.append("s_add_u32 m0, m0, 0" if abl_traffic else "s_add_u32 m0, m0, 4096")
+            if not (abl_salu and j):
+                out.append("s_mov_b32 s93, %[svn]" if j == 0 else ("s_add_u32 s93, s93, 0" if abl_traffic else "s_add_u32 s93, s93, %[svp]"))
             out.append("buffer_load_dwordx4 %[vov], %[rv], s93 offen lds")
         out.append("s_add_u32 %[svn], %[svn], 128")
         return out
@@ -438,7 +460,7 @@ def generate(variant):
         mf1 = qk_mfmas(nxt)
         plans = [qk_read_plan(kbase)]
         plans.append(spread(X(dma), 32, 0, 30) if dma_spread else spread(X(dma), 32, 0, 6))
-        plans.append(spread(X(softmax_lines(cur)), 32, 2, 32))
+        plans.append(spread(X(softmax_lines(cur, abl_poly)), 32, 2, 32))
         pre = [] if k3 else kread_ops(0, kbase) + kread_ops(1, kbase)
         if vpre:
             vp = [[] for _ in range(32)]
@@ -549,7 +571,7 @@ def generate(variant):
 
 
 N_VARIANTS = 4
-LDS_BYTES = {0: 4 * KSLOT, 1: 4 * KSLOT, 2: 5 * KSLOT, 3: 5 * KSLOT}
+LDS_BYTES = {0: 5 * KSLOT if ABL else 4 * KSLOT, 1: 5 * KSLOT if ABL else 4 * KSLOT, 2: 5 * KSLOT, 3: 5 * KSLOT}
 CLOBBER_V = range(12, 256)
 CLOBBER_A = range(0, 256)
 CLOBBER_S = range(91, 100)
