@@ -715,10 +715,15 @@ extern "C" int omh_conv_cl_bf16(const omh_conv_args* args, omh_stream_t stream) 
     if (M > 0x7fffffff) return OMH_E_SHAPE;
     // 32-bit buffer offsets
     if ((int64_t)a.Tin * a.Hin * a.Win * a.Cin * 2 >= 0x7fffffffLL) return OMH_E_SHAPE;
-    // wide tiles (N extent 96 / 192) once they give every CU most of a workgroup; the 128x128 tile otherwise
+    // wide tiles (N extent 96 / 192) once they give every CU most of a workgroup; the 128x128 tile otherwise.  The
+    // count is taken for TWO output frames of this geometry whatever Tout is (the executors convolve 1 - 8 frames per
+    // call): the kernel choice — and with it the accumulation order of every output value — then depends on the layer
+    // only, not on how many frames a call carries, so a prefix of a clip decodes / encodes bit for bit like the
+    // whole clip's first frames (tests/test_gpu_config5.py).
     const char* force = getenv("OMH_CONV_TILE");                     // "wide" / "small": test / benchmarking override
     const bool narrow = a.Cout <= 96;
-    const int64_t wide_tiles = narrow ? (M + 511) / 512 : ((M + 255) / 256) * ((a.Cout + 191) / 192);
+    const int64_t Mn = (int64_t)2 * a.Hout * a.Wout;
+    const int64_t wide_tiles = narrow ? (Mn + 511) / 512 : ((Mn + 255) / 256) * ((a.Cout + 191) / 192);
     bool wide = wide_tiles >= 192;
     if (force && force[0] == 'w') wide = true;
     if (force && force[0] == 's') wide = false;

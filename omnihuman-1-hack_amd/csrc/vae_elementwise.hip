@@ -6,16 +6,29 @@
 namespace {
 
 // One voxel (C channels, bf16) is handled by G consecutive lanes, 8 channels
-// (16 bytes) per lane per pass.
+// (16 bytes) per lane per pass.  A lane keeps its channels for every voxel it visits (grid-stride over voxels), so
+// gamma sits in registers: round 2 fetched it with 8 scalar-width loads per chunk and voxel — 24 of the 30 vector
+// memory instructions of a C = 96 voxel, which is what bounded the kernel (2.6 - 3.1 TB/s at 480x832).  Same
+// arithmetic in the same order as before: the values do not move.
 template <int G, bool XF32>
 __global__ __launch_bounds__(256)
 void rms_silu_kernel(const void* __restrict__ xv, const float* __restrict__ gamma, uint16_t* __restrict__ y,
                      int64_t P, int C, int do_silu) {
     const int lane_g = threadIdx.x % G;
-    const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
-    if (p >= P) return;            // whole group exits together (G divides the wave)
     const int nch = C >> 3;        // 8-channel chunks per voxel
     constexpr int MAXC = 4;        // chunks per lane  -> C <= 8*G*MAXC
+    float gm[MAXC][8];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane_g + G * i;
+        if (c < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gm[i][e] = gamma[c * 8 + e];
+        }
+    }
+    const int64_t per = blockDim.x / G;
+    // a group's G lanes share p: they leave the loop together (G divides the wave)
+    for (int64_t p = (int64_t)blockIdx.x * per + threadIdx.x / G; p < P; p += (int64_t)gridDim.x * per) {
     float v[MAXC][8];
     float ss = 0.f;
 #pragma unroll
@@ -50,13 +63,14 @@ void rms_silu_kernel(const void* __restrict__ xv, const float* __restrict__ gamm
             uint32_t o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float a = v[i][2 * e] * inv * gamma[c * 8 + 2 * e];
-                float b = v[i][2 * e + 1] * inv * gamma[c * 8 + 2 * e + 1];
+                float a = v[i][2 * e] * inv * gm[i][2 * e];
+                float b = v[i][2 * e + 1] * inv * gm[i][2 * e + 1];
                 if (do_silu) { a = silu(a); b = silu(b); }
                 o[e] = pack_bf2(a, b);
             }
             *(uint4*)(y + p * C + c * 8) = make_uint4(o[0], o[1], o[2], o[3]);
         }
+    }
     }
 }
 
@@ -185,6 +199,12 @@ extern "C" int omh_relu_bf16(void* x, int64_t n, omh_stream_t stream) {
     return omh_launch_status();
 }
 
+// workgroups: one pass over the voxels when there are few, else 8 per CU walking the rest
+static unsigned rms_grid(int64_t P, int G) {
+    const int64_t need = (P * G + 255) / 256;
+    return (unsigned)(need < 2048 ? need : 2048);
+}
+
 template <bool XF32>
 static int rms_silu_launch(const void* x, const float* gamma, void* y, int64_t P, int32_t C, int32_t do_silu,
                            omh_stream_t stream) {
@@ -196,13 +216,13 @@ static int rms_silu_launch(const void* x, const float* gamma, void* y, int64_t P
     omh_clear_status();
     // lanes per voxel: enough that each lane holds <= 4 chunks, rounded to a power of two
     if (nch <= 16) {
-        hipLaunchKernelGGL((rms_silu_kernel<4, XF32>), dim3((unsigned)((P * 4 + 255) / 256)), dim3(256), 0, s,
+        hipLaunchKernelGGL((rms_silu_kernel<4, XF32>), dim3(rms_grid(P, 4)), dim3(256), 0, s,
                            x, gamma, (uint16_t*)y, P, C, do_silu);
     } else if (nch <= 64) {
-        hipLaunchKernelGGL((rms_silu_kernel<16, XF32>), dim3((unsigned)((P * 16 + 255) / 256)), dim3(256), 0, s,
+        hipLaunchKernelGGL((rms_silu_kernel<16, XF32>), dim3(rms_grid(P, 16)), dim3(256), 0, s,
                            x, gamma, (uint16_t*)y, P, C, do_silu);
     } else {
-        hipLaunchKernelGGL((rms_silu_kernel<64, XF32>), dim3((unsigned)((P * 64 + 255) / 256)), dim3(256), 0, s,
+        hipLaunchKernelGGL((rms_silu_kernel<64, XF32>), dim3(rms_grid(P, 64)), dim3(256), 0, s,
                            x, gamma, (uint16_t*)y, P, C, do_silu);
     }
     return omh_launch_status();

@@ -89,11 +89,13 @@ def test_vae_81_frames_encode_decode_480x832():
     z = vae.encode([clip])[0]
     assert z.shape == (16, LT, LH, LW) and z.dtype == torch.float32 and bool(torch.isfinite(z).all())
     assert torch.equal(vae.encode([clip])[0], z)                                   # not re-entrant, but repeatable
-    zp = vae.encode([clip[:, :41]])[0]                                             # causal: a prefix encodes alike
-    assert zp.shape == (16, 11, LH, LW) and rel_rms(zp, z[:, :11]) < 3e-2
+    # causal, and the kernel choice depends on the layer only (not on the frame count of a call): a prefix of the clip
+    # encodes to the same latent frames bit for bit
+    zp = vae.encode([clip[:, :41]])[0]
+    assert zp.shape == (16, 11, LH, LW) and torch.equal(zp, z[:, :11])
     video = vae.decode([z])[0]
     assert video.shape == (3, F, 480, 832) and bool(torch.isfinite(video).all())
     assert float(video.min()) >= -1.0 and float(video.max()) <= 1.0                # vae.py:566 clamp
     assert torch.equal(vae.decode([z])[0], video)
-    vp = vae.decode([z[:, :6]])[0]
-    assert vp.shape == (3, 21, 480, 832) and rel_rms(vp, video[:, :21]) < 3e-2
+    vp = vae.decode([z[:, :6]])[0]                                                 # ... and a prefix of the latent decodes alike
+    assert vp.shape == (3, 21, 480, 832) and torch.equal(vp, video[:, :21])

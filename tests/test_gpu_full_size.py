@@ -147,14 +147,12 @@ def test_sampler_step_full_size_matches_oracle():
     assert rel_rms(x, ref) < 1e-5
 
 
-def test_vae_full_size_temporal_causality(monkeypatch):
+def test_vae_full_size_temporal_causality():
     """Chunked causal decode / encode at 480x832 (vae.py:516-568): frame chunks see only the past, so a prefix of
-    the clip decodes (encodes) to the same leading frames as the whole clip — through the sliding-window history.
-    The conv tile family is pinned: the dispatch moves the latent-resolution convs from the 128x128 kernel to the
-    wide one once 4 latent frames are batched (another summation order: prefix and whole clip then differ by
-    bf16 rounding noise, 1.4 % after 30 layers, each as close to the oracle as the other —
-    tests/probes/vae_causality_probe2.py)."""
-    monkeypatch.setenv("OMH_CONV_TILE", "wide")
+    the clip decodes (encodes) to the same leading frames as the whole clip — through the sliding-window history —
+    bit for bit, with the default dispatch: the convolution kernel is chosen by the layer's geometry, not by the number
+    of frames a call carries (round 2 needed OMH_CONV_TILE pinned here: four batched latent frames moved the
+    latent-resolution layers to another tile family and summation order)."""
     vae_mod = importlib.import_module(PKG + ".wan.modules.vae")
     torch.manual_seed(4321)
     vae = vae_mod.WanVAE(vae_pth=None, device="cuda")
@@ -170,6 +168,30 @@ def test_vae_full_size_temporal_causality(monkeypatch):
     assert mu.shape == (16, 4, 60, 104) and bool(torch.isfinite(mu).all())
     mu_head = vae.encode([video[:, :5].contiguous()])[0]
     assert torch.equal(mu_head, mu[:, :2])
+
+
+def test_vae_full_area_parity_against_the_oracle():
+    """The VAE at the benchmark's FULL area, 480 x 832, against the CPU oracle (fp32): decode of a two-frame latent (the
+    'Rep' first chunk + one steady-state chunk through both temporal upsamples, vae.py:544-568) and encode of the
+    five frames it yields (:516-542).  Measured (profiles/r03_vae_full_area_parity.json): 9.2e-3 / 2.6e-3 rel-RMS — bf16
+    convolution operands under an fp32 trunk; the bounds are 2x that.  ~1 min of host time for the oracle."""
+    from oracle import wan_vae_oracle as V
+    vae_mod = importlib.import_module(PKG + ".wan.modules.vae")
+    torch.manual_seed(4321)
+    vae = vae_mod.WanVAE(vae_pth=None, device="cuda")
+    sd = {k: v.detach().float().cpu() for k, v in vae.model.state_dict().items()}
+    cfg = V.VAEConfig(dim=96)
+    z = torch.randn(16, 2, 60, 104, generator=torch.Generator().manual_seed(5))
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    ref = V.vae_decode(sd, cfg, z)
+    out = vae.decode([z.cuda()])[0].float().cpu()
+    assert out.shape == ref.shape == (3, 5, 480, 832)
+    assert rel_rms(out, ref) < 2e-2
+    video = ref.clamp(-1, 1)
+    mu_ref = V.vae_encode(sd, cfg, video)
+    mu = vae.encode([video.cuda()])[0].float().cpu()
+    assert mu.shape == mu_ref.shape == (16, 2, 60, 104)
+    assert rel_rms(mu, mu_ref) < 6e-3
 
 
 def test_training_step_full_size_properties():
