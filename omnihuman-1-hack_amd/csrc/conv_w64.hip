@@ -176,13 +176,13 @@ int launch_cw64(const omh_conv_args& a, int64_t M, hipStream_t s) {
 }  // namespace
 
 // 3x3 taps in (h, w), 1 or 3 in t, stride 1, "same" padding, no folded upsample / frame interleave, Cin % 32 == 0,
-// Cout = 96 or a multiple of 192, at least 3 stages, the residual (if any) in the output's type, 32-bit byte offsets.
+// Cout = 96 or a multiple of 192, at least 15 stages (13 are peeled at the head of the stream), the residual (if any) in the output's type, 32-bit byte offsets.
 bool omh_conv_w64_takes(const omh_conv_args& a) {
     const int64_t M = (int64_t)a.Tout * a.Hout * a.Wout;
     const int es = a.out_f32 ? 4 : 2;
     return a.KW == 3 && a.KH == 3 && (a.KT == 3 || a.KT == 1) && a.stride_hw == 1 && a.stride_t == 1 && !a.up2 &&
            a.pad_h == 1 && a.pad_w == 1 && a.Hout == a.Hin && a.Wout == a.Win && (a.Cin & 31) == 0 && a.split_n == 0 &&
-           a.Wout >= 3 && (a.Cout == 96 || a.Cout % 192 == 0) && a.KT * 3 * (a.Cin >> 5) >= 3 &&
+           a.Wout >= 3 && (a.Cout == 96 || a.Cout % 192 == 0) && a.KT * 3 * (a.Cin >> 5) >= 15 &&
            (!a.resid || (a.resid_f32 != 0) == (a.out_f32 != 0)) && (((uintptr_t)a.resid) & 15) == 0 &&
            (((uintptr_t)a.bias) & 15) == 0 && (int64_t)a.Win * a.Cin * 2 < (1 << 24) && a.Hin < 16384 && M < (1 << 24) &&
            (M + 1024) * a.Cout * es < 0x7fffffffLL && (int64_t)a.Tin * a.Hin * a.Win * a.Cin * 2 < 0x7fffffffLL &&

@@ -48,9 +48,44 @@ A_OFF2, A_Y, W_OFF, XADDR, WADDR, EDGE0, EDGE2, VOC, ROWMASK = 12, 20, 28, 37, 4
 FRAG = (56, 84)
 TMP = 112
 T = 56
-BIASV = 120
-RING_SLOTS = (168, 184, 200, 216, 232, 72, 88)    # residual tiles in flight: v[168:247] and the dead fragment buffers
-RING_DEPTH = int(os.environ.get("OMH_CW64_RING", len(RING_SLOTS)))
+BIASV = 72                                        # epilogue: the bias runs take over the dead fragment buffers
+V_RES_OFF, V_ST_OFF, V_ROWBIT, V_LANE, V_PAIR = 248, 249, 250, 251, 252    # v[248:253]: free during the k loop as well
+# The residual tile (the fp32 trunk a block's second convolution adds: 48 KiB per wave, 192 KiB per CU) is requested
+# DURING the k loop, one 32 x 32 tile per stage from the first 12 stages, into registers the loop does not use:
+# v[120:247] (8 tiles) and a[192:255] (4 tiles; VMEM loads write AGPRs directly).  Round 2 requested it in the epilogue
+# through a ring seven tiles deep: with every request an HBM miss, the CU's ~64 lines in flight bound the read to
+# ~10 B/clk and the matrix pipe sat idle for 15 us per tile (0.32 vs 0.39 of the MFMA peak, fp32-trunk kinds vs bf16).
+UNROLL = 13                                       # stages peeled at the head of the loop (12 carry a tile's requests)
+
+
+def res_slot(n, kind):
+    if kind == "bf16":
+        return "v", 120 + 8 * n
+    return ("v", 120 + 16 * n) if n < 8 else ("a", 192 + 16 * (n - 8))
+
+
+def reg(bank, lo, n=1):
+    return f"{bank}{lo}" if n == 1 else f"{bank}[{lo}:{lo + n - 1}]"
+
+
+def res_request(n, kind):
+    """Instructions that request residual tile n = 3 j + i (v248 = the lane's byte offset in row block j: the row
+    block goes in the VGPR, not in the soffset, because the range check sees only voffset + inst_offset and tile 0's
+    lane of row -1 must be out of range for j = 0 ONLY)."""
+    i = n % NI
+    es = 2 if kind == "bf16" else 4
+    bank, base = res_slot(n, kind)
+    out = []
+    if n and i == 0:
+        out.append(f"v_add_u32 v{V_RES_OFF}, {S_JSTEP}, v{V_RES_OFF}")
+    for p in range(2):
+        if kind == "bf16":
+            out.append(f"buffer_load_dwordx4 {reg(bank, base + p * 4, 4)}, v{V_RES_OFF}, %[rres], 0 offen offset:{(i * 32 + 16 * p) * es}")
+        else:
+            for q in range(2):
+                out.append(f"buffer_load_dwordx4 {reg(bank, base + p * 8 + q * 4, 4)}, v{V_RES_OFF}, %[rres], 0 offen "
+                           f"offset:{(i * 32 + 16 * p) * es + q * 16}")
+    return out
 
 
 def vr(lo, n=1):
@@ -175,9 +210,6 @@ def group_sched(G, buf, first, reads_next, dma_instrs, ands_next):
     return out
 
 
-SCHED = os.environ.get("OMH_CW64_SCHED", "fine")      # "coarse": round-2's first schedule (whole pieces after an MFMA)
-
-
 def dma_pieces(NA, NB):
     """The 13 LDS-DMA pieces of the stage (s83 channel block, s84 kh, offsets s81 / s82) into the buffer at s80; then
     the scalar state moves on to the next stage.  Returns a list of op lists."""
@@ -238,14 +270,16 @@ def advance(e):
         e(f"v_add_u32 v{r_}, s92, v{r_}")
 
 
-def main_loop(e, NA, NB):
+def main_loop(e, NA, NB, kind):
     NP = NA + NB
+    R = 2 if kind == "bf16" else 4                               # VMEM instructions of one residual tile
     # the lane table, written to LDS by the C++ prologue
     for k in range(11):
         e(f"ds_read_b128 {vr(12 + 4 * k, 4)}, %[vtab] offset:{16 * k}")
     e(f"v_mov_b32 v{TMP + 4}, 0x80000000")                        # an offset outside every descriptor
     e("s_waitcnt lgkmcnt(0)")
     e("s_barrier")                                               # the stages overwrite the table
+    e(f"v_mov_b32 v{V_RES_OFF}, v{VOC}")                          # residual requests: the lane's row in row block 0
     for s_, v_ in (("s80", 0), ("s81", 0), ("s82", 0), ("s83", 0), ("s84", 0), ("s89", 0), ("s97", STAGE),
                    ("s98", (-(NSTAGES - 1) * STAGE) & 0xffffffff)):
         e(f"s_mov_b32 {s_}, {v_}")
@@ -256,47 +290,40 @@ def main_loop(e, NA, NB):
                 e(op[1])
     e(f"s_waitcnt vmcnt({NP})")                                  # stage 0 has landed
     e("s_barrier")
-    if SCHED == "fine":
-        LOOP_PENDING = linearize(e, frag_reads(0, 0) + and_ops(0, 0, 0), [])
-    else:
-        LOOP_PENDING = linearize(e, frag_reads(0, 0), [])
-    e(f"s_sub_u32 s85, {S_NS}, 2")                               # steps that fetch a stage two ahead (>= 1)
+    LOOP_PENDING = linearize(e, frag_reads(0, 0) + and_ops(0, 0, 0), [])
+    e(f"s_sub_u32 s85, {S_NS}, 2")                               # steps that fetch a stage two ahead (>= UNROLL)
 
-    def body(mode, first=False):
+    def body(mode, first=False, res_tile=None, r_prev=0):
         """One stage = 6 groups of 12 MFMAs.  Groups 0..4: MFMAs || reads of the next group || (mode "full") the 13
-        DMA pieces of the stage two ahead.  Then: the NEXT stage has landed (counted vmcnt), barrier (every wave has
-        read this stage), addresses advance, group 5 || reads of the next stage's group 0.  mode "last": the final
-        stage, nothing to wait for or read ahead."""
+        DMA pieces of the stage two ahead.  Then: the NEXT stage has landed (counted vmcnt: the in-order counter may
+        leave the r_prev residual requests of the previous stage's tail and this stage's pieces outstanding),
+        barrier (every wave has read this stage), addresses advance, group 5 || reads of the next stage's group 0 ||
+        the requests of residual tile res_tile.  mode "last": the final stage, nothing to wait for or read ahead."""
         pend = LOOP_PENDING
         dm = pieces if (mode == "full" and ABL != "dma") else []
         per = [dm[0:4], dm[4:7], dm[7:10], dm[10:13], dm[13:]] if dm else [[]] * 5
         for G in range(5):
             reads = frag_reads(G + 1, (G + 1) & 1) if ABL != "reads" else []
-            if SCHED == "fine":
-                flat = [op for piece in per[G] for op in piece]
-                ops = group_sched(G, G & 1, first and G == 0, reads, flat, and_ops(G + 1, (G + 1) & 1, 0))
-            else:
-                ops = spread(group_ops(G, G & 1, first=(first and G == 0)), [[r] for r in reads], 0, 8)
-                ops = spread_keep(ops, per[G])
+            flat = [op for piece in per[G] for op in piece]
+            ops = group_sched(G, G & 1, first and G == 0, reads, flat, and_ops(G + 1, (G + 1) & 1, 0))
             pend = linearize(e, ops, pend)
         if mode == "last":
-            linearize(e, group_sched(5, 1, False, [], [], []) if SCHED == "fine" else group_ops(5, 1), pend)
+            linearize(e, group_sched(5, 1, False, [], [], []), pend)
             return
-        e(f"s_waitcnt vmcnt({NP if (mode == 'full' and ABL != 'dma') else 0})")
+        e(f"s_waitcnt vmcnt({(NP if (mode == 'full' and ABL != 'dma') else 0) + r_prev})")
         e("s_waitcnt lgkmcnt(0)")
         if ABL != "bar":
             e("s_barrier")
         advance(e)
-        if SCHED == "fine":
-            pend = linearize(e, group_sched(5, 1, False, frag_reads(0, 0), [], and_ops(0, 0, 0)), [])
-        else:
-            pend = linearize(e, spread(group_ops(5, 1), [[r] for r in frag_reads(0, 0)], 0, 10), [])
+        req = [("x", ln) for ln in res_request(res_tile, kind)] if res_tile is not None else []
+        pend = linearize(e, group_sched(5, 1, False, frag_reads(0, 0), req, and_ops(0, 0, 0)), [])
         assert pend == LOOP_PENDING, (pend, LOOP_PENDING)
 
     LOOP = e.lab("loop")
     REST = e.lab("rest")
-    body("full", first=True)
-    e("s_sub_u32 s85, s85, 1")
+    for k in range(UNROLL):                                      # the head of the loop, peeled: tile k's residual
+        body("full", first=(k == 0), res_tile=(k if k < NTILES else None), r_prev=(R if 0 < k <= NTILES else 0))
+    e(f"s_sub_u32 s85, s85, {UNROLL}")
     e("s_cmp_eq_u32 s85, 0")
     e(f"s_cbranch_scc1 {REST}")
     e.label(LOOP)
@@ -332,88 +359,61 @@ def spread_keep(ops, extras):
 NTILES = NI * NJ
 
 
-def res_loads(e, n, kind, issued):
-    """Residual values of tile n = 3 j + i -> ring slot n % RING_DEPTH (v117 = the lane's offset in its row block: the row block
-    goes in the VGPR, not in the soffset, because the range check sees only voffset + inst_offset and tile 0's lane of
-    row -1 must be out of range for j = 0 ONLY)."""
-    i = n % NI
-    es = 2 if kind == "bf16" else 4
-    for p in range(2):
-        if kind == "bf16":
-            e(f"buffer_load_dwordx4 {vr(RING_SLOTS[n % RING_DEPTH] + p * 4, 4)}, v117, %[rres], 0 offen offset:{(i * 32 + 16 * p) * es}")
-            issued.append(("L", n))
-        else:
-            for q in range(2):
-                e(f"buffer_load_dwordx4 {vr(RING_SLOTS[n % RING_DEPTH] + p * 8 + q * 4, 4)}, v117, %[rres], 0 offen "
-                  f"offset:{(i * 32 + 16 * p) * es + q * 16}")
-                issued.append(("L", n))
-
-
 def epilogue(e, kind):
     """y = acc + bias (+ residual), bf16 or fp32 (wide_epilogue's order).  After the permlane widening lane (r, h)
-    holds, per tile (i, j) and run p, the 8 couts 32 i + 16 p + 8 h .. of voxel row 32 j + r of the wave's patch."""
+    holds, per tile (i, j) and run p, the 8 couts 32 i + 16 p + 8 h .. of voxel row 32 j + r of the wave's patch.
+    The residual tiles were requested during the k loop (res_request): nothing to wait for but the bias."""
     es = 2 if kind == "bf16" else 4
-    per_tile = 2 if kind == "bf16" else 4                        # VMEM instructions per tile, loads and stores alike
-    e("v_mbcnt_lo_u32_b32 v112, -1, 0")
-    e("v_mbcnt_hi_u32_b32 v112, -1, v112")                       # lane
-    e("v_lshrrev_b32 v112, 5, v112")
-    e("v_lshlrev_b32 v112, 5, v112")                             # 32 h bytes = 8 h floats
+    e(f"v_mbcnt_lo_u32_b32 v{V_LANE}, -1, 0")
+    e(f"v_mbcnt_hi_u32_b32 v{V_LANE}, -1, v{V_LANE}")             # lane
+    e(f"v_lshrrev_b32 v{V_LANE}, 5, v{V_LANE}")
+    e(f"v_lshlrev_b32 v{V_LANE}, 5, v{V_LANE}")                   # 32 h bytes = 8 h floats
     for i in range(NI):
         for p in range(2):
             for q in range(2):
-                e(f"buffer_load_dwordx4 {vr(BIASV + (2 * i + p) * 8 + 4 * q, 4)}, v112, %[rbias], 0 offen "
+                e(f"buffer_load_dwordx4 {vr(BIASV + (2 * i + p) * 8 + 4 * q, 4)}, v{V_LANE}, %[rbias], 0 offen "
                   f"offset:{(32 * i + 16 * p) * 4 + 16 * q}")
-    e(f"v_mov_b32 v116, v{VOC}")                                 # store offset of the lane's row in row block j
-    e(f"v_mov_b32 v117, v{VOC}")                                 # the same for the residual loads, two tiles ahead
-    issued = []                                                  # VMEM instructions in issue order (the bias loads are older)
-    D = RING_DEPTH - 1                                           # tiles requested ahead: per-CU read bandwidth = bytes in flight / latency
-
-    def request(n):
-        if n < NTILES:
-            if n and n % NI == 0:
-                e(f"v_add_u32 v117, {S_JSTEP}, v117")
-            res_loads(e, n, kind, issued)
-
-    for n in range(D):
-        request(n)
+    e(f"v_mov_b32 v{V_ST_OFF}, v{VOC}")                           # store offset of the lane's row in row block j
     for n in range(NTILES):
         j, i = divmod(n, NI)
         t = i * NJ + j
         if i == 0 and j:
-            e(f"v_add_u32 v116, {S_JSTEP}, v116")
-        request(n + D)
+            e(f"v_add_u32 v{V_ST_OFF}, {S_JSTEP}, v{V_ST_OFF}")
         for r_ in range(16):
             e(f"v_accvgpr_read_b32 v{T + r_}, a{t * 16 + r_}")
         e("s_nop 1")
         for q0 in (0, 2):                                        # quads (0,1), (2,3) -> two runs of 8 consecutive couts
             for r_ in range(4):
                 e(f"v_permlane32_swap_b32 v{T + 4 * q0 + r_}, v{T + 4 * (q0 + 1) + r_}")
-        last = max(k for k, tag in enumerate(issued) if tag == ("L", n))
-        e(f"s_waitcnt vmcnt({min(63, len(issued) - last - 1)})")     # in-order counter: tile n's residual has landed
-        e(f"v_bfe_u32 v113, v{ROWMASK}, {j}, 1")                  # this lane's row of the strip is an output row
-        e("v_cmp_ne_u32 vcc, 0, v113")
+        bank, rbase = res_slot(n, kind)
+        if bank == "a":                                          # parked in AGPRs: into the slot tile n - 8 has left
+            for r_ in range(16):
+                e(f"v_accvgpr_read_b32 v{120 + 16 * (n - 8) + r_}, a{rbase + r_}")
+            rbase = 120 + 16 * (n - 8)
+        if n == 0:
+            e("s_waitcnt vmcnt(0)")                              # the bias runs (and, older, every residual tile)
+        e(f"v_bfe_u32 v{V_ROWBIT}, v{ROWMASK}, {j}, 1")           # this lane's row of the strip is an output row
+        e(f"v_cmp_ne_u32 vcc, 0, v{V_ROWBIT}")
         e("s_and_saveexec_b64 s[86:87], vcc")
         for p in range(2):
             v0 = T + 8 * p
             b0 = BIASV + (2 * i + p) * 8
-            r0 = RING_SLOTS[n % RING_DEPTH] + (p * 4 if kind == "bf16" else p * 8)
+            r0 = rbase + (p * 4 if kind == "bf16" else p * 8)
             for r_ in range(0, 8, 2):
                 e(f"v_pk_add_f32 {vr(v0 + r_, 2)}, {vr(v0 + r_, 2)}, {vr(b0 + r_, 2)}")
             if kind == "bf16":
                 for r_ in range(4):                              # residual bf16 pairs -> fp32, added after the bias
-                    e(f"v_lshlrev_b32 v114, 16, v{r0 + r_}")
-                    e(f"v_and_b32 v115, 0xffff0000, v{r0 + r_}")
-                    e(f"v_pk_add_f32 {vr(v0 + 2 * r_, 2)}, {vr(v0 + 2 * r_, 2)}, v[114:115]")
+                    e(f"v_lshlrev_b32 v{V_PAIR}, 16, v{r0 + r_}")
+                    e(f"v_and_b32 v{V_PAIR + 1}, 0xffff0000, v{r0 + r_}")
+                    e(f"v_pk_add_f32 {vr(v0 + 2 * r_, 2)}, {vr(v0 + 2 * r_, 2)}, v[{V_PAIR}:{V_PAIR + 1}]")
                 for r_ in range(4):
                     e(f"v_cvt_pk_bf16_f32 v{v0 + r_}, v{v0 + 2 * r_}, v{v0 + 2 * r_ + 1}")
-                e(f"buffer_store_dwordx4 {vr(v0, 4)}, v116, %[ry], 0 offen offset:{(i * 32 + 16 * p) * es}")
-                issued.append(("S", n))
+                e(f"buffer_store_dwordx4 {vr(v0, 4)}, v{V_ST_OFF}, %[ry], 0 offen offset:{(i * 32 + 16 * p) * es}")
             else:
                 for r_ in range(0, 8, 2):
                     e(f"v_pk_add_f32 {vr(v0 + r_, 2)}, {vr(v0 + r_, 2)}, {vr(r0 + r_, 2)}")
-                e(f"buffer_store_dwordx4 {vr(v0, 4)}, v116, %[ry], 0 offen offset:{(i * 32 + 16 * p) * es}")
-                e(f"buffer_store_dwordx4 {vr(v0 + 4, 4)}, v116, %[ry], 0 offen offset:{(i * 32 + 16 * p) * es + 16}")
-                issued += [("S", n), ("S", n)]
+                e(f"buffer_store_dwordx4 {vr(v0, 4)}, v{V_ST_OFF}, %[ry], 0 offen offset:{(i * 32 + 16 * p) * es}")
+                e(f"buffer_store_dwordx4 {vr(v0 + 4, 4)}, v{V_ST_OFF}, %[ry], 0 offen offset:{(i * 32 + 16 * p) * es + 16}")
         e("s_nop 1")
         e("s_mov_b64 exec, s[86:87]")
 
@@ -421,7 +421,7 @@ def epilogue(e, kind):
 def generate(cfg, kind):
     e = Emit(cfg + kind)
     NA, NB = CONFIGS[cfg]
-    main_loop(e, NA, NB)
+    main_loop(e, NA, NB, kind)
     epilogue(e, kind)
     return e
 

@@ -69,7 +69,8 @@ def test_conv_cl_matches_torch(ops, cfg, tile, monkeypatch):
 @pytest.mark.parametrize("cfg", [
     dict(Cin=96, Cout=96, T=2, H=12, W=20, KT=3),        # P (512 x 96): one ragged tile, 27 stages
     dict(Cin=96, Cout=96, T=3, H=24, W=27, KT=3),        # P: 1944 voxels = 3.8 tiles of 510
-    dict(Cin=32, Cout=96, T=3, H=17, W=20, KT=1),        # P: exactly two tiles, the minimum of 3 stages
+    dict(Cin=160, Cout=96, T=3, H=17, W=20, KT=1),       # P: exactly two tiles, the minimum of 15 stages (no rolled loop)
+    dict(Cin=64, Cout=96, T=2, H=9, W=40, KT=3),         # P: 18 stages = the 13 peeled + 3 rolled + 2
     dict(Cin=192, Cout=192, T=1, H=20, W=31, KT=3),      # Q (256 x 192)
     dict(Cin=64, Cout=384, T=2, H=11, W=13, KT=3),       # Q: two cout tiles
     dict(Cin=384, Cout=384, T=1, H=9, W=29, KT=3),       # Q: 12 channel blocks per tap pair
@@ -100,13 +101,14 @@ def test_conv_cl_w64_equals_the_kw_shared_kernel(ops, cfg, monkeypatch):
 
 def test_conv_cl_w64_random_shapes_equal_the_kw_shared_kernel(ops, monkeypatch):
     """Seeded sweep: 24 random (Cin, Cout, T, H, W, KT) within the stream kernel's domain — image rows as short as 3
-    voxels, volumes smaller than one tile, ragged last tiles, 1 to 4 channel blocks — bit for bit against the 8-wave
+    voxels, volumes smaller than one tile, ragged last tiles, 15 to 36 stages — bit for bit against the 8-wave
     kernel, bf16 and fp32-trunk outputs."""
     import random
     rng = random.Random(20260929)
     for case in range(24):
-        Cin, Cout = rng.choice((32, 64, 96, 128)), rng.choice((96, 192, 384))
-        T, H, W, KT = rng.randint(1, 3), rng.randint(1, 40), rng.randint(3, 40), rng.choice((1, 3))
+        KT, Cout = rng.choice((1, 3)), rng.choice((96, 192, 384))
+        Cin = rng.choice((64, 96, 128)) if KT == 3 else rng.choice((160, 192, 256))       # >= 15 stages: the stream's domain
+        T, H, W = rng.randint(1, 3), rng.randint(1, 40), rng.randint(3, 40)
         torch.manual_seed(case)
         x = _bf(torch.randn(KT - 1 + T, H, W, Cin, device="cuda"))
         wp = _bf(torch.randn(Cout, KT * 9 * Cin, device="cuda") / (Cin * KT * 9) ** 0.5)
