@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OMH_ABI_VERSION 5
+#define OMH_ABI_VERSION 6
 
 #define OMH_E_BADARG   (-1)   /* null pointer / non-positive size             */
 #define OMH_E_ALIGN    (-2)   /* pointer or leading dimension not aligned     */
@@ -40,6 +40,13 @@ typedef void* omh_stream_t;   /* hipStream_t */
 int omh_abi_version(void);
 /* gfx arch string the library was built for ("gfx950"). */
 const char* omh_build_arch(void);
+/* Deterministic mode (ABI v6; debugging aid for the training step).  The backward's few
+ * remaining fp32 atomics — column sums of the bias gradients, the gate gradient of omh_gated_residual_bwd, the
+ * split-K of omh_gemm_bf16_tn, the input gradient of omh_dense_f32_bwd — make two runs of one step differ in the last
+ * bits.  With the mode on, each of those launches gives every output element to ONE workgroup that adds in a fixed
+ * order (no split K, one row block): the whole step then repeats bit for bit, at a few percent of its speed.
+ * on < 0 only queries.  The initial value is the environment's OMH_DETERMINISTIC (0 / 1).  Returns the mode in force. */
+int omh_set_deterministic(int on);
 
 /* ------------------------------------------------------------------------
  * GEMM  C[m][n] = epilogue( sum_k A[m][k] * B[n][k] )          (bf16 MFMA)

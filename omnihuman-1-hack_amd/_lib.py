@@ -21,7 +21,7 @@ class OmhError(RuntimeError):
     pass
 
 
-ABI_VERSION = 5          # == OMH_ABI_VERSION of include/omh.h; checked against the loaded library below
+ABI_VERSION = 6          # == OMH_ABI_VERSION of include/omh.h; checked against the loaded library below
 
 
 def _load():
@@ -141,6 +141,7 @@ BIAS_NONE, BIAS_N, BIAS_M = 0, 1, 2
 
 _SIGS = {
     "omh_abi_version": (i32, []),
+    "omh_set_deterministic": (i32, [i32]),
     "omh_build_arch": (C.c_char_p, []),
     "omh_gemm_bf16": (i32, [C.POINTER(GemmArgs), vp]),
     "omh_gemm_bf16_tn": (i32, [C.POINTER(GemmTnArgs), vp]),

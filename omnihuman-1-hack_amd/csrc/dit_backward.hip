@@ -54,7 +54,7 @@ void colsum_kernel(const T* __restrict__ x, int64_t ld, float* __restrict__ out,
 // Up to OMH_COLSUM_MAX column sums in ONE launch (the ~10 bias gradients of a block backward: each alone is a
 // 10-15 us latency- and atomics-bound kernel; together they overlap).  Descriptors travel in the kernel arguments.
 __global__ __launch_bounds__(256)
-void colsum_multi_kernel(const omh_colsum_batch b) {
+void colsum_multi_kernel(const omh_colsum_batch b, const int rpb) {
     int e = 0, local = blockIdx.x;
 #pragma unroll 1
     while (e + 1 < b.n && local >= b.blocks[e]) { local -= b.blocks[e]; ++e; }
@@ -63,8 +63,8 @@ void colsum_multi_kernel(const omh_colsum_batch b) {
     const int c = (local % col_chunks) * 256 + threadIdx.x;
     if (c >= C) return;
     const int64_t R = b.R[e], ld = b.ld[e];
-    const int64_t r0 = (int64_t)(local / col_chunks) * 32;
-    const int64_t r1 = min(R, r0 + 32);
+    const int64_t r0 = (int64_t)(local / col_chunks) * rpb;
+    const int64_t r1 = min(R, r0 + rpb);
     float s = 0.f;
     if (b.is_bf16[e]) {
         const uint16_t* x = (const uint16_t*)b.x[e];
@@ -498,7 +498,8 @@ extern "C" int omh_transpose_bf16(const void* in, void* out, int32_t R, int32_t 
 extern "C" int omh_colsum_accum(const void* x, int32_t is_bf16, int64_t ld, float* out, int64_t R, int32_t C,
                                 omh_stream_t stream) {
     if (!x || !out || R <= 0 || C <= 0 || ld < C) return OMH_E_BADARG;
-    const int rpb = 32;
+    if (omh_deterministic() && R > 0x7fffffff) return OMH_E_SHAPE;
+    const int rpb = omh_deterministic() ? (int)R : 32;               // deterministic: one block adds a column's rows in order
     dim3 grid((C + 255) / 256, (unsigned)((R + rpb - 1) / rpb));
     omh_clear_status();
     if (is_bf16)
@@ -514,14 +515,15 @@ extern "C" int omh_colsum_accum_multi(const omh_colsum_batch* batch, omh_stream_
     if (!batch || batch->n <= 0 || batch->n > OMH_COLSUM_MAX) return OMH_E_BADARG;
     omh_colsum_batch b = *batch;
     int64_t total = 0;
+    const int rpb = omh_deterministic() ? 0x40000000 : 32;           // deterministic: one row block per column chunk
     for (int i = 0; i < b.n; ++i) {
         if (!b.x[i] || !b.out[i] || b.R[i] <= 0 || b.C[i] <= 0 || b.ld[i] < b.C[i]) return OMH_E_BADARG;
-        b.blocks[i] = (int32_t)(((b.C[i] + 255) / 256) * ((b.R[i] + 31) / 32));
+        b.blocks[i] = (int32_t)(((b.C[i] + 255) / 256) * ((b.R[i] + rpb - 1) / rpb));
         total += b.blocks[i];
     }
     if (total > 0x7fffffff) return OMH_E_SHAPE;
     omh_clear_status();
-    hipLaunchKernelGGL(colsum_multi_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, b);
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, b, rpb);
     return omh_launch_status();
 }
 
@@ -595,6 +597,7 @@ extern "C" int omh_gated_residual_bwd(const float* dx, const void* y_bf16, void*
     if (!dx || !dy_bf16 || rows <= 0 || dim <= 0 || rows_per_batch <= 0) return OMH_E_BADARG;
     int rpb = 32;
     while (rows_per_batch % rpb) rpb >>= 1;          // blocks never straddle two batch elements
+    if (omh_deterministic() && dgate && rows_per_batch <= 0x7fffffff) rpb = (int)rows_per_batch;   // one adder per dgate element
     dim3 grid((dim + 255) / 256, (unsigned)((rows + rpb - 1) / rpb));
     omh_clear_status();
     hipLaunchKernelGGL(gated_resid_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dx, (const uint16_t*)y_bf16,
@@ -688,7 +691,7 @@ extern "C" int omh_dense_f32_bwd(const float* x, const float* W, const float* dy
                            (hipStream_t)stream, x, dy, dW_accum, db_accum, B, N, K, act_in);
     if (dx) {
         if (!dx_accumulate) omh_zero_f32(dx, 1, (int64_t)B * K, (int64_t)B * K, (hipStream_t)stream);
-        const int n_chunk = 64;
+        const int n_chunk = omh_deterministic() ? N : 64;
         dim3 grid((unsigned)(((int64_t)B * K + 255) / 256), (unsigned)((N + n_chunk - 1) / n_chunk));
         hipLaunchKernelGGL(dense_f32_bwd_x_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, W, dy, dx, B, N, K,
                            act_in, n_chunk);

@@ -9,6 +9,7 @@
 //   patchify/unpatchify :463,515-518 / :565-588
 //   dense_f32, sinusoid :17-27, 469-471, 526-528
 #include "omh_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -433,6 +434,19 @@ extern "C" int omh_cfg_unipc_step(const float* cond, const float* uncond, const 
                        last, m1, m2, mt_out, xc_out, x_next, n, guide, sigma, use_corr, ca_last, ca_m1, ca_m2, ca_mt,
                        pb_x, pb_mt, pb_m1);
     return omh_launch_status();
+}
+
+static int g_deterministic = -1;                                     // -1: not read from the environment yet
+bool omh_deterministic() {
+    if (g_deterministic < 0) {
+        const char* e = getenv("OMH_DETERMINISTIC");
+        g_deterministic = (e && e[0] == '1') ? 1 : 0;
+    }
+    return g_deterministic == 1;
+}
+extern "C" int omh_set_deterministic(int on) {
+    if (on >= 0) g_deterministic = on ? 1 : 0;
+    return omh_deterministic() ? 1 : 0;
 }
 
 extern "C" int omh_abi_version(void) { return OMH_ABI_VERSION; }

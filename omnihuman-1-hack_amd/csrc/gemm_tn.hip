@@ -238,6 +238,7 @@ int launch_tn(const omh_gemm_tn_args& a, hipStream_t s) {
     // split only when the tiles leave at least half the chip idle (more splits measured slower: 1536^2 x 6240 60 us
     // with 3, 77 with 4; 3072 x 1536 97 us unsplit, 125 with 2 — the atomics and the zero fill cost more than they win)
     int splits = spe ? atoi(spe) : (tiles * 2 <= slots ? slots / tiles : 1);
+    if (omh_deterministic()) splits = 1;                              // no atomics: every tile its whole K range
     splits = splits < 1 ? 1 : (splits > 8 ? 8 : splits);
     if (nk < 16 * splits) splits = nk / 16 < 1 ? 1 : nk / 16;        // at least 16 k-steps per split (measured: 9 lose)
     g.ksteps_per_split = (nk + splits - 1) / splits;

@@ -103,6 +103,9 @@ static inline void omh_zero_f32(float* p, int64_t rows, int64_t cols, int64_t ld
     hipLaunchKernelGGL(omh_zero_f32_kernel, dim3((unsigned)g), dim3(256), 0, s, p, rows, cols, ld);
 }
 
+// omh_set_deterministic()'s state (dit_elementwise.hip): launchers that combine partial sums with atomics ask it
+bool omh_deterministic();
+
 // hipGetLastError() reports the last error of ANY earlier runtime call on this
 // thread (e.g. a probe made by the host framework): clear it before a launch
 // so the status returned after the launch belongs to that launch only.

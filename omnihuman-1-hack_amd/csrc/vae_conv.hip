@@ -724,7 +724,8 @@ extern "C" int omh_conv_cl_bf16(const omh_conv_args* args, omh_stream_t stream) 
     const bool narrow = a.Cout <= 96;
     const int64_t Mn = (int64_t)2 * a.Hout * a.Wout;
     const int64_t wide_tiles = narrow ? (Mn + 511) / 512 : ((Mn + 255) / 256) * ((a.Cout + 191) / 192);
-    bool wide = wide_tiles >= 192;
+    const char* wmin = getenv("OMH_CONV_WIDE_MIN");                  // A/B timing of the threshold
+    bool wide = wide_tiles >= (wmin ? atoi(wmin) : 96);              // e.g. 384 channels at 60 x 104: 98
     if (force && force[0] == 'w') wide = true;
     if (force && force[0] == 's') wide = false;
     if (((uintptr_t)a.resid & 15) || ((uintptr_t)a.bias & 3)) wide = false;

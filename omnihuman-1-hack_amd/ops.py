@@ -414,6 +414,14 @@ def cast_bf16_strided(x: torch.Tensor, out: torch.Tensor):
     return out
 
 
+def set_deterministic(on=None) -> bool:
+    """omh_set_deterministic: with True the few launches of the backward that combine partial sums with fp32 atomics
+    (bias-gradient column sums, gate gradients, split-K weight gradients, the time-embedding MLP's input gradient)
+    give each output element to one workgroup — a training step then repeats bit for bit (slower; debugging aid).
+    None only queries.  Returns the mode in force.  Also settable with OMH_DETERMINISTIC=1 in the environment."""
+    return bool(lib.omh_set_deterministic(-1 if on is None else int(bool(on))))
+
+
 def colsum_accum(x: torch.Tensor, out: torch.Tensor):
     """out[c] += sum_r x[r][c]; x bf16/fp32 [R, C]."""
     _dev(x, out)

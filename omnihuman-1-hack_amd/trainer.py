@@ -64,15 +64,26 @@ def training_step(batch, distilled_model, num_train_timesteps=1000, gradient_acc
 # ----------------------------------------------------------------------------------------------------------------
 # Checkpoint save / resume in the trainers' formats (seaweed_apt/distilled_trainer.py:153-178, 199-231): the
 # ``accelerator.save_state`` directory layout (model.safetensors, optimizer.bin, scaler.pt, random_states_<rank>.pkl)
-# next to the reference's manual fallback file (pytorch_model.bin = {'model', 'optimizer', 'scaler', 'step',
+# OR the reference's manual fallback file (pytorch_model.bin = {'model', 'optimizer', 'scaler', 'step',
 # 'epoch'}), and the EMA weights as a plain state dict (ema_model_step_<n>.pt / ema_model_epoch_<n>.pt /
 # ema_model_final.pt, read back by eval_ema.py:43-47 and wan_inference.py:59-63).  Host-side I/O only.
+def _numpy_safe_globals():
+    """What a numpy RNG state needs under torch.load(weights_only=True) (accelerate writes random_states_<rank>.pkl
+    with torch.save: python tuples, one uint32 ndarray, torch ByteTensors)."""
+    import numpy as np
+    core = getattr(np, "_core", None) or np.core
+    return [core.multiarray._reconstruct, np.ndarray, np.dtype, type(np.dtype(np.uint32))]
+
+
 def save_checkpoint(checkpoint_dir, model, optimizer=None, scaler_state=None, step: int = 0, epoch: int = 0, rank: int = 0,
-                    is_main_process: bool = True):
-    """Write ``checkpoint_dir`` so that either loader finds what it expects.  Every rank writes its RNG states
-    (as accelerate does); the main process writes the rest."""
+                    is_main_process: bool = True, manual_fallback: bool = False):
+    """Write ``checkpoint_dir`` in ONE of the reference's two layouts (distilled_trainer.py:153-178): the
+    ``accelerator.save_state`` directory (model.safetensors, optimizer.bin, scaler.pt, random_states_<rank>.pkl; step and
+    epoch in the small side file train_state.json) or, with ``manual_fallback``, the single pytorch_model.bin =
+    {'model', 'optimizer', 'scaler', 'step', 'epoch'} the reference writes when save_state fails.  The model is written
+    once.  Every rank writes its RNG states (as accelerate does); the main process writes the rest."""
+    import json
     import os
-    import pickle
     import random
     import numpy as np
     os.makedirs(checkpoint_dir, exist_ok=True)
@@ -80,73 +91,95 @@ def save_checkpoint(checkpoint_dir, model, optimizer=None, scaler_state=None, st
               "torch_manual_seed": torch.get_rng_state()}
     if torch.cuda.is_available():
         states["torch_cuda_manual_seed"] = torch.cuda.get_rng_state_all()
-    with open(os.path.join(checkpoint_dir, f"random_states_{rank}.pkl"), "wb") as fh:
-        pickle.dump(states, fh)
+    torch.save(states, os.path.join(checkpoint_dir, f"random_states_{rank}.pkl"))
     if not is_main_process:
         return checkpoint_dir
     sd = {k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}
+    opt_sd = optimizer.state_dict() if optimizer is not None else None
+    if manual_fallback:
+        torch.save({"model": sd, "optimizer": opt_sd, "scaler": scaler_state, "step": int(step), "epoch": int(epoch)},
+                   os.path.join(checkpoint_dir, "pytorch_model.bin"))
+        return checkpoint_dir
     try:
         from safetensors.torch import save_file
         save_file(sd, os.path.join(checkpoint_dir, "model.safetensors"), metadata={"format": "pt"})
-    except ImportError:                                       # accelerate's own fallback name
-        torch.save(sd, os.path.join(checkpoint_dir, "pytorch_model.bin.model"))
-    opt_sd = optimizer.state_dict() if optimizer is not None else None
+    except (ImportError, RuntimeError):                       # no safetensors / tied parameters: accelerate's fallback file
+        torch.save(sd, os.path.join(checkpoint_dir, "pytorch_model.bin"))
     if opt_sd is not None:
         torch.save(opt_sd, os.path.join(checkpoint_dir, "optimizer.bin"))
     if scaler_state is not None:
         torch.save(scaler_state, os.path.join(checkpoint_dir, "scaler.pt"))
-    torch.save({"model": sd, "optimizer": opt_sd, "scaler": scaler_state, "step": int(step), "epoch": int(epoch)},
-               os.path.join(checkpoint_dir, "pytorch_model.bin"))
+    with open(os.path.join(checkpoint_dir, "train_state.json"), "w") as fh:
+        json.dump({"step": int(step), "epoch": int(epoch)}, fh)
     return checkpoint_dir
 
 
 def load_checkpoint(checkpoint_dir, model, optimizer=None, rank: int = 0, restore_rng: bool = True):
     """Resume from a directory written by ``save_checkpoint``, by ``accelerator.save_state`` or by the reference's
-    manual fallback.  Returns ``{'step', 'epoch', 'scaler'}`` (what the files hold of them).  A torch.optim.AdamW
-    state (tensor ``step`` entries) loads into ``optim.AdamW`` as is."""
+    manual fallback.  Returns ``{'step', 'epoch', 'scaler', 'rng_restored'}`` (what the files hold of them).  A
+    torch.optim.AdamW state (tensor ``step`` entries) loads into ``optim.AdamW`` as is.  Every file is read with
+    ``weights_only=True`` (tensors and plain containers; the RNG file additionally numpy's array types): a checkpoint
+    directory is data, not code.  pytorch_model.bin is opened only when something is missing without it."""
+    import json
     import os
-    import pickle
     import random
     import numpy as np
-    info = {"step": 0, "epoch": 0, "scaler": None}
+    info = {"step": 0, "epoch": 0, "scaler": None, "rng_restored": False}
+    load = lambda path: torch.load(path, map_location="cpu", weights_only=True)
     manual = os.path.join(checkpoint_dir, "pytorch_model.bin")
     st_path = os.path.join(checkpoint_dir, "model.safetensors")
+    opt_path = os.path.join(checkpoint_dir, "optimizer.bin")
+    side = os.path.join(checkpoint_dir, "train_state.json")
     blob = None
-    if os.path.exists(manual):
-        blob = torch.load(manual, map_location="cpu", weights_only=False)
-        if not (isinstance(blob, dict) and "model" in blob):     # accelerate's pytorch_model.bin is the bare state dict
-            blob = {"model": blob}
+
+    def manual_blob():
+        nonlocal blob
+        if blob is None and os.path.exists(manual):
+            blob = load(manual)
+            if not (isinstance(blob, dict) and "model" in blob):  # accelerate's pytorch_model.bin is the bare state dict
+                blob = {"model": blob}
+        return blob or {}
+
     if os.path.exists(st_path):
         from safetensors.torch import load_file
         model.load_state_dict(load_file(st_path))
-    elif blob is not None:
+    elif "model" in manual_blob():
         model.load_state_dict(blob["model"])
     else:
         raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {checkpoint_dir}")
     if optimizer is not None:
-        opt_path = os.path.join(checkpoint_dir, "optimizer.bin")
-        opt_sd = torch.load(opt_path, map_location="cpu", weights_only=False) if os.path.exists(opt_path) else \
-            (blob or {}).get("optimizer")
+        opt_sd = load(opt_path) if os.path.exists(opt_path) else manual_blob().get("optimizer")
         if opt_sd is not None:
             optimizer.load_state_dict(opt_sd)
     sc = os.path.join(checkpoint_dir, "scaler.pt")
-    info["scaler"] = torch.load(sc, map_location="cpu", weights_only=False) if os.path.exists(sc) else (blob or {}).get("scaler")
-    if blob is not None:
+    info["scaler"] = load(sc) if os.path.exists(sc) else (blob or {}).get("scaler")
+    if os.path.exists(side):
+        with open(side) as fh:
+            st = json.load(fh)
+        info["step"], info["epoch"] = int(st.get("step", 0)), int(st.get("epoch", 0))
+    elif "step" in manual_blob():
         info["step"], info["epoch"] = int(blob.get("step", 0)), int(blob.get("epoch", 0))
     rs = os.path.join(checkpoint_dir, f"random_states_{rank}.pkl")
     if os.path.exists(rs):
-        with open(rs, "rb") as fh:
-            states = pickle.load(fh)
-        info["step"] = int(states.get("step", info["step"]))
-        if restore_rng:
-            random.setstate(states["random_state"])
-            np.random.set_state(states["numpy_random_seed"])
-            torch.set_rng_state(states["torch_manual_seed"])
-            if torch.cuda.is_available() and "torch_cuda_manual_seed" in states:
-                try:
-                    torch.cuda.set_rng_state_all(states["torch_cuda_manual_seed"])
-                except (RuntimeError, IndexError):                # saved on a different number of devices
-                    pass
+        try:
+            with torch.serialization.safe_globals(_numpy_safe_globals()):
+                states = load(rs)
+        except Exception as exc:                                  # not a torch.save file / types outside the allow-list
+            import warnings
+            warnings.warn(f"{rs}: RNG states not restored ({type(exc).__name__})")
+            states = None
+        if states is not None:
+            info["step"] = int(states.get("step", info["step"]))
+            if restore_rng:
+                random.setstate(states["random_state"])
+                np.random.set_state(states["numpy_random_seed"])
+                torch.set_rng_state(states["torch_manual_seed"])
+                if torch.cuda.is_available() and "torch_cuda_manual_seed" in states:
+                    try:
+                        torch.cuda.set_rng_state_all(states["torch_cuda_manual_seed"])
+                    except (RuntimeError, IndexError):            # saved on a different number of devices
+                        pass
+                info["rng_restored"] = True
     # parameters were rewritten: the packed bf16 copies are keyed on the parameters' versions (load_state_dict's copy_
     # bumps them), nothing else to invalidate
     return info
@@ -160,5 +193,5 @@ def save_ema(path, ema_model):
 
 def load_ema(path, model):
     """eval_ema.py:43-47 / wan_inference.py:59-63."""
-    model.load_state_dict(torch.load(path, map_location="cpu", weights_only=False))
+    model.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
     return model

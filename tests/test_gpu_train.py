@@ -332,7 +332,8 @@ def test_checkpoint_save_resume_in_the_trainers_formats(wan_model_mod, tmp_path)
     m_a, o_a = fresh()
     steps(m_a, o_a, 2)
     ck = trainer.save_checkpoint(str(tmp_path / "checkpoint_2"), m_a, o_a, step=2, epoch=0)
-    assert {"model.safetensors", "optimizer.bin", "pytorch_model.bin", "random_states_0.pkl"} <= set(os.listdir(ck))
+    assert {"model.safetensors", "optimizer.bin", "train_state.json", "random_states_0.pkl"} <= set(os.listdir(ck))
+    assert "pytorch_model.bin" not in os.listdir(ck)                          # the model is written once
     ema = trainer.save_ema(str(tmp_path / "ema_model_step_2.pt"), m_a)
     steps(m_a, o_a, 2)
     # (1) resume from the accelerate layout
@@ -343,11 +344,14 @@ def test_checkpoint_save_resume_in_the_trainers_formats(wan_model_mod, tmp_path)
     for (n, a), (_, b) in zip(m_a.named_parameters(), m_b.named_parameters()):
         assert rel_rms(b.detach(), a.detach()) < 1e-3, n
     assert int(o_b.state[next(iter(m_b.parameters()))]["step"]) == 4
-    # (2) the reference's manual fallback file alone
-    os.remove(os.path.join(ck, "model.safetensors"))
-    os.remove(os.path.join(ck, "optimizer.bin"))
+    assert info["rng_restored"]
+    # (2) the reference's manual fallback file alone (distilled_trainer.py:166-173)
+    m_a2, o_a2 = fresh()
+    steps(m_a2, o_a2, 2)
+    ck2 = trainer.save_checkpoint(str(tmp_path / "checkpoint_2_manual"), m_a2, o_a2, step=2, epoch=0, manual_fallback=True)
+    assert "pytorch_model.bin" in os.listdir(ck2) and "model.safetensors" not in os.listdir(ck2)
     m_c, o_c = fresh()
-    assert trainer.load_checkpoint(ck, m_c, o_c)["step"] == 2
+    assert trainer.load_checkpoint(ck2, m_c, o_c)["step"] == 2
     steps(m_c, o_c, 2)
     for (n, a), (_, c) in zip(m_a.named_parameters(), m_c.named_parameters()):
         assert rel_rms(c.detach(), a.detach()) < 1e-3, n
@@ -712,3 +716,44 @@ def test_gemm_tn_grouped(ops):
     many = [(dyf[:, :64], xs[0][:, :64], torch.zeros(64, 64, device="cuda"), False) for _ in range(15)]   # > one group
     ops.gemm_tn_grouped(many)
     assert all(torch.equal(m_[2], many[0][2]) for m_ in many)
+
+
+def test_deterministic_mode_repeats_a_training_step_bit_for_bit(wan_model_mod, ops):
+    """omh_set_deterministic (ABI v6): the launches that combine partial sums with fp32 atomics — bias-gradient column
+    sums, gate gradients, split-K weight gradients, the time-embedding MLP's input gradient — hand each output element
+    to one workgroup, so two backward passes from the same state give the SAME bits for every parameter; without the
+    mode they agree to the atomics' rounding noise only (and to that noise the two modes agree with each other).  The
+    model is wide enough (BASELINE config 3: two clips of the 1.3B model's first blocks) for split K and multi-block
+    column sums to occur."""
+    model_mod = importlib.import_module(PKG + ".wan.modules.model")
+    cfgs = importlib.import_module(PKG + ".wan.configs")
+    trainer = importlib.import_module(PKG + ".trainer")
+    torch.manual_seed(11)
+    kw = dict(cfgs.dit_kwargs(cfgs.t2v_1_3B))
+    kw["num_layers"] = 2
+    with torch.device("cuda"):
+        m = model_mod.WanModel(**kw)
+        torch.nn.init.xavier_uniform_(m.head.head.weight)
+    m.train()
+    g = torch.Generator(device="cuda").manual_seed(9)
+    batch = (torch.randn(2, 16, 1, 60, 104, device="cuda", generator=g),
+             torch.randn(2, 512, 4096, device="cuda", generator=g),
+             torch.randn(2, 16, 1, 60, 104, device="cuda", generator=g))
+
+    def grads():
+        for p in m.parameters():
+            p.grad = None
+        trainer.forward_backward(batch, m)
+        return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    assert ops.set_deterministic() is False
+    free = grads()
+    try:
+        assert ops.set_deterministic(True) is True
+        a, b = grads(), grads()
+    finally:
+        ops.set_deterministic(False)
+    assert a.keys() == b.keys() == free.keys() and len(a) > 20
+    for n in a:
+        assert torch.equal(a[n], b[n]), n
+        assert rel_rms(a[n], free[n]) < 1e-4, n
