@@ -717,8 +717,8 @@ class _HeadFn(torch.autograd.Function):
             dhh = _dgrad(dtok, _wT(head, "head", w))
             dx = torch.zeros(R, d, dtype=torch.float32, device=dev)
             d_hb = torch.zeros(B, 2, d, dtype=torch.float32, device=dev)
-            ops.layernorm_modulate_bwd_raw(ptr(x), ptr(dhh), ptr(dx), R, d, head.eps, 1.0, ptr(mod, d), ptr(e), d,
-                                           ptr(d_hb, d), ptr(d_hb, 0), 2 * d, S)
+            ops.layernorm_modulate_bwd2(x, dhh, dx, R, d, head.eps, 1.0, ptr(mod, d), ptr(e), d,
+                                        ptr(d_hb, d), ptr(d_hb, 0), 2 * d, S)
             dmod = torch.zeros(2 * d, dtype=torch.float32, device=dev)
             ops.colsum_accum(d_hb.view(B, 2 * d), dmod)
             for b in range(B):                       # e enters both the scale and the shift (model.py:357-358)

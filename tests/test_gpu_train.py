@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_rms
+from conftest import PKG, rel_rms
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -347,7 +347,7 @@ def test_checkpoint_save_resume_in_the_trainers_formats(wan_model_mod, tmp_path)
     assert info["rng_restored"]
     # (2) the reference's manual fallback file alone (distilled_trainer.py:166-173)
     m_a2, o_a2 = fresh()
-    steps(m_a2, o_a2, 2)
+    trainer.load_checkpoint(ck, m_a2, o_a2)                                    # the same step-2 state, rewritten
     ck2 = trainer.save_checkpoint(str(tmp_path / "checkpoint_2_manual"), m_a2, o_a2, step=2, epoch=0, manual_fallback=True)
     assert "pytorch_model.bin" in os.listdir(ck2) and "model.safetensors" not in os.listdir(ck2)
     m_c, o_c = fresh()
