@@ -351,7 +351,8 @@ def train_step_flops(S=1560, ffn_freeze=True, checkpoint=True, d=1536, f=8960, L
     return (L - frozen) * passes * blk + frozen * (passes * (blk - ffn) + ffn) + 3 * rest
 
 
-def train_bench(model, device, world, dist, steps=4, warmup=2, bsz=4, ffn_freeze=True, loss_quirk=True, checkpoint=True):
+def train_bench(model, device, world, dist, steps=4, warmup=2, bsz=4, ffn_freeze=True, loss_quirk=True, checkpoint=True,
+                policy="auto"):
     """BASELINE config 3: the distilled_trainer.py student step on a batch of [16,1,60,104] clips per GPU
     (forward + per-block recompute + backward on the HIP kernels, bucketed RCCL gradient all-reduce
     overlapped with the backward, fused AdamW).  Returns clips/s over all ranks.
@@ -362,16 +363,19 @@ def train_bench(model, device, world, dist, steps=4, warmup=2, bsz=4, ffn_freeze
     learning throughput: the un-quirked leg is reported beside it.
 
     ``checkpoint``: model.use_checkpoint — True = the reference trainer's default (use_gradient_checkpointing=True,
-    distilled_trainer.py:40,65: every block is re-run in the backward), False = the reference model's other branch
-    (model.py:549-553): activations kept in HBM (0.6 GB per block at 4 clips), no second forward pass.  The work
-    counted for the roofline figure follows the setting (the recompute is only counted where it is executed)."""
+    distilled_trainer.py:40,65), False = the reference model's other branch (model.py:549-553).  ``policy``:
+    model.checkpoint_policy, how this build honours a True flag: "auto" (its default) treats the flag as the memory
+    policy it is and keeps the activations when a step's worth of them fits in half of the free HBM (0.6 GB per block
+    at 4 clips: 18 GB of 288) — same gradients bit for bit, no second forward pass; "always" re-runs every block in the
+    backward like torch.utils.checkpoint.  The work counted for the roofline figure follows what was executed (the
+    recompute pass is only counted where it ran: ``activations_kept`` in the result)."""
     trainer = importlib.import_module(PKG + ".trainer")
     optim = importlib.import_module(PKG + ".optim")
     par = importlib.import_module(PKG + ".parallel")
     model.train().requires_grad_(True)
-    old_freeze, old_ckpt = model.reference_ffn_freeze, model.use_checkpoint
+    old_freeze, old_ckpt, old_policy = model.reference_ffn_freeze, model.use_checkpoint, getattr(model, "checkpoint_policy", "auto")
     model.reference_ffn_freeze = bool(ffn_freeze)
-    model.use_checkpoint = bool(checkpoint)
+    model.use_checkpoint, model.checkpoint_policy = bool(checkpoint), policy
     opt = optim.AdamW(model.parameters(), lr=5e-6, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
     red = par.BucketedGradAllReduce(model.parameters(), bucket_mb=256.0, force=bool(dist and world == 1)) if dist else None
     g = torch.Generator(device=device).manual_seed(7 + int(os.environ.get("RANK", 0)))
@@ -434,17 +438,18 @@ def train_bench(model, device, world, dist, steps=4, warmup=2, bsz=4, ffn_freeze
     if red is not None:
         red.remove()
     # give the weights and flags back as they were found (the optimizer stepped lr = 5e-6 a few times)
-    model.reference_ffn_freeze, model.use_checkpoint = old_freeze, old_ckpt
+    model.reference_ffn_freeze, model.use_checkpoint, model.checkpoint_policy = old_freeze, old_ckpt, old_policy
     model.eval().requires_grad_(False)
     del opt
-    fl = train_step_flops(1560, ffn_freeze, checkpoint)
+    kept = bool(model.__dict__.get("_kept_activations", not checkpoint))     # what the timed forwards did
+    fl = train_step_flops(1560, ffn_freeze, not kept)
     fwd = dit_forward_flops(1560)
     reducer_ran = red is not None
     return {"clips_per_s": round(world * bsz * steps / el, 3), "ms_per_step": round(el * 1e3 / steps, 2),
             "clips_per_gpu_step": bsz, "steps": steps, "finite_loss": bool(math.isfinite(float(loss))),
             "launch_mode": mode, "reference_ffn_freeze": bool(ffn_freeze), "reference_loss_quirk": bool(loss_quirk),
-            "use_checkpoint": bool(checkpoint),
-            "work": ("fwd + per-block recompute + bwd" if checkpoint else "fwd (activations kept in HBM) + bwd")
+            "use_checkpoint": bool(checkpoint), "checkpoint_policy": policy if checkpoint else None, "activations_kept": kept,
+            "work": ("fwd (activations kept in HBM) + bwd" if kept else "fwd + per-block recompute + bwd")
                     + (" (FFN of blocks > 10 forward-only: the reference's quirk)" if ffn_freeze else " (all parameters trained)")
                     + (f" + bucketed gradient all-reduce over {world} rank(s) [{dist.get_backend()}]" if reducer_ran
                        else " + NO gradient all-reduce (single process, no process group)") + " + fused AdamW",
@@ -458,23 +463,24 @@ def train_bench(model, device, world, dist, steps=4, warmup=2, bsz=4, ffn_freeze
 
 
 def train_legs(model, device, world, dist):
-    """The training legs of the line.  Primary: B = 4 with the reference trainer's settings (quirks on, per-block
-    checkpoint on: comparable across rounds).  Then the same with the activations kept (``kept_activations``: what 288 GB
-    of HBM make the natural setting, at B = 4 and B = 1), B = 1 (the reference's default --batch_size) and B = 16 with the
-    checkpoint, and B = 4 with both quirks off (every clip and every parameter trained).  OMH_TRAIN_BATCH overrides the
-    primary batch size."""
+    """The training legs of the line.  Primary: B = 4 with the reference trainer's settings (both quirks on,
+    use_checkpoint = True) under this build's default checkpoint policy ("auto": the activations are kept, they fit).
+    ``recompute``: the same with the policy forced to "always" (every block re-run in the backward, what
+    torch.utils.checkpoint does; comparable with rounds 1-2), at B = 4, 1 and 16.  Then B = 1 (the reference's default
+    --batch_size) and B = 16 under the primary settings, and B = 4 with both quirks off (every clip and every parameter
+    trained).  OMH_TRAIN_BATCH overrides the primary batch size."""
     bsz = int(os.environ.get("OMH_TRAIN_BATCH", "4"))
     out = train_bench(model, device, world, dist, bsz=bsz)
     if os.environ.get("OMH_TRAIN_LEGS", "all") == "primary":      # (tests: the primary leg only)
         return out
     try:
-        out["kept_activations"] = train_bench(model, device, world, dist, bsz=bsz, checkpoint=False)
+        out["recompute"] = train_bench(model, device, world, dist, bsz=bsz, policy="always")
         if bsz != 1:
             out["batch_1"] = train_bench(model, device, world, dist, bsz=1)
-            out["kept_activations"]["batch_1"] = train_bench(model, device, world, dist, bsz=1, checkpoint=False)
+            out["recompute"]["batch_1"] = train_bench(model, device, world, dist, bsz=1, policy="always")
         if bsz != 16:                                           # what 288 GB allow: the GEMMs leave the tile-quantised regime
             out["batch_16"] = train_bench(model, device, world, dist, bsz=16)
-            out["kept_activations"]["batch_16"] = train_bench(model, device, world, dist, bsz=16, checkpoint=False)
+            out["recompute"]["batch_16"] = train_bench(model, device, world, dist, bsz=16, policy="always")
         out["no_reference_quirks"] = train_bench(model, device, world, dist, bsz=bsz, ffn_freeze=False, loss_quirk=False)
     except Exception as e:
         out["extra_legs_error"] = repr(e)[:300]

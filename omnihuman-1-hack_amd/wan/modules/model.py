@@ -527,6 +527,9 @@ class WanModel(nn.Module):
                            qk_norm=qk_norm, cross_attn_norm=cross_attn_norm, eps=eps)
         self.model_type = model_type
         self.use_checkpoint = use_checkpoint
+        # how a True flag is honoured (model_train.py): "auto" keeps the activations when a step's worth of them fits in
+        # half of the free HBM (same gradients, no second forward pass), "always" re-runs every block in the backward
+        self.checkpoint_policy = "auto"
         # reference quirk (model.py:317-324): FFNs of blocks > 10 receive no gradient; False = full gradients
         self.reference_ffn_freeze = True
         self.patch_size = tuple(patch_size)

@@ -21,9 +21,14 @@ as in the reference:
   block at 4 clips, 18 GB for the 1.3B model, nothing against 288 GB of HBM — and
   the backward starts straight away;
 * ``use_checkpoint = True`` (model.py:544-548, the reference's 24 GB default):
-  only the block's input is kept and the backward first re-runs
-  ``_block_forward`` — the same kernels on the same input, hence the same
-  values the loss was computed from.
+  the flag buys memory with compute, and the two modes give the same gradients
+  bit for bit, so it is honoured as what it is — a memory policy
+  (``model.checkpoint_policy``, default "auto"; OMH_CHECKPOINT_POLICY overrides):
+  "auto" keeps the activations when the whole step's worth of them fits in half
+  of the HBM that is free when the forward starts (4 clips: 18 GB of 288) and
+  otherwise — or with "always", the reference's literal behaviour — keeps only
+  the block's input and first re-runs ``_block_forward`` in the backward: the same
+  kernels on the same input, hence the same values the loss was computed from.
 
 The backward applies the chain rule by hand: every dgrad / wgrad product is an
 MFMA GEMM (``omh_gemm_bf16`` on a transposed weight copy, ``omh_gemm_bf16_tn`` on
@@ -635,13 +640,31 @@ def _dgrad_ctx(dy, wT, d_ctx, first, L):
                  strideA=L * dy.stride(0), strideB=0, strideC=Lc * d)
 
 
+def keep_activations(model, rows, device):
+    """What ``model.use_checkpoint`` amounts to for a forward over ``rows`` tokens (module docstring): True = keep
+    every block's activations for the backward, False = keep the block inputs and recompute."""
+    if not getattr(model, "use_checkpoint", True):
+        return True
+    policy = os.environ.get("OMH_CHECKPOINT_POLICY") or getattr(model, "checkpoint_policy", "auto")
+    if policy != "auto":
+        return False
+    if torch.cuda.is_current_stream_capturing():              # no memory queries under hipGraph capture: what the
+        return bool(model.__dict__.get("_kept_activations", False))       # warm-up step before the capture decided
+    blk = model.blocks[0]
+    per_row = 42 * blk.dim + 4 * blk.ffn_dim                  # bytes a block keeps per token (5 fp32 + 11 bf16 [dim], 2 bf16 [ffn])
+    need = len(model.blocks) * rows * per_row * 1.15
+    free, _ = torch.cuda.mem_get_info(device)
+    free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)      # the allocator's own free blocks
+    return need < 0.5 * free
+
+
 # ----------------------------------------------------------------------------- block node
 class _BlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, model, st, idx, *params):
         blk = model.blocks[idx]
-        keep = not getattr(model, "use_checkpoint", True)
+        keep = st.keep
         with torch.no_grad():
             x0 = x.detach()
             if not (x0.dtype == torch.float32 and x0.is_contiguous()):
@@ -880,6 +903,8 @@ def forward_train(model, x, t, context, seq_len, clip_fea=None, y=None, extra_co
     xs = _EmbedFn.apply(model, st, x_list, t, list(context), seq_len, clip_fea, y, tok, *eparams)
     if not xs.requires_grad:
         xs.requires_grad_(True)          # keeps the chain alive when the embed parameters are frozen
+    st.keep = keep_activations(model, xs.shape[0] * xs.shape[1], xs.device)
+    model.__dict__["_kept_activations"] = st.keep            # what the last training forward did (bench / tests)
     for i, blk in enumerate(model.blocks):
         xs = _BlockFn.apply(xs, model, st, i, *list(blk.parameters()))
     outs = _HeadFn.apply(xs, model, st, st.grids, *list(model.head.parameters()))

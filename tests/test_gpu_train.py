@@ -18,7 +18,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # against the autograd oracle (t2v 13 layers, both freeze settings, i2v); 1-D parameters (bias / gain gradients: long
 # sums with heavy cancellation) <= 4.5e-2.  Bounds = 2 x measured.
 TOL_GRAD = 2e-2
-TOL_GRAD_1D = 9e-2
+TOL_GRAD_1D = 9e-2          # vs the autograd oracle: 6.2e-2 / 5.9e-2 / 4.5e-2 measured (profiles/r03_measured_gradient_errors.txt)
 
 
 def _setup(wan_model_mod, freeze=True):
@@ -52,7 +52,7 @@ def test_training_step_matches_reference_gradients(wan_model_mod):
             assert got is not None, name
             e = rel_rms(got, torch.from_numpy(g[name]))
             worst[min(got.dim(), 2)] = max(worst[min(got.dim(), 2)], e)
-            assert e < (TOL_GRAD if got.dim() > 1 else TOL_GRAD_1D), (name, e)
+            assert e < TOL_GRAD, (name, e)                 # matrices and 1-D alike: 9.1e-3 / 9.0e-3 measured (round 3)
     print(f"[measured] reference golden gradients (t2v, 13 layers): worst matrix {worst[2]:.3e}, worst 1-D {worst[1]:.3e}")
     # the reference's block_idx > 10 quirk: those FFN weights get no gradient at all (model.py:317-324)
     first = int(g["ffn_grad_none_from"])
@@ -593,11 +593,13 @@ def test_training_forward_equals_inference_and_checkpoint_equals_kept_activation
     with torch.no_grad():
         want = m(list(noise.cuda()), **args)
     grads = {}
+    m.checkpoint_policy = "always"                           # True = re-run the blocks, whatever HBM is free
     for ck in (False, True):
         m.use_checkpoint = ck
         for p in m.parameters():
             p.grad = None
         out = m(list(noise.cuda()), **args)
+        assert m.__dict__["_kept_activations"] is (not ck)
         assert all(torch.equal(a, b) for a, b in zip(out, want)), f"training forward != inference forward (ckpt={ck})"
         sum(torch.nn.functional.mse_loss(a, b) for a, b in zip(out, vt.cuda())).backward()
         grads[ck] = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in m.named_parameters()}
@@ -610,6 +612,10 @@ def test_training_forward_equals_inference_and_checkpoint_equals_kept_activation
             worst = max(worst, e)
             assert e < 1e-3, (n, e)
     print(f"[measured] gradients, re-run block vs kept activations (freeze={freeze}): worst relative difference {worst:.2e}")
+    # the default policy: the flag is a memory policy, and these activations fit
+    m.checkpoint_policy, m.use_checkpoint = "auto", True
+    m(list(noise.cuda()), **args)
+    assert m.__dict__["_kept_activations"] is True
 
 
 def test_norm_backward_round3_kernels(ops):

@@ -6,4 +6,4 @@ import bench
 dev = torch.device("cuda", 0)
 model = bench.build_model(dev)
 bsz = int(os.environ.get("OMH_TRAIN_BATCH", "4"))
-print(bench.train_bench(model, dev, 1, None, steps=6, warmup=2, bsz=bsz, checkpoint=os.environ.get("OMH_TRAIN_CKPT", "1") == "1"))
+print(bench.train_bench(model, dev, 1, None, steps=6, warmup=2, bsz=bsz, policy="always" if os.environ.get("OMH_TRAIN_CKPT", "1") == "1" else "auto"))

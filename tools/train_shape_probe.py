@@ -26,7 +26,7 @@ def main():
     trainer = importlib.import_module(PKG + ".trainer")
     optim = importlib.import_module(PKG + ".optim")
     model = bench.build_model(dev)
-    model.use_checkpoint = mode != "stash"
+    model.use_checkpoint, model.checkpoint_policy = True, ("auto" if mode == "stash" else "always")
     rec = defaultdict(list)
     on = [False]
 
