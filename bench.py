@@ -421,6 +421,8 @@ def train_bench(model, device, world, dist, steps=4, warmup=2, bsz=4, ffn_freeze
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
+    tele = Telemetry(device.index or 0)
+    tele.start()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = one(True)
@@ -429,6 +431,7 @@ def train_bench(model, device, world, dist, steps=4, warmup=2, bsz=4, ffn_freeze
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    tele = tele.stop()
     if dist:
         tt = torch.tensor([el], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -459,7 +462,8 @@ def train_bench(model, device, world, dist, steps=4, warmup=2, bsz=4, ffn_freeze
             "algorithmic_tflop_per_clip": round(fl / 1e12, 2),
             "algorithmic_over_forward": round(fl / fwd, 2),
             "achieved_tflops_per_gpu": round(fl * bsz * steps / el / 1e12, 1),
-            "mfma_roofline_frac": round(fl * bsz * steps / el / 1e12 / PEAK_BF16_TFLOPS, 4)}
+            "mfma_roofline_frac": round(fl * bsz * steps / el / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "telemetry": tele}
 
 
 def train_legs(model, device, world, dist):
@@ -729,7 +733,7 @@ def main():
     if not args.no_vae:
         try:
             vae_bench = importlib.import_module(PKG + ".wan.modules.vae").bench_decode
-            vae = vae_bench(x, device, iters=3)
+            vae = vae_bench(x, device, iters=3, telemetry=Telemetry(local_rank))
         except (ImportError, AttributeError, NotImplementedError) as e:
             vae = {"frames_per_s": None, "note": f"VAE path not built: {e}"}
 

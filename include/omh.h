@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OMH_ABI_VERSION 6
+#define OMH_ABI_VERSION 7
 
 #define OMH_E_BADARG   (-1)   /* null pointer / non-positive size             */
 #define OMH_E_ALIGN    (-2)   /* pointer or leading dimension not aligned     */
@@ -316,6 +316,12 @@ typedef struct omh_conv_args {
     int32_t stride_t, stride_hw, pad_h, pad_w;
     int32_t up2, out_f32, split_n;
     int32_t resid_f32;            /* != 0: resid is fp32 (the fp32 residual trunk of the VAE executor, ABI v4) */
+    /* ABI v7: the NEXT layer's RMS_norm + SiLU on this convolution's output (vae.py:39-54 under :195-197, :203-205),
+     * fused into the producing kernel's epilogue where a workgroup holds all Cout channels of a voxel (the stream
+     * kernel at Cout = 96) and run as omh_rms_silu_cl(_f32in) on y behind the convolution everywhere else — same
+     * values either way.  norm_gamma: fp32 [Cout] or NULL (no norm); norm_out: bf16 [Tout,Hout,Wout,Cout];
+     * norm_only != 0: the caller does not need y itself (still a valid buffer: the un-fused route goes through it). */
+    const float* norm_gamma; void* norm_out; int32_t norm_only;
 } omh_conv_args;
 
 int omh_conv_cl_bf16(const omh_conv_args* args, omh_stream_t stream);

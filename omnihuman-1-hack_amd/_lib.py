@@ -21,7 +21,7 @@ class OmhError(RuntimeError):
     pass
 
 
-ABI_VERSION = 6          # == OMH_ABI_VERSION of include/omh.h; checked against the loaded library below
+ABI_VERSION = 7          # == OMH_ABI_VERSION of include/omh.h; checked against the loaded library below
 
 
 def _load():
@@ -133,7 +133,8 @@ class ConvArgs(C.Structure):
                 ("Tout", i32), ("Hout", i32), ("Wout", i32), ("Cout", i32),
                 ("KT", i32), ("KH", i32), ("KW", i32),
                 ("stride_t", i32), ("stride_hw", i32), ("pad_h", i32), ("pad_w", i32),
-                ("up2", i32), ("out_f32", i32), ("split_n", i32), ("resid_f32", i32)]
+                ("up2", i32), ("out_f32", i32), ("split_n", i32), ("resid_f32", i32),
+                ("norm_gamma", vp), ("norm_out", vp), ("norm_only", i32)]
 
 
 EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID, EPI_F32_ACCUM, EPI_GELU_ERF_BF16, EPI_GELU_BWD_BF16 = 0, 1, 2, 3, 4, 5, 6

@@ -36,10 +36,11 @@ __device__ __forceinline__ void divmod24(int v, int d, float rcp, int& q, int& r
     if (r >= d) { ++q; r -= d; }
 }
 
-template <int CFG, bool OUT_F32>
+// NORM (P only): the stream's epilogue also writes the next layer's RMS norm + SiLU of the output (omh_conv_args.norm_*)
+template <int CFG, bool OUT_F32, bool NORM>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void conv_cl_w64_kernel(const omh_conv_args p, const int tiles_m, const int tiles_n) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * STAGE + (NORM ? 512 : 0)];   // + gamma[96] for the norm
     constexpr int WBM = CFG == CFG_P ? 512 : 256, WBN = CFG == CFG_P ? 96 : 192, VM = WBM - 2;
     constexpr int A_BYTES = WBM * 64;
     constexpr int NA = CFG == CFG_P ? 8 : 4, NB = CFG == CFG_P ? 5 : 9;
@@ -139,10 +140,12 @@ void conv_cl_w64_kernel(const omh_conv_args p, const int tiles_m, const int tile
     tab[42] = rowmask;
     tab[43] = 0;
     const uint32_t vtab = lds0 + (uint32_t)tid * 176u;
+    if (NORM && tid < 96) ((float*)(smem + 3 * STAGE))[tid] = p.norm_gamma[tid];   // ordered by the stream's first barrier
 
     const __amdgpu_buffer_rsrc_t rx = rsrc_of(p.x, (int64_t)p.Tin * HW * p.Cin * 2);
     const __amdgpu_buffer_rsrc_t rw = rsrc_of(p.w, (int64_t)p.Cout * K * 2);
-    const __amdgpu_buffer_rsrc_t ry = rsrc_of(p.y, (int64_t)M * p.Cout * ES);
+    const __amdgpu_buffer_rsrc_t ry = rsrc_of(p.y, (NORM && p.norm_only) ? 0 : (int64_t)M * p.Cout * ES);   // norm_only: y's stores fall outside
+    const __amdgpu_buffer_rsrc_t rnorm = rsrc_of(p.norm_out, NORM ? (int64_t)M * p.Cout * 2 : 0);
     const __amdgpu_buffer_rsrc_t rres = rsrc_of(p.resid, p.resid ? (int64_t)M * p.Cout * ES : 0);
     const int col0 = n0 + wn * 96;
     const __amdgpu_buffer_rsrc_t rbias = rsrc_of(p.bias ? p.bias + col0 : nullptr, p.bias ? (int64_t)(p.Cout - col0) * 4 : 0);
@@ -155,22 +158,24 @@ void conv_cl_w64_kernel(const omh_conv_args p, const int tiles_m, const int tile
     const uint64_t p3 = pack2((uint32_t)(HW * p.Cin * 2), (uint32_t)(64 - p.Cin * 2));
     const uint64_t p4 = pack2((uint32_t)(4 * p.Cin + 64), lds0 + blast_rel);
     const uint64_t p5 = pack2((uint32_t)(32 * p.Cout * ES), 0u);
-    const uint64_t p6 = pack2(0u, 0u);
+    const uint64_t p6 = pack2(lds0 + 3u * STAGE, __float_as_uint(sqrtf((float)p.Cout)));   // gamma in LDS, sqrt(C)
 
 #define OMH_CW64_RUN(ASM)                                                                                              \
     asm volatile(ASM                                                                                                   \
                  :                                                                                                     \
                  : [vtab] "v"(vtab), [rx] "s"(rx), [rw] "s"(rw), [ry] "s"(ry), [rres] "s"(rres), [rbias] "s"(rbias),   \
+                   [rnorm] "s"(rnorm),                                                                                 \
                    [p0] "{s[60:61]}"(p0), [p1] "{s[62:63]}"(p1), [p2] "{s[64:65]}"(p2), [p3] "{s[66:67]}"(p3),          \
                    [p4] "{s[68:69]}"(p4), [p5] "{s[70:71]}"(p5), [p6] "{s[72:73]}"(p6)                                  \
                  : OMH_CONV_W64_CLOBBERS)
-    if (CFG == CFG_P) { if (OUT_F32) OMH_CW64_RUN(OMH_CONV_W64_ASM_P_F32); else OMH_CW64_RUN(OMH_CONV_W64_ASM_P_BF16); }
+    if (CFG == CFG_P && NORM) { if (OUT_F32) OMH_CW64_RUN(OMH_CONV_W64_ASM_P_F32_NORM); else OMH_CW64_RUN(OMH_CONV_W64_ASM_P_BF16_NORM); }
+    else if (CFG == CFG_P) { if (OUT_F32) OMH_CW64_RUN(OMH_CONV_W64_ASM_P_F32); else OMH_CW64_RUN(OMH_CONV_W64_ASM_P_BF16); }
     else { if (OUT_F32) OMH_CW64_RUN(OMH_CONV_W64_ASM_Q_F32); else OMH_CW64_RUN(OMH_CONV_W64_ASM_Q_BF16); }
 #undef OMH_CW64_RUN
     }
 }
 
-template <int CFG, bool OUT_F32>
+template <int CFG, bool OUT_F32, bool NORM = false>
 int launch_cw64(const omh_conv_args& a, int64_t M, hipStream_t s) {
     constexpr int WBM = CFG == CFG_P ? 512 : 256, WBN = CFG == CFG_P ? 96 : 192;
     const int tiles_m = (int)((M + WBM - 3) / (WBM - 2)), tiles_n = a.Cout / WBN;
@@ -190,7 +195,7 @@ int launch_cw64(const omh_conv_args& a, int64_t M, hipStream_t s) {
         if (grid > cus) grid = cus;
     }
     omh_clear_status();
-    hipLaunchKernelGGL((conv_cl_w64_kernel<CFG, OUT_F32>), dim3(grid), dim3(256), 0, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((conv_cl_w64_kernel<CFG, OUT_F32, NORM>), dim3(grid), dim3(256), 0, s, a, tiles_m, tiles_n);
     return omh_launch_status();
 }
 
@@ -212,6 +217,7 @@ bool omh_conv_w64_takes(const omh_conv_args& a) {
 
 int omh_launch_conv_w64(const omh_conv_args& a, hipStream_t s) {
     const int64_t M = (int64_t)a.Tout * a.Hout * a.Wout;
+    if (a.Cout == 96 && a.norm_gamma) return a.out_f32 ? launch_cw64<CFG_P, true, true>(a, M, s) : launch_cw64<CFG_P, false, true>(a, M, s);
     if (a.Cout == 96) return a.out_f32 ? launch_cw64<CFG_P, true>(a, M, s) : launch_cw64<CFG_P, false>(a, M, s);
     return a.out_f32 ? launch_cw64<CFG_Q, true>(a, M, s) : launch_cw64<CFG_Q, false>(a, M, s);
 }

@@ -418,11 +418,165 @@ def epilogue(e, kind):
         e("s_mov_b64 exec, s[86:87]")
 
 
-def generate(cfg, kind):
-    e = Emit(cfg + kind)
+V_SS, V_INV, V_GADDR, V_NOFF = 254, 251, 248, 250
+RNORM = 216                                       # bf16 norm kind: the row's three packed tiles, v[216:239]; v[240:247] gamma
+S_GAMMA_LDS, S_SQRTC = S_SPARE1, S_SPARE2
+
+
+def silu_norm(e, regs, gam, inv):
+    """regs[k] <- silu((inv * regs[k]) * gam[k]) in rms_silu_kernel's operation order (vae_elementwise.hip); values in
+    pairs so that a transcendental's result is never read by the next instruction (gfx950 trans forwarding: 1 wait)."""
+    for k in range(0, len(regs), 2):
+        a, g = regs[k:k + 2], gam[k:k + 2]
+        t = (V_PAIR, V_PAIR + 1)
+        for x in range(2):
+            e(f"v_mul_f32 v{a[x]}, v{inv}, v{a[x]}")
+        for x in range(2):
+            e(f"v_mul_f32 v{a[x]}, v{a[x]}, v{g[x]}")
+        for x in range(2):
+            e(f"v_mul_f32 v{t[x]}, 0xbfb8aa3b, v{a[x]}")         # -log2(e) x
+        for x in range(2):
+            e(f"v_exp_f32 v{t[x]}, v{t[x]}")
+        for x in range(2):
+            e(f"v_add_f32 v{t[x]}, 1.0, v{t[x]}")
+        for x in range(2):
+            e(f"v_rcp_f32 v{t[x]}, v{t[x]}")
+        for x in range(2):
+            e(f"v_mul_f32 v{a[x]}, v{a[x]}, v{t[x]}")
+
+
+def epilogue_norm(e, kind):
+    """epilogue() followed, per row block j, by the NEXT layer's RMS norm + SiLU of the 96 output channels (vae.py:39-54
+    under :195-197 / :203-205): bf16 [voxel][96] to %[rnorm].  A voxel row's 96 values sit in two lanes (r, h = 0 / 1),
+    48 each: sums of squares as one fma chain per run p (channel order, like rms_silu_kernel's lane p + 2... see there),
+    the two runs added, the halves exchanged with v_permlane32_swap, then sqrt / max / rcp / mul and the SiLU with the
+    same instructions in the same order as the stand-alone kernel: bit-identical outputs.  gamma is read from LDS
+    (96 floats above the stages, written by the C++ prologue).  fp32 kind: y stays in the residual slot of its tile
+    until the row is complete; bf16 kind: the rounded y (what the stand-alone kernel would read back) as packed pairs."""
+    es = 2 if kind == "bf16" else 4
+    e(f"v_mbcnt_lo_u32_b32 v{V_LANE}, -1, 0")
+    e(f"v_mbcnt_hi_u32_b32 v{V_LANE}, -1, v{V_LANE}")
+    e(f"v_lshrrev_b32 v{V_LANE}, 5, v{V_LANE}")
+    e(f"v_lshlrev_b32 v{V_LANE}, 5, v{V_LANE}")                   # 32 h bytes = 8 h floats
+    for i in range(NI):
+        for p in range(2):
+            for q in range(2):
+                e(f"buffer_load_dwordx4 {vr(BIASV + (2 * i + p) * 8 + 4 * q, 4)}, v{V_LANE}, %[rbias], 0 offen "
+                  f"offset:{(32 * i + 16 * p) * 4 + 16 * q}")
+    e(f"v_add_u32 v{V_GADDR}, {S_GAMMA_LDS}, v{V_LANE}")          # this lane's gamma runs in LDS
+    e(f"v_mov_b32 v{V_ST_OFF}, v{VOC}")
+    for n in range(NTILES):
+        j, i = divmod(n, NI)
+        t = i * NJ + j
+        if i == 0 and j:
+            e(f"v_add_u32 v{V_ST_OFF}, {S_JSTEP}, v{V_ST_OFF}")
+        for r_ in range(16):
+            e(f"v_accvgpr_read_b32 v{T + r_}, a{t * 16 + r_}")
+        e("s_nop 1")
+        for q0 in (0, 2):
+            for r_ in range(4):
+                e(f"v_permlane32_swap_b32 v{T + 4 * q0 + r_}, v{T + 4 * (q0 + 1) + r_}")
+        bank, rbase = res_slot(n, kind)
+        if bank == "a":
+            for r_ in range(16):
+                e(f"v_accvgpr_read_b32 v{120 + 16 * (n - 8) + r_}, a{rbase + r_}")
+            rbase = 120 + 16 * (n - 8)
+        if n == 0:
+            e("s_waitcnt vmcnt(0)")
+        e(f"v_bfe_u32 v{V_ROWBIT}, v{ROWMASK}, {j}, 1")
+        e(f"v_cmp_ne_u32 vcc, 0, v{V_ROWBIT}")
+        e("s_and_saveexec_b64 s[86:87], vcc")
+        for p in range(2):
+            v0 = T + 8 * p
+            b0 = BIASV + (2 * i + p) * 8
+            ss = V_SS + p
+            first = "v_mul_f32 v{0}, v{1}, v{1}" if i == 0 else "v_fmac_f32 v{0}, v{1}, v{1}"
+            for r_ in range(0, 8, 2):
+                e(f"v_pk_add_f32 {vr(v0 + r_, 2)}, {vr(v0 + r_, 2)}, {vr(b0 + r_, 2)}")
+            if kind == "bf16":
+                r0 = rbase + p * 4
+                for r_ in range(4):
+                    e(f"v_lshlrev_b32 v{V_PAIR}, 16, v{r0 + r_}")
+                    e(f"v_and_b32 v{V_PAIR + 1}, 0xffff0000, v{r0 + r_}")
+                    e(f"v_pk_add_f32 {vr(v0 + 2 * r_, 2)}, {vr(v0 + 2 * r_, 2)}, v[{V_PAIR}:{V_PAIR + 1}]")
+                keep = RNORM + 8 * i + 4 * p                     # the rounded y, packed: kept for the row's norm
+                for r_ in range(4):
+                    e(f"v_cvt_pk_bf16_f32 v{keep + r_}, v{v0 + 2 * r_}, v{v0 + 2 * r_ + 1}")
+                e(f"buffer_store_dwordx4 {vr(keep, 4)}, v{V_ST_OFF}, %[ry], 0 offen offset:{(i * 32 + 16 * p) * es}")
+                for r_ in range(4):
+                    e(f"v_lshlrev_b32 v{V_PAIR}, 16, v{keep + r_}")
+                    e(f"v_and_b32 v{V_PAIR + 1}, 0xffff0000, v{keep + r_}")
+                    e((first if r_ == 0 else "v_fmac_f32 v{0}, v{1}, v{1}").format(ss, V_PAIR))
+                    e(f"v_fmac_f32 v{ss}, v{V_PAIR + 1}, v{V_PAIR + 1}")
+            else:
+                r0 = rbase + p * 8                               # y = (acc + bias) + residual, left in the residual's slot
+                for r_ in range(0, 8, 2):
+                    e(f"v_pk_add_f32 {vr(r0 + r_, 2)}, {vr(v0 + r_, 2)}, {vr(r0 + r_, 2)}")
+                e(f"buffer_store_dwordx4 {vr(r0, 4)}, v{V_ST_OFF}, %[ry], 0 offen offset:{(i * 32 + 16 * p) * es}")
+                e(f"buffer_store_dwordx4 {vr(r0 + 4, 4)}, v{V_ST_OFF}, %[ry], 0 offen offset:{(i * 32 + 16 * p) * es + 16}")
+                for r_ in range(8):
+                    e((first if r_ == 0 else "v_fmac_f32 v{0}, v{1}, v{1}").format(ss, r0 + r_))
+        e("s_nop 1")
+        e("s_mov_b64 exec, s[86:87]")
+        if i != NI - 1:
+            continue
+        # ---- the row block is complete: 1 / rms of every voxel row, then norm + SiLU of its three tiles
+        e(f"v_add_f32 v{V_SS}, v{V_SS}, v{V_SS + 1}")
+        e(f"v_mov_b32 v{V_SS + 1}, v{V_SS}")
+        e("s_nop 1")
+        e(f"v_permlane32_swap_b32 v{V_SS}, v{V_SS + 1}")          # v254 = the low half's sum, v255 = the high half's, in all lanes
+        e("s_nop 1")
+        e(f"v_add_f32 v{V_SS}, v{V_SS}, v{V_SS + 1}")
+        e(f"v_sqrt_f32 v{V_SS}, v{V_SS}")
+        e("s_nop 0")
+        e(f"v_max_f32 v{V_SS}, 0x2b8cbccc, v{V_SS}")              # 1e-12
+        e(f"v_rcp_f32 v{V_SS}, v{V_SS}")
+        e("s_nop 0")
+        e(f"v_mul_f32 v{V_INV}, {S_SQRTC}, v{V_SS}")
+        e(f"v_bfe_u32 v{V_ROWBIT}, v{ROWMASK}, {j}, 1")
+        e(f"v_cmp_ne_u32 vcc, 0, v{V_ROWBIT}")
+        e("s_and_saveexec_b64 s[86:87], vcc")
+        noff = V_ST_OFF
+        if kind != "bf16":
+            e(f"v_lshrrev_b32 v{V_NOFF}, 1, v{V_ST_OFF}")         # bf16 output: half the fp32 output's byte offset
+            noff = V_NOFF
+        for i2 in range(NI):
+            n2 = NI * j + i2
+            if kind == "bf16":
+                for p in range(2):
+                    keep = RNORM + 8 * i2 + 4 * p
+                    for q in range(2):
+                        e(f"ds_read_b128 {vr(240 + 4 * q, 4)}, v{V_GADDR} offset:{(32 * i2 + 16 * p) * 4 + 16 * q}")
+                    for r_ in range(4):
+                        e(f"v_lshlrev_b32 v{T + 2 * r_}, 16, v{keep + r_}")
+                        e(f"v_and_b32 v{T + 2 * r_ + 1}, 0xffff0000, v{keep + r_}")
+                    e("s_waitcnt lgkmcnt(0)")
+                    silu_norm(e, [T + r_ for r_ in range(8)], [240 + r_ for r_ in range(8)], V_INV)
+                    for r_ in range(4):
+                        e(f"v_cvt_pk_bf16_f32 v{T + r_}, v{T + 2 * r_}, v{T + 2 * r_ + 1}")
+                    e(f"buffer_store_dwordx4 {vr(T, 4)}, v{noff}, %[rnorm], 0 offen offset:{(i2 * 32 + 16 * p) * 2}")
+                    e("s_nop 1")                                 # the store's data registers are rewritten next
+            else:
+                _, sb = res_slot(n2, kind)
+                sr = sb if n2 < 8 else 120 + 16 * (n2 - 8)
+                for p in range(2):
+                    for q in range(2):
+                        e(f"ds_read_b128 {vr(T + 8 * p + 4 * q, 4)}, v{V_GADDR} offset:{(32 * i2 + 16 * p) * 4 + 16 * q}")
+                e("s_waitcnt lgkmcnt(0)")
+                silu_norm(e, [sr + r_ for r_ in range(16)], [T + r_ for r_ in range(16)], V_INV)
+                for r_ in range(8):
+                    e(f"v_cvt_pk_bf16_f32 v{sr + r_}, v{sr + 2 * r_}, v{sr + 2 * r_ + 1}")
+                for p in range(2):
+                    e(f"buffer_store_dwordx4 {vr(sr + 4 * p, 4)}, v{noff}, %[rnorm], 0 offen offset:{(i2 * 32 + 16 * p) * 2}")
+        e("s_nop 1")
+        e("s_mov_b64 exec, s[86:87]")
+
+
+def generate(cfg, kind, norm=False):
+    e = Emit(cfg + kind + ("n" if norm else ""))
     NA, NB = CONFIGS[cfg]
     main_loop(e, NA, NB, kind)
-    epilogue(e, kind)
+    (epilogue_norm if norm else epilogue)(e, kind)
     return e
 
 
@@ -430,11 +584,12 @@ def main():
     print("// GENERATED by gen_conv_w64.py — do not edit; edit the generator.")
     for cfg in CONFIGS:
         for kind in KINDS:
-            e = generate(cfg, kind)
-            print(f"#define OMH_CONV_W64_ASM_{cfg}_{kind.upper()} \\")
-            print(" \\\n".join(e.text().split("\n")))
-            print("")
-            print(f"// {cfg} {kind}: {len(e.lines)} lines, {sum('v_mfma' in ln for ln in e.lines)} MFMA")
+            for norm in ((False, True) if cfg == "P" else (False,)):    # the fused norm needs all 96 channels in one wave
+                e = generate(cfg, kind, norm)
+                print(f"#define OMH_CONV_W64_ASM_{cfg}_{kind.upper()}{'_NORM' if norm else ''} \\")
+                print(" \\\n".join(e.text().split("\n")))
+                print("")
+                print(f"// {cfg} {kind}{' norm' if norm else ''}: {len(e.lines)} lines, {sum('v_mfma' in ln for ln in e.lines)} MFMA")
     clob = ['"memory"', '"vcc"', '"scc"'] + [f'"s{i}"' for i in range(80, 100)] + [f'"v{i}"' for i in range(12, 256)] + \
            [f'"a{i}"' for i in range(256)]
     print("#define OMH_CONV_W64_CLOBBERS \\")

@@ -700,6 +700,33 @@ int launch_kw3(const omh_conv_args& a, int64_t M, hipStream_t s) {
 bool omh_conv_w64_takes(const omh_conv_args& a);
 int omh_launch_conv_w64(const omh_conv_args& a, hipStream_t s);
 
+// The tile family of a call (by the layer's geometry only) and whether the stream kernel takes it
+struct ConvRoute { bool wide, w64; };
+static ConvRoute conv_route(const omh_conv_args& a) {
+    // wide tiles (N extent 96 / 192) once they give every CU most of a workgroup; the 128x128 tile otherwise.  The
+    // count is taken for TWO output frames of this geometry whatever Tout is (the executors convolve 1 - 8 frames per
+    // call): the kernel choice — and with it the accumulation order of every output value — then depends on the layer
+    // only, not on how many frames a call carries, so a prefix of a clip decodes / encodes bit for bit like the
+    // whole clip's first frames (tests/test_gpu_config5.py).
+    const char* force = getenv("OMH_CONV_TILE");                     // "wide" / "small": test / benchmarking override
+    const bool narrow = a.Cout <= 96;
+    const int64_t Mn = (int64_t)2 * a.Hout * a.Wout;
+    const int64_t wide_tiles = narrow ? (Mn + 511) / 512 : ((Mn + 255) / 256) * ((a.Cout + 191) / 192);
+    const char* wmin = getenv("OMH_CONV_WIDE_MIN");                  // A/B timing of the threshold
+    bool wide = wide_tiles >= (wmin ? atoi(wmin) : 96);              // e.g. 384 channels at 60 x 104: 98
+    if (force && force[0] == 'w') wide = true;
+    if (force && force[0] == 's') wide = false;
+    if (((uintptr_t)a.resid & 15) || ((uintptr_t)a.bias & 3)) wide = false;
+    // the residual-block convolutions: the one-wave-per-SIMD stream kernel (same values as the kw-shared 8-wave
+    // kernel).  OMH_CONV_TILE=w64 forces it wherever it applies, wide / small exclude it, OMH_CONV_W64=0 turns it off.
+    const char* w64e = getenv("OMH_CONV_W64");
+    const bool w64_forced = force && force[0] == 'w' && force[1] == '6';
+    const bool w64_ok = !(w64e && w64e[0] == '0') && (w64_forced || (!force && wide));
+    const bool w64 = w64_ok && omh_conv_w64_takes(a);
+    if (w64_forced) wide = true;                                      // not taken: the wide kernels
+    return {wide, w64};
+}
+
 extern "C" int omh_conv_cl_bf16(const omh_conv_args* args, omh_stream_t stream) {
     if (!args || !args->x || !args->w || !args->y) return OMH_E_BADARG;
     const omh_conv_args& a = *args;
@@ -715,29 +742,24 @@ extern "C" int omh_conv_cl_bf16(const omh_conv_args* args, omh_stream_t stream) 
     if (M > 0x7fffffff) return OMH_E_SHAPE;
     // 32-bit buffer offsets
     if ((int64_t)a.Tin * a.Hin * a.Win * a.Cin * 2 >= 0x7fffffffLL) return OMH_E_SHAPE;
-    // wide tiles (N extent 96 / 192) once they give every CU most of a workgroup; the 128x128 tile otherwise.  The
-    // count is taken for TWO output frames of this geometry whatever Tout is (the executors convolve 1 - 8 frames per
-    // call): the kernel choice — and with it the accumulation order of every output value — then depends on the layer
-    // only, not on how many frames a call carries, so a prefix of a clip decodes / encodes bit for bit like the
-    // whole clip's first frames (tests/test_gpu_config5.py).
-    const char* force = getenv("OMH_CONV_TILE");                     // "wide" / "small": test / benchmarking override
-    const bool narrow = a.Cout <= 96;
-    const int64_t Mn = (int64_t)2 * a.Hout * a.Wout;
-    const int64_t wide_tiles = narrow ? (Mn + 511) / 512 : ((Mn + 255) / 256) * ((a.Cout + 191) / 192);
-    const char* wmin = getenv("OMH_CONV_WIDE_MIN");                  // A/B timing of the threshold
-    bool wide = wide_tiles >= (wmin ? atoi(wmin) : 96);              // e.g. 384 channels at 60 x 104: 98
-    if (force && force[0] == 'w') wide = true;
-    if (force && force[0] == 's') wide = false;
-    if (((uintptr_t)a.resid & 15) || ((uintptr_t)a.bias & 3)) wide = false;
-    {
-        // the residual-block convolutions: the one-wave-per-SIMD stream kernel (same values as the kw-shared 8-wave
-        // kernel).  OMH_CONV_TILE=w64 forces it wherever it applies, wide / small exclude it, OMH_CONV_W64=0 turns it off.
-        const char* w64e = getenv("OMH_CONV_W64");
-        const bool w64_forced = force && force[0] == 'w' && force[1] == '6';
-        const bool w64_ok = !(w64e && w64e[0] == '0') && (w64_forced || (!force && wide));
-        if (w64_ok && omh_conv_w64_takes(a)) return omh_launch_conv_w64(a, (hipStream_t)stream);
-        if (w64_forced) wide = true;                                  // not taken: the wide kernels
+    const ConvRoute route = conv_route(a);
+    if (a.norm_gamma) {
+        // the next layer's RMS norm + SiLU (ABI v7): in the stream kernel's epilogue when one wave holds all the
+        // channels of a voxel (Cout = 96), as a second launch over y otherwise — the two write the same values
+        if (!a.norm_out || a.split_n > 0) return OMH_E_BADARG;
+        if (((uintptr_t)a.norm_out & 15) || ((uintptr_t)a.norm_gamma & 3)) return OMH_E_ALIGN;
+        const char* fe = getenv("OMH_CONV_FUSE_NORM");                // "0": never fused (tests / A/B timing)
+        if (!(route.w64 && a.Cout == 96 && !(fe && fe[0] == '0'))) {
+            omh_conv_args b = a;
+            b.norm_gamma = nullptr; b.norm_out = nullptr; b.norm_only = 0;
+            const int rc = omh_conv_cl_bf16(&b, stream);
+            if (rc) return rc;
+            return a.out_f32 ? omh_rms_silu_cl_f32in((const float*)a.y, a.norm_gamma, a.norm_out, M, a.Cout, 1, stream)
+                             : omh_rms_silu_cl(a.y, a.norm_gamma, a.norm_out, M, a.Cout, 1, stream);
+        }
     }
+    if (route.w64) return omh_launch_conv_w64(a, (hipStream_t)stream);
+    const bool wide = route.wide, narrow = a.Cout <= 96;
     if (wide) {
         hipStream_t s = (hipStream_t)stream;
         // 3x3 "same" convolutions with stride 1 at >= 32 channels: the kw-shared kernel (3x less voxel traffic)

@@ -26,6 +26,7 @@ void rms_silu_kernel(const void* __restrict__ xv, const float* __restrict__ gamm
             for (int e = 0; e < 8; ++e) gm[i][e] = gamma[c * 8 + e];
         }
     }
+    const float sqrtf_c = sqrtf((float)C);
     const int64_t per = blockDim.x / G;
     // a group's G lanes share p: they leave the loop together (G divides the wave)
     for (int64_t p = (int64_t)blockIdx.x * per + threadIdx.x / G; p < P; p += (int64_t)gridDim.x * per) {
@@ -49,13 +50,16 @@ void rms_silu_kernel(const void* __restrict__ xv, const float* __restrict__ gamm
                     v[i][2 * e + 1] = bf2f((uint16_t)(w[e] >> 16));
                 }
             }
+            // one fma per value, in channel order: the fused epilogue of the convolution stream (gen_conv_w64.py,
+            // norm kinds) adds in exactly this order, so a layer's values do not depend on which of the two ran
 #pragma unroll
-            for (int e = 0; e < 4; ++e) ss += v[i][2 * e] * v[i][2 * e] + v[i][2 * e + 1] * v[i][2 * e + 1];
+            for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(v[i][e], v[i][e], ss);
         }
     }
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-    const float inv = sqrtf((float)C) / fmaxf(sqrtf(ss), 1e-12f);
+    // sqrt(C) / max(||x||, 1e-12) on the raw v_sqrt_f32 / v_rcp_f32 (1 ulp each; the result is rounded to bf16)
+    const float inv = sqrtf_c * __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(ss), 1e-12f));
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const int c = lane_g + G * i;
@@ -63,8 +67,8 @@ void rms_silu_kernel(const void* __restrict__ xv, const float* __restrict__ gamm
             uint32_t o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float a = v[i][2 * e] * inv * gm[i][2 * e];
-                float b = v[i][2 * e + 1] * inv * gm[i][2 * e + 1];
+                float a = (v[i][2 * e] * inv) * gm[i][2 * e];
+                float b = (v[i][2 * e + 1] * inv) * gm[i][2 * e + 1];
                 if (do_silu) { a = silu(a); b = silu(b); }
                 o[e] = pack_bf2(a, b);
             }

@@ -295,10 +295,13 @@ def cfg_unipc_step(cond, uncond, x, last, m1, m2, mt_out, xc_out, x_next, guide,
 
 # ----------------------------------------------------------------------------- VAE kernels
 def conv_cl(x, w, bias, Tout, Hout, Wout, Cout, KT, KH, KW, stride_t=1, stride_hw=1, pad_h=0, pad_w=0, up2=False,
-            resid=None, out_f32=False, split_n=0, out=None):
+            resid=None, out_f32=False, split_n=0, out=None, norm_gamma=None, norm_out=None, norm_only=False):
     """Implicit-GEMM conv on channels-last bf16 ``x`` [Tin, Hin, Win, Cin] (history frames first);
-    ``w`` bf16 [Cout, KT*KH*KW*Cin].  Returns [Tout*f, Hout, Wout, Cout/f] (f = Cout/split_n or 1)."""
-    _dev(x, w, bias, resid, out)
+    ``w`` bf16 [Cout, KT*KH*KW*Cin].  Returns [Tout*f, Hout, Wout, Cout/f] (f = Cout/split_n or 1).
+    ``norm_gamma`` (fp32 [Cout]) + ``norm_out`` (bf16 [Tout, Hout, Wout, Cout]): also the next layer's RMS norm + SiLU of
+    the output (fused into the kernel's epilogue where possible, omh.h); ``norm_only``: the caller will not read the
+    returned tensor (its memory is still needed by the un-fused route)."""
+    _dev(x, w, bias, resid, out, norm_gamma, norm_out)
     assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_contiguous() and w.is_contiguous()
     Tin, Hin, Win, Cin = x.shape
     assert w.shape == (Cout, KT * KH * KW * Cin), (tuple(w.shape), Cout, KT, KH, KW, Cin)
@@ -311,7 +314,12 @@ def conv_cl(x, w, bias, Tout, Hout, Wout, Cout, KT, KH, KW, stride_t=1, stride_h
                                                       resid.dtype in (torch.bfloat16, torch.float32)))
     a = _lib.ConvArgs(_p(x), _p(w), _p(bias), _p(resid), _p(out), Tin, Hin, Win, Cin, Tout, Hout, Wout, Cout,
                       KT, KH, KW, stride_t, stride_hw, pad_h, pad_w, int(up2), int(out_f32), split_n,
-                      int(resid is not None and resid.dtype == torch.float32))
+                      int(resid is not None and resid.dtype == torch.float32),
+                      _p(norm_gamma), _p(norm_out), int(bool(norm_only)))
+    if norm_gamma is not None:
+        assert split_n == 0 and norm_gamma.dtype == torch.float32 and norm_gamma.numel() == Cout and norm_gamma.is_contiguous()
+        assert norm_out is not None and norm_out.dtype == torch.bfloat16 and norm_out.is_contiguous() and \
+            norm_out.numel() == Tout * Hout * Wout * Cout
     check(lib.omh_conv_cl_bf16(C.byref(a), _stream()), "omh_conv_cl_bf16")
     return out
 

@@ -248,8 +248,9 @@ class _ConvState:
         """Overwrite the (single) history frame — the encoder's first-chunk bypass of a strided time conv."""
         self.buf[self.off].copy_(frame)
 
-    def run(self, resid=None, out_f32=False, split_n=0, out=None):
-        """Convolve over [history | chunk]; the last ``hist`` frames of that region become the new history."""
+    def run(self, resid=None, out_f32=False, split_n=0, out=None, norm_gamma=None, norm_out=None, norm_only=False):
+        """Convolve over [history | chunk]; the last ``hist`` frames of that region become the new history.
+        ``norm_gamma`` / ``norm_out`` / ``norm_only``: also the next layer's RMS norm + SiLU (ops.conv_cl)."""
         T, (_, H, W, _) = self.T, self.buf.shape
         x = self.buf[self.off:self.off + self.hist + T]
         if self.stride_t == 1:
@@ -263,7 +264,8 @@ class _ConvState:
             Hout, Wout = (eff_h + 1 - self.KH) // 2 + 1, (eff_w + 1 - self.KW) // 2 + 1
         y = ops.conv_cl(x, self.w, self.bias, Tout, Hout, Wout, self.Cout, self.KT, self.KH, self.KW,
                         stride_t=self.stride_t, stride_hw=self.stride_hw, pad_h=self.pad[0], pad_w=self.pad[1],
-                        up2=self.up2, resid=resid, out_f32=out_f32, split_n=split_n, out=out)
+                        up2=self.up2, resid=resid, out_f32=out_f32, split_n=split_n, out=out,
+                        norm_gamma=norm_gamma, norm_out=norm_out, norm_only=norm_only)
         if self.hist:
             self.off += T                                   # the region slides: no copy
         return y
@@ -316,18 +318,35 @@ def _conv_on(st: _Stream, key, module, x, **run_kw):
     return cs.run(**run_kw)
 
 
-def _res_block(st, key, blk: ResidualBlock, x):
-    """vae.py:202-220."""
+# A 96-channel convolution writes the NEXT layer's RMS norm + SiLU of its output itself (omh_conv_args.norm_*: in the
+# stream kernel's epilogue, where one wave holds all 96 channels of a voxel) — the norm inside a block from conv1, the
+# first norm of the next block (or of the head) from conv2, straight into that layer's convolution input slot.  The
+# stand-alone kernel computes the same bits, so this is speed only (OMH_VAE_FUSE_NORM=0: always stand-alone).
+_FUSE_NORM = os.environ.get("OMH_VAE_FUSE_NORM", "1") != "0"
+
+
+def _res_block(st, key, blk: ResidualBlock, x, pre=False, nxt=None):
+    """vae.py:202-220.  ``pre``: the producer of x already wrote norm1(x) into this block's first convolution slot.
+    ``nxt`` = (gamma, conv state) of the norm + convolution that consume this block's output: returns (y, True) when
+    that norm was written into the state's slot by this block's second convolution."""
     T, H, W, _ = x.shape
+    dev = x.device
     h = x
     if not isinstance(blk.shortcut, nn.Identity):
         h = _conv_on(st, key + ".shortcut", blk.shortcut, x, out_f32=_TRUNK_F32)
     ca = st.conv(key + ".residual.2", blk.residual[2])
-    ops.rms_silu_cl(x, _gamma(blk.residual[0]), out=ca.slot(T, H, W, x.device))
-    y = ca.run()                                    # inside the block: bf16 (rounded once, feeds one norm + conv)
+    if not pre:
+        ops.rms_silu_cl(x, _gamma(blk.residual[0]), out=ca.slot(T, H, W, dev))
     cb = st.conv(key + ".residual.6", blk.residual[6])
-    ops.rms_silu_cl(y, _gamma(blk.residual[3]), out=cb.slot(T, H, W, x.device))
-    return cb.run(resid=h, out_f32=_TRUNK_F32)
+    if _FUSE_NORM and ca.Cout == 96:                 # inside the block: bf16 (rounded once, feeds one norm + conv)
+        ca.run(norm_gamma=_gamma(blk.residual[3]), norm_out=cb.slot(T, H, W, dev), norm_only=True)
+    else:
+        y = ca.run()
+        ops.rms_silu_cl(y, _gamma(blk.residual[3]), out=cb.slot(T, H, W, dev))
+    if _FUSE_NORM and nxt is not None and cb.Cout == 96:
+        gamma, cn = nxt
+        return cb.run(resid=h, out_f32=_TRUNK_F32, norm_gamma=gamma, norm_out=cn.slot(T, H, W, dev)), True
+    return cb.run(resid=h, out_f32=_TRUNK_F32), False
 
 
 def _attention(st, key, blk: AttentionBlock, x):
@@ -391,10 +410,11 @@ def _resample(st, key, rs: Resample, x):
     return x
 
 
-def _head(st, key, head: nn.Sequential, x, out_f32):
+def _head(st, key, head: nn.Sequential, x, out_f32, pre=False):
     T, H, W, _ = x.shape
     cs = st.conv(key + ".2", head[2])
-    ops.rms_silu_cl(x, _gamma(head[0]), out=cs.slot(T, H, W, x.device))
+    if not pre:                                     # (pre: the last block's convolution wrote the norm into the slot)
+        ops.rms_silu_cl(x, _gamma(head[0]), out=cs.slot(T, H, W, x.device))
     return cs.run(out_f32=out_f32)
 
 
@@ -415,20 +435,30 @@ def _last_resample(seq):
     return last
 
 
-def _run_sequential(st, prefix, seq, x, start=0, stop=None):
+def _run_sequential(st, prefix, seq, x, start=0, stop=None, head=None):
+    """Layers [start, stop) of ``seq``.  ``head`` = (key, nn.Sequential) of the head that follows the LAST layer of the
+    range: with it the return value is (x, pre) — pre: the head's norm is already in its convolution slot (_head)."""
+    last = (len(seq) if stop is None else min(stop, len(seq))) - 1
+    pre = False
     for i, layer in enumerate(seq):
-        if i < start or (stop is not None and i >= stop):
+        if i < start or i > last:
             continue
         key = f"{prefix}.{i}"
         if isinstance(layer, ResidualBlock):
-            x = _res_block(st, key, layer, x)
+            nxt = None
+            if i < last and isinstance(seq[i + 1], ResidualBlock):
+                nb = seq[i + 1]
+                nxt = (_gamma(nb.residual[0]), st.conv(f"{prefix}.{i + 1}.residual.2", nb.residual[2]))
+            elif i == last and head is not None:
+                nxt = (_gamma(head[1][0]), st.conv(head[0] + ".2", head[1][2]))
+            x, pre = _res_block(st, key, layer, x, pre=pre, nxt=nxt)
         elif isinstance(layer, AttentionBlock):
-            x = _attention(st, key, layer, x)
+            x, pre = _attention(st, key, layer, x), False
         elif isinstance(layer, Resample):
-            x = _resample(st, key, layer, x)
+            x, pre = _resample(st, key, layer, x), False
         else:  # pragma: no cover
             raise TypeError(type(layer))
-    return x
+    return (x, pre) if head is not None else x
 
 
 class WanVAE_(nn.Module):
@@ -545,8 +575,9 @@ class WanVAE_(nn.Module):
             j = 0
             while j < g:                                      # the full-resolution rest: _GROUP2 latent frames per step
                 g2 = min(_GROUP2, g - j)
-                y = _run_sequential(st, "decoder.upsamples", dec.upsamples, ymid[j * per:(j + g2) * per], start=n_mid)
-                y = _head(st, "decoder.head", dec.head, y, out_f32=True)        # fp32 [t, 8h, 8w, 3]
+                y, pre = _run_sequential(st, "decoder.upsamples", dec.upsamples, ymid[j * per:(j + g2) * per], start=n_mid,
+                                         head=("decoder.head", dec.head))
+                y = _head(st, "decoder.head", dec.head, y, out_f32=True, pre=pre)        # fp32 [t, 8h, 8w, 3]
                 ops.cl_to_nchw(y, out, t_pix, 3, lo=lo, hi=hi)
                 t_pix += y.shape[0]
                 j += g2
@@ -599,26 +630,33 @@ class WanVAE:
         return [self.model.decode(u.unsqueeze(0), self.scale, clamp=(-1.0, 1.0)).float().squeeze(0) for u in zs]
 
 
-def bench_decode(latent, device, iters=1):
+def bench_decode(latent, device, iters=1, telemetry=None):
     """bench.py hook: frames/s of decoding one [16, T', 60, 104] latent, and of encoding the decoded clip back,
-    with a random-init VAE.  Conv flops per frame from SURVEY.md section 8(d) (linear in H*W)."""
+    with a random-init VAE.  Conv flops per frame from SURVEY.md section 8(d) (linear in H*W).  ``telemetry``: an
+    object with start() / stop() -> dict (bench.Telemetry: shader clock and board power of the timed decodes)."""
     import time
     vae = WanVAE(vae_pth=None, device=device)
     z = latent.detach().float()
     z = (z - z.mean()) / z.std().clamp_min(1e-6)
     vae.decode([z[:, :2]])                     # warm-up: two chunks (first + steady state)
     torch.cuda.synchronize()
+    if telemetry is not None:
+        telemetry.start()
     t0 = time.perf_counter()
     for _ in range(iters):
         out = vae.decode([z])[0]
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
+    tele = telemetry.stop() if telemetry is not None else None
     frames = out.shape[1]
     area = (z.shape[2] * z.shape[3]) / (60 * 104)
     flops = (4.29 + (z.shape[1] - 1) * 13.49) * 1e12 * area
     res = {"frames_per_s": round(frames / dt, 2), "decode_s": round(dt, 3), "frames": int(frames), "repeats": iters,
            "conv_tflops": round(flops / dt / 1e12, 1), "mfma_roofline_frac": round(flops / dt / 2.5e15, 4),
            "finite": bool(torch.isfinite(out).all()), "weights": "random-init"}
+    if tele:
+        res["decode_telemetry"] = tele
+        res["mfma_frac_of_peak_at_measured_clock"] = round(flops / dt / 1e12 / tele["mfma_peak_at_mean_clock_tflops"], 4)
     vae.encode([out[:, :5]])                   # warm-up
     torch.cuda.synchronize()
     t0 = time.perf_counter()

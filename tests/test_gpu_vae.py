@@ -123,6 +123,48 @@ def test_conv_cl_w64_random_shapes_equal_the_kw_shared_kernel(ops, monkeypatch):
             assert torch.equal(g, r), (case, Cin, Cout, T, H, W, KT)
 
 
+@pytest.mark.parametrize("shape", [
+    dict(Cin=96, T=2, H=12, W=20),         # one ragged tile
+    dict(Cin=96, T=3, H=24, W=27),         # 3.8 tiles
+    dict(Cin=192, T=2, H=40, W=52),        # the 192 -> 96 block after the last upsample, 8.2 tiles
+])
+def test_conv_cl_fused_norm_equals_conv_then_rms_silu(ops, shape, monkeypatch):
+    """ABI v7: the next layer's RMS norm + SiLU in the stream convolution's epilogue (Cout = 96) against the same
+    convolution followed by omh_rms_silu_cl(_f32in) (OMH_CONV_FUSE_NORM=0 routes through it): the same instructions on
+    the same values in the same order, so y and the normalised output are equal bit for bit — bf16 kind (conv1 of a
+    block; also with norm_only, which writes no y), fp32-trunk kind with a residual (conv2)."""
+    Cin, T, H, W = (shape[k] for k in ("Cin", "T", "H", "W"))
+    Cout, KT = 96, 3
+    torch.manual_seed(Cin + H)
+    x = _bf(torch.randn(KT - 1 + T, H, W, Cin, device="cuda"))
+    wp = _bf(torch.randn(Cout, KT * 9 * Cin, device="cuda") / (Cin * KT * 9) ** 0.5)
+    bias = torch.randn(Cout, device="cuda")
+    gamma = torch.rand(Cout, device="cuda") + 0.5
+    rf = torch.randn(T, H, W, Cout, device="cuda")
+
+    monkeypatch.setenv("OMH_CONV_TILE", "w64")               # these volumes are below the stream kernel's default threshold
+
+    def run(fuse, **kw):
+        monkeypatch.setenv("OMH_CONV_FUSE_NORM", "1" if fuse else "0")
+        n = torch.full((T, H, W, Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+        y = ops.conv_cl(x, wp, bias, T, H, W, Cout, KT, 3, 3, pad_h=1, pad_w=1, norm_gamma=gamma, norm_out=n, **kw)
+        return y, n
+
+    for kw in (dict(), dict(resid=rf, out_f32=True), dict(resid=_bf(rf))):
+        (y1, n1), (y0, n0) = run(True, **kw), run(False, **kw)
+        assert torch.equal(y1, y0), kw.keys()
+        assert bool(torch.isfinite(n0.float()).all()) and torch.equal(n1, n0), (kw.keys(), float((n1.float() - n0.float()).abs().max()))
+        want = ops.rms_silu_cl(y0, gamma)
+        assert torch.equal(n0, want)
+    # norm_only: the normalised output alone (y's stores fall outside an empty descriptor)
+    monkeypatch.setenv("OMH_CONV_FUSE_NORM", "1")
+    n = torch.empty(T, H, W, Cout, dtype=torch.bfloat16, device="cuda")
+    sentinel = torch.full((T, H, W, Cout), 7.0, dtype=torch.bfloat16, device="cuda")
+    ops.conv_cl(x, wp, bias, T, H, W, Cout, KT, 3, 3, pad_h=1, pad_w=1, norm_gamma=gamma, norm_out=n, norm_only=True, out=sentinel)
+    _, n0 = run(False)
+    assert torch.equal(n, n0) and bool((sentinel == 7.0).all())
+
+
 @pytest.mark.parametrize("tile", ["small", "wide"])
 def test_conv_cl_upsample_downsample_stride_split(ops, tile, monkeypatch):
     monkeypatch.setenv("OMH_CONV_TILE", tile)
