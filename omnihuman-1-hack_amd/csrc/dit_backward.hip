@@ -76,6 +76,62 @@ void colsum_multi_kernel(const omh_colsum_batch b, const int rpb) {
     atomicAdd(b.out[e] + c, s);
 }
 
+// The same with 16-byte loads (round 3; the one-column-per-thread kernel above reads bf16 two bytes at a time and ran at
+// 2.8 TB/s, 2.7 ms per training step at 4 clips): a block is 32 column groups of 8 columns x 8 row lanes, a thread adds
+// rows r0 + lane, r0 + lane + 8, ... of its chunk, the 8 lanes of a column are combined in LDS in a fixed order, one
+// atomic per column and chunk (none to combine with when rpb covers all rows: deterministic mode).
+// Needs C % 8 == 0, ld % 8 == 0 and 16-byte aligned rows (the host checks).
+__global__ __launch_bounds__(256)
+void colsum_multi_vec_kernel(const omh_colsum_batch b, const int rpb) {
+    __shared__ float red[8][256 + 8];
+    int e = 0, local = blockIdx.x;
+#pragma unroll 1
+    while (e + 1 < b.n && local >= b.blocks[e]) { local -= b.blocks[e]; ++e; }
+    const int C = b.C[e];
+    const int col_chunks = (C + 255) / 256;
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int cbase = (local % col_chunks) * 256;
+    const int c0 = cbase + cg * 8;
+    const int64_t R = b.R[e], ld = b.ld[e];
+    const int64_t r0 = (int64_t)(local / col_chunks) * rpb;
+    const int64_t r1 = min(R, r0 + rpb);
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = 0.f;
+    if (c0 < C) {
+        if (b.is_bf16[e]) {
+            const uint16_t* x = (const uint16_t*)b.x[e];
+            for (int64_t r = r0 + rl; r < r1; r += 8) {
+                const uint4 u = *(const uint4*)(x + r * ld + c0);
+                const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    s[2 * k] += __uint_as_float(w[k] << 16);
+                    s[2 * k + 1] += __uint_as_float(w[k] & 0xffff0000u);
+                }
+            }
+        } else {
+            const float* x = (const float*)b.x[e];
+            for (int64_t r = r0 + rl; r < r1; r += 8) {
+                const float4 a = *(const float4*)(x + r * ld + c0);
+                const float4 c = *(const float4*)(x + r * ld + c0 + 4);
+                s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
+                s[4] += c.x; s[5] += c.y; s[6] += c.z; s[7] += c.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[rl][cg * 8 + k] = s[k];
+    __syncthreads();
+    const int c = cbase + threadIdx.x;
+    if (c < C) {
+        float t = red[0][threadIdx.x];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][threadIdx.x];
+        atomicAdd(b.out[e] + c, t);
+    }
+}
+
 // ------------------------------------------------------------------ GELU-tanh fwd / bwd (bf16)
 
 __global__ __launch_bounds__(256)
@@ -515,15 +571,20 @@ extern "C" int omh_colsum_accum_multi(const omh_colsum_batch* batch, omh_stream_
     if (!batch || batch->n <= 0 || batch->n > OMH_COLSUM_MAX) return OMH_E_BADARG;
     omh_colsum_batch b = *batch;
     int64_t total = 0;
-    const int rpb = omh_deterministic() ? 0x40000000 : 32;           // deterministic: one row block per column chunk
+    bool vec = true;                                                 // 16-byte loads: every matrix must allow them
     for (int i = 0; i < b.n; ++i) {
         if (!b.x[i] || !b.out[i] || b.R[i] <= 0 || b.C[i] <= 0 || b.ld[i] < b.C[i]) return OMH_E_BADARG;
+        vec = vec && (b.C[i] & 7) == 0 && (b.ld[i] & 7) == 0 && ((uintptr_t)b.x[i] & 15) == 0;
+    }
+    const int rpb = omh_deterministic() ? 0x40000000 : (vec ? 128 : 32);    // deterministic: one row block per column chunk
+    for (int i = 0; i < b.n; ++i) {
         b.blocks[i] = (int32_t)(((b.C[i] + 255) / 256) * ((b.R[i] + rpb - 1) / rpb));
         total += b.blocks[i];
     }
     if (total > 0x7fffffff) return OMH_E_SHAPE;
     omh_clear_status();
-    hipLaunchKernelGGL(colsum_multi_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, b, rpb);
+    if (vec) hipLaunchKernelGGL(colsum_multi_vec_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, b, rpb);
+    else hipLaunchKernelGGL(colsum_multi_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, b, rpb);
     return omh_launch_status();
 }
 

@@ -115,6 +115,15 @@ def test_backward_kernels(ops):
     ops.colsum_accum_multi(list(zip(mats, outs)))                 # 19 entries: two launches
     for m, o in zip(mats, outs):
         assert rel_rms(o, 3 + m.float().sum(0)) < 2e-5, tuple(m.shape)
+    # ... and a batch in which every matrix allows 16-byte loads (widths and row pitches multiples of 8): the vector kernel
+    big = torch.randn(6240, 4608, device="cuda").to(torch.bfloat16)
+    mats = [big[:, :1536], big[:, 1536:], torch.randn(6240, 8960, device="cuda").to(torch.bfloat16),
+            torch.randn(2048, 3072, device="cuda"), torch.randn(1, 8, device="cuda").to(torch.bfloat16),
+            torch.randn(131, 264, device="cuda"), torch.randn(7, 1536, device="cuda").to(torch.bfloat16)]
+    outs = [torch.full((m.shape[1],), -1.5, device="cuda") for m in mats]
+    ops.colsum_accum_multi(list(zip(mats, outs)))
+    for m, o in zip(mats, outs):
+        assert rel_rms(o, -1.5 + m.float().sum(0)) < 2e-5, tuple(m.shape)
     # GELU
     xp = torch.randn(64, 64, device="cuda").to(torch.bfloat16)
     dy = torch.randn(64, 64, device="cuda").to(torch.bfloat16)
