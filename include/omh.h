@@ -199,6 +199,12 @@ typedef struct omh_attn_bwd_args {
        keys, 64-position tiles staged by LDS-DMA into a double buffer, the transposed operands read from the
        row-major tiles with ds_read_b64_tr_b16 — qt / dot / kt are not read (may be NULL). */
     const float* o32;
+    /* ABI v7 (round-3 kernels only, o32 != NULL).  phase 0: everything (the dQ kernel computes delta, then dK/dV).
+       1: delta only (a small kernel, the same arithmetic as the dQ kernel's prologue); 2: dQ only, reading the delta a
+       phase-1 call left in `delta`; 3: dK/dV only, likewise.  Phases 2 and 3 are independent of each other: a caller
+       may issue them on two streams (the dQ kernel's 624 workgroups on 512 slots and the dK/dV kernel's 624 on 256
+       each leave most of their last round idle at 4 clips x 1560 positions). */
+    int32_t phase;
 } omh_attn_bwd_args;
 
 int omh_flash_attn_bwd_d128(const omh_attn_bwd_args* args, omh_stream_t stream);

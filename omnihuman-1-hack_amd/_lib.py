@@ -105,7 +105,8 @@ class AttnBwdArgs(C.Structure):
                 ("B", i32), ("H", i32), ("Lq", i32), ("Lk", i32),
                 ("q_bs", i64), ("q_rs", i64), ("k_bs", i64), ("k_rs", i64), ("o_bs", i64), ("o_rs", i64),
                 ("dq_bs", i64), ("dq_rs", i64), ("dk_bs", i64), ("dk_rs", i64), ("qt_bs", i64), ("kt_bs", i64),
-                ("ldq", i32), ("ldk", i32), ("scale", f32), ("q_prescaled", i32), ("out_bf16", i32), ("o32", vp)]
+                ("ldq", i32), ("ldk", i32), ("scale", f32), ("q_prescaled", i32), ("out_bf16", i32), ("o32", vp),
+                ("phase", i32)]
 
 
 class LnBwdArgs(C.Structure):

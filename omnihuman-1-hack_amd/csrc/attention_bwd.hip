@@ -407,6 +407,7 @@ extern "C" int omh_flash_attn_bwd_d128(const omh_attn_bwd_args* args, omh_stream
         const int rc = omh_launch_attn_bwd2(a, (hipStream_t)stream);
         return rc ? rc : omh_launch_status();
     }
+    if (a.phase != 0) return OMH_E_BADARG;                           // phases exist for the round-3 kernels only
     if (!a.qt || !a.dot || !a.kt) return OMH_E_BADARG;
     if (a.B <= 0 || a.H <= 0 || a.Lq <= 0 || a.Lk <= 0) return OMH_E_BADARG;
     if ((a.q_rs & 7) || (a.k_rs & 7) || (a.o_rs & 7) || (a.q_bs & 7) || (a.k_bs & 7) || (a.o_bs & 7) || (a.ldq & 7) ||

@@ -125,6 +125,39 @@ __device__ __forceinline__ void tile_dma(const TileSrc& t, int tile, unsigned ch
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// ---------------------------------------------------------------------------------------------- delta alone (phase 1)
+// delta[b][h][q] = sum_d dO[q][d] o32[q][d] with the dQ kernel's arithmetic: two threads per (row, head), each the
+// sequential fma chain over its 8 runs of 8 channels (d = 16 kk + 8 lh ..), the two halves added
+__global__ __launch_bounds__(256)
+void attn_bwd2_delta_kernel(const omh_attn_bwd_args p) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lh = (int)(t & 1);
+    const int64_t pair = t >> 1;
+    const int head = (int)(pair % p.H);
+    const int64_t row = pair / p.H;                       // b * Lq + q
+    const bool ok = row < (int64_t)p.B * p.Lq;
+    float del = 0.f;
+    int b = 0, q = 0;
+    if (ok) {
+        b = (int)(row / p.Lq);
+        q = (int)(row - (int64_t)b * p.Lq);
+        const uint16_t* DO = (const uint16_t*)p.dout + (int64_t)b * p.o_bs + (int64_t)q * p.o_rs + head * D;
+        const float* O32 = p.o32 + (int64_t)b * p.o_bs + (int64_t)q * p.o_rs + head * D;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const uint4 dw = *(const uint4*)(DO + kk * 16 + lh * 8);
+            const float4 o0 = *(const float4*)(O32 + kk * 16 + lh * 8);
+            const float4 o1 = *(const float4*)(O32 + kk * 16 + lh * 8 + 4);
+            del = fmaf(bf_lo(dw.x), o0.x, del); del = fmaf(bf_hi(dw.x), o0.y, del);
+            del = fmaf(bf_lo(dw.y), o0.z, del); del = fmaf(bf_hi(dw.y), o0.w, del);
+            del = fmaf(bf_lo(dw.z), o1.x, del); del = fmaf(bf_hi(dw.z), o1.y, del);
+            del = fmaf(bf_lo(dw.w), o1.z, del); del = fmaf(bf_hi(dw.w), o1.w, del);
+        }
+    }
+    del += __shfl_xor(del, 1, 64);
+    if (ok && lh == 0) p.delta[((int64_t)b * p.H + head) * p.Lq + q] = del;
+}
+
 // ---------------------------------------------------------------------------------------------- dQ (+ delta)
 __global__ __launch_bounds__(256, 2)
 void attn_bwd2_dq_kernel(const omh_attn_bwd_args p, const int q_blocks) {
@@ -152,7 +185,7 @@ void attn_bwd2_dq_kernel(const omh_attn_bwd_args p, const int q_blocks) {
         qf[kk] = __builtin_bit_cast(bf16x8, ld16(Q + (int64_t)q_row * p.q_rs + kk * 16 + lh * 8, q_ok));
         const uint4 dw = ld16(DO + (int64_t)q_row * p.o_rs + kk * 16 + lh * 8, q_ok);
         dof[kk] = __builtin_bit_cast(bf16x8, dw);
-        if (q_ok) {                                                  // delta = sum_d dO * O (fp32 O of the forward)
+        if (q_ok && p.phase == 0) {                                  // delta = sum_d dO * O (fp32 O of the forward)
             const float4 o0 = *(const float4*)(O32 + (int64_t)q_row * p.o_rs + kk * 16 + lh * 8);
             const float4 o1 = *(const float4*)(O32 + (int64_t)q_row * p.o_rs + kk * 16 + lh * 8 + 4);
             del = fmaf(bf_lo(dw.x), o0.x, del); del = fmaf(bf_hi(dw.x), o0.y, del);
@@ -167,7 +200,8 @@ void attn_bwd2_dq_kernel(const omh_attn_bwd_args p, const int q_blocks) {
     if (q_ok) {
         const float l = p.lse[row_i];
         l2 = (l > -INFINITY) ? l * LOG2E : INFINITY;
-        if (lh == 0) p.delta[row_i] = del;                           // the dK/dV kernel reads it
+        if (p.phase != 0) del = p.delta[row_i];                      // phase 2: a phase-1 launch computed it
+        else if (lh == 0) p.delta[row_i] = del;                      // the dK/dV kernel reads it
     }
     const float sc = p.q_prescaled ? 1.0f : p.scale * LOG2E;
     float lv[16], dl[16];
@@ -405,7 +439,15 @@ int omh_launch_attn_bwd2(const omh_attn_bwd_args& a, hipStream_t s) {
         attr_set = true;
     }
     const int k_blocks = (a.Lk + 127) / 128, q_blocks = (a.Lq + 127) / 128;
-    hipLaunchKernelGGL(attn_bwd2_dq_kernel, dim3(q_blocks * a.H * a.B), dim3(256), LDS_DQ, s, a, q_blocks);      // writes delta
-    hipLaunchKernelGGL(attn_bwd2_dkdv_kernel, dim3(k_blocks * a.H * a.B), dim3(256), LDS_KV, s, a, k_blocks);   // reads it
+    if (a.phase < 0 || a.phase > 3) return OMH_E_BADARG;
+    if (a.phase == 1) {
+        const int64_t threads = (int64_t)a.B * a.Lq * a.H * 2;
+        hipLaunchKernelGGL(attn_bwd2_delta_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
+        return 0;
+    }
+    if (a.phase == 0 || a.phase == 2)
+        hipLaunchKernelGGL(attn_bwd2_dq_kernel, dim3(q_blocks * a.H * a.B), dim3(256), LDS_DQ, s, a, q_blocks);    // phase 0: writes delta
+    if (a.phase == 0 || a.phase == 3)
+        hipLaunchKernelGGL(attn_bwd2_dkdv_kernel, dim3(k_blocks * a.H * a.B), dim3(256), LDS_KV, s, a, k_blocks);  // reads it
     return 0;
 }

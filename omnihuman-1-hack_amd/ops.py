@@ -132,14 +132,17 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, k_lens: Optio
     return out
 
 
-def flash_attn_bwd(q, k, v, o, dout, lse, k_lens, B, H, Lq, Lk, scale=None, q_prescaled=False, out=None, o32=None):
+def flash_attn_bwd(q, k, v, o, dout, lse, k_lens, B, H, Lq, Lk, scale=None, q_prescaled=False, out=None, o32=None,
+                   phase=0, delta=None):
     """Fused attention backward (include/omh.h).  q, dout: bf16 [B*Lq, H*128]; k, v: bf16 [B*Lk, H*128] (row stride
     free); lse fp32 [B, H, Lq] from ``flash_attn_raw(..., lse=)``; k_lens int32 [B] or None.
     Returns fp32 dq [B*Lq, H*128], dk, dv [B*Lk, H*128] — or, with ``out=(dq, dk, dv)`` bf16 2-D tensors (row stride
     free: e.g. the three column blocks of one [rows, 3*H*128] buffer), writes bf16 gradients there.
     ``q_prescaled``: q carries scale*log2(e) as in the forward call.  ``o32``: the forward's fp32 output
     (``flash_attn_raw(..., o32=)``, fp32 [B*Lq, H*128] contiguous) — selects the round-3 kernels (no transposed copies,
-    delta from dO . o32); without it round 2's kernels run (three transposes + a delta pass over the keys)."""
+    delta from dO . o32); without it round 2's kernels run (three transposes + a delta pass over the keys).
+    ``phase`` (with o32): 0 everything; 1 delta only, 2 dQ only, 3 dK / dV only — 2 and 3 read the ``delta`` tensor
+    (fp32 [B, H, Lq]) a phase-1 call filled and may run on two streams."""
     _dev(q, k, v, dout, lse, k_lens, o32)
     d = H * 128
     for t in (q, k, v, dout):
@@ -161,7 +164,10 @@ def flash_attn_bwd(q, k, v, o, dout, lse, k_lens, B, H, Lq, Lk, scale=None, q_pr
         transpose_bf16_raw(ptr(k), ptr(kt), Lk, d, rs(k), ldk, batch=B, bs_in=Lk * rs(k), bs_out=d * ldk)
     else:
         assert o32.dtype == torch.float32 and o32.is_contiguous() and o32.shape[-1] == d and rs(dout) == d
-    delta = torch.empty(B, H, Lq, dtype=torch.float32, device=dev)
+    assert phase == 0 or (o32 is not None and delta is not None)
+    if delta is None:
+        delta = torch.empty(B, H, Lq, dtype=torch.float32, device=dev)
+    assert delta.dtype == torch.float32 and delta.is_contiguous() and delta.numel() == B * H * Lq
     if out is None:
         dq = torch.empty(B * Lq, d, dtype=torch.float32, device=dev)
         dk = torch.empty(B * Lk, d, dtype=torch.float32, device=dev)
@@ -178,7 +184,7 @@ def flash_attn_bwd(q, k, v, o, dout, lse, k_lens, B, H, Lq, Lk, scale=None, q_pr
                          _p(dq), _p(dk), _p(dv), _p(k_lens), B, H, Lq, Lk,
                          Lq * rs(q), rs(q), Lk * rs(k), rs(k), Lq * rs(dout), rs(dout), Lq * dq.stride(0), dq.stride(0),
                          Lk * dk.stride(0), dk.stride(0), d * ldq, d * ldk, ldq, ldk,
-                         float(scale if scale is not None else 128 ** -0.5), int(q_prescaled), bf, _p(o32))
+                         float(scale if scale is not None else 128 ** -0.5), int(q_prescaled), bf, _p(o32), int(phase))
     check(lib.omh_flash_attn_bwd_d128(C.byref(a), _stream()), "omh_flash_attn_bwd_d128")
     return dq, dk, dv
 

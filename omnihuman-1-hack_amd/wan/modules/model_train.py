@@ -191,7 +191,32 @@ _WGRAD_STREAM = os.environ.get("OMH_WGRAD_STREAM", "1") == "1"
 # OMH_ATTN_BWD=v1: round 2's attention-backward kernels (three transposed copies + a delta pass over the keys per
 # call) instead of round 3's (csrc/attention_bwd2.hip, which read the forward's fp32 output) — A/B timing
 _ATTN_BWD2 = os.environ.get("OMH_ATTN_BWD", "v2") != "v1"
+# OMH_ATTN_BWD_SPLIT=1: the dQ and the dK / dV kernel of an attention backward on two streams (after a small delta
+# kernel they are independent; each alone leaves most of its last round of workgroups idle at S = 1560)
+_ATTN_SPLIT = os.environ.get("OMH_ATTN_BWD_SPLIT", "0") == "1"
 _side = {}
+_side2 = {}
+
+
+def _attn_bwd(q, k, v, o, do, lse, lens, B, N, Lq, Lk, scale, out, o32, q_prescaled):
+    """ops.flash_attn_bwd on the block's pre-scaled q, bf16 gradients into ``out`` — as one call, or (OMH_ATTN_BWD_SPLIT)
+    as delta -> {dQ on this stream, dK / dV on a second one} -> join."""
+    if not (_ATTN_SPLIT and o32 is not None):
+        return ops.flash_attn_bwd(q, k, v, o, do, lse, lens, B, N, Lq, Lk, scale, q_prescaled=q_prescaled, out=out, o32=o32)
+    dev = q.device
+    delta = torch.empty(B, N, Lq, dtype=torch.float32, device=dev)
+    kw = dict(q_prescaled=q_prescaled, out=out, o32=o32, delta=delta)
+    ops.flash_attn_bwd(q, k, v, o, do, lse, lens, B, N, Lq, Lk, scale, phase=1, **kw)
+    main = torch.cuda.current_stream(dev)
+    s2 = _side2.get(dev)
+    if s2 is None:
+        s2 = _side2[dev] = torch.cuda.Stream(device=dev)
+    s2.wait_stream(main)
+    with torch.cuda.stream(s2):
+        ops.flash_attn_bwd(q, k, v, o, do, lse, lens, B, N, Lq, Lk, scale, phase=3, **kw)
+    ops.flash_attn_bwd(q, k, v, o, do, lse, lens, B, N, Lq, Lk, scale, phase=2, **kw)
+    main.wait_stream(s2)
+    return out
 
 
 def _side_stream(dev):
@@ -553,8 +578,8 @@ def _block_backward(model, blk, idx, st, S, dx, P):
     dqc = bf(R, d)
     dkv = bf(Rc, 2 * d)                                               # dk | dv of the text keys, one buffer
     if not i2v:
-        ops.flash_attn_bwd(qc, kc, vc, oc, doc, S["lse_ca"], fc.ctx_lens32, B, N, Sq, Lt, D ** -0.5,
-                           out=(dqc, dkv[:, :d], dkv[:, d:]), o32=S["o32_ca"])
+        _attn_bwd(qc, kc, vc, oc, doc, S["lse_ca"], fc.ctx_lens32, B, N, Sq, Lt, D ** -0.5,
+                  (dqc, dkv[:, :d], dkv[:, d:]), S["o32_ca"], False)
     else:                                                             # the image-token branch: same q, same dO
         oi, ki = S["oi"], S["ki"]
         wg.launch()                                                  # (the second product ADDS to the first one's result)
@@ -609,8 +634,8 @@ def _block_backward(model, blk, idx, st, S, dx, P):
     do = _dgrad(dy1, P["woT"], epilogue=EPI_BF16)
     v = ops.transpose_bf16_batched(S["vt"], Sq)                       # [B*S, d]
     dqkv = bf(R, 3 * d)                                               # dq | dk | dv, one buffer
-    ops.flash_attn_bwd(q, k, v, o, do, S["lse_sa"], fc.seq_lens32, B, N, Sq, Sq, D ** -0.5, q_prescaled=True,
-                       out=(dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]), o32=S["o32_sa"])
+    _attn_bwd(q, k, v, o, do, S["lse_sa"], fc.seq_lens32, B, N, Sq, Sq, D ** -0.5,
+              (dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]), S["o32_sa"], True)
     qk = S["qk"]
     rms_bwd(ptr(qk), True, 2 * d, ptr(dqkv), 3 * d, R, [sa._norm_w("norm_q"), sa._norm_w("norm_k")], sa.qk_norm, True,
             ["self_attn.norm_q.weight", "self_attn.norm_k.weight"], sa, n_seg=2, seg_x=d, seg_dy=d)   # q and k: one launch

@@ -490,6 +490,13 @@ def test_attention_backward_round3_kernels(ops, B, H, Lq, Lk, lens):
         assert torch.equal(o32.bfloat16(), o)                          # the same values before the rounding
         dq1, dk1, dv1 = ops.flash_attn_bwd(q, k, v, o, do, lse, klens, B, H, Lq, Lk, scale, q_prescaled=pres)
         dq2, dk2, dv2 = ops.flash_attn_bwd(q, k, v, o, do, lse, klens, B, H, Lq, Lk, scale, q_prescaled=pres, o32=o32)
+        # the same in phases (ABI v7): delta alone, then dQ and dK / dV each alone (in either order): the same bits
+        delta = torch.full((B, H, Lq), float("nan"), device="cuda")
+        ph = dict(q_prescaled=pres, o32=o32, delta=delta)
+        ops.flash_attn_bwd(q, k, v, o, do, lse, klens, B, H, Lq, Lk, scale, phase=1, **ph)
+        _, dk3, dv3 = ops.flash_attn_bwd(q, k, v, o, do, lse, klens, B, H, Lq, Lk, scale, phase=3, **ph)
+        dq3, _, _ = ops.flash_attn_bwd(q, k, v, o, do, lse, klens, B, H, Lq, Lk, scale, phase=2, **ph)
+        assert torch.equal(dq3, dq2) and torch.equal(dk3, dk2) and torch.equal(dv3, dv2)
         for a_, b_, nm in ((dq2, dq1, "dq"), (dk2, dk1, "dk"), (dv2, dv1, "dv")):
             assert torch.isfinite(a_).all()
             e = rel_rms(a_, b_)
