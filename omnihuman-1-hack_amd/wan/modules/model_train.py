@@ -191,9 +191,12 @@ _WGRAD_STREAM = os.environ.get("OMH_WGRAD_STREAM", "1") == "1"
 # OMH_ATTN_BWD=v1: round 2's attention-backward kernels (three transposed copies + a delta pass over the keys per
 # call) instead of round 3's (csrc/attention_bwd2.hip, which read the forward's fp32 output) — A/B timing
 _ATTN_BWD2 = os.environ.get("OMH_ATTN_BWD", "v2") != "v1"
-# OMH_ATTN_BWD_SPLIT=1: the dQ and the dK / dV kernel of an attention backward on two streams (after a small delta
-# kernel they are independent; each alone leaves most of its last round of workgroups idle at S = 1560)
-_ATTN_SPLIT = os.environ.get("OMH_ATTN_BWD_SPLIT", "0") == "1"
+# The dQ and the dK / dV kernel of an attention backward on two streams (after a small delta kernel they are
+# independent): at 4 clips x 1560 positions each alone leaves most of its last round of workgroups idle (624 on 512 /
+# 256 slots).  Measured, one box, interleaved: 86.1 -> 85.4 ms per step at 4 clips (the weight-gradient stream already
+# fills most of those gaps), 43.6 -> 44.0 at 1 clip — hence only when a kernel has more than one round of workgroups.
+# OMH_ATTN_BWD_SPLIT=0 / 1 forces it off / on.
+_ATTN_SPLIT = os.environ.get("OMH_ATTN_BWD_SPLIT", "auto")
 _side = {}
 _side2 = {}
 
@@ -201,7 +204,8 @@ _side2 = {}
 def _attn_bwd(q, k, v, o, do, lse, lens, B, N, Lq, Lk, scale, out, o32, q_prescaled):
     """ops.flash_attn_bwd on the block's pre-scaled q, bf16 gradients into ``out`` — as one call, or (OMH_ATTN_BWD_SPLIT)
     as delta -> {dQ on this stream, dK / dV on a second one} -> join."""
-    if not (_ATTN_SPLIT and o32 is not None):
+    split = _ATTN_SPLIT == "1" or (_ATTN_SPLIT == "auto" and B * N * ((Lq + 127) // 128) > 512)
+    if not (split and o32 is not None):
         return ops.flash_attn_bwd(q, k, v, o, do, lse, lens, B, N, Lq, Lk, scale, q_prescaled=q_prescaled, out=out, o32=o32)
     dev = q.device
     delta = torch.empty(B, N, Lq, dtype=torch.float32, device=dev)
