@@ -126,28 +126,55 @@ __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w <<
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
 // ---------------------------------------------------------------------------------------------- delta alone (phase 1)
-// delta[b][h][q] = sum_d dO[q][d] o32[q][d] with the dQ kernel's arithmetic: two threads per (row, head), each the
-// sequential fma chain over its 8 runs of 8 channels (d = 16 kk + 8 lh ..), the two halves added
+// delta[b][h][q] = sum_d dO[q][d] o32[q][d] with the dQ kernel's arithmetic (two chains per (row, head): the sequential
+// fma chain over the 8 runs of 8 channels d = 16 kk + 8 lh .., the two halves added) — the same bits as phase 0.
+// A block takes 32 consecutive (row, head) pairs: their 8 KiB of dO and 16 KiB of o32 are fetched with coalesced
+// 16-byte loads into LDS (the chains' own access pattern is 16 bytes every 32: 24 us per call when read directly),
+// then 64 threads run the chains.
 __global__ __launch_bounds__(256)
 void attn_bwd2_delta_kernel(const omh_attn_bwd_args p) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int lh = (int)(t & 1);
-    const int64_t pair = t >> 1;
-    const int head = (int)(pair % p.H);
-    const int64_t row = pair / p.H;                       // b * Lq + q
-    const bool ok = row < (int64_t)p.B * p.Lq;
-    float del = 0.f;
-    int b = 0, q = 0;
-    if (ok) {
+    constexpr int PD = 256 + 16, PO = 512 + 16;                     // row pitches: 16-byte reads of 32 rows spread over the banks
+    __shared__ __attribute__((aligned(16))) unsigned char sdo[32 * PD];
+    __shared__ __attribute__((aligned(16))) unsigned char so[32 * PO];
+    const int tid = threadIdx.x;
+    const int64_t pair0 = (int64_t)blockIdx.x * 32;
+    const int64_t npairs = (int64_t)p.B * p.Lq * p.H;
+    auto locate = [&](int64_t pair, int& b, int& q, int& head) {
+        head = (int)(pair % p.H);
+        const int64_t row = pair / p.H;
         b = (int)(row / p.Lq);
         q = (int)(row - (int64_t)b * p.Lq);
-        const uint16_t* DO = (const uint16_t*)p.dout + (int64_t)b * p.o_bs + (int64_t)q * p.o_rs + head * D;
-        const float* O32 = p.o32 + (int64_t)b * p.o_bs + (int64_t)q * p.o_rs + head * D;
+    };
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {                                   // dO: 32 pairs x 16 chunks of 16 bytes
+        const int c = tid + 256 * j, pr = c >> 4, ch = c & 15;
+        if (pair0 + pr < npairs) {
+            int b, q, head;
+            locate(pair0 + pr, b, q, head);
+            *(uint4*)(sdo + pr * PD + ch * 16) =
+                *(const uint4*)((const uint16_t*)p.dout + (int64_t)b * p.o_bs + (int64_t)q * p.o_rs + head * D + ch * 8);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                                   // o32: 32 pairs x 32 chunks of 16 bytes
+        const int c = tid + 256 * j, pr = c >> 5, ch = c & 31;
+        if (pair0 + pr < npairs) {
+            int b, q, head;
+            locate(pair0 + pr, b, q, head);
+            *(float4*)(so + pr * PO + ch * 16) = *(const float4*)(p.o32 + (int64_t)b * p.o_bs + (int64_t)q * p.o_rs + head * D + ch * 4);
+        }
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    const int pr = tid >> 1, lh = tid & 1;
+    const bool ok = pair0 + pr < npairs;
+    float del = 0.f;
+    if (ok) {
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
-            const uint4 dw = *(const uint4*)(DO + kk * 16 + lh * 8);
-            const float4 o0 = *(const float4*)(O32 + kk * 16 + lh * 8);
-            const float4 o1 = *(const float4*)(O32 + kk * 16 + lh * 8 + 4);
+            const uint4 dw = *(const uint4*)(sdo + pr * PD + (2 * kk + lh) * 16);
+            const float4 o0 = *(const float4*)(so + pr * PO + (2 * kk + lh) * 32);
+            const float4 o1 = *(const float4*)(so + pr * PO + (2 * kk + lh) * 32 + 16);
             del = fmaf(bf_lo(dw.x), o0.x, del); del = fmaf(bf_hi(dw.x), o0.y, del);
             del = fmaf(bf_lo(dw.y), o0.z, del); del = fmaf(bf_hi(dw.y), o0.w, del);
             del = fmaf(bf_lo(dw.z), o1.x, del); del = fmaf(bf_hi(dw.z), o1.y, del);
@@ -155,7 +182,11 @@ void attn_bwd2_delta_kernel(const omh_attn_bwd_args p) {
         }
     }
     del += __shfl_xor(del, 1, 64);
-    if (ok && lh == 0) p.delta[((int64_t)b * p.H + head) * p.Lq + q] = del;
+    if (ok && lh == 0) {
+        int b, q, head;
+        locate(pair0 + pr, b, q, head);
+        p.delta[((int64_t)b * p.H + head) * p.Lq + q] = del;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- dQ (+ delta)
@@ -441,8 +472,8 @@ int omh_launch_attn_bwd2(const omh_attn_bwd_args& a, hipStream_t s) {
     const int k_blocks = (a.Lk + 127) / 128, q_blocks = (a.Lq + 127) / 128;
     if (a.phase < 0 || a.phase > 3) return OMH_E_BADARG;
     if (a.phase == 1) {
-        const int64_t threads = (int64_t)a.B * a.Lq * a.H * 2;
-        hipLaunchKernelGGL(attn_bwd2_delta_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
+        const int64_t pairs = (int64_t)a.B * a.Lq * a.H;
+        hipLaunchKernelGGL(attn_bwd2_delta_kernel, dim3((unsigned)((pairs + 31) / 32)), dim3(256), 0, s, a);
         return 0;
     }
     if (a.phase == 0 || a.phase == 2)
