@@ -41,6 +41,9 @@ class WanT2V:
         self.device = torch.device(f"cuda:{device_id}")
         self.config = config
         self.rank = rank
+        # t5_cpu (text2video.py:56, :205-214: keep umT5 on the host and move the context over) is accepted and has no
+        # effect: the encoder runs on the HIP kernels only (no CPU path in this build) and 11 GB of bf16 umT5-XXL
+        # next to a 1.3B / 14B DiT is nothing on 288 GB
         self.t5_cpu = t5_cpu
         self.num_train_timesteps = config.num_train_timesteps
         self.param_dtype = config.param_dtype
