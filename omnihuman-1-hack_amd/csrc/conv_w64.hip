@@ -65,6 +65,7 @@ void conv_cl_w64_kernel(const omh_conv_args p, const int tiles_m, const int tile
     const int HW = p.Hin * p.Win;
 
     const float rcp_w = 1.0f / (float)p.Wout, rcp_h = 1.0f / (float)p.Hout;
+    const int up = p.up2 ? 1 : 0;                                     // folded nearest-2x upsample: Hout = 2 Hin, Wout = 2 Win
 
     typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
@@ -85,7 +86,7 @@ void conv_cl_w64_kernel(const omh_conv_args p, const int tiles_m, const int tile
             int xo, yo, to, vy;
             divmod24(vc, p.Wout, rcp_w, vy, xo);
             divmod24(vy, p.Hout, rcp_h, to, yo);
-            off2 = (uint32_t)(((to * HW + xo) * p.Cin + ls * 8) * 2);
+            off2 = (uint32_t)(((to * HW + (xo >> up)) * p.Cin + ls * 8) * 2);   // up2: input column x >> 1 (the slab holds the UPSAMPLED row)
             ay = ok ? (uint32_t)(yo - p.pad_h) : (uint32_t)-16384;   // rows outside the volume never pass the bounds test
         }
         tab[q] = off2;
@@ -153,11 +154,11 @@ void conv_cl_w64_kernel(const omh_conv_args p, const int tiles_m, const int tile
     const int cblocks = p.Cin >> 5;
     const uint64_t p0 = pack2(lds0 + A_OFF + (uint32_t)(a_first * 1024),
                               lds0 + A_OFF + A_BYTES + (uint32_t)((CFG == CFG_P ? 4 : 9) * w * 1024));
-    const uint64_t p1 = pack2((uint32_t)(p.Win * p.Cin * 2), (uint32_t)p.Hin);
+    const uint64_t p1 = pack2((uint32_t)(p.Win * p.Cin * 2), (uint32_t)(p.Hin << up));   // row bytes of the INPUT, rows of the upsampled image
     const uint64_t p2 = pack2((uint32_t)cblocks, (uint32_t)(p.KT * 3 * cblocks));
     const uint64_t p3 = pack2((uint32_t)(HW * p.Cin * 2), (uint32_t)(64 - p.Cin * 2));
     const uint64_t p4 = pack2((uint32_t)(4 * p.Cin + 64), lds0 + blast_rel);
-    const uint64_t p5 = pack2((uint32_t)(32 * p.Cout * ES), 0u);
+    const uint64_t p5 = pack2((uint32_t)(32 * p.Cout * ES), (uint32_t)up);
     const uint64_t p6 = pack2(lds0 + 3u * STAGE, __float_as_uint(sqrtf((float)p.Cout)));   // gamma in LDS, sqrt(C)
 
 #define OMH_CW64_RUN(ASM)                                                                                              \
@@ -201,16 +202,18 @@ int launch_cw64(const omh_conv_args& a, int64_t M, hipStream_t s) {
 
 }  // namespace
 
-// 3x3 taps in (h, w), 1 or 3 in t, stride 1, "same" padding, no folded upsample / frame interleave, Cin % 32 == 0,
+// 3x3 taps in (h, w), 1 or 3 in t, stride 1, "same" padding (optionally through the folded 2x upsample), no frame interleave, Cin % 32 == 0,
 // Cout = 96 or a multiple of 192, at least 15 stages (13 are peeled at the head of the stream), the residual (if any) in the output's type, 32-bit byte offsets.
 bool omh_conv_w64_takes(const omh_conv_args& a) {
     const int64_t M = (int64_t)a.Tout * a.Hout * a.Wout;
     const int es = a.out_f32 ? 4 : 2;
-    return a.KW == 3 && a.KH == 3 && (a.KT == 3 || a.KT == 1) && a.stride_hw == 1 && a.stride_t == 1 && !a.up2 &&
-           a.pad_h == 1 && a.pad_w == 1 && a.Hout == a.Hin && a.Wout == a.Win && (a.Cin & 31) == 0 && a.split_n == 0 &&
+    const int up = a.up2 ? 1 : 0;                            // (round 3: also through the folded nearest-2x upsample)
+    if (up) { const char* ue = getenv("OMH_CONV_W64_UP2"); if (ue && ue[0] == '0') return false; }   // A/B timing
+    return a.KW == 3 && a.KH == 3 && (a.KT == 3 || a.KT == 1) && a.stride_hw == 1 && a.stride_t == 1 &&
+           a.pad_h == 1 && a.pad_w == 1 && a.Hout == (a.Hin << up) && a.Wout == (a.Win << up) && (a.Cin & 31) == 0 && a.split_n == 0 &&
            a.Wout >= 3 && (a.Cout == 96 || a.Cout % 192 == 0) && a.KT * 3 * (a.Cin >> 5) >= 15 &&
            (!a.resid || (a.resid_f32 != 0) == (a.out_f32 != 0)) && (((uintptr_t)a.resid) & 15) == 0 &&
-           (((uintptr_t)a.bias) & 15) == 0 && (int64_t)a.Win * a.Cin * 2 < (1 << 24) && a.Hin < 16384 && M < (1 << 24) &&
+           (((uintptr_t)a.bias) & 15) == 0 && (int64_t)a.Win * a.Cin * 2 < (1 << 24) && (a.Hin << up) < 16384 && M < (1 << 24) &&
            (M + 1024) * a.Cout * es < 0x7fffffffLL && (int64_t)a.Tin * a.Hin * a.Win * a.Cin * 2 < 0x7fffffffLL &&
            (int64_t)a.Cout * a.KT * 9 * a.Cin * 2 < 0x7fffffffLL;
 }

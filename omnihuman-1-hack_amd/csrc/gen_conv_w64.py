@@ -41,6 +41,7 @@ CONFIGS = {"P": (8, 5), "Q": (4, 9)}
 # scalar arguments (pairs bound to s[60:73] by conv_w64.hip)
 S_LDSA0, S_LDSB0, S_ROWB, S_HIN, S_CBLK, S_NS, S_FRAME = "s60", "s61", "s62", "s63", "s64", "s65", "s66"
 S_CWRAPA, S_CWRAPW, S_BLAST, S_JSTEP, S_SPARE0, S_SPARE1, S_SPARE2 = "s67", "s68", "s69", "s70", "s71", "s72", "s73"
+S_UP = S_SPARE0                                   # 1: the input is read through a folded nearest-2x upsample (vae.py:76-79), else 0
 # state: s80 LDS offset of the buffer being FETCHED, s81 / s82 source offsets of the A / B stage being fetched,
 # s83 channel block, s84 kh, s85 loop counter, s[86:87] exec save, s89 compute buffer
 # index, s90 / s91 piece bases, s92..s95 temporaries, s97 / s98 stage step constants
@@ -217,7 +218,8 @@ def dma_pieces(NA, NB):
     for q in range(NA):
         t = TMP + (q & 3)
         out.append([("x", f"v_add_u32 v{t}, s84, v{A_Y + q}"),                       # input row of the tap
-                    ("x", f"v_cmp_gt_u32 vcc, {S_HIN}, v{t}"),                      # inside the image (unsigned)
+                    ("x", f"v_cmp_gt_u32 vcc, {S_HIN}, v{t}"),                      # inside the (upsampled) image (unsigned)
+                    ("x", f"v_lshrrev_b32 v{t}, {S_UP}, v{t}"),                     # folded nearest-2x upsample: input row y >> 1
                     ("x", f"v_mad_u32_u24 v{t}, v{t}, {S_ROWB}, v{A_OFF2 + q}"),
                     ("x", f"v_cndmask_b32 v{t}, v{TMP + 4}, v{t}, vcc"),            # outside: beyond the descriptor -> zeros
                     ("x", f"s_add_u32 m0, s90, {q * 1024}"),

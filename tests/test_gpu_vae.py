@@ -165,6 +165,27 @@ def test_conv_cl_fused_norm_equals_conv_then_rms_silu(ops, shape, monkeypatch):
     assert torch.equal(n, n0) and bool((sentinel == 7.0).all())
 
 
+@pytest.mark.parametrize("Cin,Cout,T,H,W", [(192, 96, 2, 13, 21), (384, 192, 1, 9, 17), (160, 96, 3, 6, 5)])
+def test_conv_cl_w64_folded_upsample(ops, Cin, Cout, T, H, W, monkeypatch):
+    """The decoder's upsample convolutions (nearest-2x + Conv2d 3x3, vae.py:76-79) on the stream kernel (round 3: the slab
+    loader reads input row y >> 1, column x >> 1) against torch on the upsampled tensor, and against the 8-wave kernel."""
+    torch.manual_seed(Cin + H)
+    x = _bf(torch.randn(T, H, W, Cin, device="cuda"))
+    w = _bf(torch.randn(Cout, Cin, 3, 3, device="cuda") / (9 * Cin) ** 0.5)
+    wp = w.permute(0, 2, 3, 1).contiguous().view(Cout, -1)
+    bias = torch.randn(Cout, device="cuda")
+    out = {}
+    for tile in ("w64", "wide"):
+        monkeypatch.setenv("OMH_CONV_TILE", tile)
+        out[tile] = ops.conv_cl(x, wp, bias, T, 2 * H, 2 * W, Cout, 1, 3, 3, pad_h=1, pad_w=1, up2=True, out_f32=True)
+    xi = x.float().permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.interpolate(xi, scale_factor=2.0, mode="nearest-exact"), w.float(),
+                                     bias, padding=1).permute(0, 2, 3, 1)
+    assert out["w64"].shape == ref.shape
+    assert rel_rms(out["w64"], ref) < 2e-3 and rel_rms(out["wide"], ref) < 2e-3
+    assert rel_rms(out["w64"], out["wide"]) < 1e-5
+
+
 @pytest.mark.parametrize("tile", ["small", "wide"])
 def test_conv_cl_upsample_downsample_stride_split(ops, tile, monkeypatch):
     monkeypatch.setenv("OMH_CONV_TILE", tile)
