@@ -204,19 +204,26 @@ void gemm_bf16_tn_kernel(const omh_gemm_tn_args p, const TnGeom g) {
 // Several independent products in ONE launch (the weight gradients of a block's backward): 128 x 128 tiles, every
 // tile its whole K range — no split K, hence no atomics (bit-repeatable) — the tiles of all problems together fill the
 // chip where each problem alone (144 tiles of 1536 x 1536 on 512 slots) did not.
-__global__ __launch_bounds__(256, 2)
-void gemm_bf16_tn_grouped_kernel(const omh_gemm_tn_group g) {
+template <int WM, int WN, int MT, int NT>
+__device__ __forceinline__ void tn_grouped_body(const omh_gemm_tn_group& g) {
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     const int wid = xcd_remap(blockIdx.x, g.total_tiles);
     int e = 0;
 #pragma unroll 1
     while (e + 1 < g.n && wid >= g.first_tile[e + 1]) ++e;
     const omh_gemm_tn_args& p = g.problem[e];
     const int local = wid - g.first_tile[e];
-    const int tiles_m = (p.M + 127) / 128, tiles_n = (p.N + 127) / 128;
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     int tm, tn;
     tile_of(local, tiles_m, tiles_n, tm, tn, 4);
-    tn_tile<2, 2, 2, 2>(p, tm, tn, 0, (p.K + BK - 1) / BK, p.accumulate ? 1 : 0);
+    tn_tile<WM, WN, MT, NT>(p, tm, tn, 0, (p.K + BK - 1) / BK, p.accumulate ? 1 : 0);
 }
+__global__ __launch_bounds__(256, 2)
+void gemm_bf16_tn_grouped_kernel(const omh_gemm_tn_group g) { tn_grouped_body<2, 2, 2, 2>(g); }
+// the same on 256 x 256 tiles (half the staged bytes per flop) when the group's tiles still cover most of the chip in
+// ONE round of one workgroup per CU: a block's {cross o, cross q, cross k|v, self o} is 180 such tiles, q|k|v 108
+__global__ __launch_bounds__(512)
+void gemm_bf16_tn_grouped_big_kernel(const omh_gemm_tn_group g) { tn_grouped_body<2, 4, 4, 2>(g); }
 
 template <bool ACCUM, int WM, int WN, int MT, int NT>
 int launch_tn(const omh_gemm_tn_args& a, hipStream_t s) {
@@ -283,14 +290,32 @@ extern "C" int omh_gemm_bf16_tn_grouped(const omh_gemm_tn_group* group, omh_stre
         total += (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
     }
     if (total > 0x7fffffffLL) return OMH_E_SHAPE;
-    g.total_tiles = (int32_t)total;
-    constexpr int LDS = 2 * BK * (128 + 128) * 2;
+    int64_t total_big = 0;
+    for (int i = 0; i < g.n; ++i) total_big += (int64_t)((g.problem[i].M + 255) / 256) * ((g.problem[i].N + 255) / 256);
+    const char* te = getenv("OMH_GEMM_TN_GROUP_TILE");               // "big" / "small": test / timing override
+    // measured (one box, interleaved, whole training step): 85.2 ms with 128 x 128 tiles, 86.5 with 256 x 256 at 4 clips
+    // (43.5 / 45.2 at 1 clip) — one workgroup per CU shares the chip worse with the main stream's kernels — so: opt-in only
+    const bool big = te ? te[0] == 'b' : false;
+    (void)total_big;
+    constexpr int LDS = 2 * BK * (128 + 128) * 2, LDS_BIG = 2 * BK * (256 + 256) * 2;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_tn_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_tn_grouped_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BIG);
         attr_set = true;
     }
     omh_clear_status();
-    hipLaunchKernelGGL(gemm_bf16_tn_grouped_kernel, dim3((unsigned)total), dim3(256), LDS, (hipStream_t)stream, g);
+    if (big) {
+        total = 0;
+        for (int i = 0; i < g.n; ++i) {
+            g.first_tile[i] = (int32_t)total;
+            total += (int64_t)((g.problem[i].M + 255) / 256) * ((g.problem[i].N + 255) / 256);
+        }
+        g.total_tiles = (int32_t)total;
+        hipLaunchKernelGGL(gemm_bf16_tn_grouped_big_kernel, dim3((unsigned)total), dim3(512), LDS_BIG, (hipStream_t)stream, g);
+    } else {
+        g.total_tiles = (int32_t)total;
+        hipLaunchKernelGGL(gemm_bf16_tn_grouped_kernel, dim3((unsigned)total), dim3(256), LDS, (hipStream_t)stream, g);
+    }
     return omh_launch_status();
 }

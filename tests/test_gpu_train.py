@@ -712,9 +712,12 @@ def test_norm_backward_round3_kernels(ops):
     assert rel_rms(dwq, dws_ref[0]) < 1e-5 and rel_rms(dwk, dws_ref[1]) < 1e-5
 
 
-def test_gemm_tn_grouped(ops):
+@pytest.mark.parametrize("tile", ["small", "big"])
+def test_gemm_tn_grouped(ops, tile, monkeypatch):
     """omh_gemm_bf16_tn_grouped: several weight-gradient products in one launch == the single-problem kernel on each
-    (ragged tiles, strided operands out of fused buffers, accumulation), and bit-repeatable (no split K, no atomics)."""
+    (ragged tiles, strided operands out of fused buffers, accumulation), and bit-repeatable (no split K, no atomics) —
+    on 128 x 128 and on 256 x 256 tiles."""
+    monkeypatch.setenv("OMH_GEMM_TN_GROUP_TILE", tile)
     g = torch.Generator(device="cuda").manual_seed(8)
     R = 1000
     dyf = (torch.randn(R, 3 * 256, device="cuda", generator=g) * 0.3).bfloat16()       # dq | dk | dv style buffer
