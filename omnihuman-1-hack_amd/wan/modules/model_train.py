@@ -216,10 +216,12 @@ def _attn_bwd(q, k, v, o, do, lse, lens, B, N, Lq, Lk, scale, out, o32, q_presca
     if s2 is None:
         s2 = _side2[dev] = torch.cuda.Stream(device=dev)
     s2.wait_stream(main)
-    with torch.cuda.stream(s2):
-        ops.flash_attn_bwd(q, k, v, o, do, lse, lens, B, N, Lq, Lk, scale, phase=3, **kw)
-    ops.flash_attn_bwd(q, k, v, o, do, lse, lens, B, N, Lq, Lk, scale, phase=2, **kw)
-    main.wait_stream(s2)
+    try:
+        with torch.cuda.stream(s2):
+            ops.flash_attn_bwd(q, k, v, o, do, lse, lens, B, N, Lq, Lk, scale, phase=3, **kw)
+        ops.flash_attn_bwd(q, k, v, o, do, lse, lens, B, N, Lq, Lk, scale, phase=2, **kw)
+    finally:
+        main.wait_stream(s2)                                 # also on an exception: nothing may stay on the second stream
     return out
 
 
