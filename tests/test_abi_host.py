@@ -212,3 +212,34 @@ def test_from_pretrained_diffusers_layout_and_module_surface(omh, tmp_path):
     if not torch.cuda.is_available():
         with pytest.raises(Exception, match="MI355X|GPU|cuda"):
             m([torch.zeros(16, 1, 4, 4)], torch.tensor([1.0]), [torch.zeros(3, 64)], 4)   # no CPU fallback
+
+
+def test_checkpoint_flag_as_memory_policy(omh, wan_model_mod, monkeypatch):
+    """model.use_checkpoint (model.py:404,544-553) is honoured as a memory policy (model_train.keep_activations): False
+    keeps the activations; True keeps them under the default "auto" policy when a step's worth fits in half of the free
+    HBM and re-runs the blocks otherwise — or always with checkpoint_policy = "always" / OMH_CHECKPOINT_POLICY."""
+    mt = importlib.import_module(PKG + ".wan.modules.model_train")
+    from oracle import make_golden
+    m = wan_model_mod.WanModel(num_layers=3, **make_golden.TINY)
+    assert m.use_checkpoint is True and m.checkpoint_policy == "auto"
+    blk = m.blocks[0]
+    rows = 6240
+    need = len(m.blocks) * rows * (42 * blk.dim + 4 * blk.ffn_dim) * 1.15
+    free = {"bytes": int(4 * need)}
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda device=None: (free["bytes"], 0))
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda device=None: 0)
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda device=None: 0)
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    monkeypatch.delenv("OMH_CHECKPOINT_POLICY", raising=False)
+    dev = torch.device("cpu")
+    assert mt.keep_activations(m, rows, dev) is True                   # fits in half of the free memory
+    free["bytes"] = int(1.5 * need)
+    assert mt.keep_activations(m, rows, dev) is False                  # does not: recompute
+    free["bytes"] = int(4 * need)
+    m.checkpoint_policy = "always"
+    assert mt.keep_activations(m, rows, dev) is False
+    m.checkpoint_policy = "auto"
+    monkeypatch.setenv("OMH_CHECKPOINT_POLICY", "always")
+    assert mt.keep_activations(m, rows, dev) is False
+    m.use_checkpoint = False                                          # the reference's other branch: always kept
+    assert mt.keep_activations(m, rows, dev) is True
