@@ -75,6 +75,36 @@ class KernelTimer:
         return sum(s.elapsed_time(e) for s, e in self.pairs) / len(self.pairs)
 
 
+class BucketTimer:
+    """Like KernelTimer, but sorts the launches of one entry point into named buckets: ``classify(*a, **k)`` returns a
+    bucket name or None.  One HIP-event pair per selected launch, on the launch stream."""
+
+    def __init__(self, ops_mod, fn_name, classify):
+        self.buckets, self.enabled = {}, False
+        self.orig = getattr(ops_mod, fn_name)
+
+        def wrapped(*a, **k):
+            name = classify(*a, **k) if self.enabled else None
+            if name is None:
+                return self.orig(*a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = self.orig(*a, **k)
+            e.record()
+            self.buckets.setdefault(name, []).append((s, e))
+            return r
+        setattr(ops_mod, fn_name, wrapped)
+
+    def avg_ms(self, name):
+        pairs = self.buckets.get(name)
+        if not pairs:
+            return None
+        return sum(s.elapsed_time(e) for s, e in pairs) / len(pairs)
+
+    def count(self, name):
+        return len(self.buckets.get(name, ()))
+
+
 class Telemetry:
     """Shader clock and board power of the GPU this rank runs on, sampled from the amdgpu hwmon files (freq1_input,
     power1_input) every 50 ms by a host thread while the timed region runs.  The dominant kernels of this path are
@@ -161,9 +191,23 @@ def cpu_baseline(model, latent, t, ctx, seq_len, budget_s=60.0):
     cfg = O.DiTConfig.wan_t2v_1_3b()
     keep = ("patch_embedding", "text_embedding", "time_embedding", "time_projection", "blocks.0.")
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items() if k.startswith(keep)}
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     lat, cc, tt = latent.cpu(), ctx.cpu(), t.cpu()
+    # Thread count: this host collapses under oversubscription (round 3 measured 0.13 TFLOP/s with all 256 threads
+    # against 0.46 on 8 cores in the survey).  Sweep intra-op threads on a QUARTER-length proxy of the same block
+    # (S / 4 tokens: ~3 s per setting) and time the full-size sample once, with the best setting.
+    lat4 = lat[:, : max(1, lat.shape[1] // 4)].contiguous()
+    s4 = lat4.shape[1] * (lat4.shape[2] // 2) * (lat4.shape[3] // 2)
+    sweep = {}
+    for n in sorted({c for c in (8, 16, 32, 64, 128, ncpu) if c <= ncpu}):
+        torch.set_num_threads(n)
+        t0 = time.time()
+        O.dit_forward(sd, cfg, [lat4], tt, [cc], s4, num_layers=1, return_hidden=True)
+        sweep[n] = round(time.time() - t0, 3)
+        if sum(sweep.values()) > 0.5 * budget_s:
+            break
+    cores = min(sweep, key=sweep.get)
+    torch.set_num_threads(cores)
     t0 = time.time()
     O.dit_forward(sd, cfg, [lat], tt, [cc], seq_len, num_layers=0, return_hidden=True)
     t_embed = time.time() - t0
@@ -187,6 +231,7 @@ def cpu_baseline(model, latent, t, ctx, seq_len, budget_s=60.0):
     except Exception as e:  # the timing must survive a failure of this extra check
         parity = repr(e)[:200]
     return {"value": 1.0 / step_s, "unit": "denoising steps/s", "cores": cores, "kind": "port",
+            "host_cpus": ncpu, "thread_sweep_s_per_block_at_quarter_length": {str(k): v for k, v in sweep.items()},
             "parity_rel_rms_block0_full_size": parity,
             "sample": f"oracle fp32 DiT: embeddings + 1 of 30 blocks of one forward at S={seq_len} "
                       f"({t_blk:.1f}s/block, {t_embed:.1f}s embed), extrapolated x30 blocks x2 CFG forwards",
@@ -351,7 +396,7 @@ def train_step_flops(S=1560, ffn_freeze=True, checkpoint=True, d=1536, f=8960, L
     return (L - frozen) * passes * blk + frozen * (passes * (blk - ffn) + ffn) + 3 * rest
 
 
-def train_bench(model, device, world, dist, steps=4, warmup=2, bsz=4, ffn_freeze=True, loss_quirk=True, checkpoint=True,
+def train_bench(model, device, world, dist, steps=20, warmup=3, bsz=4, ffn_freeze=True, loss_quirk=True, checkpoint=True,
                 policy="auto"):
     """BASELINE config 3: the distilled_trainer.py student step on a batch of [16,1,60,104] clips per GPU
     (forward + per-block recompute + backward on the HIP kernels, bucketed RCCL gradient all-reduce
@@ -623,7 +668,27 @@ def main():
     nb = 2 if args.cfg == "batched" else 1
     timer = KernelTimer(ops, "flash_attn_raw", lambda *a, **k: a[7] == a[8] and a[7] == seq_len)  # Lq == Lk == S
     # secondary in-situ timings: the widest GEMM (FFN up-projection + GELU) and the HBM-bound LN+modulate pass
-    gemm_timer = KernelTimer(ops, "gemm_raw", lambda *a, **k: a[3] == nb * seq_len and a[4] == 8960 and a[5] == 1536)
+    # every GEMM shape of a DiT block at M = S, by (M, N, K, epilogue, gated?) — the argument order of ops.gemm_raw is
+    # (A, B, C, M, N, K, lda, ldb, ldc, epilogue, ...); the V^T projection runs with swapped operands (M = d, N = S)
+    MS, DM, FF = nb * seq_len, 1536, 8960
+
+    def gemm_bucket(*a, **k):
+        M, N, K, epi = a[3], a[4], a[5], a[9]
+        if M == MS and K == DM and N == FF:
+            return "ffn_up_gemm_gelu"
+        if M == MS and K == FF and N == DM:
+            return "ffn_down_gate_resid"
+        if M == MS and K == DM and N == 2 * DM:
+            return "qk_proj"
+        if M == DM and N == seq_len and K == DM and k.get("batch", 1) == nb:
+            return "v_proj_transposed"
+        if M == MS and K == DM and N == DM:
+            if epi == ops.EPI_RESID:
+                return "o_proj_gate_resid" if k.get("gate0") is not None else "cross_o_proj_resid"
+            return "cross_q_proj"
+        return None
+    gemm_timer = BucketTimer(ops, "gemm_raw", gemm_bucket)
+    cross_timer = KernelTimer(ops, "flash_attn_raw", lambda *a, **k: a[7] == seq_len and a[8] != seq_len)
     ln_timer = KernelTimer(ops, "layernorm_modulate_raw", lambda *a, **k: a[2] == nb * seq_len and a[3] == 1536)
 
     # as WanT2V.generate does: what depends on the prompt alone is computed once per sample, not per forward
@@ -659,7 +724,7 @@ def main():
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = gemm_timer.enabled = ln_timer.enabled = True
+    timer.enabled = gemm_timer.enabled = ln_timer.enabled = cross_timer.enabled = True
     tele = Telemetry(local_rank)
     tele.start()
     t0 = time.perf_counter()
@@ -670,7 +735,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timer.enabled = gemm_timer.enabled = ln_timer.enabled = False
+    timer.enabled = gemm_timer.enabled = ln_timer.enabled = cross_timer.enabled = False
     if dist:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -717,12 +782,43 @@ def main():
                     "algorithmic_flops_per_launch": attn_flops}
 
     secondary = {}
-    g_ms, l_ms = gemm_timer.avg_ms(), ln_timer.avg_ms()
-    if g_ms:      # [S,1536] x [1536,8960] + bias + GELU-tanh, bf16 out
-        gf = 2.0 * nb * seq_len * 8960 * 1536
-        secondary["ffn_up_gemm_gelu"] = {"avg_launch_ms": round(g_ms, 4), "tflops": round(gf / g_ms / 1e9, 1),
-                                        "mfma_frac": round(gf / g_ms / 1e9 / PEAK_BF16_TFLOPS, 4),
-                                        "launches_timed": len(gemm_timer.pairs)}
+    l_ms = ln_timer.avg_ms()
+    # the GEMM shapes of a block at M = S, each timed in situ (HIP events on the launch stream, every launch of the
+    # timed steps): flops = 2 M N K, fraction of the 2.5 PFLOP/s dense bf16 MFMA peak
+    shapes = {"qk_proj": (MS, 2 * DM, DM, "q|k projection + bias, bf16 out"),
+              "v_proj_transposed": (MS, DM, DM, "V^T = Wv h^T + bias (operands swapped), bf16 out"),
+              "o_proj_gate_resid": (MS, DM, DM, "x += (o Wo^T + b) * gate: fp32 read-modify-write of the residual"),
+              "cross_q_proj": (MS, DM, DM, "cross-attention q projection + bias, bf16 out"),
+              "cross_o_proj_resid": (MS, DM, DM, "x += oc Wo^T + b"),
+              "ffn_up_gemm_gelu": (MS, FF, DM, "FFN up-projection + bias + GELU-tanh, bf16 out"),
+              "ffn_down_gate_resid": (MS, DM, FF, "x += (u W2^T + b) * gate")}
+    tot_f = tot_ms = five_f = five_ms = 0.0
+    for name, (M_, N_, K_, what) in shapes.items():
+        ms_ = gemm_timer.avg_ms(name)
+        if not ms_:
+            continue
+        gf = 2.0 * M_ * N_ * K_
+        secondary[name] = {"avg_launch_ms": round(ms_, 4), "tflops": round(gf / ms_ / 1e9, 1),
+                           "mfma_frac": round(gf / ms_ / 1e9 / PEAK_BF16_TFLOPS, 4),
+                           "launches_timed": gemm_timer.count(name), "M_N_K": [M_, N_, K_], "what": what}
+        tot_f, tot_ms = tot_f + gf, tot_ms + ms_
+        if not name.startswith("cross_"):
+            five_f, five_ms = five_f + gf, five_ms + ms_
+    gemm_aggregate = None
+    if tot_ms:
+        gemm_aggregate = {"gemm_aggregate_frac": round(five_f / five_ms / 1e9 / PEAK_BF16_TFLOPS, 4),
+                          "shapes": "q|k, V^T, o-proj+gate+residual, FFN-up+GELU, FFN-down+gate+residual: sum of flops "
+                                    "/ sum of average launch times (one of each per block)",
+                          "tflop_per_block": round(five_f / 1e12, 3), "ms_per_block": round(five_ms, 4),
+                          "with_cross_attention_projections_frac": round(tot_f / tot_ms / 1e9 / PEAK_BF16_TFLOPS, 4)}
+    c_ms = cross_timer.avg_ms()
+    if c_ms:      # cross-attention launch: S queries x (un-padded) context keys, 12 heads, D = 128
+        lk = 0.5 * (ctx.shape[0] + ctx_null.shape[0])
+        cf = 4.0 * nb * seq_len * lk * 1536
+        secondary["cross_attention"] = {"avg_launch_ms": round(c_ms, 4), "tflops": round(cf / c_ms / 1e9, 1),
+                                        "mfma_frac": round(cf / c_ms / 1e9 / PEAK_BF16_TFLOPS, 4),
+                                        "launches_timed": len(cross_timer.pairs), "mean_keys": lk,
+                                        "what": "flash_attn_fwd_d128_kernel, Lq = S, Lk = context tokens (120 / 40)"}
     if l_ms:      # LayerNorm + adaLN modulate: fp32 in, bf16 out = 6 bytes per element
         lb = 6.0 * nb * seq_len * 1536
         secondary["layernorm_modulate"] = {"avg_launch_ms": round(l_ms, 4), "hbm_GBps": round(lb / l_ms / 1e6, 1),
@@ -794,7 +890,9 @@ def main():
                     "achieved_tflops_per_gpu": round(fwd_per_gpu_step * fwd_flops / (ms_per_step * 1e-3) / 1e12, 1),
                     "mfma_roofline_frac": round(fwd_per_gpu_step * fwd_flops / (ms_per_step * 1e-3) / 1e12
                                                 / PEAK_BF16_TFLOPS, 4),
-                    "kernels": secondary, "telemetry": telemetry},
+                    "kernels": secondary, "gemm_aggregate": gemm_aggregate,
+                    "gemm_aggregate_frac": None if gemm_aggregate is None else gemm_aggregate["gemm_aggregate_frac"],
+                    "telemetry": telemetry},
             "single_frame": single, "vae": vae, "encoders": encoders, "train": train, "roofline": roofline,
             "cpu_baseline": cpu,
         }

@@ -22,6 +22,9 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
          "-Wno-unused-result", f"-I{INCLUDE}"]
+# what the digests hash: the flags WITHOUT the absolute include path (the tree is copied to the GPU box and may be
+# relocated; a moved tree is not a stale build)
+_FLAGS_KEY = " ".join("-I<include>" if f.startswith("-I") else f for f in FLAGS)
 
 
 def _hipcc():
@@ -50,7 +53,7 @@ def _sources():
 
 
 def _digest():
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+    h = hashlib.sha256(_FLAGS_KEY.encode())
     # (the generators are part of the digest: editing one makes the build stale, and the streams are regenerated
     # under the build lock — not on every import)
     for f in _sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)
@@ -79,7 +82,7 @@ def have_hipcc() -> bool:
 def _obj_digest(src):
     """Digest of ONE translation unit: its source, the shared headers and the flags (so that editing one .hip
     file recompiles one object, not nine)."""
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+    h = hashlib.sha256(_FLAGS_KEY.encode())
     stem = os.path.basename(src)[:-4]
     for f in [src] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)
                             if f.endswith(".h") or (f.endswith(".inc") and f.startswith(stem))) + \

@@ -153,12 +153,15 @@ def load_checkpoint(checkpoint_dir, model, optimizer=None, rank: int = 0, restor
             optimizer.load_state_dict(opt_sd)
     sc = os.path.join(checkpoint_dir, "scaler.pt")
     info["scaler"] = load(sc) if os.path.exists(sc) else (blob or {}).get("scaler")
+    have_step = False
     if os.path.exists(side):
         with open(side) as fh:
             st = json.load(fh)
         info["step"], info["epoch"] = int(st.get("step", 0)), int(st.get("epoch", 0))
+        have_step = "step" in st
     elif "step" in manual_blob():
         info["step"], info["epoch"] = int(blob.get("step", 0)), int(blob.get("epoch", 0))
+        have_step = True
     rs = os.path.join(checkpoint_dir, f"random_states_{rank}.pkl")
     if os.path.exists(rs):
         try:
@@ -169,7 +172,10 @@ def load_checkpoint(checkpoint_dir, model, optimizer=None, rank: int = 0, restor
             warnings.warn(f"{rs}: RNG states not restored ({type(exc).__name__})")
             states = None
         if states is not None:
-            info["step"] = int(states.get("step", info["step"]))
+            # accelerate keeps its own micro-step counter in this file: it is the trainer's step only when nothing
+            # else recorded one (train_state.json / the manual blob win)
+            if not have_step:
+                info["step"] = int(states.get("step", info["step"]))
             if restore_rng:
                 random.setstate(states["random_state"])
                 np.random.set_state(states["numpy_random_seed"])

@@ -199,6 +199,8 @@ _ATTN_BWD2 = os.environ.get("OMH_ATTN_BWD", "v2") != "v1"
 _ATTN_SPLIT = os.environ.get("OMH_ATTN_BWD_SPLIT", "auto")
 _side = {}
 _side2 = {}
+# OMH_BLOCK_DX_COPY=1: never update an incoming block gradient in place (debugging aid for callers with extra taps)
+_ALWAYS_COPY_DX = os.environ.get("OMH_BLOCK_DX_COPY", "0") == "1"
 
 
 def _attn_bwd(q, k, v, o, do, lse, lens, B, N, Lq, Lk, scale, out, o32, q_prescaled):
@@ -671,7 +673,32 @@ def _dgrad_ctx(dy, wT, d_ctx, first, L):
                  strideA=L * dy.stride(0), strideB=0, strideC=Lc * d)
 
 
-def keep_activations(model, rows, device):
+def activation_bytes(model, rows, batch=1):
+    """Bytes a training forward over ``rows`` tokens (``batch`` clips) keeps for the backward when nothing is re-run."""
+    blk = model.blocks[0]
+    dim, ffn, heads = blk.dim, blk.ffn_dim, blk.self_attn.num_heads
+    i2v = hasattr(blk.cross_attn, "k_img")
+    # per token and block: fp32 [dim] x0, x1, x2, o32_sa, o32_ca (20 B) + bf16 [dim] h1, qk (2), q, k, vt, o, y1, h3, qcb,
+    # qc, oc, y3, h2 (14 -> 28 B) (+ oi for i2v) + bf16 [ffn] u, u_pre + two (i2v: three) fp32 log-sum-exp values per head
+    per_row = (48 + (2 if i2v else 0)) * dim + 4 * ffn + (12 if i2v else 8) * heads
+    ctx_rows = max(1, int(batch)) * (model.text_len + (257 if i2v else 0))
+    per_ctx_row = 8 * dim                                     # context K fp32 + normalised K bf16 + V^T bf16
+    return int(len(model.blocks) * (rows * per_row + ctx_rows * per_ctx_row) * 1.15)
+
+
+def pending_step_bytes(model):
+    """Memory the rest of the step will still claim after the forward: AdamW's two moments (8 bytes per trainable
+    parameter — the optimizer is not visible from here, so they are always assumed to be missing) and the gradients
+    where none exist yet (first step, or ``zero_grad(set_to_none=True)``).  ADVICE round 3: without this the first
+    step's free-memory reading is overstated by exactly what the backward and the optimizer step allocate."""
+    pending = 0
+    for p in model.parameters():
+        if p.requires_grad:
+            pending += p.numel() * (8 + (0 if p.grad is not None else 4))
+    return pending
+
+
+def keep_activations(model, rows, device, batch=1):
     """What ``model.use_checkpoint`` amounts to for a forward over ``rows`` tokens (module docstring): True = keep
     every block's activations for the backward, False = keep the block inputs and recompute."""
     if not getattr(model, "use_checkpoint", True):
@@ -681,12 +708,10 @@ def keep_activations(model, rows, device):
         return False
     if torch.cuda.is_current_stream_capturing():              # no memory queries under hipGraph capture: what the
         return bool(model.__dict__.get("_kept_activations", False))       # warm-up step before the capture decided
-    blk = model.blocks[0]
-    per_row = 42 * blk.dim + 4 * blk.ffn_dim                  # bytes a block keeps per token (5 fp32 + 11 bf16 [dim], 2 bf16 [ffn])
-    need = len(model.blocks) * rows * per_row * 1.15
+    need = activation_bytes(model, rows, batch)
     free, _ = torch.cuda.mem_get_info(device)
     free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)      # the allocator's own free blocks
-    return need < 0.5 * free
+    return need < 0.5 * (free - pending_step_bytes(model))
 
 
 # ----------------------------------------------------------------------------- block node
@@ -718,8 +743,16 @@ class _BlockFn(torch.autograd.Function):
             ctx.kept = None
             if S is None:                                    # use_checkpoint: re-run the forward's kernels on its input
                 _, S = _block_forward(model, blk, idx, st, x0, P, False)
-            # the incoming gradient belongs to this node alone (the residual stream has one consumer): updated in place
-            dx = dx_out if (dx_out.dtype == torch.float32 and dx_out.is_contiguous()) else dx_out.float().contiguous()
+            # The block backward updates the incoming gradient IN PLACE.  That is only legal when the buffer belongs to
+            # this node: autograd hands a node the producer's own tensor when the block output has ONE consumer (the next
+            # block / the head allocate a fresh dx), but a caller that also taps block outputs (the reference's
+            # discriminator hooks, seaweed_apt/model.py:150-155) makes autograd accumulate, and then the same buffer
+            # can be what another consumer's backward still holds.  Own-or-copy: in place only for a tensor this
+            # package's own nodes produced for us (tagged below), a private copy otherwise.
+            own = dx_out.dtype == torch.float32 and dx_out.is_contiguous() and \
+                getattr(dx_out, "_omh_exclusive", False) and not _ALWAYS_COPY_DX
+            dx = dx_out if own else dx_out.float().contiguous().clone() if (
+                dx_out.dtype == torch.float32 and dx_out.is_contiguous()) else dx_out.float().contiguous()
             try:
                 grads = _block_backward(model, blk, idx, st, S, dx, P)
             finally:
@@ -728,7 +761,9 @@ class _BlockFn(torch.autograd.Function):
         for n, p in blk.named_parameters():
             gg = grads.get(n) if p.requires_grad else None
             out.append(None if gg is None else gg.view(p.shape).to(p.dtype))
-        return (grads["__dx__"], None, None, None, *out)
+        gdx = grads["__dx__"]
+        gdx._omh_exclusive = True                             # fresh from this node: the previous block may update it in place
+        return (gdx, None, None, None, *out)
 
 
 # ----------------------------------------------------------------------------- head node
@@ -782,7 +817,9 @@ class _HeadFn(torch.autograd.Function):
         for n, p in head.named_parameters():
             gg = grads.get(n) if p.requires_grad else None
             out.append(None if gg is None else gg.view(p.shape).to(p.dtype))
-        return (dx.view(B, S, d), None, None, None, *out)
+        gdx = dx.view(B, S, d)
+        gdx._omh_exclusive = True                             # (see _BlockFn.backward: own-or-copy)
+        return (gdx, None, None, None, *out)
 
 
 # ----------------------------------------------------------------------------- embed node
@@ -934,9 +971,17 @@ def forward_train(model, x, t, context, seq_len, clip_fea=None, y=None, extra_co
     xs = _EmbedFn.apply(model, st, x_list, t, list(context), seq_len, clip_fea, y, tok, *eparams)
     if not xs.requires_grad:
         xs.requires_grad_(True)          # keeps the chain alive when the embed parameters are frozen
-    st.keep = keep_activations(model, xs.shape[0] * xs.shape[1], xs.device)
+    st.keep = keep_activations(model, xs.shape[0] * xs.shape[1], xs.device, batch=xs.shape[0])
     model.__dict__["_kept_activations"] = st.keep            # what the last training forward did (bench / tests)
     for i, blk in enumerate(model.blocks):
+        x_in = xs
         xs = _BlockFn.apply(xs, model, st, i, *list(blk.parameters()))
+        # forward hooks registered on a block (the reference's discriminator taps block outputs this way,
+        # seaweed_apt/model.py:150-155) see the block's output as under nn.Module.__call__; the extra consumer they
+        # create is why _BlockFn.backward owns-or-copies its incoming gradient
+        for hook in list(blk._forward_hooks.values()):
+            r = hook(blk, (x_in,), xs)
+            if r is not None:
+                xs = r
     outs = _HeadFn.apply(xs, model, st, st.grids, *list(model.head.parameters()))
     return list(outs)

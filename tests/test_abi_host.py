@@ -222,24 +222,27 @@ def test_checkpoint_flag_as_memory_policy(omh, wan_model_mod, monkeypatch):
     from oracle import make_golden
     m = wan_model_mod.WanModel(num_layers=3, **make_golden.TINY)
     assert m.use_checkpoint is True and m.checkpoint_policy == "auto"
-    blk = m.blocks[0]
     rows = 6240
-    need = len(m.blocks) * rows * (42 * blk.dim + 4 * blk.ffn_dim) * 1.15
-    free = {"bytes": int(4 * need)}
+    need = mt.activation_bytes(m, rows, batch=4)
+    pend = mt.pending_step_bytes(m)                    # no gradients, no optimizer state yet: 12 bytes per parameter
+    assert pend == 12 * sum(p.numel() for p in m.parameters() if p.requires_grad)
+    free = {"bytes": int(4 * need) + pend}
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda device=None: (free["bytes"], 0))
     monkeypatch.setattr(torch.cuda, "memory_reserved", lambda device=None: 0)
     monkeypatch.setattr(torch.cuda, "memory_allocated", lambda device=None: 0)
     monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
     monkeypatch.delenv("OMH_CHECKPOINT_POLICY", raising=False)
     dev = torch.device("cpu")
-    assert mt.keep_activations(m, rows, dev) is True                   # fits in half of the free memory
-    free["bytes"] = int(1.5 * need)
-    assert mt.keep_activations(m, rows, dev) is False                  # does not: recompute
-    free["bytes"] = int(4 * need)
+    assert mt.keep_activations(m, rows, dev, batch=4) is True                   # fits in half of the free memory
+    free["bytes"] = int(1.5 * need) + pend
+    assert mt.keep_activations(m, rows, dev, batch=4) is False                  # does not: recompute
+    free["bytes"] = int(2.5 * need)                                   # would fit, but not beside gradients + AdamW state
+    assert (mt.keep_activations(m, rows, dev, batch=4) is True) == (2.5 * need - pend > 2 * need)
+    free["bytes"] = int(4 * need) + pend
     m.checkpoint_policy = "always"
-    assert mt.keep_activations(m, rows, dev) is False
+    assert mt.keep_activations(m, rows, dev, batch=4) is False
     m.checkpoint_policy = "auto"
     monkeypatch.setenv("OMH_CHECKPOINT_POLICY", "always")
-    assert mt.keep_activations(m, rows, dev) is False
+    assert mt.keep_activations(m, rows, dev, batch=4) is False
     m.use_checkpoint = False                                          # the reference's other branch: always kept
-    assert mt.keep_activations(m, rows, dev) is True
+    assert mt.keep_activations(m, rows, dev, batch=4) is True

@@ -782,3 +782,63 @@ def test_deterministic_mode_repeats_a_training_step_bit_for_bit(wan_model_mod, o
     for n in a:
         assert torch.equal(a[n], b[n]), n
         assert rel_rms(a[n], free[n]) < 1e-4, n
+
+
+def test_block_output_taps_do_not_alias_the_block_backward(wan_model_mod):
+    """A forward hook on a block (the reference's discriminator features, seaweed_apt/model.py:150-155) gives the block
+    output a second consumer.  The block backward updates its incoming gradient in place — only when the tensor is its
+    own (produced by this package's next node); a gradient that comes from anywhere else is copied first.  (a) a tap
+    whose backward hands over a buffer it keeps: the buffer is not modified; (b) tap loss + output loss: gradients =
+    the sum of the two losses' separate gradients."""
+    cfg, sd, m, noise, vt, cl = _setup(wan_model_mod, freeze=False)
+    feats = {}
+    h = m.blocks[3].register_forward_hook(lambda mod, inp, out: feats.__setitem__("f", out))
+    tctx = [c.cuda() for c in cl]
+    tt = torch.ones(2, device="cuda") * 1000.0
+
+    def run(w_out, w_tap, G=None):
+        for p in m.parameters():
+            p.grad = None
+        out = m(list(noise.cuda()), t=tt, context=tctx, seq_len=24)
+        f = feats["f"]
+        assert f.requires_grad and f.shape[-1] == cfg.dim
+        loss = 0.0
+        if w_out:
+            loss = loss + w_out * sum(torch.nn.functional.mse_loss(a, b) for a, b in zip(out, vt.cuda()))
+        if w_tap:
+            if G is not None:
+                class Tap(torch.autograd.Function):
+                    @staticmethod
+                    def forward(ctx, x):
+                        return x.sum()
+
+                    @staticmethod
+                    def backward(ctx, g):
+                        return G                                    # a buffer the caller keeps using
+                loss = loss + Tap.apply(f)
+            else:
+                loss = loss + w_tap * (f * torch.linspace(-1, 1, cfg.dim, device="cuda")).sum() / f.numel()
+        loss.backward()
+        return {n: (None if p.grad is None else p.grad.clone()) for n, p in m.named_parameters()}
+
+    try:
+        # (a)
+        out = m(list(noise.cuda()), t=tt, context=tctx, seq_len=24)
+        G = torch.randn_like(feats["f"]).contiguous()
+        G0 = G.clone()
+        run(0.0, 1.0, G=G)
+        assert torch.equal(G, G0), "the block backward modified a gradient buffer it does not own"
+        # (b)
+        g_out, g_tap, g_both = run(1.0, 0.0), run(0.0, 1.0), run(1.0, 1.0)
+        assert g_tap["blocks.5.self_attn.q.weight"] is None or float(g_tap["blocks.5.self_attn.q.weight"].abs().max()) == 0
+        worst = 0.0
+        for n in g_both:
+            if g_both[n] is None:
+                continue
+            want = g_out[n].double() + (g_tap[n].double() if g_tap[n] is not None else 0.0)
+            e = float((g_both[n].double() - want).norm() / want.norm().clamp_min(1e-20))
+            worst = max(worst, e)
+            assert e < TOL_GRAD_1D, (n, e)
+        print(f"[measured] tap + output loss vs the sum of the separate gradients: worst {worst:.3e}")
+    finally:
+        h.remove()
