@@ -483,7 +483,9 @@ def train_bench(model, device, world, dist, steps=20, warmup=3, bsz=4, ffn_freez
         el = float(tt.item())
     grad_bytes = sum(st["exp_avg"].numel() * 4 for st in opt.state.values() if "exp_avg" in st)   # tensors that got a gradient
     exposed_ms = (sum(a.elapsed_time(b) for a, b in exposed) / len(exposed)) if exposed else None
+    wire_bytes = 0
     if red is not None:
+        wire_bytes = red.bytes_on_wire
         red.remove()
     # give the weights and flags back as they were found (the optimizer stepped lr = 5e-6 a few times)
     model.reference_ffn_freeze, model.use_checkpoint, model.checkpoint_policy = old_freeze, old_ckpt, old_policy
@@ -502,6 +504,8 @@ def train_bench(model, device, world, dist, steps=20, warmup=3, bsz=4, ffn_freez
                     + (f" + bucketed gradient all-reduce over {world} rank(s) [{dist.get_backend()}]" if reducer_ran
                        else " + NO gradient all-reduce (single process, no process group)") + " + fused AdamW",
             "rccl_world_size": int(dist.get_world_size()) if dist else 1,
+            "reducer": None if red is None else {"collective": red.collective, "payload": str(red.payload).replace("torch.", ""),
+                                                 "bucket_mb": 256.0, "bytes_on_wire_per_step": int(wire_bytes)},
             "grad_bytes": int(grad_bytes),
             "allreduce_exposed_ms": None if exposed_ms is None else round(exposed_ms, 3),
             "algorithmic_tflop_per_clip": round(fl / 1e12, 2),
@@ -519,11 +523,20 @@ def train_legs(model, device, world, dist):
     --batch_size) and B = 16 under the primary settings, and B = 4 with both quirks off (every clip and every parameter
     trained).  OMH_TRAIN_BATCH overrides the primary batch size."""
     bsz = int(os.environ.get("OMH_TRAIN_BATCH", "4"))
-    out = train_bench(model, device, world, dist, bsz=bsz)
+    tk = {}
+    if os.environ.get("OMH_TRAIN_STEPS"):                         # (tests: a short timed region)
+        tk = dict(steps=int(os.environ["OMH_TRAIN_STEPS"]), warmup=int(os.environ.get("OMH_TRAIN_WARMUP", "1")))
+    out = train_bench(model, device, world, dist, bsz=bsz, **tk)
+    out["leg"] = "primary: reference trainer settings, checkpoint flag as a memory policy (see activations_kept)"
     if os.environ.get("OMH_TRAIN_LEGS", "all") == "primary":      # (tests: the primary leg only)
         return out
     try:
         out["recompute"] = train_bench(model, device, world, dist, bsz=bsz, policy="always")
+        out["recompute"]["leg"] = "every block re-run in the backward (torch.utils.checkpoint's literal behaviour)"
+        # distinct names for the two B = 4 figures (ADVICE round 3: the kept-activation leg is not comparable with
+        # rounds 1-2 or with the reference's checkpointed step; the recompute leg is)
+        out["clips_per_s_activations_kept"] = out["clips_per_s"] if out.get("activations_kept") else None
+        out["clips_per_s_recompute"] = out["recompute"]["clips_per_s"]
         if bsz != 1:
             out["batch_1"] = train_bench(model, device, world, dist, bsz=1)
             out["recompute"]["batch_1"] = train_bench(model, device, world, dist, bsz=1, policy="always")

@@ -24,13 +24,41 @@ import torch
 import torch.distributed as dist
 
 
+class _Done:
+    """A completed piece of work (the host-staged validation path)."""
+
+    def wait(self):
+        return True
+
+
 class BucketedGradAllReduce:
+    """``collective``: "all_reduce" (default) or "reduce_scatter_all_gather" — the same reduction issued as its two
+    halves per bucket (each rank reduces 1/world of the bucket, then the shards are gathered): on the point-to-point xGMI
+    mesh both halves are direct exchanges that use all 7 links at once, and the split is the hook a sharded optimizer
+    step would sit between.  ``payload``: torch.float32 (default) or torch.bfloat16 — the bucket is cast to bf16 for the
+    wire (half the bytes per link; one 2^-9 rounding of each rank's gradient and of the sum, the precision of the
+    operands the gradients were computed from) and widened back to fp32 for the optimizer.  Environment overrides:
+    OMH_GRAD_COLLECTIVE = all_reduce | rs_ag, OMH_GRAD_PAYLOAD = fp32 | bf16.  All four combinations give the gradients
+    of the fp32 all-reduce (exactly for fp32 payloads on two ranks, to bf16 rounding otherwise):
+    tests/test_parallel_gloo.py."""
+
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 256.0,
-                 group: Optional["dist.ProcessGroup"] = None, average: bool = True, force: bool = False):
+                 group: Optional["dist.ProcessGroup"] = None, average: bool = True, force: bool = False,
+                 collective: Optional[str] = None, payload: Optional[torch.dtype] = None):
+        import os
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.force = force and dist.is_initialized()        # run the collectives even on a 1-rank group (tests)
         self.average = average
+        collective = collective or os.environ.get("OMH_GRAD_COLLECTIVE", "all_reduce")
+        collective = {"rs_ag": "reduce_scatter_all_gather"}.get(collective, collective)
+        if collective not in ("all_reduce", "reduce_scatter_all_gather"):
+            raise ValueError(f"collective must be 'all_reduce' or 'reduce_scatter_all_gather', got {collective!r}")
+        if payload is None:
+            payload = {"fp32": torch.float32, "bf16": torch.bfloat16}[os.environ.get("OMH_GRAD_PAYLOAD", "fp32")]
+        if payload not in (torch.float32, torch.bfloat16):
+            raise ValueError("payload must be torch.float32 or torch.bfloat16")
+        self.collective, self.payload = collective, payload
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.enabled = True
         cap = int(bucket_mb * 1024 * 1024)
@@ -46,6 +74,9 @@ class BucketedGradAllReduce:
             self.buckets.append(cur)
         self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
         self._flat = [None] * len(self.buckets)
+        self._wire = [None] * len(self.buckets)             # bf16 payload: the buffer that travels
+        self._shard = [None] * len(self.buckets)            # reduce_scatter_all_gather: this rank's reduced 1/world
+        self.bytes_on_wire = 0                              # payload bytes handed to the collectives in the last step
         self._reset()
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
@@ -73,28 +104,69 @@ class BucketedGradAllReduce:
     def _launch(self, i):
         bucket = [p for p in self.buckets[i] if p.grad is not None]
         if not bucket:
-            self._work[i] = (None, [], [])
+            self._work[i] = (None, [], [], None)
             return
+        if not any(self._work):
+            self.bytes_on_wire = 0
         n = sum(p.numel() for p in bucket)
+        # the reduce-scatter halves split the bucket evenly: pad to a multiple of 8 elements per rank
+        n_pad = -(-n // (8 * self.world)) * (8 * self.world) if self.collective != "all_reduce" else n
+        dev, gdt = bucket[0].grad.device, bucket[0].grad.dtype
         flat = self._flat[i]
-        if flat is None or flat.numel() != n or flat.device != bucket[0].grad.device:
-            flat = self._flat[i] = torch.empty(n, dtype=bucket[0].grad.dtype, device=bucket[0].grad.device)
+        if flat is None or flat.numel() != n_pad or flat.device != dev:
+            flat = self._flat[i] = torch.zeros(n_pad, dtype=gdt, device=dev)
+        wire = flat
+        if self.payload != gdt:
+            wire = self._wire[i]
+            if wire is None or wire.numel() != n_pad or wire.device != dev:
+                wire = self._wire[i] = torch.zeros(n_pad, dtype=self.payload, device=dev)
         # pack with ONE multi-tensor copy (not a launch per parameter: ~800 of them cost 10 % of a training step);
-        # a gradient that already lives in its slice (accumulation into the view finish() left behind) is skipped
-        views = list(flat.split([p.numel() for p in bucket]))
+        # a gradient that already lives in its slice (accumulation into the view finish() left behind) is skipped.
+        # With a bf16 payload the same copy is the cast onto the wire buffer.
+        sizes = [p.numel() for p in bucket]
+        views = list(flat[:n].split(sizes))
+        wviews = views if wire is flat else list(wire[:n].split(sizes))
         dst, src = [], []
-        for v, p in zip(views, bucket):
+        for v, wv, p in zip(views, wviews, bucket):
             g = p.grad.reshape(-1)
-            if g.data_ptr() != v.data_ptr():
-                dst.append(v)
+            if wire is not flat or g.data_ptr() != v.data_ptr():
+                dst.append(wv)
                 src.append(g)
         if dst:
             torch._foreach_copy_(dst, src)
         # RCCL averages in the collective; gloo (CPU tests) has no AVG, so sum now and scale in finish()
-        self._avg_in_coll = self.average and dist.get_backend(self.group) == "nccl"
+        backend = dist.get_backend(self.group)
+        self._avg_in_coll = self.average and backend == "nccl"
         op = dist.ReduceOp.AVG if self._avg_in_coll else dist.ReduceOp.SUM
-        work = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
-        self._work[i] = (work, bucket, views)
+        self.bytes_on_wire += wire.numel() * wire.element_size()
+        if backend == "gloo" and wire.is_cuda and not (self.collective == "all_reduce" and wire.dtype == torch.float32):
+            # validation mode only (ranks sharing one GPU over gloo, tests/test_gpu_bench.py): gloo's device support
+            # covers the fp32 all-reduce; the other variants go through the host, synchronously
+            host = wire.cpu()
+            if self.collective == "all_reduce":
+                dist.all_reduce(host, op=op, group=self.group)
+            else:
+                sh = torch.empty(n_pad // self.world, dtype=host.dtype)
+                dist.reduce_scatter_tensor(sh, host, op=op, group=self.group)
+                dist.all_gather_into_tensor(host, sh, group=self.group)
+            wire.copy_(host)
+            self._work[i] = (_Done(), bucket, views, None)
+            return
+        if self.collective == "all_reduce":
+            work = dist.all_reduce(wire, op=op, group=self.group, async_op=True)
+            self._work[i] = (work, bucket, views, None)
+            return
+        per = n_pad // self.world
+        shard = self._shard[i]
+        if shard is None or shard.numel() != per or shard.dtype != wire.dtype or shard.device != dev:
+            shard = self._shard[i] = torch.empty(per, dtype=wire.dtype, device=dev)
+        work = dist.reduce_scatter_tensor(shard, wire, op=op, group=self.group, async_op=True)
+        gather = lambda: dist.all_gather_into_tensor(wire, shard, group=self.group, async_op=True)
+        if backend == "nccl":
+            # RCCL runs a group's collectives in issue order on its own stream: the gather can be queued right away
+            self._work[i] = (gather(), bucket, views, None)
+        else:
+            self._work[i] = (work, bucket, views, gather)    # gloo: queue the gather once the scatter has completed
 
     def finish(self):
         """Call after ``backward()``: launches buckets that never filled (unused parameters), waits for
@@ -106,12 +178,17 @@ class BucketedGradAllReduce:
         for i in range(len(self.buckets)):
             if self._work[i] is None:
                 self._launch(i)
-        for i, (work, bucket, views) in enumerate(self._work):
+        for i, (work, bucket, views, then) in enumerate(self._work):
             if work is None:
                 continue
             work.wait()
+            if then is not None:
+                then().wait()
+            flat, wire = self._flat[i], self._wire[i] if self.payload != self._flat[i].dtype else self._flat[i]
+            if wire is not flat:
+                flat.copy_(wire)                            # widen the reduced payload back to the gradients' dtype
             if self.average and not self._avg_in_coll:
-                self._flat[i].mul_(1.0 / self.world)
+                flat.mul_(1.0 / self.world)
             for p, v in zip(bucket, views):
                 p.grad = v.view_as(p)
         self._reset()

@@ -54,6 +54,42 @@ def test_bench_gpus_2_launches_itself():
     assert d["cpu_baseline"] is None                      # rank 0 times the CPU oracle at N = 1 only
 
 
+@pytest.mark.parametrize("mode", ["replicas", "cfg_split"])
+def test_bench_gpus_8_launches_itself(mode):
+    """What the driver's scaling run does at N = 8 — `python bench.py --gpus 8`, no launcher — on the one GPU of the test
+    box (eight ranks share it over gloo): eight replicas with an eight-rank gradient reduction in the training leg
+    (issued as reduce-scatter + all-gather with a bf16 payload: the variants of parallel.BucketedGradAllReduce), and
+    `--cfg split` with FOUR pair groups (every rank creates every group; ranks 2i / 2i+1 share a clip)."""
+    env = dict(os.environ)
+    for k in ("OMH_GEMM_KERNEL", "OMH_CONV_TILE", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(OMH_DIST_BACKEND="gloo", OMH_TRAIN_LEGS="primary", OMH_TRAIN_BATCH="1", OMH_TRAIN_STEPS="1",
+               OMH_TRAIN_WARMUP="1", OMH_GRAD_COLLECTIVE="rs_ag", OMH_GRAD_PAYLOAD="bf16")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--no-vae",
+           "--no-single-frame", "--no-cpu-baseline", "--no-encoders"]
+    if mode == "cfg_split":
+        cmd += ["--cfg", "split", "--no-train"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["cpu_baseline"] is None
+    if mode == "replicas":
+        tr = d["train"]
+        assert tr["rccl_world_size"] == 8 and tr["finite_loss"] and "all-reduce over 8 rank(s)" in tr["work"]
+        assert tr["reducer"] == {"collective": "reduce_scatter_all_gather", "payload": "bfloat16", "bucket_mb": 256.0,
+                                 "bytes_on_wire_per_step": tr["reducer"]["bytes_on_wire_per_step"]}
+        assert tr["reducer"]["bytes_on_wire_per_step"] >= tr["grad_bytes"] // 2      # bf16: half the fp32 gradient bytes
+        assert tr["allreduce_exposed_ms"] is not None
+        # 8 clips in flight, one per rank: value = 8 steps / max-over-ranks time
+        assert abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
+    else:
+        assert "one clip per PAIR" in d["config"]["workload"]
+        assert abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]         # 4 clips in flight
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OMH_DIST_BACKEND"):

@@ -91,6 +91,85 @@ def test_bucketed_grad_allreduce_gloo_world2():
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
 
 
+def _variant_worker(rank, world, port, q):
+    """Every (collective, payload) variant of the reducer against the fp32 all-reduce on the same gradients."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        par = _load_parallel()
+        sizes = (1000, 37, 5001, 64, 303, 7)                     # bucket totals that are not multiples of 8 x world
+        g = torch.Generator().manual_seed(100 + rank)            # different gradients on every rank
+        grads = [torch.randn(n, generator=g) for n in sizes]
+
+        def reduced(**kw):
+            torch.manual_seed(0)
+            params = [torch.nn.Parameter(torch.zeros(n)) for n in sizes]
+            unused = torch.nn.Parameter(torch.zeros(11))
+            red = par.BucketedGradAllReduce(params + [unused], bucket_mb=0.012, **kw)
+            out = []
+            for _ in range(2):                                   # second step: the flat / wire / shard buffers are reused
+                for p in params:
+                    p.grad = None
+                sum((p * d).sum() for p, d in zip(params, grads)).backward()
+                red.finish()
+                out.append([p.grad.clone() for p in params])
+            assert unused.grad is None
+            wire = red.bytes_on_wire
+            red.remove()
+            return out, wire
+
+        base, wire32 = reduced()
+        want = []
+        for d in grads:                                           # the mean over ranks, computed independently
+            t = d.clone()
+            dist.all_reduce(t)
+            want.append(t / world)
+        for a, w in zip(base[0], want):
+            assert torch.allclose(a, w, rtol=1e-6, atol=1e-6)
+        for coll in ("all_reduce", "reduce_scatter_all_gather"):
+            for pay in (torch.float32, torch.bfloat16):
+                got, wire = reduced(collective=coll, payload=pay)
+                for step in got:
+                    for a, b in zip(step, base[0]):
+                        if pay == torch.float32:
+                            assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), (coll, pay)      # same sums, other order
+                        else:                                     # each rank's gradient and the sum rounded to bf16
+                            assert torch.allclose(a, b, rtol=2 ** -7, atol=2 ** -7 * float(b.abs().max())), (coll, pay)
+                if pay == torch.bfloat16:
+                    assert wire * 2 <= wire32 + 64 * world * len(sizes), (wire, wire32)   # half the bytes (+ padding)
+        # the environment selects the same variants (what bench.py / a launcher would set)
+        os.environ.update(OMH_GRAD_COLLECTIVE="rs_ag", OMH_GRAD_PAYLOAD="bf16")
+        red = par.BucketedGradAllReduce([torch.nn.Parameter(torch.zeros(4))])
+        assert red.collective == "reduce_scatter_all_gather" and red.payload == torch.bfloat16
+        red.remove()
+        for k in ("OMH_GRAD_COLLECTIVE", "OMH_GRAD_PAYLOAD"):
+            os.environ.pop(k)
+        with pytest.raises(ValueError):
+            par.BucketedGradAllReduce([torch.nn.Parameter(torch.zeros(4))], collective="ring")
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc()[-600:]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_reducer_variants_match_the_fp32_all_reduce(world):
+    """reduce_scatter + all_gather per bucket and the bf16 payload (SURVEY.md section 5,
+    "Distributed communication backend") against the plain fp32 all-reduce, world sizes 2 and 3 (odd: padded shards)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_variant_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
 def _cfg_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
