@@ -239,9 +239,21 @@ def test_training_step_full_size_properties():
 # Config 3 at its REAL size against the autograd oracle (VERDICT round 3, next #1a).  Bounds = 2 x the figures measured
 # on MI355X in round 4 (profiles/r04_full_size_gradient_parity.json): bf16 operands, fp32 accumulation, 30 blocks of
 # back-propagation at d = 1536.
-TOL_FULL_LOSS = 5e-3
-TOL_FULL_GRAD = 3e-2
-TOL_FULL_GRAD_1D = 6e-2
+# Round 4, first run (gpurun_out/full_size_gradient_parity_freeze*.json): loss 1.1e-4, output 3.4e-3, matrices <= 9.7e-3
+# (all 30 blocks), 1-D parameters <= 9.7e-3 on the probes; the worst 1-D figure over ALL parameters, 5.1e-2, is the
+# cross-attention K bias — a gradient that is exactly zero in exact arithmetic (adding one vector to every key shifts
+# all scores of a query row alike; softmax does not see it), so what is measured there is rounding noise against a
+# floor, and it gets its own absolute-scale bound.
+TOL_FULL_LOSS = 1e-3
+TOL_FULL_GRAD = 2e-2
+TOL_FULL_GRAD_1D = 2e-2
+TOL_FULL_GRAD_NULL = 1.1e-1
+
+
+def _null_gradient(name):
+    """Parameters whose gradient vanishes identically: the K biases of the cross-attention (softmax shift invariance;
+    no RoPE and — unlike the self-attention — compared after the norm's own scale invariance: model.py:176-178)."""
+    return name.endswith("cross_attn.k.bias") or name.endswith("cross_attn.k_img.bias")
 FULL_SIZE_PROBES = [
     "blocks.0.self_attn.q.weight", "blocks.0.self_attn.q.bias", "blocks.0.self_attn.norm_q.weight", "blocks.0.modulation",
     "blocks.0.ffn.0.weight", "blocks.0.ffn.2.bias", "blocks.0.cross_attn.k.weight", "blocks.0.cross_attn.o.bias",
@@ -299,7 +311,7 @@ def test_training_step_full_size_gradients_against_the_autograd_oracle(freeze):
     lg = torch.nn.functional.mse_loss(out[0], vt[0].cuda())
     lg.backward()
     params = dict(m.named_parameters())
-    rec = {"freeze": freeze, "oracle_seconds": round(t_oracle, 1), "loss_oracle": float(lo), "loss_hip": float(lg),
+    rec = {"freeze": freeze, "oracle_seconds": round(t_oracle, 1), "loss_oracle": float(lo.detach()), "loss_hip": float(lg.detach()),
            "loss_rel_err": abs(float(lg) - float(lo)) / float(lo), "output_rel_rms": rel_rms(out[0], oo[0].detach()),
            "probes": {}}
     norms = sorted(float(v.grad.norm()) for v in osd.values() if v.grad is not None and float(v.grad.abs().max()) > 0)
@@ -321,26 +333,27 @@ def test_training_step_full_size_gradients_against_the_autograd_oracle(freeze):
         if err > (TOL_FULL_GRAD if kind == 2 else TOL_FULL_GRAD_1D):
             bad.append((name, err))
     # every parameter, not only the probes: worst figures per kind (cheap: the gradients are there)
-    allw = {1: (0.0, None), 2: (0.0, None)}
+    allw = {0: (0.0, None), 1: (0.0, None), 2: (0.0, None)}          # 0: identically-null gradients (noise vs the floor)
     for name, p in params.items():
         og = osd[name].grad
         if og is None or float(og.abs().max()) == 0.0 or p.grad is None:
             continue
         err = float((p.grad.double().cpu() - og.double()).norm() / max(float(og.double().norm()), floor))
-        kind = 2 if og.dim() > 1 and min(og.shape) > 1 and "modulation" not in name else 1
+        kind = 0 if _null_gradient(name) else (2 if og.dim() > 1 and min(og.shape) > 1 and "modulation" not in name else 1)
         if err > allw[kind][0]:
             allw[kind] = (err, name)
-    rec.update(worst_probe_matrix=worst[2], worst_probe_1d=worst[1], worst_all_matrix=allw[2], worst_all_1d=allw[1])
+    rec.update(worst_probe_matrix=worst[2], worst_probe_1d=worst[1], worst_all_matrix=allw[2], worst_all_1d=allw[1],
+               worst_identically_null=allw[0])
     print(f"[measured] 1.3B training step vs autograd oracle (freeze={freeze}): loss {float(lg):.6f} vs {float(lo):.6f}, "
           f"output {rec['output_rel_rms']:.3e}, probes: worst matrix {worst[2]:.3e}, worst 1-D {worst[1]:.3e}; "
-          f"all parameters: matrix {allw[2]}, 1-D {allw[1]}; oracle {t_oracle:.0f} s")
+          f"all parameters: matrix {allw[2]}, 1-D {allw[1]}, identically-null gradients {allw[0]}; oracle {t_oracle:.0f} s")
     outdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(outdir, exist_ok=True)
     with open(os.path.join(outdir, f"full_size_gradient_parity_freeze{int(freeze)}.json"), "w") as fh:
         json.dump(rec, fh, indent=1)
     assert rec["loss_rel_err"] < TOL_FULL_LOSS, rec["loss_rel_err"]
     assert not bad, bad
-    assert allw[2][0] < TOL_FULL_GRAD and allw[1][0] < TOL_FULL_GRAD_1D, (allw)
+    assert allw[2][0] < TOL_FULL_GRAD and allw[1][0] < TOL_FULL_GRAD_1D and allw[0][0] < TOL_FULL_GRAD_NULL, allw
 
 
 def test_omnihuman_full_size_sampling(wan_1_3b):

@@ -18,6 +18,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # against the autograd oracle (t2v 13 layers, both freeze settings, i2v); 1-D parameters (bias / gain gradients: long
 # sums with heavy cancellation) <= 4.5e-2.  Bounds = 2 x measured.
 TOL_GRAD = 2e-2
+TOL_GRAD_NULL = 1.3e-1      # gradients that vanish identically (cross-attention K bias): noise vs a floor, 2 x 6.2e-2
 TOL_GRAD_1D = 9e-2          # vs the autograd oracle: 6.2e-2 / 5.9e-2 / 4.5e-2 measured (profiles/r03_measured_gradient_errors.txt)
 
 
@@ -75,7 +76,7 @@ def test_all_gradients_match_autograd_oracle(wan_model_mod, freeze):
     lg.backward()
     assert abs(lg.item() - lo.item()) < 2e-2 * lo.item()
     bad = []
-    worst = {1: 0.0, 2: 0.0}
+    worst = {0: (0.0, None), 1: (0.0, None), 2: (0.0, None)}
     norms = sorted(float(v.grad.norm()) for v in osd.values() if v.grad is not None and float(v.grad.abs().max()) > 0)
     floor = 1e-2 * norms[len(norms) // 2]      # near-null gradients (e.g. the cross-attention K bias, to which the
     for name, p in m.named_parameters():       # softmax is invariant) are compared on the absolute scale instead
@@ -84,12 +85,18 @@ def test_all_gradients_match_autograd_oracle(wan_model_mod, freeze):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
             continue
         err = float((p.grad.double().cpu() - og.double()).norm() / max(float(og.double().norm()), floor))
-        worst[min(og.dim(), 2)] = max(worst[min(og.dim(), 2)], err)
+        # the cross-attention K bias: its gradient is exactly zero in exact arithmetic (softmax shift invariance), what
+        # is compared there is rounding noise against the floor — its own bound
+        null = name.endswith("cross_attn.k.bias")
+        kind = 0 if null else min(og.dim(), 2)
+        if err > worst[kind][0]:
+            worst[kind] = (err, name)
         # matrices: TOL_GRAD; 1-D parameters (bias / gain gradients are long sums with heavy cancellation, so the
         # same bf16 operand noise is a larger fraction of the result): TOL_GRAD_1D
-        if err > (TOL_GRAD if og.dim() > 1 else TOL_GRAD_1D):
+        if err > (TOL_GRAD_NULL if null else TOL_GRAD if og.dim() > 1 else TOL_GRAD_1D):
             bad.append((name, err))
-    print(f"[measured] all gradients vs autograd oracle (freeze={freeze}): worst matrix {worst[2]:.3e}, worst 1-D {worst[1]:.3e}")
+    print(f"[measured] all gradients vs autograd oracle (freeze={freeze}): worst matrix {worst[2]}, worst 1-D {worst[1]}, "
+          f"identically-null gradients {worst[0]}")
     assert not bad, bad[:10]
 
 
