@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OMH_ABI_VERSION 7
+#define OMH_ABI_VERSION 8
 
 #define OMH_E_BADARG   (-1)   /* null pointer / non-positive size             */
 #define OMH_E_ALIGN    (-2)   /* pointer or leading dimension not aligned     */
@@ -158,7 +158,17 @@ typedef struct omh_attn_args {
        leaves a 2^-9 residue in every row sum of dS).  Served by the short-sequence kernel only: a call that sets it
        does not take the long-sequence kernels. */
     float* o32;
+    /* ABI v8.  OMH_ATTN_SHORT_KERNEL: run the short-sequence kernel whatever the shape (the training forward and its
+       re-run under use_checkpoint must take the same kernel whether or not they ask for lse / o32).
+       OMH_ATTN_ALLOW_SPLIT: the short-sequence kernel may split the LAST, partly filled round of its workgroups over the
+       keys (workers write fp32 partial results into `workspace`, a small kernel combines them — the flash-decoding
+       reduction): 624 workgroups on 512 slots (4 clips x 12 heads x 13 query tiles, the training step) then take 1.25
+       rounds instead of 2.  The split plan depends on B, so a sample's last bits depend on its batch: only callers that do
+       not need batch invariance set it (the training step; the inference path does not). */
+    int32_t flags;
 } omh_attn_args;
+#define OMH_ATTN_SHORT_KERNEL 1
+#define OMH_ATTN_ALLOW_SPLIT  2
 
 int omh_flash_attn_fwd_d128(const omh_attn_args* args, omh_stream_t stream);
 /* Scratch size omh_flash_attn_fwd_d128 can use for these shapes (0: none needed). */
@@ -205,9 +215,16 @@ typedef struct omh_attn_bwd_args {
        may issue them on two streams (the dQ kernel's 624 workgroups on 512 slots and the dK/dV kernel's 624 on 256
        each leave most of their last round idle at 4 clips x 1560 positions). */
     int32_t phase;
+    /* ABI v8 (round-3 kernels only).  Optional scratch, omh_flash_attn_bwd_workspace_bytes() bytes, 16-byte aligned:
+       with it the last, partly filled round of workgroups of the dQ kernel is split over the keys and that of the
+       dK/dV kernel over the queries; the workers' fp32 partial sums are added in a fixed order by a small kernel (no
+       atomics: still repeatable bit for bit for a given shape).  NULL: no split. */
+    void* workspace; int64_t workspace_bytes;
 } omh_attn_bwd_args;
 
 int omh_flash_attn_bwd_d128(const omh_attn_bwd_args* args, omh_stream_t stream);
+/* Scratch size the call can use (0: none needed / no split for these shapes); depends on B, H, Lq, Lk, phase. */
+int64_t omh_flash_attn_bwd_workspace_bytes(const omh_attn_bwd_args* args);
 
 /* ------------------------------------------------------------------------
  * LayerNorm (no affine) fused with adaLN modulation, fp32 in -> bf16 out.

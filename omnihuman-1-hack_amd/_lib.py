@@ -21,7 +21,7 @@ class OmhError(RuntimeError):
     pass
 
 
-ABI_VERSION = 7          # == OMH_ABI_VERSION of include/omh.h; checked against the loaded library below
+ABI_VERSION = 8          # == OMH_ABI_VERSION of include/omh.h; checked against the loaded library below
 
 
 def _load():
@@ -86,6 +86,9 @@ class GemmTnGroup(C.Structure):
     _fields_ = [("n", i32), ("problem", GemmTnArgs * TN_GROUP_MAX), ("first_tile", i32 * TN_GROUP_MAX), ("total_tiles", i32)]
 
 
+ATTN_SHORT_KERNEL, ATTN_ALLOW_SPLIT = 1, 2       # omh_attn_args.flags (ABI v8)
+
+
 class AttnArgs(C.Structure):
     _fields_ = [("q", vp), ("k", vp), ("vt", vp), ("o", vp),
                 ("k_lens", vp),
@@ -93,7 +96,7 @@ class AttnArgs(C.Structure):
                 ("q_bs", i64), ("q_rs", i64), ("k_bs", i64), ("k_rs", i64),
                 ("vt_bs", i64), ("o_bs", i64), ("o_rs", i64),
                 ("ldv", i32), ("scale", f32), ("lse", vp), ("q_prescaled", i32), ("workspace", vp), ("workspace_bytes", i64),
-                ("o32", vp)]
+                ("o32", vp), ("flags", i32)]
 
 
 class AttnBwdArgs(C.Structure):
@@ -106,7 +109,7 @@ class AttnBwdArgs(C.Structure):
                 ("q_bs", i64), ("q_rs", i64), ("k_bs", i64), ("k_rs", i64), ("o_bs", i64), ("o_rs", i64),
                 ("dq_bs", i64), ("dq_rs", i64), ("dk_bs", i64), ("dk_rs", i64), ("qt_bs", i64), ("kt_bs", i64),
                 ("ldq", i32), ("ldk", i32), ("scale", f32), ("q_prescaled", i32), ("out_bf16", i32), ("o32", vp),
-                ("phase", i32)]
+                ("phase", i32), ("workspace", vp), ("workspace_bytes", i64)]
 
 
 class LnBwdArgs(C.Structure):
@@ -151,6 +154,7 @@ _SIGS = {
     "omh_flash_attn_fwd_d128": (i32, [C.POINTER(AttnArgs), vp]),
     "omh_flash_attn_workspace_bytes": (i64, [C.POINTER(AttnArgs)]),
     "omh_flash_attn_bwd_d128": (i32, [C.POINTER(AttnBwdArgs), vp]),
+    "omh_flash_attn_bwd_workspace_bytes": (i64, [C.POINTER(AttnBwdArgs)]),
     "omh_layernorm_modulate": (i32, [vp, vp, i64, i32, f32, f32, vp, vp, i64, vp, vp, i64, i64, vp]),
     "omh_rmsnorm_rope": (i32, [vp, i64, vp, i64, i32, vp, f32, i32, vp, vp, i32, i32, vp, i32, vp]),
     "omh_rmsnorm_rope_bf16": (i32, [vp, i64, vp, i64, i32, vp, f32, i32, vp, vp, i32, i32, vp, i32, f32, vp]),

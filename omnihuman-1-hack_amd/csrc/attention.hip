@@ -63,8 +63,17 @@ __device__ __forceinline__ uint32_t v_addr(int row, int slot) {
     return (uint32_t)(row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
 }
 
+// Split-KV workers of the last round (omh_tail_split_plan, OMH_ATTN_ALLOW_SPLIT): ids >= n_regular.  Worker w takes tile
+// n_regular + w / splits and key tiles [s * per, (s + 1) * per) of it, s = w % splits, and writes its NORMALISED fp32
+// result + natural-log lse into slab (tail tile, s); attn_split_combine_kernel weights the slabs.
+struct AttnSplit {
+    int n_regular, n_tail, splits;
+    float* ws_o;          // [n_tail][splits][128][128] fp32
+    float* ws_lse;        // [n_tail][splits][128]      fp32 (-inf: no keys in the worker's range)
+};
+
 __global__ __launch_bounds__(256, 2)
-void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles) {
+void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles, const AttnSplit wk) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (KT_BYTES + VT_BYTES)];
 
     const int tid = threadIdx.x;
@@ -72,14 +81,27 @@ void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles) {
     const int li = lane & 31, lh = lane >> 5;
 
     // work id -> (batch*head, q tile); consecutive ids (same head) share an XCD
-    const int nwg = q_tiles * p.H * p.B;
-    const int wid = xcd_remap(blockIdx.x, nwg);
+    const bool worker = (int)blockIdx.x >= wk.n_regular;
+    int wid, split = 0;
+    if (worker) {
+        const int w = blockIdx.x - wk.n_regular;
+        wid = wk.n_regular + w / wk.splits;
+        split = w % wk.splits;
+    } else {
+        wid = xcd_remap(blockIdx.x, wk.n_regular);
+    }
     const int bh = wid / q_tiles, qt = wid % q_tiles;
     const int b = bh / p.H, head = bh % p.H;
 
     int klen = p.k_lens ? p.k_lens[b] : p.Lk;
     klen = min(max(klen, 0), p.Lk);
-    const int n_tiles = (klen + KB - 1) / KB;
+    const int n_tiles_all = (klen + KB - 1) / KB;
+    int t_first = 0, n_tiles = n_tiles_all;
+    if (worker) {
+        const int per = (n_tiles_all + wk.splits - 1) / wk.splits;
+        t_first = min(split * per, n_tiles_all);
+        n_tiles = min(t_first + per, n_tiles_all) - t_first;
+    }
 
     const __bf16* __restrict__ Q = (const __bf16*)p.q + (int64_t)b * p.q_bs + head * D;
     const __bf16* __restrict__ K = (const __bf16*)p.k + (int64_t)b * p.k_bs + head * D;
@@ -145,15 +167,16 @@ void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles) {
     const float sc = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;   // scores -> log2 domain
 
     if (n_tiles > 0) {
-        OMH_GLOAD(0)
+        OMH_GLOAD(t_first)
         OMH_LSTORE(0)
     }
     __syncthreads();
 
     const int krow_l = swap_bits23(li);
-    for (int t = 0; t < n_tiles; ++t) {
-        const int buf = t & 1;
-        OMH_GLOAD(min(t + 1, n_tiles - 1))   // unconditional: keeps the staging registers out of scratch
+    for (int tt = 0; tt < n_tiles; ++tt) {
+        const int buf = tt & 1;
+        const int t = t_first + tt;
+        OMH_GLOAD(t_first + min(tt + 1, n_tiles - 1))   // unconditional: keeps the staging registers out of scratch
         const unsigned char* kt = smem + buf * (KT_BYTES + VT_BYTES);
         const unsigned char* vt = kt + KT_BYTES;
 
@@ -245,6 +268,22 @@ void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles) {
     }
 
     // ---- normalise and store: lane holds O[q][32db + 8g + 4h + 0..3]
+    if (worker) {                                      // split-KV worker: fp32 slab, combined by attn_split_combine_kernel
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        const int64_t slab = (int64_t)(wid - wk.n_regular) * wk.splits + split;
+        const int r = wave * 32 + li;
+        float* so = wk.ws_o + (slab * QB + r) * D;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                *(float4*)(so + db * 32 + gq * 8 + lh * 4) =
+                    make_float4(oacc[db][4 * gq] * inv, oacc[db][4 * gq + 1] * inv, oacc[db][4 * gq + 2] * inv,
+                                oacc[db][4 * gq + 3] * inv);
+        if (lh == 0)
+            wk.ws_lse[slab * QB + r] = l_run > 0.f ? (m_run + log2f(l_run)) * 0.6931471805599453f : -INFINITY;
+        return;
+    }
     if (q_row < p.Lq) {
         const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
         uint16_t* O = (uint16_t*)p.o + (int64_t)b * p.o_bs + (int64_t)q_row * p.o_rs + head * D;
@@ -555,6 +594,42 @@ void flash_attn_fwd_d128_pp_kernel(const omh_attn_args p, const int q_tiles) {
     }
 }
 
+// out[row] = sum_s w_s O_s[row] / sum_s w_s,  w_s = exp(lse_s - max lse)  (flash-decoding reduction over the split-KV
+// workers of a tail tile): one wave per query row, a lane per pair of channels; also the fp32 output and the lse.
+__global__ __launch_bounds__(256)
+void attn_split_combine_kernel(const omh_attn_args p, const int q_tiles, const AttnSplit wk) {
+    const int lane = threadIdx.x & 63;
+    const int rowid = blockIdx.x * 4 + (threadIdx.x >> 6);                // (tail tile, row in tile)
+    const int tt = rowid / QB, r = rowid % QB;
+    if (tt >= wk.n_tail) return;
+    const int tile = wk.n_regular + tt;
+    const int bh = tile / q_tiles, qt = tile % q_tiles;
+    const int b = bh / p.H, head = bh % p.H;
+    const int row = qt * QB + r;
+    if (row >= p.Lq) return;
+    float mx = -INFINITY;
+    for (int s = 0; s < wk.splits; ++s) mx = fmaxf(mx, wk.ws_lse[((int64_t)tt * wk.splits + s) * QB + r]);
+    float acc0 = 0.f, acc1 = 0.f, wsum = 0.f;
+    if (mx > -INFINITY) {
+        for (int s = 0; s < wk.splits; ++s) {                             // fixed order: repeatable bit for bit
+            const int64_t part = (int64_t)tt * wk.splits + s;
+            const float l = wk.ws_lse[part * QB + r];
+            if (l == -INFINITY) continue;
+            const float w = __expf(l - mx);
+            const float2 v = *(const float2*)(wk.ws_o + (part * QB + r) * D + 2 * lane);
+            acc0 += w * v.x;
+            acc1 += w * v.y;
+            wsum += w;
+        }
+    }
+    const float inv = wsum > 0.f ? 1.0f / wsum : 0.f;
+    const int64_t eo = (int64_t)b * p.o_bs + (int64_t)row * p.o_rs + head * D + 2 * lane;
+    *(uint32_t*)((uint16_t*)p.o + eo) = pack_bf2(acc0 * inv, acc1 * inv);
+    if (p.o32) *(float2*)(p.o32 + eo) = make_float2(acc0 * inv, acc1 * inv);
+    if (p.lse && lane == 0)
+        p.lse[((int64_t)b * p.H + head) * p.Lq + row] = wsum > 0.f ? mx + __logf(wsum) : -INFINITY;
+}
+
 }  // namespace
 
 // attention_w64.hip: 4 waves x 64 query rows, asm-owned register file (long sequences)
@@ -573,9 +648,29 @@ static AttnChoice attn_choice(const omh_attn_args& a) {
     const bool fits32 = ((int64_t)a.Lq * a.q_rs * 2 < 0x7fffffffLL) && ((int64_t)a.Lk * a.k_rs * 2 < 0x7fffffffLL) &&
                         ((int64_t)a.Lq * a.o_rs * 2 < 0x7fffffffLL) && ((int64_t)D * a.ldv * 2 < 0x7fffffffLL);
     AttnChoice c;
-    c.w64 = a.o32 ? false : (force ? (force[0] == 'w' && fits32) : (big && fits32));      // fp32 output: base kernel only
-    c.pp = a.o32 ? false : (force ? (force[0] == 'p') : (big && !c.w64));
+    const bool short_only = a.o32 || (a.flags & OMH_ATTN_SHORT_KERNEL);                    // fp32 output: base kernel only
+    c.w64 = short_only ? false : (force ? (force[0] == 'w' && fits32) : (big && fits32));
+    c.pp = short_only ? false : (force ? (force[0] == 'p') : (big && !c.w64));
     return c;
+}
+// Split plan of the short-sequence kernel (OMH_ATTN_ALLOW_SPLIT; two workgroups per CU; >= 4 key tiles per worker)
+static OmhSplitPlan base_split_plan(const omh_attn_args& a) {
+    const int q_tiles = (a.Lq + QB - 1) / QB;
+    const int nwg = q_tiles * a.H * a.B;
+    OmhSplitPlan none = {nwg, 0, 1};
+    const char* e = getenv("OMH_ATTN_SPLIT");                      // "0": never split (A/B timing; tests flip it in-process)
+    if (!(a.flags & OMH_ATTN_ALLOW_SPLIT) || (e && e[0] == '0')) return none;
+    // measured at one clip x 1560 keys: 32.1 -> 24.8 us + 12.8 us of combine (the workers' fp32 results + the bf16 / fp32 /
+    // lse outputs are all HBM traffic): the forward's split only pays on long key loops — 16 key tiles per worker, and
+    // only launches that do not fill the chip once.  OMH_ATTN_SPLIT=tail: 4 tiles per worker, any launch (tests, A/B).
+    const bool tail = e && e[0] == 't';
+    return omh_tail_split_plan(nwg, 2 * omh_cu_count(), (a.Lk + KB - 1) / KB, tail ? 4 : 16, !tail);
+}
+int64_t omh_attn_base_workspace_bytes(const omh_attn_args& a) {
+    const AttnChoice ch = attn_choice(a);
+    if (ch.w64 || ch.pp) return 0;
+    const OmhSplitPlan pl = base_split_plan(a);
+    return (int64_t)pl.n_tail * pl.splits * QB * (D + 1) * 4;
 }
 bool omh_attn_takes_w64(const omh_attn_args& a) { return attn_choice(a).w64; }
 
@@ -601,8 +696,20 @@ extern "C" int omh_flash_attn_fwd_d128(const omh_attn_args* args, omh_stream_t s
                            (hipStream_t)stream, a, q_tiles2);
     } else {
         const int q_tiles = (a.Lq + QB - 1) / QB;
-        hipLaunchKernelGGL(flash_attn_fwd_d128_kernel, dim3(q_tiles * a.H * a.B), dim3(256), 0, (hipStream_t)stream,
-                           a, q_tiles);
+        OmhSplitPlan pl = base_split_plan(a);
+        const int64_t need = (int64_t)pl.n_tail * pl.splits * QB * (D + 1) * 4;
+        if (pl.n_tail && (!a.workspace || a.workspace_bytes < need || ((uintptr_t)a.workspace & 15))) {
+            pl.n_regular += pl.n_tail; pl.n_tail = 0; pl.splits = 1;     // no workspace from the caller: one more round instead
+        }
+        AttnSplit wk;
+        wk.n_regular = pl.n_regular; wk.n_tail = pl.n_tail; wk.splits = pl.splits;
+        wk.ws_o = pl.n_tail ? (float*)a.workspace : nullptr;
+        wk.ws_lse = pl.n_tail ? wk.ws_o + (int64_t)pl.n_tail * pl.splits * QB * D : nullptr;
+        hipLaunchKernelGGL(flash_attn_fwd_d128_kernel, dim3(pl.n_regular + pl.n_tail * pl.splits), dim3(256), 0,
+                           (hipStream_t)stream, a, q_tiles, wk);
+        if (pl.n_tail)
+            hipLaunchKernelGGL(attn_split_combine_kernel, dim3((pl.n_tail * QB + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                               a, q_tiles, wk);
     }
     return omh_launch_status();
 }

@@ -125,114 +125,90 @@ __device__ __forceinline__ void tile_dma(const TileSrc& t, int tile, unsigned ch
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
-// ---------------------------------------------------------------------------------------------- delta alone (phase 1)
-// delta[b][h][q] = sum_d dO[q][d] o32[q][d] with the dQ kernel's arithmetic (two chains per (row, head): the sequential
-// fma chain over the 8 runs of 8 channels d = 16 kk + 8 lh .., the two halves added) — the same bits as phase 0.
-// A block takes 32 consecutive (row, head) pairs: their 8 KiB of dO and 16 KiB of o32 are fetched with coalesced
-// 16-byte loads into LDS (the chains' own access pattern is 16 bytes every 32: 24 us per call when read directly),
-// then 64 threads run the chains.
+// ---------------------------------------------------------------------------------------------- delta
+// delta[b][h][q] = sum_d dO[q][d] o32[q][d]: 16 lanes per (row, head) pair, 8 channels each (one 16-byte dO load and two
+// 16-byte o32 loads per lane: a wave covers 4 pairs = 1 KiB + 2 KiB of contiguous memory when the tensors are dense),
+// an fma chain over the lane's 8 channels, then a fixed butterfly over the 16 lanes — one arithmetic, whatever the
+// phase (round 3 had a second copy of it in the dQ kernel's prologue and a 38 us LDS-staged kernel here; 57 MB at
+// 4 clips: ~12 us of traffic).
 __global__ __launch_bounds__(256)
 void attn_bwd2_delta_kernel(const omh_attn_bwd_args p) {
-    constexpr int PD = 256 + 16, PO = 512 + 16;                     // row pitches: 16-byte reads of 32 rows spread over the banks
-    __shared__ __attribute__((aligned(16))) unsigned char sdo[32 * PD];
-    __shared__ __attribute__((aligned(16))) unsigned char so[32 * PO];
     const int tid = threadIdx.x;
-    const int64_t pair0 = (int64_t)blockIdx.x * 32;
-    const int64_t npairs = (int64_t)p.B * p.Lq * p.H;
-    auto locate = [&](int64_t pair, int& b, int& q, int& head) {
-        head = (int)(pair % p.H);
-        const int64_t row = pair / p.H;
-        b = (int)(row / p.Lq);
-        q = (int)(row - (int64_t)b * p.Lq);
-    };
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {                                   // dO: 32 pairs x 16 chunks of 16 bytes
-        const int c = tid + 256 * j, pr = c >> 4, ch = c & 15;
-        if (pair0 + pr < npairs) {
-            int b, q, head;
-            locate(pair0 + pr, b, q, head);
-            *(uint4*)(sdo + pr * PD + ch * 16) =
-                *(const uint4*)((const uint16_t*)p.dout + (int64_t)b * p.o_bs + (int64_t)q * p.o_rs + head * D + ch * 8);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {                                   // o32: 32 pairs x 32 chunks of 16 bytes
-        const int c = tid + 256 * j, pr = c >> 5, ch = c & 31;
-        if (pair0 + pr < npairs) {
-            int b, q, head;
-            locate(pair0 + pr, b, q, head);
-            *(float4*)(so + pr * PO + ch * 16) = *(const float4*)(p.o32 + (int64_t)b * p.o_bs + (int64_t)q * p.o_rs + head * D + ch * 4);
-        }
-    }
-    __syncthreads();
-    if (tid >= 64) return;
-    const int pr = tid >> 1, lh = tid & 1;
-    const bool ok = pair0 + pr < npairs;
+    const uint32_t npairs = (uint32_t)p.B * (uint32_t)p.Lq * (uint32_t)p.H;      // < 2^31: checked by the launcher
+    const uint32_t pair = blockIdx.x * 16u + (uint32_t)(tid >> 4);
+    const int sub = tid & 15;
     float del = 0.f;
+    int b = 0, q = 0, head = 0;
+    const bool ok = pair < npairs;
     if (ok) {
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            const uint4 dw = *(const uint4*)(sdo + pr * PD + (2 * kk + lh) * 16);
-            const float4 o0 = *(const float4*)(so + pr * PO + (2 * kk + lh) * 32);
-            const float4 o1 = *(const float4*)(so + pr * PO + (2 * kk + lh) * 32 + 16);
-            del = fmaf(bf_lo(dw.x), o0.x, del); del = fmaf(bf_hi(dw.x), o0.y, del);
-            del = fmaf(bf_lo(dw.y), o0.z, del); del = fmaf(bf_hi(dw.y), o0.w, del);
-            del = fmaf(bf_lo(dw.z), o1.x, del); del = fmaf(bf_hi(dw.z), o1.y, del);
-            del = fmaf(bf_lo(dw.w), o1.z, del); del = fmaf(bf_hi(dw.w), o1.w, del);
-        }
+        const uint32_t row = pair / (uint32_t)p.H;
+        head = (int)(pair - row * (uint32_t)p.H);
+        b = (int)(row / (uint32_t)p.Lq);
+        q = (int)(row - (uint32_t)b * (uint32_t)p.Lq);
+        const int64_t off = (int64_t)b * p.o_bs + (int64_t)q * p.o_rs + head * D + sub * 8;
+        const uint4 dw = *(const uint4*)((const uint16_t*)p.dout + off);
+        const float4 o0 = *(const float4*)(p.o32 + off);
+        const float4 o1 = *(const float4*)(p.o32 + off + 4);
+        del = bf_lo(dw.x) * o0.x;
+        del = fmaf(bf_hi(dw.x), o0.y, del);
+        del = fmaf(bf_lo(dw.y), o0.z, del); del = fmaf(bf_hi(dw.y), o0.w, del);
+        del = fmaf(bf_lo(dw.z), o1.x, del); del = fmaf(bf_hi(dw.z), o1.y, del);
+        del = fmaf(bf_lo(dw.w), o1.z, del); del = fmaf(bf_hi(dw.w), o1.w, del);
     }
     del += __shfl_xor(del, 1, 64);
-    if (ok && lh == 0) {
-        int b, q, head;
-        locate(pair0 + pr, b, q, head);
-        p.delta[((int64_t)b * p.H + head) * p.Lq + q] = del;
-    }
+    del += __shfl_xor(del, 2, 64);
+    del += __shfl_xor(del, 4, 64);
+    del += __shfl_xor(del, 8, 64);
+    if (ok && sub == 0) p.delta[((int64_t)b * p.H + head) * p.Lq + q] = del;
 }
 
 // ---------------------------------------------------------------------------------------------- dQ (+ delta)
+// Workers of the last, partly filled round (omh_tail_split_plan; ABI v8 omh_attn_bwd_args.workspace): ids >= n_regular.
+// Worker w takes workgroup-tile n_regular + w / splits and the s-th share of its inner loop (s = w % splits; key tiles
+// for dQ, query tiles for dK / dV) and writes fp32 partial sums into slab (tail tile, s) of `ws`; attn_bwd2_sum_kernel
+// adds the slabs in the order of s.
+struct BwdSplit {
+    int n_regular, n_tail, splits;
+    float* ws;            // dQ: [n_tail][splits][128][128];  dK, dV: [n_tail][splits][2][128][128]  fp32
+};
+
 __global__ __launch_bounds__(256, 2)
-void attn_bwd2_dq_kernel(const omh_attn_bwd_args p, const int q_blocks) {
+void attn_bwd2_dq_kernel(const omh_attn_bwd_args p, const int q_blocks, const BwdSplit wk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // [2 stages][K tile | V tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int wid = blockIdx.x;
+    const bool worker = (int)blockIdx.x >= wk.n_regular;
+    const int wid = worker ? wk.n_regular + ((int)blockIdx.x - wk.n_regular) / wk.splits : (int)blockIdx.x;
+    const int split = worker ? ((int)blockIdx.x - wk.n_regular) % wk.splits : 0;
     const int qb = wid % q_blocks, bh = wid / q_blocks;
     const int b = bh / p.H, head = bh % p.H;
     int klen = p.k_lens ? p.k_lens[b] : p.Lk;
     klen = min(max(klen, 0), p.Lk);
-    const int n_tiles = (klen + TB - 1) / TB;
+    const int n_tiles_all = (klen + TB - 1) / TB;
+    int t_first = 0, n_tiles = n_tiles_all;
+    if (worker) {
+        const int per = (n_tiles_all + wk.splits - 1) / wk.splits;
+        t_first = min(split * per, n_tiles_all);
+        n_tiles = min(t_first + per, n_tiles_all) - t_first;
+    }
 
     const uint16_t* Q = (const uint16_t*)p.q + (int64_t)b * p.q_bs + head * D;
     const uint16_t* DO = (const uint16_t*)p.dout + (int64_t)b * p.o_bs + head * D;
     const uint16_t* K = (const uint16_t*)p.k + (int64_t)b * p.k_bs + head * D;
     const uint16_t* V = (const uint16_t*)p.v + (int64_t)b * p.k_bs + head * D;
-    const float* O32 = p.o32 + (int64_t)b * p.o_bs + head * D;
-
     const int q_row = qb * 128 + wave * 32 + li;
     const bool q_ok = q_row < p.Lq;
     bf16x8 qf[8], dof[8];
-    float del = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
         qf[kk] = __builtin_bit_cast(bf16x8, ld16(Q + (int64_t)q_row * p.q_rs + kk * 16 + lh * 8, q_ok));
-        const uint4 dw = ld16(DO + (int64_t)q_row * p.o_rs + kk * 16 + lh * 8, q_ok);
-        dof[kk] = __builtin_bit_cast(bf16x8, dw);
-        if (q_ok && p.phase == 0) {                                  // delta = sum_d dO * O (fp32 O of the forward)
-            const float4 o0 = *(const float4*)(O32 + (int64_t)q_row * p.o_rs + kk * 16 + lh * 8);
-            const float4 o1 = *(const float4*)(O32 + (int64_t)q_row * p.o_rs + kk * 16 + lh * 8 + 4);
-            del = fmaf(bf_lo(dw.x), o0.x, del); del = fmaf(bf_hi(dw.x), o0.y, del);
-            del = fmaf(bf_lo(dw.y), o0.z, del); del = fmaf(bf_hi(dw.y), o0.w, del);
-            del = fmaf(bf_lo(dw.z), o1.x, del); del = fmaf(bf_hi(dw.z), o1.y, del);
-            del = fmaf(bf_lo(dw.w), o1.z, del); del = fmaf(bf_hi(dw.w), o1.w, del);
-        }
+        dof[kk] = __builtin_bit_cast(bf16x8, ld16(DO + (int64_t)q_row * p.o_rs + kk * 16 + lh * 8, q_ok));
     }
-    del += __shfl_xor(del, 32, 64);
-    float l2 = INFINITY;
+    float l2 = INFINITY, del = 0.f;
     const int64_t row_i = ((int64_t)b * p.H + head) * p.Lq + q_row;
     if (q_ok) {
         const float l = p.lse[row_i];
         l2 = (l > -INFINITY) ? l * LOG2E : INFINITY;
-        if (p.phase != 0) del = p.delta[row_i];                      // phase 2: a phase-1 launch computed it
-        else if (lh == 0) p.delta[row_i] = del;                      // the dK/dV kernel reads it
+        del = p.delta[row_i];                                        // attn_bwd2_delta_kernel ran before (every phase)
     }
     const float sc = p.q_prescaled ? 1.0f : p.scale * LOG2E;
     float lv[16], dl[16];
@@ -250,8 +226,8 @@ void attn_bwd2_dq_kernel(const omh_attn_bwd_args p, const int q_blocks) {
         for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
 
     if (n_tiles > 0) {
-        tile_dma(ks, 0, smem, wave_lds);
-        tile_dma(vs, 0, smem + TILE_BYTES, wave_lds);
+        tile_dma(ks, t_first, smem, wave_lds);
+        tile_dma(vs, t_first, smem + TILE_BYTES, wave_lds);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     for (int t = 0; t < n_tiles; ++t) {
@@ -259,10 +235,10 @@ void attn_bwd2_dq_kernel(const omh_attn_bwd_args p, const int q_blocks) {
         const unsigned char* vt = kt + TILE_BYTES;
         if (t + 1 < n_tiles) {                                       // the other stage was last read before the barrier
             unsigned char* nk = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
-            tile_dma(ks, t + 1, nk, wave_lds);
-            tile_dma(vs, t + 1, nk + TILE_BYTES, wave_lds);
+            tile_dma(ks, t_first + t + 1, nk, wave_lds);
+            tile_dma(vs, t_first + t + 1, nk + TILE_BYTES, wave_lds);
         }
-        const int k0 = t * TB;
+        const int k0 = (t_first + t) * TB;
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
             // S^T = K Q^T and dP^T = V dO^T as [key][query], lane = query; register r <-> key k0 + 32hb + 16(r>>3) + 8lh + (r&7)
@@ -292,6 +268,16 @@ void attn_bwd2_dq_kernel(const omh_attn_bwd_args p, const int q_blocks) {
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
+    if (worker) {                                                    // partial sums over this worker's keys
+        float* W = wk.ws + (((int64_t)(wid - wk.n_regular) * wk.splits + split) * 128 + wave * 32 + li) * D;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(float4*)(W + db * 32 + g * 8 + lh * 4) =
+                    make_float4(dq[db][4 * g], dq[db][4 * g + 1], dq[db][4 * g + 2], dq[db][4 * g + 3]);
+        return;
+    }
     if (q_ok) {
         const int64_t eo = (int64_t)b * p.dq_bs + (int64_t)q_row * p.dq_rs + head * D;
         if (p.out_bf16) {
@@ -316,16 +302,24 @@ void attn_bwd2_dq_kernel(const omh_attn_bwd_args p, const int q_blocks) {
 
 // ---------------------------------------------------------------------------------------------- dK, dV
 __global__ __launch_bounds__(256)
-void attn_bwd2_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks) {
+void attn_bwd2_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks, const BwdSplit wk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // [2 stages][Q tile | dO tile] + lse/delta
     float* stat = (float*)(smem + 4 * TILE_BYTES);                              // [2 stages][lse 64 | delta 64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int wid = blockIdx.x;
+    const bool worker = (int)blockIdx.x >= wk.n_regular;
+    const int wid = worker ? wk.n_regular + ((int)blockIdx.x - wk.n_regular) / wk.splits : (int)blockIdx.x;
+    const int split = worker ? ((int)blockIdx.x - wk.n_regular) % wk.splits : 0;
     const int kb = wid % k_blocks, bh = wid / k_blocks;
     const int b = bh / p.H, head = bh % p.H;
     int klen = p.k_lens ? p.k_lens[b] : p.Lk;
     klen = min(max(klen, 0), p.Lk);
-    const int n_tiles = (p.Lq + TB - 1) / TB;
+    const int n_tiles_all = (p.Lq + TB - 1) / TB;
+    int t_first = 0, n_tiles = n_tiles_all;
+    if (worker) {                                                    // this worker's share of the query tiles
+        const int per = (n_tiles_all + wk.splits - 1) / wk.splits;
+        t_first = min(split * per, n_tiles_all);
+        n_tiles = min(t_first + per, n_tiles_all) - t_first;
+    }
 
     const uint16_t* Q = (const uint16_t*)p.q + (int64_t)b * p.q_bs + head * D;
     const uint16_t* DO = (const uint16_t*)p.dout + (int64_t)b * p.o_bs + head * D;
@@ -368,9 +362,9 @@ void attn_bwd2_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks) {
         dd = in ? DEL[q] : 0.f;
     };
     float gl = 0.f, gd = 0.f;
-    tile_dma(qs, 0, smem, wave_lds);
-    tile_dma(dos, 0, smem + TILE_BYTES, wave_lds);
-    if (tid < 64) { stat_load(0, gl, gd); stat[tid] = gl; stat[64 + tid] = gd; }
+    tile_dma(qs, t_first, smem, wave_lds);                           // (a tile index past the end arrives as zeros)
+    tile_dma(dos, t_first, smem + TILE_BYTES, wave_lds);
+    if (tid < 64) { stat_load(t_first, gl, gd); stat[tid] = gl; stat[64 + tid] = gd; }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     for (int t = 0; t < n_tiles; ++t) {
         const unsigned char* qt = smem + (t & 1) * 2 * TILE_BYTES;
@@ -379,9 +373,9 @@ void attn_bwd2_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks) {
         const bool more = t + 1 < n_tiles;
         if (more) {
             unsigned char* nq = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
-            tile_dma(qs, t + 1, nq, wave_lds);
-            tile_dma(dos, t + 1, nq + TILE_BYTES, wave_lds);
-            if (tid < 64) stat_load(t + 1, gl, gd);
+            tile_dma(qs, t_first + t + 1, nq, wave_lds);
+            tile_dma(dos, t_first + t + 1, nq + TILE_BYTES, wave_lds);
+            if (tid < 64) stat_load(t_first + t + 1, gl, gd);
         }
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
@@ -425,6 +419,18 @@ void attn_bwd2_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks) {
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
+    if (worker) {                                                    // partial sums over this worker's queries
+        float* W = wk.ws + ((((int64_t)(wid - wk.n_regular) * wk.splits + split) * 2) * 128 + wave * 32 + li) * D;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = db * 32 + g * 8 + lh * 4;
+                *(float4*)(W + d0) = make_float4(dk[db][4 * g], dk[db][4 * g + 1], dk[db][4 * g + 2], dk[db][4 * g + 3]);
+                *(float4*)(W + 128 * D + d0) = make_float4(dv[db][4 * g], dv[db][4 * g + 1], dv[db][4 * g + 2], dv[db][4 * g + 3]);
+            }
+        return;
+    }
     if (key < p.Lk) {
         const int64_t eo = (int64_t)b * p.dk_bs + (int64_t)key * p.dk_rs + head * D;
         if (p.out_bf16) {
@@ -453,7 +459,60 @@ void attn_bwd2_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks) {
     }
 }
 
+// out[row] = sum_s slab_s[row] in the order of s (fixed: repeatable bit for bit).  One wave per (tail tile, row);
+// NOUT = 1: dQ rows; NOUT = 2: dK and dV rows of the same key.
+template <int NOUT>
+__global__ __launch_bounds__(256)
+void attn_bwd2_sum_kernel(const omh_attn_bwd_args p, const int blocks, const BwdSplit wk) {
+    const int lane = threadIdx.x & 63;
+    const int rowid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tt = rowid / 128, r = rowid % 128;
+    if (tt >= wk.n_tail) return;
+    const int tile = wk.n_regular + tt;
+    const int blk = tile % blocks, bh = tile / blocks;
+    const int b = bh / p.H, head = bh % p.H;
+    const int row = blk * 128 + r;
+    if (row >= (NOUT == 1 ? p.Lq : p.Lk)) return;
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int s = 0; s < wk.splits; ++s) {
+            const float2 v = *(const float2*)(wk.ws + ((((int64_t)tt * wk.splits + s) * NOUT + o) * 128 + r) * D + 2 * lane);
+            a0 += v.x;
+            a1 += v.y;
+        }
+        const int64_t eo = (NOUT == 1 ? (int64_t)b * p.dq_bs + (int64_t)row * p.dq_rs
+                                      : (int64_t)b * p.dk_bs + (int64_t)row * p.dk_rs) + head * D + 2 * lane;
+        void* base = NOUT == 1 ? p.dq : (o == 0 ? p.dk : p.dv);
+        if (p.out_bf16) *(uint32_t*)((uint16_t*)base + eo) = pack_bf2(a0, a1);
+        else *(float2*)((float*)base + eo) = make_float2(a0, a1);
+    }
+}
+
 }  // namespace
+
+// Split plans: the dQ kernel runs two workgroups per CU (250 VGPRs), the dK / dV kernel one (214 VGPRs + 158 AGPRs:
+// forcing two spills 179 registers); at least 4 tiles of 64 positions per worker
+static OmhSplitPlan bwd2_plan(const omh_attn_bwd_args& a, bool dq) {
+    const int blocks = dq ? (a.Lq + 127) / 128 : (a.Lk + 127) / 128;
+    const int nwg = blocks * a.H * a.B;
+    OmhSplitPlan none = {nwg, 0, 1};
+    const char* e = getenv("OMH_ATTN_SPLIT");                      // "0": never split (A/B timing; tests flip it in-process)
+    if (e && e[0] == '0') return none;
+    // OMH_ATTN_SPLIT=tail: also the last round of a launch that fills the chip (measured: no gain, omh_common.h)
+    const bool tail = e && e[0] == 't';
+    return omh_tail_split_plan(nwg, (dq ? 2 : 1) * omh_cu_count(), ((dq ? a.Lk : a.Lq) + TB - 1) / TB, 4, !tail);
+}
+static int64_t bwd2_ws_bytes(const OmhSplitPlan& pl, int nout) {
+    return (int64_t)pl.n_tail * pl.splits * nout * 128 * D * 4;
+}
+extern "C" int64_t omh_flash_attn_bwd_workspace_bytes(const omh_attn_bwd_args* args) {
+    if (!args || !args->o32 || args->B <= 0 || args->H <= 0 || args->Lq <= 0 || args->Lk <= 0) return 0;
+    int64_t n = 0;
+    if (args->phase == 0 || args->phase == 2) n += bwd2_ws_bytes(bwd2_plan(*args, true), 1);
+    if (args->phase == 0 || args->phase == 3) n += bwd2_ws_bytes(bwd2_plan(*args, false), 2);
+    return n;
+}
 
 // called by omh_flash_attn_bwd_d128 (attention_bwd.hip) when args->o32 is set; arguments already validated there
 int omh_launch_attn_bwd2(const omh_attn_bwd_args& a, hipStream_t s) {
@@ -471,14 +530,31 @@ int omh_launch_attn_bwd2(const omh_attn_bwd_args& a, hipStream_t s) {
     }
     const int k_blocks = (a.Lk + 127) / 128, q_blocks = (a.Lq + 127) / 128;
     if (a.phase < 0 || a.phase > 3) return OMH_E_BADARG;
-    if (a.phase == 1) {
-        const int64_t pairs = (int64_t)a.B * a.Lq * a.H;
-        hipLaunchKernelGGL(attn_bwd2_delta_kernel, dim3((unsigned)((pairs + 31) / 32)), dim3(256), 0, s, a);
-        return 0;
+    const int64_t pairs = (int64_t)a.B * a.Lq * a.H;
+    if (pairs >= 0x7fffffffLL) return OMH_E_SHAPE;
+    if (a.phase == 0 || a.phase == 1) {                              // phase 0 = delta, then dQ, then dK / dV
+        hipLaunchKernelGGL(attn_bwd2_delta_kernel, dim3((unsigned)((pairs + 15) / 16)), dim3(256), 0, s, a);
+        if (a.phase == 1) return 0;
     }
-    if (a.phase == 0 || a.phase == 2)
-        hipLaunchKernelGGL(attn_bwd2_dq_kernel, dim3(q_blocks * a.H * a.B), dim3(256), LDS_DQ, s, a, q_blocks);    // phase 0: writes delta
-    if (a.phase == 0 || a.phase == 3)
-        hipLaunchKernelGGL(attn_bwd2_dkdv_kernel, dim3(k_blocks * a.H * a.B), dim3(256), LDS_KV, s, a, k_blocks);  // reads it
+    // workspace: [dQ slabs | dK, dV slabs]; without (enough of) it the kernels run unsplit
+    OmhSplitPlan pq = bwd2_plan(a, true), pk = bwd2_plan(a, false);
+    const bool run_q = a.phase == 0 || a.phase == 2, run_k = a.phase == 0 || a.phase == 3;
+    const int64_t need_q = run_q ? bwd2_ws_bytes(pq, 1) : 0, need_k = run_k ? bwd2_ws_bytes(pk, 2) : 0;
+    if (!a.workspace || ((uintptr_t)a.workspace & 15) || a.workspace_bytes < need_q + need_k) {
+        pq.n_regular += pq.n_tail; pq.n_tail = 0; pq.splits = 1;
+        pk.n_regular += pk.n_tail; pk.n_tail = 0; pk.splits = 1;
+    }
+    BwdSplit wq = {pq.n_regular, pq.n_tail, pq.splits, (float*)a.workspace};
+    BwdSplit wkv = {pk.n_regular, pk.n_tail, pk.splits, (float*)((char*)a.workspace + (pq.n_tail ? need_q : 0))};
+    if (run_q) {                                                                                               // phase 0: writes delta
+        hipLaunchKernelGGL(attn_bwd2_dq_kernel, dim3(wq.n_regular + wq.n_tail * wq.splits), dim3(256), LDS_DQ, s, a, q_blocks, wq);
+        if (wq.n_tail)
+            hipLaunchKernelGGL(attn_bwd2_sum_kernel<1>, dim3((wq.n_tail * 128 + 3) / 4), dim3(256), 0, s, a, q_blocks, wq);
+    }
+    if (run_k) {                                                                                               // reads delta
+        hipLaunchKernelGGL(attn_bwd2_dkdv_kernel, dim3(wkv.n_regular + wkv.n_tail * wkv.splits), dim3(256), LDS_KV, s, a, k_blocks, wkv);
+        if (wkv.n_tail)
+            hipLaunchKernelGGL(attn_bwd2_sum_kernel<2>, dim3((wkv.n_tail * 128 + 3) / 4), dim3(256), 0, s, a, k_blocks, wkv);
+    }
     return 0;
 }

@@ -114,3 +114,51 @@ static inline int omh_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
+
+
+// ---- split of a launch's last, partly filled round of workgroups (host side; attention.hip, attention_bwd2.hip) ----
+// A launch of `nwg` equal workgroups on `slots` resident slots takes ceil(nwg / slots) rounds; its last round holds
+// r = nwg mod slots workgroups.  Those r are split into `splits` workers each over their inner loop (`loop_tiles` tiles,
+// at least `min_tiles` per worker), dispatched as the LAST blocks of the same launch: they start when the last full
+// round drains, and that round then costs ceil(r splits / slots) / splits of a full one — the smallest `splits` <= 8
+// that minimises this is taken, if it saves at least a fifth of the round (the workers write partial results into a
+// workspace that a small kernel combines in a fixed order: that is not free).  Examples (MI355X, 256 CUs): 624
+// workgroups on 512 slots: r = 112, 4 workers each, 1.25 rounds instead of 2; 156 on 512 (one clip): 3 workers each,
+// 1/3 of a round; 156 on 256: 3 workers, 2/3.
+// `single_round_only`: split only launches that do not fill the chip once.  Measured on the training step (round 4,
+// profiles/r04_attention_split_ab.txt): a workgroup alone on its CU runs almost twice as fast as one that shares it, so
+// the partly filled LAST round of a long launch costs about half a round, not a whole one — splitting it saves 3-13 %
+// of the kernel and the combine pass (10 us: the partial results are HBM traffic) takes that back; a launch of 156
+// workgroups (one clip) on 256 CUs gains 25-37 % before the combine.
+struct OmhSplitPlan { int n_regular, n_tail, splits; };
+static inline OmhSplitPlan omh_tail_split_plan(int nwg, int slots, int loop_tiles, int min_tiles, bool single_round_only = false) {
+    OmhSplitPlan pl = {nwg, 0, 1};
+    if (nwg <= 0 || slots <= 0) return pl;
+    if (single_round_only && nwg >= slots) return pl;
+    const int r = nwg % slots;
+    if (r == 0) return pl;
+    int smax = loop_tiles / min_tiles;
+    if (smax > 8) smax = 8;
+    int best_s = 1;
+    double best = 1.0;
+    for (int sp = 2; sp <= smax; ++sp) {
+        const double c = (double)((r * sp + slots - 1) / slots) / sp;
+        if (c < best - 1e-9) { best = c; best_s = sp; }
+    }
+    if (best_s < 2 || best > 0.8) return pl;
+    pl.n_tail = r;
+    pl.n_regular = nwg - r;
+    pl.splits = best_s;
+    return pl;
+}
+static inline int omh_cu_count() {                       // whole XCDs; cached
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        ncu -= ncu % 8;
+        if (ncu < 8) ncu = 256;
+    }
+    return ncu;
+}

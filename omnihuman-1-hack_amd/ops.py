@@ -10,7 +10,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (BIAS_M, BIAS_N, BIAS_NONE, EPI_BF16, EPI_F32, EPI_F32_ACCUM, EPI_GELU_BF16, EPI_GELU_BWD_BF16,
+from ._lib import (ATTN_ALLOW_SPLIT, ATTN_SHORT_KERNEL, BIAS_M, BIAS_N, BIAS_NONE, EPI_BF16, EPI_F32, EPI_F32_ACCUM, EPI_GELU_BF16, EPI_GELU_BWD_BF16,
                    EPI_GELU_ERF_BF16, EPI_RESID, AttnArgs, GemmArgs, OmhError, check, lib)
 
 __all__ = ["gemm", "flash_attn", "layernorm_modulate", "rmsnorm_rope", "cast_bf16", "patchify", "unpatchify",
@@ -101,10 +101,12 @@ def gemm_tn_grouped(problems):
 
 
 def flash_attn_raw(q, k, vt, o, k_lens, B, H, Lq, Lk, q_bs, q_rs, k_bs, k_rs, vt_bs, o_bs, o_rs, ldv, scale,
-                   lse=None, q_prescaled=0, o32=None):
+                   lse=None, q_prescaled=0, o32=None, flags=0):
+    """``flags``: ATTN_SHORT_KERNEL | ATTN_ALLOW_SPLIT (include/omh.h, ABI v8): the training step pins the short-sequence
+    kernel (forward and re-run take the same one) and lets it split its last round of workgroups over the keys."""
     a = AttnArgs(q, k, vt, o, k_lens, B, H, Lq, Lk, q_bs, q_rs, k_bs, k_rs, vt_bs, o_bs, o_rs, ldv, scale, lse,
-                 int(q_prescaled), None, 0, o32)
-    need = lib.omh_flash_attn_workspace_bytes(C.byref(a))          # split-KV tail of the long-sequence kernel
+                 int(q_prescaled), None, 0, o32, int(flags))
+    need = lib.omh_flash_attn_workspace_bytes(C.byref(a))          # split-KV tail (long-sequence kernel; short one if allowed)
     ws = None
     if need > 0:
         ws = torch.empty(need, dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()))
@@ -133,7 +135,7 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, k_lens: Optio
 
 
 def flash_attn_bwd(q, k, v, o, dout, lse, k_lens, B, H, Lq, Lk, scale=None, q_prescaled=False, out=None, o32=None,
-                   phase=0, delta=None):
+                   phase=0, delta=None, split=True):
     """Fused attention backward (include/omh.h).  q, dout: bf16 [B*Lq, H*128]; k, v: bf16 [B*Lk, H*128] (row stride
     free); lse fp32 [B, H, Lq] from ``flash_attn_raw(..., lse=)``; k_lens int32 [B] or None.
     Returns fp32 dq [B*Lq, H*128], dk, dv [B*Lk, H*128] — or, with ``out=(dq, dk, dv)`` bf16 2-D tensors (row stride
@@ -142,7 +144,8 @@ def flash_attn_bwd(q, k, v, o, dout, lse, k_lens, B, H, Lq, Lk, scale=None, q_pr
     (``flash_attn_raw(..., o32=)``, fp32 [B*Lq, H*128] contiguous) — selects the round-3 kernels (no transposed copies,
     delta from dO . o32); without it round 2's kernels run (three transposes + a delta pass over the keys).
     ``phase`` (with o32): 0 everything; 1 delta only, 2 dQ only, 3 dK / dV only — 2 and 3 read the ``delta`` tensor
-    (fp32 [B, H, Lq]) a phase-1 call filled and may run on two streams."""
+    (fp32 [B, H, Lq]) a phase-1 call filled and may run on two streams.  ``split`` (with o32): hand the kernels scratch so
+    that a partly filled last round of workgroups is split over the inner loop (include/omh.h, ABI v8)."""
     _dev(q, k, v, dout, lse, k_lens, o32)
     d = H * 128
     for t in (q, k, v, dout):
@@ -185,7 +188,12 @@ def flash_attn_bwd(q, k, v, o, dout, lse, k_lens, B, H, Lq, Lk, scale=None, q_pr
                          _p(dq), _p(dk), _p(dv), _p(k_lens), B, H, Lq, Lk,
                          Lq * rs(q), rs(q), Lk * rs(k), rs(k), Lq * rs(dout), rs(dout), Lq * dq.stride(0), dq.stride(0),
                          Lk * dk.stride(0), dk.stride(0), d * ldq, d * ldk, ldq, ldk,
-                         float(scale if scale is not None else 128 ** -0.5), int(q_prescaled), bf, _p(o32), int(phase))
+                         float(scale if scale is not None else 128 ** -0.5), int(q_prescaled), bf, _p(o32), int(phase),
+                         None, 0)
+    need = lib.omh_flash_attn_bwd_workspace_bytes(C.byref(a)) if split else 0     # partial sums of the split last round
+    if need > 0:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), need
     check(lib.omh_flash_attn_bwd_d128(C.byref(a), _stream()), "omh_flash_attn_bwd_d128")
     return dq, dk, dv
 

@@ -197,6 +197,10 @@ _ATTN_BWD2 = os.environ.get("OMH_ATTN_BWD", "v2") != "v1"
 # fills most of those gaps), 43.6 -> 44.0 at 1 clip — hence only when a kernel has more than one round of workgroups.
 # OMH_ATTN_BWD_SPLIT=0 / 1 forces it off / on.
 _ATTN_SPLIT = os.environ.get("OMH_ATTN_BWD_SPLIT", "auto")
+# Every attention launch of the training forward — kept activations, the forward under use_checkpoint and its re-run in
+# the backward alike — takes the short-sequence kernel (the choice must not depend on whether lse / o32
+# are requested) and may split its last round of workgroups over the keys (4 clips: 624 workgroups on 512 slots).
+_ATTN_FLAGS = ops.ATTN_SHORT_KERNEL | ops.ATTN_ALLOW_SPLIT
 _side = {}
 _side2 = {}
 # OMH_BLOCK_DX_COPY=1: never update an incoming block gradient in place (debugging aid for callers with extra taps)
@@ -437,7 +441,7 @@ def _block_forward(model, blk, idx, st, x0, P, keep, need=True):
     o32_sa = f32(R, d) if (_ATTN_BWD2 and need) else None     # the output before its rounding: delta of the backward
     ops.flash_attn_raw(ptr(q), ptr(k), ptr(vt), ptr(o), ptr(fc.seq_lens32), B, N, Sq, Sq, Sq * d, d, Sq * d, d, d * Sp,
                        Sq * d, d, Sp, D ** -0.5, lse=ptr(lse_sa) if need else None, q_prescaled=1,
-                       o32=ptr(o32_sa) if o32_sa is not None else None)
+                       o32=ptr(o32_sa) if o32_sa is not None else None, flags=_ATTN_FLAGS)
     x1, y1 = resid(x0, o, P["wo"], sa.o.bias.detach(), 2, True)
     S.update(h1=h1, qk=qk, q=q, k=k, vt=vt, o=o, lse_sa=lse_sa, y1=y1, x1=x1, o32_sa=o32_sa)
     # ---- cross-attention: x2 = x1 + o(attn(norm3(x1), context))                                     model.py:313
@@ -475,7 +479,7 @@ def _block_forward(model, blk, idx, st, x0, P, keep, need=True):
     # the reference passes the (text + 257) lengths here (model.py:223,537); keys are clipped to the text rows
     ops.flash_attn_raw(ptr(qc), ptr(kc), ptr(vtc), ptr(oc), ptr(fc.ctx_lens32), B, N, Sq, Lt, Sq * d, d, Lt * d, d,
                        d * Ltp, Sq * d, d, Ltp, D ** -0.5, lse=ptr(lse_ca) if need else None,
-                       o32=ptr(o32_ca) if o32_ca is not None else None)
+                       o32=ptr(o32_ca) if o32_ca is not None else None, flags=_ATTN_FLAGS)
     x2, _ = resid(x1, oc, P["wo_c"], ca.o.bias.detach(), None, False)
     S.update(h3=h3, qcb=qcb, qc=qc, kf=kf, kc=kc, vtc=vtc, oc=oc, lse_ca=lse_ca, x2=x2, o32_ca=o32_ca)
     if i2v:                                                  # model.py:189-230: extra attention over the 257 image tokens
@@ -483,7 +487,7 @@ def _block_forward(model, blk, idx, st, x0, P, keep, need=True):
         oi = bf(R, d)
         lse_ci = f32(B, N, Sq) if need else None
         ops.flash_attn_raw(ptr(qc), ptr(ki), ptr(vti), ptr(oi), None, B, N, Sq, n_img, Sq * d, d, n_img * d, d, d * Lip,
-                           Sq * d, d, Lip, D ** -0.5, lse=ptr(lse_ci) if need else None)
+                           Sq * d, d, Lip, D ** -0.5, lse=ptr(lse_ci) if need else None, flags=_ATTN_FLAGS)
         resid(x2, oi, P["wo_c"], None, None, False, xout=x2)          # x2 += o_img Wo^T   (in place)
         S.update(kfi=kfi, ki=ki, vti=vti, oi=oi, lse_ci=lse_ci)
     # ---- FFN: x3 = x2 + (W2 gelu(W1 (LN(x2)(1+e4)+e3) + b1) + b2) * e5                               model.py:314-328

@@ -468,6 +468,94 @@ def test_attention_backward_prescaled_q_and_bf16_outputs(ops):
         assert e < 1.2e-2, (nm, e)          # bf16 rounding of the output + the 2^-9 perturbation of q between the two
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,lens", [(4, 12, 1560, 1560, None), (1, 12, 1560, 1560, None),
+                                            (4, 12, 1560, 512, [512, 40, 0, 300]), (1, 12, 1560, 512, [120])])
+def test_attention_tail_split_matches_the_unsplit_launch(ops, monkeypatch, B, H, Lq, Lk, lens):
+    """ABI v8: the last, partly filled round of workgroups of the short-sequence forward (OMH_ATTN_ALLOW_SPLIT) and of
+    the dQ / dK-dV kernels (omh_attn_bwd_args.workspace) is split over the inner loop, the workers' fp32 partial results
+    combined in a fixed order.  At the training step's real shapes (4 clips x 12 heads x 1560 tokens: 624 workgroups on
+    512 slots; 1 clip: 156, everything split; the cross-attention with ragged key lengths): rows outside the split
+    tiles equal the unsplit launch bit for bit, the split rows to fp32-association / one-bf16-ulp noise, repeatably."""
+    torch.manual_seed(B * 7 + Lk)
+    D = 128
+    d = H * D
+    scale = D ** -0.5
+    q = (torch.randn(B * Lq, d, device="cuda") * (scale * 1.4426950408889634)).bfloat16()
+    k = torch.randn(B * Lk, d, device="cuda").bfloat16()
+    v = torch.randn(B * Lk, d, device="cuda").bfloat16()
+    do = torch.randn(B * Lq, d, device="cuda").bfloat16()
+    klens = None if lens is None else torch.tensor(lens, dtype=torch.int32, device="cuda")
+    Lp = (Lk + 63) // 64 * 64
+    vt = torch.zeros(B, d, Lp, device="cuda", dtype=torch.bfloat16)
+    ops.transpose_bf16_raw(ops.ptr(v), ops.ptr(vt), Lk, d, d, Lp, batch=B, bs_in=Lk * d, bs_out=d * Lp)
+
+    def fwd(flags):
+        o = torch.empty(B * Lq, d, device="cuda", dtype=torch.bfloat16)
+        o32 = torch.empty(B * Lq, d, device="cuda")
+        lse = torch.empty(B, H, Lq, device="cuda")
+        ops.flash_attn_raw(ops.ptr(q), ops.ptr(k), ops.ptr(vt), ops.ptr(o), None if klens is None else ops.ptr(klens), B, H,
+                           Lq, Lk, Lq * d, d, Lk * d, d, d * Lp, Lq * d, d, Lp, scale, lse=ops.ptr(lse), q_prescaled=1,
+                           o32=ops.ptr(o32), flags=flags)
+        return o, o32, lse
+    # OMH_ATTN_SPLIT=tail: split the last round of ANY launch with >= 4 tiles per worker (the shipped policy splits only
+    # launches that do not fill the chip once, and the forward only on long key loops: profiles/r04_attention_split_ab.txt)
+    monkeypatch.setenv("OMH_ATTN_SPLIT", "tail")
+    o0, o320, lse0 = fwd(ops.ATTN_SHORT_KERNEL)
+    o1, o321, lse1 = fwd(ops.ATTN_SHORT_KERNEL | ops.ATTN_ALLOW_SPLIT)
+    o2, o322, lse2 = fwd(ops.ATTN_SHORT_KERNEL | ops.ATTN_ALLOW_SPLIT)
+    assert torch.equal(o1, o2) and torch.equal(o321, o322) and torch.equal(lse1, lse2)           # repeatable
+    assert torch.equal(o321.bfloat16(), o1)
+    same_rows = (o321 == o320).view(B, Lq, H, D).all(-1)                                          # [B, Lq, H]
+    frac_same = float(same_rows.float().mean())
+    nwg = ((Lq + 127) // 128) * H * B
+    if nwg % 512 == nwg:                                                # everything in the last round: every tile is split
+        assert frac_same < 0.5
+    else:
+        assert frac_same > 0.5 and frac_same < 1.0                       # the full rounds are untouched, the tail did change
+    live = torch.isfinite(lse0)
+    assert torch.equal(torch.isfinite(lse1), live)
+    assert rel_rms(o321, o320) < 2e-3 and float((lse1[live] - lse0[live]).abs().max()) < 1e-4
+    monkeypatch.setenv("OMH_ATTN_SPLIT", "0")
+    o3, o323, lse3 = fwd(ops.ATTN_SHORT_KERNEL | ops.ATTN_ALLOW_SPLIT)
+    assert torch.equal(o323, o320) and torch.equal(lse3, lse0)                                     # the override: no split
+    # ---- backward on the unsplit forward's tensors: split (default) vs OMH_ATTN_SPLIT=0
+    kw = dict(q_prescaled=True, o32=o320)
+    ref = ops.flash_attn_bwd(q, k, v, None, do, lse0, klens, B, H, Lq, Lk, scale, **kw)
+    monkeypatch.setenv("OMH_ATTN_SPLIT", "tail")
+    got = ops.flash_attn_bwd(q, k, v, None, do, lse0, klens, B, H, Lq, Lk, scale, **kw)
+    again = ops.flash_attn_bwd(q, k, v, None, do, lse0, klens, B, H, Lq, Lk, scale, **kw)
+    nosplit = ops.flash_attn_bwd(q, k, v, None, do, lse0, klens, B, H, Lq, Lk, scale, split=False, **kw)
+    for g, r, a, n, nm in zip(got, ref, again, nosplit, ("dq", "dk", "dv")):
+        assert torch.equal(g, a), nm                                     # fixed-order combine: bit-repeatable
+        assert torch.equal(n, r), nm
+        assert bool(torch.isfinite(g).all()) and rel_rms(g, r) < 1e-5, (nm, rel_rms(g, r))
+        assert not torch.equal(g, r), nm                                 # the split path did run
+    # the phases (two streams in the training step) and bf16 column-block outputs: the same bits as the single call
+    delta = torch.empty(B, H, Lq, device="cuda")
+    ph = dict(delta=delta, **kw)
+    ops.flash_attn_bwd(q, k, v, None, do, lse0, klens, B, H, Lq, Lk, scale, phase=1, **ph)
+    dq3, _, _ = ops.flash_attn_bwd(q, k, v, None, do, lse0, klens, B, H, Lq, Lk, scale, phase=2, **ph)
+    _, dk3, dv3 = ops.flash_attn_bwd(q, k, v, None, do, lse0, klens, B, H, Lq, Lk, scale, phase=3, **ph)
+    assert torch.equal(dq3, got[0]) and torch.equal(dk3, got[1]) and torch.equal(dv3, got[2])
+    buf = torch.full((B * Lq, 3 * d), 3.0, device="cuda", dtype=torch.bfloat16)
+    kvb = torch.full((B * Lk, 2 * d), 3.0, device="cuda", dtype=torch.bfloat16)
+    ops.flash_attn_bwd(q, k, v, None, do, lse0, klens, B, H, Lq, Lk, scale, out=(buf[:, d:2 * d], kvb[:, :d], kvb[:, d:]), **kw)
+    assert torch.equal(buf[:, d:2 * d], got[0].bfloat16()) and torch.equal(kvb[:, :d], got[1].bfloat16())
+    assert torch.equal(kvb[:, d:], got[2].bfloat16()) and bool((buf[:, :d] == 3.0).all()) and bool((buf[:, 2 * d:] == 3.0).all())
+    # the shipped policy: one clip (a launch that does not fill the chip) splits dQ and dK / dV, four clips do not
+    monkeypatch.delenv("OMH_ATTN_SPLIT")
+    dflt = ops.flash_attn_bwd(q, k, v, None, do, lse0, klens, B, H, Lq, Lk, scale, **kw)
+    for g, r, t_, nm in zip(dflt, ref, got, ("dq", "dk", "dv")):
+        if B == 1:
+            assert torch.equal(g, t_), nm
+        elif nm == "dq" or Lk == Lq:
+            assert torch.equal(g, r), nm                                 # 624 workgroups: more than one round
+        else:
+            assert torch.equal(g, t_), nm                                # cross-attention dK / dV: 192 workgroups on 256 CUs
+    od, _, lsed = fwd(ops.ATTN_SHORT_KERNEL | ops.ATTN_ALLOW_SPLIT)
+    assert torch.equal(od, o0) and torch.equal(lsed, lse0)               # 25 / 8 key tiles: the forward is not split
+
+
 @pytest.mark.parametrize("B,H,Lq,Lk,lens", [(2, 2, 200, 136, [136, 77]), (1, 3, 1560, 1560, [1560]), (3, 1, 130, 512, [512, 0, 300]),
                                             (2, 2, 64, 64, [64, 33]), (1, 1, 257, 70, [70])])
 def test_attention_backward_round3_kernels(ops, B, H, Lq, Lk, lens):
