@@ -246,7 +246,7 @@ def vae_cpu_baseline(device):
     from oracle import wan_vae_oracle as V
     vae_mod = importlib.import_module(PKG + ".wan.modules.vae")
     torch.manual_seed(4321)
-    vae = vae_mod.WanVAE(vae_pth=None, device=device)
+    vae = vae_mod.WanVAE(vae_pth=None, dtype=torch.bfloat16, device=device)
     sd = {k: v.detach().float().cpu() for k, v in vae.model.state_dict().items()}
     cfg = V.VAEConfig(dim=96)
     z = torch.randn(16, 2, 30, 52, generator=torch.Generator().manual_seed(5))
@@ -843,6 +843,12 @@ def main():
         try:
             vae_bench = importlib.import_module(PKG + ".wan.modules.vae").bench_decode
             vae = vae_bench(x, device, iters=3, telemetry=Telemetry(local_rank))
+            # the same clip through WanVAE(dtype=torch.float): the reference's own arithmetic class (its VAE computes in
+            # fp32, vae.py:619-624,649-663), here split-bf16 operand pairs = 3 MFMA products per tile
+            try:
+                vae["fp32_mode"] = vae_bench(x, device, iters=1, dtype=torch.float32)
+            except Exception as e:
+                vae["fp32_mode"] = {"frames_per_s": None, "error": repr(e)[:200]}
         except (ImportError, AttributeError, NotImplementedError) as e:
             vae = {"frames_per_s": None, "note": f"VAE path not built: {e}"}
 

@@ -377,6 +377,25 @@ int omh_cl_to_nchw(const float* x, float* y, int32_t C, int32_t T, int32_t H, in
                    const float* mul, const float* add, float lo, float hi, int32_t t_total, int32_t t0,
                    omh_stream_t stream);
 
+/* ---- ABI v8: the fp32-faithful VAE mode (the reference computes its VAE in fp32: WanVAE(dtype=torch.float) ->
+ * amp.autocast(dtype=self.dtype), vae.py:619-624,649-663).  Every convolution / GEMM operand is carried as a bf16
+ * PAIR hi = bf16(x), lo = bf16(x - hi) (x = hi + lo to 2^-17), laid out as three channel blocks so that the UNCHANGED
+ * bf16 MFMA kernels compute an fp32-class product as a contraction three times as long:
+ *   activations  [hi | lo | hi]   (pattern 0)        weights  [hi | hi | lo]   (pattern 1)
+ *   sum over the 3 Cp channels = x_hi w_hi + x_lo w_hi + x_hi w_lo = x w - x_lo w_lo      (fp32 accumulate)
+ * omh_split3_f32: x fp32 [rows, C] (pitch ldx) -> y bf16 [rows, 3 Cp] (pitch ldy >= 3 Cp), channels C..Cp-1 zero;
+ *   Cp % 4 == 0.  omh_rms_silu_cl_split3: omh_rms_silu_cl_f32in with a pattern-0 result [P, 3 C] (IEEE exp /
+ *   division).  omh_nchw_to_cl_f32 / omh_softmax_rows_f32: the boundary convert and the row softmax with fp32 results
+ *   (then omh_split3_f32). */
+int omh_split3_f32(const float* x, int64_t ldx, void* y_bf16, int64_t ldy, int64_t rows, int32_t C, int32_t Cp,
+                   int32_t pattern, omh_stream_t stream);
+int omh_rms_silu_cl_split3(const float* x_f32, const float* gamma, void* y_bf16x3, int64_t P, int32_t C,
+                           int32_t do_silu, omh_stream_t stream);
+int omh_nchw_to_cl_f32(const float* x, float* y, int32_t C, int32_t T, int32_t H, int32_t W, int32_t Cp,
+                       const float* mul, const float* add, int32_t t_total, int32_t t0, omh_stream_t stream);
+int omh_softmax_rows_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t R, int32_t L, float scale,
+                         omh_stream_t stream);
+
 /* Row softmax for the VAE's single-head mid-block attention (vae.py:252):
  *   y[r][j] = bf16( softmax_j( x[r][j] * scale ) ), x fp32 [R, L] (ldx), y bf16 (ldy). */
 int omh_softmax_rows(const float* x, int64_t ldx, void* y_bf16, int64_t ldy, int64_t R, int32_t L, float scale,

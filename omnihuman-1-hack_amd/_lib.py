@@ -171,6 +171,10 @@ _SIGS = {
     "omh_nchw_to_cl": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp]),
     "omh_cl_to_nchw": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, f32, f32, i32, i32, vp]),
     "omh_softmax_rows": (i32, [vp, i64, vp, i64, i64, i32, f32, vp]),
+    "omh_softmax_rows_f32": (i32, [vp, i64, vp, i64, i64, i32, f32, vp]),
+    "omh_split3_f32": (i32, [vp, i64, vp, i64, i64, i32, i32, i32, vp]),
+    "omh_rms_silu_cl_split3": (i32, [vp, vp, vp, i64, i32, i32, vp]),
+    "omh_nchw_to_cl_f32": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp]),
     "omh_transpose_bf16": (i32, [vp, vp, i32, i32, i64, i64, i32, i64, i64, vp]),
     "omh_colsum_accum": (i32, [vp, i32, i64, vp, i64, i32, vp]),
     "omh_colsum_accum_multi": (i32, [vp, vp]),

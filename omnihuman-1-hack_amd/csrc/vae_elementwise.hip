@@ -10,7 +10,10 @@ namespace {
 // gamma sits in registers: round 2 fetched it with 8 scalar-width loads per chunk and voxel — 24 of the 30 vector
 // memory instructions of a C = 96 voxel, which is what bounded the kernel (2.6 - 3.1 TB/s at 480x832).  Same
 // arithmetic in the same order as before: the values do not move.
-template <int G, bool XF32>
+// OUT3 (the fp32-faithful VAE mode, omh_rms_silu_cl_split3): the result is not rounded once but written as a bf16 pair
+// hi = bf16(v), lo = bf16(v - hi) in three blocks of C channels [hi | lo | hi] per voxel — the split-bf16 operand layout
+// of omh_split3_f32.
+template <int G, bool XF32, bool OUT3 = false>
 __global__ __launch_bounds__(256)
 void rms_silu_kernel(const void* __restrict__ xv, const float* __restrict__ gamma, uint16_t* __restrict__ y,
                      int64_t P, int C, int do_silu) {
@@ -59,20 +62,34 @@ void rms_silu_kernel(const void* __restrict__ xv, const float* __restrict__ gamm
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
     // sqrt(C) / max(||x||, 1e-12) on the raw v_sqrt_f32 / v_rcp_f32 (1 ulp each; the result is rounded to bf16)
-    const float inv = sqrtf_c * __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(ss), 1e-12f));
+    const float inv = OUT3 ? sqrtf_c / fmaxf(sqrtf(ss), 1e-12f)
+                           : sqrtf_c * __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(ss), 1e-12f));
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const int c = lane_g + G * i;
         if (c < nch) {
-            uint32_t o[4];
+            uint32_t o[4], ol[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float a = (v[i][2 * e] * inv) * gm[i][2 * e];
                 float b = (v[i][2 * e + 1] * inv) * gm[i][2 * e + 1];
-                if (do_silu) { a = silu(a); b = silu(b); }
+                if (do_silu) {
+                    if (OUT3) {                                   // IEEE exp / division: the fast forms are 1-ulp class
+                        a = a / (1.0f + expf(-a));
+                        b = b / (1.0f + expf(-b));
+                    } else { a = silu(a); b = silu(b); }
+                }
                 o[e] = pack_bf2(a, b);
+                if (OUT3) ol[e] = pack_bf2(a - __uint_as_float(o[e] << 16), b - __uint_as_float(o[e] & 0xffff0000u));
             }
-            *(uint4*)(y + p * C + c * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+            if (OUT3) {
+                uint16_t* yo = y + p * 3 * C + c * 8;
+                *(uint4*)yo = make_uint4(o[0], o[1], o[2], o[3]);
+                *(uint4*)(yo + C) = make_uint4(ol[0], ol[1], ol[2], ol[3]);
+                *(uint4*)(yo + 2 * C) = make_uint4(o[0], o[1], o[2], o[3]);
+            } else {
+                *(uint4*)(y + p * C + c * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
         }
     }
     }
@@ -142,6 +159,84 @@ void softmax_rows_kernel(const float* __restrict__ x, int64_t ldx, uint16_t* __r
     for (int j = tid; j < L; j += 256) yr[j] = f2bf(exp2f((xr[j] - mx) * sc) * inv);
 }
 
+// fp32 [rows, C] (row pitch ldx) -> split-bf16 operand [rows, 3 Cp] (row pitch ldy): with hi = bf16(x), lo = bf16(x - hi)
+// (x = hi + lo to 2^-17 relative), pattern 0 writes the channel blocks [hi | lo | hi], pattern 1 [hi | hi | lo]; pad
+// channels C..Cp-1 are zero.  A product over 3 Cp channels of a pattern-0 row with a pattern-1 row is
+// x_hi w_hi + x_lo w_hi + x_hi w_lo = x w - x_lo w_lo: an fp32-class product on the bf16 MFMA path (three products per
+// tile, fp32 accumulate).  One thread per 4 channels.
+__global__ __launch_bounds__(256)
+void split3_kernel(const float* __restrict__ x, int64_t ldx, uint16_t* __restrict__ y, int64_t ldy, int64_t rows,
+                   int C, int Cp, int pattern) {
+    const int q = Cp >> 2;                                           // 4-channel groups per row
+    const int64_t total = rows * q;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const bool vec = (C & 3) == 0 && (ldx & 3) == 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t r = i / q;
+        const int c = (int)(i - r * q) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* xr = x + r * ldx + c;
+        if (vec && c + 3 < C) { const float4 t = *(const float4*)xr; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (c + e < C) v[e] = xr[e];
+        }
+        const uint32_t h0 = pack_bf2(v[0], v[1]), h1 = pack_bf2(v[2], v[3]);
+        const uint32_t l0 = pack_bf2(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u));
+        const uint32_t l1 = pack_bf2(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u));
+        uint16_t* yr = y + r * ldy + c;
+        const uint2 hi = make_uint2(h0, h1), lo = make_uint2(l0, l1);
+        *(uint2*)yr = hi;
+        *(uint2*)(yr + Cp) = pattern == 0 ? lo : hi;
+        *(uint2*)(yr + 2 * Cp) = pattern == 0 ? hi : lo;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void nchw_to_cl_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int T, int H, int W, int Cp,
+                           const float* __restrict__ mul, const float* __restrict__ add, int t_total, int t0) {
+    const int64_t vox = (int64_t)T * H * W;
+    const int64_t total = vox * Cp;
+    const int64_t cstride = (int64_t)t_total * H * W, toff = (int64_t)t0 * H * W;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % Cp);
+        const int64_t v = i / Cp;
+        float val = 0.f;
+        if (c < C) {
+            val = x[(int64_t)c * cstride + toff + v];
+            if (mul) val *= mul[c];
+            if (add) val += add[c];
+        }
+        y[i] = val;
+    }
+}
+
+// row softmax with an fp32 result (the fp32-faithful VAE mode): IEEE exp and division
+__global__ __launch_bounds__(256)
+void softmax_rows_f32_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy, int L,
+                             float scale) {
+    __shared__ float red[8];
+    const int64_t r = blockIdx.x;
+    const float* xr = x + r * ldx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float mx = -INFINITY;
+    for (int j = tid; j < L; j += 256) mx = fmaxf(mx, xr[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float s = 0.f;
+    for (int j = tid; j < L; j += 256) s += expf((xr[j] - mx) * scale);
+    s = wave_sum(s);
+    if (lane == 0) red[4 + wave] = s;
+    __syncthreads();
+    const float tot = red[4] + red[5] + red[6] + red[7];
+    float* yr = y + r * ldy;
+    for (int j = tid; j < L; j += 256) yr[j] = expf((xr[j] - mx) * scale) / tot;
+}
+
 inline int grid_for(int64_t n, int per_block) {
     int64_t g = (n + per_block - 1) / per_block;
     return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -209,7 +304,7 @@ static unsigned rms_grid(int64_t P, int G) {
     return (unsigned)(need < 2048 ? need : 2048);
 }
 
-template <bool XF32>
+template <bool XF32, bool OUT3 = false>
 static int rms_silu_launch(const void* x, const float* gamma, void* y, int64_t P, int32_t C, int32_t do_silu,
                            omh_stream_t stream) {
     if (!x || !gamma || !y || P <= 0 || C <= 0) return OMH_E_BADARG;
@@ -220,13 +315,13 @@ static int rms_silu_launch(const void* x, const float* gamma, void* y, int64_t P
     omh_clear_status();
     // lanes per voxel: enough that each lane holds <= 4 chunks, rounded to a power of two
     if (nch <= 16) {
-        hipLaunchKernelGGL((rms_silu_kernel<4, XF32>), dim3(rms_grid(P, 4)), dim3(256), 0, s,
+        hipLaunchKernelGGL((rms_silu_kernel<4, XF32, OUT3>), dim3(rms_grid(P, 4)), dim3(256), 0, s,
                            x, gamma, (uint16_t*)y, P, C, do_silu);
     } else if (nch <= 64) {
-        hipLaunchKernelGGL((rms_silu_kernel<16, XF32>), dim3(rms_grid(P, 16)), dim3(256), 0, s,
+        hipLaunchKernelGGL((rms_silu_kernel<16, XF32, OUT3>), dim3(rms_grid(P, 16)), dim3(256), 0, s,
                            x, gamma, (uint16_t*)y, P, C, do_silu);
     } else {
-        hipLaunchKernelGGL((rms_silu_kernel<64, XF32>), dim3(rms_grid(P, 64)), dim3(256), 0, s,
+        hipLaunchKernelGGL((rms_silu_kernel<64, XF32, OUT3>), dim3(rms_grid(P, 64)), dim3(256), 0, s,
                            x, gamma, (uint16_t*)y, P, C, do_silu);
     }
     return omh_launch_status();
@@ -240,6 +335,42 @@ extern "C" int omh_rms_silu_cl(const void* x, const float* gamma, void* y, int64
 extern "C" int omh_rms_silu_cl_f32in(const float* x, const float* gamma, void* y, int64_t P, int32_t C,
                                      int32_t do_silu, omh_stream_t stream) {
     return rms_silu_launch<true>(x, gamma, y, P, C, do_silu, stream);
+}
+
+extern "C" int omh_rms_silu_cl_split3(const float* x, const float* gamma, void* y, int64_t P, int32_t C,
+                                      int32_t do_silu, omh_stream_t stream) {
+    return rms_silu_launch<true, true>(x, gamma, y, P, C, do_silu, stream);
+}
+
+extern "C" int omh_split3_f32(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t C, int32_t Cp,
+                              int32_t pattern, omh_stream_t stream) {
+    if (!x || !y || rows <= 0 || C <= 0 || Cp < C || (pattern != 0 && pattern != 1)) return OMH_E_BADARG;
+    if ((Cp & 3) || (ldy & 3) || ldy < 3 * (int64_t)Cp || ldx < C) return OMH_E_SHAPE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return OMH_E_ALIGN;
+    omh_clear_status();
+    hipLaunchKernelGGL(split3_kernel, dim3(grid_for(rows * (Cp / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       (uint16_t*)y, ldy, rows, C, Cp, pattern);
+    return omh_launch_status();
+}
+
+extern "C" int omh_nchw_to_cl_f32(const float* x, float* y, int32_t C, int32_t T, int32_t H, int32_t W, int32_t Cp,
+                                  const float* mul, const float* add, int32_t t_total, int32_t t0, omh_stream_t stream) {
+    if (!x || !y || C <= 0 || T <= 0 || H <= 0 || W <= 0 || Cp < C || t0 < 0 || t0 + T > t_total)
+        return OMH_E_BADARG;
+    const int64_t total = (int64_t)T * H * W * Cp;
+    omh_clear_status();
+    hipLaunchKernelGGL(nchw_to_cl_f32_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, C, T,
+                       H, W, Cp, mul, add, t_total, t0);
+    return omh_launch_status();
+}
+
+extern "C" int omh_softmax_rows_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t R, int32_t L,
+                                    float scale, omh_stream_t stream) {
+    if (!x || !y || R <= 0 || L <= 0 || R > 0x7fffffff) return OMH_E_BADARG;
+    omh_clear_status();
+    hipLaunchKernelGGL(softmax_rows_f32_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, L,
+                       scale);
+    return omh_launch_status();
 }
 
 extern "C" int omh_nchw_to_cl(const float* x, void* y, int32_t C, int32_t T, int32_t H, int32_t W, int32_t Cp,

@@ -353,6 +353,59 @@ def rms_silu_cl(x, gamma, out=None, do_silu=True):
     return out
 
 
+# ---- the fp32-faithful VAE mode (include/omh.h, ABI v8): operands as bf16 pairs in three channel blocks
+def split3(x: torch.Tensor, pattern: int, Cp: Optional[int] = None, out=None):
+    """x fp32 [..., C] (last dim contiguous, rows contiguous or a 2-D view with a row pitch) -> bf16 [..., 3 Cp] with
+    hi = bf16(x), lo = bf16(x - hi): pattern 0 = [hi | lo | hi] (activations), 1 = [hi | hi | lo] (weights)."""
+    _dev(x, out)
+    assert x.dtype == torch.float32 and x.stride(-1) == 1
+    Cc = x.shape[-1]
+    Cp = Cp or (Cc + 7) // 8 * 8
+    if x.dim() == 2:
+        rows, ldx = x.shape[0], x.stride(0)
+    else:
+        assert x.is_contiguous()
+        rows, ldx = x.numel() // Cc, Cc
+    if out is None:
+        out = torch.empty(*x.shape[:-1], 3 * Cp, dtype=torch.bfloat16, device=x.device)
+    assert out.dtype == torch.bfloat16 and out.shape[-1] == 3 * Cp and out.numel() == rows * 3 * Cp and out.is_contiguous()
+    check(lib.omh_split3_f32(_p(x), ldx, _p(out), 3 * Cp, rows, Cc, Cp, int(pattern), _stream()), "omh_split3_f32")
+    return out
+
+
+def rms_silu_cl_split3(x, gamma, out=None, do_silu=True):
+    """x fp32 [..., C] -> pattern-0 bf16 [..., 3 C]: RMS norm (* gamma), SiLU, split."""
+    _dev(x, gamma, out)
+    assert x.dtype == torch.float32 and x.is_contiguous() and gamma.dtype == torch.float32
+    Cc = x.shape[-1]
+    if out is None:
+        out = torch.empty(*x.shape[:-1], 3 * Cc, dtype=torch.bfloat16, device=x.device)
+    assert out.is_contiguous() and out.dtype == torch.bfloat16 and out.shape[-1] == 3 * Cc
+    check(lib.omh_rms_silu_cl_split3(_p(x), _p(gamma), _p(out), x.numel() // Cc, Cc, int(do_silu), _stream()),
+          "omh_rms_silu_cl_split3")
+    return out
+
+
+def nchw_to_cl_f32(x, T, t0, Cp, mul=None, add=None):
+    """x fp32 [C, Ttot, H, W] frames [t0, t0+T) -> fp32 [T, H, W, Cp]."""
+    _dev(x, mul, add)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    Cc, Ttot, H, W = x.shape
+    out = torch.empty(T, H, W, Cp, dtype=torch.float32, device=x.device)
+    check(lib.omh_nchw_to_cl_f32(_p(x), _p(out), Cc, T, H, W, Cp, _p(mul), _p(add), Ttot, t0, _stream()),
+          "omh_nchw_to_cl_f32")
+    return out
+
+
+def softmax_rows_f32(x, out, L, scale):
+    """x fp32 [R, >=L] -> out fp32 [R, >=L] (first L columns), row softmax of x*scale."""
+    _dev(x, out)
+    assert x.dtype == torch.float32 and out.dtype == torch.float32 and x.stride(1) == 1 and out.stride(1) == 1
+    check(lib.omh_softmax_rows_f32(_p(x), x.stride(0), _p(out), out.stride(0), x.shape[0], L, scale, _stream()),
+          "omh_softmax_rows_f32")
+    return out
+
+
 def relu_bf16_(x):
     """In-place ReLU on a contiguous bf16 tensor (numel % 8 == 0)."""
     _dev(x)

@@ -189,16 +189,25 @@ def _round_up(a, b):
 class _ConvState:
     """Packed weight + temporal-history input buffer of one convolution."""
 
-    def __init__(self, conv, up2=False, stride_hw=1, pad=None):
+    def __init__(self, conv, up2=False, stride_hw=1, pad=None, f32=False):
         w = conv.weight.detach()
         if w.dim() == 4:                      # Conv2d -> [Cout, Cin, 1, kh, kw]
             w = w.unsqueeze(2)
         self.Cout, self.Cin_raw, self.KT, self.KH, self.KW = w.shape
-        self.Cin = _round_up(self.Cin_raw, 8)
+        self.f32 = bool(f32)
+        cp = _round_up(self.Cin_raw, 8)
         wp = w.float().permute(0, 2, 3, 4, 1)                       # [Cout, kt, kh, kw, Cin]
-        if self.Cin != self.Cin_raw:
-            wp = torch.nn.functional.pad(wp, (0, self.Cin - self.Cin_raw))
-        self.w = ops.cast_bf16(wp.contiguous().view(self.Cout, -1))
+        if self.f32:
+            # fp32-faithful mode: the weight as a bf16 pair per channel, blocks [hi | hi | lo] per tap (pattern 1 of
+            # omh_split3_f32) against activations [hi | lo | hi]: the same kernels on a contraction 3x as long
+            self.Cin = 3 * cp
+            taps = self.KT * self.KH * self.KW
+            self.w = ops.split3(wp.contiguous().view(self.Cout * taps, self.Cin_raw), 1, Cp=cp).view(self.Cout, -1)
+        else:
+            self.Cin = cp
+            if self.Cin != self.Cin_raw:
+                wp = torch.nn.functional.pad(wp, (0, self.Cin - self.Cin_raw))
+            self.w = ops.cast_bf16(wp.contiguous().view(self.Cout, -1))
         self.bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
         st = conv.stride if isinstance(conv.stride, tuple) else (conv.stride,) * 3
         self.stride_t = st[0] if len(st) == 3 else 1
@@ -246,7 +255,7 @@ class _ConvState:
 
     def set_history(self, frame):
         """Overwrite the (single) history frame — the encoder's first-chunk bypass of a strided time conv."""
-        self.buf[self.off].copy_(frame)
+        _fill(self.buf[self.off:self.off + 1], frame.unsqueeze(0))
 
     def run(self, resid=None, out_f32=False, split_n=0, out=None, norm_gamma=None, norm_out=None, norm_only=False):
         """Convolve over [history | chunk]; the last ``hist`` frames of that region become the new history.
@@ -274,16 +283,27 @@ class _ConvState:
 class _Stream:
     """All per-call state of one encode or decode (the reference's _feat_map)."""
 
-    def __init__(self, device):
+    def __init__(self, device, f32=False):
         self.device = device
         self.convs = {}
         self.seen = set()
+        # fp32-faithful mode (WanVAE(dtype=torch.float), the reference's default: vae.py:619-624,649-663): every tensor
+        # between kernels is fp32, every MFMA operand a bf16 pair (omh_split3_f32) — three products per tile, fp32
+        # accumulate; no fused norm epilogues (their output is a single bf16)
+        self.f32 = bool(f32)
+        self.trunk_f32 = _TRUNK_F32 or self.f32
 
     def conv(self, key, module, **kw):
         st = self.convs.get(key)
         if st is None:
-            st = self.convs[key] = _ConvState(module, **kw)
+            st = self.convs[key] = _ConvState(module, f32=self.f32, **kw)
         return st
+
+    def norm(self, x, gamma, out, do_silu=True):
+        """RMS norm (+ SiLU) of trunk tensor x into a convolution's input slot."""
+        if self.f32:
+            return ops.rms_silu_cl_split3(x, gamma, out=out, do_silu=do_silu)
+        return ops.rms_silu_cl(x, gamma, out=out, do_silu=do_silu)
 
 
 def _gamma(norm: RMS_norm):
@@ -303,8 +323,11 @@ _GROUP2 = max(1, int(os.environ.get("OMH_VAE_GROUP2", "2")))
 
 
 def _fill(slot, x):
-    """Write trunk tensor x into a convolution's bf16 input slot."""
-    if x.dtype == torch.float32 and x.shape[-1] == slot.shape[-1]:
+    """Write trunk tensor x into a convolution's bf16 input slot (a split-bf16 slot, three channel blocks, in the
+    fp32-faithful mode)."""
+    if x.dtype == torch.float32 and slot.shape[-1] == 3 * _round_up(x.shape[-1], 8):
+        ops.split3(x.contiguous(), 0, Cp=slot.shape[-1] // 3, out=slot)
+    elif x.dtype == torch.float32 and x.shape[-1] == slot.shape[-1]:
         ops.cast_bf16(x.contiguous(), out=slot)
     else:
         slot.copy_(x)
@@ -332,26 +355,30 @@ def _res_block(st, key, blk: ResidualBlock, x, pre=False, nxt=None):
     T, H, W, _ = x.shape
     dev = x.device
     h = x
+    tf = st.trunk_f32
+    fuse = _FUSE_NORM and not st.f32
     if not isinstance(blk.shortcut, nn.Identity):
-        h = _conv_on(st, key + ".shortcut", blk.shortcut, x, out_f32=_TRUNK_F32)
+        h = _conv_on(st, key + ".shortcut", blk.shortcut, x, out_f32=tf)
     ca = st.conv(key + ".residual.2", blk.residual[2])
     if not pre:
-        ops.rms_silu_cl(x, _gamma(blk.residual[0]), out=ca.slot(T, H, W, dev))
+        st.norm(x, _gamma(blk.residual[0]), ca.slot(T, H, W, dev))
     cb = st.conv(key + ".residual.6", blk.residual[6])
-    if _FUSE_NORM and ca.Cout == 96:                 # inside the block: bf16 (rounded once, feeds one norm + conv)
+    if fuse and ca.Cout == 96:                       # inside the block: bf16 (rounded once, feeds one norm + conv)
         ca.run(norm_gamma=_gamma(blk.residual[3]), norm_out=cb.slot(T, H, W, dev), norm_only=True)
     else:
-        y = ca.run()
-        ops.rms_silu_cl(y, _gamma(blk.residual[3]), out=cb.slot(T, H, W, dev))
-    if _FUSE_NORM and nxt is not None and cb.Cout == 96:
+        y = ca.run(out_f32=st.f32)
+        st.norm(y, _gamma(blk.residual[3]), cb.slot(T, H, W, dev))
+    if fuse and nxt is not None and cb.Cout == 96:
         gamma, cn = nxt
-        return cb.run(resid=h, out_f32=_TRUNK_F32, norm_gamma=gamma, norm_out=cn.slot(T, H, W, dev)), True
-    return cb.run(resid=h, out_f32=_TRUNK_F32), False
+        return cb.run(resid=h, out_f32=tf, norm_gamma=gamma, norm_out=cn.slot(T, H, W, dev)), True
+    return cb.run(resid=h, out_f32=tf), False
 
 
 def _attention(st, key, blk: AttentionBlock, x):
     """vae.py:240-262 — per-frame single-head attention, D = C.  Scores go through the GEMM kernel
     (fp32 [HW, HW]) and a row-softmax kernel; it is 0.5 % of the decoder's work."""
+    if st.f32:
+        return _attention_f32(st, key, blk, x)
     T, H, W, Cc = x.shape
     HW = H * W
     HWp = _round_up(HW, 8)
@@ -378,7 +405,45 @@ def _attention(st, key, blk: AttentionBlock, x):
     del s, p
     cs = st.conv(key + ".proj", blk.proj)
     cs.slot(T, H, W, dev).copy_(o.view(T, H, W, Cc))
-    return cs.run(resid=x, out_f32=_TRUNK_F32)
+    return cs.run(resid=x, out_f32=st.trunk_f32)
+
+
+def _attention_f32(st, key, blk: AttentionBlock, x):
+    """The same block in the fp32-faithful mode: every GEMM operand a bf16 pair (activation-like operands in pattern 0,
+    weight-like ones in pattern 1: q against k, P against V^T), fp32 results, an fp32 softmax."""
+    T, H, W, Cc = x.shape
+    HW = H * W
+    HWp = _round_up(HW, 8)
+    dev = x.device
+    f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+    n3 = ops.rms_silu_cl_split3(x, _gamma(blk.norm), do_silu=False).view(T * HW, 3 * Cc)       # [hi | lo | hi]
+    wk = "attn3:" + key
+    if wk not in st.convs:
+        wqkv = blk.to_qkv.weight.detach().float().view(3 * Cc, Cc).contiguous()
+        b = blk.to_qkv.bias.detach().float()
+        st.convs[wk] = (ops.split3(wqkv[:2 * Cc], 1), b[:2 * Cc].contiguous(), ops.split3(wqkv[2 * Cc:], 1), b[2 * Cc:].contiguous())
+    wqk, bqk, wv, bv = st.convs[wk]
+    K3 = 3 * Cc
+    qk = ops.gemm(n3, wqk, bias=bqk, epilogue=ops.EPI_F32)                                     # fp32 [T*HW, 2C]
+    vt = torch.zeros(T, Cc, HWp, dtype=torch.float32, device=dev)                               # V^T = Wv n^T + bv
+    ops.gemm_raw(ops.ptr(wv), ops.ptr(n3), ops.ptr(vt), Cc, HW, K3, K3, K3, HWp, ops.EPI_F32, bias=ops.ptr(bv),
+                 bias_mode=ops.BIAS_M, batch=T, strideA=0, strideB=HW * K3, strideC=Cc * HWp)
+    q3 = ops.split3(qk[:, :Cc], 0)                                                              # [T*HW, 3C]
+    k3 = ops.split3(qk[:, Cc:], 1)
+    s = f32(T, HW, HW)
+    ops.gemm_raw(ops.ptr(q3), ops.ptr(k3), ops.ptr(s), HW, HW, K3, K3, K3, HW, ops.EPI_F32, batch=T,
+                 strideA=HW * K3, strideB=HW * K3, strideC=HW * HW)
+    p = torch.zeros(T * HW, HWp, dtype=torch.float32, device=dev)
+    ops.softmax_rows_f32(s.view(T * HW, HW), p, HW, 1.0 / math.sqrt(Cc))
+    p3 = ops.split3(p, 0, Cp=HWp)                                                               # [T*HW, 3 HWp]
+    v3 = ops.split3(vt.view(T * Cc, HWp), 1, Cp=HWp)                                            # [T*C, 3 HWp]
+    o = f32(T, HW, Cc)
+    ops.gemm_raw(ops.ptr(p3), ops.ptr(v3), ops.ptr(o), HW, Cc, 3 * HWp, 3 * HWp, 3 * HWp, Cc, ops.EPI_F32, batch=T,
+                 strideA=HW * 3 * HWp, strideB=Cc * 3 * HWp, strideC=HW * Cc)
+    del s, p, p3
+    cs = st.conv(key + ".proj", blk.proj)
+    _fill(cs.slot(T, H, W, dev), o.view(T, H, W, Cc))
+    return cs.run(resid=x, out_f32=True)
 
 
 def _resample(st, key, rs: Resample, x):
@@ -389,14 +454,14 @@ def _resample(st, key, rs: Resample, x):
             if key not in st.seen:
                 st.seen.add(key)                    # first chunk: the reference's 'Rep' bypass (vae.py:106-108)
             else:
-                x = _conv_on(st, key + ".time_conv", rs.time_conv, x, split_n=Cc)    # [2T, H, W, C]
+                x = _conv_on(st, key + ".time_conv", rs.time_conv, x, split_n=Cc, out_f32=st.f32)    # [2T, H, W, C]
         cs = st.conv(key + ".resample.1", rs.resample[1], up2=True)
         _fill(cs.slot(x.shape[0], H, W, x.device), x)
-        return cs.run(out_f32=_TRUNK_F32)
+        return cs.run(out_f32=st.trunk_f32)
     if rs.mode in ("downsample2d", "downsample3d"):
         cs = st.conv(key + ".resample.1", rs.resample[1], stride_hw=2, pad=(0, 0))
         _fill(cs.slot(T, H, W, x.device), x)
-        x = cs.run(out_f32=_TRUNK_F32)
+        x = cs.run(out_f32=st.trunk_f32)
         if rs.mode == "downsample3d":
             tc = st.conv(key + ".time_conv", rs.time_conv)
             if key not in st.seen:
@@ -405,7 +470,7 @@ def _resample(st, key, rs: Resample, x):
                 tc.set_history(x[-1])
             else:
                 _fill(tc.slot(x.shape[0], x.shape[1], x.shape[2], x.device), x)
-                x = tc.run(out_f32=_TRUNK_F32)
+                x = tc.run(out_f32=st.trunk_f32)
         return x
     return x
 
@@ -414,8 +479,8 @@ def _head(st, key, head: nn.Sequential, x, out_f32, pre=False):
     T, H, W, _ = x.shape
     cs = st.conv(key + ".2", head[2])
     if not pre:                                     # (pre: the last block's convolution wrote the norm into the slot)
-        ops.rms_silu_cl(x, _gamma(head[0]), out=cs.slot(T, H, W, x.device))
-    return cs.run(out_f32=out_f32)
+        st.norm(x, _gamma(head[0]), cs.slot(T, H, W, x.device))
+    return cs.run(out_f32=out_f32 or st.f32)
 
 
 def _first_resample(seq):
@@ -480,6 +545,11 @@ class WanVAE_(nn.Module):
     def _device(self):
         return self.conv1.weight.device
 
+    def _f32(self):
+        """True: the fp32-faithful arithmetic (split-bf16 operands) — set by the WanVAE wrapper from its ``dtype``
+        (``compute_dtype`` attribute; a bare WanVAE_ computes with bf16 operands)."""
+        return getattr(self, "compute_dtype", torch.bfloat16) == torch.float32
+
     @torch.no_grad()
     def encode(self, x, scale):
         """x fp32 [1, 3, T, H, W] -> mu [1, z, (T-1)/4+1, H/8, W/8] (vae.py:516-542)."""
@@ -490,7 +560,7 @@ class WanVAE_(nn.Module):
         vid = x[0].to(device=dev, dtype=torch.float32).contiguous()
         _, T, H, W = vid.shape
         n_chunks = 1 + (T - 1) // 4
-        st = _Stream(dev)
+        st = _Stream(dev, f32=self._f32())
         enc = self.encoder
         out = None
         t_lat = 0
@@ -505,17 +575,22 @@ class WanVAE_(nn.Module):
         while i < n_chunks:
             # the first frame alone (its chunk bypasses the temporal downsamples, vae.py:146-148), then _GROUP2 chunks
             # of 4 frames per step (causal convolutions over [history | frames]: same values as chunk by chunk)
-            g = 1 if i == 0 else min(_GROUP2, n_chunks - i)
+            # (fp32 mode: one chunk — a [history | 8 frames] region of 3 x 96 channels at 480x832 would pass the 2 GiB
+            # of 32-bit buffer offsets)
+            g = 1 if i == 0 else min(1 if st.f32 else _GROUP2, n_chunks - i)
             t0, tn = (0, 1) if i == 0 else (1 + 4 * (i - 1), 4 * g)
             c1 = st.conv("encoder.conv1", enc.conv1)
-            ops.nchw_to_cl(vid, tn, t0, c1.Cin, out=c1.slot(tn, H, W, dev))
-            h = c1.run(out_f32=_TRUNK_F32)
+            if st.f32:
+                _fill(c1.slot(tn, H, W, dev), ops.nchw_to_cl_f32(vid, tn, t0, c1.Cin // 3))
+            else:
+                ops.nchw_to_cl(vid, tn, t0, c1.Cin, out=c1.slot(tn, H, W, dev))
+            h = c1.run(out_f32=st.trunk_f32)
             rows.append(_run_sequential(st, "encoder.downsamples", enc.downsamples, h, stop=n_tail))
             i += g
         h = torch.cat(rows, dim=0) if len(rows) > 1 else rows[0]                   # [n_chunks, h, w, C]
         h = _run_sequential(st, "encoder.downsamples", enc.downsamples, h, start=n_tail)
         h = _run_sequential(st, "encoder.middle", enc.middle, h)
-        h = _head(st, "encoder.head", enc.head, h, out_f32=False)                  # [t, h, w, 2z]
+        h = _head(st, "encoder.head", enc.head, h, out_f32=False)                  # [t, h, w, 2z] (fp32 in the fp32 mode)
         mu = _conv_on(st, "conv1", self.conv1, h, out_f32=True)
         out = torch.empty(self.z_dim, n_chunks, h.shape[1], h.shape[2], dtype=torch.float32, device=dev)
         if isinstance(scale[0], torch.Tensor):
@@ -543,10 +618,11 @@ class WanVAE_(nn.Module):
         else:
             mul = torch.full((self.z_dim,), 1.0 / float(scale[1]), device=dev)
             add = torch.full((self.z_dim,), float(scale[0]), device=dev)
-        st = _Stream(dev)
+        st = _Stream(dev, f32=self._f32())
         dec = self.decoder
-        zcl = ops.nchw_to_cl(lat, Tl, 0, _round_up(self.z_dim, 8), mul=mul, add=add)       # z/scale1 + scale0
-        x_all = _conv_on(st, "conv2", self.conv2, zcl)                                     # [T', h, w, z]
+        zc = _round_up(self.z_dim, 8)
+        zcl = (ops.nchw_to_cl_f32 if st.f32 else ops.nchw_to_cl)(lat, Tl, 0, zc, mul=mul, add=add)   # z/scale1 + scale0
+        x_all = _conv_on(st, "conv2", self.conv2, zcl, out_f32=st.f32)                     # [T', h, w, z]
         T_out = 4 * (Tl - 1) + 1
         out = torch.empty(3, T_out, 8 * h, 8 * w, dtype=torch.float32, device=dev)
         lo, hi = (-3.0e38, 3.0e38) if clamp is None else clamp
@@ -557,8 +633,8 @@ class WanVAE_(nn.Module):
         # skips the temporal upsample, vae.py:105-125).
         n_front = _first_resample(dec.upsamples)
         c1 = st.conv("decoder.conv1", dec.conv1)
-        c1.slot(Tl, h, w, dev).copy_(x_all)
-        y_all = c1.run(out_f32=_TRUNK_F32)
+        _fill(c1.slot(Tl, h, w, dev), x_all)
+        y_all = c1.run(out_f32=st.trunk_f32)
         y_all = _run_sequential(st, "decoder.middle", dec.middle, y_all)
         y_all = _run_sequential(st, "decoder.upsamples", dec.upsamples, y_all, stop=n_front)
         # From the first Resample to just past the second one (the 2h x 2w stage: 49 920 voxels per latent frame at
@@ -569,12 +645,12 @@ class WanVAE_(nn.Module):
         n_mid = res_idx[1] + 1 if len(res_idx) > 1 else len(dec.upsamples)
         i = 0
         while i < Tl:
-            g = 1 if i == 0 else min(_GROUP, Tl - i)
+            g = 1 if i == 0 else min(2 if st.f32 else _GROUP, Tl - i)
             ymid = _run_sequential(st, "decoder.upsamples", dec.upsamples, y_all[i:i + g], start=n_front, stop=n_mid)
             per = ymid.shape[0] // g
             j = 0
             while j < g:                                      # the full-resolution rest: _GROUP2 latent frames per step
-                g2 = min(_GROUP2, g - j)
+                g2 = min(1 if st.f32 else _GROUP2, g - j)
                 y, pre = _run_sequential(st, "decoder.upsamples", dec.upsamples, ymid[j * per:(j + g2) * per], start=n_mid,
                                          head=("decoder.head", dec.head))
                 y = _head(st, "decoder.head", dec.head, y, out_f32=True, pre=pre)        # fp32 [t, 8h, 8w, 3]
@@ -610,16 +686,25 @@ class WanVAE:
     """vae.py:619-663."""
 
     def __init__(self, z_dim=16, vae_pth="cache/vae_step_411000.pth", dtype=torch.float, device="cuda", **cfg):
+        """``dtype`` selects the arithmetic class, as the reference's ``amp.autocast(dtype=self.dtype)`` does
+        (vae.py:649-663): ``torch.float`` — the reference's default — computes every convolution / GEMM with split-bf16
+        operand pairs and fp32 accumulation (an fp32-class product, three MFMA products per tile: <= 2e-4 from the fp32
+        reference over the whole VAE); ``torch.bfloat16`` (what this package's pipelines and the benchmark pass) rounds
+        the operands once to bf16 (1e-2 over the whole VAE, three times the throughput).  The latent mean / std stay
+        fp32 in both."""
+        if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError(f"WanVAE dtype must be torch.float / torch.bfloat16 (torch.float16 = bfloat16 here), got {dtype}")
         self.dtype = dtype
         self.device = device
         mean = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508,
                 0.4134, -0.0715, 0.5517, -0.3632, -0.1922, -0.9497, 0.2503, -0.2921]
         std = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743,
                3.2687, 2.1526, 2.8652, 1.5579, 1.6382, 1.1253, 2.8251, 1.9160]
-        self.mean = torch.tensor(mean, dtype=dtype, device=device)
-        self.std = torch.tensor(std, dtype=dtype, device=device)
+        self.mean = torch.tensor(mean, dtype=torch.float32, device=device)
+        self.std = torch.tensor(std, dtype=torch.float32, device=device)
         self.scale = [self.mean, 1.0 / self.std]
         self.model = _video_vae(pretrained_path=vae_pth, z_dim=z_dim, **cfg).eval().requires_grad_(False).to(device)
+        self.model.compute_dtype = torch.float32 if dtype == torch.float32 else torch.bfloat16
 
     def encode(self, videos):
         """videos: list of [3, T, H, W] -> list of fp32 [z, (T-1)/4+1, H/8, W/8]."""
@@ -630,12 +715,12 @@ class WanVAE:
         return [self.model.decode(u.unsqueeze(0), self.scale, clamp=(-1.0, 1.0)).float().squeeze(0) for u in zs]
 
 
-def bench_decode(latent, device, iters=1, telemetry=None):
+def bench_decode(latent, device, iters=1, telemetry=None, dtype=torch.bfloat16):
     """bench.py hook: frames/s of decoding one [16, T', 60, 104] latent, and of encoding the decoded clip back,
     with a random-init VAE.  Conv flops per frame from SURVEY.md section 8(d) (linear in H*W).  ``telemetry``: an
     object with start() / stop() -> dict (bench.Telemetry: shader clock and board power of the timed decodes)."""
     import time
-    vae = WanVAE(vae_pth=None, device=device)
+    vae = WanVAE(vae_pth=None, device=device, dtype=dtype)
     z = latent.detach().float()
     z = (z - z.mean()) / z.std().clamp_min(1e-6)
     vae.decode([z[:, :2]])                     # warm-up: two chunks (first + steady state)
@@ -653,7 +738,11 @@ def bench_decode(latent, device, iters=1, telemetry=None):
     flops = (4.29 + (z.shape[1] - 1) * 13.49) * 1e12 * area
     res = {"frames_per_s": round(frames / dt, 2), "decode_s": round(dt, 3), "frames": int(frames), "repeats": iters,
            "conv_tflops": round(flops / dt / 1e12, 1), "mfma_roofline_frac": round(flops / dt / 2.5e15, 4),
-           "finite": bool(torch.isfinite(out).all()), "weights": "random-init"}
+           "finite": bool(torch.isfinite(out).all()), "weights": "random-init",
+           "operands": "bf16 (one rounding per convolution operand), fp32 accumulate, fp32 residual trunk"
+                       if dtype != torch.float32 else
+                       "split-bf16 pairs (hi + lo, three MFMA products per tile), fp32 accumulate: WanVAE(dtype=torch.float)",
+           "executed_mfma_tflops": round(flops * (3 if dtype == torch.float32 else 1) / dt / 1e12, 1)}
     if tele:
         res["decode_telemetry"] = tele
         res["mfma_frac_of_peak_at_measured_clock"] = round(flops / dt / 1e12 / tele["mfma_peak_at_mean_clock_tflops"], 4)

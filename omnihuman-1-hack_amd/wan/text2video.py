@@ -58,7 +58,8 @@ class WanT2V:
         self.vae_stride = config.vae_stride
         self.patch_size = config.patch_size
         if vae is None:
-            vae = WanVAE(vae_pth=os.path.join(checkpoint_dir, config.vae_checkpoint), device=self.device)
+            vae = WanVAE(vae_pth=os.path.join(checkpoint_dir, config.vae_checkpoint), device=self.device,
+                         dtype=getattr(config, "vae_dtype", torch.bfloat16))    # bf16 operands; torch.float: fp32-faithful
         self.vae = vae
         if model is None:
             logging.info(f"Creating WanModel from {checkpoint_dir}")

@@ -5,7 +5,7 @@ import torch
 from oracle import wan_vae_oracle as V
 vae_mod = importlib.import_module("omnihuman-1-hack_amd.wan.modules.vae")
 torch.manual_seed(4321)
-vae = vae_mod.WanVAE(vae_pth=None, device="cuda")
+vae = vae_mod.WanVAE(vae_pth=None, dtype=torch.bfloat16, device="cuda")
 sd = {k: v.detach().float().cpu() for k, v in vae.model.state_dict().items()}
 cfg = V.VAEConfig(dim=96)
 torch.set_num_threads(32)

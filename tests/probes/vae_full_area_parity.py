@@ -19,7 +19,7 @@ def main():
     dev = torch.device("cuda", 0)
     vae_mod = importlib.import_module(PKG + ".wan.modules.vae")
     torch.manual_seed(4321)
-    vae = vae_mod.WanVAE(vae_pth=None, device=dev)
+    vae = vae_mod.WanVAE(vae_pth=None, dtype=torch.bfloat16, device=dev)
     sd = {k: v.detach().float().cpu() for k, v in vae.model.state_dict().items()}
     cfg = V.VAEConfig(dim=96)
     z = torch.randn(16, 2, 60, 104, generator=torch.Generator().manual_seed(5))

@@ -12,7 +12,7 @@ def child():
     rel = lambda a, b: float((a.float().cpu() - b).norm() / b.norm())
     cfg = V.VAEConfig(dim=96)
     sd = V.synth_state_dict(cfg, "vae96wide")
-    vae = vae_mod.WanVAE(vae_pth=None, device="cuda", dim=96)
+    vae = vae_mod.WanVAE(vae_pth=None, dtype=torch.bfloat16, device="cuda", dim=96)
     vae.model.load_state_dict(sd)
     z = torch.from_numpy(detgen.normalish("vae/zwide", (16, 4, 16, 24)))
     ref = V.vae_decode(sd, cfg, z)

@@ -83,7 +83,7 @@ def test_vae_81_frames_encode_decode_480x832():
     """vae.py:516-568 on the whole 81-frame clip (image2video.py:237-246 encode, :333 decode)."""
     dev = torch.device("cuda", 0)
     vae_mod = importlib.import_module(PKG + ".wan.modules.vae")
-    vae = vae_mod.WanVAE(vae_pth=None, device=dev)
+    vae = vae_mod.WanVAE(vae_pth=None, dtype=torch.bfloat16, device=dev)
     g = torch.Generator(device=dev).manual_seed(3)
     clip = (torch.rand(3, F, 480, 832, device=dev, generator=g) * 2 - 1) * 0.5
     z = vae.encode([clip])[0]

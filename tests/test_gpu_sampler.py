@@ -79,7 +79,7 @@ def test_wan_t2v_generate_tiny_matches_oracle(solver):
     sd = O.synth_state_dict(ocfg, "t2vgen")
     model = wan.modules.model.WanModel(**kw)
     model.load_state_dict(sd)
-    vae = vae_mod.WanVAE(vae_pth=None, device="cuda", dim=16)
+    vae = vae_mod.WanVAE(vae_pth=None, dtype=torch.bfloat16, device="cuda", dim=16)
     pipe = t2v.WanT2V(cfgs.t2v_1_3B, checkpoint_dir="", model=model, vae=vae)
     ctx = [torch.from_numpy(detgen.normalish("t2vgen/c", (9, 64)))]
     ctx0 = [torch.from_numpy(detgen.normalish("t2vgen/n", (21, 64)))]
@@ -119,7 +119,7 @@ def test_wan_i2v_generate_tiny_matches_oracle():
     model.load_state_dict(sd)
     vcfg = V.VAEConfig(dim=16)
     vsd = V.synth_state_dict(vcfg, "i2vgen/vae")
-    vae = vae_mod.WanVAE(vae_pth=None, device="cuda", dim=16)
+    vae = vae_mod.WanVAE(vae_pth=None, dtype=torch.bfloat16, device="cuda", dim=16)
     vae.model.load_state_dict(vsd)
     clip_fea = torch.from_numpy(detgen.normalish("i2vgen/clip", (1, 257, 1280)))
 
@@ -171,7 +171,7 @@ def _tiny_t2v(rank=0):
     kw = dict(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64, text_len=32, freq_dim=64)
     model = wan.modules.model.WanModel(**kw)
     model.load_state_dict(O.synth_state_dict(O.DiTConfig(**kw), "t2vgen"))
-    vae = vae_mod.WanVAE(vae_pth=None, device="cuda", dim=16)
+    vae = vae_mod.WanVAE(vae_pth=None, dtype=torch.bfloat16, device="cuda", dim=16)
     pipe = t2v.WanT2V(cfgs.t2v_1_3B, checkpoint_dir="", model=model, vae=vae, rank=rank)
     args = dict(size=(64, 48), frame_num=5, shift=3.0, sampling_steps=4, guide_scale=4.0, return_latent=True,
                 context=[torch.from_numpy(detgen.normalish("t2vgen/c", (9, 64)))],
@@ -197,7 +197,7 @@ def _tiny_i2v(rank=0):
     ocfg = O.DiTConfig(model_type="i2v", in_dim=36, num_layers=2, **make_golden.TINY)
     model = wan.modules.model.WanModel(model_type="i2v", in_dim=36, num_layers=2, **make_golden.TINY)
     model.load_state_dict(O.synth_state_dict(ocfg, "i2vgen"))
-    vae = vae_mod.WanVAE(vae_pth=None, device="cuda", dim=16)
+    vae = vae_mod.WanVAE(vae_pth=None, dtype=torch.bfloat16, device="cuda", dim=16)
     vae.model.load_state_dict(V.synth_state_dict(V.VAEConfig(dim=16), "i2vgen/vae"))
     clip = _ClipStub(torch.from_numpy(detgen.normalish("i2vgen/clip", (1, 257, 1280))))
     pipe = wan.WanI2V(cfgs.i2v_14B, checkpoint_dir="", model=model, vae=vae, clip=clip, rank=rank)

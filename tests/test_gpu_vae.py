@@ -272,7 +272,7 @@ def test_vae_decode_encode_match_oracle(dim, window, monkeypatch):
         monkeypatch.setattr(vae_mod._ConvState, "slot", small_slot)
     cfg = V.VAEConfig(dim=dim)
     sd = V.synth_state_dict(cfg, f"vae{dim}")
-    vae = vae_mod.WanVAE(vae_pth=None, device="cuda", dim=dim)
+    vae = vae_mod.WanVAE(vae_pth=None, dtype=torch.bfloat16, device="cuda", dim=dim)
     vae.model.load_state_dict(sd)
     z = torch.from_numpy(detgen.normalish("vae/z", (16, 3, 8, 8)))
     ref = V.vae_decode(sd, cfg, z)
@@ -294,10 +294,80 @@ def test_vae_decode_at_wide_tile_sizes_matches_oracle():
     vae_mod = importlib.import_module("omnihuman-1-hack_amd.wan.modules.vae")
     cfg = V.VAEConfig(dim=96)
     sd = V.synth_state_dict(cfg, "vae96wide")
-    vae = vae_mod.WanVAE(vae_pth=None, device="cuda", dim=96)
+    vae = vae_mod.WanVAE(vae_pth=None, dtype=torch.bfloat16, device="cuda", dim=96)
     vae.model.load_state_dict(sd)
     z = torch.from_numpy(detgen.normalish("vae/zwide", (16, 2, 30, 52)))
     ref = V.vae_decode(sd, cfg, z)
     out = vae.decode([z.cuda()])[0]
     assert out.shape == ref.shape == (3, 5, 240, 416)
     assert rel_rms(out, ref) < TOL_VAE
+
+
+TOL_VAE_F32 = 2.0e-4        # WanVAE(dtype=torch.float): split-bf16 operand pairs, fp32 accumulate
+
+
+def test_split3_operands(ops):
+    """omh_split3_f32: x = hi + lo to 2^-16 relative, the two block patterns, zero pad channels, strided rows; a product
+    of a pattern-0 row with a pattern-1 row over the 3 Cp channels = x . w to fp32 class."""
+    torch.manual_seed(5)
+    x = torch.randn(37, 20, device="cuda") * 3
+    a = ops.split3(x, 0)                                                   # Cp = 24
+    assert a.shape == (37, 72) and a.dtype == torch.bfloat16
+    hi, lo, hi2 = a[:, :24].float(), a[:, 24:48].float(), a[:, 48:].float()
+    assert torch.equal(hi, hi2) and torch.equal(hi[:, :20], x.bfloat16().float())
+    assert bool((a[:, 20:24] == 0).all()) and bool((a[:, 44:48] == 0).all())
+    assert float(((hi + lo)[:, :20] - x).abs().max()) <= 2.0 ** -16 * float(x.abs().max())
+    b = ops.split3(x, 1)
+    assert torch.equal(b[:, :24], a[:, :24]) and torch.equal(b[:, 24:48], a[:, :24]) and torch.equal(b[:, 48:], a[:, 24:48])
+    big = torch.randn(64, 96, device="cuda")
+    v = ops.split3(big[:, 32:64], 0)                                       # a column block of a wider matrix
+    assert torch.equal(v[:, :32], big[:, 32:64].bfloat16())
+    # the GEMM on split operands against fp64
+    A, W = torch.randn(200, 96, device="cuda"), torch.randn(64, 96, device="cuda")
+    got = ops.gemm(ops.split3(A, 0), ops.split3(W, 1), epilogue=ops.EPI_F32)
+    want = A.double() @ W.double().t()
+    assert rel_rms(got, want) < 5e-6                                       # (one bf16 rounding of the operands: 3e-3)
+    assert rel_rms(ops.gemm(A.bfloat16(), W.bfloat16(), epilogue=ops.EPI_F32), want) > 1e-3
+
+
+@pytest.mark.parametrize("dim", [16, 96])
+def test_vae_fp32_mode_matches_oracle(dim):
+    """WanVAE(dtype=torch.float) — the reference's default arithmetic (vae.py:619-624: autocast to fp32) — against the
+    fp32 oracle on the tiny clip of test_vae_decode_encode_matches_oracle: every chunk kind, both resamplers' first-chunk
+    bypasses, the mid-block attention with split q / k / P / V operands."""
+    from oracle import wan_vae_oracle as V, detgen
+    vae_mod = importlib.import_module("omnihuman-1-hack_amd.wan.modules.vae")
+    cfg = V.VAEConfig(dim=dim)
+    sd = V.synth_state_dict(cfg, f"vae{dim}")
+    vae = vae_mod.WanVAE(vae_pth=None, dtype=torch.float, device="cuda", dim=dim)
+    vae.model.load_state_dict(sd)
+    z = torch.from_numpy(detgen.normalish("vae/z", (16, 3, 8, 8)))
+    ref = V.vae_decode(sd, cfg, z)
+    out = vae.decode([z.cuda()])[0]
+    assert out.shape == ref.shape == (3, 9, 64, 64) and out.dtype == torch.float32
+    e = rel_rms(out, ref)
+    vid = torch.from_numpy(detgen.uniform("vae/vid", (3, 9, 32, 32)))
+    refe = V.vae_encode(sd, cfg, vid)
+    oute = vae.encode([vid.cuda()])[0]
+    ee = rel_rms(oute, refe)
+    print(f"[measured] fp32-mode VAE (dim {dim}) vs oracle: decode {e:.3e}, encode {ee:.3e}")
+    assert e < TOL_VAE_F32 and ee < TOL_VAE_F32, (e, ee)
+    with pytest.raises(ValueError):
+        vae_mod.WanVAE(vae_pth=None, dtype=torch.int8, device="cuda", dim=dim)
+
+
+def test_vae_fp32_mode_at_wide_tile_sizes():
+    """The fp32 mode through the 512x96 / 256x192 stream tiles (3 x 96 = 288, 3 x 192 = 576 input channels per tap),
+    the folded upsamples and the frame-interleaving time convolution with an fp32 result."""
+    from oracle import wan_vae_oracle as V, detgen
+    vae_mod = importlib.import_module("omnihuman-1-hack_amd.wan.modules.vae")
+    cfg = V.VAEConfig(dim=96)
+    sd = V.synth_state_dict(cfg, "vae96wide")
+    vae = vae_mod.WanVAE(vae_pth=None, device="cuda", dim=96)               # default dtype: torch.float
+    vae.model.load_state_dict(sd)
+    z = torch.from_numpy(detgen.normalish("vae/zwide", (16, 2, 30, 52)))
+    ref = V.vae_decode(sd, cfg, z)
+    out = vae.decode([z.cuda()])[0]
+    e = rel_rms(out, ref)
+    print(f"[measured] fp32-mode VAE decode 240x416 vs oracle: {e:.3e}")
+    assert out.shape == ref.shape == (3, 5, 240, 416) and e < TOL_VAE_F32

@@ -41,7 +41,7 @@ def main():
     g = torch.Generator(device=dev).manual_seed(9)
     F, lat_t, lat_h, lat_w = 81, 21, 60, 104
     S = lat_t * (lat_h // 2) * (lat_w // 2)
-    vae = vae_mod.WanVAE(vae_pth=None, device=dev)
+    vae = vae_mod.WanVAE(vae_pth=None, dtype=torch.bfloat16, device=dev)
     clip = torch.cat([torch.rand(3, 1, 480, 832, device=dev, generator=g) * 2 - 1,
                       torch.zeros(3, F - 1, 480, 832, device=dev)], dim=1)
     vae.encode([clip[:, :5]])

@@ -18,7 +18,7 @@ with torch.device(dev):
     dit = model_mod.WanModel(**cfgs.dit_kwargs(cfgs.t2v_1_3B))
     torch.nn.init.xavier_uniform_(dit.head.head.weight)
 dit.eval().requires_grad_(False)
-vae = vae_mod.WanVAE(vae_pth=None, device=dev)
+vae = vae_mod.WanVAE(vae_pth=None, dtype=torch.bfloat16, device=dev)
 
 
 class T2V:
