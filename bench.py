@@ -235,6 +235,10 @@ def cpu_baseline(model, latent, t, ctx, seq_len, budget_s=60.0):
             "parity_rel_rms_block0_full_size": parity,
             "sample": f"oracle fp32 DiT: embeddings + 1 of 30 blocks of one forward at S={seq_len} "
                       f"({t_blk:.1f}s/block, {t_embed:.1f}s embed), extrapolated x30 blocks x2 CFG forwards",
+            "note": "threads = the best of the sweep (this host slows down past 16-32 intra-op threads).  The survey's "
+                    "0.46 TFLOP/s on 8 cores (BASELINE.md section 2) was the S = 1560 forward, where GEMMs are 88 % of the "
+                    "work; at S = 32760 70 % of a block is the 12 x S x S softmax attention, which the fp32 reference path "
+                    "materialises as a 51 GB score tensor — memory-bound on the host",
             "tflops": dit_forward_flops(seq_len) / 30 / t_blk / 1e12}
 
 
