@@ -478,6 +478,9 @@ int launch(const omh_gemm_args& a, hipStream_t s) {
 // gemm_w64.hip: 256 x 384 tile, one wave per SIMD, generated k loop
 bool omh_gemm_w64_takes(const omh_gemm_args& a);
 int omh_launch_gemm_w64(const omh_gemm_args& a, hipStream_t stream);
+// ... and its 256 x 192 gated-residual variant with the old C tile prefetched during the k loop
+bool omh_gemm_w64_r192_takes(const omh_gemm_args& a);
+int omh_launch_gemm_w64_r192(const omh_gemm_args& a, hipStream_t stream);
 
 static int launch_8w(const omh_gemm_args& a, hipStream_t s) {
     switch (a.epilogue) {
@@ -533,6 +536,21 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
         // applies AND fills the chip (>= 256 tiles, last round of tiles at least 3/4 full or >= 4 rounds)
         const char* gk = getenv("OMH_GEMM_KERNEL");
         const bool force = gk && gk[0] == 'w', never = v5 || (gk && gk[0] == '8') || (!force && getenv("OMH_GEMM_TILE"));
+        // gated residual with a short contraction (o-projections: K = dim): the 256 x 192 stream that requests the old C
+        // tile during its k loop.  OMH_GEMM_W64_R192 = 0 / 1 forces it off / on (A/B timing, tests).
+        {
+            const char* r192 = getenv("OMH_GEMM_W64_R192");
+            const bool off = r192 && r192[0] == '0', on = r192 && r192[0] == '1';
+            const bool never192 = (gk && gk[0] == '8') || (!force && getenv("OMH_GEMM_TILE"));
+            if (!never192 && !off && omh_gemm_w64_r192_takes(a)) {          // (also the training epilogues: c_in, aux)
+                const int64_t t192 = (int64_t)((a.M + 255) / 256) * ((a.N + 191) / 192);
+                if (on || (a.K <= 3072 && t192 >= 192)) {
+                    omh_clear_status();
+                    omh_launch_gemm_w64_r192(a, s);
+                    return omh_launch_status();
+                }
+            }
+        }
         if (!never && omh_gemm_w64_takes(a)) {
             // (a ragged last tile column stays in this kernel, masked: handing N % 384 = 128 columns of the FFN's 8960
             // to the 8-wave kernel as a second launch measured 778 us against 757 us)

@@ -9,13 +9,14 @@
 namespace {
 
 constexpr int TM = 256, TN = 384, BK = 64;
+constexpr int TN192 = 192;       // the gated-residual stream with the old C tile requested during the k loop (round 4)
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, int64_t bytes) {
     const uint32_t n = bytes <= 0 ? 0u : (bytes > 0xffffffffLL ? 0xffffffffu : (uint32_t)bytes);
     return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)n, 0x00020000);
 }
 
-enum { K_F32 = 0, K_BF16 = 1, K_GELU = 2, K_RESID = 3 };
+enum { K_F32 = 0, K_BF16 = 1, K_GELU = 2, K_RESID = 3, K_RESID192 = 4 };
 
 // two wave-uniform 32-bit scalars in one SGPR pair (inline asm takes at most 30 operands)
 __device__ __forceinline__ uint64_t pack2(uint32_t lo, uint32_t hi) {
@@ -27,14 +28,15 @@ struct W64Tile { uint32_t sxb, swb; int m0, n0; };
 
 // Tile `idx` of this launch: XCD-contiguous work order (xcd_remap) walking 8 m-tiles x all n-tiles (tile_of), and the
 // byte offsets of this WAVE's first X / W rows (wave w stages X rows 64 w .. and W rows 96 w ..).
+template <int TNW>
 __device__ __forceinline__ W64Tile w64_tile(const omh_gemm_args& p, int idx, int tiles_m, int tiles_n, int w) {
     const int wid = xcd_remap(idx, tiles_m * tiles_n);
     int tm, tn;
     tile_of(wid, tiles_m, tiles_n, tm, tn, 8);
     W64Tile t;
-    t.m0 = tm * TM; t.n0 = tn * TN;
+    t.m0 = tm * TM; t.n0 = tn * TNW;
     t.sxb = (uint32_t)(((int64_t)(t.m0 + w * 64) * p.lda) * 2);
-    t.swb = (uint32_t)(((int64_t)(t.n0 + w * 96) * p.ldb) * 2);
+    t.swb = (uint32_t)(((int64_t)(t.n0 + w * (TNW / 4)) * p.ldb) * 2);
     return t;
 }
 
@@ -44,7 +46,9 @@ __device__ __forceinline__ W64Tile w64_tile(const omh_gemm_args& p, int idx, int
 template <int KIND>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int tiles_n) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[163840];     // 2 stages x (X 32 KiB | W 48 KiB)
+    constexpr int TNW = KIND == K_RESID192 ? TN192 : TN;                    // tile width; a wave owns TNW / 2 columns
+    constexpr int WBYTES = TNW * 128, STAGE_B = 32768 + WBYTES;             // W tile, one stage (X 32 KiB | W)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_B];
     constexpr int ES = (KIND == K_BF16 || KIND == K_GELU) ? 2 : 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -58,7 +62,7 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
     const uint32_t xh = (uint32_t)(x3 >> 1);
     const uint32_t hb = (uint32_t)((h ^ (x3 & 1)) << 4);
     const uint32_t xab = lds0 + (uint32_t)(wm * 16384 + r * 128) + hb;
-    const uint32_t wab = lds0 + 32768u + (uint32_t)(wn * 24576 + r * 128) + hb;
+    const uint32_t wab = lds0 + 32768u + (uint32_t)(wn * (WBYTES / 2) + r * 128) + hb;
     // LDS-DMA: a 1 KiB piece = 8 rows x 8 slots; lane -> (row lane >> 3, physical slot lane & 7), fetched from the
     // logical slot (lane & 7) ^ ((row >> 1) & 7) with (row >> 1) & 7 = 4 (piece & 1) + (lane >> 4)
     const int pr = lane >> 3, ps = lane & 7;
@@ -75,22 +79,34 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
     const __amdgpu_buffer_rsrc_t rb = rsrc_of(p.B, (((int64_t)p.N - 1) * p.ldb + p.K) * 2);
     const __amdgpu_buffer_rsrc_t rc = rsrc_of(p.C, (((int64_t)p.M - 1) * p.ldc + p.N) * ES);
     const __amdgpu_buffer_rsrc_t rbias = rsrc_of(p.bias, (p.bias && p.bias_mode == OMH_BIAS_N) ? (int64_t)p.N * 4 : 0);
-    const __amdgpu_buffer_rsrc_t rg0 = rsrc_of(p.gate0, (KIND == K_RESID && p.gate0) ? (int64_t)p.N * 4 : 0);
-    const bool has_g1 = KIND == K_RESID && p.gate1 != nullptr;
+    constexpr bool RES = KIND == K_RESID || KIND == K_RESID192;
+    const __amdgpu_buffer_rsrc_t rg0 = rsrc_of(p.gate0, (RES && p.gate0) ? (int64_t)p.N * 4 : 0);
+    const bool has_g1 = RES && p.gate1 != nullptr;
     const int grows = has_g1 ? p.gate_rows : 1;
     const int nb = has_g1 ? (p.M + grows - 1) / grows : 1;
     const __amdgpu_buffer_rsrc_t rg1 = rsrc_of(p.gate1, has_g1 ? ((int64_t)(nb - 1) * p.gate1_stride + p.N) * 4 : 0);
+    // resid192 (training epilogues, ABI v5): the old values may come from another tensor (c_in), y = bf16(acc + bias)
+    // goes to aux (same row pitch as C; absent: an empty descriptor drops the stores)
+    const __amdgpu_buffer_rsrc_t rcin = rsrc_of(p.c_in ? (const void*)p.c_in : (const void*)p.C, (((int64_t)p.M - 1) * p.ldc + p.N) * 4);
+    const __amdgpu_buffer_rsrc_t raux = rsrc_of(p.aux, p.aux ? (((int64_t)p.M - 1) * p.ldc + p.N) * 2 : 0);
 
-    const uint64_t p0 = pack2(lds0 + (uint32_t)w * 8192u, lds0 + (uint32_t)w * 12288u);
+    const uint64_t p0 = pack2(lds0 + (uint32_t)w * 8192u, lds0 + (uint32_t)w * (uint32_t)(WBYTES / 4));
     const uint64_t p2 = pack2((uint32_t)(8 * p.lda * 2), (uint32_t)(8 * p.ldb * 2));
     const uint64_t p4 = pack2((uint32_t)(32 * p.ldc * ES), (uint32_t)p.N);
     const uint64_t p6 = pack2((uint32_t)(p.gate1_stride * 4), __float_as_uint(p.gate_const));
     const uint32_t nk = (uint32_t)(p.K / BK);
-    const uint32_t region = lds0 + 114688u + (uint32_t)w * 4096u;           // column vectors: stage 1's W region
+    const uint32_t region = lds0 + (uint32_t)(STAGE_B + 32768) + (uint32_t)w * 4096u;   // column vectors: stage 1's W region
 
     int idx = blockIdx.x;
-    W64Tile t = w64_tile(p, idx, tiles_m, tiles_n, w);
-    {
+    W64Tile t = w64_tile<TNW>(p, idx, tiles_m, tiles_n, w);
+    if (KIND == K_RESID192) {
+        const uint64_t p8 = pack2(t.sxb, t.swb);
+        asm volatile(OMH_GEMM_W64_ASM_PRO192
+                     :
+                     : [vox0] "v"(vox0), [vox1] "v"(vox1), [vow0] "v"(vow0), [vow1] "v"(vow1), [ra] "s"(ra), [rb] "s"(rb),
+                       [p0] "{s[60:61]}"(p0), [p2] "{s[64:65]}"(p2), [p8] "{s[76:77]}"(p8)
+                     : "memory", "scc", "s80", "s81", "s82");
+    } else {
         const uint64_t p8 = pack2(t.sxb, t.swb);
         asm volatile(OMH_GEMM_W64_ASM_PRO
                      :
@@ -102,8 +118,8 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
     while (true) {
         const int nidx = idx + (int)gridDim.x;
         const bool has_next = nidx < total;
-        const W64Tile tn = w64_tile(p, has_next ? nidx : idx, tiles_m, tiles_n, w);
-        const int mw = t.m0 + wm * 128, nw = t.n0 + wn * 192;
+        const W64Tile tn = w64_tile<TNW>(p, has_next ? nidx : idx, tiles_m, tiles_n, w);
+        const int mw = t.m0 + wm * 128, nw = t.n0 + wn * (TNW / 2);
         const int blo = has_g1 ? mw / grows : 0;                            // batch index of the patch's first row
         // rows of the wave's patch from here on take the gate of batch blo + 1
         const uint32_t mb = has_g1 ? (uint32_t)((blo + 1) * grows - mw) : 0xffffffffu;
@@ -125,7 +141,17 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
         if (KIND == K_F32) OMH_GW64_RUN(OMH_GEMM_W64_ASM_F32);
         else if (KIND == K_BF16) OMH_GW64_RUN(OMH_GEMM_W64_ASM_BF16);
         else if (KIND == K_GELU) OMH_GW64_RUN(OMH_GEMM_W64_ASM_GELU);
-        else OMH_GW64_RUN(OMH_GEMM_W64_ASM_RESID);
+        else if (KIND == K_RESID) OMH_GW64_RUN(OMH_GEMM_W64_ASM_RESID);
+        else
+            asm volatile(OMH_GEMM_W64_ASM_RESID192
+                 :
+                 : [xab] "v"(xab), [wab] "v"(wab), [xh] "v"(xh), [vox0] "v"(vox0), [vox1] "v"(vox1), [vow0] "v"(vow0),
+                   [vow1] "v"(vow1), [voc] "v"(voc), [vlane] "v"(vlane), [ra] "s"(ra), [rb] "s"(rb), [rc] "s"(rc),
+                   [rbias] "s"(rbias), [rg0] "s"(rg0), [rg1] "s"(rg1), [rcin] "s"(rcin), [raux] "s"(raux),
+                   [p0] "{s[60:61]}"(p0), [p1] "{s[62:63]}"(p1),
+                   [p2] "{s[64:65]}"(p2), [p3] "{s[66:67]}"(p3), [p4] "{s[68:69]}"(p4), [p5] "{s[70:71]}"(p5),
+                   [p6] "{s[72:73]}"(p6), [p7] "{s[74:75]}"(p7), [p8] "{s[76:77]}"(p8), [p9] "{s[78:79]}"(p9)
+                 : OMH_GEMM_W64_CLOBBERS);
 #undef OMH_GW64_RUN
         if (!has_next) break;
         idx = nidx;
@@ -135,7 +161,8 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
 
 template <int KIND>
 int launch_w64(const omh_gemm_args& a, hipStream_t stream) {
-    const int tiles_m = (a.M + TM - 1) / TM, tiles_n = (a.N + TN - 1) / TN;
+    constexpr int TNW = KIND == K_RESID192 ? TN192 : TN;
+    const int tiles_m = (a.M + TM - 1) / TM, tiles_n = (a.N + TNW - 1) / TNW;
     const int total = tiles_m * tiles_n;
     static int ncu = 0;
     if (!ncu) {
@@ -168,6 +195,16 @@ bool omh_gemm_w64_takes(const omh_gemm_args& a) {
            ((int64_t)a.M + TM) * a.lda * 2 < 0x7fffffffLL && ((int64_t)a.N + TN) * a.ldb * 2 < 0x7fffffffLL &&
            ((int64_t)a.M + TM) * a.ldc * es < 0xffffffffLL;
 }
+
+// The 256 x 192 gated-residual stream (old C requested during the first 12 k steps): in-place RESID shapes the big
+// stream takes, with 16 <= K / 64 (12 peeled steps + the tail logic) — chosen by omh_gemm_bf16 for short contractions,
+// where the 256 x 384 stream's read-modify-write epilogue is as long as its k loop.
+bool omh_gemm_w64_r192_takes(const omh_gemm_args& a) {
+    if (a.aux && (a.ldaux != a.ldc || ((uintptr_t)a.aux & 15))) return false;       // aux offsets = C offsets / 2
+    if (a.c_in && ((uintptr_t)a.c_in & 15)) return false;
+    return a.epilogue == OMH_EPI_RESID && omh_gemm_w64_takes(a) && a.K >= 16 * BK;
+}
+int omh_launch_gemm_w64_r192(const omh_gemm_args& a, hipStream_t stream) { return launch_w64<K_RESID192>(a, stream); }
 
 int omh_launch_gemm_w64(const omh_gemm_args& a, hipStream_t stream) {
     switch (a.epilogue) {

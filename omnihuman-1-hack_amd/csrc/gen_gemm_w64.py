@@ -33,7 +33,21 @@ import sys
 NI, NJ = 6, 4                   # n tiles (weights) x m tiles (activations) per wave
 STAGE = 81920
 WOFF = 32768                    # W tile behind the X tile inside a stage
+FB = 40                         # registers of one fragment buffer: 4 NI + 4 NJ
+NW = 12                         # W pieces (1 KiB) per wave and k tile: 2 NI
 KINDS = ("f32", "bf16", "gelu", "resid")
+
+
+def configure(ni):
+    """Tile configuration of the streams generated next: ni = 6 -> 256 x 384 (the default), ni = 3 -> 256 x 192 (the
+    "resid192" stream: 12 accumulator tiles per wave, all in AGPRs; v[96:255] + a[192:223] hold the tile's OLD C values,
+    requested during the k loop)."""
+    global NI, STAGE, FB, NW, NTILES
+    NI = ni
+    STAGE = 32768 + ni * 8192
+    FB = 4 * ni + 4 * NJ
+    NW = 2 * ni
+    NTILES = NI * NJ
 
 # fixed scalar registers (unpacked from the 64-bit operand pairs in the prologue)
 S_LDX, S_LDW, S_SXB, S_SWB, S_SXS, S_SWS, S_NK, S_SCB = "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67"
@@ -48,8 +62,8 @@ def acc(i, j):
     return (f"a[{t * 16}:{t * 16 + 15}]") if t < 16 else (f"v[{128 + (t - 16) * 16}:{128 + (t - 16) * 16 + 15}]")
 
 
-def wfrag(buf, i):   return 32 + buf * 40 + 4 * i
-def xfrag(buf, j):   return 32 + buf * 40 + 24 + 4 * j
+def wfrag(buf, i):   return 32 + buf * FB + 4 * i
+def xfrag(buf, j):   return 32 + buf * FB + 4 * NI + 4 * j
 def XA(s, kk):       return 12 + s * 4 + kk
 def WA(s, kk):       return 20 + s * 4 + kk
 def vr(lo, n=1):     return f"v{lo}" if n == 1 else f"v[{lo}:{lo + n - 1}]"
@@ -112,7 +126,7 @@ def group_mfmas(buf, first=False):
 
 
 def dma_piece(stage, operand, q, xb=S_SXB, wb=S_SWB):
-    """One 1 KiB LDS-DMA piece.  X: wave w fetches rows w*64 + 8 q (q < 8); W: rows w*96 + 8 q (q < 12).
+    """One 1 KiB LDS-DMA piece.  X: wave w fetches rows w*64 + 8 q (q < 8); W: rows w*16 NI + 8 q (q < 2 NI).
     s81 / s82: running source offsets of the X / W piece; s80: k byte offset of the tile being fetched."""
     base = stage * STAGE + (WOFF if operand == "w" else 0)
     vo = ("%[vow1]" if q & 1 else "%[vow0]") if operand == "w" else ("%[vox1]" if q & 1 else "%[vox0]")
@@ -129,7 +143,7 @@ def dma_piece(stage, operand, q, xb=S_SXB, wb=S_SWB):
 
 
 def all_pieces(stage, xb=S_SXB, wb=S_SWB):
-    return [dma_piece(stage, "x", q, xb, wb) for q in range(8)] + [dma_piece(stage, "w", q, xb, wb) for q in range(12)]
+    return [dma_piece(stage, "x", q, xb, wb) for q in range(8)] + [dma_piece(stage, "w", q, xb, wb) for q in range(NW)]
 
 
 def unpack(e, pairs=range(NPAIRS)):
@@ -137,8 +151,8 @@ def unpack(e, pairs=range(NPAIRS)):
 
 
 def tile_prologue(e, xb, wb):
-    """k tile 0 -> stage 0 (all 20 pieces per wave), k tile 1 -> stage 1 (the 8 X pieces; the k loop issues the 12 W
-    pieces): 28 LDS-DMA instructions."""
+    """k tile 0 -> stage 0 (all 8 + NW pieces per wave), k tile 1 -> stage 1 (the 8 X pieces; the k loop issues the NW
+    W pieces): 16 + NW LDS-DMA instructions."""
     e("s_mov_b32 s80, 0")
     for ops in all_pieces(0, xb, wb):
         for op in ops:
@@ -179,10 +193,34 @@ def with_dma_tail(ops, dm, start=12):
     return out
 
 
-def main_loop(e, epi_vmem):
+CPRE = 96                      # resid192: v[96:255] = old C of tiles 0..9, a[192:223] = tiles 10, 11
+
+
+def c_slot(k, lo, n=4):
+    """Register range [lo, lo + n) of accumulator tile k's old C values."""
+    base, f = (CPRE + 16 * k, "v") if k < 10 else (192 + 16 * (k - 10), "a")
+    return f"{f}[{base + lo}:{base + lo + n - 1}]"
+
+
+def c_prefetch(k):
+    """The four 16-byte pieces per lane of the OLD C values of accumulator tile k (processing order = (i, j) = divmod
+    (k, NJ)): issued from k step k of the main loop, behind that step's W pieces, so the step's counted vmcnt leaves them
+    in flight for a whole k step."""
+    i, j = divmod(k, NJ)
+    ops = [("x", f"s_mul_i32 s88, {S_SCJ}, {j}"), ("x", f"s_add_u32 s88, s88, {S_SCB}")]
+    for p in range(2):
+        for q in range(2):
+            lo = p * 8 + q * 4
+            dst = c_slot(k, lo)
+            ops.append(("x", f"buffer_load_dwordx4 {dst}, %[voc], %[rcin], s88 offen offset:{(i * 32 + 16 * p) * 4 + q * 16}"))
+    return ops
+
+
+def main_loop(e, epi_vmem, cpre=False):
     """The k loop of one output tile.  On entry the tile's prologue DMA (tile_prologue) is in flight, followed in issue
     order by `epi_vmem` stores / loads of the previous tile's epilogue (none for the workgroup's first tile, whose
-    prologue stream ended with its own wait)."""
+    prologue stream ended with its own wait).  ``cpre``: k steps 0 .. NTILES-1 are peeled and each requests one
+    accumulator tile's old C values (c_prefetch); K >= (NTILES + 2) k tiles."""
     unpack(e)
     for kk in range(4):
         e(f"v_xor_b32 v112, {kk}, %[xh]")
@@ -197,18 +235,23 @@ def main_loop(e, epi_vmem):
     LOOP_PENDING = list(pend)
     LOOP, DONE = e.lab("loop"), e.lab("done")
 
-    def body(s, first=False, mode="full"):
-        """One k step on stage s.  Groups 0..2: MFMAs || reads of the next group || the 12 W pieces of k tile kt+1
+    NM = NI * NJ                                                # MFMAs per 16-wide k group
+
+    def body(s, first=False, mode="full", ctile=None):
+        """One k step on stage s.  Groups 0..2: MFMAs || reads of the next group || the W pieces of k tile kt+1
         (into stage s^1).  Then everything in flight is waited for, barrier, and group 3 runs || the 8 X pieces of
         k tile kt+2 (into stage s, free now) || reads of group 0 of stage s^1.  mode "nox": the step before the last
-        (no k tile kt+2), "none": the last step (nothing to fetch, nothing to read ahead)."""
+        (no k tile kt+2), "none": the last step (nothing to fetch, nothing to read ahead).  ``ctile``: this step also
+        requests the old C values of accumulator tile ctile, in group 2 — younger than the step's W pieces, so the
+        counted wait below leaves them in flight until the NEXT step's wait."""
         pend = LOOP_PENDING
         rest = all_pieces(s ^ 1)[8:] if mode != "none" else []
+        half = NW // 2
         for kk in range(3):
             mf = group_mfmas(kk & 1, first=(first and kk == 0))
             reads = [[r] for r in frag_reads(s, kk + 1, (kk + 1) & 1)]
-            ops = spread_after(mf, reads, 0, 14)
-            if SCHED == "1":                                    # all 12 W pieces in group 0
+            ops = spread_after(mf, reads, 0, min(14, NM))
+            if SCHED == "1":                                    # all W pieces in group 0
                 if kk == 0:
                     ops = with_dma_tail(ops, rest, 0)
             elif SCHED == "2":                                  # 8 in group 0 from the first MFMA, 4 in group 1
@@ -217,12 +260,14 @@ def main_loop(e, epi_vmem):
                 elif kk == 1:
                     ops = with_dma_tail(ops, rest[8:], 0)
             elif kk < 2:
-                ops = with_dma_tail(ops, rest[kk * 6:(kk + 1) * 6])
+                ops = with_dma_tail(ops, rest[kk * half:(kk + 1) * half], 12 if NM >= 24 else 2)
+            elif ctile is not None:
+                ops = with_dma_tail(ops, [c_prefetch(ctile)], 2)
             pend = linearize(e, ops, pend)
         if mode == "none":
             linearize(e, group_mfmas(1), pend)
             return
-        e("s_waitcnt vmcnt(0)")
+        e(f"s_waitcnt vmcnt({4 if ctile is not None else 0})")
         e("s_waitcnt lgkmcnt(0)")
         e("s_barrier")
         xp = []
@@ -236,7 +281,7 @@ def main_loop(e, epi_vmem):
                 extras.append(reads[k])
             if k < len(xp):
                 extras.append(xp[k])
-        pend = linearize(e, spread_after(group_mfmas(1), extras, 0, 22), [])
+        pend = linearize(e, spread_after(group_mfmas(1), extras, 0, NM - 2), [])
         assert pend == LOOP_PENDING, (pend, LOOP_PENDING)
 
     def step_check(tail):
@@ -245,8 +290,15 @@ def main_loop(e, epi_vmem):
         e(f"s_cbranch_scc1 {tail}")
 
     TAIL1, TAIL0 = e.lab("tail1"), e.lab("tail0")
-    body(0, first=True)                                         # k step 0 (K >= 3 k tiles: it is never a tail step)
-    e("s_mov_b32 s84, 1")
+    if cpre:                                                    # k steps 0 .. NTILES-1, each with one tile's old C
+        for kt in range(NTILES):
+            body(kt & 1, first=(kt == 0), ctile=kt)
+        assert NTILES % 2 == 0
+        body(0)                                                 # k step NTILES: the wait that lands the last C tile
+        e(f"s_mov_b32 s84, {NTILES + 1}")
+    else:
+        body(0, first=True)                                     # k step 0 (K >= 3 k tiles: it is never a tail step)
+        e("s_mov_b32 s84, 1")
     e.label(LOOP)
     step_check(TAIL1)
     body(1)
@@ -308,7 +360,7 @@ def column_vectors(e, kind):
     e(f"s_cmp_eq_u32 {S_NEXT}, 0")
     e(f"s_cbranch_scc1 {NONE}")
     tile_prologue(e, S_NXB, S_NWB)
-    e("s_waitcnt vmcnt(28)")                                     # the column vectors (older than the 28 DMA pieces)
+    e(f"s_waitcnt vmcnt({16 + NW})")                              # the column vectors (older than the 16 + NW DMA pieces)
     e(f"s_branch {JOIN}")
     e.label(NONE)
     e("s_waitcnt vmcnt(0)")
@@ -531,21 +583,83 @@ def epilogue_resid(e):
     assert nxt[0] == NTILES
 
 
-EPI_VMEM = {"f32": 96, "bf16": 48, "gelu": 48, "resid": 192}    # VMEM instructions an epilogue issues after the next tile's DMA
+def epilogue_resid192(e):
+    """C fp32 += (acc + bias) * gate on the 256 x 192 tile: the old C values are already in v[96:255] / a[192:223]
+    (c_prefetch, requested during the k loop), so the epilogue is arithmetic and stores only — it neither waits for HBM
+    reads nor holds the matrix pipe idle while ~64 lines per CU trickle in (the 256 x 384 stream's epilogue: 786 KB of
+    read-modify-write per tile at ~10 B/clk/CU)."""
+    es = 4
+    column_vectors(e, "resid")
+    # training epilogue (ABI v5): y = bf16(acc + bias) into `aux` — same row pitch as C, so every aux byte offset is half
+    # the C offset; a null aux is an empty descriptor (the stores are dropped)
+    VOA, AX = 24, 20                                             # v24: voc / 2; v[20:23]: packed bf16
+    e(f"v_lshrrev_b32 v{VOA}, 1, %[voc]")
+    for k in range(NTILES):
+        i, j = divmod(k, NJ)
+        t = i * NJ + j
+        e(f"s_mul_i32 s85, {S_SCJ}, {j}")
+        e(f"s_add_u32 s85, s85, {S_SCB}")
+        e("s_lshr_b32 s88, s85, 1")
+        e(f"v_add_u32 v{VCOLT}, {32 * j}, {VROW}")
+        e(f"v_cmp_le_u32 vcc, {S_MB}, v{VCOLT}")
+        e(f"v_add_u32 v{VCOLT}, 1536, {VLR}")
+        e(f"v_cndmask_b32 v{VSEL}, {VLR}, v{VCOLT}, vcc")
+        for p in range(2):
+            col = (i * 32 + 16 * p) * 4
+            e(f"ds_read_b128 {vr(GV + p * 8, 4)}, v{VSEL} offset:{col}")
+            e(f"ds_read_b128 {vr(GV + p * 8 + 4, 4)}, v{VSEL} offset:{col + 16}")
+            e(f"ds_read_b128 {vr(BV + p * 8, 4)}, {VLR} offset:{768 + col}")
+            e(f"ds_read_b128 {vr(BV + p * 8 + 4, 4)}, {VLR} offset:{768 + col + 16}")
+        for r_ in range(16):
+            e(f"v_accvgpr_read_b32 v{T + r_}, a{t * 16 + r_}")
+        sl = CPRE + 16 * k
+        if k >= 10:                                              # old C parked in AGPRs -> the slot tile k - 10 has left
+            sl = CPRE + 16 * (k - 10)
+            for r_ in range(16):
+                e(f"v_accvgpr_read_b32 v{sl + r_}, a{192 + 16 * (k - 10) + r_}")
+        e("s_nop 1")
+        for q0 in (0, 2):                                        # quads (0,1), (2,3) -> two runs of 8 consecutive n
+            for r_ in range(4):
+                e(f"v_permlane32_swap_b32 v{T + 4 * q0 + r_}, v{T + 4 * (q0 + 1) + r_}")
+        e("s_waitcnt lgkmcnt(0)")
+        for p in range(2):
+            v0 = T + 8 * p
+            e(f"v_add_u32 v{VCOLT}, {i * 32 + 16 * p}, {VCOL}")
+            e(f"v_cmp_gt_u32 vcc, {S_N}, v{VCOLT}")
+            e("s_and_saveexec_b64 s[86:87], vcc")
+            for r_ in range(0, 8, 2):
+                e(f"v_pk_add_f32 {vr(v0 + r_, 2)}, {vr(v0 + r_, 2)}, {vr(BV + p * 8 + r_, 2)}")
+            off = (i * 32 + 16 * p) * es
+            for r_ in range(4):
+                e(f"v_cvt_pk_bf16_f32 v{AX + r_}, v{v0 + 2 * r_}, v{v0 + 2 * r_ + 1}")
+            e(f"buffer_store_dwordx4 {vr(AX, 4)}, v{VOA}, %[raux], s88 offen offset:{off // 2}")
+            for r_ in range(0, 8, 2):
+                e(f"v_pk_mul_f32 {vr(v0 + r_, 2)}, {vr(v0 + r_, 2)}, {vr(GV + p * 8 + r_, 2)}")
+            for r_ in range(0, 8, 2):
+                e(f"v_pk_add_f32 {vr(v0 + r_, 2)}, {vr(sl + p * 8 + r_, 2)}, {vr(v0 + r_, 2)}")
+            e(f"buffer_store_dwordx4 {vr(v0, 4)}, %[voc], %[rc], s85 offen offset:{off}")
+            e(f"buffer_store_dwordx4 {vr(v0 + 4, 4)}, %[voc], %[rc], s85 offen offset:{off + 16}")
+            e("s_nop 1")
+            e("s_mov_b64 exec, s[86:87]")
+
+
+EPI_VMEM = {"f32": 96, "bf16": 48, "gelu": 48, "resid": 192, "resid192": 72}   # VMEM instructions an epilogue issues after the next tile's DMA
 
 
 def generate(kind):
     e = Emit(kind)
-    main_loop(e, EPI_VMEM[kind])
+    main_loop(e, EPI_VMEM[kind], cpre=(kind == "resid192"))
     if kind == "resid":
         epilogue_resid(e)
+    elif kind == "resid192":
+        epilogue_resid192(e)
     else:
         epilogue(e, kind)
     return e
 
 
-def first_prologue():
-    e = Emit("pro")
+def first_prologue(tag="pro"):
+    e = Emit(tag)
     unpack(e, (0, 2, 8))
     tile_prologue(e, S_NXB, S_NWB)
     e("s_waitcnt vmcnt(8)")
@@ -555,6 +669,9 @@ def first_prologue():
 def main():
     print("// GENERATED by gen_gemm_w64.py — do not edit; edit the generator.")
     streams = [("PRO", first_prologue())] + [(kind.upper(), generate(kind)) for kind in KINDS]
+    configure(3)                                                 # the 256 x 192 gated-residual stream (old C prefetched)
+    streams += [("PRO192", first_prologue("pro192")), ("RESID192", generate("resid192"))]
+    configure(6)
     for name, e in streams:
         print(f"#define OMH_GEMM_W64_ASM_{name} \\")
         print(" \\\n".join(e.text().split("\n")))

@@ -272,8 +272,8 @@ def test_training_step_full_size_properties():
 # floor, and it gets its own absolute-scale bound.
 TOL_FULL_LOSS = 1e-3
 TOL_FULL_GRAD = 2e-2
-TOL_FULL_GRAD_1D = 2e-2
-TOL_FULL_GRAD_NULL = 1.1e-1
+TOL_FULL_GRAD_1D = 2.2e-2       # all 1-D parameters: 1.09e-2 measured (blocks.11.cross_attn.norm_k.weight)
+TOL_FULL_GRAD_NULL = 1.1e-1     # 5.1e-2 measured
 
 
 def _null_gradient(name):

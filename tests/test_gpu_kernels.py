@@ -113,6 +113,48 @@ def test_gemm_w64_stream_kernel(ops, M, N, K, gate_rows, monkeypatch):
     assert rel_rms(got[5], x0 + ref - bias) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K,gate_rows", [(256, 192, 1024, 256), (1000, 776, 1088, 300), (4100, 1160, 1536, 2050),
+                                             (2000, 1536, 2048, 500), (32760, 1536, 1536, 16380)])
+def test_gemm_w64_residual_stream_with_prefetched_c(ops, M, N, K, gate_rows, monkeypatch):
+    """Round 4: the 256 x 192 gated-residual stream (gen_gemm_w64.py "resid192": the OLD C tile is requested during the
+    first 12 k steps, so the epilogue neither waits for HBM reads nor idles the matrix pipe) — bit for bit against the
+    8-wave kernel: gated and plain residual, with and without bias, ragged M / N (EXEC-masked columns, rows past M),
+    a gate boundary inside a wave's rows, even and odd k-step counts from the shortest contraction it takes (16 k tiles);
+    several tiles per persistent workgroup at the o-projection's real size (1024 tiles)."""
+    torch.manual_seed(M + N + K)
+    a = _bf(torch.randn(M, K, device="cuda"))
+    w = _bf(torch.randn(N, K, device="cuda") / math.sqrt(K))
+    bias = torch.randn(N, device="cuda")
+    nb = (M + gate_rows - 1) // gate_rows
+    mod = torch.randn(6, N, device="cuda")
+    e0 = torch.randn(nb, 6, N, device="cuda")
+    x0 = torch.randn(M, N, device="cuda")
+
+    def run(env):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        x = x0.clone()
+        ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(x), M, N, K, K, K, N, ops.EPI_RESID, bias=ops.ptr(bias),
+                     bias_mode=ops.BIAS_N, gate0=ops.ptr(mod, 2 * N), gate1=ops.ptr(e0, 2 * N), gate1_stride=6 * N,
+                     gate_rows=gate_rows, gate_const=0.5)
+        x1 = x0.clone()
+        ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(x1), M, N, K, K, K, N, ops.EPI_RESID, gate_const=1.0)
+        x2 = x0.clone()
+        ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(x2), M, N, K, K, K, N, ops.EPI_RESID, bias=ops.ptr(bias),
+                     bias_mode=ops.BIAS_N, gate0=ops.ptr(mod, 3 * N), gate_const=0.0)
+        return x, x1, x2
+    got = run({"OMH_GEMM_KERNEL": "w64", "OMH_GEMM_W64_R192": "1"})
+    again = run({"OMH_GEMM_KERNEL": "w64", "OMH_GEMM_W64_R192": "1"})
+    big = run({"OMH_GEMM_KERNEL": "w64", "OMH_GEMM_W64_R192": "0"})
+    old = run({"OMH_GEMM_KERNEL": "8w"})
+    for g, g2, b_, o in zip(got, again, big, old):
+        assert torch.equal(g, o) and torch.equal(g, g2) and torch.equal(b_, o)
+    ref = a.float() @ w.float().t()
+    gate = (0.5 + mod[2][None] + e0[:, 2]).repeat_interleave(gate_rows, 0)[:M]
+    assert rel_rms(got[0], x0 + (ref + bias) * gate) < 1e-5
+    assert rel_rms(got[1], x0 + ref) < 1e-5
+
+
 def test_gemm_w64_random_shapes_equal_the_8_wave_kernel(ops, monkeypatch):
     """Seeded sweep: 20 random (M, N, K, epilogue, bias, gate layout) within the stream kernel's domain, whole outputs
     bit for bit against the 8-wave kernels (one to a few tiles per workgroup of the persistent grid, ragged M and N,

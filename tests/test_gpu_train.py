@@ -18,8 +18,11 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # against the autograd oracle (t2v 13 layers, both freeze settings, i2v); 1-D parameters (bias / gain gradients: long
 # sums with heavy cancellation) <= 4.5e-2.  Bounds = 2 x measured.
 TOL_GRAD = 2e-2
-TOL_GRAD_NULL = 1.3e-1      # gradients that vanish identically (cross-attention K bias): noise vs a floor, 2 x 6.2e-2
-TOL_GRAD_1D = 9e-2          # vs the autograd oracle: 6.2e-2 / 5.9e-2 / 4.5e-2 measured (profiles/r03_measured_gradient_errors.txt)
+# Round 4 (profiles/r04_measured_parity_figures.txt), bounds = 2 x measured: the 6.2e-2 / 4.5e-2 of round 3 were the
+# cross-attention K biases — gradients that vanish identically (softmax shift invariance), i.e. rounding noise against a
+# floor; every other 1-D parameter is within 1.9e-2 (worst: blocks.3.self_attn.k.bias).
+TOL_GRAD_NULL = 1.4e-1      # identically-null gradients: 6.8e-2 measured
+TOL_GRAD_1D = 4e-2          # 1.87e-2 measured
 
 
 def _setup(wan_model_mod, freeze=True):
@@ -309,10 +312,13 @@ def test_i2v_training_gradients(wan_model_mod):
             continue
         assert p.grad is not None, name
         err = float((p.grad.double().cpu() - og.double()).norm() / max(float(og.double().norm()), floor))
-        worst[min(og.dim(), 2)] = max(worst[min(og.dim(), 2)], err)
-        if err > (TOL_GRAD if og.dim() > 1 else TOL_GRAD_1D):
+        null = name.endswith("cross_attn.k.bias") or name.endswith("cross_attn.k_img.bias")   # identically-null gradients
+        kind = 0 if null else min(og.dim(), 2)
+        worst[kind] = max(worst.get(kind, 0.0), err)
+        if err > (TOL_GRAD_NULL if null else TOL_GRAD if og.dim() > 1 else TOL_GRAD_1D):
             bad.append((name, err))
-    print(f"[measured] i2v gradients vs autograd oracle: worst matrix {worst[2]:.3e}, worst 1-D {worst[1]:.3e}")
+    print(f"[measured] i2v gradients vs autograd oracle: worst matrix {worst[2]:.3e}, worst 1-D {worst[1]:.3e}, "
+          f"identically-null {worst.get(0, 0.0):.3e}")
     assert not bad, bad[:10]
 
 
