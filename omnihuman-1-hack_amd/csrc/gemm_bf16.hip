@@ -543,8 +543,12 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
             const bool off = r192 && r192[0] == '0', on = r192 && r192[0] == '1';
             const bool never192 = (gk && gk[0] == '8') || (!force && getenv("OMH_GEMM_TILE"));
             if (!never192 && !off && omh_gemm_w64_r192_takes(a)) {          // (also the training epilogues: c_in, aux)
+                // measured (round 4, one box, R192 = 0 / 1): 32760 x 1536 x 1536 206 -> 186 us, 21840 rows 148 -> 119,
+                // 6240 rows 51 -> 39 (K = 8960: 177 -> 151), 3120 rows 33.5 -> 35.4 (too few tiles), 32760 x 1536 x 8960
+                // 697 -> 840 (a long k loop amortises the big stream's epilogue: stays there)
                 const int64_t t192 = (int64_t)((a.M + 255) / 256) * ((a.N + 191) / 192);
-                if (on || (a.K <= 3072 && t192 >= 192)) {
+                const int64_t t384 = (int64_t)((a.M + 255) / 256) * ((a.N + 383) / 384);
+                if (on || (t192 >= 192 && (a.K <= 3072 || t384 < 256))) {
                     omh_clear_status();
                     omh_launch_gemm_w64_r192(a, s);
                     return omh_launch_status();
