@@ -481,6 +481,8 @@ int omh_launch_gemm_w64(const omh_gemm_args& a, hipStream_t stream);
 // ... and its 256 x 192 gated-residual variant with the old C tile prefetched during the k loop
 bool omh_gemm_w64_r192_takes(const omh_gemm_args& a);
 int omh_launch_gemm_w64_r192(const omh_gemm_args& a, hipStream_t stream);
+bool omh_gemm_w64_n192_takes(const omh_gemm_args& a);
+int omh_launch_gemm_w64_n192(const omh_gemm_args& a, hipStream_t stream);
 
 static int launch_8w(const omh_gemm_args& a, hipStream_t s) {
     switch (a.epilogue) {
@@ -551,6 +553,21 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
                 if (on || (t192 >= 192 && (a.K <= 3072 || t384 < 256))) {
                     omh_clear_status();
                     omh_launch_gemm_w64_r192(a, s);
+                    return omh_launch_status();
+                }
+            }
+        }
+        // plain fp32 / bf16 products too small for the 256 x 384 stream (< 128 of its tiles) but with 160 .. 256 tiles
+        // of 256 x 192: one round of the narrow stream (OMH_GEMM_W64_N192 = 0 / 1: off / wherever it applies)
+        {
+            const char* n192 = getenv("OMH_GEMM_W64_N192");
+            const bool off = n192 && n192[0] == '0', on = n192 && n192[0] == '1';
+            if (!never && !off && omh_gemm_w64_n192_takes(a)) {
+                const int64_t t192 = (int64_t)((a.M + 255) / 256) * ((a.N + 191) / 192);
+                const int64_t t384 = (int64_t)((a.M + 255) / 256) * ((a.N + 383) / 384);
+                if (on || (!force && t384 < 128 && t192 >= 160 && t192 <= 256)) {
+                    omh_clear_status();
+                    omh_launch_gemm_w64_n192(a, s);
                     return omh_launch_status();
                 }
             }

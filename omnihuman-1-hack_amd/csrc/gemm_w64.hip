@@ -16,7 +16,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, int64_t
     return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)n, 0x00020000);
 }
 
-enum { K_F32 = 0, K_BF16 = 1, K_GELU = 2, K_RESID = 3, K_RESID192 = 4 };
+enum { K_F32 = 0, K_BF16 = 1, K_GELU = 2, K_RESID = 3, K_RESID192 = 4, K_F32_192 = 5, K_BF16_192 = 6 };   // >= 4: 256 x 192
 
 // two wave-uniform 32-bit scalars in one SGPR pair (inline asm takes at most 30 operands)
 __device__ __forceinline__ uint64_t pack2(uint32_t lo, uint32_t hi) {
@@ -46,10 +46,10 @@ __device__ __forceinline__ W64Tile w64_tile(const omh_gemm_args& p, int idx, int
 template <int KIND>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int tiles_n) {
-    constexpr int TNW = KIND == K_RESID192 ? TN192 : TN;                    // tile width; a wave owns TNW / 2 columns
+    constexpr int TNW = KIND >= K_RESID192 ? TN192 : TN;                    // tile width; a wave owns TNW / 2 columns
     constexpr int WBYTES = TNW * 128, STAGE_B = 32768 + WBYTES;             // W tile, one stage (X 32 KiB | W)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_B];
-    constexpr int ES = (KIND == K_BF16 || KIND == K_GELU) ? 2 : 4;
+    constexpr int ES = (KIND == K_BF16 || KIND == K_GELU || KIND == K_BF16_192) ? 2 : 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1;
@@ -99,7 +99,7 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
 
     int idx = blockIdx.x;
     W64Tile t = w64_tile<TNW>(p, idx, tiles_m, tiles_n, w);
-    if (KIND == K_RESID192) {
+    if (KIND >= K_RESID192) {
         const uint64_t p8 = pack2(t.sxb, t.swb);
         asm volatile(OMH_GEMM_W64_ASM_PRO192
                      :
@@ -142,6 +142,8 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
         else if (KIND == K_BF16) OMH_GW64_RUN(OMH_GEMM_W64_ASM_BF16);
         else if (KIND == K_GELU) OMH_GW64_RUN(OMH_GEMM_W64_ASM_GELU);
         else if (KIND == K_RESID) OMH_GW64_RUN(OMH_GEMM_W64_ASM_RESID);
+        else if (KIND == K_F32_192) OMH_GW64_RUN(OMH_GEMM_W64_ASM_F32_192);
+        else if (KIND == K_BF16_192) OMH_GW64_RUN(OMH_GEMM_W64_ASM_BF16_192);
         else
             asm volatile(OMH_GEMM_W64_ASM_RESID192
                  :
@@ -161,7 +163,7 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
 
 template <int KIND>
 int launch_w64(const omh_gemm_args& a, hipStream_t stream) {
-    constexpr int TNW = KIND == K_RESID192 ? TN192 : TN;
+    constexpr int TNW = KIND >= K_RESID192 ? TN192 : TN;
     const int tiles_m = (a.M + TM - 1) / TM, tiles_n = (a.N + TNW - 1) / TNW;
     const int total = tiles_m * tiles_n;
     static int ncu = 0;
@@ -205,6 +207,14 @@ bool omh_gemm_w64_r192_takes(const omh_gemm_args& a) {
     return a.epilogue == OMH_EPI_RESID && omh_gemm_w64_takes(a) && a.K >= 16 * BK;
 }
 int omh_launch_gemm_w64_r192(const omh_gemm_args& a, hipStream_t stream) { return launch_w64<K_RESID192>(a, stream); }
+// The same 256 x 192 tile for the plain fp32 / bf16 epilogues: twice the tiles of the 256 x 384 stream, for products whose
+// 256 x 384 tiles would fill less than half of the chip (the training step's M = 6 240: 100 tiles -> 200).
+bool omh_gemm_w64_n192_takes(const omh_gemm_args& a) {
+    return (a.epilogue == OMH_EPI_F32 || a.epilogue == OMH_EPI_BF16) && omh_gemm_w64_takes(a);
+}
+int omh_launch_gemm_w64_n192(const omh_gemm_args& a, hipStream_t stream) {
+    return a.epilogue == OMH_EPI_F32 ? launch_w64<K_F32_192>(a, stream) : launch_w64<K_BF16_192>(a, stream);
+}
 
 int omh_launch_gemm_w64(const omh_gemm_args& a, hipStream_t stream) {
     switch (a.epilogue) {

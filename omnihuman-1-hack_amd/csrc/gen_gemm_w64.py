@@ -643,12 +643,14 @@ def epilogue_resid192(e):
             e("s_mov_b64 exec, s[86:87]")
 
 
-EPI_VMEM = {"f32": 96, "bf16": 48, "gelu": 48, "resid": 192, "resid192": 72}   # VMEM instructions an epilogue issues after the next tile's DMA
+# VMEM instructions PER ACCUMULATOR TILE an epilogue issues after the next tile's prologue DMA (the k loop's first wait
+# counts them: an over-estimate would let k tile 0 be read before it has landed)
+EPI_VMEM_TILE = {"f32": 4, "bf16": 2, "gelu": 2, "resid": 8, "resid192": 6}
 
 
-def generate(kind):
-    e = Emit(kind)
-    main_loop(e, EPI_VMEM[kind], cpre=(kind == "resid192"))
+def generate(kind, tag=None):
+    e = Emit(tag or kind)
+    main_loop(e, EPI_VMEM_TILE[kind] * NTILES, cpre=(kind == "resid192"))
     if kind == "resid":
         epilogue_resid(e)
     elif kind == "resid192":
@@ -670,7 +672,8 @@ def main():
     print("// GENERATED by gen_gemm_w64.py — do not edit; edit the generator.")
     streams = [("PRO", first_prologue())] + [(kind.upper(), generate(kind)) for kind in KINDS]
     configure(3)                                                 # the 256 x 192 gated-residual stream (old C prefetched)
-    streams += [("PRO192", first_prologue("pro192")), ("RESID192", generate("resid192"))]
+    streams += [("PRO192", first_prologue("pro192")), ("RESID192", generate("resid192")),
+                ("F32_192", generate("f32", "f32n3")), ("BF16_192", generate("bf16", "bf16n3"))]
     configure(6)
     for name, e in streams:
         print(f"#define OMH_GEMM_W64_ASM_{name} \\")

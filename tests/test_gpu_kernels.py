@@ -155,6 +155,30 @@ def test_gemm_w64_residual_stream_with_prefetched_c(ops, M, N, K, gate_rows, mon
     assert rel_rms(got[1], x0 + ref) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 192, 256), (1000, 776, 320), (6240, 1536, 1536), (6240, 1536, 4608), (4100, 1160, 448)])
+def test_gemm_w64_narrow_streams(ops, M, N, K, monkeypatch):
+    """The 256 x 192 fp32 / bf16 streams (the training step's M = 6 240 products: 200 tiles instead of 100 of 256 x 384):
+    bit for bit against the 8-wave kernels, with and without bias, ragged shapes, odd and even k-step counts."""
+    torch.manual_seed(M + K)
+    a = _bf(torch.randn(M, K, device="cuda"))
+    w = _bf(torch.randn(N, K, device="cuda") / math.sqrt(K))
+    bias = torch.randn(N, device="cuda")
+
+    def run(env):
+        for k_ in ("OMH_GEMM_KERNEL", "OMH_GEMM_W64_N192"):
+            monkeypatch.delenv(k_, raising=False)
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        return (ops.gemm(a, w, bias=bias, epilogue=ops.EPI_F32), ops.gemm(a, w, epilogue=ops.EPI_F32),
+                ops.gemm(a, w, bias=bias, epilogue=ops.EPI_BF16), ops.gemm(a, w, epilogue=ops.EPI_BF16))
+    got, again, old = run({"OMH_GEMM_W64_N192": "1"}), run({"OMH_GEMM_W64_N192": "1"}), run({"OMH_GEMM_KERNEL": "8w"})
+    for g, g2, o in zip(got, again, old):
+        assert torch.equal(g, o) and torch.equal(g, g2)
+    assert rel_rms(got[0], a.float() @ w.float().t() + bias) < 2e-5
+    dflt = run({})                                                  # the default dispatch gives the same bits, whichever kernel
+    assert all(torch.equal(d_, o) for d_, o in zip(dflt, old))
+
+
 def test_gemm_w64_random_shapes_equal_the_8_wave_kernel(ops, monkeypatch):
     """Seeded sweep: 20 random (M, N, K, epilogue, bias, gate layout) within the stream kernel's domain, whole outputs
     bit for bit against the 8-wave kernels (one to a few tiles per workgroup of the persistent grid, ragged M and N,
