@@ -554,10 +554,9 @@ def test_attention_tail_split_matches_the_unsplit_launch(ops, monkeypatch, B, H,
     for g, r, t_, nm in zip(dflt, ref, got, ("dq", "dk", "dv")):
         if B == 1:
             assert torch.equal(g, t_), nm
-        elif nm == "dq" or Lk == Lq:
-            assert torch.equal(g, r), nm                                 # 624 workgroups: more than one round
         else:
-            assert torch.equal(g, t_), nm                                # cross-attention dK / dV: 192 workgroups on 256 CUs
+            assert torch.equal(g, r), nm                                 # 624 (192: dK / dV of the cross-attention) workgroups:
+                                                                         # the chip is (nearly) full, nothing is split
     od, _, lsed = fwd(ops.ATTN_SHORT_KERNEL | ops.ATTN_ALLOW_SPLIT)
     assert torch.equal(od, o0) and torch.equal(lsed, lse0)               # 25 / 8 key tiles: the forward is not split
 
