@@ -664,7 +664,7 @@ static OmhSplitPlan base_split_plan(const omh_attn_args& a) {
     // lse outputs are all HBM traffic): the forward's split only pays on long key loops — 16 key tiles per worker, and
     // only launches that do not fill the chip once.  OMH_ATTN_SPLIT=tail: 4 tiles per worker, any launch (tests, A/B).
     const bool tail = e && e[0] == 't';
-    return omh_tail_split_plan(nwg, 2 * omh_cu_count(), (a.Lk + KB - 1) / KB, tail ? 4 : 16, !tail);
+    return omh_tail_split_plan(nwg, 2 * omh_cu_count(), (a.Lk + KB - 1) / KB, tail ? 4 : 16, !tail, tail ? 0.8 : 0.67);
 }
 int64_t omh_attn_base_workspace_bytes(const omh_attn_args& a) {
     const AttnChoice ch = attn_choice(a);

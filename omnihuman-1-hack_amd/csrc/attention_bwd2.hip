@@ -501,7 +501,7 @@ static OmhSplitPlan bwd2_plan(const omh_attn_bwd_args& a, bool dq) {
     if (e && e[0] == '0') return none;
     // OMH_ATTN_SPLIT=tail: also the last round of a launch that fills the chip (measured: no gain, omh_common.h)
     const bool tail = e && e[0] == 't';
-    return omh_tail_split_plan(nwg, (dq ? 2 : 1) * omh_cu_count(), ((dq ? a.Lk : a.Lq) + TB - 1) / TB, 4, !tail);
+    return omh_tail_split_plan(nwg, (dq ? 2 : 1) * omh_cu_count(), ((dq ? a.Lk : a.Lq) + TB - 1) / TB, 4, !tail, tail ? 0.8 : 0.67);
 }
 static int64_t bwd2_ws_bytes(const OmhSplitPlan& pl, int nout) {
     return (int64_t)pl.n_tail * pl.splits * nout * 128 * D * 4;

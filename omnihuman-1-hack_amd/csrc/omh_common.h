@@ -131,7 +131,8 @@ static inline int omh_launch_status() {
 // of the kernel and the combine pass (10 us: the partial results are HBM traffic) takes that back; a launch of 156
 // workgroups (one clip) on 256 CUs gains 25-37 % before the combine.
 struct OmhSplitPlan { int n_regular, n_tail, splits; };
-static inline OmhSplitPlan omh_tail_split_plan(int nwg, int slots, int loop_tiles, int min_tiles, bool single_round_only = false) {
+static inline OmhSplitPlan omh_tail_split_plan(int nwg, int slots, int loop_tiles, int min_tiles, bool single_round_only = false,
+                                               double max_cost = 0.67) {
     OmhSplitPlan pl = {nwg, 0, 1};
     if (nwg <= 0 || slots <= 0) return pl;
     if (single_round_only && nwg >= slots) return pl;
@@ -147,7 +148,7 @@ static inline OmhSplitPlan omh_tail_split_plan(int nwg, int slots, int loop_tile
     }
     // at least a third of the round must go: 192 workgroups on 256 slots split 4 ways (0.75 of a round on paper)
     // measured 0.9 % SLOWER per training step at 4 clips — a lone workgroup already has its CU to itself
-    if (best_s < 2 || best > 0.67) return pl;
+    if (best_s < 2 || best > max_cost) return pl;
     pl.n_tail = r;
     pl.n_regular = nwg - r;
     pl.splits = best_s;
