@@ -537,7 +537,15 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
         // OMH_GEMM_KERNEL = "w64": the 256 x 384 stream kernel wherever it applies; "8w": never; unset: where it
         // applies AND fills the chip (>= 256 tiles, last round of tiles at least 3/4 full or >= 4 rounds)
         const char* gk = getenv("OMH_GEMM_KERNEL");
-        const bool force = gk && gk[0] == 'w', never = v5 || (gk && gk[0] == '8') || (!force && getenv("OMH_GEMM_TILE"));
+        // (the fused training epilogues stay on the 8-wave kernels — except GELU_BWD, which the big stream has, and the
+        // out-of-place / aux-writing gated residual, which the 256 x 192 stream has)
+        // GELU_BWD on the 256 x 384 stream: built and bit-identical (test_gemm_w64_gelu_backward_stream), but measured EQUAL
+        // to the 8-wave kernel in isolation (6240 x 8960 x 1536: 204-225 vs 202-208 us; 1560 rows 58 vs 56-62) — the 357 us
+        // the 8-wave kernel shows inside a training step is the weight-gradient stream sharing the chip, not the kernel.
+        // Opt-in: OMH_GEMM_W64_GBWD=1.
+        const char* gbwd = getenv("OMH_GEMM_W64_GBWD");
+        const bool v5_8w = v5 && !(a.epilogue == OMH_EPI_GELU_BWD_BF16 && !a.c_in && gbwd && gbwd[0] == '1');
+        const bool force = gk && gk[0] == 'w', never = v5_8w || (gk && gk[0] == '8') || (!force && getenv("OMH_GEMM_TILE"));
         // gated residual with a short contraction (o-projections: K = dim): the 256 x 192 stream that requests the old C
         // tile during its k loop.  OMH_GEMM_W64_R192 = 0 / 1 forces it off / on (A/B timing, tests).
         {

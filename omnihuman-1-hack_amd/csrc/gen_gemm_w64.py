@@ -583,6 +583,99 @@ def epilogue_resid(e):
     assert nxt[0] == NTILES
 
 
+def epilogue_gelubwd(e):
+    """C bf16 = (acc + bias) * gelu_tanh'(aux): the FFN dgrad GEMM of the training step (du_pre = (dy W2) gelu'(u_pre),
+    model.py:272-274 under autograd; OMH_EPI_GELU_BWD_BF16).  aux = the bf16 pre-activations, same shape and row pitch as
+    C, so a lane's aux bytes sit at its C store offset; they are requested two accumulator tiles ahead (ring of three
+    8-register slots).  gelu_tanh_grad of omh_common.h operation by operation (same bits as the 8-wave kernel):
+        s = rcp(1 + exp2((k x) fma(a, x^2, 1)));  g = fma((x 2c) fma(3a, x^2, 1), s (1 - s), s)."""
+    es = 2
+    column_vectors(e, "bf16")
+    AR = 80                                                      # v[80:103]: ring of three tiles' aux words (2 x 4 each)
+    X, X2, TT, SS = 104, 112, 120, 20                            # v[104:111] x, v[112:119] x^2, v[120:127] temporaries, v[20:27] s
+    KA, K1, KK, K2C, K3A, KM1 = 48, 50, 52, 54, 56, 58           # constant pairs in v[48:59] (GV is free for this kind)
+    for r_, val in ((KA, "0x3d372713"), (K1, "1.0"), (KK, "0xc0135761"), (K2C, "0x3fcc422a"), (K3A, "0x3e095d4e"),
+                    (KM1, "-1.0")):
+        e(f"v_mov_b32 v{r_}, {val}")
+        e(f"v_mov_b32 v{r_ + 1}, {val}")
+
+    def aux_loads(n):
+        i = n % NI
+        for p in range(2):
+            e(f"buffer_load_dwordx4 {vr(AR + (n % 3) * 8 + p * 4, 4)}, %[voc], %[raux], s88 offen offset:{(i * 32 + 16 * p) * es}")
+
+    e(f"s_mov_b32 s85, {S_SCB}")
+    e(f"s_mov_b32 s88, {S_SCB}")
+    aux_loads(0)
+    aux_loads(1)
+    for n in range(NTILES):
+        j, i = divmod(n, NI)
+        t = i * NJ + j
+        if i == 0 and j:
+            e(f"s_add_u32 s85, s85, {S_SCJ}")
+            e(f"v_add_u32 {VROW}, 32, {VROW}")
+        if n + 2 < NTILES:
+            if (n + 2) % NI == 0:
+                e(f"s_add_u32 s88, s88, {S_SCJ}")
+            aux_loads(n + 2)
+        for p in range(2):
+            col = (i * 32 + 16 * p) * 4
+            e(f"ds_read_b128 {vr(BV + p * 8, 4)}, {VLR} offset:{768 + col}")
+            e(f"ds_read_b128 {vr(BV + p * 8 + 4, 4)}, {VLR} offset:{768 + col + 16}")
+        for r_ in range(16):
+            if t < 16:
+                e(f"v_accvgpr_read_b32 v{T + r_}, a{t * 16 + r_}")
+            else:
+                e(f"v_mov_b32 v{T + r_}, v{128 + (t - 16) * 16 + r_}")
+        e("s_nop 1")
+        for q0 in (0, 2):
+            for r_ in range(4):
+                e(f"v_permlane32_swap_b32 v{T + 4 * q0 + r_}, v{T + 4 * (q0 + 1) + r_}")
+        e("s_waitcnt lgkmcnt(0)")
+        # in issue order behind tile n's aux loads: S(n-2) L(n+1) S(n-1) L(n+2), two instructions each
+        behind = 2 * ((n >= 2) + (n + 1 < NTILES) + (n >= 1) + (n + 2 < NTILES))
+        e(f"s_waitcnt vmcnt({behind})")
+        for p in range(2):
+            v0 = T + 8 * p
+            aw = AR + (n % 3) * 8 + p * 4
+            e(f"v_add_u32 v{VCOLT}, {i * 32 + 16 * p}, {VCOL}")
+            e(f"v_cmp_gt_u32 vcc, {S_N}, v{VCOLT}")
+            e("s_and_saveexec_b64 s[86:87], vcc")
+            for r_ in range(0, 8, 2):
+                e(f"v_pk_add_f32 {vr(v0 + r_, 2)}, {vr(v0 + r_, 2)}, {vr(BV + p * 8 + r_, 2)}")
+            for w_ in range(4):                                  # bf16 pair -> two fp32
+                e(f"v_lshlrev_b32 v{X + 2 * w_}, 16, v{aw + w_}")
+                e(f"v_and_b32 v{X + 2 * w_ + 1}, 0xffff0000, v{aw + w_}")
+            for q in range(4):
+                x, x2, tt = X + 2 * q, X2 + 2 * q, TT + 2 * q
+                e(f"v_pk_mul_f32 {vr(x2, 2)}, {vr(x, 2)}, {vr(x, 2)}")                       # x^2
+                e(f"v_pk_mul_f32 {vr(tt, 2)}, {vr(KK, 2)}, {vr(x, 2)}")                      # k x
+                e(f"v_pk_fma_f32 {vr(SS + 2 * q, 2)}, {vr(KA, 2)}, {vr(x2, 2)}, {vr(K1, 2)}")  # fma(a, x^2, 1)
+                e(f"v_pk_mul_f32 {vr(tt, 2)}, {vr(tt, 2)}, {vr(SS + 2 * q, 2)}")             # (k x) * ...
+            for q in range(8):
+                e(f"v_exp_f32 v{TT + q}, v{TT + q}")
+            for q in range(4):
+                e(f"v_pk_add_f32 {vr(TT + 2 * q, 2)}, {vr(K1, 2)}, {vr(TT + 2 * q, 2)}")      # 1 + 2^t
+            for q in range(8):
+                e(f"v_rcp_f32 v{SS + q}, v{TT + q}")                                         # s
+            e("s_nop 0")
+            for q in range(4):
+                x, x2, tt, ss = X + 2 * q, X2 + 2 * q, TT + 2 * q, SS + 2 * q
+                e(f"v_pk_mul_f32 {vr(x, 2)}, {vr(x, 2)}, {vr(K2C, 2)}")                      # x * 2c
+                e(f"v_pk_fma_f32 {vr(x2, 2)}, {vr(K3A, 2)}, {vr(x2, 2)}, {vr(K1, 2)}")       # fma(3a, x^2, 1)
+                e(f"v_pk_mul_f32 {vr(x, 2)}, {vr(x, 2)}, {vr(x2, 2)}")                       # w
+                e(f"v_pk_fma_f32 {vr(tt, 2)}, {vr(ss, 2)}, {vr(KM1, 2)}, {vr(K1, 2)}")       # 1 - s
+                e(f"v_pk_mul_f32 {vr(tt, 2)}, {vr(ss, 2)}, {vr(tt, 2)}")                     # s (1 - s)
+                e(f"v_pk_fma_f32 {vr(tt, 2)}, {vr(x, 2)}, {vr(tt, 2)}, {vr(ss, 2)}")         # g = fma(w, s(1-s), s)
+                e(f"v_pk_mul_f32 {vr(v0 + 2 * q, 2)}, {vr(v0 + 2 * q, 2)}, {vr(tt, 2)}")     # v *= g
+            off = (i * 32 + 16 * p) * es
+            for r_ in range(4):
+                e(f"v_cvt_pk_bf16_f32 v{v0 + r_}, v{v0 + 2 * r_}, v{v0 + 2 * r_ + 1}")
+            e(f"buffer_store_dwordx4 {vr(v0, 4)}, %[voc], %[rc], s85 offen offset:{off}")
+            e("s_nop 1")
+            e("s_mov_b64 exec, s[86:87]")
+
+
 def epilogue_resid192(e):
     """C fp32 += (acc + bias) * gate on the 256 x 192 tile: the old C values are already in v[96:255] / a[192:223]
     (c_prefetch, requested during the k loop), so the epilogue is arithmetic and stores only — it neither waits for HBM
@@ -645,7 +738,7 @@ def epilogue_resid192(e):
 
 # VMEM instructions PER ACCUMULATOR TILE an epilogue issues after the next tile's prologue DMA (the k loop's first wait
 # counts them: an over-estimate would let k tile 0 be read before it has landed)
-EPI_VMEM_TILE = {"f32": 4, "bf16": 2, "gelu": 2, "resid": 8, "resid192": 6}
+EPI_VMEM_TILE = {"f32": 4, "bf16": 2, "gelu": 2, "resid": 8, "resid192": 6, "gelubwd": 4}
 
 
 def generate(kind, tag=None):
@@ -655,6 +748,8 @@ def generate(kind, tag=None):
         epilogue_resid(e)
     elif kind == "resid192":
         epilogue_resid192(e)
+    elif kind == "gelubwd":
+        epilogue_gelubwd(e)
     else:
         epilogue(e, kind)
     return e
@@ -670,7 +765,7 @@ def first_prologue(tag="pro"):
 
 def main():
     print("// GENERATED by gen_gemm_w64.py — do not edit; edit the generator.")
-    streams = [("PRO", first_prologue())] + [(kind.upper(), generate(kind)) for kind in KINDS]
+    streams = [("PRO", first_prologue())] + [(kind.upper(), generate(kind)) for kind in KINDS + ("gelubwd",)]
     configure(3)                                                 # the 256 x 192 gated-residual stream (old C prefetched)
     streams += [("PRO192", first_prologue("pro192")), ("RESID192", generate("resid192")),
                 ("F32_192", generate("f32", "f32n3")), ("BF16_192", generate("bf16", "bf16n3"))]

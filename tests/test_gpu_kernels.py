@@ -179,6 +179,39 @@ def test_gemm_w64_narrow_streams(ops, M, N, K, monkeypatch):
     assert all(torch.equal(d_, o) for d_, o in zip(dflt, old))
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 384, 256), (1000, 776, 320), (6240, 8960, 1536), (4100, 1160, 448)])
+def test_gemm_w64_gelu_backward_stream(ops, M, N, K, monkeypatch):
+    """Round 4: the FFN dgrad product with GELU' in its epilogue (OMH_EPI_GELU_BWD_BF16: du_pre = (dy W2) gelu'(u_pre)) on
+    the 256 x 384 stream — bit for bit against the 8-wave kernel (gelu_tanh_grad operation by operation), and against
+    autograd's derivative of the tanh GELU."""
+    torch.manual_seed(M + N)
+    a = _bf(torch.randn(M, K, device="cuda"))
+    w = _bf(torch.randn(N, K, device="cuda") / math.sqrt(K))
+    pre = _bf(torch.randn(M, N, device="cuda") * 1.5)
+
+    monkeypatch.setenv("OMH_GEMM_W64_GBWD", "1")                    # opt-in: measured equal to the 8-wave kernel, not the default
+
+    def run(kernel):
+        monkeypatch.setenv("OMH_GEMM_KERNEL", kernel)
+        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(out), M, N, K, K, K, N, ops.EPI_GELU_BWD_BF16, aux=ops.ptr(pre), ldaux=N)
+        return out
+    got, again, old = run("w64"), run("w64"), run("8w")
+    assert torch.equal(got, old) and torch.equal(got, again)
+    xf = pre.float().requires_grad_(True)
+    torch.nn.functional.gelu(xf, approximate="tanh").sum().backward()
+    ref = (a.float() @ w.float().t()) * xf.grad
+    assert rel_rms(got.float(), ref) < 5e-3
+    monkeypatch.delenv("OMH_GEMM_KERNEL")
+    assert torch.equal(run_default(ops, a, w, pre, M, N, K), old)      # whichever kernel the dispatch picks: the same bits
+
+
+def run_default(ops, a, w, pre, M, N, K):
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(out), M, N, K, K, K, N, ops.EPI_GELU_BWD_BF16, aux=ops.ptr(pre), ldaux=N)
+    return out
+
+
 def test_gemm_w64_random_shapes_equal_the_8_wave_kernel(ops, monkeypatch):
     """Seeded sweep: 20 random (M, N, K, epilogue, bias, gate layout) within the stream kernel's domain, whole outputs
     bit for bit against the 8-wave kernels (one to a few tiles per workgroup of the persistent grid, ragged M and N,
