@@ -7,6 +7,14 @@ a = torch.randn(S, K, device="cuda").to(torch.bfloat16)
 w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).to(torch.bfloat16)
 bias = torch.randn(N, device="cuda")
 out = torch.empty(S, N, dtype=torch.bfloat16, device="cuda")
+epi = os.environ.get("EPI", "gelu")
+if epi == "resid":                      # the o-projection's epilogue: x += (a W^T + b) * gate, fp32 read-modify-write
+    x = torch.randn(S, N, device="cuda")
+    mod, e0 = torch.randn(6, N, device="cuda"), torch.randn(1, 6, N, device="cuda")
 for _ in range(3):
-    ops.gemm(a, w, out=out, bias=bias, epilogue=ops.EPI_GELU_BF16 if os.environ.get("EPI", "gelu") == "gelu" else ops.EPI_BF16)
+    if epi == "resid":
+        ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(x), S, N, K, K, K, N, ops.EPI_RESID, bias=ops.ptr(bias), bias_mode=ops.BIAS_N,
+                     gate0=ops.ptr(mod, 2 * N), gate1=ops.ptr(e0, 2 * N), gate1_stride=6 * N, gate_rows=S, gate_const=0.0)
+    else:
+        ops.gemm(a, w, out=out, bias=bias, epilogue=ops.EPI_GELU_BF16 if epi == "gelu" else ops.EPI_BF16)
 torch.cuda.synchronize()
