@@ -19,8 +19,10 @@ constexpr int MAXV_GENERIC = 32;   // float4 chunks per lane -> dim <= 8192 (spe
 // A wave takes LN_RPW consecutive rows: the modulation vectors (up to four [dim] fp32 vectors, 24 floats per lane each at
 // dim = 1536) are fetched once per wave and batch element instead of once per row — per row they were twice the
 // loads of x itself — and the next row's x is requested before the current row's reductions.
-constexpr int LN_RPW = 4;
-template <int MAXV>
+// LN_RPW rows per wave: 4 on the long sequences (the modulation vectors are fetched once per 4 rows), 1 when the launch
+// would otherwise not give every CU a few waves (the training step's 6 240 rows: 390 workgroups of 4-row waves on 256
+// CUs ran at 2.7 TB/s).  The per-row arithmetic is the same: same bits.
+template <int MAXV, int LN_RPW>
 __global__ __launch_bounds__(256)
 void layernorm_modulate_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t rows, int dim,
                                float eps, float mul_const, const float* __restrict__ mul0,
@@ -330,9 +332,12 @@ extern "C" int omh_layernorm_modulate(const float* x, void* y, int64_t rows, int
     if ((dim & 3) || dim > MAXV_GENERIC * 256) return OMH_E_SHAPE;
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 7) || (mul1_stride & 3) || (add1_stride & 3)) return OMH_E_ALIGN;
     omh_clear_status();
-    auto kern = dim <= 6 * 256 ? layernorm_modulate_kernel<6>
-                               : (dim <= 20 * 256 ? layernorm_modulate_kernel<20> : layernorm_modulate_kernel<MAXV_GENERIC>);
-    hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 4 * LN_RPW - 1) / (4 * LN_RPW))), dim3(256), 0,
+    const bool few = rows < 16384;
+    auto kern = dim <= 6 * 256 ? (few ? layernorm_modulate_kernel<6, 1> : layernorm_modulate_kernel<6, 4>)
+                               : (dim <= 20 * 256 ? (few ? layernorm_modulate_kernel<20, 1> : layernorm_modulate_kernel<20, 4>)
+                                                  : (few ? layernorm_modulate_kernel<MAXV_GENERIC, 1> : layernorm_modulate_kernel<MAXV_GENERIC, 4>));
+    const int rpw = few ? 1 : 4;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))), dim3(256), 0,
                        (hipStream_t)stream, x, (uint16_t*)y, rows, dim, eps, mul_const, mul0, mul1, mul1_stride,
                        add0, add1, add1_stride, rows_per_batch);
     return omh_launch_status();

@@ -931,14 +931,16 @@ def test_block_output_taps_do_not_alias_the_block_backward(wan_model_mod):
         # (b)
         g_out, g_tap, g_both = run(1.0, 0.0), run(0.0, 1.0), run(1.0, 1.0)
         assert g_tap["blocks.5.self_attn.q.weight"] is None or float(g_tap["blocks.5.self_attn.q.weight"].abs().max()) == 0
-        worst = 0.0
+        worst = (0.0, None)
         for n in g_both:
             if g_both[n] is None:
                 continue
             want = g_out[n].double() + (g_tap[n].double() if g_tap[n] is not None else 0.0)
             e = float((g_both[n].double() - want).norm() / want.norm().clamp_min(1e-20))
-            worst = max(worst, e)
-            assert e < TOL_GRAD_1D, (n, e)
-        print(f"[measured] tap + output loss vs the sum of the separate gradients: worst {worst:.3e}")
+            null = n.endswith("cross_attn.k.bias")                  # identically-null gradient: pure rounding noise
+            if not null and e > worst[0]:
+                worst = (e, n)
+            assert e < (1.0 if null else TOL_GRAD_1D), (n, e)
+        print(f"[measured] tap + output loss vs the sum of the separate gradients: worst {worst}")
     finally:
         h.remove()
