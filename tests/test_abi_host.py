@@ -246,3 +246,36 @@ def test_checkpoint_flag_as_memory_policy(omh, wan_model_mod, monkeypatch):
     assert mt.keep_activations(m, rows, dev, batch=4) is False
     m.use_checkpoint = False                                          # the reference's other branch: always kept
     assert mt.keep_activations(m, rows, dev, batch=4) is True
+
+
+def test_attention_split_plans_without_a_gpu(omh):
+    """ABI v8 workspace queries are pure host arithmetic (omh_tail_split_plan: 256 CUs assumed without a device): the
+    training step's shapes — one clip (156 workgroups: dQ split 3 ways on 512 slots, dK / dV 3 ways on 256), four
+    clips (624: nothing is split, measured not to pay), phases, the forward's stricter rule (16 key tiles per worker)."""
+    import ctypes as C
+    binding = importlib.import_module(PKG + "._lib")
+    lib = binding.lib
+
+    def bwd_bytes(B, H, Lq, Lk, phase=0):
+        a = binding.AttnBwdArgs()
+        a.B, a.H, a.Lq, a.Lk, a.phase = B, H, Lq, Lk, phase
+        a.o32 = C.c_void_p(16)                                      # only its presence matters to the query
+        return lib.omh_flash_attn_bwd_workspace_bytes(C.byref(a))
+    tile = 128 * 128 * 4
+    assert bwd_bytes(1, 12, 1560, 1560) == 156 * 3 * tile + 156 * 3 * 2 * tile
+    assert bwd_bytes(1, 12, 1560, 1560, phase=2) == 156 * 3 * tile
+    assert bwd_bytes(1, 12, 1560, 1560, phase=3) == 156 * 3 * 2 * tile
+    assert bwd_bytes(1, 12, 1560, 1560, phase=1) == 0
+    assert bwd_bytes(4, 12, 1560, 1560) == 0                        # 624 workgroups: more than a round, no split
+    assert bwd_bytes(4, 12, 1560, 512) == 0                         # cross-attention dK / dV: 192 on 256, < 1/3 to gain
+    assert bwd_bytes(1, 12, 1560, 512) == 156 * 2 * tile + 48 * 5 * 2 * tile      # dQ: 8 key tiles -> 2 workers; dK/dV: 48 x 5 = 240 <= 256
+
+    def fwd_bytes(B, H, Lq, Lk, flags):
+        a = binding.AttnArgs()
+        a.B, a.H, a.Lq, a.Lk, a.flags = B, H, Lq, Lk, flags
+        a.q_rs = a.k_rs = a.o_rs = H * 128
+        return lib.omh_flash_attn_workspace_bytes(C.byref(a))
+    both = binding.ATTN_SHORT_KERNEL | binding.ATTN_ALLOW_SPLIT
+    assert fwd_bytes(1, 12, 1560, 1560, both) == 0                  # 25 key tiles: < 2 x 16 per worker
+    assert fwd_bytes(1, 12, 1560, 4096, binding.ATTN_SHORT_KERNEL) == 0            # not allowed: never
+    assert fwd_bytes(1, 12, 1560, 4096, both) == 156 * 3 * 128 * 129 * 4           # 64 key tiles: 3 workers of >= 16
