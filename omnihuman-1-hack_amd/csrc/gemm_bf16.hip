@@ -481,6 +481,8 @@ int omh_launch_gemm_w64(const omh_gemm_args& a, hipStream_t stream);
 // ... and its 256 x 192 gated-residual variant with the old C tile prefetched during the k loop
 bool omh_gemm_w64_r192_takes(const omh_gemm_args& a);
 int omh_launch_gemm_w64_r192(const omh_gemm_args& a, hipStream_t stream);
+bool omh_gemm_w64_bf16m_takes(const omh_gemm_args& a);
+int omh_launch_gemm_w64_bf16m(const omh_gemm_args& a, hipStream_t stream);
 bool omh_gemm_w64_n192_takes(const omh_gemm_args& a);
 int omh_launch_gemm_w64_n192(const omh_gemm_args& a, hipStream_t stream);
 
@@ -562,6 +564,35 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
                     omh_clear_status();
                     omh_launch_gemm_w64_r192(a, s);
                     return omh_launch_status();
+                }
+            }
+        }
+        // bf16 output with a per-row bias (V^T = Wv h^T + bv: 1536 x 32 760 x 1536) on the 256 x 384 stream.  Its tile count
+        // decides: 6 x 86 = 516 tiles is two rounds of 256 persistent workgroups plus FOUR tiles; the last tile column
+        // (120 of the 32 760 columns) is therefore handed to the 8-wave kernels as a second small launch and the stream
+        // takes 6 x 85 = 510 tiles = two rounds.  Built, bit-identical (test_gemm_w64_per_row_bias_stream) and measured
+        // EQUAL to the 8-wave kernel (144-159 vs 141-149 us: 24 k steps per tile do not amortise the stream's per-tile
+        // cost, and the tail is a second launch): opt-in, OMH_GEMM_W64_BF16M = 1.
+        {
+            const char* bm = getenv("OMH_GEMM_W64_BF16M");
+            const bool on = bm && bm[0] == '1', off = !on;
+            if (!never && !off && omh_gemm_w64_bf16m_takes(a)) {
+                const int tm = (a.M + 255) / 256, tn = (a.N + 383) / 384;
+                auto util = [&](int t) { const int64_t n = (int64_t)tm * t; return n <= 0 ? 0.0 : (double)n / (double)(((n + 255) / 256) * 256); };
+                const bool cut = tn > 1 && util(tn - 1) > util(tn) + 0.05;
+                const int tmain = cut ? tn - 1 : tn;
+                if (on || ((int64_t)tm * tmain >= 256 && util(tmain) >= 0.9)) {
+                    omh_gemm_args m = a;
+                    if (cut) m.N = tmain * 384;
+                    omh_clear_status();
+                    omh_launch_gemm_w64_bf16m(m, s);
+                    int rc = omh_launch_status();
+                    if (rc || !cut) return rc;
+                    omh_gemm_args r = a;                                  // columns [tmain * 384, N): rows of B, columns of C
+                    r.N = a.N - m.N;
+                    r.B = (const char*)a.B + (int64_t)m.N * a.ldb * 2;
+                    r.C = (char*)a.C + (int64_t)m.N * 2;
+                    return launch_8w(r, s);
                 }
             }
         }

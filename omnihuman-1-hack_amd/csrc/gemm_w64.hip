@@ -16,8 +16,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, int64_t
     return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)n, 0x00020000);
 }
 
-enum { K_F32 = 0, K_BF16 = 1, K_GELU = 2, K_RESID = 3, K_GELUBWD = 4,
-       K_RESID192 = 5, K_F32_192 = 6, K_BF16_192 = 7 };                      // >= K_RESID192: the 256 x 192 tile
+enum { K_F32 = 0, K_BF16 = 1, K_GELU = 2, K_RESID = 3, K_GELUBWD = 4, K_BF16M = 5,
+       K_RESID192 = 6, K_F32_192 = 7, K_BF16_192 = 8 };                      // >= K_RESID192: the 256 x 192 tile
 
 // two wave-uniform 32-bit scalars in one SGPR pair (inline asm takes at most 30 operands)
 __device__ __forceinline__ uint64_t pack2(uint32_t lo, uint32_t hi) {
@@ -50,7 +50,7 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
     constexpr int TNW = KIND >= K_RESID192 ? TN192 : TN;                    // tile width; a wave owns TNW / 2 columns
     constexpr int WBYTES = TNW * 128, STAGE_B = 32768 + WBYTES;             // W tile, one stage (X 32 KiB | W)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_B];
-    constexpr int ES = (KIND == K_BF16 || KIND == K_GELU || KIND == K_BF16_192 || KIND == K_GELUBWD) ? 2 : 4;
+    constexpr int ES = (KIND == K_BF16 || KIND == K_GELU || KIND == K_BF16_192 || KIND == K_GELUBWD || KIND == K_BF16M) ? 2 : 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1;
@@ -80,6 +80,8 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
     const __amdgpu_buffer_rsrc_t rb = rsrc_of(p.B, (((int64_t)p.N - 1) * p.ldb + p.K) * 2);
     const __amdgpu_buffer_rsrc_t rc = rsrc_of(p.C, (((int64_t)p.M - 1) * p.ldc + p.N) * ES);
     const __amdgpu_buffer_rsrc_t rbias = rsrc_of(p.bias, (p.bias && p.bias_mode == OMH_BIAS_N) ? (int64_t)p.N * 4 : 0);
+    // K_BF16M: per-ROW bias (OMH_BIAS_M: the V^T projection, weights in the row slot)
+    const __amdgpu_buffer_rsrc_t rbm = rsrc_of(p.bias, (KIND == K_BF16M && p.bias) ? (int64_t)p.M * 4 : 0);
     constexpr bool RES = KIND == K_RESID || KIND == K_RESID192;
     const __amdgpu_buffer_rsrc_t rg0 = rsrc_of(p.gate0, (RES && p.gate0) ? (int64_t)p.N * 4 : 0);
     const bool has_g1 = RES && p.gate1 != nullptr;
@@ -143,7 +145,18 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
         else if (KIND == K_BF16) OMH_GW64_RUN(OMH_GEMM_W64_ASM_BF16);
         else if (KIND == K_GELU) OMH_GW64_RUN(OMH_GEMM_W64_ASM_GELU);
         else if (KIND == K_RESID) OMH_GW64_RUN(OMH_GEMM_W64_ASM_RESID);
-        else if (KIND == K_GELUBWD)
+        else if (KIND == K_BF16M) {
+            const uint32_t vbm = (uint32_t)((t.m0 + wm * 128 + r) * 4);
+            asm volatile(OMH_GEMM_W64_ASM_BF16M
+                 :
+                 : [xab] "v"(xab), [wab] "v"(wab), [xh] "v"(xh), [vox0] "v"(vox0), [vox1] "v"(vox1), [vow0] "v"(vow0),
+                   [vow1] "v"(vow1), [voc] "v"(voc), [vlane] "v"(vlane), [vbm] "v"(vbm), [ra] "s"(ra), [rb] "s"(rb), [rc] "s"(rc),
+                   [rbias] "s"(rbias), [rg0] "s"(rg0), [rg1] "s"(rg1), [rbm] "s"(rbm),
+                   [p0] "{s[60:61]}"(p0), [p1] "{s[62:63]}"(p1),
+                   [p2] "{s[64:65]}"(p2), [p3] "{s[66:67]}"(p3), [p4] "{s[68:69]}"(p4), [p5] "{s[70:71]}"(p5),
+                   [p6] "{s[72:73]}"(p6), [p7] "{s[74:75]}"(p7), [p8] "{s[76:77]}"(p8), [p9] "{s[78:79]}"(p9)
+                 : OMH_GEMM_W64_CLOBBERS);
+        } else if (KIND == K_GELUBWD)
             asm volatile(OMH_GEMM_W64_ASM_GELUBWD
                  :
                  : [xab] "v"(xab), [wab] "v"(wab), [xh] "v"(xh), [vox0] "v"(vox0), [vox1] "v"(vox1), [vow0] "v"(vow0),
@@ -220,6 +233,14 @@ bool omh_gemm_w64_r192_takes(const omh_gemm_args& a) {
     return a.epilogue == OMH_EPI_RESID && omh_gemm_w64_takes(a) && a.K >= 16 * BK;
 }
 int omh_launch_gemm_w64_r192(const omh_gemm_args& a, hipStream_t stream) { return launch_w64<K_RESID192>(a, stream); }
+// bf16 output with a per-ROW bias (the V^T projection) on the 256 x 384 stream
+bool omh_gemm_w64_bf16m_takes(const omh_gemm_args& a) {
+    if (a.epilogue != OMH_EPI_BF16 || !a.bias || a.bias_mode != OMH_BIAS_M) return false;
+    omh_gemm_args b = a;
+    b.bias_mode = OMH_BIAS_N;
+    return omh_gemm_w64_takes(b);
+}
+int omh_launch_gemm_w64_bf16m(const omh_gemm_args& a, hipStream_t stream) { return launch_w64<K_BF16M>(a, stream); }
 // The same 256 x 192 tile for the plain fp32 / bf16 epilogues: twice the tiles of the 256 x 384 stream, for products whose
 // 256 x 384 tiles would fill less than half of the chip (the training step's M = 6 240: 100 tiles -> 200).
 bool omh_gemm_w64_n192_takes(const omh_gemm_args& a) {

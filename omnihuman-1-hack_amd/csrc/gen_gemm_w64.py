@@ -411,11 +411,18 @@ def c_loads(e, n, es):
               f"offset:{(i * 32 + 16 * p) * es + q * 16}")
 
 
+RBM = 120                    # bf16m: v[120:123] = bias of the lane's row in row blocks j = 0..3 (per-ROW bias, OMH_BIAS_M)
+
+
 def epilogue(e, kind):
-    out_bf16 = kind in ("bf16", "gelu")
+    out_bf16 = kind in ("bf16", "gelu", "bf16m")
+    rowbias = kind == "bf16m"    # C = bf16(acc + bias[m]): the V^T projection (operands swapped, model.py:152-153 via :214)
     resid = kind == "resid"
     es = 2 if out_bf16 else 4
-    column_vectors(e, kind)
+    if rowbias:                  # older than the next tile's prologue DMA: column_vectors' wait covers them
+        for j in range(NJ):
+            e(f"buffer_load_dword v{RBM + j}, %[vbm], %[rbm], 0 offen offset:{j * 128}")
+    column_vectors(e, "bf16" if rowbias else kind)
     if kind == "gelu":
         for r_, val in ((KC, "0x3d372713"), (KC + 1, "0x3d372713"), (KC + 2, "1.0"), (KC + 3, "1.0"),
                         (KC + 4, "0xc0135761"), (KC + 5, "0xc0135761")):
@@ -446,8 +453,12 @@ def epilogue(e, kind):
             if resid:
                 e(f"ds_read_b128 {vr(GV + p * 8, 4)}, v{VSEL} offset:{col}")
                 e(f"ds_read_b128 {vr(GV + p * 8 + 4, 4)}, v{VSEL} offset:{col + 16}")
-            e(f"ds_read_b128 {vr(BV + p * 8, 4)}, {VLR} offset:{768 + col}")
-            e(f"ds_read_b128 {vr(BV + p * 8 + 4, 4)}, {VLR} offset:{768 + col + 16}")
+            if rowbias:
+                for r_ in range(8):
+                    e(f"v_mov_b32 v{BV + p * 8 + r_}, v{RBM + j}")
+            else:
+                e(f"ds_read_b128 {vr(BV + p * 8, 4)}, {VLR} offset:{768 + col}")
+                e(f"ds_read_b128 {vr(BV + p * 8 + 4, 4)}, {VLR} offset:{768 + col + 16}")
         for r_ in range(16):
             if t < 16:
                 e(f"v_accvgpr_read_b32 v{T + r_}, a{t * 16 + r_}")
@@ -738,7 +749,7 @@ def epilogue_resid192(e):
 
 # VMEM instructions PER ACCUMULATOR TILE an epilogue issues after the next tile's prologue DMA (the k loop's first wait
 # counts them: an over-estimate would let k tile 0 be read before it has landed)
-EPI_VMEM_TILE = {"f32": 4, "bf16": 2, "gelu": 2, "resid": 8, "resid192": 6, "gelubwd": 4}
+EPI_VMEM_TILE = {"f32": 4, "bf16": 2, "gelu": 2, "resid": 8, "resid192": 6, "gelubwd": 4, "bf16m": 2}
 
 
 def generate(kind, tag=None):
@@ -765,7 +776,7 @@ def first_prologue(tag="pro"):
 
 def main():
     print("// GENERATED by gen_gemm_w64.py — do not edit; edit the generator.")
-    streams = [("PRO", first_prologue())] + [(kind.upper(), generate(kind)) for kind in KINDS + ("gelubwd",)]
+    streams = [("PRO", first_prologue())] + [(kind.upper(), generate(kind)) for kind in KINDS + ("gelubwd", "bf16m")]
     configure(3)                                                 # the 256 x 192 gated-residual stream (old C prefetched)
     streams += [("PRO192", first_prologue("pro192")), ("RESID192", generate("resid192")),
                 ("F32_192", generate("f32", "f32n3")), ("BF16_192", generate("bf16", "bf16n3"))]

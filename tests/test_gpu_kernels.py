@@ -212,6 +212,32 @@ def run_default(ops, a, w, pre, M, N, K):
     return out
 
 
+@pytest.mark.parametrize("M,N,K,ldc", [(256, 384, 256, 384), (1000, 776, 320, 832), (1536, 32760, 1536, 32768), (1536, 1560, 1536, 1600)])
+def test_gemm_w64_per_row_bias_stream(ops, M, N, K, ldc, monkeypatch):
+    """Round 4: bf16 output with a per-ROW bias (OMH_BIAS_M: V^T = Wv h^T + bv, the operands-swapped projection of
+    model.py:152-153) on the 256 x 384 stream — bit for bit against the 8-wave kernel; at the real shape the last tile
+    column (120 of 32 760 columns) goes to the 8-wave kernel as a second launch so that the stream's tiles are exactly
+    two rounds of the persistent grid; pad columns [N, ldc) stay untouched."""
+    torch.manual_seed(M + N)
+    w = _bf(torch.randn(M, K, device="cuda") / math.sqrt(K))
+    h = _bf(torch.randn(N, K, device="cuda"))
+    bias = torch.randn(M, device="cuda")
+
+    def run(env):
+        for k_ in ("OMH_GEMM_KERNEL", "OMH_GEMM_W64_BF16M"):
+            monkeypatch.delenv(k_, raising=False)
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        out = torch.full((M, ldc), 7.0, device="cuda", dtype=torch.bfloat16)
+        ops.gemm_raw(ops.ptr(w), ops.ptr(h), ops.ptr(out), M, N, K, K, K, ldc, ops.EPI_BF16, bias=ops.ptr(bias), bias_mode=ops.BIAS_M)
+        return out
+    got, again, old, dflt = run({"OMH_GEMM_W64_BF16M": "1"}), run({"OMH_GEMM_W64_BF16M": "1"}), run({"OMH_GEMM_KERNEL": "8w"}), run({})
+    assert torch.equal(got, old) and torch.equal(got, again) and torch.equal(dflt, old)
+    assert bool((got[:, N:] == 7.0).all())
+    ref = w.float() @ h.float().t() + bias[:, None]
+    assert rel_rms(got[:, :N].float(), ref) < 4e-3
+
+
 def test_gemm_w64_random_shapes_equal_the_8_wave_kernel(ops, monkeypatch):
     """Seeded sweep: 20 random (M, N, K, epilogue, bias, gate layout) within the stream kernel's domain, whole outputs
     bit for bit against the 8-wave kernels (one to a few tiles per workgroup of the persistent grid, ragged M and N,
