@@ -23,6 +23,7 @@
 //     different values (conflict-free ds_read_b128 of 16 rows at one column) and 4 consecutive rows differ in bits
 //     2..3 (conflict-free transposing reads of 4 rows x 64 bytes).
 #include "omh_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -100,25 +101,27 @@ __device__ __forceinline__ bf16x8 tr_frag2(const unsigned char* tile, uint32_t a
 // and is fetched from logical slot (c & 15) ^ swz(row) of source row `first_row + row`
 struct TileSrc {
     __amdgpu_buffer_rsrc_t rsrc;
-    uint32_t voff[4];
+    uint32_t voff[8];               // 1024 / THREADS chunks per thread (4 for 256 threads, 8 for 128)
     uint32_t tile_bytes;            // 64 rows of the source
 };
+template <int THREADS = 256>
 __device__ __forceinline__ TileSrc tile_src(const uint16_t* base, int64_t rows, int64_t rs, int tid) {
     TileSrc t;
     t.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(((rows - 1) * rs + D) * 2), 0x00020000);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int c = tid + 256 * j;
+    for (int j = 0; j < 1024 / THREADS; ++j) {
+        const int c = tid + THREADS * j;
         const int row = c >> 4;
         t.voff[j] = (uint32_t)((row * rs + (((c & 15) ^ swz(row)) << 3)) * 2);
     }
     t.tile_bytes = (uint32_t)(TB * rs * 2);
     return t;
 }
+template <int THREADS = 256>
 __device__ __forceinline__ void tile_dma(const TileSrc& t, int tile, unsigned char* dst, int wave_lds) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(t.rsrc, (lds_vptr)(dst + wave_lds + j * 4096), 16,
+    for (int j = 0; j < 1024 / THREADS; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(t.rsrc, (lds_vptr)(dst + wave_lds + j * (THREADS * 16)), 16,
                                                  t.voff[j] + (uint32_t)tile * t.tile_bytes, 0, 0, 0);
 }
 
@@ -301,8 +304,18 @@ void attn_bwd2_dq_kernel(const omh_attn_bwd_args p, const int q_blocks, const Bw
 }
 
 // ---------------------------------------------------------------------------------------------- dK, dV
-__global__ __launch_bounds__(256)
+// WAVES x KPW = 4 x 1: 4 waves of 32 keys.  The kernel is bound by the LDS pipe (1.5 LDS instructions per MFMA: each
+// of the 4 waves re-reads the whole shared Q / dO tile for its 32 keys).  The template also expresses 2 waves of 64
+// keys (<2, 2>: every fragment read feeds TWO key blocks, 0.75 per MFMA; two workgroups per CU, one wave per SIMD) —
+// tried in round 4 and NOT instantiated: 256 accumulator registers fill the AGPRs, the remaining live set (128 K / V
+// operand registers + 64 score + 32 packed P / dS + fragments + addresses) is ~290 > 256 arch VGPRs, and hipcc spills
+// 334 registers (812 bytes of scratch per lane).  It needs an asm-owned register map with P / dS overlaid on the score
+// registers and lse / delta folded into the MFMA C operand.
+template <int WAVES, int KPW>
+__global__ __launch_bounds__(64 * WAVES, 1)
 void attn_bwd2_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks, const BwdSplit wk) {
+    constexpr int THREADS = 64 * WAVES;
+    static_assert(WAVES * KPW == 4, "a workgroup covers 128 keys");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // [2 stages][Q tile | dO tile] + lse/delta
     float* stat = (float*)(smem + 4 * TILE_BYTES);                              // [2 stages][lse 64 | delta 64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -328,30 +341,31 @@ void attn_bwd2_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks, const 
     const float* LSE = p.lse + ((int64_t)b * p.H + head) * p.Lq;
     const float* DEL = p.delta + ((int64_t)b * p.H + head) * p.Lq;
 
-    const int key = kb * 128 + wave * 32 + li;
-    const bool key_ok = key < klen;
-    bf16x8 kf[8], vf[8];
+    const int key0 = kb * 128 + wave * (32 * KPW) + li;              // key of key block 0; block c: + 32 c
+    bf16x8 kf[KPW][8], vf[KPW][8];
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-        const int64_t off = (int64_t)key * p.k_rs + kk * 16 + lh * 8;
-        kf[kk] = __builtin_bit_cast(bf16x8, ld16(K + off, key < p.Lk));
-        vf[kk] = __builtin_bit_cast(bf16x8, ld16(V + off, key < p.Lk));
-    }
-    bool ok[16];
+    for (int c = 0; c < KPW; ++c)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ok[r] = key_ok;
+        for (int kk = 0; kk < 8; ++kk) {
+            const int key = key0 + 32 * c;
+            const int64_t off = (int64_t)key * p.k_rs + kk * 16 + lh * 8;
+            kf[c][kk] = __builtin_bit_cast(bf16x8, ld16(K + off, key < p.Lk));
+            vf[c][kk] = __builtin_bit_cast(bf16x8, ld16(V + off, key < p.Lk));
+        }
     const float sc = p.q_prescaled ? 1.0f : p.scale * LOG2E;
     const float ds_scale = p.q_prescaled ? (1.0f / LOG2E) : p.scale;     // dK = dS^T q' / log2(e) on a pre-scaled q
 
     const FragAddr fa = frag_addr(lane);
-    const TileSrc qs = tile_src(Q, p.Lq, p.q_rs, tid), dos = tile_src(DO, p.Lq, p.o_rs, tid);
+    const TileSrc qs = tile_src<THREADS>(Q, p.Lq, p.q_rs, tid), dos = tile_src<THREADS>(DO, p.Lq, p.o_rs, tid);
     const int wave_lds = __builtin_amdgcn_readfirstlane(wave) * 1024;
 
-    f32x16 dv[4], dk[4];
+    f32x16 dv[KPW][4], dk[KPW][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int c = 0; c < KPW; ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { dv[i][r] = 0.f; dk[i][r] = 0.f; }
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dv[c][i][r] = 0.f; dk[c][i][r] = 0.f; }
 
     // lse / delta of a tile's 64 queries: threads 0..63 fetch them one tile ahead and park them in LDS
     auto stat_load = [&](int tile, float& l, float& dd) {
@@ -362,8 +376,8 @@ void attn_bwd2_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks, const 
         dd = in ? DEL[q] : 0.f;
     };
     float gl = 0.f, gd = 0.f;
-    tile_dma(qs, t_first, smem, wave_lds);                           // (a tile index past the end arrives as zeros)
-    tile_dma(dos, t_first, smem + TILE_BYTES, wave_lds);
+    tile_dma<THREADS>(qs, t_first, smem, wave_lds);                  // (a tile index past the end arrives as zeros)
+    tile_dma<THREADS>(dos, t_first, smem + TILE_BYTES, wave_lds);
     if (tid < 64) { stat_load(t_first, gl, gd); stat[tid] = gl; stat[64 + tid] = gd; }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     for (int t = 0; t < n_tiles; ++t) {
@@ -373,22 +387,27 @@ void attn_bwd2_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks, const 
         const bool more = t + 1 < n_tiles;
         if (more) {
             unsigned char* nq = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
-            tile_dma(qs, t_first + t + 1, nq, wave_lds);
-            tile_dma(dos, t_first + t + 1, nq + TILE_BYTES, wave_lds);
+            tile_dma<THREADS>(qs, t_first + t + 1, nq, wave_lds);
+            tile_dma<THREADS>(dos, t_first + t + 1, nq + TILE_BYTES, wave_lds);
             if (tid < 64) stat_load(t_first + t + 1, gl, gd);
         }
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
             // S = Q K^T and dP = dO V^T as [query][key], lane = key; register r <-> query 64t + 32hb + 16(r>>3) + 8lh + (r&7)
-            f32x16 s, dp;
+            f32x16 s[KPW], dp[KPW];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            for (int c = 0; c < KPW; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[c][r] = 0.f; dp[c][r] = 0.f; }
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 const bf16x8 qa = *(const bf16x8*)(qt + fa.row[kk] + hb * 32 * 256);
                 const bf16x8 da = *(const bf16x8*)(dot + fa.row[kk] + hb * 32 * 256);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kk], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[kk], dp, 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < KPW; ++c) {
+                    s[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[c][kk], s[c], 0, 0, 0);
+                    dp[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[c][kk], dp[c], 0, 0, 0);
+                }
             }
             float lv[16], dl[16];
 #pragma unroll
@@ -398,8 +417,15 @@ void attn_bwd2_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks, const 
                     lv[8 * a + e] = st[32 * hb + 16 * a + 8 * lh + e];
                     dl[8 * a + e] = st[64 + 32 * hb + 16 * a + 8 * lh + e];
                 }
-            bf16x8 pf[2], dsf[2];
-            p_and_ds(s, dp, lv, dl, ok, sc, ds_scale, pf, dsf);
+            bf16x8 pf[KPW][2], dsf[KPW][2];
+#pragma unroll
+            for (int c = 0; c < KPW; ++c) {
+                bool ok[16];
+                const bool key_ok = key0 + 32 * c < klen;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ok[r] = key_ok;
+                p_and_ds(s[c], dp[c], lv, dl, ok, sc, ds_scale, pf[c], dsf[c]);
+            }
             // dV^T += dO^T P ,  dK^T += Q^T dS   ([d][key], lane = key): dO^T, Q^T gathered from the row-major tiles
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -408,8 +434,11 @@ void attn_bwd2_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks, const 
                     const uint32_t ad = fa.tr[db] + (32 * hb + 16 * a) * 256;
                     const bf16x8 ta = tr_frag2(dot, ad);
                     const bf16x8 tq = tr_frag2(qt, ad);
-                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta, pf[a], dv[db], 0, 0, 0);
-                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq, dsf[a], dk[db], 0, 0, 0);
+#pragma unroll
+                    for (int c = 0; c < KPW; ++c) {
+                        dv[c][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta, pf[c][a], dv[c][db], 0, 0, 0);
+                        dk[c][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq, dsf[c][a], dk[c][db], 0, 0, 0);
+                    }
                 }
         }
         if (more && tid < 64) {                                      // the other stage's statistics: last read a tile ago
@@ -419,19 +448,22 @@ void attn_bwd2_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks, const 
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    if (worker) {                                                    // partial sums over this worker's queries
-        float* W = wk.ws + ((((int64_t)(wid - wk.n_regular) * wk.splits + split) * 2) * 128 + wave * 32 + li) * D;
 #pragma unroll
-        for (int db = 0; db < 4; ++db)
+    for (int c = 0; c < KPW; ++c) {
+        const int key = key0 + 32 * c;
+        if (worker) {                                                // partial sums over this worker's queries
+            float* W = wk.ws + ((((int64_t)(wid - wk.n_regular) * wk.splits + split) * 2) * 128 + wave * (32 * KPW) + 32 * c + li) * D;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d0 = db * 32 + g * 8 + lh * 4;
-                *(float4*)(W + d0) = make_float4(dk[db][4 * g], dk[db][4 * g + 1], dk[db][4 * g + 2], dk[db][4 * g + 3]);
-                *(float4*)(W + 128 * D + d0) = make_float4(dv[db][4 * g], dv[db][4 * g + 1], dv[db][4 * g + 2], dv[db][4 * g + 3]);
-            }
-        return;
-    }
-    if (key < p.Lk) {
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = db * 32 + g * 8 + lh * 4;
+                    *(float4*)(W + d0) = make_float4(dk[c][db][4 * g], dk[c][db][4 * g + 1], dk[c][db][4 * g + 2], dk[c][db][4 * g + 3]);
+                    *(float4*)(W + 128 * D + d0) = make_float4(dv[c][db][4 * g], dv[c][db][4 * g + 1], dv[c][db][4 * g + 2], dv[c][db][4 * g + 3]);
+                }
+            continue;
+        }
+        if (key >= p.Lk) continue;
         const int64_t eo = (int64_t)b * p.dk_bs + (int64_t)key * p.dk_rs + head * D;
         if (p.out_bf16) {
             uint16_t* DK = (uint16_t*)p.dk + eo;
@@ -441,8 +473,8 @@ void attn_bwd2_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks, const 
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int d0 = db * 32 + g * 8 + lh * 4;
-                    *(uint2*)(DK + d0) = make_uint2(pack_bf2(dk[db][4 * g], dk[db][4 * g + 1]), pack_bf2(dk[db][4 * g + 2], dk[db][4 * g + 3]));
-                    *(uint2*)(DV + d0) = make_uint2(pack_bf2(dv[db][4 * g], dv[db][4 * g + 1]), pack_bf2(dv[db][4 * g + 2], dv[db][4 * g + 3]));
+                    *(uint2*)(DK + d0) = make_uint2(pack_bf2(dk[c][db][4 * g], dk[c][db][4 * g + 1]), pack_bf2(dk[c][db][4 * g + 2], dk[c][db][4 * g + 3]));
+                    *(uint2*)(DV + d0) = make_uint2(pack_bf2(dv[c][db][4 * g], dv[c][db][4 * g + 1]), pack_bf2(dv[c][db][4 * g + 2], dv[c][db][4 * g + 3]));
                 }
         } else {
             float* DK = (float*)p.dk + eo;
@@ -452,8 +484,8 @@ void attn_bwd2_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks, const 
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int d0 = db * 32 + g * 8 + lh * 4;
-                    *(float4*)(DK + d0) = make_float4(dk[db][4 * g], dk[db][4 * g + 1], dk[db][4 * g + 2], dk[db][4 * g + 3]);
-                    *(float4*)(DV + d0) = make_float4(dv[db][4 * g], dv[db][4 * g + 1], dv[db][4 * g + 2], dv[db][4 * g + 3]);
+                    *(float4*)(DK + d0) = make_float4(dk[c][db][4 * g], dk[c][db][4 * g + 1], dk[c][db][4 * g + 2], dk[c][db][4 * g + 3]);
+                    *(float4*)(DV + d0) = make_float4(dv[c][db][4 * g], dv[c][db][4 * g + 1], dv[c][db][4 * g + 2], dv[c][db][4 * g + 3]);
                 }
         }
     }
@@ -525,7 +557,7 @@ int omh_launch_attn_bwd2(const omh_attn_bwd_args& a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)attn_bwd2_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
-        (void)hipFuncSetAttribute((const void*)attn_bwd2_dkdv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV);
+        (void)hipFuncSetAttribute((const void*)attn_bwd2_dkdv_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV);
         attr_set = true;
     }
     const int k_blocks = (a.Lk + 127) / 128, q_blocks = (a.Lq + 127) / 128;
@@ -552,7 +584,7 @@ int omh_launch_attn_bwd2(const omh_attn_bwd_args& a, hipStream_t s) {
             hipLaunchKernelGGL(attn_bwd2_sum_kernel<1>, dim3((wq.n_tail * 128 + 3) / 4), dim3(256), 0, s, a, q_blocks, wq);
     }
     if (run_k) {                                                                                               // reads delta
-        hipLaunchKernelGGL(attn_bwd2_dkdv_kernel, dim3(wkv.n_regular + wkv.n_tail * wkv.splits), dim3(256), LDS_KV, s, a, k_blocks, wkv);
+        hipLaunchKernelGGL((attn_bwd2_dkdv_kernel<4, 1>), dim3(wkv.n_regular + wkv.n_tail * wkv.splits), dim3(256), LDS_KV, s, a, k_blocks, wkv);
         if (wkv.n_tail)
             hipLaunchKernelGGL(attn_bwd2_sum_kernel<2>, dim3((wkv.n_tail * 128 + 3) / 4), dim3(256), 0, s, a, k_blocks, wkv);
     }
