@@ -521,6 +521,14 @@ int omh_adamw_multi(const int64_t* table, int32_t n_tensors, float lr, float bet
  * workgroup per 64 x 64 tile; kind 1: dst fp32 = src, one workgroup per 4096 elements.  first_tile = prefix sum of the
  * entries' workgroup counts (ascending), total_tiles = their sum. */
 int omh_pack_weights_multi(const int64_t* table, int32_t n_entries, int64_t total_tiles, omh_stream_t stream);
+/* ABI v8: omh_adamw_multi and omh_pack_weights_multi in ONE pass — the optimizer step writes the bf16 operand copies
+ * itself instead of a second launch re-reading every updated parameter.  table: DEVICE array of n_entries x 12 int64
+ * {param, grad, exp_avg, exp_avg_sq (fp32), dst, dstT, rows, cols, ld_dst, ld_dstT, first_tile, kind}; kind 0: a
+ * [rows, cols] weight with bf16 copies (dst / dstT, either may be 0), one workgroup per 64 x 64 tile; kind 1: fp32 copy
+ * dst = updated param; kind 2: no copy; kinds 1, 2: one workgroup per 4096 elements.  Same arithmetic as the two
+ * separate entry points; the copies are the bf16 images of the parameters just written. */
+int omh_adamw_pack_multi(const int64_t* table, int32_t n_entries, int64_t total_tiles, float lr, float beta1, float beta2,
+                         float eps, float weight_decay, int32_t step, float grad_scale, omh_stream_t stream);
 /* EMA of the weights, ema = decay*ema + (1-decay)*p (distilled_trainer.py:319-334). */
 int omh_ema_update(float* ema, const float* p, int64_t n, float decay, omh_stream_t stream);
 

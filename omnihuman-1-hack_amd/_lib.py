@@ -198,6 +198,7 @@ _SIGS = {
     "omh_dense_f32_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "omh_adamw_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
     "omh_adamw_multi": (i32, [vp, i32, f32, f32, f32, f32, f32, i32, f32, vp]),
+    "omh_adamw_pack_multi": (i32, [vp, i32, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
     "omh_ema_update": (i32, [vp, vp, i64, f32, vp]),
     "omh_pack_weights_multi": (i32, [vp, i32, i64, vp]),
     "omh_gather_rows_f32": (i32, [vp, vp, vp, i64, i32, i64, vp]),

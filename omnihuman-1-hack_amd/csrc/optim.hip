@@ -131,6 +131,120 @@ void pack_weights_kernel(const int64_t* __restrict__ table, int n_entries) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- AdamW + weight packs
+// Round 4: the optimizer step WRITES the bf16 operand copies the next training forward reads, instead of a second pass
+// (pack_weights_kernel) that re-reads every updated fp32 parameter: entry e of the device table = {p, g, m, v fp32, dst,
+// dstT, rows, cols, ld_dst, ld_dstT, first tile, kind}; kind 0: a [rows, cols] weight, one workgroup per 64 x 64 tile:
+// AdamW on the tile, then dst = bf16(p) and / or dstT = bf16(p)^T through LDS (either may be 0); kind 1: a vector with an
+// fp32 copy (dst fp32 = p: the concatenated biases of fused projections); kind 2: AdamW only; kinds 1 / 2 take 4096
+// elements per workgroup.  The update is adamw_multi_kernel's arithmetic (equal up to the compiler's fma contraction), the copies are
+// pack_weights_kernel's images of the parameters just written.
+constexpr int AP_COLS = 12;
+
+__device__ __forceinline__ float adamw_one(float p, float g, float& m, float& v, float lr, float beta1, float beta2, float eps,
+                                           float wd, float bc1, float bc2, float inv_scale) {
+    const float gi = g * inv_scale;
+    const float mi = beta1 * m + (1.0f - beta1) * gi;
+    const float vi = beta2 * v + (1.0f - beta2) * gi * gi;
+    m = mi;
+    v = vi;
+    return p * (1.0f - lr * wd) - (lr / bc1) * (mi / (sqrtf(vi) / bc2 + eps));
+}
+
+__global__ __launch_bounds__(256)
+void adamw_pack_kernel(const int64_t* __restrict__ table, int n_entries, float lr, float beta1, float beta2, float eps,
+                       float wd, float bc1, float bc2, float inv_scale) {
+    __shared__ uint16_t tile[64][66];
+    const int64_t t = blockIdx.x;
+    int lo = 0, hi = n_entries - 1;                               // last entry whose first tile is <= t
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[(int64_t)mid * AP_COLS + 10] <= t) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* e = table + (int64_t)lo * AP_COLS;
+    float* P = (float*)e[0];
+    const float* G = (const float*)e[1];
+    float* M = (float*)e[2];
+    float* V = (float*)e[3];
+    const int64_t rows = e[6], cols = e[7], ld_dst = e[8], ld_t = e[9];
+    const int64_t local = t - e[10];
+    const int kind = (int)e[11];
+    const int tid = threadIdx.x;
+    if (kind != 0) {
+        float* dst = kind == 1 ? (float*)e[4] : nullptr;
+        const int64_t n = rows * cols, i0 = local * 4096;
+        for (int64_t i = i0 + tid; i < min(n, i0 + 4096); i += 256) {
+            float m = M[i], v = V[i];
+            const float pn = adamw_one(P[i], G[i], m, v, lr, beta1, beta2, eps, wd, bc1, bc2, inv_scale);
+            M[i] = m; V[i] = v; P[i] = pn;
+            if (dst) dst[i] = pn;
+        }
+        return;
+    }
+    uint16_t* dst = (uint16_t*)e[4];
+    uint16_t* dstT = (uint16_t*)e[5];
+    const int64_t tiles_c = (cols + 63) >> 6;
+    const int64_t r0 = (local / tiles_c) << 6, c0 = (local % tiles_c) << 6;
+    const bool vec = (cols & 3) == 0;
+    const int tr = tid >> 4, tc = (tid & 15) << 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rl = tr + 16 * j;
+        const int64_t r = r0 + rl, c = c0 + tc;
+        float pv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < rows) {
+            const int64_t o = r * cols + c;
+            if (vec && c + 3 < cols) {
+                const float4 p4 = *(const float4*)(P + o), g4 = *(const float4*)(G + o);
+                float4 m4 = *(const float4*)(M + o), v4 = *(const float4*)(V + o);
+                pv[0] = adamw_one(p4.x, g4.x, m4.x, v4.x, lr, beta1, beta2, eps, wd, bc1, bc2, inv_scale);
+                pv[1] = adamw_one(p4.y, g4.y, m4.y, v4.y, lr, beta1, beta2, eps, wd, bc1, bc2, inv_scale);
+                pv[2] = adamw_one(p4.z, g4.z, m4.z, v4.z, lr, beta1, beta2, eps, wd, bc1, bc2, inv_scale);
+                pv[3] = adamw_one(p4.w, g4.w, m4.w, v4.w, lr, beta1, beta2, eps, wd, bc1, bc2, inv_scale);
+                *(float4*)(M + o) = m4;
+                *(float4*)(V + o) = v4;
+                *(float4*)(P + o) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+            } else {
+                for (int k = 0; k < 4; ++k)
+                    if (c + k < cols) {
+                        float m = M[o + k], v = V[o + k];
+                        pv[k] = adamw_one(P[o + k], G[o + k], m, v, lr, beta1, beta2, eps, wd, bc1, bc2, inv_scale);
+                        M[o + k] = m; V[o + k] = v; P[o + k] = pv[k];
+                    }
+            }
+        }
+        const uint32_t lo2 = pack_bf2(pv[0], pv[1]), hi2 = pack_bf2(pv[2], pv[3]);
+        if (dst && r < rows) {
+            if ((ld_dst & 3) == 0 && c + 3 < cols) *(uint2*)(dst + r * ld_dst + c) = make_uint2(lo2, hi2);
+            else {
+                if (c < cols) dst[r * ld_dst + c] = (uint16_t)(lo2 & 0xffff);
+                if (c + 1 < cols) dst[r * ld_dst + c + 1] = (uint16_t)(lo2 >> 16);
+                if (c + 2 < cols) dst[r * ld_dst + c + 2] = (uint16_t)(hi2 & 0xffff);
+                if (c + 3 < cols) dst[r * ld_dst + c + 3] = (uint16_t)(hi2 >> 16);
+            }
+        }
+        *(uint32_t*)&tile[rl][tc] = lo2;
+        *(uint32_t*)&tile[rl][tc + 2] = hi2;
+    }
+    if (!dstT) return;                                            // workgroup-uniform
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int cl = tr + 16 * j;                               // source column = row of the transposed copy
+        const int64_t c = c0 + cl, r = r0 + tc;
+        if (c >= cols) continue;
+        const uint16_t a0 = tile[tc][cl], a1 = tile[tc + 1][cl], a2 = tile[tc + 2][cl], a3 = tile[tc + 3][cl];
+        if ((ld_t & 3) == 0 && r + 3 < rows) {
+            *(uint2*)(dstT + c * ld_t + r) = make_uint2((uint32_t)a0 | ((uint32_t)a1 << 16), (uint32_t)a2 | ((uint32_t)a3 << 16));
+        } else {
+            if (r < rows) dstT[c * ld_t + r] = a0;
+            if (r + 1 < rows) dstT[c * ld_t + r + 1] = a1;
+            if (r + 2 < rows) dstT[c * ld_t + r + 2] = a2;
+            if (r + 3 < rows) dstT[c * ld_t + r + 3] = a3;
+        }
+    }
+}
+
 inline int grid_for(int64_t n) {
     int64_t g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -158,6 +272,19 @@ extern "C" int omh_adamw_multi(const int64_t* table, int32_t n_tensors, float lr
     omh_clear_status();
     hipLaunchKernelGGL(adamw_multi_kernel, dim3(64, n_tensors), dim3(256), 0, (hipStream_t)stream, table, lr, beta1,
                        beta2, eps, weight_decay, bc1, bc2, 1.0f / grad_scale);
+    return omh_launch_status();
+}
+
+extern "C" int omh_adamw_pack_multi(const int64_t* table, int32_t n_entries, int64_t total_tiles, float lr, float beta1,
+                                    float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
+                                    omh_stream_t stream) {
+    if (!table || n_entries <= 0 || total_tiles <= 0 || total_tiles > 0x7fffffffLL || step <= 0 || grad_scale == 0.f)
+        return OMH_E_BADARG;
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2 = sqrtf(1.0f - powf(beta2, (float)step));
+    omh_clear_status();
+    hipLaunchKernelGGL(adamw_pack_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, table, n_entries,
+                       lr, beta1, beta2, eps, weight_decay, bc1, bc2, 1.0f / grad_scale);
     return omh_launch_status();
 }
 

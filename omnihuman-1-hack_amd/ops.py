@@ -657,6 +657,15 @@ def adamw_multi(table, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=
           "omh_adamw_multi")
 
 
+def adamw_pack_multi(table, n_entries, total_tiles, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    """AdamW + the bf16 operand copies of the updated weights in one launch; ``table``: int64 device tensor
+    [n_entries, 12] (include/omh.h)."""
+    _dev(table)
+    assert table.dtype == torch.int64 and table.is_contiguous() and table.shape == (n_entries, 12)
+    check(lib.omh_adamw_pack_multi(_p(table), n_entries, total_tiles, lr, beta1, beta2, eps, weight_decay, step, grad_scale,
+                                   _stream()), "omh_adamw_pack_multi")
+
+
 def pack_weights_multi(table, n_entries, total_tiles):
     """One launch for every bf16 operand copy (and transposed copy) of the fp32 master weights; ``table``: int64 device
     tensor [n_entries, 9] (include/omh.h)."""

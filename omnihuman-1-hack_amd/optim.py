@@ -1,9 +1,18 @@
 """Optimizer side of the training step on gfx950 kernels: AdamW with the
 constructor of ``torch.optim.AdamW`` (seaweed_apt/distilled_trainer.py:69-75)
 and the EMA update of distilled_trainer.py:319-334 kept on the GPU."""
+import os
+
 import torch
 
 from . import ops
+
+# OMH_ADAMW_PACK=0: the bf16 operand copies of the training step in their own launch after the step (round 3), not
+# written by the optimizer kernel (A/B timing)
+try:
+    from .wan.modules.model_train import pack_entry_of
+except Exception:  # pragma: no cover
+    pack_entry_of = None
 
 
 class AdamW(torch.optim.Optimizer):
@@ -20,6 +29,8 @@ class AdamW(torch.optim.Optimizer):
             by_step = {}
             keep = []                                       # keeps .contiguous() copies alive until the launch
             touched = []
+            marks = []                                      # (TrainPacks, row): copies this step writes itself
+            fuse = os.environ.get("OMH_ADAMW_PACK", "1") != "0" and pack_entry_of is not None
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -35,8 +46,14 @@ class AdamW(torch.optim.Optimizer):
                 keep.append(g)
                 touched.append(p)
                 assert p.dtype == torch.float32 and p.is_contiguous() and g.dtype == torch.float32
-                by_step.setdefault((st["step"], p.device), []).append(
-                    (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()))
+                row = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+                ent = pack_entry_of(p) if fuse else None
+                if ent is not None:                             # this weight has bf16 operand copies for the training step
+                    packs, ri = ent
+                    pr = packs.rows[ri]                          # [src, dst, dstT, rows, cols, ld_dst, ld_t, tile0, kind]
+                    row = row + (pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], 0 if pr[8] == 0 else 1)
+                    marks.append((packs, ri))
+                by_step.setdefault((st["step"], p.device), []).append(row)
             # one multi-tensor launch per (step count, device): ~750 parameter tensors -> 1 kernel
             for (step, dev), rows in by_step.items():
                 # the pointer table is re-uploaded only when an address changed (never under a graphed step,
@@ -44,6 +61,28 @@ class AdamW(torch.optim.Optimizer):
                 cache = self.__dict__.setdefault("_tables", {})
                 # keyed per parameter group and device; parameters that joined later (a different step count) get
                 # their own table instead of evicting the main one every step
+                if any(len(r) > 5 for r in rows):
+                    # AdamW + the bf16 operand copies in one pass (omh_adamw_pack_multi): 12-column table with the first
+                    # tile of every entry (64 x 64 tiles for weights with copies, 4096-element chunks otherwise)
+                    key = (gi, dev, len(rows), "pack")
+                    ent = cache.get(key)
+                    if ent is None or ent[0] != rows:
+                        full, tile0 = [], 0
+                        for r in rows:
+                            if len(r) > 5 and r[11] == 0:
+                                e_ = [r[0], r[1], r[2], r[3], r[5], r[6], r[7], r[8], r[9], r[10], tile0, 0]
+                                tile0 += ((r[7] + 63) // 64) * ((r[8] + 63) // 64)
+                            elif len(r) > 5:
+                                e_ = [r[0], r[1], r[2], r[3], r[5], 0, 1, r[4], 0, 0, tile0, 1]
+                                tile0 += (r[4] + 4095) // 4096
+                            else:
+                                e_ = [r[0], r[1], r[2], r[3], 0, 0, 1, r[4], 0, 0, tile0, 2]
+                                tile0 += (r[4] + 4095) // 4096
+                            full.append(e_)
+                        ent = cache[key] = (rows, torch.tensor(full, dtype=torch.int64).to(dev, non_blocking=False), tile0)
+                    ops.adamw_pack_multi(ent[1], len(rows), ent[2], group["lr"], b1, b2, group["eps"], group["weight_decay"],
+                                         step, grad_scale)
+                    continue
                 key = (gi, dev, len(rows))
                 ent = cache.get(key)
                 if ent is None or ent[0] != rows:
@@ -55,6 +94,11 @@ class AdamW(torch.optim.Optimizer):
             # ``_version``, model.py:_Packed) that these parameters changed
             if touched:
                 torch.autograd.graph.increment_version(touched)
+            by_packs = {}
+            for packs, ri in marks:                         # ... and these copies are already those of the new version
+                by_packs.setdefault(id(packs), (packs, []))[1].append(ri)
+            for packs, idx in by_packs.values():
+                packs.mark_current(idx)
         return loss
 
 

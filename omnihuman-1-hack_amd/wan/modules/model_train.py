@@ -81,6 +81,23 @@ class _State:
 
 
 # ----------------------------------------------------------------------------- bf16 weight copies, one launch per step
+# parameter data_ptr -> (weakref to its TrainPacks, row index in TrainPacks.rows): lets the optimizer write the bf16
+# copies of a weight in the same pass that updates it (optim.AdamW, omh_adamw_pack_multi) instead of a re-pack launch
+import weakref
+_PACK_REGISTRY = {}
+
+
+def pack_entry_of(param):
+    """(packs, row) if ``param`` has bf16 operand copies in a live TrainPacks whose buffers are current, else None."""
+    ent = _PACK_REGISTRY.get(param.data_ptr())
+    if ent is None:
+        return None
+    packs = ent[0]()
+    if packs is None or packs.table is None or ent[1] >= len(packs.rows) or packs.rows[ent[1]][0] != param.data_ptr():
+        return None
+    return packs, ent[1]
+
+
 class TrainPacks:
     """bf16 operand copies of every block's Linear weights for the training step, in persistent buffers, rebuilt by
     ONE ``omh_pack_weights_multi`` launch whenever a parameter changed (version counters): per block
@@ -145,6 +162,15 @@ class TrainPacks:
         self.rows, self.subsets = rows, {}
         self.table, self.total_tiles = self._table(range(len(rows)), dev)
         self.n = len(rows)
+        ref = weakref.ref(self)
+        for i, r in enumerate(rows):
+            _PACK_REGISTRY[r[0]] = (ref, i)
+
+    def mark_current(self, indices):
+        """The optimizer wrote the copies of rows ``indices`` itself (omh_adamw_pack_multi): their versions are current."""
+        if self.sig is not None:
+            for i in indices:
+                self.sig[i] = self.params[i]._version
 
     def _table(self, idx, dev):
         """Device table of the entries ``idx`` (each with the first tile it owns in the launch) and the tile count."""
