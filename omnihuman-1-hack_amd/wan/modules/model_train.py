@@ -11,7 +11,10 @@ node finishes.
 
 A block node's forward is ``_block_forward``: the kernels and epilogues of the
 inference block (model.py:279-330 on libomh.so; same operands, same roundings,
-bit-identical output), with the residual stream written out of place and the
+bit-identical output wherever the inference path takes the same attention kernel: the training forward — kept
+activations, the forward under use_checkpoint and its re-run alike — pins the short-sequence kernel
+(OMH_ATTN_SHORT_KERNEL), the inference path switches to the long-sequence stream from 512 query tiles
+on, e.g. 16 clips x 1560 tokens), with the residual stream written out of place and the
 few extra tensors the backward needs emitted by the producing kernels' epilogues
 (the branch outputs y = o W^T + b for the gate gradients, the FFN pre-activation
 for GELU').  What happens to those tensors is ``model.use_checkpoint``'s call,
