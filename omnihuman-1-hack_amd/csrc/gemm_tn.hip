@@ -260,6 +260,16 @@ int launch_tn(const omh_gemm_tn_args& a, hipStream_t s) {
 
 }  // namespace
 
+// gemm_tn_w64.hip: the 256 x 384 stream kernel (one workgroup per CU, persistent)
+bool omh_gemm_tn_w64_takes(const omh_gemm_tn_args& a);
+int64_t omh_gemm_tn_w64_tiles(const omh_gemm_tn_args& a);
+int omh_launch_gemm_tn_w64(omh_gemm_tn_group g, hipStream_t stream);
+// OMH_GEMM_TN_W64=0: never the stream kernel (A/B timing and the bit-equality tests); =1: whenever it takes the shapes
+static int tn_w64_mode() {
+    const char* e = getenv("OMH_GEMM_TN_W64");
+    return e ? atoi(e) : -1;
+}
+
 extern "C" int omh_gemm_bf16_tn(const omh_gemm_tn_args* args, omh_stream_t stream) {
     if (!args || !args->A || !args->B || !args->C) return OMH_E_BADARG;
     const omh_gemm_tn_args& a = *args;
@@ -269,6 +279,15 @@ extern "C" int omh_gemm_bf16_tn(const omh_gemm_tn_args* args, omh_stream_t strea
     if (((int64_t)a.K + 64) * a.lda * 2 >= 0x7fffffffLL || ((int64_t)a.K + 64) * a.ldb * 2 >= 0x7fffffffLL)
         return OMH_E_SHAPE;                                          // 32-bit buffer offsets
     hipStream_t s = (hipStream_t)stream;
+    {   // one product that fills at least 3/8 of the chip with 256 x 384 tiles (the FFN weights: 140 / 144 tiles)
+        const int mode = tn_w64_mode();
+        if (mode != 0 && omh_gemm_tn_w64_takes(a) && (mode == 1 || omh_gemm_tn_w64_tiles(a) >= 96)) {
+            omh_gemm_tn_group g1;
+            g1.n = 1;
+            g1.problem[0] = a;
+            return omh_launch_gemm_tn_w64(g1, s);
+        }
+    }
     const int64_t big_tiles = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256);
     const char* force = getenv("OMH_GEMM_TN_TILE");                  // "big" / "small": test override
     const bool big = force ? force[0] == 'b' : big_tiles >= 128;
@@ -290,6 +309,16 @@ extern "C" int omh_gemm_bf16_tn_grouped(const omh_gemm_tn_group* group, omh_stre
         total += (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
     }
     if (total > 0x7fffffffLL) return OMH_E_SHAPE;
+    {   // all of them on the 256 x 384 stream when every product qualifies and together they are worth a launch
+        const int mode = tn_w64_mode();
+        bool all = mode != 0;
+        int64_t t384 = 0;
+        for (int i = 0; all && i < g.n; ++i) {
+            all = omh_gemm_tn_w64_takes(g.problem[i]);
+            t384 += all ? omh_gemm_tn_w64_tiles(g.problem[i]) : 0;
+        }
+        if (all && (mode == 1 || t384 >= 48)) return omh_launch_gemm_tn_w64(g, (hipStream_t)stream);
+    }
     int64_t total_big = 0;
     for (int i = 0; i < g.n; ++i) total_big += (int64_t)((g.problem[i].M + 255) / 256) * ((g.problem[i].N + 255) / 256);
     const char* te = getenv("OMH_GEMM_TN_GROUP_TILE");               // "big" / "small": test / timing override

@@ -101,8 +101,15 @@ class BucketedGradAllReduce:
         if len(self._ready[i]) == len(self.buckets[i]) and self._work[i] is None:
             self._launch(i)
 
+    _omh_joins_side_streams = True      # model_train._may_defer_join: this hook waits for the weight-gradient stream itself
+
     def _launch(self, i):
         bucket = [p for p in self.buckets[i] if p.grad is not None]
+        if bucket and bucket[0].grad.is_cuda:
+            # the weight gradients of the block that just returned may still be in flight on the training step's second
+            # stream (its join is deferred to the end of the backward pass): this bucket is about to read them
+            from .wan.modules.model_train import join_side_streams
+            join_side_streams(bucket[0].grad.device)
         if not bucket:
             self._work[i] = (None, [], [], None)
             return

@@ -272,6 +272,49 @@ def _wgrad_join(dev):
         torch.cuda.current_stream(dev).wait_stream(_side[dev])
 
 
+def join_side_streams(dev=None):
+    """The current stream waits for the weight-gradient stream (all devices, or ``dev``).  For code that reads parameter
+    gradients INSIDE a backward pass (a gradient hook): with the deferred join (below) a block's weight gradients may still be
+    in flight on the second stream when its backward returns.  parallel.BucketedGradAllReduce calls this before it packs a
+    bucket; after ``backward()`` has returned nothing is in flight."""
+    for d in ([dev] if dev is not None else list(_side)):
+        d = torch.device(d) if not isinstance(d, torch.device) else d
+        if d in _side:
+            torch.cuda.current_stream(d).wait_stream(_side[d])
+
+
+# The join of the weight-gradient stream at the END OF THE BACKWARD PASS instead of the end of every block's backward
+# (OMH_WGRAD_DEFER=0: per block, as rounds 2-3).  A block's last group (q|k|v) is launched when its backward is nearly
+# done; joining there made the main stream wait for it with most of the chip idle, 30 times per step.  Deferred, the
+# group of block i runs under the backward of block i-1.  Legal only when nothing reads the gradients before the pass
+# ends: every trainable parameter's .grad is None (autograd then just stores the tensor; an existing .grad would be
+# accumulated into on the main stream), no tensor / post-accumulate hooks on the parameters other than this package's
+# reducer (which calls join_side_streams), and no other multi-process gradient reducer in sight (torch DDP hooks the
+# accumulator nodes, which cannot be seen from here: with torch.distributed initialised on more than one rank and none
+# of our reducer's hooks on the parameters the join stays per block).
+_DEFER_JOIN = os.environ.get("OMH_WGRAD_DEFER", "1") == "1"
+_join_pending = {}                      # (device, id(model)) -> token of the pass whose end-of-pass join is queued
+
+
+def _may_defer_join(model):
+    if not (_DEFER_JOIN and _WGRAD_STREAM):
+        return False
+    ours = False
+    for p in model.blocks.parameters():                      # (only the blocks' products run on the second stream)
+        if not p.requires_grad:
+            continue
+        if p.grad is not None or getattr(p, "_backward_hooks", None):
+            return False
+        for h in (getattr(p, "_post_accumulate_grad_hooks", None) or {}).values():
+            if not getattr(getattr(h, "__self__", None), "_omh_joins_side_streams", False):
+                return False
+            ours = True
+    if not ours and torch.distributed.is_available() and torch.distributed.is_initialized() and \
+            torch.distributed.get_world_size() > 1:
+        return False
+    return True
+
+
 def _wgrad(dy, x, out=None):
     """dW[N, K] (+)= dy[R, N]^T @ x[R, K]  (fp32) on dy and x as they are (row-major bf16, row stride free): the
     k-major GEMM of csrc/gemm_tn.hip — no transposed copies.  With ``out`` the product is ADDED to it."""
@@ -786,10 +829,33 @@ class _BlockFn(torch.autograd.Function):
                 getattr(dx_out, "_omh_exclusive", False) and not _ALWAYS_COPY_DX
             dx = dx_out if own else dx_out.float().contiguous().clone() if (
                 dx_out.dtype == torch.float32 and dx_out.is_contiguous()) else dx_out.float().contiguous()
+            # the join of the weight-gradient stream: deferred to the end of this backward pass when legal — decided by the
+            # first block of this forward to run in a pass (a second forward of the same model in the pass then finds
+            # gradients in place and joins per block; so does a second pass over the same graph)
+            key = (dev, id(model))
+            tok = _join_pending.get(key)
+            if tok is not None and st.__dict__.get("defer_tok") is tok:
+                defer = True
+            elif st.__dict__.get("no_defer", False):
+                defer = False
+            elif _may_defer_join(model):
+                if tok is None:
+                    tok = _join_pending[key] = object()
+
+                    def _end_of_pass(dev=dev, key=key):
+                        _join_pending.pop(key, None)
+                        _wgrad_join(dev)
+                    torch.autograd.Variable._execution_engine.queue_callback(_end_of_pass)
+                st.defer_tok, defer = tok, True
+            else:
+                st.no_defer, defer = True, False
+            done = False
             try:
                 grads = _block_backward(model, blk, idx, st, S, dx, P)
+                done = True
             finally:
-                _wgrad_join(dev)                             # also on an exception: nothing may stay on the side stream
+                if not (done and defer):
+                    _wgrad_join(dev)                         # also on an exception: nothing may stay on the side stream
         out = []
         for n, p in blk.named_parameters():
             gg = grads.get(n) if p.requires_grad else None
@@ -997,6 +1063,9 @@ def forward_train(model, x, t, context, seq_len, clip_fea=None, y=None, extra_co
     graph of hand-written nodes (see module docstring).  ``extra_conditions``: [B, Ne, dim] condition tokens (or a
     dict holding them under 'tokens') that receive a gradient like any other input."""
     st = _State()
+    for key in [k for k in _join_pending if k[1] == id(model)]:   # a backward pass that died before its end-of-pass join
+        _join_pending.pop(key, None)
+        _wgrad_join(key[0])
     st.packs = TrainPacks.of(model).refresh(model)           # bf16 weight copies: one launch when anything changed
     x_list = list(x) if not isinstance(x, (list, tuple)) else list(x)
     eparams = [p for _, p in _embed_params(model)]

@@ -560,6 +560,70 @@ def test_gemm_tn(ops, M, N, K, pad, tile, monkeypatch):
     assert torch.equal(ops.gemm_tn(sel, b), b.float()[idx])
 
 
+@pytest.mark.parametrize("M,N,K,pad", [(256, 384, 192, 0), (256, 384, 200, 0), (512, 776, 1000, 0), (256, 8960, 333, 0),
+                                        (1536, 1536, 6240, 0), (768, 392, 640, 40), (1536, 3072, 2048, 64),
+                                        (4608, 1536, 1560, 0)])
+def test_gemm_tn_w64_stream_equals_the_tiled_kernel(ops, M, N, K, pad, monkeypatch):
+    """gemm_tn_w64.hip (the 256 x 384 generated stream, OMH_GEMM_TN_W64=1 forces it) == gemm_tn.hip's 128 x 128 kernel
+    without split K BIT FOR BIT (same MFMA, same order over k) — store and accumulate epilogues, partial last k tile
+    (K % 64 = 8, 40, 13 ...), ragged last column tile (N % 384 != 0), strided operands and a strided output — and nothing
+    is written outside the output."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a_full = torch.randn(K, M + pad, device="cuda", generator=g).bfloat16()
+    b_full = torch.randn(K, N + pad, device="cuda", generator=g).bfloat16()
+    a, b = a_full[:, :M], b_full[:, :N]
+    base = torch.randn(M, N, device="cuda", generator=g)
+    monkeypatch.setenv("OMH_GEMM_TN_W64", "0")
+    monkeypatch.setenv("OMH_GEMM_TN_TILE", "small")
+    monkeypatch.setenv("OMH_GEMM_TN_SPLIT", "1")
+    want = ops.gemm_tn(a, b)
+    want_acc = ops.gemm_tn(a, b, out=base.clone(), accumulate=True)
+    monkeypatch.setenv("OMH_GEMM_TN_W64", "1")
+    got = ops.gemm_tn(a, b)
+    assert rel_rms(got, a.float().t() @ b.float()) < 2e-5
+    assert torch.equal(got, want)
+    assert torch.equal(ops.gemm_tn(a, b, out=base.clone(), accumulate=True), want_acc)
+    # a strided output inside a guard band: columns >= N and the rows around stay untouched
+    canvas = torch.full((M + 2, N + 24), -3.0, device="cuda")
+    view = canvas[1:M + 1, 8:N + 8]
+    ops.gemm_tn(a, b, out=view)
+    assert torch.equal(view, want)
+    canvas[1:M + 1, 8:N + 8] = -3.0
+    assert bool((canvas == -3.0).all())
+    # selector: one-hot rows of A pick single rows of B exactly
+    sel = torch.zeros(K, M, device="cuda", dtype=torch.bfloat16)
+    idx = (torch.arange(M, device="cuda") * 7 + 3) % K
+    sel[idx, torch.arange(M, device="cuda")] = 1.0
+    assert torch.equal(ops.gemm_tn(sel, b), b.float()[idx])
+
+
+def test_gemm_tn_w64_stream_grouped(ops, monkeypatch):
+    """A block's weight-gradient group (q|k|v out of the fused gradient buffer, o, cross k|v over the context rows, one
+    accumulating) on the stream kernel == each product on the tiled kernel, bit for bit; more tiles than workgroups
+    (persistent loop) included."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    R, d = 1000, 512
+    dqkv = (torch.randn(R, 3 * d, device="cuda", generator=g) * 0.3).bfloat16()
+    h1 = (torch.randn(R, d, device="cuda", generator=g) * 0.3).bfloat16()
+    dy1 = (torch.randn(R, d, device="cuda", generator=g) * 0.3).bfloat16()
+    ctx = (torch.randn(333, d, device="cuda", generator=g) * 0.3).bfloat16()
+    dkv = (torch.randn(333, 2 * d, device="cuda", generator=g) * 0.3).bfloat16()
+    u = (torch.randn(R, 8960, device="cuda", generator=g) * 0.3).bfloat16()
+    base = torch.randn(d, d, device="cuda", generator=g)
+    probs = [(dqkv, h1, None), (dy1, h1, base), (dkv, ctx, None), (dy1, u, None), (u[:, :8960 - 8960 % 256], dy1, None),
+             (dqkv[:, d:2 * d], h1[:, :392], None), (u, u[:, :2304], None)]        # 356 tiles of 256 x 384 in all
+    monkeypatch.setenv("OMH_GEMM_TN_W64", "0")
+    monkeypatch.setenv("OMH_GEMM_TN_TILE", "small")
+    monkeypatch.setenv("OMH_GEMM_TN_SPLIT", "1")
+    want = [ops.gemm_tn(dy, x, out=None if b_ is None else b_.clone(), accumulate=b_ is not None) for dy, x, b_ in probs]
+    monkeypatch.setenv("OMH_GEMM_TN_W64", "1")
+    items = [(dy, x, torch.full((dy.shape[1], x.shape[1]), 7.0, device="cuda") if b_ is None else b_.clone(), b_ is not None)
+             for dy, x, b_ in probs]
+    ops.gemm_tn_grouped(items)
+    for (dy, x, out, acc), ref in zip(items, want):
+        assert torch.equal(out, ref), (tuple(out.shape), rel_rms(out, ref))
+
+
 @pytest.mark.parametrize("M,N,K,pad", [(128, 128, 64, 0), (300, 200, 72, 0), (1560, 1536, 1536, 0), (6240, 1536, 8960, 0),
                                         (1000, 8960, 1536, 0), (257, 72, 1000, 24), (512, 5120, 1536, 0)])
 @pytest.mark.parametrize("tile", ["big", "small", "auto"])
