@@ -994,3 +994,51 @@ def test_adamw_writes_the_operand_copies_of_the_next_forward(wan_model_mod, monk
         assert torch.allclose(p1[n], p0[n], rtol=1e-5, atol=1e-7), n
     for n in v1:
         assert torch.allclose(v1[n], v0[n], rtol=1e-5, atol=1e-20), n
+
+
+def test_deferred_join_of_the_weight_gradient_stream(wan_model_mod, monkeypatch):
+    """The join of the weight-gradient stream at the end of the backward pass (model_train._may_defer_join) instead of
+    per block: same weight gradients bit for bit as with the per-block join (the grouped products have no split K), also
+    with TWO forwards of the model in one pass (the second finds gradients in place and joins per block) and on a second
+    backward into existing .grad tensors; refused when a foreign gradient hook is registered or a .grad exists."""
+    mt = importlib.import_module(PKG + ".wan.modules.model_train")
+    cfg, sd, m, noise, vt, cl = _setup(wan_model_mod, freeze=False)
+    args = dict(t=torch.ones(2, device="cuda") * 1000.0, context=[c.cuda() for c in cl], seq_len=24)
+
+    def grads(two_forwards, accumulate=False):
+        if not accumulate:
+            m.zero_grad(set_to_none=True)
+        out = m(list(noise.cuda()), **args)
+        loss = sum(torch.nn.functional.mse_loss(a, b) for a, b in zip(out, vt.cuda()))
+        if two_forwards:
+            out2 = m(list((noise * 0.5).cuda()), **args)
+            loss = loss + sum(torch.nn.functional.mse_loss(a, b) for a, b in zip(out2, vt.cuda()))
+        loss.backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    assert mt._DEFER_JOIN and mt._may_defer_join(m) is True
+    for two in (False, True):
+        monkeypatch.setattr(mt, "_DEFER_JOIN", True)
+        got = grads(two)
+        assert not mt._join_pending                                     # the end-of-pass callback ran
+        acc = grads(two, accumulate=True)                               # second pass: .grad exists -> per-block join
+        monkeypatch.setattr(mt, "_DEFER_JOIN", False)
+        want = grads(two)
+        for n in want:
+            if want[n].dim() >= 2 and n.startswith("blocks."):
+                assert torch.equal(got[n], want[n]), n
+                assert rel_rms(acc[n], 2 * want[n]) < 1e-6, n
+            else:                                                        # column sums with fp32 atomics, and what hangs off
+                assert rel_rms(got[n], want[n]) < 1e-4, n                # them (modulation -> time embedding)
+    monkeypatch.setattr(mt, "_DEFER_JOIN", True)
+    assert mt._may_defer_join(m) is False                                # gradients in place
+    m.zero_grad(set_to_none=True)
+    p0 = m.blocks[3].self_attn.o.weight
+    h = p0.register_post_accumulate_grad_hook(lambda p: None)
+    assert mt._may_defer_join(m) is False                                # somebody reads gradients inside the pass
+    h.remove()
+    assert mt._may_defer_join(m) is True
+    h = p0.register_hook(lambda g_: g_)
+    assert mt._may_defer_join(m) is False
+    h.remove()
