@@ -263,7 +263,7 @@ def _attn_bwd(q, k, v, o, do, lse, lens, B, N, Lq, Lk, scale, out, o32, q_presca
 def _side_stream(dev):
     s = _side.get(dev)
     if s is None:
-        s = _side[dev] = torch.cuda.Stream(device=dev)
+        s = _side[dev] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("OMH_WGRAD_PRIO", "0")))
     return s
 
 
@@ -293,6 +293,12 @@ def join_side_streams(dev=None):
 # accumulator nodes, which cannot be seen from here: with torch.distributed initialised on more than one rank and none
 # of our reducer's hooks on the parameters the join stays per block).
 _DEFER_JOIN = os.environ.get("OMH_WGRAD_DEFER", "1") == "1"
+# what else rides the second stream (OMH_SIDE_KV=0 / OMH_SIDE_BIAS=0: on the main one, A/B timing): the cross-attention's
+# key / value gradient path and the bias gradients' column sums — neither feeds the block's input gradient
+_SIDE_KV = os.environ.get("OMH_SIDE_KV", "1") == "1"
+_SIDE_BIAS = os.environ.get("OMH_SIDE_BIAS", "0") == "1"      # measured: 75.3 ms with, 75.1 without (one box, interleaved)
+# (tried and dropped: the forward's context keys / values and the backward's V transposes on a third stream — 75.55 ms
+# with, 75.4 without at 4 clips, slower at 1 clip: the extra fork / join costs what the overlap wins)
 _join_pending = {}                      # (device, id(model)) -> token of the pass whose end-of-pass join is queued
 
 
@@ -319,6 +325,20 @@ def _wgrad(dy, x, out=None):
     """dW[N, K] (+)= dy[R, N]^T @ x[R, K]  (fp32) on dy and x as they are (row-major bf16, row stride free): the
     k-major GEMM of csrc/gemm_tn.hip — no transposed copies.  With ``out`` the product is ADDED to it."""
     return ops.gemm_tn(dy, x, out=out, accumulate=out is not None)
+
+
+def _on_side(dev, fn, tensors=()):
+    """``fn()`` on the weight-gradient stream, behind everything the main stream has queued so far (its inputs were
+    produced there); ``tensors``: what fn reads or writes that may be freed before the stream gets to it."""
+    if not _WGRAD_STREAM:
+        return fn()
+    main, sd = torch.cuda.current_stream(dev), _side_stream(dev)
+    sd.wait_stream(main)
+    with torch.cuda.stream(sd):
+        fn()
+    for tt in tensors:
+        if tt is not None:
+            tt.record_stream(sd)
 
 
 class _WgradGroup:
@@ -470,6 +490,19 @@ def _block_forward(model, blk, idx, st, x0, P, keep, need=True):
     bf = lambda *shape: torch.empty(*shape, dtype=torch.bfloat16, device=dev)
     S = {"x0": x0}
 
+    def ctx_kv(lo, L, wkv, k_lin, v_lin, norm_name, key):
+        """K (normalised bf16 [B*L, d], its fp32 pre-norm) and V ([B*L, d] for the backward, V^T for the forward)
+        of context rows [lo, lo + L) — model.py:176-178 / 216-220 as WanT2VCrossAttention._context_kv computes them."""
+        Lp = _ru(L, 64)
+        kf = torch.empty(B, L, d, dtype=torch.float32, device=dev)
+        ops.gemm_raw(ptr(fc.ctx, lo * d), ptr(wkv), ptr(kf), L, d, d, d, d, d, EPI_F32, bias=ptr(k_lin.bias.detach()),
+                     bias_mode=BIAS_N, batch=B, strideA=Lc * d, strideB=0, strideC=L * d)
+        kn = ops.rmsnorm_rope(kf.view(B * L, d), ca._norm_w(norm_name), ca.eps, do_norm=ca.qk_norm)
+        vtc = _vt_buffer(model, (idx, key), B, d, Lp, L, dev, keep)
+        ops.gemm_raw(ptr(wkv, d * d), ptr(fc.ctx, lo * d), ptr(vtc), d, L, d, d, d, Lp, EPI_BF16,
+                     bias=ptr(v_lin.bias.detach()), bias_mode=BIAS_M, batch=B, strideA=0, strideB=Lc * d, strideC=d * Lp)
+        return kf, kn, vtc, Lp
+
     def ln_mod(xin, shift_i, scale_i):
         h = bf(R, d)
         ops.layernorm_modulate_raw(ptr(xin), ptr(h), R, d, blk.eps, 1.0, ptr(mod, scale_i * d), ptr(e0, scale_i * d), six,
@@ -530,19 +563,6 @@ def _block_forward(model, blk, idx, st, x0, P, keep, need=True):
     wnq = ca._norm_w("norm_q")
     ops.rmsnorm_rope_bf16_raw(ptr(qcb), d, ptr(qc), R, d, ptr(wnq) if wnq is not None else None, ca.eps, int(ca.qk_norm),
                               None, None, 0, D, None, Sq)
-
-    def ctx_kv(lo, L, wkv, k_lin, v_lin, norm_name, key):
-        """K (normalised bf16 [B*L, d], its fp32 pre-norm) and V ([B*L, d] for the backward, V^T for the forward)
-        of context rows [lo, lo + L) — model.py:176-178 / 216-220 as WanT2VCrossAttention._context_kv computes them."""
-        Lp = _ru(L, 64)
-        kf = torch.empty(B, L, d, dtype=torch.float32, device=dev)
-        ops.gemm_raw(ptr(fc.ctx, lo * d), ptr(wkv), ptr(kf), L, d, d, d, d, d, EPI_F32, bias=ptr(k_lin.bias.detach()),
-                     bias_mode=BIAS_N, batch=B, strideA=Lc * d, strideB=0, strideC=L * d)
-        kn = ops.rmsnorm_rope(kf.view(B * L, d), ca._norm_w(norm_name), ca.eps, do_norm=ca.qk_norm)
-        vtc = _vt_buffer(model, (idx, key), B, d, Lp, L, dev, keep)
-        ops.gemm_raw(ptr(wkv, d * d), ptr(fc.ctx, lo * d), ptr(vtc), d, L, d, d, d, Lp, EPI_BF16,
-                     bias=ptr(v_lin.bias.detach()), bias_mode=BIAS_M, batch=B, strideA=0, strideB=Lc * d, strideC=d * Lp)
-        return kf, kn, vtc, Lp
 
     kf, kc, vtc, Ltp = ctx_kv(n_img, Lt, P["wkv_c"], ca.k, ca.v, "norm_k", "ca")
     oc = bf(R, d)
@@ -691,12 +711,20 @@ def _block_backward(model, blk, idx, st, S, dx, P):
     h3 = S["h3"]
     g["cross_attn.q.weight"], g["cross_attn.q.bias"] = wg.add(dqc, h3), _bgrad(dqc, arena)
     dh3 = _dgrad(dqc, P["wq_cT"])
-    rms_bwd(ptr(S["kf"]), False, d, ptr(dkv), 2 * d, Rc, [ca._norm_w("norm_k")], ca.qk_norm, False,
-            ["cross_attn.norm_k.weight"], ca)
+    # The gradient of the text keys / values is off the critical path (nothing in this block reads it again): its norm
+    # backward and its context-gradient GEMM go to the second stream, in front of the weight-gradient group that reads
+    # dkv there (one stream: in order).  st.d_ctx is read by the embedding node, which joins first.
+    def kv_path():
+        rms_bwd(ptr(S["kf"]), False, d, ptr(dkv), 2 * d, Rc, [ca._norm_w("norm_k")], ca.qk_norm, False,
+                ["cross_attn.norm_k.weight"], ca)
+        _dgrad_ctx(dkv, P["wkv_cT"], st.d_ctx, n_img, Lt)
+    if _SIDE_KV and not i2v:
+        _on_side(dev, kv_path, (dkv, S["kf"], st.d_ctx, arena.buf, fc.ctx))
+    else:
+        kv_path()
     dwkv, dbkv = wg.add(dkv, ctx2), _bgrad(dkv, arena)                 # [2d, d]: k | v in one GEMM
     g["cross_attn.k.weight"], g["cross_attn.v.weight"] = dwkv[:d], dwkv[d:]
     g["cross_attn.k.bias"], g["cross_attn.v.bias"] = dbkv[:d], dbkv[d:]
-    _dgrad_ctx(dkv, P["wkv_cT"], st.d_ctx, n_img, Lt)
     x1 = S["x1"]
     if blk.cross_attn_norm:
         # ---- self-attention branch: x1 = x0 + y1 * g2  (dy1 = bf16(dx * g2) and the gate's gradient: same pass)
@@ -735,7 +763,10 @@ def _block_backward(model, blk, idx, st, S, dx, P):
     g["modulation"] = dmod
     ops.colsum_accum(d_eb.view(1, B * six), st.d_e0.view(B * six))      # d_e0 += d_eb
     wg.launch()
-    arena.flush()
+    if _SIDE_BIAS:                                                   # the bias gradients' column sums: second stream too
+        _on_side(dev, arena.flush, [dy_ for dy_, _ in arena.pending] + [arena.buf])
+    else:
+        arena.flush()
     g["__dx__"] = dx
     return g
 
@@ -994,6 +1025,7 @@ class _EmbedFn(torch.autograd.Function):
         dev = dxs.device
         g = {}
         with torch.no_grad():
+            _wgrad_join(dev)            # st.d_ctx, st.d_e0: the blocks' second-stream work adds into them
             dxs = dxs.contiguous().float()
             # ---- patch embedding: x[b,:n] = tok_b Wpe^T + bpe
             pt, ph, pw = model.patch_size
