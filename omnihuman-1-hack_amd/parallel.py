@@ -101,20 +101,27 @@ class BucketedGradAllReduce:
         if len(self._ready[i]) == len(self.buckets[i]) and self._work[i] is None:
             self._launch(i)
 
-    _omh_joins_side_streams = True      # model_train._may_defer_join: this hook waits for the weight-gradient stream itself
+    _omh_joins_side_streams = True      # model_train._may_defer_join: this hook orders itself behind the weight-gradient stream
 
     def _launch(self, i):
         bucket = [p for p in self.buckets[i] if p.grad is not None]
-        if bucket and bucket[0].grad.is_cuda:
-            # the weight gradients of the block that just returned may still be in flight on the training step's second
-            # stream (its join is deferred to the end of the backward pass): this bucket is about to read them
-            from .wan.modules.model_train import join_side_streams
-            join_side_streams(bucket[0].grad.device)
         if not bucket:
             self._work[i] = (None, [], [], None)
             return
         if not any(self._work):
             self.bytes_on_wire = 0
+        # The weight gradients of the block that just returned may still be in flight on the training step's second
+        # stream (model_train: its join is deferred to the end of the backward pass).  The bucket is therefore packed and
+        # its collective queued FROM that stream — behind the gradients it reads, and behind what the main stream has
+        # produced so far — so the main stream never waits here; finish() makes it wait for the collectives.
+        side = None
+        if bucket[0].grad.is_cuda:
+            from .wan.modules.model_train import reducer_stream
+            side = reducer_stream(bucket[0].grad.device)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            self._pack_and_launch(i, bucket)
+
+    def _pack_and_launch(self, i, bucket):
         n = sum(p.numel() for p in bucket)
         # the reduce-scatter halves split the bucket evenly: pad to a multiple of 8 elements per rank
         n_pad = -(-n // (8 * self.world)) * (8 * self.world) if self.collective != "all_reduce" else n
@@ -185,6 +192,9 @@ class BucketedGradAllReduce:
         for i in range(len(self.buckets)):
             if self._work[i] is None:
                 self._launch(i)
+        if any(w is not None and w[1] and w[1][0].grad is not None and w[1][0].grad.is_cuda for w in self._work):
+            from .wan.modules.model_train import join_side_streams
+            join_side_streams()                             # the packs (and host-staged copies) queued on the second stream
         for i, (work, bucket, views, then) in enumerate(self._work):
             if work is None:
                 continue

@@ -275,12 +275,25 @@ def _wgrad_join(dev):
 def join_side_streams(dev=None):
     """The current stream waits for the weight-gradient stream (all devices, or ``dev``).  For code that reads parameter
     gradients INSIDE a backward pass (a gradient hook): with the deferred join (below) a block's weight gradients may still be
-    in flight on the second stream when its backward returns.  parallel.BucketedGradAllReduce calls this before it packs a
-    bucket; after ``backward()`` has returned nothing is in flight."""
+    in flight on the second stream when its backward returns (parallel.BucketedGradAllReduce instead packs its buckets ON
+    that stream: reducer_stream).  After ``backward()`` has returned nothing is in flight."""
     for d in ([dev] if dev is not None else list(_side)):
         d = torch.device(d) if not isinstance(d, torch.device) else d
         if d in _side:
             torch.cuda.current_stream(d).wait_stream(_side[d])
+
+
+def reducer_stream(dev):
+    """The stream a gradient reducer should pack and launch from inside a backward pass: the weight-gradient stream, made
+    to wait for what the main stream has queued so far (None when the step runs on one stream)."""
+    if not _WGRAD_STREAM:
+        return None
+    dev = torch.device(dev) if not isinstance(dev, torch.device) else dev
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    sd = _side_stream(dev)
+    sd.wait_stream(torch.cuda.current_stream(dev))
+    return sd
 
 
 # The join of the weight-gradient stream at the END OF THE BACKWARD PASS instead of the end of every block's backward
@@ -289,7 +302,7 @@ def join_side_streams(dev=None):
 # group of block i runs under the backward of block i-1.  Legal only when nothing reads the gradients before the pass
 # ends: every trainable parameter's .grad is None (autograd then just stores the tensor; an existing .grad would be
 # accumulated into on the main stream), no tensor / post-accumulate hooks on the parameters other than this package's
-# reducer (which calls join_side_streams), and no other multi-process gradient reducer in sight (torch DDP hooks the
+# reducer (which packs its buckets on that stream: reducer_stream), and no other multi-process gradient reducer in sight (torch DDP hooks the
 # accumulator nodes, which cannot be seen from here: with torch.distributed initialised on more than one rank and none
 # of our reducer's hooks on the parameters the join stays per block).
 _DEFER_JOIN = os.environ.get("OMH_WGRAD_DEFER", "1") == "1"
