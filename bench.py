@@ -519,6 +519,49 @@ def train_bench(model, device, world, dist, steps=20, warmup=3, bsz=4, ffn_freez
             "telemetry": tele}
 
 
+def wgrad_group_bench(device, bsz=4, reps=20):
+    """A block's weight-gradient group (q|k|v, o, cross q, cross o over the clip rows, cross k|v over the context rows:
+    model_train._WgradGroup) alone on the chip, as ONE launch of omh_gemm_bf16_tn_grouped: the 256 x 384 k-major stream
+    kernel (csrc/gemm_tn_w64.hip) against gemm_tn.hip's 128 x 128 tiles (OMH_GEMM_TN_W64=0) on the same operands."""
+    ops = importlib.import_module(PKG + ".ops")
+    R, Rc, d = bsz * 1560, bsz * 512, 1536
+    g = torch.Generator(device=device).manual_seed(3)
+    shapes = [(d, d, R), (d, d, R), (d, d, R), (2 * d, d, Rc), (3 * d, d, R)]
+    items = [((torch.randn(K, M, device=device, generator=g) * 0.3).bfloat16(),
+              (torch.randn(K, N, device=device, generator=g) * 0.3).bfloat16(),
+              torch.empty(M, N, dtype=torch.float32, device=device), False) for M, N, K in shapes]
+    flop = sum(2.0 * M * N * K for M, N, K in shapes)
+
+    def timed():
+        for _ in range(3):
+            ops.gemm_tn_grouped(items)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.gemm_tn_grouped(items)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
+    old = os.environ.get("OMH_GEMM_TN_W64")
+    try:
+        os.environ.pop("OMH_GEMM_TN_W64", None)
+        us = timed()
+        ref = [t[2].clone() for t in items]
+        os.environ["OMH_GEMM_TN_W64"] = "0"
+        us_tiled = timed()
+        same = all(torch.equal(a, t[2]) for a, t in zip(ref, items))
+    finally:
+        if old is None:
+            os.environ.pop("OMH_GEMM_TN_W64", None)
+        else:
+            os.environ["OMH_GEMM_TN_W64"] = old
+    return {"products": [f"{M}x{N} over {K} rows" for M, N, K in shapes], "tiles_256x384": 192, "us_per_launch": round(us, 1),
+            "tflops": round(flop / us / 1e6, 1), "mfma_roofline_frac": round(flop / us / 1e6 / 2500.0, 4),
+            "tiled_128x128_us_per_launch": round(us_tiled, 1), "tiled_128x128_tflops": round(flop / us_tiled / 1e6, 1),
+            "bit_identical_to_tiled": bool(same)}
+
+
 def train_legs(model, device, world, dist):
     """The training legs of the line.  Primary: B = 4 with the reference trainer's settings (both quirks on,
     use_checkpoint = True) under this build's default checkpoint policy ("auto": the activations are kept, they fit).
@@ -534,6 +577,10 @@ def train_legs(model, device, world, dist):
     out["leg"] = "primary: reference trainer settings, checkpoint flag as a memory policy (see activations_kept)"
     if os.environ.get("OMH_TRAIN_LEGS", "all") == "primary":      # (tests: the primary leg only)
         return out
+    try:
+        out["weight_gradient_group"] = wgrad_group_bench(device, bsz)
+    except Exception as e:
+        out["weight_gradient_group"] = {"error": repr(e)[:200]}
     try:
         out["recompute"] = train_bench(model, device, world, dist, bsz=bsz, policy="always")
         out["recompute"]["leg"] = "every block re-run in the backward (torch.utils.checkpoint's literal behaviour)"

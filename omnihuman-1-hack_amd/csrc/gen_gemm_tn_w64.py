@@ -34,6 +34,11 @@ BOFF = 32768                    # B tile behind the A tile inside a stage
 PA, PB = 512, 768               # row pitches
 FB = 4 * NI + 4 * NJ
 NTILES = NI * NJ
+import os
+READ_END = int(os.environ.get("OMH_GTW64_READ_END", "20"))       # the next group's 20 reads go behind the first READ_END MFMAs
+DMA_START = int(os.environ.get("OMH_GTW64_DMA_START", "4"))      # a group's 6 B pieces: every other MFMA from this one on
+# (measured on a block's group, one launch: start 12 -> 203 us, 8 -> 201, 4 -> 197, 2 -> 196, 0 -> 196.5; reads behind the first
+# 16 / 20 / 24 MFMAs: 208 / 203 / 204)
 
 S_LDA, S_LDB, S_SAB, S_SBB, S_SAS, S_SBS, S_NK, S_SCB = "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67"
 S_LDC4, S_NREM, S_KSA, S_KSB, S_CM, S_CN = "s68", "s69", "s70", "s71", "s72", "s73"
@@ -213,9 +218,9 @@ def main_loop(e):
             mf = group_mfmas(kk & 1, first=(first and kk == 0))
             reads = frag_reads(s, kk + 1, (kk + 1) & 1)
             reads = [reads[k:k + 2] for k in range(0, len(reads), 2)]
-            ops = spread_after(mf, reads, 0, 20)
+            ops = spread_after(mf, reads, 0, READ_END)
             if kk < 2:
-                ops = with_dma_tail(ops, rest[kk * 6:(kk + 1) * 6], 12)
+                ops = with_dma_tail(ops, rest[kk * 6:(kk + 1) * 6], DMA_START)
             pend = linearize(e, ops, pend)
         if mode == "none":
             linearize(e, group_mfmas(1), pend)
