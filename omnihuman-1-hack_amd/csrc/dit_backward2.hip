@@ -16,8 +16,15 @@
 namespace {
 
 constexpr int MAXV2 = 32;
-constexpr int RPW2 = 2;                    // rows per wave
+constexpr int RPW2 = 2;                    // rows per wave (RMSNorm kernel; LayerNorm kernel on short inputs)
 constexpr int ROWS_PER_WG = 4 * RPW2;
+// The LayerNorm kernel takes 4 rows per wave from 4 096 rows on: 390 workgroups at 6 240 rows are ONE round of the 512
+// resident ones (2 per CU at 204 VGPRs) where 780 were a round and a half, and half as many partials go through the
+// column-sum launch.  Measured at 6 240 rows (us, 2 -> 4 rows per wave): 50.3 -> 45.3 plain, 54.2 -> 48.8 with the next
+// branch's residual backward, 70.9 -> 63.6 with its gate gradient too; the RMSNorm kernel (104 VGPRs, 4 waves per SIMD)
+// does not gain (two segments 45.4 -> 43.5, one segment 23.1 -> 28.5).
+constexpr int RPW_LN_LONG = 4, LN_LONG_ROWS = 4096;
+static inline int ln_rows_per_wg(int64_t rows) { return 4 * (rows >= LN_LONG_ROWS ? RPW_LN_LONG : RPW2); }
 
 template <typename T> __device__ __forceinline__ float4 ld4t(const T* row, int c);
 template <> __device__ __forceinline__ float4 ld4t<float>(const float* row, int c) { return ((const float4*)row)[c]; }
@@ -54,7 +61,7 @@ __device__ __forceinline__ void combine_and_store(float4 (&acc)[NP][NV], float* 
 }
 
 // ------------------------------------------------------------------ LayerNorm + modulate backward (+ next residual)
-template <int NV, typename GT, bool NEXT, bool GATE>
+template <int NV, typename GT, bool NEXT, bool GATE, int RPW>
 __global__ __launch_bounds__(256)
 void ln_bwd2_kernel(const omh_ln_bwd_args a, const int nj) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -63,7 +70,7 @@ void ln_bwd2_kernel(const omh_ln_bwd_args a, const int nj) {
     const int j = blockIdx.x, b = blockIdx.y;
     const int dim = a.dim, nv = dim >> 2;
     const int64_t rpb = a.rows_per_batch;
-    const int64_t base = (int64_t)b * rpb + (int64_t)j * ROWS_PER_WG;
+    const int64_t base = (int64_t)b * rpb + (int64_t)j * (4 * RPW);
     const int64_t end = min((int64_t)(b + 1) * rpb, a.rows);
     const float4* m0 = (const float4*)a.mul0;
     const float4* m1 = a.mul1 ? (const float4*)(a.mul1 + (int64_t)b * a.mul1_stride) : nullptr;
@@ -76,7 +83,7 @@ void ln_bwd2_kernel(const omh_ln_bwd_args a, const int nj) {
         for (int i = 0; i < NV; ++i) acc[k][i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
 #pragma unroll
-    for (int rr = 0; rr < RPW2; ++rr) {
+    for (int rr = 0; rr < RPW; ++rr) {
         const int64_t row = base + wave + 4 * rr;
         if (row >= end) continue;                                       // wave-uniform
         const float* xr = a.x + row * dim;
@@ -299,7 +306,13 @@ int launch_ln(const omh_ln_bwd_args& a, int nj, int nb, hipStream_t s) {
     const bool next = a.dy_next != nullptr, gate = next && a.y_next && a.dgate;
     const dim3 grid((unsigned)nj, (unsigned)nb), blk(256);
     const size_t lds = (size_t)(gate ? 3 : 2) * a.dim * sizeof(float);
-#define OMH_LN2(GT, NEXT, GATE) hipLaunchKernelGGL((ln_bwd2_kernel<NV, GT, NEXT, GATE>), grid, blk, lds, s, a, nj)
+#define OMH_LN2(GT, NEXT, GATE)                                                                                       \
+    do {                                                                                                              \
+        if (ln_rows_per_wg(a.rows) == 4 * RPW_LN_LONG)                                                                \
+            hipLaunchKernelGGL((ln_bwd2_kernel<NV, GT, NEXT, GATE, RPW_LN_LONG>), grid, blk, lds, s, a, nj);          \
+        else                                                                                                          \
+            hipLaunchKernelGGL((ln_bwd2_kernel<NV, GT, NEXT, GATE, RPW2>), grid, blk, lds, s, a, nj);                 \
+    } while (0)
     if (a.dy_bf16) {
         if (gate) OMH_LN2(uint16_t, true, true); else if (next) OMH_LN2(uint16_t, true, false); else OMH_LN2(uint16_t, false, false);
     } else {
@@ -326,7 +339,7 @@ void launch_rms(const omh_rms_bwd_args& a, int nj, hipStream_t s) {
 extern "C" int64_t omh_layernorm_modulate_bwd2_workspace(int64_t rows, int32_t dim, int64_t rows_per_batch) {
     if (rows <= 0 || dim <= 0 || rows_per_batch <= 0) return 0;
     const int64_t nb = (rows + rows_per_batch - 1) / rows_per_batch;
-    const int64_t nj = (rows_per_batch + ROWS_PER_WG - 1) / ROWS_PER_WG;
+    const int64_t nj = (rows_per_batch + ln_rows_per_wg(rows) - 1) / ln_rows_per_wg(rows);
     return nb * nj * 3 * dim;
 }
 
@@ -340,7 +353,7 @@ extern "C" int omh_layernorm_modulate_bwd2(const omh_ln_bwd_args* args, omh_stre
     if ((((uintptr_t)a.dmul | (uintptr_t)a.dadd | (uintptr_t)a.dgate) & 15) || (a.dstride & 3) || (a.dgate_stride & 3)) return OMH_E_ALIGN;
     if (a.workspace_floats < omh_layernorm_modulate_bwd2_workspace(a.rows, a.dim, a.rows_per_batch)) return OMH_E_SHAPE;
     const int64_t nb = (a.rows + a.rows_per_batch - 1) / a.rows_per_batch;
-    const int64_t nj = (a.rows_per_batch + ROWS_PER_WG - 1) / ROWS_PER_WG;
+    const int64_t nj = (a.rows_per_batch + ln_rows_per_wg(a.rows) - 1) / ln_rows_per_wg(a.rows);
     if (nj > 0x7fffffff || nb > 65535) return OMH_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     omh_clear_status();
