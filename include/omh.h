@@ -114,7 +114,11 @@ int omh_gemm_bf16_tn(const omh_gemm_tn_args* args, omh_stream_t stream);
 /* Up to OMH_TN_GROUP_MAX such products in ONE launch: all the weight gradients of one block's backward (q|k|v, o,
  * cross q, cross k|v, cross o, FFN 1, FFN 2).  Each alone is 144 ... 840 tiles of 128 x 128 over a contraction of 6 240
  * rows and leaves most of the chip idle or needs a split K with fp32 atomics; together they fill it, every tile runs
- * its whole K range, and the result is bit-repeatable.  first_tile / total_tiles are scratch filled by the library. */
+ * its whole K range, and the result is bit-repeatable.  first_tile / total_tiles are scratch filled by the library.
+ * Products with M % 256 == 0 (every weight of the DiT) run on the 256 x 384 k-major stream kernel (gemm_tn_w64.hip:
+ * persistent workgroups over the tiles of the whole group, 192 tiles for a block's attention weights = one round of
+ * the chip) when the group is worth a launch; same MFMA, same order over k, same bits as the 128 x 128 tiles.
+ * OMH_GEMM_TN_W64 = 0 / 1 forces the choice (also for omh_gemm_bf16_tn). */
 #define OMH_TN_GROUP_MAX 12
 typedef struct omh_gemm_tn_group {
     int32_t n;
