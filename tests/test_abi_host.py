@@ -279,3 +279,55 @@ def test_attention_split_plans_without_a_gpu(omh):
     assert fwd_bytes(1, 12, 1560, 1560, both) == 0                  # 25 key tiles: < 2 x 16 per worker
     assert fwd_bytes(1, 12, 1560, 4096, binding.ATTN_SHORT_KERNEL) == 0            # not allowed: never
     assert fwd_bytes(1, 12, 1560, 4096, both) == 156 * 3 * 128 * 129 * 4           # 64 key tiles: 3 workers of >= 16
+
+
+def test_k_major_stream_generator_invariants():
+    """csrc/gen_gemm_tn_w64.py (no GPU): both streams assemble the same k loop — 7 step bodies x 4 groups x 24 MFMAs —,
+    name only the operands gemm_tn_w64.hip binds, wait on lgkmcnt before every MFMA whose fragments are in flight (the
+    generator asserts the loop-carried set itself), and keep every LDS offset inside the 16-bit field."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gen = os.path.join(root, PKG, "csrc", "gen_gemm_tn_w64.py")
+    txt = subprocess.run([sys.executable, gen], check=True, capture_output=True, text=True).stdout
+    assert open(os.path.join(root, PKG, "csrc", "gemm_tn_w64_asm.inc")).read() == txt      # the committed stream is current
+    streams = txt.split("#define OMH_GEMM_TN_W64_ASM_")[1:]
+    assert [s.split(" ")[0] for s in streams] == ["ST", "ACC"]
+    bound = {"mab", "nab", "voa0", "voa1", "vob0", "vob1", "vob2", "voc", "ra", "rb", "rc"}
+    for s in streams:
+        body = s.split("#define OMH_GEMM_TN_W64_CLOBBERS")[0]
+        assert body.count("v_mfma_f32_32x32x16_bf16") == 7 * 4 * 24
+        assert set(re.findall(r"%\[(\w+)\]", body)) == bound
+        assert all(int(o) < 65536 for o in re.findall(r"ds_read_b64_tr_b16 [^\n]*offset:(\d+)", body))
+        assert body.count("buffer_load_dwordx4") == 28 + 3 * 20 + 2 * 12      # prologue + 3 full step bodies + 2 last-but-one
+    assert streams[0].count("buffer_store_dword ") == 24 * 16 and streams[1].count("buffer_load_dword ") == 24 * 16
+
+
+def test_deferred_join_policy_without_a_gpu(omh):
+    """model_train._may_defer_join (host logic only): the weight-gradient stream may be joined at the end of the pass only
+    when no block parameter has a gradient in place and nobody but this package's reducer hooks the parameters."""
+    mt = importlib.import_module(PKG + ".wan.modules.model_train")
+    par = importlib.import_module(PKG + ".parallel")
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.blocks = torch.nn.ModuleList([torch.nn.Linear(4, 4) for _ in range(2)])
+            self.head = torch.nn.Linear(4, 4)
+    m = Tiny()
+    assert mt._may_defer_join(m) is (mt._DEFER_JOIN and mt._WGRAD_STREAM)
+    m.head.weight.grad = torch.zeros(4, 4)                         # the head runs before the blocks: not a reason
+    assert mt._may_defer_join(m) is True
+    m.blocks[1].bias.grad = torch.zeros(4)
+    assert mt._may_defer_join(m) is False
+    m.blocks[1].bias.grad = None
+    h = m.blocks[0].weight.register_post_accumulate_grad_hook(lambda p: None)
+    assert mt._may_defer_join(m) is False
+    h.remove()
+    red = par.BucketedGradAllReduce.__new__(par.BucketedGradAllReduce)           # (its hook orders itself behind the stream)
+    h = m.blocks[0].weight.register_post_accumulate_grad_hook(red._on_grad)
+    assert mt._may_defer_join(m) is True
+    h.remove()
+    m.blocks[0].weight.requires_grad_(False)
+    m.blocks[0].weight.grad = torch.zeros(4, 4)                     # frozen parameters do not count
+    assert mt._may_defer_join(m) is True
