@@ -315,11 +315,24 @@ _SIDE_BIAS = os.environ.get("OMH_SIDE_BIAS", "0") == "1"      # measured: 75.3 m
 _join_pending = {}                      # (device, id(model)) -> token of the pass whose end-of-pass join is queued
 
 
+def _block_params(model, idx=None):
+    """[(name, parameter)] of block ``idx`` (None: the parameters of all blocks), cached on the model: walking the module
+    tree 60 times per step is ~2 ms of host time, and the one-clip backward is bound by the host (tools/
+    host_phase_probe.py).  Parameter OBJECTS are stable under load_state_dict / .to() / requires_grad_; a model whose
+    blocks are replaced gets a new cache through the length / identity check."""
+    cache = model.__dict__.get("_omh_block_params")
+    blocks = model.blocks
+    if cache is None or len(cache[0]) != len(blocks) or any(c[0] is not b for c, b in zip(cache[0], blocks)):
+        per = [(b, list(b.named_parameters())) for b in blocks]
+        cache = model.__dict__["_omh_block_params"] = (per, [p for _, lst in per for _, p in lst])
+    return cache[1] if idx is None else cache[0][idx][1]
+
+
 def _may_defer_join(model):
     if not (_DEFER_JOIN and _WGRAD_STREAM):
         return False
     ours = False
-    for p in model.blocks.parameters():                      # (only the blocks' products run on the second stream)
+    for p in _block_params(model):                           # (only the blocks' products run on the second stream)
         if not p.requires_grad:
             continue
         if p.grad is not None or getattr(p, "_backward_hooks", None):
@@ -901,7 +914,7 @@ class _BlockFn(torch.autograd.Function):
                 if not (done and defer):
                     _wgrad_join(dev)                         # also on an exception: nothing may stay on the side stream
         out = []
-        for n, p in blk.named_parameters():
+        for n, p in _block_params(model, idx):
             gg = grads.get(n) if p.requires_grad else None
             out.append(None if gg is None else gg.view(p.shape).to(p.dtype))
         gdx = grads["__dx__"]
@@ -1122,7 +1135,7 @@ def forward_train(model, x, t, context, seq_len, clip_fea=None, y=None, extra_co
     model.__dict__["_kept_activations"] = st.keep            # what the last training forward did (bench / tests)
     for i, blk in enumerate(model.blocks):
         x_in = xs
-        xs = _BlockFn.apply(xs, model, st, i, *list(blk.parameters()))
+        xs = _BlockFn.apply(xs, model, st, i, *[p for _, p in _block_params(model, i)])
         # forward hooks registered on a block (the reference's discriminator taps block outputs this way,
         # seaweed_apt/model.py:150-155) see the block's output as under nn.Module.__call__; the extra consumer they
         # create is why _BlockFn.backward owns-or-copies its incoming gradient
