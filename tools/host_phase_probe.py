@@ -59,4 +59,4 @@ if os.environ.get("PROFILE"):
         pr.disable()
         opt.step(); opt.zero_grad(set_to_none=True)
     torch.cuda.synchronize()
-    pstats.Stats(pr).sort_stats("tottime").print_stats(45)
+    pstats.Stats(pr).sort_stats("cumulative").print_stats("ops.py|model_train.py|optim.py", 40)
