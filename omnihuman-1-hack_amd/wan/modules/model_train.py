@@ -913,6 +913,8 @@ class _BlockFn(torch.autograd.Function):
             finally:
                 if not (done and defer):
                     _wgrad_join(dev)                         # also on an exception: nothing may stay on the side stream
+                if not done:
+                    _join_pending.pop(key, None)             # (the engine drops its callbacks with the failed pass)
         out = []
         for n, p in _block_params(model, idx):
             gg = grads.get(n) if p.requires_grad else None
