@@ -685,8 +685,8 @@ def _block_backward(model, blk, idx, st, S, dx, P):
                 g[nm] = dw
 
     # ---- FFN branch: x3 = x2 + y3 * g5
-    dy3 = resid_bwd(S["y3"], 5)
     if not frozen_ffn:
+        dy3 = resid_bwd(S["y3"], 5)
         u, u_pre, h2 = S["u"], S["u_pre"], S["h2"]
         g["ffn.2.weight"], g["ffn.2.bias"] = wg.add(dy3, u), _bgrad(dy3, arena)
         du_pre = bf(R, f)                                            # (dy3 W2) * gelu'(u_pre): GELU' in the GEMM's epilogue
@@ -698,7 +698,10 @@ def _block_backward(model, blk, idx, st, S, dx, P):
         dy2 = ln_bwd(S["x2"], dh2, 3, 4, nxt=(None, None))
         del du_pre, dh2
     else:
-        dy2 = resid_bwd(None, None)
+        # the reference's quirk ran this block's FFN without a graph (model.py:317-324): nothing flows back through y3, only
+        # its gate gets a gradient (dx . y3) — in the same pass over dx that makes the cross-attention branch's dy2 = bf16(dx)
+        dy2 = bf(R, d)
+        ops.gated_residual_bwd_raw(ptr(dx), ptr(S["y3"]), ptr(dy2), ptr(d_eb, 5 * d), six, R, d, 1.0, None, None, 0, Sq)
     oc, qc, kc = S["oc"], S["qc"], S["kc"]
     g["cross_attn.o.weight"], g["cross_attn.o.bias"] = wg.add(dy2, oc), _bgrad(dy2, arena)
     doc = _dgrad(dy2, P["wo_cT"], epilogue=EPI_BF16)
