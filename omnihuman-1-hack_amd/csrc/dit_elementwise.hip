@@ -19,9 +19,9 @@ constexpr int MAXV_GENERIC = 32;   // float4 chunks per lane -> dim <= 8192 (spe
 // A wave takes LN_RPW consecutive rows: the modulation vectors (up to four [dim] fp32 vectors, 24 floats per lane each at
 // dim = 1536) are fetched once per wave and batch element instead of once per row — per row they were twice the
 // loads of x itself — and the next row's x is requested before the current row's reductions.
-// LN_RPW rows per wave: 4 on the long sequences (the modulation vectors are fetched once per 4 rows), 1 when the launch
-// would otherwise not give every CU a few waves (the training step's 6 240 rows: 390 workgroups of 4-row waves on 256
-// CUs ran at 2.7 TB/s).  The per-row arithmetic is the same: same bits.
+// LN_RPW rows per wave: 4 on the long sequences (the modulation vectors are fetched once per 4 rows), 2 or 1 when the
+// launch would otherwise not give every CU a few waves (omh_layernorm_modulate picks by the row count, from
+// measurements).  The per-row arithmetic is the same: same bits.
 template <int MAXV, int LN_RPW>
 __global__ __launch_bounds__(256)
 void layernorm_modulate_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t rows, int dim,
@@ -332,14 +332,16 @@ extern "C" int omh_layernorm_modulate(const float* x, void* y, int64_t rows, int
     if ((dim & 3) || dim > MAXV_GENERIC * 256) return OMH_E_SHAPE;
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 7) || (mul1_stride & 3) || (add1_stride & 3)) return OMH_E_ALIGN;
     omh_clear_status();
-    // one row per wave on short launches: measured 23.8 vs 20.9 us at 6 240 x 1536 (the modulation-vector loads per row
-    // cost more than the extra waves hide) — kept selectable, off
-    static const char* rpw_env = getenv("OMH_LN_RPW1");
-    const bool few = rpw_env && rpw_env[0] == '1' && rows < 16384;
-    auto kern = dim <= 6 * 256 ? (few ? layernorm_modulate_kernel<6, 1> : layernorm_modulate_kernel<6, 4>)
-                               : (dim <= 20 * 256 ? (few ? layernorm_modulate_kernel<20, 1> : layernorm_modulate_kernel<20, 4>)
-                                                  : (few ? layernorm_modulate_kernel<MAXV_GENERIC, 1> : layernorm_modulate_kernel<MAXV_GENERIC, 4>));
-    const int rpw = few ? 1 : 4;
+    // rows per wave: 4 on long inputs (the modulation vectors fetched once per 4 rows), fewer when that would leave the CUs
+    // with a handful of waves.  Measured alone (us at 1536 columns, 1 / 2 / 4 rows per wave; tools/ln_rpw_probe.py):
+    // 1 560 rows 6.6 / 7.7 / 10.9, 3 120 rows 8.0 / 8.8 / 11.4, 6 240 rows 19.4 / 16.3 / 17.5, 24 960 rows 69 / 58 / 52.
+    // OMH_LN_RPW = 1 / 2 / 4 forces it (timing).  Same per-row arithmetic: same bits.
+    const char* force = getenv("OMH_LN_RPW");
+    int rpw = rows <= 4096 ? 1 : (rows < 16384 ? 2 : 4);
+    if (force) rpw = atoi(force) == 1 ? 1 : (atoi(force) == 2 ? 2 : 4);
+#define OMH_LN_PICK(MV) (rpw == 1 ? layernorm_modulate_kernel<MV, 1> : (rpw == 2 ? layernorm_modulate_kernel<MV, 2> : layernorm_modulate_kernel<MV, 4>))
+    auto kern = dim <= 6 * 256 ? OMH_LN_PICK(6) : (dim <= 20 * 256 ? OMH_LN_PICK(20) : OMH_LN_PICK(MAXV_GENERIC));
+#undef OMH_LN_PICK
     hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))), dim3(256), 0,
                        (hipStream_t)stream, x, (uint16_t*)y, rows, dim, eps, mul_const, mul0, mul1, mul1_stride,
                        add0, add1, add1_stride, rows_per_batch);
