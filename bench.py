@@ -24,6 +24,7 @@ Extra objects on the JSON line:
   vae           frames/s of the 3D causal VAE decode of the final latent and of encoding the decoded clip.
 """
 import argparse
+import contextlib
 import importlib
 import json
 import math
@@ -401,7 +402,7 @@ def train_step_flops(S=1560, ffn_freeze=True, checkpoint=True, d=1536, f=8960, L
 
 
 def train_bench(model, device, world, dist, steps=20, warmup=3, bsz=4, ffn_freeze=True, loss_quirk=True, checkpoint=True,
-                policy="auto"):
+                policy="auto", accum=1, direct_accum=True):
     """BASELINE config 3: the distilled_trainer.py student step on a batch of [16,1,60,104] clips per GPU
     (forward + per-block recompute + backward on the HIP kernels, bucketed RCCL gradient all-reduce
     overlapped with the backward, fused AdamW).  Returns clips/s over all ranks.
@@ -417,7 +418,13 @@ def train_bench(model, device, world, dist, steps=20, warmup=3, bsz=4, ffn_freez
     policy it is and keeps the activations when a step's worth of them fits in half of the free HBM (0.6 GB per block
     at 4 clips: 18 GB of 288) — same gradients bit for bit, no second forward pass; "always" re-runs every block in the
     backward like torch.utils.checkpoint.  The work counted for the roofline figure follows what was executed (the
-    recompute pass is only counted where it ran: ``activations_kept`` in the result)."""
+    recompute pass is only counted where it ran: ``activations_kept`` in the result).
+
+    ``accum``: micro-steps per optimizer step (the reference trainer accumulates: distilled_trainer.py:41 default 16,
+    --gradient_accumulation_steps default 4 at :372; loss / accum at :289, optimizer step on the last one at :116-134).
+    A timed "step" is then ``accum`` forward + backward passes (the reducer only on the last one) and one AdamW step.
+    ``direct_accum``: model.direct_grad_accumulation — the block backward adds into the existing .grad tensors
+    (model_train._grad_targets) instead of handing autograd a fresh gradient to add."""
     trainer = importlib.import_module(PKG + ".trainer")
     optim = importlib.import_module(PKG + ".optim")
     par = importlib.import_module(PKG + ".parallel")
@@ -425,6 +432,7 @@ def train_bench(model, device, world, dist, steps=20, warmup=3, bsz=4, ffn_freez
     old_freeze, old_ckpt, old_policy = model.reference_ffn_freeze, model.use_checkpoint, getattr(model, "checkpoint_policy", "auto")
     model.reference_ffn_freeze = bool(ffn_freeze)
     model.use_checkpoint, model.checkpoint_policy = bool(checkpoint), policy
+    model.direct_grad_accumulation = bool(direct_accum)
     opt = optim.AdamW(model.parameters(), lr=5e-6, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
     red = par.BucketedGradAllReduce(model.parameters(), bucket_mb=256.0, force=bool(dist and world == 1)) if dist else None
     g = torch.Generator(device=device).manual_seed(7 + int(os.environ.get("RANK", 0)))
@@ -434,7 +442,12 @@ def train_bench(model, device, world, dist, steps=20, warmup=3, bsz=4, ffn_freez
     exposed = []                                            # (event before finish(), event after) per timed step
 
     def one_eager(timed=False):
-        loss = trainer.forward_backward(batch, model, num_train_timesteps=1000, reference_loss_quirk=loss_quirk)
+        for k in range(accum - 1):                          # the non-final micro-steps: no gradient reduction
+            with (red.no_sync() if red is not None else contextlib.nullcontext()):
+                trainer.forward_backward(batch, model, num_train_timesteps=1000, gradient_accumulation_steps=accum,
+                                         reference_loss_quirk=loss_quirk)
+        loss = trainer.forward_backward(batch, model, num_train_timesteps=1000, gradient_accumulation_steps=accum,
+                                        reference_loss_quirk=loss_quirk)
         if red is not None:
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -493,14 +506,18 @@ def train_bench(model, device, world, dist, steps=20, warmup=3, bsz=4, ffn_freez
         red.remove()
     # give the weights and flags back as they were found (the optimizer stepped lr = 5e-6 a few times)
     model.reference_ffn_freeze, model.use_checkpoint, model.checkpoint_policy = old_freeze, old_ckpt, old_policy
+    model.__dict__.pop("direct_grad_accumulation", None)
     model.eval().requires_grad_(False)
     del opt
     kept = bool(model.__dict__.get("_kept_activations", not checkpoint))     # what the timed forwards did
     fl = train_step_flops(1560, ffn_freeze, not kept)
     fwd = dit_forward_flops(1560)
     reducer_ran = red is not None
-    return {"clips_per_s": round(world * bsz * steps / el, 3), "ms_per_step": round(el * 1e3 / steps, 2),
-            "clips_per_gpu_step": bsz, "steps": steps, "finite_loss": bool(math.isfinite(float(loss))),
+    bsz_step = bsz * accum                                   # clips per GPU and optimizer step
+    return {"clips_per_s": round(world * bsz_step * steps / el, 3), "ms_per_step": round(el * 1e3 / steps, 2),
+            "clips_per_gpu_step": bsz_step, "steps": steps,
+            "micro_steps_per_step": accum, "ms_per_micro_step": round(el * 1e3 / steps / accum, 2),
+            "grads_accumulated_in_place": bool(direct_accum) if accum > 1 else None, "finite_loss": bool(math.isfinite(float(loss))),
             "launch_mode": mode, "reference_ffn_freeze": bool(ffn_freeze), "reference_loss_quirk": bool(loss_quirk),
             "use_checkpoint": bool(checkpoint), "checkpoint_policy": policy if checkpoint else None, "activations_kept": kept,
             "work": ("fwd (activations kept in HBM) + bwd" if kept else "fwd + per-block recompute + bwd")
@@ -514,8 +531,8 @@ def train_bench(model, device, world, dist, steps=20, warmup=3, bsz=4, ffn_freez
             "allreduce_exposed_ms": None if exposed_ms is None else round(exposed_ms, 3),
             "algorithmic_tflop_per_clip": round(fl / 1e12, 2),
             "algorithmic_over_forward": round(fl / fwd, 2),
-            "achieved_tflops_per_gpu": round(fl * bsz * steps / el / 1e12, 1),
-            "mfma_roofline_frac": round(fl * bsz * steps / el / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "achieved_tflops_per_gpu": round(fl * bsz_step * steps / el / 1e12, 1),
+            "mfma_roofline_frac": round(fl * bsz_step * steps / el / 1e12 / PEAK_BF16_TFLOPS, 4),
             "telemetry": tele}
 
 
@@ -595,6 +612,12 @@ def train_legs(model, device, world, dist):
             out["batch_16"] = train_bench(model, device, world, dist, bsz=16)
             out["recompute"]["batch_16"] = train_bench(model, device, world, dist, bsz=16, policy="always")
         out["no_reference_quirks"] = train_bench(model, device, world, dist, bsz=bsz, ffn_freeze=False, loss_quirk=False)
+        # the reference trainer's gradient accumulation (4 micro-steps per optimizer step: its --gradient_accumulation_steps
+        # default), the block backward adding into the existing .grad tensors / autograd adding fresh gradients to them
+        ak = dict(tk) if tk else dict(steps=6, warmup=2)
+        out["accumulation_4"] = train_bench(model, device, world, dist, bsz=bsz, accum=4, **ak)
+        out["accumulation_4"]["autograd_route"] = train_bench(model, device, world, dist, bsz=bsz, accum=4,
+                                                              direct_accum=False, **ak)
     except Exception as e:
         out["extra_legs_error"] = repr(e)[:300]
     return out

@@ -300,8 +300,9 @@ def reducer_stream(dev):
 # (OMH_WGRAD_DEFER=0: per block, as rounds 2-3).  A block's last group (q|k|v) is launched when its backward is nearly
 # done; joining there made the main stream wait for it with most of the chip idle, 30 times per step.  Deferred, the
 # group of block i runs under the backward of block i-1.  Legal only when nothing reads the gradients before the pass
-# ends: every trainable parameter's .grad is None (autograd then just stores the tensor; an existing .grad would be
-# accumulated into on the main stream), no tensor / post-accumulate hooks on the parameters other than this package's
+# ends: every trainable parameter's .grad is None (autograd then just stores the tensor) or is accumulated into by the
+# block backward itself (_grad_targets below; an existing .grad that autograd has to add to is added to on the main
+# stream), no tensor / post-accumulate hooks on the parameters other than this package's
 # reducer (which packs its buckets on that stream: reducer_stream), and no other multi-process gradient reducer in sight (torch DDP hooks the
 # accumulator nodes, which cannot be seen from here: with torch.distributed initialised on more than one rank and none
 # of our reducer's hooks on the parameters the join stays per block).
@@ -328,14 +329,69 @@ def _block_params(model, idx=None):
     return cache[1] if idx is None else cache[0][idx][1]
 
 
+# Gradient accumulation (the reference trainer's 16 micro-steps, distilled_trainer.py:41,116-134,289): from the second
+# micro-step on every parameter has a .grad, autograd would add each block's fresh gradients to it on the main stream
+# (3.6 GB read + 3.6 GB written per micro-step at 1.3B) and the join of the weight-gradient stream would fall back to
+# once per block.  Instead the block backward accumulates INTO the existing .grad tensors — the weight-gradient GEMMs
+# through their accumulate epilogue on the second stream, the bias / gain / modulation sums through kernels that add
+# into their output anyway — and hands autograd None for those parameters.  fp32 arithmetic is the same
+# (old + (sum over the rows)): matrices bit-identical to the autograd route.  OMH_GRAD_ACCUM_DIRECT=0 or
+# ``model.direct_grad_accumulation = False`` restore the autograd route.
+_DIRECT_ACCUM = os.environ.get("OMH_GRAD_ACCUM_DIRECT", "1") == "1"
+
+
+def _direct_on(model):
+    return _DIRECT_ACCUM and getattr(model, "direct_grad_accumulation", True)
+
+
+def _direct_usable(p):
+    """``p.grad`` is something the kernels can add into in place: dense fp32 of the parameter's own shape."""
+    g = p.grad
+    return (g is not None and g.dtype == torch.float32 and p.dtype == torch.float32 and g.shape == p.shape
+            and g.layout == torch.strided and g.is_contiguous() and g.device == p.device and not g.requires_grad)
+
+
+def _grad_targets(ctx, model, idx):
+    """The existing ``.grad`` tensors block ``idx``'s backward may accumulate into: {name: parameter} ({} when the block
+    has none: first micro-step), or None when gradients exist but the autograd route has to be taken — a gradient of
+    another dtype / layout, tensor hooks or foreign post-accumulate hooks on a parameter (they would not fire), a
+    multi-process reducer that is not this package's (torch DDP hooks the accumulator nodes and would wait for them
+    forever), double backward, or a pass that does not run the parameters' AccumulateGrad nodes at all
+    (``torch.autograd.grad(loss, params)``: the caller wants the gradients returned, not accumulated)."""
+    have = [(n, p) for n, p in _block_params(model, idx) if p.requires_grad and p.grad is not None]
+    if not have:
+        return {}
+    if not _direct_on(model) or torch.is_grad_enabled():
+        return None
+    ours = False
+    for _, p in have:
+        if not _direct_usable(p) or getattr(p, "_backward_hooks", None):
+            return None
+        for h in (getattr(p, "_post_accumulate_grad_hooks", None) or {}).values():
+            if not getattr(getattr(h, "__self__", None), "_omh_joins_side_streams", False):
+                return None
+            ours = True
+    if not ours and torch.distributed.is_available() and torch.distributed.is_initialized():
+        return None
+    nodes = {id(fn.variable): fn for fn, _ in ctx.next_functions if fn is not None and hasattr(fn, "variable")}
+    try:                                                      # (backward(inputs=[...]): only the named leaves accumulate)
+        have = [(n, p) for n, p in have if id(p) in nodes and torch._C._will_engine_execute_node(nodes[id(p)])]
+    except Exception:                                         # autograd.grad(..., inputs=[p]): the engine says so by raising
+        return None
+    return dict(have) if have else None
+
+
 def _may_defer_join(model):
     if not (_DEFER_JOIN and _WGRAD_STREAM):
         return False
     ours = False
+    direct = _direct_on(model)
     for p in _block_params(model):                           # (only the blocks' products run on the second stream)
         if not p.requires_grad:
             continue
-        if p.grad is not None or getattr(p, "_backward_hooks", None):
+        if getattr(p, "_backward_hooks", None):
+            return False
+        if p.grad is not None and not (direct and _direct_usable(p)):      # autograd would add to it on the main stream
             return False
         for h in (getattr(p, "_post_accumulate_grad_hooks", None) or {}).values():
             if not getattr(getattr(h, "__self__", None), "_omh_joins_side_streams", False):
@@ -622,8 +678,10 @@ def _block_forward(model, blk, idx, st, x0, P, keep, need=True):
 
 
 # ----------------------------------------------------------------------------- block backward
-def _block_backward(model, blk, idx, st, S, dx, P):
-    """Back-propagate dx (fp32 [B, S, d], updated in place) through block ``idx`` given its kept tensors ``S``."""
+def _block_backward(model, blk, idx, st, S, dx, P, tgt=None):
+    """Back-propagate dx (fp32 [B, S, d], updated in place) through block ``idx`` given its kept tensors ``S``.
+    ``tgt`` ({name: parameter}, _grad_targets): parameters whose existing ``.grad`` the gradient is ADDED to in place
+    (gradient accumulation); the returned dict then holds that ``.grad`` tensor under the name."""
     fc = st.fc
     x0 = S["x0"]
     B, Sq, d = x0.shape
@@ -646,6 +704,46 @@ def _block_backward(model, blk, idx, st, S, dx, P):
     wg = _WgradGroup(dev)
     d_eb = arena.take(B, 6, d)                                        # grads of e = modulation + e0
     g = {}
+    tgt = tgt or {}
+
+    def acc1(name, n):
+        """The fp32 accumulator of a 1-D gradient: the parameter's own .grad (added to) or a zeroed arena slice."""
+        p = tgt.get(name)
+        return p.grad.view(n) if p is not None else arena.take(n)
+
+    def bgrad(dy, names, now=False):
+        """Bias gradients = column sums of dy, deferred to arena.flush() at the end of the block (``now``: launched here,
+        on the current stream); ``names``: the parameters stacked along dy's columns, each ``d`` wide when there are
+        several.  One pair for the whole width unless a parameter accumulates into its own .grad."""
+        if len(names) == 1 or not any(n in tgt for n in names):
+            out = acc1(names[0], dy.shape[1]) if len(names) == 1 else arena.take(dy.shape[1])
+            pairs = [(dy, out)]
+            for j, n in enumerate(names):
+                g[n] = out if len(names) == 1 else out[j * d:(j + 1) * d]
+        else:
+            pairs = []
+            for j, n in enumerate(names):
+                g[n] = acc1(n, d)
+                pairs.append((dy[:, j * d:(j + 1) * d], g[n]))
+        if now:
+            ops.colsum_accum_multi(pairs)
+        else:
+            arena.pending.extend(pairs)
+
+    def wgrad(dy, x, names):
+        """Weight gradients dy^T x into g[names] (parameters stacked along dy's columns, ``d`` wide each): one product,
+        or one per parameter — same tiles, same launch — when a parameter accumulates into its own .grad."""
+        if len(names) == 1:
+            p = tgt.get(names[0])
+            g[names[0]] = wg.add(dy, x, out=p.grad if p is not None else None)
+        elif not any(n in tgt for n in names):
+            out = wg.add(dy, x)
+            for j, n in enumerate(names):
+                g[n] = out[j * d:(j + 1) * d]
+        else:
+            for j, n in enumerate(names):
+                p = tgt.get(n)
+                g[n] = wg.add(dy[:, j * d:(j + 1) * d], x, out=p.grad if p is not None else None)
 
     def ln_bwd(xin, dh, shift_i, scale_i, nxt=None):
         """dx += LN+modulate backward of dh; ``nxt = (y, gate_i)``: also the next branch's gated-residual backward on
@@ -674,7 +772,7 @@ def _block_backward(model, blk, idx, st, S, dx, P):
 
     def rms_bwd(x, x_bf16, ldx, dy, lddy, rows, weights, norm_on, rope, names, mod_, n_seg=1, seg_x=0, seg_dy=0):
         """In place on dy (bf16): dy <- gradient of the pre-norm projection; the norm gains' gradients into g[names]."""
-        dws = [arena.take(d) if norm_on else None for _ in range(n_seg)]
+        dws = [acc1(nm, d) if norm_on else None for nm in names[:n_seg]]
         rk = dict(rope_cos=ptr(fc.rope_cos), rope_sin=ptr(fc.rope_sin), rope_len=fc.rope_cos.shape[0], grid=ptr(fc.grid32),
                   seq_len=Sq) if rope else {}
         ops.rmsnorm_rope_bwd2(x, x_bf16, ldx, dy, True, lddy, dy, lddy, rows, d, mod_.eps, norm_on,
@@ -688,10 +786,10 @@ def _block_backward(model, blk, idx, st, S, dx, P):
     if not frozen_ffn:
         dy3 = resid_bwd(S["y3"], 5)
         u, u_pre, h2 = S["u"], S["u_pre"], S["h2"]
-        g["ffn.2.weight"], g["ffn.2.bias"] = wg.add(dy3, u), _bgrad(dy3, arena)
+        wgrad(dy3, u, ["ffn.2.weight"]), bgrad(dy3, ["ffn.2.bias"])
         du_pre = bf(R, f)                                            # (dy3 W2) * gelu'(u_pre): GELU' in the GEMM's epilogue
         ops.gemm_raw(ptr(dy3), ptr(P["w2T"]), ptr(du_pre), R, f, d, d, d, f, EPI_GELU_BWD, aux=ptr(u_pre), ldaux=f)
-        g["ffn.0.weight"], g["ffn.0.bias"] = wg.add(du_pre, h2), _bgrad(du_pre, arena)
+        wgrad(du_pre, h2, ["ffn.0.weight"]), bgrad(du_pre, ["ffn.0.bias"])
         wg.launch()                                                  # FFN weight gradients: second stream, from here on
         dh2 = _dgrad(du_pre, P["w1T"])
         # ---- cross-attention branch: x2 = x1 + y2  (its dy2 = bf16(dx) comes out of the same pass)
@@ -703,7 +801,7 @@ def _block_backward(model, blk, idx, st, S, dx, P):
         dy2 = bf(R, d)
         ops.gated_residual_bwd_raw(ptr(dx), ptr(S["y3"]), ptr(dy2), ptr(d_eb, 5 * d), six, R, d, 1.0, None, None, 0, Sq)
     oc, qc, kc = S["oc"], S["qc"], S["kc"]
-    g["cross_attn.o.weight"], g["cross_attn.o.bias"] = wg.add(dy2, oc), _bgrad(dy2, arena)
+    wgrad(dy2, oc, ["cross_attn.o.weight"]), bgrad(dy2, ["cross_attn.o.bias"])
     doc = _dgrad(dy2, P["wo_cT"], epilogue=EPI_BF16)
     Rc = B * Lt
     ctx2 = fc.ctx.view(B * Lc, d) if not i2v else fc.ctx[:, n_img:].contiguous().view(Rc, d)
@@ -731,33 +829,34 @@ def _block_backward(model, blk, idx, st, S, dx, P):
         ops.cast_bf16_strided(dvi, dkvi[:, d:])
         rms_bwd(ptr(S["kfi"]), False, d, ptr(dkvi), 2 * d, Ri, [ca._norm_w("norm_k_img")], ca.qk_norm, False,
                 ["cross_attn.norm_k_img.weight"], ca)
-        dwi, dbi = wg.add(dkvi, ctxi), _bgrad(dkvi, arena)
-        g["cross_attn.k_img.weight"], g["cross_attn.v_img.weight"] = dwi[:d], dwi[d:]
-        g["cross_attn.k_img.bias"], g["cross_attn.v_img.bias"] = dbi[:d], dbi[d:]
+        wgrad(dkvi, ctxi, ["cross_attn.k_img.weight", "cross_attn.v_img.weight"])
+        bgrad(dkvi, ["cross_attn.k_img.bias", "cross_attn.v_img.bias"])
         _dgrad_ctx(dkvi, P["wkv_iT"], st.d_ctx, 0, n_img)
         del dq32, dk32, dv32, dqi, dki, dvi
     rms_bwd(ptr(S["qcb"]), True, d, ptr(dqc), d, R, [ca._norm_w("norm_q")], ca.qk_norm, False, ["cross_attn.norm_q.weight"], ca)
     h3 = S["h3"]
-    g["cross_attn.q.weight"], g["cross_attn.q.bias"] = wg.add(dqc, h3), _bgrad(dqc, arena)
+    wgrad(dqc, h3, ["cross_attn.q.weight"]), bgrad(dqc, ["cross_attn.q.bias"])
     dh3 = _dgrad(dqc, P["wq_cT"])
     # The gradient of the text keys / values is off the critical path (nothing in this block reads it again): its norm
     # backward and its context-gradient GEMM go to the second stream, in front of the weight-gradient group that reads
     # dkv there (one stream: in order).  st.d_ctx is read by the embedding node, which joins first.
+    # (The k | v bias gradients are column sums of dkv AFTER the norm backward has rewritten its k half in place: they are
+    # launched right behind it on the same stream, not with the block's other column sums at the end of the main stream's
+    # block — that flush does not wait for the second stream and would read the k half before or while it is rewritten.)
     def kv_path():
         rms_bwd(ptr(S["kf"]), False, d, ptr(dkv), 2 * d, Rc, [ca._norm_w("norm_k")], ca.qk_norm, False,
                 ["cross_attn.norm_k.weight"], ca)
+        bgrad(dkv, ["cross_attn.k.bias", "cross_attn.v.bias"], now=True)
         _dgrad_ctx(dkv, P["wkv_cT"], st.d_ctx, n_img, Lt)
     if _SIDE_KV and not i2v:
         _on_side(dev, kv_path, (dkv, S["kf"], st.d_ctx, arena.buf, fc.ctx))
     else:
         kv_path()
-    dwkv, dbkv = wg.add(dkv, ctx2), _bgrad(dkv, arena)                 # [2d, d]: k | v in one GEMM
-    g["cross_attn.k.weight"], g["cross_attn.v.weight"] = dwkv[:d], dwkv[d:]
-    g["cross_attn.k.bias"], g["cross_attn.v.bias"] = dbkv[:d], dbkv[d:]
+    wgrad(dkv, ctx2, ["cross_attn.k.weight", "cross_attn.v.weight"])   # [2d, d]: k | v in one GEMM
     x1 = S["x1"]
     if blk.cross_attn_norm:
         # ---- self-attention branch: x1 = x0 + y1 * g2  (dy1 = bf16(dx * g2) and the gate's gradient: same pass)
-        dw3, db3 = arena.take(d), arena.take(d)
+        dw3, db3 = acc1("norm3.weight", d), acc1("norm3.bias", d)
         dy1 = bf(R, d)
         ops.layernorm_modulate_bwd2(x1, dh3, dx, R, d, blk.norm3.eps, 0.0, ptr(S["w3"]), None, 0, ptr(dw3), ptr(db3), 0, Sq,
                                     dy_next=dy1, y_next=S["y1"], gate_const=0.0, gate0=ptr(mod, 2 * d), gate1=ptr(e0, 2 * d),
@@ -768,7 +867,7 @@ def _block_backward(model, blk, idx, st, S, dx, P):
         dy1 = resid_bwd(S["y1"], 2)
     del dy2, doc, dh3
     o, q, k, h1 = S["o"], S["q"], S["k"], S["h1"]
-    g["self_attn.o.weight"], g["self_attn.o.bias"] = wg.add(dy1, o), _bgrad(dy1, arena)
+    wgrad(dy1, o, ["self_attn.o.weight"]), bgrad(dy1, ["self_attn.o.bias"])
     # the cross-attention's weight gradients + the self-attention's o: 3 x 144 full-K tiles + 288 short ones = about one
     # round of the 512 resident 128 x 128 tiles (with q|k|v's 432 tiles in the same launch it would be 2.2 rounds = 3)
     wg.launch()
@@ -780,14 +879,13 @@ def _block_backward(model, blk, idx, st, S, dx, P):
     qk = S["qk"]
     rms_bwd(ptr(qk), True, 2 * d, ptr(dqkv), 3 * d, R, [sa._norm_w("norm_q"), sa._norm_w("norm_k")], sa.qk_norm, True,
             ["self_attn.norm_q.weight", "self_attn.norm_k.weight"], sa, n_seg=2, seg_x=d, seg_dy=d)   # q and k: one launch
-    dwqkv, dbqkv = wg.add(dqkv, h1), _bgrad(dqkv, arena)               # [3d, d]: q | k | v in one GEMM
+    wgrad(dqkv, h1, [f"self_attn.{nm}.weight" for nm in "qkv"])       # [3d, d]: q | k | v in one GEMM
+    bgrad(dqkv, [f"self_attn.{nm}.bias" for nm in "qkv"])
     wg.launch()                                                      # the self-attention's weight gradients
-    for j, nm in enumerate(("q", "k", "v")):
-        g[f"self_attn.{nm}.weight"], g[f"self_attn.{nm}.bias"] = dwqkv[j * d:(j + 1) * d], dbqkv[j * d:(j + 1) * d]
     dh1 = _dgrad(dqkv, P["wqkvT"])                                      # K = 3d: dq Wq + dk Wk + dv Wv
     ln_bwd(x0, dh1, 0, 1)
     # ---- modulation / e0
-    dmod = arena.take(six)
+    dmod = acc1("modulation", six)
     ops.colsum_accum(d_eb.view(B, six), dmod)
     g["modulation"] = dmod
     ops.colsum_accum(d_eb.view(1, B * six), st.d_e0.view(B * six))      # d_e0 += d_eb
@@ -892,10 +990,16 @@ class _BlockFn(torch.autograd.Function):
             # the join of the weight-gradient stream: deferred to the end of this backward pass when legal — decided by the
             # first block of this forward to run in a pass (a second forward of the same model in the pass then finds
             # gradients in place and joins per block; so does a second pass over the same graph)
+            tgt = _grad_targets(ctx, model, idx)             # gradient accumulation: existing .grad tensors to add into
             key = (dev, id(model))
             tok = _join_pending.get(key)
             if tok is not None and st.__dict__.get("defer_tok") is tok:
                 defer = True
+            elif tok is not None:
+                # another forward of this model in the same pass: the engine sums the two contributions to a parameter's
+                # gradient on the main stream as soon as this node returns — behind this block's join, which also covers
+                # what the other forward's blocks left on the second stream
+                defer = False
             elif st.__dict__.get("no_defer", False):
                 defer = False
             elif _may_defer_join(model):
@@ -911,16 +1015,21 @@ class _BlockFn(torch.autograd.Function):
                 st.no_defer, defer = True, False
             done = False
             try:
-                grads = _block_backward(model, blk, idx, st, S, dx, P)
+                grads = _block_backward(model, blk, idx, st, S, dx, P, tgt)
                 done = True
             finally:
-                if not (done and defer):
+                # (tgt None: gradients exist and autograd will add this block's to them on the main stream)
+                if not (done and defer and tgt is not None):
                     _wgrad_join(dev)                         # also on an exception: nothing may stay on the side stream
                 if not done:
                     _join_pending.pop(key, None)             # (the engine drops its callbacks with the failed pass)
         out = []
         for n, p in _block_params(model, idx):
             gg = grads.get(n) if p.requires_grad else None
+            if gg is not None and tgt and n in tgt:          # added to p.grad in place: nothing for autograd to do, and
+                gg = None                                    # its AccumulateGrad node — the hooks on it — does not run:
+                for h in list((getattr(p, "_post_accumulate_grad_hooks", None) or {}).values()):
+                    h(p)                                     # this package's reducer (only its hooks get this far) is told here
             out.append(None if gg is None else gg.view(p.shape).to(p.dtype))
         gdx = grads["__dx__"]
         gdx._omh_exclusive = True                             # fresh from this node: the previous block may update it in place

@@ -305,7 +305,8 @@ def test_k_major_stream_generator_invariants():
 
 def test_deferred_join_policy_without_a_gpu(omh):
     """model_train._may_defer_join (host logic only): the weight-gradient stream may be joined at the end of the pass only
-    when no block parameter has a gradient in place and nobody but this package's reducer hooks the parameters."""
+    when no block parameter has a gradient in place that autograd would add to (the block backward adds into dense fp32
+    ones itself) and nobody but this package's reducer hooks the parameters."""
     mt = importlib.import_module(PKG + ".wan.modules.model_train")
     par = importlib.import_module(PKG + ".parallel")
 
@@ -318,7 +319,12 @@ def test_deferred_join_policy_without_a_gpu(omh):
     assert mt._may_defer_join(m) is (mt._DEFER_JOIN and mt._WGRAD_STREAM)
     m.head.weight.grad = torch.zeros(4, 4)                         # the head runs before the blocks: not a reason
     assert mt._may_defer_join(m) is True
-    m.blocks[1].bias.grad = torch.zeros(4)
+    m.blocks[1].bias.grad = torch.zeros(4)                          # a gradient in place the block backward adds into
+    assert mt._may_defer_join(m) is True
+    m.direct_grad_accumulation = False                              # ... that autograd adds to, on the main stream
+    assert mt._may_defer_join(m) is False
+    del m.direct_grad_accumulation
+    m.blocks[1].bias.grad = torch.zeros(8)[::2]                     # not something the kernels can add into (strided)
     assert mt._may_defer_join(m) is False
     m.blocks[1].bias.grad = None
     h = m.blocks[0].weight.register_post_accumulate_grad_hook(lambda p: None)
@@ -331,3 +337,74 @@ def test_deferred_join_policy_without_a_gpu(omh):
     m.blocks[0].weight.requires_grad_(False)
     m.blocks[0].weight.grad = torch.zeros(4, 4)                     # frozen parameters do not count
     assert mt._may_defer_join(m) is True
+
+
+
+def test_gradient_accumulation_targets_without_a_gpu(omh):
+    """model_train._grad_targets (host logic only): which existing .grad tensors a block's backward may add into — none
+    on the first micro-step, all dense fp32 ones afterwards; the autograd route (None) for a strided gradient,
+    tensor hooks / foreign post-accumulate hooks, ``torch.autograd.grad`` w.r.t. the parameters, double backward, an
+    initialised process group without this package's reducer, and when switched off."""
+    mt = importlib.import_module(PKG + ".wan.modules.model_train")
+    par = importlib.import_module(PKG + ".parallel")
+    seen = []
+
+    class Blk(torch.nn.Linear):
+        pass
+
+    class Node(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, model, idx, *params):
+            ctx.model, ctx.idx = model, idx
+            return x @ params[0].t() + params[1]
+
+        @staticmethod
+        def backward(ctx, g):
+            seen.append(mt._grad_targets(ctx, ctx.model, ctx.idx))
+            return g, None, None, g.t() @ g, g.sum(0)
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.blocks = torch.nn.ModuleList([Blk(4, 4) for _ in range(2)])
+
+        def forward(self, x):
+            for i, b in enumerate(self.blocks):
+                x = Node.apply(x, self, i, *[p for _, p in mt._block_params(self, i)])
+            return x.sum()
+    m = Tiny()
+    x = torch.ones(3, 4)
+
+    def run(fn=None):
+        seen.clear()
+        (fn or (lambda: m(x).backward()))()
+        return list(seen)
+    assert run() == [{}, {}]                                               # first micro-step: nothing in place
+    got = run()                                                            # second: every parameter of both blocks
+    assert [sorted(t) for t in got] == [["bias", "weight"]] * 2 and got[0]["weight"] is m.blocks[1].weight
+    assert run(lambda: torch.autograd.grad(m(x), [m.blocks[0].weight, m.blocks[1].bias])) == [None, None]
+    xg = torch.ones(3, 4, requires_grad=True)
+    assert run(lambda: torch.autograd.grad(m(xg), [xg])) == [None, None]   # no AccumulateGrad node runs
+    assert [sorted(t) for t in run(lambda: m(x).backward(inputs=[m.blocks[1].weight]))] == [["weight"]]
+    got = run(lambda: m(x).backward(inputs=[m.blocks[0].bias]))            # block 1: gradients in place, none to accumulate
+    assert got[0] is None and sorted(got[1]) == ["bias"]
+    m.direct_grad_accumulation = False
+    assert run() == [None, None]
+    del m.direct_grad_accumulation
+    h = m.blocks[1].weight.register_hook(lambda g: g)
+    assert [t is None for t in run()] == [True, False]
+    h.remove()
+    h = m.blocks[0].bias.register_post_accumulate_grad_hook(lambda p: None)
+    assert [t is None for t in run()] == [False, True]
+    h.remove()
+    red = par.BucketedGradAllReduce.__new__(par.BucketedGradAllReduce)
+    red.enabled = False
+    h = m.blocks[0].bias.register_post_accumulate_grad_hook(red._on_grad)   # this package's reducer: told by the block node
+    assert all(t for t in run())
+    h.remove()
+    m.blocks[0].weight.grad = torch.zeros(4, 8)[:, ::2]                    # strided
+    assert [t is None for t in run()] == [False, True]
+    m.blocks[0].weight.grad = None                                         # (e.g. a frozen FFN: never gets a gradient)
+    assert [sorted(t) for t in run()] == [["bias", "weight"], ["bias"]]
+    assert run(lambda: m(x).backward(create_graph=True)) == [None, None]
+

@@ -1022,7 +1022,7 @@ def test_deferred_join_of_the_weight_gradient_stream(wan_model_mod, monkeypatch)
         monkeypatch.setattr(mt, "_DEFER_JOIN", True)
         got = grads(two)
         assert not mt._join_pending                                     # the end-of-pass callback ran
-        acc = grads(two, accumulate=True)                               # second pass: .grad exists -> per-block join
+        acc = grads(two, accumulate=True)                               # second pass: into the existing .grad tensors
         monkeypatch.setattr(mt, "_DEFER_JOIN", False)
         want = grads(two)
         for n in want:
@@ -1032,7 +1032,10 @@ def test_deferred_join_of_the_weight_gradient_stream(wan_model_mod, monkeypatch)
             else:                                                        # column sums with fp32 atomics, and what hangs off
                 assert rel_rms(got[n], want[n]) < 1e-4, n                # them (modulation -> time embedding)
     monkeypatch.setattr(mt, "_DEFER_JOIN", True)
-    assert mt._may_defer_join(m) is False                                # gradients in place
+    assert mt._may_defer_join(m) is True                                 # gradients in place: the blocks add into them
+    m.direct_grad_accumulation = False
+    assert mt._may_defer_join(m) is False                                # ... autograd does, on the main stream
+    del m.direct_grad_accumulation
     m.zero_grad(set_to_none=True)
     p0 = m.blocks[3].self_attn.o.weight
     h = p0.register_post_accumulate_grad_hook(lambda p: None)
@@ -1042,3 +1045,120 @@ def test_deferred_join_of_the_weight_gradient_stream(wan_model_mod, monkeypatch)
     h = p0.register_hook(lambda g_: g_)
     assert mt._may_defer_join(m) is False
     h.remove()
+
+
+def test_gradient_accumulation_adds_into_the_existing_grads(wan_model_mod, monkeypatch):
+    """Gradient accumulation (distilled_trainer.py:41,116-134,289: 16 micro-steps per optimizer step).  From the second
+    micro-step on the block backward adds INTO the existing .grad tensors (weight-gradient GEMMs with their accumulate
+    epilogue on the second stream, 1-D sums through kernels that add into their output) and returns None to autograd:
+    the .grad tensors stay the same objects / storage, the matrices equal the autograd route (fresh gradient, then
+    grad += on the main stream) bit for bit, the 1-D sums to fp32 rounding; the join of the second stream stays at the end
+    of the pass.  ``torch.autograd.grad`` w.r.t. parameters that hold a .grad must return the gradients and leave
+    .grad alone; a bf16 / foreign-hooked parameter sends its block down the autograd route."""
+    mt = importlib.import_module(PKG + ".wan.modules.model_train")
+    for freeze in (False, True):
+        cfg, sd, m, noise, vt, cl = _setup(wan_model_mod, freeze=freeze)
+        args = dict(t=torch.ones(2, device="cuda") * 1000.0, context=[c.cuda() for c in cl], seq_len=24)
+
+        def loss_of(scale):
+            out = m(list((noise * scale).cuda()), **args)
+            return sum(torch.nn.functional.mse_loss(a, b) for a, b in zip(out, vt.cuda()))
+
+        def three_micro_steps(direct):
+            m.direct_grad_accumulation = direct
+            m.zero_grad(set_to_none=True)
+            ptrs, calls = None, []
+            for k, scale in enumerate((1.0, 0.5, -0.75)):
+                real = mt._grad_targets
+                monkeypatch.setattr(mt, "_grad_targets", lambda *a, **kw: calls.append(real(*a, **kw)) or calls[-1])
+                loss_of(scale).backward()
+                monkeypatch.setattr(mt, "_grad_targets", real)
+                assert not mt._join_pending
+                if k == 0:
+                    ptrs = {n: (id(p.grad), p.grad.data_ptr()) for n, p in m.named_parameters() if p.grad is not None}
+            torch.cuda.synchronize()
+            return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}, ptrs, calls
+
+        want, _, calls0 = three_micro_steps(False)
+        assert all(c is None or c == {} for c in calls0)
+        got, ptrs, calls1 = three_micro_steps(True)
+        nblk = len(m.blocks)
+        assert all(c == {} for c in calls1[:nblk]) and all(c for c in calls1[nblk:])      # micro-steps 2, 3: direct
+        assert set(got) == set(want)
+        for n, p in m.named_parameters():
+            if p.grad is None:
+                continue
+            if n.startswith("blocks."):                                   # still the first micro-step's tensor
+                assert (id(p.grad), p.grad.data_ptr()) == ptrs[n], n
+            if want[n].dim() >= 2 and n.startswith("blocks."):
+                assert torch.equal(got[n], want[n]), n
+            else:
+                assert rel_rms(got[n], want[n]) < 1e-5, n
+        # autograd.grad with gradients in place: returned, not accumulated
+        before = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        ps = [m.blocks[2].self_attn.q.weight, m.blocks[2].cross_attn.k.bias, m.blocks[0].modulation]
+        gs = torch.autograd.grad(loss_of(1.0), ps)
+        torch.cuda.synchronize()
+        for n, p in m.named_parameters():
+            if p.grad is not None:
+                assert torch.equal(p.grad, before[n]), n
+        m.zero_grad(set_to_none=True)
+        loss_of(1.0).backward()
+        torch.cuda.synchronize()
+        for p, g_ in zip(ps, gs):
+            assert rel_rms(g_, p.grad) < 1e-5
+        # a parameter with a foreign hook: its block takes the autograd route (hook fires, values right), the others stay direct
+        seen = []
+        h = m.blocks[1].self_attn.o.weight.register_post_accumulate_grad_hook(lambda p: seen.append(1))
+        calls = []
+        real = mt._grad_targets
+        monkeypatch.setattr(mt, "_grad_targets", lambda *a, **kw: calls.append(real(*a, **kw)) or calls[-1])
+        loss_of(0.5).backward()
+        monkeypatch.setattr(mt, "_grad_targets", real)
+        h.remove()
+        torch.cuda.synchronize()
+        assert seen == [1] and sum(c is None for c in calls) == 1 and all(c for c in calls if c is not None)
+        ref = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        m.direct_grad_accumulation = False
+        m.zero_grad(set_to_none=True)
+        loss_of(1.0).backward()
+        loss_of(0.5).backward()
+        torch.cuda.synchronize()
+        for n, p in m.named_parameters():
+            if p.grad is not None:
+                if p.grad.dim() >= 2 and n.startswith("blocks."):
+                    assert torch.equal(p.grad, ref[n]), n
+                else:
+                    assert rel_rms(p.grad, ref[n]) < 1e-5, n
+        del m.direct_grad_accumulation
+
+
+def test_cross_attention_key_bias_gradient_waits_for_the_norm_backward(wan_model_mod, monkeypatch):
+    """The k | v bias gradients of the cross-attention are column sums of dkv AFTER the key norm's backward has rewritten
+    the k half in place — on the second stream when the key / value gradient path runs there.  With that stream held back
+    (a long sleep queued on it before the pass) a column sum launched from the main stream would read the k half too
+    early: the values must equal the one-stream schedule's."""
+    mt = importlib.import_module(PKG + ".wan.modules.model_train")
+    cfg, sd, m, noise, vt, cl = _setup(wan_model_mod, freeze=False)
+    args = dict(t=torch.ones(2, device="cuda") * 1000.0, context=[c.cuda() for c in cl], seq_len=24)
+
+    def grads(side_kv, hold):
+        monkeypatch.setattr(mt, "_SIDE_KV", side_kv)
+        m.zero_grad(set_to_none=True)
+        out = m(list(noise.cuda()), **args)
+        loss = sum(torch.nn.functional.mse_loss(a, b) for a, b in zip(out, vt.cuda()))
+        torch.cuda.synchronize()
+        if hold:
+            with torch.cuda.stream(mt._side_stream(torch.device("cuda", torch.cuda.current_device()))):
+                torch.cuda._sleep(int(2.0e8))                              # ~0.1 s: the whole backward is enqueued meanwhile
+        loss.backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.clone() for n, p in m.named_parameters() if "cross_attn" in n and n.endswith(".bias")}
+
+    want = grads(False, False)
+    assert any(float(v.abs().max()) > 0 for n, v in want.items() if n.endswith("cross_attn.k.bias"))
+    for hold in (False, True):
+        got = grads(True, hold)
+        for n in want:
+            assert rel_rms(got[n], want[n]) < 1e-5, (n, hold)
+
