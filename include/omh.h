@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OMH_ABI_VERSION 8
+#define OMH_ABI_VERSION 9
 
 #define OMH_E_BADARG   (-1)   /* null pointer / non-positive size             */
 #define OMH_E_ALIGN    (-2)   /* pointer or leading dimension not aligned     */
@@ -94,9 +94,19 @@ typedef struct omh_gemm_args {
               OMH_EPI_GELU_BF16      OUT  aux = bf16(acc + bias): the pre-activation the GELU backward needs
               OMH_EPI_GELU_BWD_BF16  IN   the forward's pre-activation                                        */
     const float* c_in; void* aux; int32_t ldaux;
+    /* ABI v9 — split K for few-row, long-contraction products (the FFN-down projection and the FFN-up input gradient of
+       model.py:272-274,328 at one or two [16,1,60,104] clips: 56 / 104 tiles of 256 x 192 on 256 CUs).  With
+       workspace_bytes >= omh_gemm_workspace_bytes(args) > 0 the contraction is cut into S = 2..4 equal slices, slice s
+       of every tile is one workgroup of the 256 x 192 stream writing its fp32 partial to workspace[s], and a second
+       launch adds the slices in the order s = 0..S-1 (no atomics: bit-repeatable), the bias, and applies the epilogue
+       (OMH_EPI_RESID with c_in / aux / gates, OMH_EPI_F32).  S depends on (M, N, K) only.  NULL / too small: the
+       unsplit kernels, as before.  16-byte aligned. */
+    void* workspace; int64_t workspace_bytes;
 } omh_gemm_args;
 
 int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream);
+/* Bytes of `workspace` with which omh_gemm_bf16 would split the contraction of this product (0: it would not). */
+int64_t omh_gemm_workspace_bytes(const omh_gemm_args* args);
 
 /* bf16 GEMM with both operands K-MAJOR (row-major [K, *]):  C[m][n] (+)= sum_k A[k][m] * B[k][n],  fp32 C.
  * The weight gradient of every nn.Linear in the training step — dW[out][in] = sum_r dy[r][out] x[r][in], what

@@ -21,7 +21,7 @@ class OmhError(RuntimeError):
     pass
 
 
-ABI_VERSION = 8          # == OMH_ABI_VERSION of include/omh.h; checked against the loaded library below
+ABI_VERSION = 9          # == OMH_ABI_VERSION of include/omh.h; checked against the loaded library below
 
 
 def _load():
@@ -62,7 +62,8 @@ class GemmArgs(C.Structure):
                 ("gate0", vp), ("gate1", vp),
                 ("gate1_stride", i64), ("gate_rows", i32), ("gate_const", f32),
                 ("b_kmajor", i32),
-                ("c_in", vp), ("aux", vp), ("ldaux", i32)]
+                ("c_in", vp), ("aux", vp), ("ldaux", i32),
+                ("workspace", vp), ("workspace_bytes", i64)]
 
 
 COLSUM_MAX = 16
@@ -149,6 +150,7 @@ _SIGS = {
     "omh_set_deterministic": (i32, [i32]),
     "omh_build_arch": (C.c_char_p, []),
     "omh_gemm_bf16": (i32, [C.POINTER(GemmArgs), vp]),
+    "omh_gemm_workspace_bytes": (i64, [C.POINTER(GemmArgs)]),
     "omh_gemm_bf16_tn": (i32, [C.POINTER(GemmTnArgs), vp]),
     "omh_gemm_bf16_tn_grouped": (i32, [C.POINTER(GemmTnGroup), vp]),
     "omh_flash_attn_fwd_d128": (i32, [C.POINTER(AttnArgs), vp]),

@@ -485,6 +485,10 @@ bool omh_gemm_w64_bf16m_takes(const omh_gemm_args& a);
 int omh_launch_gemm_w64_bf16m(const omh_gemm_args& a, hipStream_t stream);
 bool omh_gemm_w64_n192_takes(const omh_gemm_args& a);
 int omh_launch_gemm_w64_n192(const omh_gemm_args& a, hipStream_t stream);
+// ... split K over 2..4 slices of that stream + a combine launch, for few-row long-contraction products (ABI v9)
+int omh_gemm_splitk_slices(const omh_gemm_args& a);
+int64_t omh_gemm_splitk_workspace(const omh_gemm_args& a);
+int omh_launch_gemm_splitk(const omh_gemm_args& a, int S, hipStream_t stream);
 
 static int launch_8w(const omh_gemm_args& a, hipStream_t s) {
     switch (a.epilogue) {
@@ -535,6 +539,17 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
     if (((int64_t)a.M + 128) * a.lda * 2 >= 0x7fffffffLL || ((int64_t)a.N + 128) * a.ldb * 2 >= 0x7fffffffLL)
         return OMH_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
+    if (a.workspace && !getenv("OMH_GEMM_TILE") && !getenv("OMH_GEMM_KERNEL")) {
+        // few rows, long contraction (M = 1 560 / 3 120 against K = 8 960): the contraction in slices on the 256 x 192
+        // stream, then one combine launch (gemm_w64.hip).  Only with a workspace of the size the query below returns.
+        const int S = omh_gemm_splitk_slices(a);
+        if (S > 1) {
+            if (((uintptr_t)a.workspace & 15) || a.workspace_bytes < omh_gemm_splitk_workspace(a)) return OMH_E_BADARG;
+            omh_clear_status();
+            omh_launch_gemm_splitk(a, S, s);
+            return omh_launch_status();
+        }
+    }
     {
         // OMH_GEMM_KERNEL = "w64": the 256 x 384 stream kernel wherever it applies; "8w": never; unset: where it
         // applies AND fills the chip (>= 256 tiles, last round of tiles at least 3/4 full or >= 4 rounds)
@@ -634,4 +649,11 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
         }
     }
     return launch_8w(a, s);
+}
+
+extern "C" int64_t omh_gemm_workspace_bytes(const omh_gemm_args* args) {
+    if (!args || !args->A || !args->B || !args->C || args->M <= 0 || args->N <= 0 || args->K <= 0) return 0;
+    if (getenv("OMH_GEMM_TILE") || getenv("OMH_GEMM_KERNEL")) return 0;     // a forced kernel family: no slices
+    if ((args->K & 7) || (args->lda & 7) || (args->ldb & 7) || ((uintptr_t)args->A & 15) || ((uintptr_t)args->B & 15)) return 0;
+    return omh_gemm_splitk_workspace(*args);
 }

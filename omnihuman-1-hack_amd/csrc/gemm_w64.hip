@@ -25,19 +25,25 @@ __device__ __forceinline__ uint64_t pack2(uint32_t lo, uint32_t hi) {
            ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32);
 }
 
-struct W64Tile { uint32_t sxb, swb; int m0, n0; };
+struct W64Tile { uint32_t sxb, swb, coff; int m0, n0; };
+// Split K (ABI v9, K_F32_192 only): `n` slices of the contraction, slice s starts kbytes * s into every A / B row and
+// writes its fp32 partial tile cbytes * s into C (= the workspace: n slices of [M, ldc]).  n = 1: the whole product.
+struct W64Split { int n; uint32_t kbytes, cbytes; };
 
 // Tile `idx` of this launch: XCD-contiguous work order (xcd_remap) walking 8 m-tiles x all n-tiles (tile_of), and the
 // byte offsets of this WAVE's first X / W rows (wave w stages X rows 64 w .. and W rows 96 w ..).
 template <int TNW>
-__device__ __forceinline__ W64Tile w64_tile(const omh_gemm_args& p, int idx, int tiles_m, int tiles_n, int w) {
-    const int wid = xcd_remap(idx, tiles_m * tiles_n);
+__device__ __forceinline__ W64Tile w64_tile(const omh_gemm_args& p, int idx, int tiles_m, int tiles_n, int w, const W64Split sp) {
+    int wid = xcd_remap(idx, tiles_m * tiles_n * sp.n);
+    int sl = 0;
+    if (sp.n > 1) { sl = wid / (tiles_m * tiles_n); wid -= sl * (tiles_m * tiles_n); }     // slice-major: a slice's tiles share rows
     int tm, tn;
     tile_of(wid, tiles_m, tiles_n, tm, tn, 8);
     W64Tile t;
     t.m0 = tm * TM; t.n0 = tn * TNW;
-    t.sxb = (uint32_t)(((int64_t)(t.m0 + w * 64) * p.lda) * 2);
-    t.swb = (uint32_t)(((int64_t)(t.n0 + w * (TNW / 4)) * p.ldb) * 2);
+    t.sxb = (uint32_t)(((int64_t)(t.m0 + w * 64) * p.lda) * 2) + (uint32_t)sl * sp.kbytes;
+    t.swb = (uint32_t)(((int64_t)(t.n0 + w * (TNW / 4)) * p.ldb) * 2) + (uint32_t)sl * sp.kbytes;
+    t.coff = (uint32_t)sl * sp.cbytes;
     return t;
 }
 
@@ -46,7 +52,7 @@ __device__ __forceinline__ W64Tile w64_tile(const omh_gemm_args& p, int idx, int
 // epilogue's stores drain under tile t + 1's k loop.
 template <int KIND>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int tiles_n) {
+void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int tiles_n, const W64Split sp) {
     constexpr int TNW = KIND >= K_RESID192 ? TN192 : TN;                    // tile width; a wave owns TNW / 2 columns
     constexpr int WBYTES = TNW * 128, STAGE_B = 32768 + WBYTES;             // W tile, one stage (X 32 KiB | W)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_B];
@@ -55,7 +61,7 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int total = tiles_m * tiles_n;
+    const int total = tiles_m * tiles_n * sp.n;
 
     typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
@@ -76,9 +82,10 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
     const uint32_t voc = (uint32_t)(((int64_t)(wm * 128 + r) * p.ldc + 8 * h) * ES);
     const uint32_t vlane = (uint32_t)lane;
 
-    const __amdgpu_buffer_rsrc_t ra = rsrc_of(p.A, (((int64_t)p.M - 1) * p.lda + p.K) * 2);
-    const __amdgpu_buffer_rsrc_t rb = rsrc_of(p.B, (((int64_t)p.N - 1) * p.ldb + p.K) * 2);
-    const __amdgpu_buffer_rsrc_t rc = rsrc_of(p.C, (((int64_t)p.M - 1) * p.ldc + p.N) * ES);
+    // (split K: p.K is ONE slice's length, the rows hold sp.n of them; C = the workspace's sp.n slices)
+    const __amdgpu_buffer_rsrc_t ra = rsrc_of(p.A, (((int64_t)p.M - 1) * p.lda + (int64_t)p.K * sp.n) * 2);
+    const __amdgpu_buffer_rsrc_t rb = rsrc_of(p.B, (((int64_t)p.N - 1) * p.ldb + (int64_t)p.K * sp.n) * 2);
+    const __amdgpu_buffer_rsrc_t rc = rsrc_of(p.C, (((int64_t)p.M - 1) * p.ldc + p.N) * ES + (int64_t)(sp.n - 1) * sp.cbytes);
     const __amdgpu_buffer_rsrc_t rbias = rsrc_of(p.bias, (p.bias && p.bias_mode == OMH_BIAS_N) ? (int64_t)p.N * 4 : 0);
     // K_BF16M: per-ROW bias (OMH_BIAS_M: the V^T projection, weights in the row slot)
     const __amdgpu_buffer_rsrc_t rbm = rsrc_of(p.bias, (KIND == K_BF16M && p.bias) ? (int64_t)p.M * 4 : 0);
@@ -101,7 +108,7 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
     const uint32_t region = lds0 + (uint32_t)(STAGE_B + 32768) + (uint32_t)w * 4096u;   // column vectors: stage 1's W region
 
     int idx = blockIdx.x;
-    W64Tile t = w64_tile<TNW>(p, idx, tiles_m, tiles_n, w);
+    W64Tile t = w64_tile<TNW>(p, idx, tiles_m, tiles_n, w, sp);
     if (KIND >= K_RESID192) {
         const uint64_t p8 = pack2(t.sxb, t.swb);
         asm volatile(OMH_GEMM_W64_ASM_PRO192
@@ -121,13 +128,13 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
     while (true) {
         const int nidx = idx + (int)gridDim.x;
         const bool has_next = nidx < total;
-        const W64Tile tn = w64_tile<TNW>(p, has_next ? nidx : idx, tiles_m, tiles_n, w);
+        const W64Tile tn = w64_tile<TNW>(p, has_next ? nidx : idx, tiles_m, tiles_n, w, sp);
         const int mw = t.m0 + wm * 128, nw = t.n0 + wn * (TNW / 2);
         const int blo = has_g1 ? mw / grows : 0;                            // batch index of the patch's first row
         // rows of the wave's patch from here on take the gate of batch blo + 1
         const uint32_t mb = has_g1 ? (uint32_t)((blo + 1) * grows - mw) : 0xffffffffu;
         const uint64_t p1 = pack2(t.sxb, t.swb);
-        const uint64_t p3 = pack2(nk, (uint32_t)(((int64_t)t.m0 * p.ldc + nw) * ES));
+        const uint64_t p3 = pack2(nk, (uint32_t)(((int64_t)t.m0 * p.ldc + nw) * ES) + t.coff);
         const uint64_t p5 = pack2(mb, (uint32_t)(((int64_t)blo * p.gate1_stride + nw) * 4));
         const uint64_t p7 = pack2((uint32_t)(nw * 4), region);
         const uint64_t p8 = pack2(tn.sxb, tn.swb);
@@ -186,10 +193,10 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
 }
 
 template <int KIND>
-int launch_w64(const omh_gemm_args& a, hipStream_t stream) {
+int launch_w64(const omh_gemm_args& a, hipStream_t stream, const W64Split sp = W64Split{1, 0u, 0u}) {
     constexpr int TNW = KIND >= K_RESID192 ? TN192 : TN;
     const int tiles_m = (a.M + TM - 1) / TM, tiles_n = (a.N + TNW - 1) / TNW;
-    const int total = tiles_m * tiles_n;
+    const int total = tiles_m * tiles_n * sp.n;
     static int ncu = 0;
     if (!ncu) {
         int dev = 0;
@@ -198,7 +205,7 @@ int launch_w64(const omh_gemm_args& a, hipStream_t stream) {
         ncu -= ncu % 8;                                                   // whole XCD rounds keep xcd_remap's chunks aligned
         if (ncu < 8) ncu = 256;
     }
-    hipLaunchKernelGGL(gemm_bf16_nt_w64_kernel<KIND>, dim3(total < ncu ? total : ncu), dim3(256), 0, stream, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL(gemm_bf16_nt_w64_kernel<KIND>, dim3(total < ncu ? total : ncu), dim3(256), 0, stream, a, tiles_m, tiles_n, sp);
     return 0;
 }
 
@@ -258,4 +265,108 @@ int omh_launch_gemm_w64(const omh_gemm_args& a, hipStream_t stream) {
         case OMH_EPI_GELU_BWD_BF16: return launch_w64<K_GELUBWD>(a, stream);
         default:                return launch_w64<K_RESID>(a, stream);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Split K (ABI v9).  A product with few rows and a long contraction — the FFN-down projection and the FFN-up input
+// gradient at one or two [16,1,60,104] clips: M = 1 560 / 3 120, N = 1 536, K = 8 960 — has 56 / 104 tiles of 256 x 192
+// for 256 CUs, each with 140 k steps.  Its contraction is cut into S = 4 / 2 equal slices: slice s of a tile is one
+// workgroup of the fp32 256 x 192 stream (same instruction stream, k window moved by the tile's byte offsets) writing
+// its partial to slice s of the workspace ([S][tiles_m * 256][N] fp32: the rows a ragged last m-tile writes past M land
+// in the slice's own padding), and splitk_combine_kernel adds the slices in the order 0..S-1, the bias, and applies the
+// epilogue.  No atomics, one fixed order: bit-repeatable; S is a function of (M, N, K) only, so the inference forward and
+// the training forward (c_in / aux) of one shape add the same partials.
+namespace {
+
+template <bool RESID>
+__global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __restrict__ ws, const int S, const int64_t slice,
+                                                             const omh_gemm_args p) {
+    const int nq = p.N >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)p.M * nq) return;
+    const int m = (int)(i / nq), n = (int)(i - (int64_t)m * nq) * 4;
+    const float* w = ws + (int64_t)m * p.N + n;
+    float4 acc = *(const float4*)w;
+    for (int s = 1; s < S; ++s) {
+        const float4 v = *(const float4*)(w + (int64_t)s * slice);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (p.bias) {
+        const float4 b = *(const float4*)(p.bias + n);
+        acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+    }
+    float* c = (float*)p.C + (int64_t)m * p.ldc + n;
+    if (!RESID) {
+        *(float4*)c = acc;
+        return;
+    }
+    float4 g = make_float4(p.gate_const, p.gate_const, p.gate_const, p.gate_const);
+    if (p.gate0) { const float4 v = *(const float4*)(p.gate0 + n); g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w; }
+    if (p.gate1) {
+        const float4 v = *(const float4*)(p.gate1 + (int64_t)(m / p.gate_rows) * p.gate1_stride + n);
+        g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+    }
+    const float4 o = *(const float4*)((p.c_in ? p.c_in : (const float*)p.C) + (int64_t)m * p.ldc + n);
+    *(float4*)c = make_float4(o.x + acc.x * g.x, o.y + acc.y * g.y, o.z + acc.z * g.z, o.w + acc.w * g.w);
+    if (p.aux) {                                                          // y = bf16(acc + bias): the branch output
+        uint2 y;
+        y.x = pack_bf2(acc.x, acc.y);
+        y.y = pack_bf2(acc.z, acc.w);
+        *(uint2*)((unsigned short*)p.aux + (int64_t)m * p.ldaux + n) = y;
+    }
+}
+
+omh_gemm_args splitk_partial(const omh_gemm_args& a, int S, void* ws) {
+    omh_gemm_args q = a;
+    q.C = ws; q.ldc = a.N; q.K = a.K / S;
+    q.epilogue = OMH_EPI_F32; q.bias = nullptr; q.bias_mode = OMH_BIAS_NONE;
+    q.gate0 = q.gate1 = nullptr; q.c_in = nullptr; q.aux = nullptr; q.ldaux = 0;
+    q.workspace = nullptr; q.workspace_bytes = 0;
+    return q;
+}
+
+}  // namespace
+
+// Number of slices omh_gemm_bf16 cuts this product's contraction into when it is handed a workspace (1: none).
+// OMH_GEMM_SPLITK = 0 switches the path off (A/B timing, tests).
+int omh_gemm_splitk_slices(const omh_gemm_args& a) {
+    const char* e = getenv("OMH_GEMM_SPLITK");
+    if (e && e[0] == '0') return 1;
+    if (a.batch != 1 || a.b_kmajor || !(a.epilogue == OMH_EPI_RESID || a.epilogue == OMH_EPI_F32)) return 1;
+    if (a.bias && a.bias_mode != OMH_BIAS_N) return 1;
+    if (a.K < 4096 || a.M < TM || (a.N & 7) || (a.ldc & 3) || ((uintptr_t)a.C & 15)) return 1;
+    if (a.bias && ((uintptr_t)a.bias & 15)) return 1;
+    if (a.epilogue == OMH_EPI_RESID) {
+        if ((a.gate0 && ((uintptr_t)a.gate0 & 15)) || (a.gate1 && (((uintptr_t)a.gate1 & 15) || (a.gate1_stride & 3) || a.gate_rows <= 0)))
+            return 1;
+        if ((a.c_in && ((uintptr_t)a.c_in & 15)) || (a.aux && ((a.ldaux & 3) || ((uintptr_t)a.aux & 7)))) return 1;
+    } else if (a.aux || a.c_in) {
+        return 1;
+    }
+    const int64_t t192 = (int64_t)((a.M + TM - 1) / TM) * ((a.N + TN192 - 1) / TN192);
+    if (t192 > 128) return 1;                                             // half of the chip or more: no slices
+    int S = 0;
+    for (int s = 4; s >= 2 && !S; --s)
+        if (t192 * s <= 256 && a.K % (BK * s) == 0 && a.K / s >= 1024) S = s;
+    if (!S) return 1;
+    const omh_gemm_args q = splitk_partial(a, S, (void*)a.C);             // (any 16-byte aligned address: shape check only)
+    return omh_gemm_w64_n192_takes(q) ? S : 1;
+}
+
+int64_t omh_gemm_splitk_workspace(const omh_gemm_args& a) {
+    const int S = omh_gemm_splitk_slices(a);
+    return S > 1 ? (int64_t)S * ((a.M + TM - 1) / TM * TM) * a.N * 4 : 0;
+}
+
+int omh_launch_gemm_splitk(const omh_gemm_args& a, int S, hipStream_t stream) {
+    const int64_t slice = (int64_t)((a.M + TM - 1) / TM * TM) * a.N;      // floats per slice
+    const omh_gemm_args q = splitk_partial(a, S, a.workspace);
+    launch_w64<K_F32_192>(q, stream, W64Split{S, (uint32_t)(q.K * 2), (uint32_t)(slice * 4)});
+    const int64_t n4 = (int64_t)a.M * (a.N >> 2);
+    const dim3 grid((unsigned)((n4 + 255) / 256));
+    if (a.epilogue == OMH_EPI_RESID)
+        hipLaunchKernelGGL(splitk_combine_kernel<true>, grid, dim3(256), 0, stream, (const float*)a.workspace, S, slice, a);
+    else
+        hipLaunchKernelGGL(splitk_combine_kernel<false>, grid, dim3(256), 0, stream, (const float*)a.workspace, S, slice, a);
+    return 0;
 }

@@ -49,11 +49,21 @@ def ptr(t: torch.Tensor, elem_off: int = 0):
 
 def gemm_raw(A, B, Cp, M, N, K, lda, ldb, ldc, epilogue, bias=None, bias_mode=BIAS_NONE, batch=1,
              strideA=0, strideB=0, strideC=0, gate0=None, gate1=None, gate1_stride=0, gate_rows=1,
-             gate_const=0.0, b_kmajor=False, c_in=None, aux=None, ldaux=0):
+             gate_const=0.0, b_kmajor=False, c_in=None, aux=None, ldaux=0, split_k=False):
     """C[m][n] = epi(sum_k A[m][k] B[n][k])  (b_kmajor: B[k][n], [K, N] row-major); all pointers are c_void_p.
-    ``c_in`` / ``aux`` / ``ldaux``: the fused training epilogues of include/omh.h (ABI v5)."""
+    ``c_in`` / ``aux`` / ``ldaux``: the fused training epilogues of include/omh.h (ABI v5).  ``split_k``: hand the
+    library a workspace so that it may cut a few-row, long contraction into slices (ABI v9: the FFN-down projection and
+    the FFN-up input gradient at one or two clips; another fp32 summation order than the unsplit kernels, so only
+    callers that do not need batch-invariant bits for that product ask for it)."""
     a = GemmArgs(A, B, Cp, M, N, K, lda, ldb, ldc, batch, strideA, strideB, strideC, epilogue, bias_mode, bias,
-                 gate0, gate1, gate1_stride, gate_rows, gate_const, int(b_kmajor), c_in, aux, ldaux)
+                 gate0, gate1, gate1_stride, gate_rows, gate_const, int(b_kmajor), c_in, aux, ldaux, None, 0)
+    ws = None
+    # (the library's own rule again below; this is only to skip the query where it cannot say anything but 0)
+    if split_k and K >= 4096 and batch == 1 and ((M + 255) // 256) * ((N + 191) // 192) <= 128:
+        need = lib.omh_gemm_workspace_bytes(C.byref(a))      # few rows, long contraction: split K (include/omh.h, ABI v9)
+        if need > 0:
+            ws = torch.empty(need, dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()))
+            a.workspace, a.workspace_bytes = ws.data_ptr(), need
     check(lib.omh_gemm_bf16(C.byref(a), _stream()), "omh_gemm_bf16")
 
 

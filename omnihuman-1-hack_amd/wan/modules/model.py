@@ -368,11 +368,13 @@ class WanAttentionBlock(nn.Module):
             M, K = a.shape
             if gate_i is None:
                 ops.gemm_raw(ptr(a), ptr(w), xp, M, d, K, K, K, d, EPI_RESID, bias=ptr(b) if b is not None else None,
-                             bias_mode=BIAS_N if b is not None else BIAS_NONE, gate_const=1.0)
+                             bias_mode=BIAS_N if b is not None else BIAS_NONE, gate_const=1.0, split_k=True)
             else:
+                # (split_k: at one or two [16,1,60,104] clips the FFN-down contraction, K = ffn_dim over 56 / 104 tiles,
+                # runs in slices — ABI v9; nothing is split at the sampling sizes)
                 ops.gemm_raw(ptr(a), ptr(w), xp, M, d, K, K, K, d, EPI_RESID, bias=ptr(b), bias_mode=BIAS_N,
                              gate0=ptr(mod, gate_i * d), gate1=ptr(e0, gate_i * d), gate1_stride=six_d, gate_rows=S,
-                             gate_const=0.0)
+                             gate_const=0.0, split_k=True)
 
         # ---- self-attention: x += o(attn(LN(x)(1+e1)+e0)) * e2        model.py:292-296
         h = ln_mod(0, 1)

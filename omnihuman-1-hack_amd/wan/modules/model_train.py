@@ -502,14 +502,15 @@ def _bgrad(dy, arena=None):
     return ops.colsum_accum(dy, out)
 
 
-def _dgrad(dy, wT, out=None, accumulate=False, epilogue=None):
-    """dx[R, K] = dy[R, N] @ W[N, K]  with wT = W^T bf16 [K, N] (row stride free); fp32 output unless ``epilogue``."""
+def _dgrad(dy, wT, out=None, accumulate=False, epilogue=None, split_k=False):
+    """dx[R, K] = dy[R, N] @ W[N, K]  with wT = W^T bf16 [K, N] (row stride free); fp32 output unless ``epilogue``.
+    ``split_k``: ops.gemm_raw's (the FFN-up input gradient: N = ffn_dim)."""
     R, N = dy.shape
     K = wT.shape[0]
     epi = epilogue if epilogue is not None else (EPI_ACC if accumulate else EPI_F32)
     if out is None:
         out = torch.empty(R, K, dtype=torch.bfloat16 if epi == EPI_BF16 else torch.float32, device=dy.device)
-    ops.gemm_raw(ptr(dy), ptr(wT), ptr(out), R, K, N, dy.stride(0), wT.stride(0), out.stride(0), epi)
+    ops.gemm_raw(ptr(dy), ptr(wT), ptr(out), R, K, N, dy.stride(0), wT.stride(0), out.stride(0), epi, split_k=split_k)
     return out
 
 
@@ -600,11 +601,11 @@ def _block_forward(model, blk, idx, st, x0, P, keep, need=True):
         if gate_i is None:
             ops.gemm_raw(ptr(a), ptr(w), ptr(xo), M, d, K, a.stride(0), w.stride(0), d, EPI_RESID,
                          bias=ptr(b) if b is not None else None, bias_mode=BIAS_N if b is not None else BIAS_NONE,
-                         gate_const=1.0, **kw)
+                         gate_const=1.0, split_k=True, **kw)
         else:
             ops.gemm_raw(ptr(a), ptr(w), ptr(xo), M, d, K, a.stride(0), w.stride(0), d, EPI_RESID, bias=ptr(b),
                          bias_mode=BIAS_N, gate0=ptr(mod, gate_i * d), gate1=ptr(e0, gate_i * d), gate1_stride=six,
-                         gate_rows=Sq, gate_const=0.0, **kw)
+                         gate_rows=Sq, gate_const=0.0, split_k=True, **kw)      # (same slices as the inference block: model.py)
         return xo, y
 
     # ---- self-attention: x1 = x0 + o(attn(LN(x0)(1+e1)+e0)) * e2                                    model.py:292-296
@@ -791,7 +792,7 @@ def _block_backward(model, blk, idx, st, S, dx, P, tgt=None):
         ops.gemm_raw(ptr(dy3), ptr(P["w2T"]), ptr(du_pre), R, f, d, d, d, f, EPI_GELU_BWD, aux=ptr(u_pre), ldaux=f)
         wgrad(du_pre, h2, ["ffn.0.weight"]), bgrad(du_pre, ["ffn.0.bias"])
         wg.launch()                                                  # FFN weight gradients: second stream, from here on
-        dh2 = _dgrad(du_pre, P["w1T"])
+        dh2 = _dgrad(du_pre, P["w1T"], split_k=True)
         # ---- cross-attention branch: x2 = x1 + y2  (its dy2 = bf16(dx) comes out of the same pass)
         dy2 = ln_bwd(S["x2"], dh2, 3, 4, nxt=(None, None))
         del du_pre, dh2

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(omh):
         assert hasattr(lib, name), f"{name} declared in include/omh.h but not exported by libomh.so"
     binding = importlib.import_module(PKG + "._lib")
     assert sorted(binding.EXPORTED) == decl, "ctypes signatures out of sync with the header"
-    assert binding.lib.omh_abi_version() == 8 and binding.lib.omh_build_arch() == b"gfx950"
+    assert binding.lib.omh_abi_version() == 9 and binding.lib.omh_build_arch() == b"gfx950"
 
 
 def test_argument_validation_without_gpu(omh):
@@ -408,3 +408,35 @@ def test_gradient_accumulation_targets_without_a_gpu(omh):
     assert [sorted(t) for t in run()] == [["bias", "weight"], ["bias"]]
     assert run(lambda: m(x).backward(create_graph=True)) == [None, None]
 
+
+
+def test_gemm_split_k_plan_without_a_gpu(omh, monkeypatch):
+    """ABI v9: omh_gemm_workspace_bytes is pure host arithmetic — the slices of a product's contraction as a function of
+    (M, N, K): four at one [16,1,60,104] clip's FFN-down / FFN-up input gradient (56 tiles of 256 x 192), two at two clips
+    (104), none from four clips on, none for short contractions, other epilogues, forced kernel families, or switched off."""
+    import ctypes as C
+    binding = importlib.import_module(PKG + "._lib")
+    for k_ in ("OMH_GEMM_KERNEL", "OMH_GEMM_TILE", "OMH_GEMM_SPLITK"):
+        monkeypatch.delenv(k_, raising=False)
+
+    def need(M, N, K, epi=binding.EPI_RESID, **kw):
+        a = binding.GemmArgs()
+        a.A = a.B = a.C = C.c_void_p(4096)                               # only alignment matters to the query
+        a.M, a.N, a.K, a.lda, a.ldb, a.ldc, a.batch, a.epilogue = M, N, K, K, K, N, 1, epi
+        for k_, v_ in kw.items():
+            setattr(a, k_, v_)
+        return binding.lib.omh_gemm_workspace_bytes(C.byref(a))
+    assert need(1560, 1536, 8960) == 4 * 1792 * 1536 * 4
+    assert need(3120, 1536, 8960) == 2 * 3328 * 1536 * 4
+    assert need(1560, 1536, 8960, epi=binding.EPI_F32) == 4 * 1792 * 1536 * 4
+    assert need(6240, 1536, 8960) == 0 and need(32760, 1536, 8960) == 0
+    assert need(1560, 1536, 1536) == 0 and need(1560, 8960, 1536) == 0   # short contractions
+    assert need(200, 1536, 8960) == 0                                    # less than one tile of rows: the 8-wave kernels
+    assert need(1560, 1536, 8960, epi=binding.EPI_BF16) == 0 and need(1560, 1536, 8960, epi=binding.EPI_F32_ACCUM) == 0
+    assert need(1560, 1536, 8960, batch=2) == 0 and need(1560, 1536, 8960, b_kmajor=1) == 0
+    assert need(780, 776, 4416) == 3 * 1024 * 776 * 4                    # 69 k tiles: three slices of 23
+    monkeypatch.setenv("OMH_GEMM_SPLITK", "0")
+    assert need(1560, 1536, 8960) == 0
+    monkeypatch.delenv("OMH_GEMM_SPLITK")
+    monkeypatch.setenv("OMH_GEMM_KERNEL", "8w")
+    assert need(1560, 1536, 8960) == 0

@@ -231,3 +231,81 @@ def test_accelerate_prepare_wraps_the_model_and_trains():
     assert sorted(r[:2] for r in res) == [(0, "ok"), (1, "ok")], res
     print(f"[measured] Accelerator(mixed_precision='bf16').prepare -> DDP, 2 ranks (gloo, one GPU): worst relative "
           f"gradient difference vs the mean of the bare models' gradients {max(r[2] for r in res):.2e}")
+
+
+def _accumulation_worker(rank, world, port, q):
+    """Gradient accumulation under this build's reducer (distilled_trainer.py:116-134: the non-final micro-steps without
+    synchronisation): the block backward adding into the existing .grad tensors and telling the reducer itself
+    (model_train._grad_targets) against autograd's own accumulation, on two ranks."""
+    try:
+        import importlib
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        par = importlib.import_module(PKG + ".parallel")
+        mt = importlib.import_module(PKG + ".wan.modules.model_train")
+        base, noise, context, vt = _tiny_model_and_batch(rank)
+
+        def optimizer_steps(direct):
+            m = copy.deepcopy(base)
+            m.direct_grad_accumulation = direct
+            red = par.BucketedGradAllReduce(m.parameters(), bucket_mb=1.0)
+            seen, real = [], mt._grad_targets
+            mt._grad_targets = lambda *a, **kw: seen.append(real(*a, **kw)) or seen[-1]
+            out = []
+            try:
+                for step in range(2):
+                    for k, scale in enumerate((1.0, 0.5, -0.75)):
+                        if k < 2:
+                            with red.no_sync():
+                                _reference_step(m, noise * scale, context, vt)
+                        else:
+                            _reference_step(m, noise * scale, context, vt)
+                    red.finish()
+                    torch.cuda.synchronize()
+                    out.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+                    m.zero_grad(set_to_none=False)           # the gradients stay views of the reducer's flat buffers
+            finally:
+                mt._grad_targets = real
+            red.remove()
+            return out, seen
+        want, seen0 = optimizer_steps(False)
+        got, seen1 = optimizer_steps(True)
+        nblk = len(base.blocks)
+        assert all(s is None or s == {} for s in seen0)
+        assert all(s == {} for s in seen1[:nblk]) and all(s for s in seen1[nblk:])      # everything after micro-step 1: in place
+        worst = 0.0
+        for a, b in zip(got, want):
+            assert set(a) == set(b)
+            for n in b:
+                if b[n].dim() >= 2 and n.startswith("blocks."):
+                    assert torch.equal(a[n], b[n]), n
+                else:
+                    e = float((a[n].double() - b[n].double()).norm() / b[n].double().norm().clamp_min(1e-30))
+                    worst = max(worst, e)
+                    assert e < 1e-4, (n, e)
+        probe = got[1]["blocks.3.self_attn.o.weight"]
+        other = [torch.empty_like(probe) for _ in range(world)]
+        dist.all_gather(other, probe)
+        assert torch.equal(other[0], other[1])               # the averaged gradient, identical on both ranks
+        q.put((rank, "ok", worst))
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL " + repr(e) + traceback.format_exc()[-1500:], None))
+
+
+def test_gradient_accumulation_in_place_under_the_bucketed_reducer_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_accumulation_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    assert sorted(r[:2] for r in res) == [(0, "ok"), (1, "ok")], res
+    print(f"[measured] gradient accumulation in place vs autograd's, bucketed reducer, 2 ranks (gloo, one GPU): matrices "
+          f"bit-identical, worst 1-D difference {max(r[2] for r in res):.2e}")

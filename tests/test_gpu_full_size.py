@@ -277,8 +277,9 @@ TOL_FULL_GRAD_NULL = 1.1e-1     # 5.1e-2 measured
 
 
 def _null_gradient(name):
-    """Parameters whose gradient vanishes identically: the K biases of the cross-attention (softmax shift invariance;
-    no RoPE and — unlike the self-attention — compared after the norm's own scale invariance: model.py:176-178)."""
+    """Parameters whose gradient all but vanishes: the K biases of the cross-attention.  The column sums of dK are zero
+    identically (softmax shift invariance, no RoPE); what is left comes through the key RMSNorm's per-token scale
+    (model.py:176-178) and is small: compared against the floor."""
     return name.endswith("cross_attn.k.bias") or name.endswith("cross_attn.k_img.bias")
 FULL_SIZE_PROBES = [
     "blocks.0.self_attn.q.weight", "blocks.0.self_attn.q.bias", "blocks.0.self_attn.norm_q.weight", "blocks.0.modulation",

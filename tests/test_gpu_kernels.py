@@ -155,6 +155,74 @@ def test_gemm_w64_residual_stream_with_prefetched_c(ops, M, N, K, gate_rows, mon
     assert rel_rms(got[1], x0 + ref) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K,S,gate_rows", [(1560, 1536, 8960, 4, 1560), (3120, 1536, 8960, 2, 1560), (300, 1536, 4096, 4, 150),
+                                              (3000, 1600, 8960, 2, 1000), (780, 776, 4416, 3, 780)])
+def test_gemm_split_k_for_few_row_long_contraction_products(ops, M, N, K, S, gate_rows, monkeypatch):
+    """ABI v9: the contraction of a few-row, long-K product (FFN-down / FFN-up input gradient at one or two clips:
+    model.py:272-274,328) in S slices on the fp32 256 x 192 stream + one combine launch (gated residual in place, out of
+    place with the bf16 branch output, plain fp32 with bias).  Against the unsplit kernels (fp32 sums in another order:
+    1e-6), against fp32 arithmetic, repeatable bit for bit; ragged M / N, a gate boundary inside the rows; the workspace
+    query says 0 where nothing is split, and a workspace that is too small is refused."""
+    import ctypes as C
+    binding, omh = ops._lib, ops.lib
+    for k_ in ("OMH_GEMM_KERNEL", "OMH_GEMM_TILE", "OMH_GEMM_SPLITK"):
+        monkeypatch.delenv(k_, raising=False)
+    torch.manual_seed(M + N + K)
+    a = _bf(torch.randn(M, K, device="cuda"))
+    w = _bf(torch.randn(N, K, device="cuda") / math.sqrt(K))
+    bias = torch.randn(N, device="cuda")
+    nb = (M + gate_rows - 1) // gate_rows
+    mod = torch.randn(6, N, device="cuda")
+    e0 = torch.randn(nb, 6, N, device="cuda")
+    x0 = torch.randn(M, N, device="cuda")
+
+    def args(Cp, epi, **kw):
+        g = binding.GemmArgs(ops.ptr(a), ops.ptr(w), Cp, M, N, K, K, K, N, 1, 0, 0, 0, epi, ops.BIAS_N, ops.ptr(bias),
+                             None, None, 0, 1, 0.0, 0, None, None, 0, None, 0)
+        for k_, v_ in kw.items():
+            setattr(g, k_, v_)
+        return g
+    need = omh.omh_gemm_workspace_bytes(C.byref(args(ops.ptr(x0), ops.EPI_RESID)))
+    assert need == S * ((M + 255) // 256 * 256) * N * 4
+    assert omh.omh_gemm_workspace_bytes(C.byref(args(ops.ptr(x0), ops.EPI_F32))) == need
+    assert omh.omh_gemm_workspace_bytes(C.byref(args(ops.ptr(x0), ops.EPI_BF16))) == 0
+    small = torch.empty(need - 16, dtype=torch.uint8, device="cuda")
+    rc = omh.omh_gemm_bf16(C.byref(args(ops.ptr(x0.clone()), ops.EPI_RESID, workspace=small.data_ptr(), workspace_bytes=need - 16)), None)
+    assert rc == -1                                                   # OMH_E_BADARG
+
+    def run(split):
+        monkeypatch.setenv("OMH_GEMM_SPLITK", "1" if split else "0")
+        x = x0.clone()
+        ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(x), M, N, K, K, K, N, ops.EPI_RESID, bias=ops.ptr(bias),
+                     bias_mode=ops.BIAS_N, gate0=ops.ptr(mod, 2 * N), gate1=ops.ptr(e0, 2 * N), gate1_stride=6 * N,
+                     gate_rows=gate_rows, gate_const=0.5, split_k=True)
+        x1 = torch.empty_like(x0)                                        # out of place + the bf16 branch output (training)
+        y1 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(x1), M, N, K, K, K, N, ops.EPI_RESID, bias=ops.ptr(bias),
+                     bias_mode=ops.BIAS_N, gate0=ops.ptr(mod, 3 * N), gate_const=0.0, c_in=ops.ptr(x0), aux=ops.ptr(y1), ldaux=N,
+                     split_k=True)
+        f, f0 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+        ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(f), M, N, K, K, K, N, ops.EPI_F32, bias=ops.ptr(bias), bias_mode=ops.BIAS_N,
+                     split_k=True)
+        ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(f0), M, N, K, K, K, N, ops.EPI_F32, split_k=True)
+        nosplit = torch.empty(M, N, device="cuda")                       # a caller that does not ask: the unsplit kernels
+        ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(nosplit), M, N, K, K, K, N, ops.EPI_F32)
+        return x, x1, y1.float(), f, f0, nosplit
+    got, again, old = run(True), run(True), run(False)
+    monkeypatch.delenv("OMH_GEMM_SPLITK")
+    for g, g2, o in zip(got, again, old):
+        assert torch.equal(g, g2)
+        assert not torch.equal(g, o) or g is got[2] or g is got[5]      # (it did take the other path)
+    assert torch.equal(got[5], old[5]) and torch.equal(got[5], old[4])
+    ref = a.float() @ w.float().t()
+    gate = (0.5 + mod[2][None] + e0[:, 2]).repeat_interleave(gate_rows, 0)[:M]
+    assert rel_rms(got[0], old[0]) < 2e-6 and rel_rms(got[0], x0 + (ref + bias) * gate) < 1e-5
+    assert rel_rms(got[1], old[1]) < 2e-6 and rel_rms(got[1], x0 + (ref + bias) * mod[3][None]) < 1e-5
+    assert rel_rms(got[2], old[2]) < 1e-3 and rel_rms(got[2], ref + bias) < 4e-3      # bf16: the odd last-bit flip
+    assert rel_rms(got[3], old[3]) < 2e-6 and rel_rms(got[3], ref + bias) < 2e-5
+    assert rel_rms(got[4], ref) < 2e-5
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 192, 256), (1000, 776, 320), (6240, 1536, 1536), (6240, 1536, 4608), (4100, 1160, 448)])
 def test_gemm_w64_narrow_streams(ops, M, N, K, monkeypatch):
     """The 256 x 192 fp32 / bf16 streams (the training step's M = 6 240 products: 200 tiles instead of 100 of 256 x 384):
