@@ -561,7 +561,11 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
         // the 8-wave kernel shows inside a training step is the weight-gradient stream sharing the chip, not the kernel.
         // Opt-in: OMH_GEMM_W64_GBWD=1.
         const char* gbwd = getenv("OMH_GEMM_W64_GBWD");
-        const bool v5_8w = v5 && !(a.epilogue == OMH_EPI_GELU_BWD_BF16 && !a.c_in && gbwd && gbwd[0] == '1');
+        // GELU + pre-activation to aux (the FFN-up projection of a training forward, ABI v5) on the 256 x 384 stream
+        // ("geluaux": bit-identical, test_gemm_w64_gelu_stream_with_the_pre_activation); OMH_GEMM_W64_GAUX=0: 8-wave kernels
+        const char* gaux = getenv("OMH_GEMM_W64_GAUX");
+        const bool gelu_aux = a.epilogue == OMH_EPI_GELU_BF16 && a.aux && !a.c_in && !(gaux && gaux[0] == '0');
+        const bool v5_8w = v5 && !gelu_aux && !(a.epilogue == OMH_EPI_GELU_BWD_BF16 && !a.c_in && gbwd && gbwd[0] == '1');
         const bool force = gk && gk[0] == 'w', never = v5_8w || (gk && gk[0] == '8') || (!force && getenv("OMH_GEMM_TILE"));
         // gated residual with a short contraction (o-projections: K = dim): the 256 x 192 stream that requests the old C
         // tile during its k loop.  OMH_GEMM_W64_R192 = 0 / 1 forces it off / on (A/B timing, tests).

@@ -16,8 +16,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, int64_t
     return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)n, 0x00020000);
 }
 
-enum { K_F32 = 0, K_BF16 = 1, K_GELU = 2, K_RESID = 3, K_GELUBWD = 4, K_BF16M = 5,
-       K_RESID192 = 6, K_F32_192 = 7, K_BF16_192 = 8 };                      // >= K_RESID192: the 256 x 192 tile
+enum { K_F32 = 0, K_BF16 = 1, K_GELU = 2, K_RESID = 3, K_GELUBWD = 4, K_BF16M = 5, K_GELUAUX = 6,
+       K_RESID192 = 7, K_F32_192 = 8, K_BF16_192 = 9 };                      // >= K_RESID192: the 256 x 192 tile
 
 // two wave-uniform 32-bit scalars in one SGPR pair (inline asm takes at most 30 operands)
 __device__ __forceinline__ uint64_t pack2(uint32_t lo, uint32_t hi) {
@@ -56,7 +56,8 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
     constexpr int TNW = KIND >= K_RESID192 ? TN192 : TN;                    // tile width; a wave owns TNW / 2 columns
     constexpr int WBYTES = TNW * 128, STAGE_B = 32768 + WBYTES;             // W tile, one stage (X 32 KiB | W)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_B];
-    constexpr int ES = (KIND == K_BF16 || KIND == K_GELU || KIND == K_BF16_192 || KIND == K_GELUBWD || KIND == K_BF16M) ? 2 : 4;
+    constexpr int ES = (KIND == K_BF16 || KIND == K_GELU || KIND == K_BF16_192 || KIND == K_GELUBWD || KIND == K_BF16M ||
+                        KIND == K_GELUAUX) ? 2 : 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1;
@@ -163,7 +164,17 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
                    [p2] "{s[64:65]}"(p2), [p3] "{s[66:67]}"(p3), [p4] "{s[68:69]}"(p4), [p5] "{s[70:71]}"(p5),
                    [p6] "{s[72:73]}"(p6), [p7] "{s[74:75]}"(p7), [p8] "{s[76:77]}"(p8), [p9] "{s[78:79]}"(p9)
                  : OMH_GEMM_W64_CLOBBERS);
-        } else if (KIND == K_GELUBWD)
+        } else if (KIND == K_GELUAUX)                  // gelu + the pre-activation to aux (C's shape and row pitch)
+            asm volatile(OMH_GEMM_W64_ASM_GELUAUX
+                 :
+                 : [xab] "v"(xab), [wab] "v"(wab), [xh] "v"(xh), [vox0] "v"(vox0), [vox1] "v"(vox1), [vow0] "v"(vow0),
+                   [vow1] "v"(vow1), [voc] "v"(voc), [vlane] "v"(vlane), [ra] "s"(ra), [rb] "s"(rb), [rc] "s"(rc),
+                   [rbias] "s"(rbias), [rg0] "s"(rg0), [rg1] "s"(rg1), [raux] "s"(raux),
+                   [p0] "{s[60:61]}"(p0), [p1] "{s[62:63]}"(p1),
+                   [p2] "{s[64:65]}"(p2), [p3] "{s[66:67]}"(p3), [p4] "{s[68:69]}"(p4), [p5] "{s[70:71]}"(p5),
+                   [p6] "{s[72:73]}"(p6), [p7] "{s[74:75]}"(p7), [p8] "{s[76:77]}"(p8), [p9] "{s[78:79]}"(p9)
+                 : OMH_GEMM_W64_CLOBBERS);
+        else if (KIND == K_GELUBWD)
             asm volatile(OMH_GEMM_W64_ASM_GELUBWD
                  :
                  : [xab] "v"(xab), [wab] "v"(wab), [xh] "v"(xh), [vox0] "v"(vox0), [vox1] "v"(vox1), [vow0] "v"(vow0),
@@ -217,6 +228,8 @@ int launch_w64(const omh_gemm_args& a, hipStream_t stream, const W64Split sp = W
 bool omh_gemm_w64_takes(const omh_gemm_args& a) {
     const bool gbwd = a.epilogue == OMH_EPI_GELU_BWD_BF16;       // aux = pre-activations with C's shape and row pitch
     if (gbwd && (!a.aux || a.ldaux != a.ldc || ((uintptr_t)a.aux & 15))) return false;
+    // GELU with the pre-activation written to aux (the training forward's FFN-up): same shape and row pitch as C
+    if (a.epilogue == OMH_EPI_GELU_BF16 && a.aux && (a.ldaux != a.ldc || ((uintptr_t)a.aux & 15))) return false;
     const bool bf16_out = a.epilogue == OMH_EPI_BF16 || a.epilogue == OMH_EPI_GELU_BF16 || gbwd;
     if (!(bf16_out || a.epilogue == OMH_EPI_F32 || a.epilogue == OMH_EPI_RESID)) return false;
     if (a.bias && a.bias_mode == OMH_BIAS_M) return false;
@@ -261,7 +274,7 @@ int omh_launch_gemm_w64(const omh_gemm_args& a, hipStream_t stream) {
     switch (a.epilogue) {
         case OMH_EPI_F32:       return launch_w64<K_F32>(a, stream);
         case OMH_EPI_BF16:      return launch_w64<K_BF16>(a, stream);
-        case OMH_EPI_GELU_BF16: return launch_w64<K_GELU>(a, stream);
+        case OMH_EPI_GELU_BF16: return a.aux ? launch_w64<K_GELUAUX>(a, stream) : launch_w64<K_GELU>(a, stream);
         case OMH_EPI_GELU_BWD_BF16: return launch_w64<K_GELUBWD>(a, stream);
         default:                return launch_w64<K_RESID>(a, stream);
     }

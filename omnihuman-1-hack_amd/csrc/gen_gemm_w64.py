@@ -415,6 +415,13 @@ RBM = 120                    # bf16m: v[120:123] = bias of the lane's row in row
 
 
 def epilogue(e, kind):
+    # "geluaux": the gelu stream that also writes the pre-activation u_pre = bf16(acc + bias) to `aux` (same shape and row
+    # pitch as C: a lane's aux bytes sit at its C store offset) — the FFN-up projection of a training forward whose block
+    # is back-propagated (OMH_EPI_GELU_BF16 with aux, ABI v5; model.py:272-274 under autograd).  The converted words go
+    # through a ring of four 4-register slots in v[80:95] (free in every kind but "resid").
+    aux = kind == "geluaux"
+    if aux:
+        kind = "gelu"
     out_bf16 = kind in ("bf16", "gelu", "bf16m")
     rowbias = kind == "bf16m"    # C = bf16(acc + bias[m]): the V^T projection (operands swapped, model.py:152-153 via :214)
     resid = kind == "resid"
@@ -485,9 +492,14 @@ def epilogue(e, kind):
                     e(f"v_pk_mul_f32 {vr(v0 + r_, 2)}, {vr(v0 + r_, 2)}, {vr(GV + p * 8 + r_, 2)}")
                 for r_ in range(0, 8, 2):
                     e(f"v_pk_add_f32 {vr(v0 + r_, 2)}, {vr(CO + (n % 3) * 16 + p * 8 + r_, 2)}, {vr(v0 + r_, 2)}")
+            off = (i * 32 + 16 * p) * es
+            if aux:
+                ax = CO + ((2 * n + p) % 4) * 4
+                for r_ in range(4):
+                    e(f"v_cvt_pk_bf16_f32 v{ax + r_}, v{v0 + 2 * r_}, v{v0 + 2 * r_ + 1}")
+                e(f"buffer_store_dwordx4 {vr(ax, 4)}, %[voc], %[raux], s85 offen offset:{off}")
             if kind == "gelu":
                 gelu_pairs(e, v0)
-            off = (i * 32 + 16 * p) * es
             if out_bf16:
                 for r_ in range(4):
                     e(f"v_cvt_pk_bf16_f32 v{v0 + r_}, v{v0 + 2 * r_}, v{v0 + 2 * r_ + 1}")
@@ -749,7 +761,7 @@ def epilogue_resid192(e):
 
 # VMEM instructions PER ACCUMULATOR TILE an epilogue issues after the next tile's prologue DMA (the k loop's first wait
 # counts them: an over-estimate would let k tile 0 be read before it has landed)
-EPI_VMEM_TILE = {"f32": 4, "bf16": 2, "gelu": 2, "resid": 8, "resid192": 6, "gelubwd": 4, "bf16m": 2}
+EPI_VMEM_TILE = {"f32": 4, "bf16": 2, "gelu": 2, "geluaux": 4, "resid": 8, "resid192": 6, "gelubwd": 4, "bf16m": 2}
 
 
 def generate(kind, tag=None):
@@ -776,7 +788,7 @@ def first_prologue(tag="pro"):
 
 def main():
     print("// GENERATED by gen_gemm_w64.py — do not edit; edit the generator.")
-    streams = [("PRO", first_prologue())] + [(kind.upper(), generate(kind)) for kind in KINDS + ("gelubwd", "bf16m")]
+    streams = [("PRO", first_prologue())] + [(kind.upper(), generate(kind)) for kind in KINDS + ("gelubwd", "bf16m", "geluaux")]
     configure(3)                                                 # the 256 x 192 gated-residual stream (old C prefetched)
     streams += [("PRO192", first_prologue("pro192")), ("RESID192", generate("resid192")),
                 ("F32_192", generate("f32", "f32n3")), ("BF16_192", generate("bf16", "bf16n3"))]

@@ -274,6 +274,37 @@ def test_gemm_w64_gelu_backward_stream(ops, M, N, K, monkeypatch):
     assert torch.equal(run_default(ops, a, w, pre, M, N, K), old)      # whichever kernel the dispatch picks: the same bits
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 384, 256), (1000, 776, 320), (6240, 8960, 1536), (4100, 1160, 448), (1560, 8960, 1536)])
+def test_gemm_w64_gelu_stream_with_the_pre_activation(ops, M, N, K, monkeypatch):
+    """Round 4 (third part): the FFN-up projection of a training forward — C = bf16(gelu_tanh(a W^T + b)) AND the
+    pre-activation aux = bf16(a W^T + b) that the GELU backward reads (OMH_EPI_GELU_BF16 with aux, ABI v5) — on the
+    256 x 384 stream ("geluaux": the gelu stream with a second store per run): both outputs bit for bit against the 8-wave
+    kernel, the guard band behind aux untouched, ragged M / N, several tiles per persistent workgroup."""
+    torch.manual_seed(M + N + 1)
+    a = _bf(torch.randn(M, K, device="cuda"))
+    w = _bf(torch.randn(N, K, device="cuda") / math.sqrt(K))
+    bias = torch.randn(N, device="cuda")
+
+    def run(env):
+        for k_ in ("OMH_GEMM_KERNEL", "OMH_GEMM_W64_GAUX"):
+            monkeypatch.delenv(k_, raising=False)
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        pre = torch.full((M + 8, N), 7.0, device="cuda", dtype=torch.bfloat16)         # 8 guard rows
+        ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(out), M, N, K, K, K, N, ops.EPI_GELU_BF16, bias=ops.ptr(bias),
+                     bias_mode=ops.BIAS_N, aux=ops.ptr(pre), ldaux=N)
+        assert bool((pre[M:] == 7.0).all())
+        return out, pre[:M].clone()
+    got, again, old, dflt = run({"OMH_GEMM_KERNEL": "w64"}), run({"OMH_GEMM_KERNEL": "w64"}), run({"OMH_GEMM_KERNEL": "8w"}), run({})
+    off = run({"OMH_GEMM_W64_GAUX": "0"})
+    for g, g2, o, d_, f in zip(got, again, old, dflt, off):
+        assert torch.equal(g, o) and torch.equal(g, g2) and torch.equal(d_, o) and torch.equal(f, o)
+    ref = a.float() @ w.float().t() + bias
+    assert rel_rms(got[1].float(), ref) < 4e-3
+    assert rel_rms(got[0].float(), torch.nn.functional.gelu(ref, approximate="tanh")) < 5e-3
+
+
 def run_default(ops, a, w, pre, M, N, K):
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(out), M, N, K, K, K, N, ops.EPI_GELU_BWD_BF16, aux=ops.ptr(pre), ldaux=N)
