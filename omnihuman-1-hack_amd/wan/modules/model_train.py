@@ -973,7 +973,8 @@ class _BlockFn(torch.autograd.Function):
         blk = model.blocks[idx]
         P = st.packs[idx]
         dev = x0.device
-        with torch.no_grad():
+        tgt = _grad_targets(ctx, model, idx)                 # gradient accumulation: existing .grad tensors to add into
+        with torch.no_grad():                                # (asked before no_grad: it looks at the pass's grad mode)
             S = ctx.kept
             ctx.kept = None
             if S is None:                                    # use_checkpoint: re-run the forward's kernels on its input
@@ -991,7 +992,6 @@ class _BlockFn(torch.autograd.Function):
             # the join of the weight-gradient stream: deferred to the end of this backward pass when legal — decided by the
             # first block of this forward to run in a pass (a second forward of the same model in the pass then finds
             # gradients in place and joins per block; so does a second pass over the same graph)
-            tgt = _grad_targets(ctx, model, idx)             # gradient accumulation: existing .grad tensors to add into
             key = (dev, id(model))
             tok = _join_pending.get(key)
             if tok is not None and st.__dict__.get("defer_tok") is tok:
