@@ -53,6 +53,11 @@ the reference computes the FFN on the CPU under ``no_grad`` and adds
 upstream *through that FFN* — receive no gradient; only the gate ``e[5]`` does.
 ``model.reference_ffn_freeze = False`` turns the quirk off (full gradients).
 
+Gradient accumulation (the reference trainer's mode, distilled_trainer.py:41,116-134,289): when a parameter already
+holds a dense fp32 ``.grad``, the block backward adds this micro-step's gradient INTO it (``_grad_targets``) instead of
+handing autograd a fresh tensor to add — same values, one pass over the gradients less, and the weight-gradient
+stream keeps its end-of-pass join.  ``model.direct_grad_accumulation = False`` restores the autograd route.
+
 The i2v backbone trains too: the image-token branch of the cross-attention
 (k_img / v_img / norm_k_img) and img_emb (LayerNorm, Linear, GELU(erf), Linear,
 LayerNorm on the CLIP tokens).
