@@ -481,6 +481,18 @@ int omh_rmsnorm_rope_bwd_t(const void* x, int32_t x_bf16, int64_t ldx, const voi
  *   dy_next[r][c] = bf16(dx[r][c] * gate),  gate = gate_const + gate0[c] + gate1[b * gate1_stride + c]
  *   dgate[b * dgate_stride + c] += sum_rows dx * y_next            (only with y_next and dgate)
  * workspace: omh_layernorm_modulate_bwd2_workspace(rows, dim, rows_per_batch) floats, 16-byte aligned. */
+/* ABI v9: the second launch of one of the two functions below, handed back to the caller instead of being issued
+ * (`deferred` != NULL in the argument struct: the struct is filled in, the partials stay in `workspace`, which the caller
+ * keeps alive): a block's backward collects the five it produces on its main stream and issues them as ONE launch with
+ * omh_partial_colsum_multi — same sums in the same order, four launches fewer per block. */
+typedef struct omh_partial_reduce {
+    const float* part; int32_t nj, np, nb, dim, grid_y;
+    float* out[3]; int64_t stride[3];
+} omh_partial_reduce;
+#define OMH_PARTIAL_REDUCE_MAX 8
+typedef struct omh_partial_reduce_batch { int32_t n; omh_partial_reduce e[OMH_PARTIAL_REDUCE_MAX]; } omh_partial_reduce_batch;
+int omh_partial_colsum_multi(const omh_partial_reduce_batch* batch, omh_stream_t stream);
+
 typedef struct omh_ln_bwd_args {
     const float* x; const void* dy; int32_t dy_bf16; float* dx;
     int64_t rows; int32_t dim; float eps; float mul_const;
@@ -489,6 +501,7 @@ typedef struct omh_ln_bwd_args {
     void* dy_next; const void* y_next; float gate_const; const float* gate0; const float* gate1; int64_t gate1_stride;
     float* dgate; int64_t dgate_stride;
     float* workspace; int64_t workspace_floats;
+    omh_partial_reduce* deferred;          /* ABI v9; NULL: the partials are added here */
 } omh_ln_bwd_args;
 int64_t omh_layernorm_modulate_bwd2_workspace(int64_t rows, int32_t dim, int64_t rows_per_batch);
 int omh_layernorm_modulate_bwd2(const omh_ln_bwd_args* args, omh_stream_t stream);
@@ -504,6 +517,7 @@ typedef struct omh_rms_bwd_args {
     int64_t rows; int32_t dim; float eps; int32_t do_norm;
     const float* rope_cos; const float* rope_sin; int32_t rope_len, head_dim; const int32_t* grid; int32_t seq_len;
     float* workspace; int64_t workspace_floats;
+    omh_partial_reduce* deferred;          /* ABI v9; NULL: the partials are added here */
 } omh_rms_bwd_args;
 int64_t omh_rmsnorm_rope_bwd2_workspace(int64_t rows, int32_t dim, int32_t n_seg);
 int omh_rmsnorm_rope_bwd2(const omh_rms_bwd_args* args, omh_stream_t stream);

@@ -113,6 +113,18 @@ class AttnBwdArgs(C.Structure):
                 ("phase", i32), ("workspace", vp), ("workspace_bytes", i64)]
 
 
+class PartialReduce(C.Structure):
+    _fields_ = [("part", vp), ("nj", i32), ("np", i32), ("nb", i32), ("dim", i32), ("grid_y", i32),
+                ("out", vp * 3), ("stride", i64 * 3)]
+
+
+PARTIAL_REDUCE_MAX = 8
+
+
+class PartialReduceBatch(C.Structure):
+    _fields_ = [("n", i32), ("e", PartialReduce * PARTIAL_REDUCE_MAX)]
+
+
 class LnBwdArgs(C.Structure):
     _fields_ = [("x", vp), ("dy", vp), ("dy_bf16", i32), ("dx", vp),
                 ("rows", i64), ("dim", i32), ("eps", f32), ("mul_const", f32),
@@ -120,7 +132,7 @@ class LnBwdArgs(C.Structure):
                 ("dmul", vp), ("dadd", vp), ("dstride", i64), ("rows_per_batch", i64),
                 ("dy_next", vp), ("y_next", vp), ("gate_const", f32), ("gate0", vp), ("gate1", vp), ("gate1_stride", i64),
                 ("dgate", vp), ("dgate_stride", i64),
-                ("workspace", vp), ("workspace_floats", i64)]
+                ("workspace", vp), ("workspace_floats", i64), ("deferred", C.POINTER(PartialReduce))]
 
 
 class RmsBwdArgs(C.Structure):
@@ -129,7 +141,7 @@ class RmsBwdArgs(C.Structure):
                 ("weight", vp * 2), ("dweight", vp * 2),
                 ("rows", i64), ("dim", i32), ("eps", f32), ("do_norm", i32),
                 ("rope_cos", vp), ("rope_sin", vp), ("rope_len", i32), ("head_dim", i32), ("grid", vp), ("seq_len", i32),
-                ("workspace", vp), ("workspace_floats", i64)]
+                ("workspace", vp), ("workspace_floats", i64), ("deferred", C.POINTER(PartialReduce))]
 
 
 class ConvArgs(C.Structure):
@@ -195,6 +207,7 @@ _SIGS = {
     "omh_layernorm_modulate_bwd2": (i32, [C.POINTER(LnBwdArgs), vp]),
     "omh_rmsnorm_rope_bwd2_workspace": (i64, [i64, i32, i32]),
     "omh_rmsnorm_rope_bwd2": (i32, [C.POINTER(RmsBwdArgs), vp]),
+    "omh_partial_colsum_multi": (i32, [C.POINTER(PartialReduceBatch), vp]),
     "omh_softmax_bwd_rows": (i32, [vp, i64, vp, i64, vp, i64, i64, i32, f32, vp]),
     "omh_unpatchify_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "omh_dense_f32_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),

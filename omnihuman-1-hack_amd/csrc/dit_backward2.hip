@@ -161,13 +161,13 @@ void ln_bwd2_kernel(const omh_ln_bwd_args a, const int nj) {
 // columns (16 float4 lanes) x 16 slices of j; a thread adds its slice's partials (j = slice, slice + 16, ...), the 16
 // slices are then added in slice order through LDS.
 // stride_k == 0: the parameter is shared by all nb row groups — the b == 0 workgroups add all nb * nj partials.
-__global__ __launch_bounds__(256)
-void partial_colsum_kernel(const float* __restrict__ part, int nj, int np, int nb, int dim, float* o0, int64_t s0,
-                           float* o1, int64_t s1, float* o2, int64_t s2) {
+__device__ __forceinline__
+void partial_colsum_body(const float* __restrict__ part, int nj, int np, int nb, int dim, float* o0, int64_t s0,
+                         float* o1, int64_t s1, float* o2, int64_t s2, const int by) {
     __shared__ float4 red[16][16];
     const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
     const int c4 = blockIdx.x * 16 + cl;                            // float4 column
-    const int k = blockIdx.y % np, b = blockIdx.y / np;
+    const int k = by % np, b = by / np;
     float* out = k == 0 ? o0 : (k == 1 ? o1 : o2);
     const int64_t st = k == 0 ? s0 : (k == 1 ? s1 : s2);
     if (!out || (st == 0 && b != 0)) return;                        // workgroup-uniform
@@ -202,6 +202,22 @@ void partial_colsum_kernel(const float* __restrict__ part, int nj, int np, int n
         w.x += t.x; w.y += t.y; w.z += t.z; w.w += t.w;
         *o = w;
     }
+}
+
+__global__ __launch_bounds__(256)
+void partial_colsum_kernel(const float* __restrict__ part, int nj, int np, int nb, int dim, float* o0, int64_t s0,
+                           float* o1, int64_t s1, float* o2, int64_t s2) {
+    partial_colsum_body(part, nj, np, nb, dim, o0, s0, o1, s1, o2, s2, (int)blockIdx.y);
+}
+
+// several deferred second stages in one launch (blockIdx.z = entry): the same body, workgroups outside an entry's own
+// grid leave at once (workgroup-uniform)
+__global__ __launch_bounds__(256)
+void partial_colsum_multi_kernel(const omh_partial_reduce_batch bt) {
+    const omh_partial_reduce& e = bt.e[blockIdx.z];
+    if ((int)blockIdx.y >= e.grid_y || (int)blockIdx.x * 64 >= e.dim) return;
+    partial_colsum_body(e.part, e.nj, e.np, e.nb, e.dim, e.out[0], e.stride[0], e.out[1], e.stride[1], e.out[2], e.stride[2],
+                        (int)blockIdx.y);
 }
 
 // ------------------------------------------------------------------ RMSNorm (+RoPE) backward, 1 or 2 column segments
@@ -359,9 +375,32 @@ extern "C" int omh_layernorm_modulate_bwd2(const omh_ln_bwd_args* args, omh_stre
     omh_clear_status();
     const int np = a.dim <= 6 * 256 ? launch_ln<6>(a, (int)nj, (int)nb, s)
                                     : (a.dim <= 20 * 256 ? launch_ln<20>(a, (int)nj, (int)nb, s) : launch_ln<MAXV2>(a, (int)nj, (int)nb, s));
+    if (a.deferred) {
+        omh_partial_reduce& d = *a.deferred;
+        d.part = a.workspace; d.nj = (int)nj; d.np = np; d.nb = (int)nb; d.dim = a.dim; d.grid_y = (int)(nb * np);
+        d.out[0] = a.dmul; d.stride[0] = a.dstride; d.out[1] = a.dadd; d.stride[1] = a.dstride;
+        d.out[2] = np == 3 ? a.dgate : nullptr; d.stride[2] = a.dgate_stride;
+        return omh_launch_status();
+    }
     hipLaunchKernelGGL(partial_colsum_kernel, dim3((a.dim + 63) / 64, (unsigned)(nb * np)), dim3(256), 0, s, a.workspace,
                        (int)nj, np, (int)nb, a.dim, a.dmul, a.dstride, a.dadd, a.dstride, np == 3 ? a.dgate : nullptr,
                        a.dgate_stride);
+    return omh_launch_status();
+}
+
+extern "C" int omh_partial_colsum_multi(const omh_partial_reduce_batch* batch, omh_stream_t stream) {
+    if (!batch || batch->n < 0 || batch->n > OMH_PARTIAL_REDUCE_MAX) return OMH_E_BADARG;
+    if (batch->n == 0) return 0;
+    int gx = 0, gy = 0;
+    for (int i = 0; i < batch->n; ++i) {
+        const omh_partial_reduce& e = batch->e[i];
+        if (!e.part || e.nj <= 0 || e.np < 1 || e.np > 3 || e.nb < 1 || e.dim <= 0 || (e.dim & 3) || e.grid_y < 1) return OMH_E_BADARG;
+        if ((((uintptr_t)e.part | (uintptr_t)e.out[0] | (uintptr_t)e.out[1] | (uintptr_t)e.out[2]) & 15)) return OMH_E_ALIGN;
+        gx = gx > (e.dim + 63) / 64 ? gx : (e.dim + 63) / 64;
+        gy = gy > e.grid_y ? gy : e.grid_y;
+    }
+    omh_clear_status();
+    hipLaunchKernelGGL(partial_colsum_multi_kernel, dim3(gx, gy, batch->n), dim3(256), 0, (hipStream_t)stream, *batch);
     return omh_launch_status();
 }
 
@@ -389,7 +428,12 @@ extern "C" int omh_rmsnorm_rope_bwd2(const omh_rms_bwd_args* args, omh_stream_t 
     if (a.dim <= 6 * 256) launch_rms<6>(a, (int)nj, s);
     else if (a.dim <= 20 * 256) launch_rms<20>(a, (int)nj, s);
     else launch_rms<MAXV2>(a, (int)nj, s);
-    if (any_dw)          // segment = "batch" of the column-sum launch, one partial array per workgroup
+    if (any_dw && a.deferred) {
+        omh_partial_reduce& d = *a.deferred;
+        d.part = a.workspace; d.nj = (int)nj; d.np = 1; d.nb = 1; d.dim = a.dim; d.grid_y = a.n_seg;
+        d.out[0] = a.dweight[0]; d.stride[0] = (int64_t)(a.n_seg > 1 ? a.dweight[1] - a.dweight[0] : 1);
+        d.out[1] = d.out[2] = nullptr; d.stride[1] = d.stride[2] = 0;
+    } else if (any_dw)   // segment = "batch" of the column-sum launch, one partial array per workgroup
         hipLaunchKernelGGL(partial_colsum_kernel, dim3((a.dim + 63) / 64, (unsigned)a.n_seg), dim3(256), 0, s, a.workspace,
                            (int)nj, 1, 1, a.dim, a.dweight[0], (int64_t)(a.n_seg > 1 ? a.dweight[1] - a.dweight[0] : 1),
                            nullptr, 0, nullptr, 0);

@@ -605,31 +605,53 @@ def rmsnorm_rope_bwd_t_raw(x, x_bf16, ldx, dy, dy_bf16, lddy, dx, lddx, dw, rows
 
 def layernorm_modulate_bwd2(x, dy, dx, rows, dim, eps, mul_const, mul0, mul1, mul1_stride, dmul, dadd, dstride,
                             rows_per_batch, dy_next=None, y_next=None, gate_const=1.0, gate0=None, gate1=None,
-                            gate1_stride=0, dgate=None, dgate_stride=0):
+                            gate1_stride=0, dgate=None, dgate_stride=0, defer=None):
     """Repeatable LayerNorm+modulate backward, optionally fused with the next branch's gated-residual backward
     (include/omh.h).  x, dx fp32 tensors [rows, dim]; dy fp32 or bf16 tensor; the pointer-like arguments (mul0 ... dgate)
-    are c_void_p / None as for the *_raw ops; dy_next / y_next bf16 tensors or None."""
+    are c_void_p / None as for the *_raw ops; dy_next / y_next bf16 tensors or None.  ``defer`` (a list): the second
+    launch — the partial column sums into dmul / dadd / dgate — is appended to it instead of being issued; the caller
+    issues the list with ``partial_colsum_multi`` on the same stream before anything reads those sums."""
     _dev(x, dy, dx, dy_next, y_next)
     need = lib.omh_layernorm_modulate_bwd2_workspace(rows, dim, rows_per_batch)
     ws = torch.empty(need, dtype=torch.float32, device=x.device)
+    d = _lib.PartialReduce() if defer is not None else None
     a = _lib.LnBwdArgs(_p(x), _p(dy), int(dy.dtype == torch.bfloat16), _p(dx), rows, dim, eps, mul_const, mul0, mul1,
                        mul1_stride, dmul, dadd, dstride, rows_per_batch, _p(dy_next), _p(y_next), gate_const, gate0, gate1,
-                       gate1_stride, dgate, dgate_stride, _p(ws), need)
+                       gate1_stride, dgate, dgate_stride, _p(ws), need, C.pointer(d) if d is not None else None)
     check(lib.omh_layernorm_modulate_bwd2(C.byref(a), _stream()), "omh_layernorm_modulate_bwd2")
+    if d is not None and d.part:
+        defer.append((d, ws))                                # (the partials live in ws until the deferred launch)
+
+
+def partial_colsum_multi(deferred):
+    """Issue the second launches collected by ``layernorm_modulate_bwd2(defer=)`` / ``rmsnorm_rope_bwd2(defer=)``: one
+    launch per 8 entries, the same sums in the same order."""
+    for k in range(0, len(deferred), _lib.PARTIAL_REDUCE_MAX):
+        chunk = deferred[k:k + _lib.PARTIAL_REDUCE_MAX]
+        b = _lib.PartialReduceBatch()
+        b.n = len(chunk)
+        for i, (d, _ws) in enumerate(chunk):
+            b.e[i] = d
+        check(lib.omh_partial_colsum_multi(C.byref(b), _stream()), "omh_partial_colsum_multi")
 
 
 def rmsnorm_rope_bwd2(x, x_bf16, ldx, dy, dy_bf16, lddy, dx, lddx, rows, dim, eps, do_norm, weights, dweights, device,
                       n_seg=1, seg_x=0, seg_dy=0, seg_dx=0, rope_cos=None, rope_sin=None, rope_len=0, head_dim=128,
-                      grid=None, seq_len=0):
+                      grid=None, seq_len=0, defer=None):
     """Repeatable RMSNorm(+RoPE) backward on 1 or 2 column segments (include/omh.h); x / dy / dx and the table
-    pointers are c_void_p; weights / dweights: lists of fp32 tensors or None per segment."""
+    pointers are c_void_p; weights / dweights: lists of fp32 tensors or None per segment.  ``defer``: as for
+    ``layernorm_modulate_bwd2`` (the gains' partial sums)."""
     need = lib.omh_rmsnorm_rope_bwd2_workspace(rows, dim, n_seg) if any(d is not None for d in dweights) else 0
     ws = torch.empty(max(need, 1), dtype=torch.float32, device=device)
     W = (C.c_void_p * 2)(*[(w.data_ptr() if w is not None else None) for w in (list(weights) + [None])[:2]])
     DW = (C.c_void_p * 2)(*[(w.data_ptr() if w is not None else None) for w in (list(dweights) + [None])[:2]])
+    d = _lib.PartialReduce() if defer is not None else None
     a = _lib.RmsBwdArgs(x, int(x_bf16), ldx, dy, int(dy_bf16), lddy, dx, lddx, n_seg, seg_x, seg_dy, seg_dx, W, DW, rows, dim,
-                        eps, int(do_norm), rope_cos, rope_sin, rope_len, head_dim, grid, seq_len, _p(ws), need)
+                        eps, int(do_norm), rope_cos, rope_sin, rope_len, head_dim, grid, seq_len, _p(ws), need,
+                        C.pointer(d) if d is not None else None)
     check(lib.omh_rmsnorm_rope_bwd2(C.byref(a), _stream()), "omh_rmsnorm_rope_bwd2")
+    if d is not None and d.part:
+        defer.append((d, ws))
 
 
 def softmax_bwd_rows(p, dp, ds, L, scale):

@@ -314,6 +314,11 @@ def reducer_stream(dev):
 _DEFER_JOIN = os.environ.get("OMH_WGRAD_DEFER", "1") == "1"
 # what else rides the second stream (OMH_SIDE_KV=0 / OMH_SIDE_BIAS=0: on the main one, A/B timing): the cross-attention's
 # key / value gradient path and the bias gradients' column sums — neither feeds the block's input gradient
+# the norm backwards' second launches (partial column sums -> parameter / modulation gradients) of a block's main stream
+# collected into ONE launch at the end of the block (ops.partial_colsum_multi).  Bit-identical, four launches fewer per
+# block — and measured EQUAL (73.2 / 73.3 vs 73.1 / 73.3 ms at 4 clips, 38.3 / 38.7 vs 37.0 / 39.5 at one clip, interleaved
+# on one box: the 5 us kernels were not what the main stream waits for): opt-in, OMH_DEFER_COLSUM=1.
+_DEFER_COLSUM = os.environ.get("OMH_DEFER_COLSUM", "0") == "1"
 _SIDE_KV = os.environ.get("OMH_SIDE_KV", "1") == "1"
 _SIDE_BIAS = os.environ.get("OMH_SIDE_BIAS", "0") == "1"      # measured: 75.3 ms with, 75.1 without (one box, interleaved)
 # (tried and dropped: the forward's context keys / values and the backward's V transposes on a third stream — 75.55 ms
@@ -711,6 +716,7 @@ def _block_backward(model, blk, idx, st, S, dx, P, tgt=None):
     d_eb = arena.take(B, 6, d)                                        # grads of e = modulation + e0
     g = {}
     tgt = tgt or {}
+    deferred = [] if _DEFER_COLSUM else None                          # second launches of the norm backwards (main stream)
 
     def acc1(name, n):
         """The fp32 accumulator of a 1-D gradient: the parameter's own .grad (added to) or a zeroed arena slice."""
@@ -764,7 +770,7 @@ def _block_backward(model, blk, idx, st, S, dx, P, tgt=None):
                 kw = dict(dy_next=dy_next, y_next=y, gate_const=0.0, gate0=ptr(mod, gi * d), gate1=ptr(e0, gi * d),
                           gate1_stride=six, dgate=ptr(d_eb, gi * d), dgate_stride=six)
         ops.layernorm_modulate_bwd2(xin, dh, dx, R, d, eps, 1.0, ptr(mod, scale_i * d), ptr(e0, scale_i * d), six,
-                                    ptr(d_eb, scale_i * d), ptr(d_eb, shift_i * d), six, Sq, **kw)
+                                    ptr(d_eb, scale_i * d), ptr(d_eb, shift_i * d), six, Sq, defer=deferred, **kw)
         return dy_next
 
     def resid_bwd(y, gate_i):
@@ -776,14 +782,15 @@ def _block_backward(model, blk, idx, st, S, dx, P, tgt=None):
                                        ptr(mod, gate_i * d), ptr(e0, gate_i * d), six, Sq)
         return dy
 
-    def rms_bwd(x, x_bf16, ldx, dy, lddy, rows, weights, norm_on, rope, names, mod_, n_seg=1, seg_x=0, seg_dy=0):
-        """In place on dy (bf16): dy <- gradient of the pre-norm projection; the norm gains' gradients into g[names]."""
+    def rms_bwd(x, x_bf16, ldx, dy, lddy, rows, weights, norm_on, rope, names, mod_, n_seg=1, seg_x=0, seg_dy=0, defer=True):
+        """In place on dy (bf16): dy <- gradient of the pre-norm projection; the norm gains' gradients into g[names]
+        (``defer`` False: summed at once — the call that may run on the second stream)."""
         dws = [acc1(nm, d) if norm_on else None for nm in names[:n_seg]]
         rk = dict(rope_cos=ptr(fc.rope_cos), rope_sin=ptr(fc.rope_sin), rope_len=fc.rope_cos.shape[0], grid=ptr(fc.grid32),
                   seq_len=Sq) if rope else {}
         ops.rmsnorm_rope_bwd2(x, x_bf16, ldx, dy, True, lddy, dy, lddy, rows, d, mod_.eps, norm_on,
                               [w if norm_on else None for w in weights], dws, dev, n_seg=n_seg, seg_x=seg_x, seg_dy=seg_dy,
-                              seg_dx=seg_dy, head_dim=D, **rk)
+                              seg_dx=seg_dy, head_dim=D, defer=deferred if defer else None, **rk)
         for nm, dw in zip(names, dws):
             if dw is not None:
                 g[nm] = dw
@@ -851,7 +858,7 @@ def _block_backward(model, blk, idx, st, S, dx, P, tgt=None):
     # block — that flush does not wait for the second stream and would read the k half before or while it is rewritten.)
     def kv_path():
         rms_bwd(ptr(S["kf"]), False, d, ptr(dkv), 2 * d, Rc, [ca._norm_w("norm_k")], ca.qk_norm, False,
-                ["cross_attn.norm_k.weight"], ca)
+                ["cross_attn.norm_k.weight"], ca, defer=False)
         bgrad(dkv, ["cross_attn.k.bias", "cross_attn.v.bias"], now=True)
         _dgrad_ctx(dkv, P["wkv_cT"], st.d_ctx, n_img, Lt)
     if _SIDE_KV and not i2v:
@@ -866,7 +873,7 @@ def _block_backward(model, blk, idx, st, S, dx, P, tgt=None):
         dy1 = bf(R, d)
         ops.layernorm_modulate_bwd2(x1, dh3, dx, R, d, blk.norm3.eps, 0.0, ptr(S["w3"]), None, 0, ptr(dw3), ptr(db3), 0, Sq,
                                     dy_next=dy1, y_next=S["y1"], gate_const=0.0, gate0=ptr(mod, 2 * d), gate1=ptr(e0, 2 * d),
-                                    gate1_stride=six, dgate=ptr(d_eb, 2 * d), dgate_stride=six)
+                                    gate1_stride=six, dgate=ptr(d_eb, 2 * d), dgate_stride=six, defer=deferred)
         g["norm3.weight"], g["norm3.bias"] = dw3, db3
     else:
         ops.colsum_accum(dh3.view(1, R * d), dx.view(R * d))          # dx += dh3
@@ -891,6 +898,8 @@ def _block_backward(model, blk, idx, st, S, dx, P, tgt=None):
     dh1 = _dgrad(dqkv, P["wqkvT"])                                      # K = 3d: dq Wq + dk Wk + dv Wv
     ln_bwd(x0, dh1, 0, 1)
     # ---- modulation / e0
+    if deferred:                                                     # d_eb and the gains are complete behind this launch
+        ops.partial_colsum_multi(deferred)
     dmod = acc1("modulation", six)
     ops.colsum_accum(d_eb.view(B, six), dmod)
     g["modulation"] = dmod

@@ -1162,3 +1162,36 @@ def test_cross_attention_key_bias_gradient_waits_for_the_norm_backward(wan_model
         for n in want:
             assert rel_rms(got[n], want[n]) < 1e-5, (n, hold)
 
+
+
+def test_norm_backward_second_launches_deferred_to_one_launch(wan_model_mod, monkeypatch):
+    """ABI v9 (omh_partial_reduce): the partial column sums of a block's norm backwards (LayerNorm+modulate x 3, q|k and
+    cross-q RMSNorm) issued as ONE launch at the end of the block instead of five: every gradient identical bit for bit
+    under the deterministic mode (ordered reductions everywhere), both freeze settings, also into existing .grad tensors."""
+    mt = importlib.import_module(PKG + ".wan.modules.model_train")
+    ops = importlib.import_module(PKG + ".ops")
+    ops.set_deterministic(True)
+    try:
+        for freeze in (True, False):
+            cfg, sd, m, noise, vt, cl = _setup(wan_model_mod, freeze=freeze)
+            args = dict(t=torch.ones(2, device="cuda") * 1000.0, context=[c.cuda() for c in cl], seq_len=24)
+
+            def grads(defer):
+                monkeypatch.setattr(mt, "_DEFER_COLSUM", defer)
+                m.zero_grad(set_to_none=True)
+                calls = []
+                real = ops.partial_colsum_multi
+                monkeypatch.setattr(ops, "partial_colsum_multi", lambda lst: calls.append(len(lst)) or real(lst))
+                for scale in (1.0, 0.5):                                   # the second pass accumulates in place
+                    out = m(list((noise * scale).cuda()), **args)
+                    sum(torch.nn.functional.mse_loss(a, b) for a, b in zip(out, vt.cuda())).backward()
+                monkeypatch.setattr(ops, "partial_colsum_multi", real)
+                torch.cuda.synchronize()
+                return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}, calls
+            want, c0 = grads(False)
+            got, c1 = grads(True)
+            assert c0 == [] and len(c1) == 2 * len(m.blocks) and all(3 <= n <= 5 for n in c1), c1
+            for n in want:
+                assert torch.equal(got[n], want[n]), n
+    finally:
+        ops.set_deterministic(False)
