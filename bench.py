@@ -618,6 +618,10 @@ def train_legs(model, device, world, dist):
         out["accumulation_4"] = train_bench(model, device, world, dist, bsz=bsz, accum=4, **ak)
         out["accumulation_4"]["autograd_route"] = train_bench(model, device, world, dist, bsz=bsz, accum=4,
                                                               direct_accum=False, **ak)
+        if bsz != 1:        # the reference CLI's literal defaults: --batch_size 1 --gradient_accumulation_steps 4 (:362,372)
+            out["accumulation_4"]["batch_1"] = train_bench(model, device, world, dist, bsz=1, accum=4, **ak)
+            out["accumulation_4"]["batch_1"]["autograd_route"] = train_bench(model, device, world, dist, bsz=1, accum=4,
+                                                                             direct_accum=False, **ak)
     except Exception as e:
         out["extra_legs_error"] = repr(e)[:300]
     return out
