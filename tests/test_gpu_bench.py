@@ -100,3 +100,30 @@ def test_bench_refuses_more_ranks_than_gpus():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and not r.stdout.strip()
     assert "HIP device(s) visible" in r.stderr
+
+
+def test_bench_training_legs_with_gradient_accumulation():
+    """`bench.py --only-train` with every leg (one timed step each): the accumulation legs — the reference trainer's cycle
+    of 4 micro-steps at the primary batch and at its CLI default of one clip, in place and on the autograd route — are
+    present, finite and say which route they took; over the forced one-rank RCCL group, so the reducer's no_sync() /
+    finish() pattern of an accumulation cycle runs too."""
+    env = dict(os.environ)
+    for k in ("OMH_GEMM_KERNEL", "OMH_CONV_TILE", "OMH_TRAIN_LEGS", "OMH_GRAD_ACCUM_DIRECT"):
+        env.pop(k, None)
+    env.update(OMH_TRAIN_STEPS="1", OMH_TRAIN_WARMUP="1", OMH_TRAIN_BATCH="2", OMH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29547")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--only-train"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    t = json.loads(lines[0])["train"]
+    assert "extra_legs_error" not in t, t.get("extra_legs_error")
+    acc = t["accumulation_4"]
+    for leg, direct, clips in ((acc, True, 8), (acc["autograd_route"], False, 8), (acc["batch_1"], True, 4),
+                               (acc["batch_1"]["autograd_route"], False, 4)):
+        assert leg["micro_steps_per_step"] == 4 and leg["clips_per_gpu_step"] == clips and leg["finite_loss"]
+        assert leg["grads_accumulated_in_place"] is direct and leg["clips_per_s"] > 0
+        assert leg["rccl_world_size"] == 1 and "all-reduce over 1 rank(s) [nccl]" in leg["work"]
+        assert abs(leg["ms_per_micro_step"] * 4 - leg["ms_per_step"]) < 0.05
+    assert t["micro_steps_per_step"] == 1 and t["grads_accumulated_in_place"] is None
