@@ -280,6 +280,13 @@ int omh_rmsnorm_rope_bf16(const void* x_bf16, int64_t ldx, void* y_bf16, int64_t
                           const float* rope_cos, const float* rope_sin, int32_t rope_len,
                           int32_t head_dim, const int32_t* grid, int32_t seq_len, float out_scale,
                           omh_stream_t stream);
+/* ABI v9: omh_rmsnorm_rope_bf16 on TWO column segments of the same rows in one launch — q and k of the self-attention out
+ * of the fused q|k projection (model.py:144-145: norm_q / norm_k + rope_apply): segment 1 reads x + seg_x elements, with
+ * its own gain, output and output scale.  The same row arithmetic as two calls (same bits). */
+int omh_rmsnorm_rope_bf16_pair(const void* x_bf16, int64_t ldx, int64_t seg_x, void* y0_bf16, void* y1_bf16, int64_t rows,
+                               int32_t dim, const float* weight0, const float* weight1, float eps, int32_t do_norm,
+                               const float* rope_cos, const float* rope_sin, int32_t rope_len, int32_t head_dim,
+                               const int32_t* grid, int32_t seq_len, float out_scale0, float out_scale1, omh_stream_t stream);
 
 /* fp32 -> bf16 cast (round to nearest even) of a contiguous buffer. */
 int omh_cast_f32_bf16(const float* x, void* y_bf16, int64_t n, omh_stream_t stream);

@@ -172,6 +172,7 @@ _SIGS = {
     "omh_layernorm_modulate": (i32, [vp, vp, i64, i32, f32, f32, vp, vp, i64, vp, vp, i64, i64, vp]),
     "omh_rmsnorm_rope": (i32, [vp, i64, vp, i64, i32, vp, f32, i32, vp, vp, i32, i32, vp, i32, vp]),
     "omh_rmsnorm_rope_bf16": (i32, [vp, i64, vp, i64, i32, vp, f32, i32, vp, vp, i32, i32, vp, i32, f32, vp]),
+    "omh_rmsnorm_rope_bf16_pair": (i32, [vp, i64, i64, vp, vp, i64, i32, vp, vp, f32, i32, vp, vp, i32, i32, vp, i32, f32, f32, vp]),
     "omh_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
     "omh_patchify": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "omh_unpatchify": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),

@@ -106,11 +106,11 @@ void layernorm_modulate_kernel(const float* __restrict__ x, uint16_t* __restrict
 
 // ------------------------------------------------------------------ RMSNorm (+RoPE)
 template <int MAXV, bool IN_BF16>
-__global__ __launch_bounds__(256)
-void rmsnorm_rope_kernel(const void* __restrict__ xv, int64_t ldx, uint16_t* __restrict__ y, int64_t rows,
-                         int dim, const float* __restrict__ weight, float eps, int do_norm,
-                         const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
-                         int rope_len, int head_dim, const int* __restrict__ grid, int seq_len, float out_scale) {
+__device__ __forceinline__
+void rmsnorm_rope_row(const void* __restrict__ xv, int64_t ldx, uint16_t* __restrict__ y, int64_t rows,
+                      int dim, const float* __restrict__ weight, float eps, int do_norm,
+                      const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
+                      int rope_len, int head_dim, const int* __restrict__ grid, int seq_len, float out_scale) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -197,6 +197,31 @@ void rmsnorm_rope_kernel(const void* __restrict__ xv, int64_t ldx, uint16_t* __r
             yr[c] = o;
         }
     }
+}
+
+template <int MAXV, bool IN_BF16>
+__global__ __launch_bounds__(256)
+void rmsnorm_rope_kernel(const void* __restrict__ xv, int64_t ldx, uint16_t* __restrict__ y, int64_t rows,
+                         int dim, const float* __restrict__ weight, float eps, int do_norm,
+                         const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
+                         int rope_len, int head_dim, const int* __restrict__ grid, int seq_len, float out_scale) {
+    rmsnorm_rope_row<MAXV, IN_BF16>(xv, ldx, y, rows, dim, weight, eps, do_norm, rope_cos, rope_sin, rope_len, head_dim, grid,
+                                    seq_len, out_scale);
+}
+
+// Two column segments of the same rows in ONE launch (blockIdx.y = segment): q and k of the self-attention out of the fused
+// q|k projection, each with its own gain, output and output scale — the same row arithmetic as two launches of the kernel
+// above (same bits), one launch fewer per block (latency-bound at one or two [16,1,60,104] clips: 2 x 8 us -> 10 us).
+template <int MAXV>
+__global__ __launch_bounds__(256)
+void rmsnorm_rope_pair_kernel(const uint16_t* __restrict__ x, int64_t ldx, int64_t seg_x, uint16_t* __restrict__ y0,
+                              uint16_t* __restrict__ y1, int64_t rows, int dim, const float* __restrict__ w0,
+                              const float* __restrict__ w1, float eps, int do_norm, const float* __restrict__ rope_cos,
+                              const float* __restrict__ rope_sin, int rope_len, int head_dim,
+                              const int* __restrict__ grid, int seq_len, float scale0, float scale1) {
+    const bool s = blockIdx.y != 0;                                  // workgroup-uniform
+    rmsnorm_rope_row<MAXV, true>(x + (s ? seg_x : 0), ldx, s ? y1 : y0, rows, dim, s ? w1 : w0, eps, do_norm, rope_cos, rope_sin,
+                                 rope_len, head_dim, grid, seq_len, s ? scale1 : scale0);
 }
 
 // ------------------------------------------------------------------ cast
@@ -381,6 +406,25 @@ extern "C" int omh_rmsnorm_rope_bf16(const void* x_bf16, int64_t ldx, void* y, i
                                      const int32_t* grid, int32_t seq_len, float out_scale, omh_stream_t stream) {
     return rmsnorm_rope_launch<true>(x_bf16, ldx, y, rows, dim, weight, eps, do_norm, rope_cos, rope_sin, rope_len,
                                      head_dim, grid, seq_len, out_scale, stream);
+}
+
+extern "C" int omh_rmsnorm_rope_bf16_pair(const void* x_bf16, int64_t ldx, int64_t seg_x, void* y0, void* y1, int64_t rows,
+                                          int32_t dim, const float* weight0, const float* weight1, float eps, int32_t do_norm,
+                                          const float* rope_cos, const float* rope_sin, int32_t rope_len, int32_t head_dim,
+                                          const int32_t* grid, int32_t seq_len, float out_scale0, float out_scale1,
+                                          omh_stream_t stream) {
+    if (!x_bf16 || !y0 || !y1 || rows <= 0 || dim <= 0) return OMH_E_BADARG;
+    if ((dim & 3) || dim > MAXV_GENERIC * 256 || (ldx & 3) || (seg_x & 3)) return OMH_E_SHAPE;
+    if (rope_cos && (!rope_sin || !grid || seq_len <= 0 || head_dim <= 0 || (head_dim & 3) || dim % head_dim))
+        return OMH_E_BADARG;
+    if (((uintptr_t)x_bf16 & 7) || ((uintptr_t)y0 & 7) || ((uintptr_t)y1 & 7)) return OMH_E_ALIGN;
+    omh_clear_status();
+    auto kern = dim <= 6 * 256 ? rmsnorm_rope_pair_kernel<6>
+                               : (dim <= 20 * 256 ? rmsnorm_rope_pair_kernel<20> : rmsnorm_rope_pair_kernel<MAXV_GENERIC>);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 3) / 4), 2), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)x_bf16, ldx, seg_x, (uint16_t*)y0, (uint16_t*)y1, rows, dim, weight0, weight1, eps,
+                       do_norm, rope_cos, rope_sin, rope_len, head_dim, grid, seq_len, out_scale0, out_scale1);
+    return omh_launch_status();
 }
 
 extern "C" int omh_cast_f32_bf16(const float* x, void* y, int64_t n, omh_stream_t stream) {

@@ -248,6 +248,23 @@ def rmsnorm_rope_bf16_raw(x, ldx, y, rows, dim, weight, eps, do_norm, rope_cos, 
                                     head_dim, grid, seq_len, float(out_scale), _stream()), "omh_rmsnorm_rope_bf16")
 
 
+def rmsnorm_rope_bf16_pair_raw(x, ldx, seg_x, y0, y1, rows, dim, weight0, weight1, eps, do_norm, rope_cos, rope_sin, rope_len,
+                               head_dim, grid, seq_len, out_scale0=1.0, out_scale1=1.0):
+    """``rmsnorm_rope_bf16_raw`` on two column segments of the same rows in one launch (include/omh.h, ABI v9): segment 1
+    reads ``x + seg_x`` elements, with its own gain / output / output scale.  Same bits as two calls
+    (OMH_RMS_PAIR=0: issued as the two calls, A/B timing)."""
+    if _os.environ.get("OMH_RMS_PAIR") == "0":
+        rmsnorm_rope_bf16_raw(x, ldx, y0, rows, dim, weight0, eps, do_norm, rope_cos, rope_sin, rope_len, head_dim, grid,
+                              seq_len, out_scale0)
+        x1 = C.c_void_p(x.value + 2 * seg_x) if isinstance(x, C.c_void_p) else x + 2 * seg_x
+        rmsnorm_rope_bf16_raw(x1, ldx, y1, rows, dim, weight1, eps, do_norm, rope_cos, rope_sin, rope_len, head_dim, grid,
+                              seq_len, out_scale1)
+        return
+    check(lib.omh_rmsnorm_rope_bf16_pair(x, ldx, seg_x, y0, y1, rows, dim, weight0, weight1, eps, do_norm, rope_cos, rope_sin,
+                                         rope_len, head_dim, grid, seq_len, float(out_scale0), float(out_scale1), _stream()),
+          "omh_rmsnorm_rope_bf16_pair")
+
+
 def rmsnorm_rope(x: torch.Tensor, weight: Optional[torch.Tensor], eps: float, do_norm: bool = True,
                  rope_cos=None, rope_sin=None, head_dim: int = 128, grid: Optional[torch.Tensor] = None,
                  seq_len: int = 0, out=None):

@@ -199,11 +199,11 @@ class WanSelfAttention(nn.Module):
         # q leaves the norm kernel already multiplied by softmax_scale * log2(e) (attention.py:96-127), in fp32
         # before its one rounding to bf16: the attention kernel's exponentials then need no per-score multiply
         q_scale = D ** -0.5 * 1.4426950408889634
-        for dst, off, nm, osc in ((q, 0, "norm_q", q_scale), (k, d, "norm_k", 1.0)):
-            w = self._norm_w(nm)
-            ops.rmsnorm_rope_bf16_raw(ptr(qk, off), 2 * d, ptr(dst), R, d, ptr(w) if w is not None else None,
-                                      self.eps, int(self.qk_norm), ptr(fc.rope_cos), ptr(fc.rope_sin),
-                                      fc.rope_cos.shape[0], D, ptr(fc.grid32), S, out_scale=osc)
+        wq, wk = self._norm_w("norm_q"), self._norm_w("norm_k")          # q and k: one launch (two column segments)
+        ops.rmsnorm_rope_bf16_pair_raw(ptr(qk), 2 * d, d, ptr(q), ptr(k), R, d, ptr(wq) if wq is not None else None,
+                                       ptr(wk) if wk is not None else None, self.eps, int(self.qk_norm), ptr(fc.rope_cos),
+                                       ptr(fc.rope_sin), fc.rope_cos.shape[0], D, ptr(fc.grid32), S, out_scale0=q_scale,
+                                       out_scale1=1.0)
         del qk
         # V^T[b] = Wv h_b^T + bv  ->  [B, dim, Sp]   (pad columns stay zero)
         Sp = _round_up(S, 64)

@@ -625,10 +625,10 @@ def _block_forward(model, blk, idx, st, x0, P, keep, need=True):
     ops.gemm_raw(ptr(h1), ptr(wqkv), ptr(qk), R, 2 * d, d, d, d, 2 * d, EPI_BF16, bias=ptr(bqkv), bias_mode=BIAS_N)
     q, k = bf(R, d), bf(R, d)
     nq, nk = sa._norm_w("norm_q"), sa._norm_w("norm_k")
-    for dst, off, w, osc in ((q, 0, nq, D ** -0.5 * LOG2E), (k, d, nk, 1.0)):
-        ops.rmsnorm_rope_bf16_raw(ptr(qk, off), 2 * d, ptr(dst), R, d, ptr(w) if w is not None else None, sa.eps,
-                                  int(sa.qk_norm), ptr(fc.rope_cos), ptr(fc.rope_sin), fc.rope_cos.shape[0], D,
-                                  ptr(fc.grid32), Sq, out_scale=osc)
+    ops.rmsnorm_rope_bf16_pair_raw(ptr(qk), 2 * d, d, ptr(q), ptr(k), R, d, ptr(nq) if nq is not None else None,
+                                   ptr(nk) if nk is not None else None, sa.eps, int(sa.qk_norm), ptr(fc.rope_cos),
+                                   ptr(fc.rope_sin), fc.rope_cos.shape[0], D, ptr(fc.grid32), Sq,
+                                   out_scale0=D ** -0.5 * LOG2E, out_scale1=1.0)      # q and k: one launch, as model.py
     Sp = _ru(Sq, 64)
     vt = _vt_buffer(model, (idx, "sa"), B, d, Sp, Sq, dev, keep)
     ops.gemm_raw(ptr(wqkv, 2 * d * d), ptr(h1), ptr(vt), d, Sq, d, d, d, Sp, EPI_BF16, bias=ptr(bqkv, 2 * d),

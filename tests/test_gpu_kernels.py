@@ -538,6 +538,34 @@ def test_rmsnorm_rope_matches_oracle(ops):
     assert rel_rms(y2.float(), O.rms_norm(x[:, :d].cpu(), torch.ones(d), 1e-6)) < 4e-3
 
 
+@pytest.mark.parametrize("rows,d,S", [(60, 256, 30), (3120, 1536, 1560), (1001, 5120, 1001)])
+def test_rmsnorm_rope_pair_equals_two_launches(ops, rows, d, S):
+    """ABI v9: q and k of the self-attention normalised + rotated out of the fused q|k projection in ONE launch (two column
+    segments, each with its own gain, output and output scale): bit for bit the two single-segment launches; without gains
+    and without RoPE too; ragged row count (rows % 4 != 0)."""
+    from oracle import wan_dit_oracle as O
+    torch.manual_seed(rows)
+    D = 128
+    B = rows // S
+    qk = (torch.randn(rows, 2 * d, device="cuda") * 1.3).bfloat16()
+    wq, wk = torch.rand(d, device="cuda") + 0.5, torch.rand(d, device="cuda") + 0.5
+    ang = O.rope_table(D)
+    cos, sin = torch.cos(ang).float().cuda(), torch.sin(ang).float().cuda()
+    gs = {30: (2, 3, 4), 1560: (1, 30, 52), 1001: (1, 25, 40)}[S]
+    grid = torch.tensor([gs] * B, dtype=torch.int32, device="cuda")
+    for gains, rope in ((True, True), (False, True), (True, False)):
+        rk = (ops.ptr(cos), ops.ptr(sin), 1024, D, ops.ptr(grid), S) if rope else (None, None, 0, D, None, 0)
+        w0, w1 = (ops.ptr(wq), ops.ptr(wk)) if gains else (None, None)
+        q0, k0 = torch.empty(rows, d, dtype=torch.bfloat16, device="cuda"), torch.empty(rows, d, dtype=torch.bfloat16, device="cuda")
+        ops.rmsnorm_rope_bf16_raw(ops.ptr(qk), 2 * d, ops.ptr(q0), rows, d, w0, 1e-6, 1, *rk, out_scale=0.1275)
+        ops.rmsnorm_rope_bf16_raw(ops.ptr(qk, d), 2 * d, ops.ptr(k0), rows, d, w1, 1e-6, 1, *rk, out_scale=1.0)
+        q1, k1 = torch.full_like(q0, 3.0), torch.full_like(k0, 3.0)
+        ops.rmsnorm_rope_bf16_pair_raw(ops.ptr(qk), 2 * d, d, ops.ptr(q1), ops.ptr(k1), rows, d, w0, w1, 1e-6, 1, *rk,
+                                       out_scale0=0.1275, out_scale1=1.0)
+        assert torch.equal(q1, q0) and torch.equal(k1, k0), (gains, rope)
+    assert float(q0.float().abs().mean()) > 1e-3 and not torch.equal(q0, k0)
+
+
 def test_patchify_unpatchify_dense_sinusoid(ops):
     from oracle import wan_dit_oracle as O
     torch.manual_seed(4)
