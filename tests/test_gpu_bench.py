@@ -86,7 +86,7 @@ def test_bench_gpus_8_launches_itself(mode):
         # 8 clips in flight, one per rank: value = 8 steps / max-over-ranks time
         assert abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
     else:
-        assert "one clip per PAIR" in d["config"]["workload"]
+        assert "one clip per PAIR" in d["config"]["workload_detail"]
         assert abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]         # 4 clips in flight
 
 
