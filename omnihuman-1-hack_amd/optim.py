@@ -2,6 +2,7 @@
 constructor of ``torch.optim.AdamW`` (seaweed_apt/distilled_trainer.py:69-75)
 and the EMA update of distilled_trainer.py:319-334 kept on the GPU."""
 import os
+import weakref
 
 import torch
 
@@ -39,6 +40,9 @@ class AdamW(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    # model_train.pending_step_bytes stops counting them while they are alive (weak: a deleted optimizer
+                    # frees them again)
+                    p._omh_moments_allocated = weakref.ref(st["exp_avg"])
                 # a state dict saved by torch.optim.AdamW (the 'optimizer' entry of the reference's checkpoints,
                 # distilled_trainer.py:153-178) holds the step as a 0-d tensor: normalise to a Python int
                 st["step"] = int(st["step"]) + 1

@@ -113,7 +113,7 @@ def _dev_ints(values, dtype, device):
 class _FwdCtx:
     """Per-forward shared state handed to every block."""
     __slots__ = ("B", "S", "dim", "e0", "seq_lens32", "ctx_lens32", "grid32", "rope_cos", "rope_sin", "ctx",
-                 "Lc", "n_img", "seq_lens_host", "ctx_lens_host", "kv")
+                 "Lc", "n_img", "seq_lens_host", "ctx_lens_host", "kv", "split_k")
 
 
 class ContextState:
@@ -368,13 +368,13 @@ class WanAttentionBlock(nn.Module):
             M, K = a.shape
             if gate_i is None:
                 ops.gemm_raw(ptr(a), ptr(w), xp, M, d, K, K, K, d, EPI_RESID, bias=ptr(b) if b is not None else None,
-                             bias_mode=BIAS_N if b is not None else BIAS_NONE, gate_const=1.0, split_k=True)
+                             bias_mode=BIAS_N if b is not None else BIAS_NONE, gate_const=1.0, split_k=fc.split_k)
             else:
                 # (split_k: at one or two [16,1,60,104] clips the FFN-down contraction, K = ffn_dim over 56 / 104 tiles,
                 # runs in slices — ABI v9; nothing is split at the sampling sizes)
                 ops.gemm_raw(ptr(a), ptr(w), xp, M, d, K, K, K, d, EPI_RESID, bias=ptr(b), bias_mode=BIAS_N,
                              gate0=ptr(mod, gate_i * d), gate1=ptr(e0, gate_i * d), gate1_stride=six_d, gate_rows=S,
-                             gate_const=0.0, split_k=True)
+                             gate_const=0.0, split_k=fc.split_k)
 
         # ---- self-attention: x += o(attn(LN(x)(1+e1)+e0)) * e2        model.py:292-296
         h = ln_mod(0, 1)
@@ -479,6 +479,7 @@ def _make_ctx_for_block(block, x, e, seq_lens, grid_sizes, freqs, context, conte
     B, S, d = x.shape
     fc = _FwdCtx()
     fc.B, fc.S, fc.dim = B, S, d
+    fc.split_k = True
     fc.e0 = e.contiguous()
     fc.seq_lens32 = seq_lens.to(device=x.device, dtype=torch.int32).contiguous()
     fc.grid32 = grid_sizes.to(device=x.device, dtype=torch.int32).contiguous()
@@ -534,6 +535,14 @@ class WanModel(nn.Module):
         self.checkpoint_policy = "auto"
         # reference quirk (model.py:317-324): FFNs of blocks > 10 receive no gradient; False = full gradients
         self.reference_ffn_freeze = True
+        # False (default): products with few rows and a long contraction — the FFN-down projection at one or two
+        # [16,1,60,104] clips — are summed in 2-4 k slices (ABI v9), so a sample's last bits depend on how many samples
+        # share its forward (a clip alone, in a CFG pair, in a batch of four: 4 / 2 / no slices; 9e-3 between the
+        # guided velocities, where each is 1e-2 from the oracle).  True: every product keeps one summation order
+        # whatever the batch — bit-identical outputs for a sample alone and inside any batch, at the price of the
+        # small-M speed-up (15.3 -> 16.1 ms per single-frame CFG pair).  Nothing is split at the sampling sizes
+        # (S = 32 760) either way.  ADVICE round 4; pinned by test_batch_invariant_flag_pins_the_summation_order.
+        self.batch_invariant = False
         self.patch_size = tuple(patch_size)
         self.text_len, self.in_dim, self.dim, self.ffn_dim = text_len, in_dim, dim, ffn_dim
         self.freq_dim, self.text_dim, self.out_dim = freq_dim, text_dim, out_dim
@@ -663,6 +672,7 @@ class WanModel(nn.Module):
             ctx, ctx_lens = self._embed_context(context, clip_fea, extra_conditions)
         fc = _FwdCtx()
         fc.B, fc.S, fc.dim = B, seq_len, d
+        fc.split_k = not getattr(self, "batch_invariant", False)
         fc.e0 = e0.contiguous()
         fc.seq_lens32 = _dev_ints(lens, torch.int32, device)
         fc.grid32 = _dev_ints(grids, torch.int32, device)

@@ -89,21 +89,34 @@ class _State:
 
 
 # ----------------------------------------------------------------------------- bf16 weight copies, one launch per step
-# parameter data_ptr -> (weakref to its TrainPacks, row index in TrainPacks.rows): lets the optimizer write the bf16
-# copies of a weight in the same pass that updates it (optim.AdamW, omh_adamw_pack_multi) instead of a re-pack launch
+# id(parameter) -> (weakref to its TrainPacks, row index in TrainPacks.rows, weakref to the parameter): lets the optimizer
+# write the bf16 copies of a weight in the same pass that updates it (optim.AdamW, omh_adamw_pack_multi) instead of a
+# re-pack launch.  Keyed by the parameter OBJECT, never by its address: a storage that was freed or moved (offload, a
+# .to() without a refresh()) can be handed to an unrelated tensor by the caching allocator.
 import weakref
 _PACK_REGISTRY = {}
 
 
+def _purge_pack_entries(keys):
+    for k in keys:
+        _PACK_REGISTRY.pop(k, None)
+
+
 def pack_entry_of(param):
-    """(packs, row) if ``param`` has bf16 operand copies in a live TrainPacks whose buffers are current, else None."""
-    ent = _PACK_REGISTRY.get(param.data_ptr())
+    """(packs, row) if ``param`` IS the tensor a live TrainPacks keeps bf16 operand copies of, still at the address and
+    with the shape the pack table was built for; else None (the optimizer then takes the plain AdamW row and the copies
+    are rebuilt by the next refresh())."""
+    ent = _PACK_REGISTRY.get(id(param))
     if ent is None:
         return None
-    packs = ent[0]()
-    if packs is None or packs.table is None or ent[1] >= len(packs.rows) or packs.rows[ent[1]][0] != param.data_ptr():
+    packs, ri = ent[0](), ent[1]
+    if packs is None or ent[2]() is not param or packs.table is None or ri >= len(packs.rows):
         return None
-    return packs, ent[1]
+    row = packs.rows[ri]
+    if packs.params[ri] is not param or row[0] != param.data_ptr() or param.numel() != row[3] * row[4] \
+            or param.dtype != torch.float32 or not param.is_contiguous():
+        return None
+    return packs, ri
 
 
 class TrainPacks:
@@ -170,9 +183,15 @@ class TrainPacks:
         self.rows, self.subsets = rows, {}
         self.table, self.total_tiles = self._table(range(len(rows)), dev)
         self.n = len(rows)
+        _purge_pack_entries(self.__dict__.get("_registry_keys", ()))      # a re-layout drops the rows it replaces
         ref = weakref.ref(self)
-        for i, r in enumerate(rows):
-            _PACK_REGISTRY[r[0]] = (ref, i)
+        self._registry_keys = [id(p) for p in self.params]
+        for i, p in enumerate(self.params):
+            _PACK_REGISTRY[id(p)] = (ref, i, weakref.ref(p))
+        fin = self.__dict__.get("_registry_finalizer")
+        if fin is not None:
+            fin.detach()
+        self._registry_finalizer = weakref.finalize(self, _purge_pack_entries, self._registry_keys)
 
     def mark_current(self, indices):
         """The optimizer wrote the copies of rows ``indices`` itself (omh_adamw_pack_multi): their versions are current."""
@@ -611,11 +630,11 @@ def _block_forward(model, blk, idx, st, x0, P, keep, need=True):
         if gate_i is None:
             ops.gemm_raw(ptr(a), ptr(w), ptr(xo), M, d, K, a.stride(0), w.stride(0), d, EPI_RESID,
                          bias=ptr(b) if b is not None else None, bias_mode=BIAS_N if b is not None else BIAS_NONE,
-                         gate_const=1.0, split_k=True, **kw)
+                         gate_const=1.0, split_k=fc.split_k, **kw)
         else:
             ops.gemm_raw(ptr(a), ptr(w), ptr(xo), M, d, K, a.stride(0), w.stride(0), d, EPI_RESID, bias=ptr(b),
                          bias_mode=BIAS_N, gate0=ptr(mod, gate_i * d), gate1=ptr(e0, gate_i * d), gate1_stride=six,
-                         gate_rows=Sq, gate_const=0.0, split_k=True, **kw)      # (same slices as the inference block: model.py)
+                         gate_rows=Sq, gate_const=0.0, split_k=fc.split_k, **kw)      # (same slices as the inference block: model.py)
         return xo, y
 
     # ---- self-attention: x1 = x0 + o(attn(LN(x0)(1+e1)+e0)) * e2                                    model.py:292-296
@@ -804,7 +823,7 @@ def _block_backward(model, blk, idx, st, S, dx, P, tgt=None):
         ops.gemm_raw(ptr(dy3), ptr(P["w2T"]), ptr(du_pre), R, f, d, d, d, f, EPI_GELU_BWD, aux=ptr(u_pre), ldaux=f)
         wgrad(du_pre, h2, ["ffn.0.weight"]), bgrad(du_pre, ["ffn.0.bias"])
         wg.launch()                                                  # FFN weight gradients: second stream, from here on
-        dh2 = _dgrad(du_pre, P["w1T"], split_k=True)
+        dh2 = _dgrad(du_pre, P["w1T"], split_k=fc.split_k)
         # ---- cross-attention branch: x2 = x1 + y2  (its dy2 = bf16(dx) comes out of the same pass)
         dy2 = ln_bwd(S["x2"], dh2, 3, 4, nxt=(None, None))
         del du_pre, dh2
@@ -937,13 +956,16 @@ def activation_bytes(model, rows, batch=1):
 
 def pending_step_bytes(model):
     """Memory the rest of the step will still claim after the forward: AdamW's two moments (8 bytes per trainable
-    parameter — the optimizer is not visible from here, so they are always assumed to be missing) and the gradients
+    parameter, until this package's optimizer has allocated them and said so: ``param._omh_moments_allocated``, ADVICE
+    round 4 — counted again on every later step they made ``auto`` recompute although memory sufficed) and the gradients
     where none exist yet (first step, or ``zero_grad(set_to_none=True)``).  ADVICE round 3: without this the first
     step's free-memory reading is overstated by exactly what the backward and the optimizer step allocate."""
     pending = 0
     for p in model.parameters():
         if p.requires_grad:
-            pending += p.numel() * (8 + (0 if p.grad is not None else 4))
+            mref = getattr(p, "_omh_moments_allocated", None)                      # set by optim.AdamW.step
+            have_moments = mref is not None and mref() is not None
+            pending += p.numel() * ((0 if have_moments else 8) + (0 if p.grad is not None else 4))
     return pending
 
 
@@ -1017,6 +1039,11 @@ class _BlockFn(torch.autograd.Function):
                 defer = False
             elif st.__dict__.get("no_defer", False):
                 defer = False
+            elif any(o is not st and not o.__dict__.get("bwd_done", False)
+                     for o in model.__dict__.get("_omh_live_states", ())):
+                # another forward of this model still awaits its backward: whichever order the engine picks, the sum of
+                # the two contributions to a shared parameter is formed on the main stream — join per block
+                st.no_defer, defer = True, False
             elif _may_defer_join(model):
                 if tok is None:
                     tok = _join_pending[key] = object()
@@ -1038,6 +1065,8 @@ class _BlockFn(torch.autograd.Function):
                     _wgrad_join(dev)                         # also on an exception: nothing may stay on the side stream
                 if not done:
                     _join_pending.pop(key, None)             # (the engine drops its callbacks with the failed pass)
+                if idx == 0:
+                    st.bwd_done = True                       # the last block node of this forward's backward
         out = []
         for n, p in _block_params(model, idx):
             gg = grads.get(n) if p.requires_grad else None
@@ -1254,6 +1283,9 @@ def forward_train(model, x, t, context, seq_len, clip_fea=None, y=None, extra_co
         _join_pending.pop(key, None)
         _wgrad_join(key[0])
     st.packs = TrainPacks.of(model).refresh(model)           # bf16 weight copies: one launch when anything changed
+    # forwards of this model whose backward has not run yet: with more than one of them in a pass the
+    # engine sums their contributions to a shared parameter on the main stream, so none of them may defer its join
+    model.__dict__.setdefault("_omh_live_states", weakref.WeakSet()).add(st)
     x_list = list(x) if not isinstance(x, (list, tuple)) else list(x)
     eparams = [p for _, p in _embed_params(model)]
     tok = extra_conditions.get("tokens") if isinstance(extra_conditions, dict) else extra_conditions
@@ -1263,13 +1295,21 @@ def forward_train(model, x, t, context, seq_len, clip_fea=None, y=None, extra_co
     st.keep = keep_activations(model, xs.shape[0] * xs.shape[1], xs.device, batch=xs.shape[0])
     model.__dict__["_kept_activations"] = st.keep            # what the last training forward did (bench / tests)
     for i, blk in enumerate(model.blocks):
+        if blk._forward_pre_hooks:
+            # the block nodes take their other inputs from the forward state, so a pre-hook could only rewrite x — and a
+            # rewritten x is something the reference never does: refuse loudly rather than skip it silently
+            raise NotImplementedError("forward pre-hooks on WanAttentionBlock are not honoured by the training forward; "
+                                      "register a forward hook (block outputs) instead")
         x_in = xs
         xs = _BlockFn.apply(xs, model, st, i, *[p for _, p in _block_params(model, i)])
         # forward hooks registered on a block (the reference's discriminator taps block outputs this way,
         # seaweed_apt/model.py:150-155) see the block's output as under nn.Module.__call__; the extra consumer they
         # create is why _BlockFn.backward owns-or-copies its incoming gradient
-        for hook in list(blk._forward_hooks.values()):
-            r = hook(blk, (x_in,), xs)
+        for hid, hook in list(blk._forward_hooks.items()):
+            if hid in getattr(blk, "_forward_hooks_with_kwargs", ()):      # register_forward_hook(..., with_kwargs=True)
+                r = hook(blk, (x_in,), {}, xs)
+            else:
+                r = hook(blk, (x_in,), xs)
             if r is not None:
                 xs = r
     outs = _HeadFn.apply(xs, model, st, st.grids, *list(model.head.parameters()))

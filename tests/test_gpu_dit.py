@@ -206,3 +206,33 @@ def test_wan_14b_width_one_layer(wan_model_mod, model_type):
             clip_fea=clip.cuda() if i2v else None, y=[u.cuda() for u in ys] if i2v else None)
     for o, r in zip(out, ref):
         assert o.shape == r.shape and rel_rms(o, r) < TOL_TINY
+
+
+def test_batch_invariant_flag_pins_the_summation_order(wan_model_mod):
+    """the inference block asks for split K on its gated-residual GEMMs, so at one / two [16,1,60,104]
+    clips the FFN-down contraction (K = 8 960 over 56 / 104 tiles of 256 x 192) is summed in 4 / 2 slices and a
+    sample's last bits depend on its batch.  ``model.batch_invariant = True`` switches that off: a clip alone and the
+    same clip inside a batch of two then agree BIT FOR BIT; with the default the two agree to fp32 summation noise
+    (and are NOT identical — which is what pins that the split is really taken by default)."""
+    torch.manual_seed(7)
+    m = wan_model_mod.WanModel(dim=1536, ffn_dim=8960, num_heads=12, num_layers=2, text_dim=4096, text_len=512,
+                               freq_dim=256)
+    with torch.no_grad():
+        torch.nn.init.xavier_uniform_(m.head.head.weight)
+    m = m.cuda().eval().requires_grad_(False)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x0 = torch.randn(16, 1, 60, 104, device="cuda", generator=g)
+    x1 = torch.randn(16, 1, 60, 104, device="cuda", generator=g)
+    c0 = torch.randn(77, 4096, device="cuda", generator=g)
+    c1 = torch.randn(31, 4096, device="cuda", generator=g)
+    t1, t2 = torch.tensor([600.0], device="cuda"), torch.tensor([600.0, 600.0], device="cuda")
+    assert m.batch_invariant is False
+    alone = m([x0], t1, [c0], 1560)[0]
+    both = m([x0, x1], t2, [c0, c1], 1560)[0]
+    assert rel_rms(both, alone) < 1e-3
+    assert not torch.equal(both, alone), "the default takes the k slices: 4 for one clip, 2 for two"
+    m.batch_invariant = True
+    alone_i = m([x0], t1, [c0], 1560)[0]
+    both_i = m([x0, x1], t2, [c0, c1], 1560)[0]
+    assert torch.equal(both_i, alone_i)
+    assert rel_rms(alone_i, alone) < 1e-3
