@@ -612,19 +612,16 @@ def wgrad_group_bench(device, bsz=4, reps=20):
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps * 1e3
-    old = os.environ.get("OMH_GEMM_TN_W64")
+    old = ops.get_option("GEMM_TN_W64")
     try:
-        os.environ.pop("OMH_GEMM_TN_W64", None)
+        ops.set_option("GEMM_TN_W64", None)
         us = timed()
         ref = [t[2].clone() for t in items]
-        os.environ["OMH_GEMM_TN_W64"] = "0"
+        ops.set_option("GEMM_TN_W64", "0")
         us_tiled = timed()
         same = all(torch.equal(a, t[2]) for a, t in zip(ref, items))
     finally:
-        if old is None:
-            os.environ.pop("OMH_GEMM_TN_W64", None)
-        else:
-            os.environ["OMH_GEMM_TN_W64"] = old
+        ops.set_option("GEMM_TN_W64", old)
     return {"products": [f"{M}x{N} over {K} rows" for M, N, K in shapes], "tiles_256x384": 192, "us_per_launch": round(us, 1),
             "tflops": round(flop / us / 1e6, 1), "mfma_roofline_frac": round(flop / us / 1e6 / 2500.0, 4),
             "tiled_128x128_us_per_launch": round(us_tiled, 1), "tiled_128x128_tflops": round(flop / us_tiled / 1e6, 1),
@@ -911,7 +908,7 @@ def main():
     if attn_ms:
         ach = attn_flops / (attn_ms * 1e-3) / 1e12
         kname = {"pp": "flash_attn_fwd_d128_pp_kernel", "base": "flash_attn_fwd_d128_kernel"}.get(
-            os.environ.get("OMH_ATTN_KERNEL", ""), "flash_attn_fwd_d128_w64_v2_kernel")
+            (ops.get_option("ATTN_KERNEL") or ""), "flash_attn_fwd_d128_w64_v2_kernel")
         traffic = tsrc = None
         tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tj):

@@ -13,8 +13,11 @@
  * Conventions
  *  - plain C types only: device pointers (void* / float*), sizes, strides in
  *    ELEMENTS, a hipStream_t passed as void*.  No torch types.
- *  - every call is asynchronous on the given stream, allocates nothing and
- *    keeps no hidden state; the caller owns all buffers.
+ *  - every call is asynchronous on the given stream and allocates nothing;
+ *    the caller owns all buffers.  The only process state is the option
+ *    table below (omh_set_option; omh_set_deterministic is one of its
+ *    entries): it is seeded from the environment ONCE, at the first call
+ *    into the library, and the launch path never reads the environment.
  *  - return 0 on success, a negative OMH_E_* code on a rejected argument,
  *    or the positive hipError_t of a failed launch.
  *  - bf16 = 16-bit brain float (upper half of an IEEE fp32), fp32 accumulate
@@ -29,7 +32,7 @@
 extern "C" {
 #endif
 
-#define OMH_ABI_VERSION 9
+#define OMH_ABI_VERSION 10
 
 #define OMH_E_BADARG   (-1)   /* null pointer / non-positive size             */
 #define OMH_E_ALIGN    (-2)   /* pointer or leading dimension not aligned     */
@@ -47,6 +50,27 @@ const char* omh_build_arch(void);
  * order (no split K, one row block): the whole step then repeats bit for bit, at a few percent of its speed.
  * on < 0 only queries.  The initial value is the environment's OMH_DETERMINISTIC (0 / 1).  Returns the mode in force. */
 int omh_set_deterministic(int on);
+
+/* Process options (ABI v10).  Every dispatch switch of the library — kernel-family overrides used by the parity tests
+ * (one product on every kernel that can take it) and by A/B timing — is an entry of one table:
+ *   ATTN_KERNEL ("w64" / "pp" / "base")   ATTN_SPLIT ("0" / "tail")   W64_SPLIT ("0")   W64_VARIANT ("0".."2")
+ *   GEMM_KERNEL ("w64" / "8w")   GEMM_TILE ("big" / "small" / "tiny")   GEMM_RULE   GEMM_GROUP_M   GEMM_SPLITK ("0")
+ *   GEMM_QKV ("0")   GEMM_W64_R192 / R256 / N192 / BF16M / GBWD / GAUX ("0" / "1")
+ *   GEMM_TN_W64 ("0" / "1")   GEMM_TN_TILE   GEMM_TN_GROUP_TILE ("big" / "small")   GEMM_TN_SPLIT (count)
+ *   CONV_TILE ("w64" / "wide" / "small")   CONV_W64   CONV_WIDE_MIN   CONV_FUSE_NORM   CONV_KW3   CONV_PERSIST
+ *   CONV_W64_UP2   CONV_EPI   LN_RPW ("1" / "2" / "4")   DETERMINISTIC ("0" / "1")
+ * An unset option means "the library decides" (the shipped dispatch).  The table is seeded from the environment
+ * (variable OMH_<NAME>) exactly once, at the first call into the library; afterwards only omh_set_option changes it —
+ * no entry point calls getenv on the launch path.  Setting an option is not synchronised against concurrent launches.
+ *   omh_set_option(key, value): key with or without the "OMH_" prefix; value NULL or "" unsets; at most 47 characters.
+ *                               (NULL, NULL) restores every option to its start-up (environment) value.
+ *                               Returns 0, OMH_E_BADARG for an unknown key, OMH_E_SHAPE for a value that is too long.
+ *   omh_get_option(key): the value in force, NULL when unset or unknown (the pointer is valid until the next set).
+ *   omh_option_count / omh_option_name(i): enumerate the table (DETERMINISTIC is not enumerated). */
+int omh_set_option(const char* key, const char* value);
+const char* omh_get_option(const char* key);
+int omh_option_count(void);
+const char* omh_option_name(int index);
 
 /* ------------------------------------------------------------------------
  * GEMM  C[m][n] = epilogue( sum_k A[m][k] * B[n][k] )          (bf16 MFMA)
@@ -180,6 +204,10 @@ typedef struct omh_attn_args {
        rounds instead of 2.  The split plan depends on B, so a sample's last bits depend on its batch: only callers that do
        not need batch invariance set it (the training step; the inference path does not). */
     int32_t flags;
+    /* ABI v10, optional: int32 [B] device pointer or NULL (= Lq).  The reference's flash_attention(q_lens=...)
+       (attention.py:24-60,79-80: queries past q_lens[b] are cut out of the packed varlen batch): output rows
+       i >= q_lens[b] are written as ZERO (o, o32; lse = -inf).  Served by the short-sequence kernel, unsplit. */
+    const int32_t* q_lens;
 } omh_attn_args;
 #define OMH_ATTN_SHORT_KERNEL 1
 #define OMH_ATTN_ALLOW_SPLIT  2

@@ -21,7 +21,7 @@ class OmhError(RuntimeError):
     pass
 
 
-ABI_VERSION = 9          # == OMH_ABI_VERSION of include/omh.h; checked against the loaded library below
+ABI_VERSION = 10         # == OMH_ABI_VERSION of include/omh.h; checked against the loaded library below
 
 
 def _load():
@@ -97,7 +97,7 @@ class AttnArgs(C.Structure):
                 ("q_bs", i64), ("q_rs", i64), ("k_bs", i64), ("k_rs", i64),
                 ("vt_bs", i64), ("o_bs", i64), ("o_rs", i64),
                 ("ldv", i32), ("scale", f32), ("lse", vp), ("q_prescaled", i32), ("workspace", vp), ("workspace_bytes", i64),
-                ("o32", vp), ("flags", i32)]
+                ("o32", vp), ("flags", i32), ("q_lens", vp)]
 
 
 class AttnBwdArgs(C.Structure):
@@ -161,6 +161,10 @@ _SIGS = {
     "omh_abi_version": (i32, []),
     "omh_set_deterministic": (i32, [i32]),
     "omh_build_arch": (C.c_char_p, []),
+    "omh_set_option": (i32, [C.c_char_p, C.c_char_p]),
+    "omh_get_option": (C.c_char_p, [C.c_char_p]),
+    "omh_option_count": (i32, []),
+    "omh_option_name": (C.c_char_p, [i32]),
     "omh_gemm_bf16": (i32, [C.POINTER(GemmArgs), vp]),
     "omh_gemm_workspace_bytes": (i64, [C.POINTER(GemmArgs)]),
     "omh_gemm_bf16_tn": (i32, [C.POINTER(GemmTnArgs), vp]),

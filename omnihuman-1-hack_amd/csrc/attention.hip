@@ -285,6 +285,9 @@ void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles, const 
         return;
     }
     if (q_row < p.Lq) {
+        // q_lens (ABI v10): a query row past its sample's length is a pad row of the reference's varlen batch -> zeros
+        const bool live = !p.q_lens || q_row < p.q_lens[b];
+        if (!live) l_run = 0.f;
         const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
         uint16_t* O = (uint16_t*)p.o + (int64_t)b * p.o_bs + (int64_t)q_row * p.o_rs + head * D;
 #pragma unroll
@@ -639,7 +642,7 @@ int omh_launch_attn_w64(const omh_attn_args& a, hipStream_t stream);
 // per call — the tests flip it inside one process; a getenv is ~50 ns against ~3.5 us of launch).
 struct AttnChoice { bool w64, pp; };
 static AttnChoice attn_choice(const omh_attn_args& a) {
-    const char* force = getenv("OMH_ATTN_KERNEL");
+    const char* force = omh_opt(OMH_OPT_ATTN_KERNEL);
     const int q_tiles2 = (a.Lq + QB2 - 1) / QB2;
     // long sequences that fill the chip with 256-row workgroups take the 4 x 64 kernel (attention_w64.hip); "pp" keeps
     // the 8-wave kernel it replaced selectable for A/B timing
@@ -648,7 +651,7 @@ static AttnChoice attn_choice(const omh_attn_args& a) {
     const bool fits32 = ((int64_t)a.Lq * a.q_rs * 2 < 0x7fffffffLL) && ((int64_t)a.Lk * a.k_rs * 2 < 0x7fffffffLL) &&
                         ((int64_t)a.Lq * a.o_rs * 2 < 0x7fffffffLL) && ((int64_t)D * a.ldv * 2 < 0x7fffffffLL);
     AttnChoice c;
-    const bool short_only = a.o32 || (a.flags & OMH_ATTN_SHORT_KERNEL);                    // fp32 output: base kernel only
+    const bool short_only = a.o32 || a.q_lens || (a.flags & OMH_ATTN_SHORT_KERNEL);        // fp32 output / q_lens: base kernel only
     c.w64 = short_only ? false : (force ? (force[0] == 'w' && fits32) : (big && fits32));
     c.pp = short_only ? false : (force ? (force[0] == 'p') : (big && !c.w64));
     return c;
@@ -658,8 +661,8 @@ static OmhSplitPlan base_split_plan(const omh_attn_args& a) {
     const int q_tiles = (a.Lq + QB - 1) / QB;
     const int nwg = q_tiles * a.H * a.B;
     OmhSplitPlan none = {nwg, 0, 1};
-    const char* e = getenv("OMH_ATTN_SPLIT");                      // "0": never split (A/B timing; tests flip it in-process)
-    if (!(a.flags & OMH_ATTN_ALLOW_SPLIT) || (e && e[0] == '0')) return none;
+    const char* e = omh_opt(OMH_OPT_ATTN_SPLIT);                      // "0": never split (A/B timing; tests flip it in-process)
+    if (!(a.flags & OMH_ATTN_ALLOW_SPLIT) || a.q_lens || (e && e[0] == '0')) return none;
     // measured at one clip x 1560 keys: 32.1 -> 24.8 us + 12.8 us of combine (the workers' fp32 results + the bf16 / fp32 /
     // lse outputs are all HBM traffic): the forward's split only pays on long key loops — 16 key tiles per worker, and
     // only launches that do not fill the chip once.  OMH_ATTN_SPLIT=tail: 4 tiles per worker, any launch (tests, A/B).

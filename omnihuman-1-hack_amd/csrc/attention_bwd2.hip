@@ -529,7 +529,7 @@ static OmhSplitPlan bwd2_plan(const omh_attn_bwd_args& a, bool dq) {
     const int blocks = dq ? (a.Lq + 127) / 128 : (a.Lk + 127) / 128;
     const int nwg = blocks * a.H * a.B;
     OmhSplitPlan none = {nwg, 0, 1};
-    const char* e = getenv("OMH_ATTN_SPLIT");                      // "0": never split (A/B timing; tests flip it in-process)
+    const char* e = omh_opt(OMH_OPT_ATTN_SPLIT);                      // "0": never split (A/B timing; tests flip it in-process)
     if (e && e[0] == '0') return none;
     // OMH_ATTN_SPLIT=tail: also the last round of a launch that fills the chip (measured: no gain, omh_common.h)
     const bool tail = e && e[0] == 't';

@@ -183,7 +183,7 @@ int launch_cw64(const omh_conv_args& a, int64_t M, hipStream_t s) {
     // One workgroup per CU walks the tiles (no re-launch between a CU's tiles: +1-2 % on every layer, one box, interleaved:
     // 794 -> 784 us at 96 channels, 735 -> 722 at 192, whole decode 255.6 -> 258.3 frames/s); OMH_CONV_PERSIST=0: one
     // workgroup per tile (A/B timing).
-    const char* pe = getenv("OMH_CONV_PERSIST");
+    const char* pe = omh_opt(OMH_OPT_CONV_PERSIST);
     int grid = tiles_m * tiles_n;
     if (!(pe && pe[0] == '0')) {
         static int cus = 0;
@@ -208,7 +208,7 @@ bool omh_conv_w64_takes(const omh_conv_args& a) {
     const int64_t M = (int64_t)a.Tout * a.Hout * a.Wout;
     const int es = a.out_f32 ? 4 : 2;
     const int up = a.up2 ? 1 : 0;                            // (round 3: also through the folded nearest-2x upsample)
-    if (up) { const char* ue = getenv("OMH_CONV_W64_UP2"); if (ue && ue[0] == '0') return false; }   // A/B timing
+    if (up) { const char* ue = omh_opt(OMH_OPT_CONV_W64_UP2); if (ue && ue[0] == '0') return false; }   // A/B timing
     return a.KW == 3 && a.KH == 3 && (a.KT == 3 || a.KT == 1) && a.stride_hw == 1 && a.stride_t == 1 &&
            a.pad_h == 1 && a.pad_w == 1 && a.Hout == (a.Hin << up) && a.Wout == (a.Win << up) && (a.Cin & 31) == 0 && a.split_n == 0 &&
            a.Wout >= 3 && (a.Cout == 96 || a.Cout % 192 == 0) && a.KT * 3 * (a.Cin >> 5) >= 15 &&

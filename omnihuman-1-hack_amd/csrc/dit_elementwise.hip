@@ -9,6 +9,9 @@
 //   patchify/unpatchify :463,515-518 / :565-588
 //   dense_f32, sinusoid :17-27, 469-471, 526-528
 #include "omh_common.h"
+#include <mutex>
+#include <stdio.h>
+#include <string.h>
 #include <stdlib.h>
 
 namespace {
@@ -361,7 +364,7 @@ extern "C" int omh_layernorm_modulate(const float* x, void* y, int64_t rows, int
     // with a handful of waves.  Measured alone (us at 1536 columns, 1 / 2 / 4 rows per wave; tools/ln_rpw_probe.py):
     // 1 560 rows 6.6 / 7.7 / 10.9, 3 120 rows 8.0 / 8.8 / 11.4, 6 240 rows 19.4 / 16.3 / 17.5, 24 960 rows 69 / 58 / 52.
     // OMH_LN_RPW = 1 / 2 / 4 forces it (timing).  Same per-row arithmetic: same bits.
-    const char* force = getenv("OMH_LN_RPW");
+    const char* force = omh_opt(OMH_OPT_LN_RPW);
     int rpw = rows <= 4096 ? 1 : (rows < 16384 ? 2 : 4);
     if (force) rpw = atoi(force) == 1 ? 1 : (atoi(force) == 2 ? 2 : 4);
 #define OMH_LN_PICK(MV) (rpw == 1 ? layernorm_modulate_kernel<MV, 1> : (rpw == 2 ? layernorm_modulate_kernel<MV, 2> : layernorm_modulate_kernel<MV, 4>))
@@ -490,17 +493,85 @@ extern "C" int omh_cfg_unipc_step(const float* cond, const float* uncond, const 
     return omh_launch_status();
 }
 
-static int g_deterministic = -1;                                     // -1: not read from the environment yet
-bool omh_deterministic() {
-    if (g_deterministic < 0) {
+// ---------------------------------------------------------------------------------------------------------------------
+// Process options (omh_common.h).  g_opt_val[i][0] == 0: unset.  The table is filled from the environment once.
+namespace {
+const char* const g_opt_name[OMH_OPT_COUNT] = {
+#define X(n) #n,
+    OMH_OPTIONS(X)
+#undef X
+};
+char g_opt_val[OMH_OPT_COUNT][48];
+char g_opt_env[OMH_OPT_COUNT][48];                                   // what the environment said (omh_set_option(NULL, NULL) restores it)
+int g_deterministic = 0, g_deterministic_env = 0;
+std::once_flag g_opt_once;
+
+void opt_store(char* dst, const char* v) {
+    size_t n = v ? strlen(v) : 0;
+    if (n > 47) n = 47;
+    if (n) memcpy(dst, v, n);
+    dst[n] = 0;
+}
+void opt_init() {
+    std::call_once(g_opt_once, [] {
+        char name[64];
+        for (int i = 0; i < OMH_OPT_COUNT; ++i) {
+            snprintf(name, sizeof name, "OMH_%s", g_opt_name[i]);
+            opt_store(g_opt_env[i], getenv(name));
+            opt_store(g_opt_val[i], g_opt_env[i]);
+        }
         const char* e = getenv("OMH_DETERMINISTIC");
-        g_deterministic = (e && e[0] == '1') ? 1 : 0;
+        g_deterministic = g_deterministic_env = (e && e[0] == '1') ? 1 : 0;
+    });
+}
+int opt_index(const char* key) {
+    if (!key) return -1;
+    if (!strncmp(key, "OMH_", 4)) key += 4;
+    for (int i = 0; i < OMH_OPT_COUNT; ++i)
+        if (!strcmp(key, g_opt_name[i])) return i;
+    return -1;
+}
+}  // namespace
+
+const char* omh_opt(int id) {
+    opt_init();
+    return g_opt_val[id][0] ? g_opt_val[id] : nullptr;
+}
+extern "C" int omh_set_option(const char* key, const char* value) {
+    opt_init();
+    if (!key) {                                                      // (NULL, NULL): back to what the environment said at start-up
+        if (value) return OMH_E_BADARG;
+        for (int i = 0; i < OMH_OPT_COUNT; ++i) opt_store(g_opt_val[i], g_opt_env[i]);
+        g_deterministic = g_deterministic_env;
+        return 0;
     }
+    if (!strcmp(key, "DETERMINISTIC") || !strcmp(key, "OMH_DETERMINISTIC")) {
+        g_deterministic = (value && value[0] == '1') ? 1 : 0;
+        return 0;
+    }
+    const int i = opt_index(key);
+    if (i < 0) return OMH_E_BADARG;
+    if (value && strlen(value) > 47) return OMH_E_SHAPE;
+    opt_store(g_opt_val[i], value);
+    return 0;
+}
+extern "C" const char* omh_get_option(const char* key) {
+    opt_init();
+    if (key && (!strcmp(key, "DETERMINISTIC") || !strcmp(key, "OMH_DETERMINISTIC"))) return g_deterministic ? "1" : nullptr;
+    const int i = opt_index(key);
+    return i < 0 ? nullptr : omh_opt(i);
+}
+extern "C" int omh_option_count(void) { return OMH_OPT_COUNT; }
+extern "C" const char* omh_option_name(int i) { return (i >= 0 && i < OMH_OPT_COUNT) ? g_opt_name[i] : nullptr; }
+
+bool omh_deterministic() {
+    opt_init();
     return g_deterministic == 1;
 }
 extern "C" int omh_set_deterministic(int on) {
+    opt_init();
     if (on >= 0) g_deterministic = on ? 1 : 0;
-    return omh_deterministic() ? 1 : 0;
+    return g_deterministic;
 }
 
 extern "C" int omh_abi_version(void) { return OMH_ABI_VERSION; }

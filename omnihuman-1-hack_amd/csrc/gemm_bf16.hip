@@ -411,7 +411,7 @@ int launch_cfg(const omh_gemm_args& a, hipStream_t s) {
     g.tiles_n = (a.N + BN - 1) / BN;
     // m-tiles walked together by one XCD: as many A panels (BM x K bf16) as stay resident in ~3 MiB of its 4 MiB
     // L2 while the n-tiles stream past (measured: 4 at K=1536 and 2 at K>=6144 beat the former fixed 8 by 2-4 %)
-    static const char* gme = getenv("OMH_GEMM_GROUP_M");
+    const char* gme = omh_opt(OMH_OPT_GEMM_GROUP_M);
     const int fit = (int)(3200000LL / ((int64_t)BM * a.K * 2));
     g.group_m = gme ? atoi(gme) : (fit < 2 ? 2 : (fit > 8 ? 8 : fit));
     dim3 grid(g.tiles_m * g.tiles_n, 1, a.batch);
@@ -447,7 +447,7 @@ int launch(const omh_gemm_args& a, hipStream_t s) {
     // 10-38 % slower on 11 of the 28 shapes probed, all of them in the training step and the S = 1560 forward.
     const int64_t big_tiles = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) * a.batch;
     const int64_t mid_tiles = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
-    const char* force = getenv("OMH_GEMM_TILE");               // "big" / "small" / "tiny": test / benchmarking override
+    const char* force = omh_opt(OMH_OPT_GEMM_TILE);               // "big" / "small" / "tiny": test / benchmarking override
     if (force) {
         if (force[0] == 'm' && !BKM) return launch_cfg<EPI, 2, 4, 3, 2, 2, false>(a, s);      // "mid192"
         if (force[0] == 'b') return launch_cfg<EPI, 2, 4, 4, 2, 2, BKM>(a, s);
@@ -456,7 +456,7 @@ int launch(const omh_gemm_args& a, hipStream_t s) {
     }
     if (BKM && mid_tiles < 256) return launch_cfg<EPI, 2, 2, 2, 2, 2, BKM>(a, s);   // no 64x64 k-major variant
     if (mid_tiles < 256) return launch_cfg<EPI, 2, 2, 1, 1, 2>(a, s);
-    static const char* rule = getenv("OMH_GEMM_RULE");         // "old": the former rule, for A/B timing on one box
+    const char* rule = omh_opt(OMH_OPT_GEMM_RULE);         // "old": the former rule, for A/B timing on one box
     if (rule && rule[0] == 'o')
         return big_tiles >= 256 ? launch_cfg<EPI, 2, 4, 4, 2, 2, BKM>(a, s) : launch_cfg<EPI, 2, 2, 2, 2, 2, BKM>(a, s);
     float cost_big, cost_small;
@@ -539,7 +539,7 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
     if (((int64_t)a.M + 128) * a.lda * 2 >= 0x7fffffffLL || ((int64_t)a.N + 128) * a.ldb * 2 >= 0x7fffffffLL)
         return OMH_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    if (a.workspace && !getenv("OMH_GEMM_TILE") && !getenv("OMH_GEMM_KERNEL")) {
+    if (a.workspace && !omh_opt(OMH_OPT_GEMM_TILE) && !omh_opt(OMH_OPT_GEMM_KERNEL)) {
         // few rows, long contraction (M = 1 560 / 3 120 against K = 8 960): the contraction in slices on the 256 x 192
         // stream, then one combine launch (gemm_w64.hip).  Only with a workspace of the size the query below returns.
         const int S = omh_gemm_splitk_slices(a);
@@ -553,26 +553,26 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
     {
         // OMH_GEMM_KERNEL = "w64": the 256 x 384 stream kernel wherever it applies; "8w": never; unset: where it
         // applies AND fills the chip (>= 256 tiles, last round of tiles at least 3/4 full or >= 4 rounds)
-        const char* gk = getenv("OMH_GEMM_KERNEL");
+        const char* gk = omh_opt(OMH_OPT_GEMM_KERNEL);
         // (the fused training epilogues stay on the 8-wave kernels — except GELU_BWD, which the big stream has, and the
         // out-of-place / aux-writing gated residual, which the 256 x 192 stream has)
         // GELU_BWD on the 256 x 384 stream: built and bit-identical (test_gemm_w64_gelu_backward_stream), but measured EQUAL
         // to the 8-wave kernel in isolation (6240 x 8960 x 1536: 204-225 vs 202-208 us; 1560 rows 58 vs 56-62) — the 357 us
         // the 8-wave kernel shows inside a training step is the weight-gradient stream sharing the chip, not the kernel.
         // Opt-in: OMH_GEMM_W64_GBWD=1.
-        const char* gbwd = getenv("OMH_GEMM_W64_GBWD");
+        const char* gbwd = omh_opt(OMH_OPT_GEMM_W64_GBWD);
         // GELU + pre-activation to aux (the FFN-up projection of a training forward, ABI v5) on the 256 x 384 stream
         // ("geluaux": bit-identical, test_gemm_w64_gelu_stream_with_the_pre_activation); OMH_GEMM_W64_GAUX=0: 8-wave kernels
-        const char* gaux = getenv("OMH_GEMM_W64_GAUX");
+        const char* gaux = omh_opt(OMH_OPT_GEMM_W64_GAUX);
         const bool gelu_aux = a.epilogue == OMH_EPI_GELU_BF16 && a.aux && !a.c_in && !(gaux && gaux[0] == '0');
         const bool v5_8w = v5 && !gelu_aux && !(a.epilogue == OMH_EPI_GELU_BWD_BF16 && !a.c_in && gbwd && gbwd[0] == '1');
-        const bool force = gk && gk[0] == 'w', never = v5_8w || (gk && gk[0] == '8') || (!force && getenv("OMH_GEMM_TILE"));
+        const bool force = gk && gk[0] == 'w', never = v5_8w || (gk && gk[0] == '8') || (!force && omh_opt(OMH_OPT_GEMM_TILE));
         // gated residual with a short contraction (o-projections: K = dim): the 256 x 192 stream that requests the old C
         // tile during its k loop.  OMH_GEMM_W64_R192 = 0 / 1 forces it off / on (A/B timing, tests).
         {
-            const char* r192 = getenv("OMH_GEMM_W64_R192");
+            const char* r192 = omh_opt(OMH_OPT_GEMM_W64_R192);
             const bool off = r192 && r192[0] == '0', on = r192 && r192[0] == '1';
-            const bool never192 = (gk && gk[0] == '8') || (!force && getenv("OMH_GEMM_TILE"));
+            const bool never192 = (gk && gk[0] == '8') || (!force && omh_opt(OMH_OPT_GEMM_TILE));
             if (!never192 && !off && omh_gemm_w64_r192_takes(a)) {          // (also the training epilogues: c_in, aux)
                 // measured (round 4, one box, R192 = 0 / 1): 32760 x 1536 x 1536 206 -> 186 us, 21840 rows 148 -> 119,
                 // 6240 rows 51 -> 39 (K = 8960: 177 -> 151), 3120 rows 33.5 -> 35.4 (too few tiles), 32760 x 1536 x 8960
@@ -593,7 +593,7 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
         // EQUAL to the 8-wave kernel (144-159 vs 141-149 us: 24 k steps per tile do not amortise the stream's per-tile
         // cost, and the tail is a second launch): opt-in, OMH_GEMM_W64_BF16M = 1.
         {
-            const char* bm = getenv("OMH_GEMM_W64_BF16M");
+            const char* bm = omh_opt(OMH_OPT_GEMM_W64_BF16M);
             const bool on = bm && bm[0] == '1', off = !on;
             if (!never && !off && omh_gemm_w64_bf16m_takes(a)) {
                 const int tm = (a.M + 255) / 256, tn = (a.N + 383) / 384;
@@ -618,7 +618,7 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
         // plain fp32 / bf16 products too small for the 256 x 384 stream (< 128 of its tiles) but with 160 .. 256 tiles
         // of 256 x 192: one round of the narrow stream (OMH_GEMM_W64_N192 = 0 / 1: off / wherever it applies)
         {
-            const char* n192 = getenv("OMH_GEMM_W64_N192");
+            const char* n192 = omh_opt(OMH_OPT_GEMM_W64_N192);
             const bool off = n192 && n192[0] == '0', on = n192 && n192[0] == '1';
             if (!never && !off && omh_gemm_w64_n192_takes(a)) {
                 const int64_t t192 = (int64_t)((a.M + 255) / 256) * ((a.N + 191) / 192);
@@ -657,7 +657,7 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
 
 extern "C" int64_t omh_gemm_workspace_bytes(const omh_gemm_args* args) {
     if (!args || !args->A || !args->B || !args->C || args->M <= 0 || args->N <= 0 || args->K <= 0) return 0;
-    if (getenv("OMH_GEMM_TILE") || getenv("OMH_GEMM_KERNEL")) return 0;     // a forced kernel family: no slices
+    if (omh_opt(OMH_OPT_GEMM_TILE) || omh_opt(OMH_OPT_GEMM_KERNEL)) return 0;     // a forced kernel family: no slices
     if ((args->K & 7) || (args->lda & 7) || (args->ldb & 7) || ((uintptr_t)args->A & 15) || ((uintptr_t)args->B & 15)) return 0;
     return omh_gemm_splitk_workspace(*args);
 }

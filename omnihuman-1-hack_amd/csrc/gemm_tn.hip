@@ -241,7 +241,7 @@ int launch_tn(const omh_gemm_tn_args& a, hipStream_t s) {
     const int nk = (a.K + BK - 1) / BK;
     const int slots = (BM == 256) ? 256 : 512;                       // resident workgroups on the chip
     const int tiles = g.tiles_m * g.tiles_n;
-    const char* spe = getenv("OMH_GEMM_TN_SPLIT");                    // forced split count (tests / timing)
+    const char* spe = omh_opt(OMH_OPT_GEMM_TN_SPLIT);                    // forced split count (tests / timing)
     // split only when the tiles leave at least half the chip idle (more splits measured slower: 1536^2 x 6240 60 us
     // with 3, 77 with 4; 3072 x 1536 97 us unsplit, 125 with 2 — the atomics and the zero fill cost more than they win)
     int splits = spe ? atoi(spe) : (tiles * 2 <= slots ? slots / tiles : 1);
@@ -266,7 +266,7 @@ int64_t omh_gemm_tn_w64_tiles(const omh_gemm_tn_args& a);
 int omh_launch_gemm_tn_w64(omh_gemm_tn_group g, hipStream_t stream);
 // OMH_GEMM_TN_W64=0: never the stream kernel (A/B timing and the bit-equality tests); =1: whenever it takes the shapes
 static int tn_w64_mode() {
-    const char* e = getenv("OMH_GEMM_TN_W64");
+    const char* e = omh_opt(OMH_OPT_GEMM_TN_W64);
     return e ? atoi(e) : -1;
 }
 
@@ -289,7 +289,7 @@ extern "C" int omh_gemm_bf16_tn(const omh_gemm_tn_args* args, omh_stream_t strea
         }
     }
     const int64_t big_tiles = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256);
-    const char* force = getenv("OMH_GEMM_TN_TILE");                  // "big" / "small": test override
+    const char* force = omh_opt(OMH_OPT_GEMM_TN_TILE);                  // "big" / "small": test override
     const bool big = force ? force[0] == 'b' : big_tiles >= 128;
     if (big) return a.accumulate ? launch_tn<true, 2, 4, 4, 2>(a, s) : launch_tn<false, 2, 4, 4, 2>(a, s);
     return a.accumulate ? launch_tn<true, 2, 2, 2, 2>(a, s) : launch_tn<false, 2, 2, 2, 2>(a, s);
@@ -321,7 +321,7 @@ extern "C" int omh_gemm_bf16_tn_grouped(const omh_gemm_tn_group* group, omh_stre
     }
     int64_t total_big = 0;
     for (int i = 0; i < g.n; ++i) total_big += (int64_t)((g.problem[i].M + 255) / 256) * ((g.problem[i].N + 255) / 256);
-    const char* te = getenv("OMH_GEMM_TN_GROUP_TILE");               // "big" / "small": test / timing override
+    const char* te = omh_opt(OMH_OPT_GEMM_TN_GROUP_TILE);               // "big" / "small": test / timing override
     // measured (one box, interleaved, whole training step): 85.2 ms with 128 x 128 tiles, 86.5 with 256 x 256 at 4 clips
     // (43.5 / 45.2 at 1 clip) — one workgroup per CU shares the chip worse with the main stream's kernels — so: opt-in only
     const bool big = te ? te[0] == 'b' : false;

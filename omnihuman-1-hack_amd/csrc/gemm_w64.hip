@@ -343,7 +343,7 @@ omh_gemm_args splitk_partial(const omh_gemm_args& a, int S, void* ws) {
 // Number of slices omh_gemm_bf16 cuts this product's contraction into when it is handed a workspace (1: none).
 // OMH_GEMM_SPLITK = 0 switches the path off (A/B timing, tests).
 int omh_gemm_splitk_slices(const omh_gemm_args& a) {
-    const char* e = getenv("OMH_GEMM_SPLITK");
+    const char* e = omh_opt(OMH_OPT_GEMM_SPLITK);
     if (e && e[0] == '0') return 1;
     if (a.batch != 1 || a.b_kmajor || !(a.epilogue == OMH_EPI_RESID || a.epilogue == OMH_EPI_F32)) return 1;
     if (a.bias && a.bias_mode != OMH_BIAS_N) return 1;

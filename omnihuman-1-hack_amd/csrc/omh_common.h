@@ -5,6 +5,24 @@
 
 #include "../../include/omh.h"
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Process options (ABI v10, include/omh.h: omh_set_option / omh_get_option).  Every dispatch switch of the library —
+// kernel-family overrides for tests and A/B timing — lives in ONE table.  The environment is consulted exactly once per
+// process (the first omh_opt() / omh_set_option() call: variable OMH_<NAME> seeds option <NAME>); after that the launch
+// path never calls getenv and a switch changes only through omh_set_option().  omh_opt() returns NULL for an unset option.
+#define OMH_OPTIONS(X)                                                                                                   \
+    X(ATTN_KERNEL) X(ATTN_SPLIT) X(W64_SPLIT) X(W64_VARIANT) X(CONV_PERSIST) X(CONV_W64_UP2) X(LN_RPW) X(GEMM_GROUP_M)    \
+    X(GEMM_TILE) X(GEMM_RULE) X(GEMM_KERNEL) X(GEMM_W64_GBWD) X(GEMM_W64_GAUX) X(GEMM_W64_R192) X(GEMM_W64_BF16M)        \
+    X(GEMM_W64_N192) X(GEMM_TN_SPLIT) X(GEMM_TN_W64) X(GEMM_TN_TILE) X(GEMM_TN_GROUP_TILE) X(GEMM_SPLITK) X(CONV_TILE)   \
+    X(CONV_WIDE_MIN) X(CONV_W64) X(CONV_FUSE_NORM) X(CONV_KW3) X(GEMM_QKV) X(GEMM_W64_R256) X(CONV_EPI)
+enum OmhOpt {
+#define X(n) OMH_OPT_##n,
+    OMH_OPTIONS(X)
+#undef X
+    OMH_OPT_COUNT
+};
+const char* omh_opt(int id);
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;

@@ -708,18 +708,18 @@ static ConvRoute conv_route(const omh_conv_args& a) {
     // call): the kernel choice — and with it the accumulation order of every output value — then depends on the layer
     // only, not on how many frames a call carries, so a prefix of a clip decodes / encodes bit for bit like the
     // whole clip's first frames (tests/test_gpu_config5.py).
-    const char* force = getenv("OMH_CONV_TILE");                     // "wide" / "small": test / benchmarking override
+    const char* force = omh_opt(OMH_OPT_CONV_TILE);                     // "wide" / "small": test / benchmarking override
     const bool narrow = a.Cout <= 96;
     const int64_t Mn = (int64_t)2 * a.Hout * a.Wout;
     const int64_t wide_tiles = narrow ? (Mn + 511) / 512 : ((Mn + 255) / 256) * ((a.Cout + 191) / 192);
-    const char* wmin = getenv("OMH_CONV_WIDE_MIN");                  // A/B timing of the threshold
+    const char* wmin = omh_opt(OMH_OPT_CONV_WIDE_MIN);                  // A/B timing of the threshold
     bool wide = wide_tiles >= (wmin ? atoi(wmin) : 96);              // e.g. 384 channels at 60 x 104: 98
     if (force && force[0] == 'w') wide = true;
     if (force && force[0] == 's') wide = false;
     if (((uintptr_t)a.resid & 15) || ((uintptr_t)a.bias & 3)) wide = false;
     // the residual-block convolutions: the one-wave-per-SIMD stream kernel (same values as the kw-shared 8-wave
     // kernel).  OMH_CONV_TILE=w64 forces it wherever it applies, wide / small exclude it, OMH_CONV_W64=0 turns it off.
-    const char* w64e = getenv("OMH_CONV_W64");
+    const char* w64e = omh_opt(OMH_OPT_CONV_W64);
     const bool w64_forced = force && force[0] == 'w' && force[1] == '6';
     const bool w64_ok = !(w64e && w64e[0] == '0') && (w64_forced || (!force && wide));
     const bool w64 = w64_ok && omh_conv_w64_takes(a);
@@ -748,7 +748,7 @@ extern "C" int omh_conv_cl_bf16(const omh_conv_args* args, omh_stream_t stream) 
         // channels of a voxel (Cout = 96), as a second launch over y otherwise — the two write the same values
         if (!a.norm_out || a.split_n > 0) return OMH_E_BADARG;
         if (((uintptr_t)a.norm_out & 15) || ((uintptr_t)a.norm_gamma & 3)) return OMH_E_ALIGN;
-        const char* fe = getenv("OMH_CONV_FUSE_NORM");                // "0": never fused (tests / A/B timing)
+        const char* fe = omh_opt(OMH_OPT_CONV_FUSE_NORM);                // "0": never fused (tests / A/B timing)
         if (!(route.w64 && a.Cout == 96 && !(fe && fe[0] == '0'))) {
             omh_conv_args b = a;
             b.norm_gamma = nullptr; b.norm_out = nullptr; b.norm_only = 0;
@@ -763,7 +763,7 @@ extern "C" int omh_conv_cl_bf16(const omh_conv_args* args, omh_stream_t stream) 
     if (wide) {
         hipStream_t s = (hipStream_t)stream;
         // 3x3 "same" convolutions with stride 1 at >= 32 channels: the kw-shared kernel (3x less voxel traffic)
-        const char* kw3e = getenv("OMH_CONV_KW3");                     // "0": off (tests / A/B timing)
+        const char* kw3e = omh_opt(OMH_OPT_CONV_KW3);                     // "0": off (tests / A/B timing)
         const bool kw3 = !(kw3e && kw3e[0] == '0') && a.KW == 3 && a.KH == 3 && (a.KT == 3 || a.KT == 1) &&
                          a.stride_hw == 1 && a.stride_t == 1 && !a.up2 && a.pad_h == 1 && a.pad_w == 1 &&
                          a.Hout == a.Hin && a.Wout == a.Win && (a.Cin & 31) == 0 && a.split_n == 0 && a.Wout >= 3;

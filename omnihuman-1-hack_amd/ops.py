@@ -118,12 +118,47 @@ def gemm_tn_grouped(problems):
         check(lib.omh_gemm_bf16_tn_grouped(C.byref(g), _stream()), "omh_gemm_bf16_tn_grouped")
 
 
+def set_option(key, value=None):
+    """A dispatch switch of libomh.so (include/omh.h, omh_set_option): ``value`` None unsets it.  The library reads the
+    environment once, at its first call; from then on this is the only way to change a switch (tests, A/B timing)."""
+    check(lib.omh_set_option(key.encode(), None if value is None else str(value).encode()), f"omh_set_option({key})")
+
+
+def get_option(key):
+    v = lib.omh_get_option(key.encode())
+    return None if v is None else v.decode()
+
+
+def reset_options():
+    """Every option back to what the environment said when the library was first called."""
+    check(lib.omh_set_option(None, None), "omh_set_option(NULL)")
+
+
+class options:
+    """``with ops.options(GEMM_KERNEL="8w", GEMM_TILE=None): ...`` — set, run, restore."""
+
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
+
+
 def flash_attn_raw(q, k, vt, o, k_lens, B, H, Lq, Lk, q_bs, q_rs, k_bs, k_rs, vt_bs, o_bs, o_rs, ldv, scale,
-                   lse=None, q_prescaled=0, o32=None, flags=0):
+                   lse=None, q_prescaled=0, o32=None, flags=0, q_lens=None):
     """``flags``: ATTN_SHORT_KERNEL | ATTN_ALLOW_SPLIT (include/omh.h, ABI v8): the training step pins the short-sequence
-    kernel (forward and re-run take the same one) and lets it split its last round of workgroups over the keys."""
+    kernel (forward and re-run take the same one) and lets it split its last round of workgroups over the keys.
+    ``q_lens`` (ABI v10): int32 [B] device pointer; output rows past a sample's query length are written as zero."""
     a = AttnArgs(q, k, vt, o, k_lens, B, H, Lq, Lk, q_bs, q_rs, k_bs, k_rs, vt_bs, o_bs, o_rs, ldv, scale, lse,
-                 int(q_prescaled), None, 0, o32, int(flags))
+                 int(q_prescaled), None, 0, o32, int(flags), q_lens)
     need = lib.omh_flash_attn_workspace_bytes(C.byref(a))          # split-KV tail (long-sequence kernel; short one if allowed)
     ws = None
     if need > 0:
@@ -133,10 +168,12 @@ def flash_attn_raw(q, k, vt, o, k_lens, B, H, Lq, Lk, q_bs, q_rs, k_bs, k_rs, vt
 
 
 def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, k_lens: Optional[torch.Tensor] = None,
-               scale: Optional[float] = None, out: Optional[torch.Tensor] = None):
+               scale: Optional[float] = None, out: Optional[torch.Tensor] = None, q_lens: Optional[torch.Tensor] = None):
     """q [B,Lq,H,128], k [B,Lk,H,128] bf16; vt [B,H*128,ldv] bf16 (V transposed,
-    ldv >= roundup(Lk,64)); k_lens int32 [B] or None.  Returns [B,Lq,H,128] bf16."""
-    _dev(q, k, vt, k_lens, out)
+    ldv >= roundup(Lk,64)); k_lens / q_lens int32 [B] or None.  Returns [B,Lq,H,128] bf16 (rows past q_lens: zero)."""
+    _dev(q, k, vt, k_lens, out, q_lens)
+    if q_lens is not None:
+        assert q_lens.dtype == torch.int32 and q_lens.numel() == q.shape[0]
     B, Lq, H, D = q.shape
     Lk = k.shape[1]
     assert D == 128 and k.shape == (B, Lk, H, D) and vt.shape[0] == B and vt.shape[1] == H * D
@@ -148,7 +185,7 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, k_lens: Optio
         out = torch.empty(B, Lq, H, D, dtype=torch.bfloat16, device=q.device)
     flash_attn_raw(_p(q), _p(k), _p(vt), _p(out), _p(k_lens), B, H, Lq, Lk, q.stride(0), q.stride(1), k.stride(0),
                    k.stride(1), vt.stride(0), out.stride(0), out.stride(1), vt.stride(1),
-                   float(scale if scale is not None else D ** -0.5))
+                   float(scale if scale is not None else D ** -0.5), q_lens=_p(q_lens))
     return out
 
 

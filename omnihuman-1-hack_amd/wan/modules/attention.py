@@ -4,8 +4,8 @@
 
 The reference packs variable-length sequences and calls flash-attn's varlen
 kernel; the result is softmax(q k^T * scale) v per head over the first
-``k_lens[b]`` keys of each sample, for every one of the Lq query rows
-(``q_lens`` is never passed by model.py).  This wrapper keeps that contract
+``k_lens[b]`` keys of each sample, for every one of the first ``q_lens[b]``
+query rows (rows past it are zero; ``q_lens`` is never passed by model.py).  This wrapper keeps that contract
 for head_dim 128.  The DiT blocks do not go through it (they hand the kernel
 pre-laid-out q / k / V^T buffers); it exists for callers of the reference API.
 """
@@ -21,9 +21,11 @@ def flash_attention(q, k, v, q_lens=None, k_lens=None, dropout_p=0., softmax_sca
     """q [B, Lq, N, 128], k/v [B, Lk, N, 128]; returns [B, Lq, N, 128] in q's dtype."""
     assert dtype in (torch.float16, torch.bfloat16)
     assert q.device.type == "cuda" and q.size(-1) <= 256
-    if q_lens is not None or causal or dropout_p != 0. or tuple(window_size) != (-1, -1):
-        raise NotImplementedError("only the reference's call pattern is built: q_lens=None, non-causal, "
-                                  "no dropout, full window (model.py:151-156,181,221-223)")
+    if causal or dropout_p != 0. or tuple(window_size) != (-1, -1):
+        # the reference forwards these to flash-attn (attention.py:96-127) but no caller in the repository sets them
+        # (model.py:151-156,181,221-223): rejected here rather than silently ignored (INTEGRATION.md)
+        raise NotImplementedError("flash_attention on gfx950: causal / window_size / dropout_p are not built "
+                                  "(no caller in the reference uses them); q_lens and k_lens are")
     B, Lq, N, D = q.shape
     Lk = k.shape[1]
     if D != 128:
@@ -37,7 +39,10 @@ def flash_attention(q, k, v, q_lens=None, k_lens=None, dropout_p=0., softmax_sca
     vt = torch.zeros(B, N * D, Lp, dtype=torch.bfloat16, device=q.device)
     vt[:, :, :Lk] = v.to(torch.bfloat16).reshape(B, Lk, N * D).transpose(1, 2)   # layout change only
     kl = None if k_lens is None else k_lens.to(device=q.device, dtype=torch.int32).contiguous()
-    o = ops.flash_attn(qb, kb, vt, kl, scale=softmax_scale)
+    # q_lens (attention.py:55-60,79): the reference cuts the queries past q_lens[b] out of the packed batch — and can only
+    # un-flatten the result when every q_lens[b] == Lq (attention.py:110); here those rows come back as zeros
+    ql = None if q_lens is None else q_lens.to(device=q.device, dtype=torch.int32).contiguous()
+    o = ops.flash_attn(qb, kb, vt, kl, scale=softmax_scale, q_lens=ql)
     return o.type(out_dtype)
 
 

@@ -538,7 +538,7 @@ class WanModel(nn.Module):
         # False (default): products with few rows and a long contraction — the FFN-down projection at one or two
         # [16,1,60,104] clips — are summed in 2-4 k slices (ABI v9), so a sample's last bits depend on how many samples
         # share its forward (a clip alone, in a CFG pair, in a batch of four: 4 / 2 / no slices; 9e-3 between the
-        # guided velocities, where each is 1e-2 from the oracle).  True: every product keeps one summation order
+        # guided velocities, where each is 1e-2 from the fp32 arithmetic).  True: every product keeps one summation order
         # whatever the batch — bit-identical outputs for a sample alone and inside any batch, at the price of the
         # small-M speed-up (15.3 -> 16.1 ms per single-frame CFG pair).  Nothing is split at the sampling sizes
         # (S = 32 760) either way.  ADVICE round 4; pinned by test_batch_invariant_flag_pins_the_summation_order.

@@ -50,3 +50,18 @@ def rel_rms(a, b):
     import torch
     a, b = a.double().cpu(), b.double().cpu()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def set_option(key, value):
+    """Flip a dispatch switch of libomh.so for the running test (include/omh.h: omh_set_option; ``value`` None unsets).
+    The library reads the environment once per process, so the tests change switches through the ABI, not through
+    os.environ; the autouse fixture below restores every switch after each test."""
+    importlib.import_module(PKG + ".ops").set_option(key, value)
+
+
+@pytest.fixture(autouse=True)
+def _restore_library_options():
+    yield
+    mod = sys.modules.get(PKG + ".ops")
+    if mod is not None:
+        mod.reset_options()

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(omh):
         assert hasattr(lib, name), f"{name} declared in include/omh.h but not exported by libomh.so"
     binding = importlib.import_module(PKG + "._lib")
     assert sorted(binding.EXPORTED) == decl, "ctypes signatures out of sync with the header"
-    assert binding.lib.omh_abi_version() == 9 and binding.lib.omh_build_arch() == b"gfx950"
+    assert binding.lib.omh_abi_version() == 10 and binding.lib.omh_build_arch() == b"gfx950"
 
 
 def test_argument_validation_without_gpu(omh):
@@ -424,8 +424,9 @@ def test_gemm_split_k_plan_without_a_gpu(omh, monkeypatch):
     (104), none from four clips on, none for short contractions, other epilogues, forced kernel families, or switched off."""
     import ctypes as C
     binding = importlib.import_module(PKG + "._lib")
+    from conftest import set_option
     for k_ in ("OMH_GEMM_KERNEL", "OMH_GEMM_TILE", "OMH_GEMM_SPLITK"):
-        monkeypatch.delenv(k_, raising=False)
+        set_option(k_, None)
 
     def need(M, N, K, epi=binding.EPI_RESID, **kw):
         a = binding.GemmArgs()
@@ -443,11 +444,45 @@ def test_gemm_split_k_plan_without_a_gpu(omh, monkeypatch):
     assert need(1560, 1536, 8960, epi=binding.EPI_BF16) == 0 and need(1560, 1536, 8960, epi=binding.EPI_F32_ACCUM) == 0
     assert need(1560, 1536, 8960, batch=2) == 0 and need(1560, 1536, 8960, b_kmajor=1) == 0
     assert need(780, 776, 4416) == 3 * 1024 * 776 * 4                    # 69 k tiles: three slices of 23
-    monkeypatch.setenv("OMH_GEMM_SPLITK", "0")
+    set_option("OMH_GEMM_SPLITK", "0")
     assert need(1560, 1536, 8960) == 0
-    monkeypatch.delenv("OMH_GEMM_SPLITK")
-    monkeypatch.setenv("OMH_GEMM_KERNEL", "8w")
+    set_option("OMH_GEMM_SPLITK", None)
+    set_option("OMH_GEMM_KERNEL", "8w")
     assert need(1560, 1536, 8960) == 0
+
+
+def test_options_are_a_table_not_the_environment(omh, monkeypatch):
+    """ABI v10: the dispatch switches live in one table that the library fills from the
+    environment ONCE; after that a changed environment variable is invisible and omh_set_option is the only way in.
+    Unknown keys and over-long values are refused; (NULL, NULL) restores the start-up values."""
+    binding = importlib.import_module(PKG + "._lib")
+    ops = importlib.import_module(PKG + ".ops")
+    lib = binding.lib
+    names = [lib.omh_option_name(i).decode() for i in range(lib.omh_option_count())]
+    assert "GEMM_KERNEL" in names and "ATTN_KERNEL" in names and "CONV_TILE" in names and len(set(names)) == len(names)
+    start = {n: ops.get_option(n) for n in names}
+    monkeypatch.setenv("OMH_GEMM_KERNEL", "8w")                         # the library has been called already: not seen
+    assert ops.get_option("GEMM_KERNEL") == start["GEMM_KERNEL"]
+    ops.set_option("OMH_GEMM_KERNEL", "w64")                            # with or without the prefix
+    assert ops.get_option("GEMM_KERNEL") == "w64"
+    ops.set_option("GEMM_KERNEL", None)
+    assert ops.get_option("OMH_GEMM_KERNEL") is None
+    assert lib.omh_set_option(b"NO_SUCH_SWITCH", b"1") == -1 and lib.omh_get_option(b"NO_SUCH_SWITCH") is None
+    assert lib.omh_set_option(b"GEMM_TILE", b"x" * 48) == -3
+    with ops.options(GEMM_TILE="big", CONV_TILE="w64"):
+        assert ops.get_option("GEMM_TILE") == "big" and ops.get_option("CONV_TILE") == "w64"
+    assert ops.get_option("GEMM_TILE") == start["GEMM_TILE"]
+    ops.set_option("LN_RPW", "2")
+    ops.set_deterministic(True)
+    ops.reset_options()
+    assert {n: ops.get_option(n) for n in names} == start and ops.get_option("DETERMINISTIC") is None
+    # the launch path holds no getenv: the one-time seeding in dit_elementwise.hip is the only call in the sources
+    import glob
+    hits = []
+    for f in glob.glob(os.path.join(ROOT, PKG, "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, PKG, "csrc", "*.h")):
+        src = re.sub(r"//[^\n]*", "", open(f).read())
+        hits += [(os.path.basename(f), m.start()) for m in re.finditer(r"\bgetenv\s*\(", src)]
+    assert len(hits) == 2 and all(h[0] == "dit_elementwise.hip" for h in hits), hits
 
 
 def test_pack_registry_is_keyed_by_parameter_identity(omh, wan_model_mod):

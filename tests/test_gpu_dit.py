@@ -3,7 +3,7 @@
 import pytest
 import torch
 
-from conftest import rel_rms
+from conftest import rel_rms, set_option
 
 pytestmark = pytest.mark.gpu
 
@@ -153,13 +153,13 @@ def test_wan_1_3b_single_frame_cfg_pair():
     e_pair = rel_rms(vt, torch.add(u, c - u, alpha=7.5))
     print(f"[measured] batched teacher pair vs two calls (split K: 2 vs 4 slices): {e_pair:.3e}")
     assert e_pair < TOL_CFG and rel_rms(vt.cpu(), ref) < TOL_CFG
-    os.environ["OMH_GEMM_SPLITK"] = "0"
+    set_option("OMH_GEMM_SPLITK", "0")
     try:
         c0 = m([noise.cuda()], t.cuda(), [cpos.cuda()], 1560)[0]
         u0 = m([noise.cuda()], t.cuda(), [cneg.cuda()], 1560)[0]
         assert torch.equal(trainer.teacher_cfg_velocity(m, noise, t, cpos, cneg, 7.5), torch.add(u0, c0 - u0, alpha=7.5))
     finally:
-        del os.environ["OMH_GEMM_SPLITK"]
+        set_option("OMH_GEMM_SPLITK", None)
 
 
 def test_tiny_i2v_model_matches_oracle_and_reference_vectors(wan_model_mod):

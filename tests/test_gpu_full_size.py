@@ -10,7 +10,7 @@ import math
 import pytest
 import torch
 
-from conftest import rel_rms
+from conftest import rel_rms, set_option
 
 pytestmark = pytest.mark.gpu
 PKG = "omnihuman-1-hack_amd"
@@ -33,7 +33,7 @@ def test_self_attention_full_size(ops, kernel, monkeypatch):
     """One self-attention launch of the benchmark (12 heads x 32 760 x 32 760, D = 128; attention.py:96-127): the
     generated stream kernel the dispatch picks at this size ("w64") and round 1's 8-wave kernel ("pp"); pinned so that
     the query slice of property (4) runs the same kernel."""
-    monkeypatch.setenv("OMH_ATTN_KERNEL", kernel)
+    set_option("OMH_ATTN_KERNEL", kernel)
     torch.manual_seed(5)
     B, H, L, D = 1, 12, S_FULL, 128
     q = _bf(torch.randn(B, L, H, D, device="cuda"))
@@ -453,7 +453,7 @@ def test_self_attention_split_kv_tail_config4(ops, monkeypatch):
     vt = _vt(v, B, L, H, D)
 
     def run(split):
-        monkeypatch.setenv("OMH_W64_SPLIT", split)
+        set_option("OMH_W64_SPLIT", split)
         out = torch.empty(B, L, H, D, dtype=torch.bfloat16, device="cuda")
         lse = torch.empty(B, H, L, dtype=torch.float32, device="cuda")
         ops.flash_attn_raw(ops.ptr(q), ops.ptr(k), ops.ptr(vt), ops.ptr(out), None, B, H, L, L, q.stride(0), q.stride(1),
@@ -485,7 +485,7 @@ def test_vae_convolutions_full_size_stream_kernel_equals_8_wave_kernel(ops, C, T
     rf = torch.randn(T, H, W, C, device="cuda")
 
     def run(tile):
-        monkeypatch.setenv("OMH_CONV_TILE", tile)
+        set_option("OMH_CONV_TILE", tile)
         return (ops.conv_cl(x, wp, bias, T, H, W, C, 3, 3, 3, pad_h=1, pad_w=1),
                 ops.conv_cl(x, wp, bias, T, H, W, C, 3, 3, 3, pad_h=1, pad_w=1, resid=rf, out_f32=True))
 

@@ -5,7 +5,7 @@ import math
 import pytest
 import torch
 
-from conftest import rel_rms
+from conftest import rel_rms, set_option
 
 pytestmark = pytest.mark.gpu
 
@@ -18,7 +18,7 @@ def _bf(x):
                                    (64, 8960, 256), (1000, 1536, 8960)])
 @pytest.mark.parametrize("tile", ["big", "mid192", "small", "tiny"])
 def test_gemm_bf16_f32_bias(ops, M, N, K, tile, monkeypatch):
-    monkeypatch.setenv("OMH_GEMM_TILE", tile)          # all three tile configurations on every (ragged) shape
+    set_option("OMH_GEMM_TILE", tile)          # all three tile configurations on every (ragged) shape
     torch.manual_seed(M * 7 + N)
     a = _bf(torch.randn(M, K, device="cuda"))
     w = _bf(torch.randn(N, K, device="cuda") / math.sqrt(K))
@@ -46,7 +46,7 @@ def test_gemm_asymmetric_layout(ops):
 
 @pytest.mark.parametrize("tile", ["big", "mid192", "small", "tiny"])
 def test_gemm_resid_gate_and_batch(ops, tile, monkeypatch):
-    monkeypatch.setenv("OMH_GEMM_TILE", tile)
+    set_option("OMH_GEMM_TILE", tile)
     B, S, d, K = 2, 200, 256, 320
     torch.manual_seed(1)
     a = _bf(torch.randn(B * S, K, device="cuda"))
@@ -91,7 +91,7 @@ def test_gemm_w64_stream_kernel(ops, M, N, K, gate_rows, monkeypatch):
     ref = a.float() @ w.float().t() + bias
 
     def run(kernel):
-        monkeypatch.setenv("OMH_GEMM_KERNEL", kernel)
+        set_option("OMH_GEMM_KERNEL", kernel)
         x = x0.clone()
         ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(x), M, N, K, K, K, N, ops.EPI_RESID, bias=ops.ptr(bias),
                      bias_mode=ops.BIAS_N, gate0=ops.ptr(mod, 2 * N), gate1=ops.ptr(e0, 2 * N), gate1_stride=6 * N,
@@ -132,7 +132,7 @@ def test_gemm_w64_residual_stream_with_prefetched_c(ops, M, N, K, gate_rows, mon
 
     def run(env):
         for k_, v_ in env.items():
-            monkeypatch.setenv(k_, v_)
+            set_option(k_, v_)
         x = x0.clone()
         ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(x), M, N, K, K, K, N, ops.EPI_RESID, bias=ops.ptr(bias),
                      bias_mode=ops.BIAS_N, gate0=ops.ptr(mod, 2 * N), gate1=ops.ptr(e0, 2 * N), gate1_stride=6 * N,
@@ -166,7 +166,7 @@ def test_gemm_split_k_for_few_row_long_contraction_products(ops, M, N, K, S, gat
     import ctypes as C
     binding, omh = ops._lib, ops.lib
     for k_ in ("OMH_GEMM_KERNEL", "OMH_GEMM_TILE", "OMH_GEMM_SPLITK"):
-        monkeypatch.delenv(k_, raising=False)
+        set_option(k_, None)
     torch.manual_seed(M + N + K)
     a = _bf(torch.randn(M, K, device="cuda"))
     w = _bf(torch.randn(N, K, device="cuda") / math.sqrt(K))
@@ -191,7 +191,7 @@ def test_gemm_split_k_for_few_row_long_contraction_products(ops, M, N, K, S, gat
     assert rc == -1                                                   # OMH_E_BADARG
 
     def run(split):
-        monkeypatch.setenv("OMH_GEMM_SPLITK", "1" if split else "0")
+        set_option("OMH_GEMM_SPLITK", "1" if split else "0")
         x = x0.clone()
         ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(x), M, N, K, K, K, N, ops.EPI_RESID, bias=ops.ptr(bias),
                      bias_mode=ops.BIAS_N, gate0=ops.ptr(mod, 2 * N), gate1=ops.ptr(e0, 2 * N), gate1_stride=6 * N,
@@ -209,7 +209,7 @@ def test_gemm_split_k_for_few_row_long_contraction_products(ops, M, N, K, S, gat
         ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(nosplit), M, N, K, K, K, N, ops.EPI_F32)
         return x, x1, y1.float(), f, f0, nosplit
     got, again, old = run(True), run(True), run(False)
-    monkeypatch.delenv("OMH_GEMM_SPLITK")
+    set_option("OMH_GEMM_SPLITK", None)
     for g, g2, o in zip(got, again, old):
         assert torch.equal(g, g2)
         assert not torch.equal(g, o) or g is got[2] or g is got[5]      # (it did take the other path)
@@ -234,9 +234,9 @@ def test_gemm_w64_narrow_streams(ops, M, N, K, monkeypatch):
 
     def run(env):
         for k_ in ("OMH_GEMM_KERNEL", "OMH_GEMM_W64_N192"):
-            monkeypatch.delenv(k_, raising=False)
+            set_option(k_, None)
         for k_, v_ in env.items():
-            monkeypatch.setenv(k_, v_)
+            set_option(k_, v_)
         return (ops.gemm(a, w, bias=bias, epilogue=ops.EPI_F32), ops.gemm(a, w, epilogue=ops.EPI_F32),
                 ops.gemm(a, w, bias=bias, epilogue=ops.EPI_BF16), ops.gemm(a, w, epilogue=ops.EPI_BF16))
     got, again, old = run({"OMH_GEMM_W64_N192": "1"}), run({"OMH_GEMM_W64_N192": "1"}), run({"OMH_GEMM_KERNEL": "8w"})
@@ -257,10 +257,10 @@ def test_gemm_w64_gelu_backward_stream(ops, M, N, K, monkeypatch):
     w = _bf(torch.randn(N, K, device="cuda") / math.sqrt(K))
     pre = _bf(torch.randn(M, N, device="cuda") * 1.5)
 
-    monkeypatch.setenv("OMH_GEMM_W64_GBWD", "1")                    # opt-in: measured equal to the 8-wave kernel, not the default
+    set_option("OMH_GEMM_W64_GBWD", "1")                    # opt-in: measured equal to the 8-wave kernel, not the default
 
     def run(kernel):
-        monkeypatch.setenv("OMH_GEMM_KERNEL", kernel)
+        set_option("OMH_GEMM_KERNEL", kernel)
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(out), M, N, K, K, K, N, ops.EPI_GELU_BWD_BF16, aux=ops.ptr(pre), ldaux=N)
         return out
@@ -270,7 +270,7 @@ def test_gemm_w64_gelu_backward_stream(ops, M, N, K, monkeypatch):
     torch.nn.functional.gelu(xf, approximate="tanh").sum().backward()
     ref = (a.float() @ w.float().t()) * xf.grad
     assert rel_rms(got.float(), ref) < 5e-3
-    monkeypatch.delenv("OMH_GEMM_KERNEL")
+    set_option("OMH_GEMM_KERNEL", None)
     assert torch.equal(run_default(ops, a, w, pre, M, N, K), old)      # whichever kernel the dispatch picks: the same bits
 
 
@@ -287,9 +287,9 @@ def test_gemm_w64_gelu_stream_with_the_pre_activation(ops, M, N, K, monkeypatch)
 
     def run(env):
         for k_ in ("OMH_GEMM_KERNEL", "OMH_GEMM_W64_GAUX"):
-            monkeypatch.delenv(k_, raising=False)
+            set_option(k_, None)
         for k_, v_ in env.items():
-            monkeypatch.setenv(k_, v_)
+            set_option(k_, v_)
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         pre = torch.full((M + 8, N), 7.0, device="cuda", dtype=torch.bfloat16)         # 8 guard rows
         ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(out), M, N, K, K, K, N, ops.EPI_GELU_BF16, bias=ops.ptr(bias),
@@ -324,9 +324,9 @@ def test_gemm_w64_per_row_bias_stream(ops, M, N, K, ldc, monkeypatch):
 
     def run(env):
         for k_ in ("OMH_GEMM_KERNEL", "OMH_GEMM_W64_BF16M"):
-            monkeypatch.delenv(k_, raising=False)
+            set_option(k_, None)
         for k_, v_ in env.items():
-            monkeypatch.setenv(k_, v_)
+            set_option(k_, v_)
         out = torch.full((M, ldc), 7.0, device="cuda", dtype=torch.bfloat16)
         ops.gemm_raw(ops.ptr(w), ops.ptr(h), ops.ptr(out), M, N, K, K, K, ldc, ops.EPI_BF16, bias=ops.ptr(bias), bias_mode=ops.BIAS_M)
         return out
@@ -357,7 +357,7 @@ def test_gemm_w64_random_shapes_equal_the_8_wave_kernel(ops, monkeypatch):
         x0 = torch.randn(M, N, device="cuda")
         outs = {}
         for kernel in ("w64", "8w"):
-            monkeypatch.setenv("OMH_GEMM_KERNEL", kernel)
+            set_option("OMH_GEMM_KERNEL", kernel)
             out = x0.clone() if epi == ops.EPI_RESID else torch.empty(
                 M, N, device="cuda", dtype=torch.float32 if epi == ops.EPI_F32 else torch.bfloat16)
             ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(out), M, N, K, K, K, N, epi,
@@ -373,13 +373,13 @@ def test_gemm_w64_random_shapes_equal_the_8_wave_kernel(ops, monkeypatch):
 def test_gemm_w64_is_the_default_on_the_large_shapes(ops, monkeypatch):
     """Unset OMH_GEMM_KERNEL: >= 256 tiles of 256 x 384 -> the stream kernel; its output is that of the forced call and
     (the kernels agree bit for bit) of the 8-wave kernel."""
-    monkeypatch.delenv("OMH_GEMM_KERNEL", raising=False)
-    monkeypatch.delenv("OMH_GEMM_TILE", raising=False)
+    set_option("OMH_GEMM_KERNEL", None)
+    set_option("OMH_GEMM_TILE", None)
     M, N, K = 32760, 1536, 256
     a = _bf(torch.randn(M, K, device="cuda"))
     w = _bf(torch.randn(N, K, device="cuda") / math.sqrt(K))
     d = ops.gemm(a, w)
-    monkeypatch.setenv("OMH_GEMM_KERNEL", "8w")
+    set_option("OMH_GEMM_KERNEL", "8w")
     assert torch.equal(d, ops.gemm(a, w))
 
 
@@ -400,7 +400,7 @@ def _attn_ref(q, k, v, k_lens, scale):
     (2, 3, 130, 512, [37, 512]), (1, 2, 64, 320, [257]), (2, 1, 100, 64, [0, 5])])
 @pytest.mark.parametrize("kernel", ["base", "pp", "w64"])
 def test_flash_attention(ops, B, H, Lq, Lk, klens, kernel, monkeypatch):
-    monkeypatch.setenv("OMH_ATTN_KERNEL", kernel)      # both kernels on every shape (ragged rows/keys, empty rows)
+    set_option("OMH_ATTN_KERNEL", kernel)      # both kernels on every shape (ragged rows/keys, empty rows)
     torch.manual_seed(Lq + Lk)
     D = 128
     q = _bf(torch.randn(B, Lq, H, D, device="cuda"))
@@ -416,6 +416,43 @@ def test_flash_attention(ops, B, H, Lq, Lk, klens, kernel, monkeypatch):
     # P is rounded to bf16 before P.V and the output to bf16: ~2^-9 relative each
     assert rel_rms(out.float(), ref) < 8e-3
     assert float((out.float() - ref).abs().max()) < 3e-2
+
+
+def test_flash_attention_q_lens(ops, wan_model_mod):
+    """ABI v10 / VERDICT round 4 item 10: flash_attention(q_lens=...) (attention.py:24-60,79) — query rows past a sample's
+    length are pad rows of the reference's packed batch: zeros here; the rows inside are what the call without q_lens
+    gives, bit for bit; also at a size whose default dispatch would take the long-sequence kernel, and through the
+    reference-signature wrapper.  causal / window_size / dropout_p are rejected loudly."""
+    attn_mod = __import__("importlib").import_module(wan_model_mod.__name__.rsplit(".", 1)[0] + ".attention")
+    torch.manual_seed(3)
+    D = 128
+    for (B, H, Lq, Lk, qlens, klens) in ((2, 2, 200, 150, [200, 77], [150, 60]), (3, 1, 129, 64, [0, 129, 1], None),
+                                         (1, 12, 5601, 5601, [4000], [5000])):
+        q = _bf(torch.randn(B, Lq, H, D, device="cuda"))
+        k = _bf(torch.randn(B, Lk, H, D, device="cuda"))
+        v = _bf(torch.randn(B, Lk, H, D, device="cuda"))
+        Lp = (Lk + 63) // 64 * 64
+        vt = torch.zeros(B, H * D, Lp, dtype=torch.bfloat16, device="cuda")
+        vt[:, :, :Lk] = v.reshape(B, Lk, H * D).transpose(1, 2)
+        kl = None if klens is None else torch.tensor(klens, dtype=torch.int32, device="cuda")
+        ql = torch.tensor(qlens, dtype=torch.int32, device="cuda")
+        out = ops.flash_attn(q, k, vt, kl, q_lens=ql)
+        ref = _attn_ref(q, k, v, klens, D ** -0.5)
+        set_option("OMH_ATTN_KERNEL", "base")
+        plain = ops.flash_attn(q, k, vt, kl)
+        set_option("OMH_ATTN_KERNEL", None)
+        for b in range(B):
+            n = qlens[b]
+            assert torch.equal(out[b, :n], plain[b, :n])
+            assert float(out[b, n:].float().abs().sum()) == 0.0
+            if n:
+                assert rel_rms(out[b, :n].float(), ref[b, :n]) < 8e-3
+        w = attn_mod.flash_attention(q, k, v, q_lens=ql, k_lens=kl)
+        assert torch.equal(w, out)
+    with pytest.raises(NotImplementedError):
+        attn_mod.flash_attention(q, k, v, causal=True)
+    with pytest.raises(NotImplementedError):
+        attn_mod.flash_attention(q, k, v, window_size=(128, 128))
 
 
 def test_flash_attention_long_sequence_dispatch(ops):
@@ -439,7 +476,7 @@ def test_flash_attention_long_sequence_dispatch(ops):
 @pytest.mark.parametrize("kernel", ["base", "pp", "w64"])
 def test_flash_attention_peaked_rows(ops, kernel, monkeypatch):
     """Forces large online-softmax rescales: one key dominates late in the sequence."""
-    monkeypatch.setenv("OMH_ATTN_KERNEL", kernel)
+    set_option("OMH_ATTN_KERNEL", kernel)
     torch.manual_seed(5)
     B, H, L, D = 1, 2, 384, 128
     q = _bf(torch.randn(B, L, H, D, device="cuda"))
@@ -460,8 +497,8 @@ def test_flash_attention_w64_prescaled_q_lse_and_late_rescale(ops, variant, monk
     requested, ragged rows and keys, masked keys, and a key that dominates LATE in the sequence with large scores so
     that the deferred running-max update (rescale of the AGPR accumulators) runs after hundreds of tiles.  Against
     fp32 softmax attention on the same bf16 operands, and bit for bit against itself."""
-    monkeypatch.setenv("OMH_ATTN_KERNEL", "w64")
-    monkeypatch.setenv("OMH_W64_VARIANT", variant)
+    set_option("OMH_ATTN_KERNEL", "w64")
+    set_option("OMH_W64_VARIANT", variant)
     D, LOG2E = 128, 1.4426950408889634
     g = torch.Generator(device="cuda").manual_seed(11)
     for (B, H, Lq, Lk, klens, amp) in ((1, 2, 300, 200, None, 1.0), (2, 2, 777, 1000, [1000, 333], 1.0),
@@ -596,7 +633,7 @@ def test_flash_attention_is_bitwise_repeatable(ops, kernel, monkeypatch):
     that hipcc's hazard recognizer does not see: issued right behind the last K.Q^T MFMA it sometimes read scores
     missing their last k-slice — a valid softmax offset, but a different one from run to run (outputs differing
     in the last bf16 bit, a 1.3B forward at S=1560 differing by 0.017 between two runs)."""
-    monkeypatch.setenv("OMH_ATTN_KERNEL", kernel)
+    set_option("OMH_ATTN_KERNEL", kernel)
     g = torch.Generator(device="cuda").manual_seed(5)
     for (Lq, Lk, klen) in ((1560, 1560, 1560), (1560, 512, 120)):
         H = 12
@@ -669,8 +706,8 @@ def test_gemm_tn(ops, M, N, K, pad, tile, monkeypatch):
     """omh_gemm_bf16_tn — C = A^T B with both operands k-major (the weight gradient on dy and x as they are):
     against fp32 matmul on the same bf16 inputs; ragged M / N / K tails, strided rows, both tile configurations,
     accumulation, and an asymmetric pattern that a transposed or permuted fragment gather would scramble."""
-    monkeypatch.setenv("OMH_GEMM_TN_TILE", tile.split("-")[0])
-    monkeypatch.setenv("OMH_GEMM_TN_SPLIT", tile.split("split")[1] if "split" in tile else "1")    # split K: fp32 atomics
+    set_option("OMH_GEMM_TN_TILE", tile.split("-")[0])
+    set_option("OMH_GEMM_TN_SPLIT", tile.split("split")[1] if "split" in tile else "1")    # split K: fp32 atomics
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     a_full = torch.randn(K, M + pad, device="cuda", generator=g).bfloat16()
     b_full = torch.randn(K, N + pad, device="cuda", generator=g).bfloat16()
@@ -700,12 +737,12 @@ def test_gemm_tn_w64_stream_equals_the_tiled_kernel(ops, M, N, K, pad, monkeypat
     b_full = torch.randn(K, N + pad, device="cuda", generator=g).bfloat16()
     a, b = a_full[:, :M], b_full[:, :N]
     base = torch.randn(M, N, device="cuda", generator=g)
-    monkeypatch.setenv("OMH_GEMM_TN_W64", "0")
-    monkeypatch.setenv("OMH_GEMM_TN_TILE", "small")
-    monkeypatch.setenv("OMH_GEMM_TN_SPLIT", "1")
+    set_option("OMH_GEMM_TN_W64", "0")
+    set_option("OMH_GEMM_TN_TILE", "small")
+    set_option("OMH_GEMM_TN_SPLIT", "1")
     want = ops.gemm_tn(a, b)
     want_acc = ops.gemm_tn(a, b, out=base.clone(), accumulate=True)
-    monkeypatch.setenv("OMH_GEMM_TN_W64", "1")
+    set_option("OMH_GEMM_TN_W64", "1")
     got = ops.gemm_tn(a, b)
     assert rel_rms(got, a.float().t() @ b.float()) < 2e-5
     assert torch.equal(got, want)
@@ -739,11 +776,11 @@ def test_gemm_tn_w64_stream_grouped(ops, monkeypatch):
     base = torch.randn(d, d, device="cuda", generator=g)
     probs = [(dqkv, h1, None), (dy1, h1, base), (dkv, ctx, None), (dy1, u, None), (u[:, :8960 - 8960 % 256], dy1, None),
              (dqkv[:, d:2 * d], h1[:, :392], None), (u, u[:, :2304], None)]        # 356 tiles of 256 x 384 in all
-    monkeypatch.setenv("OMH_GEMM_TN_W64", "0")
-    monkeypatch.setenv("OMH_GEMM_TN_TILE", "small")
-    monkeypatch.setenv("OMH_GEMM_TN_SPLIT", "1")
+    set_option("OMH_GEMM_TN_W64", "0")
+    set_option("OMH_GEMM_TN_TILE", "small")
+    set_option("OMH_GEMM_TN_SPLIT", "1")
     want = [ops.gemm_tn(dy, x, out=None if b_ is None else b_.clone(), accumulate=b_ is not None) for dy, x, b_ in probs]
-    monkeypatch.setenv("OMH_GEMM_TN_W64", "1")
+    set_option("OMH_GEMM_TN_W64", "1")
     items = [(dy, x, torch.full((dy.shape[1], x.shape[1]), 7.0, device="cuda") if b_ is None else b_.clone(), b_ is not None)
              for dy, x, b_ in probs]
     ops.gemm_tn_grouped(items)
@@ -759,7 +796,7 @@ def test_gemm_b_kmajor(ops, M, N, K, pad, tile, monkeypatch):
     fp32 matmul on the same bf16 inputs; ragged M / N / K tails, a strided B, both tile configurations and the cost
     rule, the three epilogues the backward uses, a batched strided call, and an exact selector pattern."""
     if tile != "auto":
-        monkeypatch.setenv("OMH_GEMM_TILE", tile)
+        set_option("OMH_GEMM_TILE", tile)
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     a = torch.randn(M, K, device="cuda", generator=g).bfloat16()
     b_full = (torch.randn(K, N + pad, device="cuda", generator=g) / math.sqrt(K)).bfloat16()

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import PKG, rel_rms
+from conftest import PKG, rel_rms, set_option
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -505,7 +505,7 @@ def test_attention_tail_split_matches_the_unsplit_launch(ops, monkeypatch, B, H,
         return o, o32, lse
     # OMH_ATTN_SPLIT=tail: split the last round of ANY launch with >= 4 tiles per worker (the shipped policy splits only
     # launches that do not fill the chip once, and the forward only on long key loops: profiles/r04_attention_split_ab.txt)
-    monkeypatch.setenv("OMH_ATTN_SPLIT", "tail")
+    set_option("OMH_ATTN_SPLIT", "tail")
     o0, o320, lse0 = fwd(ops.ATTN_SHORT_KERNEL)
     o1, o321, lse1 = fwd(ops.ATTN_SHORT_KERNEL | ops.ATTN_ALLOW_SPLIT)
     o2, o322, lse2 = fwd(ops.ATTN_SHORT_KERNEL | ops.ATTN_ALLOW_SPLIT)
@@ -521,13 +521,13 @@ def test_attention_tail_split_matches_the_unsplit_launch(ops, monkeypatch, B, H,
     live = torch.isfinite(lse0)
     assert torch.equal(torch.isfinite(lse1), live)
     assert rel_rms(o321, o320) < 2e-3 and float((lse1[live] - lse0[live]).abs().max()) < 1e-4
-    monkeypatch.setenv("OMH_ATTN_SPLIT", "0")
+    set_option("OMH_ATTN_SPLIT", "0")
     o3, o323, lse3 = fwd(ops.ATTN_SHORT_KERNEL | ops.ATTN_ALLOW_SPLIT)
     assert torch.equal(o323, o320) and torch.equal(lse3, lse0)                                     # the override: no split
     # ---- backward on the unsplit forward's tensors: split (default) vs OMH_ATTN_SPLIT=0
     kw = dict(q_prescaled=True, o32=o320)
     ref = ops.flash_attn_bwd(q, k, v, None, do, lse0, klens, B, H, Lq, Lk, scale, **kw)
-    monkeypatch.setenv("OMH_ATTN_SPLIT", "tail")
+    set_option("OMH_ATTN_SPLIT", "tail")
     got = ops.flash_attn_bwd(q, k, v, None, do, lse0, klens, B, H, Lq, Lk, scale, **kw)
     again = ops.flash_attn_bwd(q, k, v, None, do, lse0, klens, B, H, Lq, Lk, scale, **kw)
     nosplit = ops.flash_attn_bwd(q, k, v, None, do, lse0, klens, B, H, Lq, Lk, scale, split=False, **kw)
@@ -549,7 +549,7 @@ def test_attention_tail_split_matches_the_unsplit_launch(ops, monkeypatch, B, H,
     assert torch.equal(buf[:, d:2 * d], got[0].bfloat16()) and torch.equal(kvb[:, :d], got[1].bfloat16())
     assert torch.equal(kvb[:, d:], got[2].bfloat16()) and bool((buf[:, :d] == 3.0).all()) and bool((buf[:, 2 * d:] == 3.0).all())
     # the shipped policy: one clip (a launch that does not fill the chip) splits dQ and dK / dV, four clips do not
-    monkeypatch.delenv("OMH_ATTN_SPLIT")
+    set_option("OMH_ATTN_SPLIT", None)
     dflt = ops.flash_attn_bwd(q, k, v, None, do, lse0, klens, B, H, Lq, Lk, scale, **kw)
     for g, r, t_, nm in zip(dflt, ref, got, ("dq", "dk", "dv")):
         if B == 1:
@@ -817,7 +817,7 @@ def test_gemm_tn_grouped(ops, tile, monkeypatch):
     """omh_gemm_bf16_tn_grouped: several weight-gradient products in one launch == the single-problem kernel on each
     (ragged tiles, strided operands out of fused buffers, accumulation), and bit-repeatable (no split K, no atomics) —
     on 128 x 128 and on 256 x 256 tiles."""
-    monkeypatch.setenv("OMH_GEMM_TN_GROUP_TILE", tile)
+    set_option("OMH_GEMM_TN_GROUP_TILE", tile)
     g = torch.Generator(device="cuda").manual_seed(8)
     R = 1000
     dyf = (torch.randn(R, 3 * 256, device="cuda", generator=g) * 0.3).bfloat16()       # dq | dk | dv style buffer

@@ -5,7 +5,7 @@ import importlib
 import pytest
 import torch
 
-from conftest import rel_rms
+from conftest import rel_rms, set_option
 
 pytestmark = pytest.mark.gpu
 
@@ -40,8 +40,8 @@ def test_conv_cl_matches_torch(ops, cfg, tile, monkeypatch):
     # every tile configuration on every shape: 128x128; wide tiles with the kw-shared kernel where it applies
     # (3x3 taps, stride 1, Cin % 32 == 0); wide tiles without it; the one-wave-per-SIMD stream kernel where IT applies
     # (kw-shared shapes with Cout = 96 or a multiple of 192), the wide kernels elsewhere
-    monkeypatch.setenv("OMH_CONV_TILE", tile.split("-")[0])
-    monkeypatch.setenv("OMH_CONV_KW3", "0" if tile.endswith("nokw3") else "1")
+    set_option("OMH_CONV_TILE", tile.split("-")[0])
+    set_option("OMH_CONV_KW3", "0" if tile.endswith("nokw3") else "1")
     torch.manual_seed(cfg["Cin"] + cfg["Cout"])
     Cin, Cout, T, H, W, KT, KH, KW = (cfg[k] for k in ("Cin", "Cout", "T", "H", "W", "KT", "KH", "KW"))
     hist = KT - 1
@@ -87,7 +87,7 @@ def test_conv_cl_w64_equals_the_kw_shared_kernel(ops, cfg, monkeypatch):
     rb, rf = _bf(torch.randn(T, H, W, Cout, device="cuda")), torch.randn(T, H, W, Cout, device="cuda")
 
     def run(tile):
-        monkeypatch.setenv("OMH_CONV_TILE", tile)
+        set_option("OMH_CONV_TILE", tile)
         kw = dict(pad_h=1, pad_w=1)
         return (ops.conv_cl(x, wp, bias, T, H, W, Cout, KT, 3, 3, resid=rb, **kw),
                 ops.conv_cl(x, wp, None, T, H, W, Cout, KT, 3, 3, **kw),
@@ -116,7 +116,7 @@ def test_conv_cl_w64_random_shapes_equal_the_kw_shared_kernel(ops, monkeypatch):
         rf = torch.randn(T, H, W, Cout, device="cuda")
         out = {}
         for tile in ("w64", "wide"):
-            monkeypatch.setenv("OMH_CONV_TILE", tile)
+            set_option("OMH_CONV_TILE", tile)
             out[tile] = (ops.conv_cl(x, wp, bias, T, H, W, Cout, KT, 3, 3, pad_h=1, pad_w=1, resid=_bf(rf)),
                          ops.conv_cl(x, wp, bias, T, H, W, Cout, KT, 3, 3, pad_h=1, pad_w=1, resid=rf, out_f32=True))
         for g, r in zip(out["w64"], out["wide"]):
@@ -142,10 +142,10 @@ def test_conv_cl_fused_norm_equals_conv_then_rms_silu(ops, shape, monkeypatch):
     gamma = torch.rand(Cout, device="cuda") + 0.5
     rf = torch.randn(T, H, W, Cout, device="cuda")
 
-    monkeypatch.setenv("OMH_CONV_TILE", "w64")               # these volumes are below the stream kernel's default threshold
+    set_option("OMH_CONV_TILE", "w64")               # these volumes are below the stream kernel's default threshold
 
     def run(fuse, **kw):
-        monkeypatch.setenv("OMH_CONV_FUSE_NORM", "1" if fuse else "0")
+        set_option("OMH_CONV_FUSE_NORM", "1" if fuse else "0")
         n = torch.full((T, H, W, Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
         y = ops.conv_cl(x, wp, bias, T, H, W, Cout, KT, 3, 3, pad_h=1, pad_w=1, norm_gamma=gamma, norm_out=n, **kw)
         return y, n
@@ -157,7 +157,7 @@ def test_conv_cl_fused_norm_equals_conv_then_rms_silu(ops, shape, monkeypatch):
         want = ops.rms_silu_cl(y0, gamma)
         assert torch.equal(n0, want)
     # norm_only: the normalised output alone (y's stores fall outside an empty descriptor)
-    monkeypatch.setenv("OMH_CONV_FUSE_NORM", "1")
+    set_option("OMH_CONV_FUSE_NORM", "1")
     n = torch.empty(T, H, W, Cout, dtype=torch.bfloat16, device="cuda")
     sentinel = torch.full((T, H, W, Cout), 7.0, dtype=torch.bfloat16, device="cuda")
     ops.conv_cl(x, wp, bias, T, H, W, Cout, KT, 3, 3, pad_h=1, pad_w=1, norm_gamma=gamma, norm_out=n, norm_only=True, out=sentinel)
@@ -176,7 +176,7 @@ def test_conv_cl_w64_folded_upsample(ops, Cin, Cout, T, H, W, monkeypatch):
     bias = torch.randn(Cout, device="cuda")
     out = {}
     for tile in ("w64", "wide"):
-        monkeypatch.setenv("OMH_CONV_TILE", tile)
+        set_option("OMH_CONV_TILE", tile)
         out[tile] = ops.conv_cl(x, wp, bias, T, 2 * H, 2 * W, Cout, 1, 3, 3, pad_h=1, pad_w=1, up2=True, out_f32=True)
     xi = x.float().permute(0, 3, 1, 2)
     ref = torch.nn.functional.conv2d(torch.nn.functional.interpolate(xi, scale_factor=2.0, mode="nearest-exact"), w.float(),
@@ -188,7 +188,7 @@ def test_conv_cl_w64_folded_upsample(ops, Cin, Cout, T, H, W, monkeypatch):
 
 @pytest.mark.parametrize("tile", ["small", "wide"])
 def test_conv_cl_upsample_downsample_stride_split(ops, tile, monkeypatch):
-    monkeypatch.setenv("OMH_CONV_TILE", tile)
+    set_option("OMH_CONV_TILE", tile)
     torch.manual_seed(9)
     C, H, W = 32, 6, 10
     x = _bf(torch.randn(2, H, W, C, device="cuda"))

@@ -15,9 +15,9 @@ res = {v: [] for v in variants}
 for rnd in range(3):
     for v in variants:
         if v == "pp":
-            os.environ["OMH_ATTN_KERNEL"] = "pp"
+            ops.set_option("OMH_ATTN_KERNEL", "pp")
         else:
-            os.environ["OMH_ATTN_KERNEL"] = "w64"; os.environ["OMH_W64_VARIANT"] = v
+            ops.set_option("OMH_ATTN_KERNEL", "w64"); ops.set_option("OMH_W64_VARIANT", v)
         for _ in range(2):
             ops.flash_attn(q, k, vt, None, out=o)
         torch.cuda.synchronize()

@@ -20,7 +20,7 @@ LOG2E = 1.4426950408889634
 
 
 def run(kind, q, k, vt, k_lens=None, lse=False, pre=1):
-    os.environ["OMH_ATTN_KERNEL"] = kind
+    ops.set_option("OMH_ATTN_KERNEL", kind)
     B, Lq, H, _ = q.shape
     Lk = k.shape[1]
     out = torch.full((B, Lq, H, D), float("nan"), dtype=torch.bfloat16, device="cuda")
@@ -92,7 +92,7 @@ def timeit():
     res = {}
     for rnd in range(3):
         for kind in ("pp", "w64"):
-            os.environ["OMH_ATTN_KERNEL"] = kind
+            ops.set_option("OMH_ATTN_KERNEL", kind)
             for _ in range(3):
                 ops.flash_attn(q, k, vt, None, out=o)
             torch.cuda.synchronize()
@@ -105,7 +105,7 @@ def timeit():
             res.setdefault(kind, []).append(ms)
             print(f"round {rnd} {kind}: {ms:.4f} ms {4.0 * S * S * H * D / ms / 1e9:.1f} TF", flush=True)
     # sampled-row parity at full size
-    os.environ["OMH_ATTN_KERNEL"] = "w64"
+    ops.set_option("OMH_ATTN_KERNEL", "w64")
     ops.flash_attn(q, k, vt, None, out=o)
     rows = torch.tensor([0, 1, 255, 256, 16383, S - 257, S - 1, 12345], device="cuda")
     for h in (0, 7):

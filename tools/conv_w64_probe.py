@@ -7,7 +7,7 @@ bf = lambda t: t.to(torch.bfloat16)
 
 
 def outs(tile, x, wp, bias, rb, rf, T, H, W, Cout, KT):
-    os.environ["OMH_CONV_TILE"] = tile
+    ops.set_option("OMH_CONV_TILE", tile)
     kw = dict(pad_h=1, pad_w=1)
     return (ops.conv_cl(x, wp, bias, T, H, W, Cout, KT, 3, 3, resid=rb, **kw),
             ops.conv_cl(x, wp, None, T, H, W, Cout, KT, 3, 3, **kw),
@@ -38,7 +38,7 @@ def timeit(Cin, Cout, T, H, W, KT=3, f32=False):
     res = {}
     for rnd in range(3):
         for tile in ("wide", "w64"):
-            os.environ["OMH_CONV_TILE"] = tile
+            ops.set_option("OMH_CONV_TILE", tile)
             f = lambda: ops.conv_cl(x, wp, bias, T, H, W, Cout, KT, 3, 3, pad_h=1, pad_w=1, resid=r, out_f32=f32)
             f(); f()
             torch.cuda.synchronize()

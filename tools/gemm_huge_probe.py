@@ -22,7 +22,7 @@ for M, N, K, epi in [(32760, 1536, 1536, "EPI_BF16"), (32760, 3072, 1536, "EPI_B
     out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16 if "BF16" in epi else torch.float32)
     r = {}
     for tile in ("big", "huge"):
-        os.environ["OMH_GEMM_TILE"] = tile
+        ops.set_option("OMH_GEMM_TILE", tile)
         if epi == "EPI_RESID":
             f = lambda: ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(out), M, N, K, K, K, N, e, gate_const=0.5)
         else:

@@ -3,9 +3,9 @@ import importlib, math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 ops = importlib.import_module("omnihuman-1-hack_amd.ops")
-os.environ["OMH_GEMM_TILE"] = "big"
-os.environ["OMH_GEMM_TN_TILE"] = "big"
-os.environ["OMH_GEMM_TN_SPLIT"] = "1"
+ops.set_option("OMH_GEMM_TILE", "big")
+ops.set_option("OMH_GEMM_TN_TILE", "big")
+ops.set_option("OMH_GEMM_TN_SPLIT", "1")
 M, N, K = 6240, 1536, 8960
 a = torch.randn(M, K, device="cuda").bfloat16()
 w = (torch.randn(K, N, device="cuda") / math.sqrt(K)).bfloat16()

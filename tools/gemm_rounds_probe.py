@@ -3,7 +3,7 @@ import importlib, math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 ops = importlib.import_module("omnihuman-1-hack_amd.ops")
-os.environ["OMH_GEMM_TILE"] = "big"
+ops.set_option("OMH_GEMM_TILE", "big")
 
 def t(fn, n=20):
     for _ in range(3): fn()

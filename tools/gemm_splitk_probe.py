@@ -32,10 +32,10 @@ for M, N, K in ((1560, 1536, 8960), (3120, 1536, 8960), (1560, 1536, 4608), (312
     for rnd in range(2):
         for mode in ("split", "unsplit"):
             if mode == "unsplit":
-                os.environ["OMH_GEMM_SPLITK"] = "0"
+                ops.set_option("OMH_GEMM_SPLITK", "0")
             else:
-                os.environ.pop("OMH_GEMM_SPLITK", None)
+                ops.set_option("OMH_GEMM_SPLITK", None)
             row.setdefault(mode + " resid", []).append(round(t(resid), 1))
             row.setdefault(mode + " f32", []).append(round(t(f32), 1))
-    os.environ.pop("OMH_GEMM_SPLITK", None)
+    ops.set_option("OMH_GEMM_SPLITK", None)
     print((M, N, K), row, "TFLOP/s split resid", round(2.0 * M * N * K / min(row["split resid"]) / 1e6, 1), flush=True)

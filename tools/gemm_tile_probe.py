@@ -35,19 +35,19 @@ for M, N, K, epi in shapes:
     kw = dict(gate_const=1.0) if epi == ops.EPI_RESID else {}
     fn = lambda: ops.gemm_raw(ops.ptr(a), ops.ptr(w), ops.ptr(out), M, N, K, K, K, N, epi, bias=ops.ptr(b), bias_mode=ops.BIAS_N, **kw)
     row = {"M": M, "N": N, "K": K, "epi": epi}
-    os.environ.pop("OMH_GEMM_TILE", None)
-    os.environ.pop("OMH_GEMM_KERNEL", None)
+    ops.set_option("OMH_GEMM_TILE", None)
+    ops.set_option("OMH_GEMM_KERNEL", None)
     row["auto_us"] = round(timeit(fn), 1)
     for t in ("big", "mid192", "small", "tiny"):
-        os.environ["OMH_GEMM_TILE"] = t
+        ops.set_option("OMH_GEMM_TILE", t)
         row[t + "_us"] = round(timeit(fn), 1)
-    os.environ.pop("OMH_GEMM_TILE", None)
-    os.environ["OMH_GEMM_KERNEL"] = "w64"
+    ops.set_option("OMH_GEMM_TILE", None)
+    ops.set_option("OMH_GEMM_KERNEL", "w64")
     try:
         row["w64_us"] = round(timeit(fn), 1)
     except Exception as e:
         row["w64_us"] = None
-    os.environ.pop("OMH_GEMM_KERNEL", None)
+    ops.set_option("OMH_GEMM_KERNEL", None)
     row["auto_tflops"] = round(2 * M * N * K / row["auto_us"] / 1e6, 0)
     res.append(row)
     print(json.dumps(row), flush=True)

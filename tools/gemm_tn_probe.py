@@ -33,8 +33,8 @@ for (M, N, K) in ((1536, 1536, 6240), (3072, 1536, 6240), (8960, 1536, 6240), (1
         ops.gemm_raw(ops.ptr(dyT), ops.ptr(xT), ops.ptr(out), M, N, Rp, Rp, Rp, N, ops.EPI_F32)
     row = {"transposes+nt": t(nt), "nt_gemm_only": t(nt_gemm_only)}
     for tile in ("big", "small"):
-        os.environ["OMH_GEMM_TN_TILE"] = tile
+        ops.set_option("OMH_GEMM_TN_TILE", tile)
         row["tn_" + tile] = t(lambda: ops.gemm_tn(dy, x, out=out))
-    os.environ.pop("OMH_GEMM_TN_TILE")
+    ops.set_option("OMH_GEMM_TN_TILE", None)
     row["tn_auto"] = t(lambda: ops.gemm_tn(dy, x, out=out))
     print(f"{M}x{N}x{K}", row, flush=True)

@@ -9,7 +9,7 @@ P = ops.ptr
 
 
 def run(kernel, epi, a, w, bias=None, out=None, gate0=None, gate1=None, gate_rows=1, gate_const=0.0):
-    os.environ["OMH_GEMM_KERNEL"] = kernel
+    ops.set_option("OMH_GEMM_KERNEL", kernel)
     M, K = a.shape
     N = w.shape[0]
     if out is None:

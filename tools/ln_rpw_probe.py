@@ -10,7 +10,7 @@ for R in (6240, 3120, 1560, 24960):
     res = {}
     for rep in range(2):
         for rpw in ("1", "2", "4"):
-            os.environ["OMH_LN_RPW"] = rpw
+            ops.set_option("OMH_LN_RPW", rpw)
             f = lambda: ops.layernorm_modulate_raw(ptr(x), ptr(h), R, d, 1e-6, 1.0, ptr(mod, d), ptr(e0, d), 6 * d, ptr(mod, 0), ptr(e0, 0), 6 * d, 1560)
             for _ in range(5): f()
             torch.cuda.synchronize(); s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True); s.record()

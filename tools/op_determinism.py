@@ -86,9 +86,9 @@ def main():
     vtt = vt()
     sl = torch.tensor([S], dtype=torch.int32, device=dev)
     for kern in ("base", "pp"):
-        os.environ["OMH_ATTN_KERNEL"] = kern
+        ops.set_option("OMH_ATTN_KERNEL", kern)
         rep(f"flash_attn_self[{kern}]", lambda: ops.flash_attn(q.view(1, S, N, D), k.view(1, S, N, D), vtt, k_lens=sl), res)
-    del os.environ["OMH_ATTN_KERNEL"]
+    ops.set_option("OMH_ATTN_KERNEL", None)
     rep("flash_attn_self[auto]", lambda: ops.flash_attn(q.view(1, S, N, D), k.view(1, S, N, D), vtt, k_lens=sl), res)
     L = 512
     kc = (rn(1, L, N, D)).bfloat16()

@@ -31,8 +31,8 @@ ffn = [(torch.randn(R, 8960, device="cuda").bfloat16(), torch.randn(R, 1536, dev
         torch.empty(1536, 8960, dtype=torch.float32, device="cuda"), False)]
 fflop = 2 * 2.0 * 8960 * 1536 * R
 for tile in ("small", "big", "w64"):
-    os.environ["OMH_GEMM_TN_GROUP_TILE"] = "small" if tile == "w64" else tile
-    os.environ["OMH_GEMM_TN_W64"] = "1" if tile == "w64" else "0"
+    ops.set_option("OMH_GEMM_TN_GROUP_TILE", "small" if tile == "w64" else tile)
+    ops.set_option("OMH_GEMM_TN_W64", "1" if tile == "w64" else "0")
     f1 = t(lambda: (ops.gemm_tn(ffn[0][0], ffn[0][1], out=ffn[0][2]), ops.gemm_tn(ffn[1][0], ffn[1][1], out=ffn[1][2])))
     f2 = t(lambda: ops.gemm_tn_grouped(ffn))
     fall = t(lambda: ops.gemm_tn_grouped(items + ffn))

@@ -8,7 +8,7 @@ shapes = [(d, d, R), (d, d, R), (d, d, R), (2 * d, d, 2048), (3 * d, d, R)]
 items = [((torch.randn(K, M, device="cuda") * 0.3).bfloat16(), (torch.randn(K, N, device="cuda") * 0.3).bfloat16(),
           torch.empty(M, N, dtype=torch.float32, device="cuda"), False) for M, N, K in shapes]
 for mode in ("1", "0"):
-    os.environ["OMH_GEMM_TN_W64"] = mode
+    ops.set_option("OMH_GEMM_TN_W64", mode)
     for _ in range(3):
         ops.gemm_tn_grouped(items)
 torch.cuda.synchronize()
