@@ -88,7 +88,15 @@ enum {
     OMH_EPI_RESID     = 3,  /* C fp32 += (acc + bias) * gate     (model.py:296,313,328) */
     OMH_EPI_F32_ACCUM = 4,  /* C fp32 += acc + bias               (used by backward) */
     OMH_EPI_GELU_ERF_BF16 = 5, /* C bf16 = gelu_erf(acc + bias)   (i2v MLPProj, model.py:369) */
-    OMH_EPI_GELU_BWD_BF16 = 6  /* C bf16 = acc * gelu_tanh'(aux)   (backward of model.py:273 fused into the dgrad GEMM) */
+    OMH_EPI_GELU_BWD_BF16 = 6, /* C bf16 = acc * gelu_tanh'(aux)   (backward of model.py:273 fused into the dgrad GEMM) */
+    /* ABI v10 — the fused q | k | v projection of the self-attention (model.py:144-146,152-153 on concatenated
+       weights [3 dim, dim]): columns n < n_split go to C bf16 [M, ldc] = acc + bias[n] (q | k, what the norm kernel
+       reads); columns n >= n_split go TRANSPOSED to aux: aux[(n - n_split) * ldaux + m] bf16 = acc + bias[n] — V^T
+       [dim, ldaux >= M], the layout the attention kernel reads (omh_attn_args.vt).  One launch reads the activations
+       once.  batch == 1, bias [N] or none, M and n_split multiples of 8, aux 16-byte aligned, ldaux a multiple of 8;
+       columns m >= M of aux are not written.  Same bits as the two separate products
+       (BF16 on [M, n_split], and BF16 + OMH_BIAS_M with the operands swapped). */
+    OMH_EPI_BF16_SPLIT_T = 7
 };
 enum { OMH_BIAS_NONE = 0, OMH_BIAS_N = 1, OMH_BIAS_M = 2 };
 
@@ -126,6 +134,8 @@ typedef struct omh_gemm_args {
        (OMH_EPI_RESID with c_in / aux / gates, OMH_EPI_F32).  S depends on (M, N, K) only.  NULL / too small: the
        unsplit kernels, as before.  16-byte aligned. */
     void* workspace; int64_t workspace_bytes;
+    /* ABI v10 — OMH_EPI_BF16_SPLIT_T: first column that goes (transposed) to aux. */
+    int32_t n_split;
 } omh_gemm_args;
 
 int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream);

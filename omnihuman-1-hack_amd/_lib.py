@@ -63,7 +63,7 @@ class GemmArgs(C.Structure):
                 ("gate1_stride", i64), ("gate_rows", i32), ("gate_const", f32),
                 ("b_kmajor", i32),
                 ("c_in", vp), ("aux", vp), ("ldaux", i32),
-                ("workspace", vp), ("workspace_bytes", i64)]
+                ("workspace", vp), ("workspace_bytes", i64), ("n_split", i32)]
 
 
 COLSUM_MAX = 16
@@ -154,7 +154,7 @@ class ConvArgs(C.Structure):
                 ("norm_gamma", vp), ("norm_out", vp), ("norm_only", i32)]
 
 
-EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID, EPI_F32_ACCUM, EPI_GELU_ERF_BF16, EPI_GELU_BWD_BF16 = 0, 1, 2, 3, 4, 5, 6
+EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID, EPI_F32_ACCUM, EPI_GELU_ERF_BF16, EPI_GELU_BWD_BF16, EPI_BF16_SPLIT_T = 0, 1, 2, 3, 4, 5, 6, 7
 BIAS_NONE, BIAS_N, BIAS_M = 0, 1, 2
 
 _SIGS = {

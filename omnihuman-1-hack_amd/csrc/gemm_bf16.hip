@@ -490,6 +490,10 @@ int omh_gemm_splitk_slices(const omh_gemm_args& a);
 int64_t omh_gemm_splitk_workspace(const omh_gemm_args& a);
 int omh_launch_gemm_splitk(const omh_gemm_args& a, int S, hipStream_t stream);
 
+// ... the fused q | k | v projection: columns below n_split to C, the rest transposed to aux (ABI v10)
+bool omh_gemm_w64_qkv_takes(const omh_gemm_args& a);
+int omh_launch_gemm_w64_qkv(const omh_gemm_args& a, hipStream_t stream);
+
 static int launch_8w(const omh_gemm_args& a, hipStream_t s) {
     switch (a.epilogue) {
         case OMH_EPI_BF16:      return launch<OMH_EPI_BF16>(a, s);
@@ -508,6 +512,34 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
     const omh_gemm_args& a = *args;
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.batch <= 0) return OMH_E_BADARG;
     if ((a.K & 7) || (a.lda & 7) || (a.ldb & 7)) return OMH_E_ALIGN;
+    if (a.epilogue == OMH_EPI_BF16_SPLIT_T) {
+        // q | k | v in one product: one launch of the 256 x 384 stream where it fills the chip (>= one round of tiles),
+        // else the two products it stands for, through this same entry point.  OMH GEMM_QKV = "0": always the two.
+        if (!a.aux || a.batch != 1 || a.b_kmajor || a.c_in || a.n_split <= 0 || a.n_split >= a.N) return OMH_E_BADARG;
+        if (a.bias && a.bias_mode != OMH_BIAS_N) return OMH_E_BADARG;
+        if ((a.n_split & 7) || (a.M & 7) || (a.ldaux & 7) || a.ldaux < a.M || ((uintptr_t)a.aux & 15)) return OMH_E_ALIGN;
+        const char* q = omh_opt(OMH_OPT_GEMM_QKV);
+        const char* gk = omh_opt(OMH_OPT_GEMM_KERNEL);
+        const bool off = (q && q[0] == '0') || (gk && gk[0] == '8') || omh_opt(OMH_OPT_GEMM_TILE);
+        const int64_t tiles = (int64_t)((a.M + 255) / 256) * ((a.N + 383) / 384);
+        if (!off && omh_gemm_w64_qkv_takes(a) && (tiles >= 256 || (q && q[0] == '1'))) {
+            omh_clear_status();
+            omh_launch_gemm_w64_qkv(a, (hipStream_t)stream);
+            return omh_launch_status();
+        }
+        omh_gemm_args qk = a;                                             // C[M, n_split] = bf16(A B[:n_split]^T + bias)
+        qk.N = a.n_split; qk.epilogue = OMH_EPI_BF16; qk.aux = nullptr; qk.ldaux = 0; qk.n_split = 0;
+        const int rc = omh_gemm_bf16(&qk, stream);
+        if (rc) return rc;
+        omh_gemm_args v = a;                                              // aux[N - n_split, M] = bf16(B[n_split:] A^T + bias[m])
+        v.A = (const char*)a.B + (int64_t)a.n_split * a.ldb * 2; v.lda = a.ldb;
+        v.B = a.A; v.ldb = a.lda;
+        v.C = a.aux; v.ldc = a.ldaux;
+        v.M = a.N - a.n_split; v.N = a.M;
+        v.epilogue = OMH_EPI_BF16; v.aux = nullptr; v.ldaux = 0; v.n_split = 0;
+        v.bias = a.bias ? a.bias + a.n_split : nullptr; v.bias_mode = a.bias ? OMH_BIAS_M : OMH_BIAS_NONE;
+        return omh_gemm_bf16(&v, stream);
+    }
     if (a.b_kmajor) {                       // B = [K, N] row-major: dx = dy W on the weight as stored
         if ((a.N & 7) || a.ldb < a.N) return OMH_E_ALIGN;
         if (((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15) || ((uintptr_t)a.C & 15)) return OMH_E_ALIGN;

@@ -17,7 +17,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, int64_t
 }
 
 enum { K_F32 = 0, K_BF16 = 1, K_GELU = 2, K_RESID = 3, K_GELUBWD = 4, K_BF16M = 5, K_GELUAUX = 6,
-       K_RESID192 = 7, K_F32_192 = 8, K_BF16_192 = 9 };                      // >= K_RESID192: the 256 x 192 tile
+       K_RESID192 = 7, K_F32_192 = 8, K_BF16_192 = 9,                        // K_RESID192 .. K_BF16_192: the 256 x 192 tile
+       K_QKV = 10 };        // 256 x 384: columns < n_split -> C bf16 (the BF16 stream), columns >= n_split -> aux TRANSPOSED (BF16VT)
+constexpr bool is_n192(int kind) { return kind >= K_RESID192 && kind <= K_BF16_192; }
 
 // two wave-uniform 32-bit scalars in one SGPR pair (inline asm takes at most 30 operands)
 __device__ __forceinline__ uint64_t pack2(uint32_t lo, uint32_t hi) {
@@ -53,11 +55,11 @@ __device__ __forceinline__ W64Tile w64_tile(const omh_gemm_args& p, int idx, int
 template <int KIND>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int tiles_n, const W64Split sp) {
-    constexpr int TNW = KIND >= K_RESID192 ? TN192 : TN;                    // tile width; a wave owns TNW / 2 columns
+    constexpr int TNW = is_n192(KIND) ? TN192 : TN;                         // tile width; a wave owns TNW / 2 columns
     constexpr int WBYTES = TNW * 128, STAGE_B = 32768 + WBYTES;             // W tile, one stage (X 32 KiB | W)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_B];
     constexpr int ES = (KIND == K_BF16 || KIND == K_GELU || KIND == K_BF16_192 || KIND == K_GELUBWD || KIND == K_BF16M ||
-                        KIND == K_GELUAUX) ? 2 : 4;
+                        KIND == K_GELUAUX || KIND == K_QKV) ? 2 : 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1;
@@ -86,7 +88,14 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
     // (split K: p.K is ONE slice's length, the rows hold sp.n of them; C = the workspace's sp.n slices)
     const __amdgpu_buffer_rsrc_t ra = rsrc_of(p.A, (((int64_t)p.M - 1) * p.lda + (int64_t)p.K * sp.n) * 2);
     const __amdgpu_buffer_rsrc_t rb = rsrc_of(p.B, (((int64_t)p.N - 1) * p.ldb + (int64_t)p.K * sp.n) * 2);
-    const __amdgpu_buffer_rsrc_t rc = rsrc_of(p.C, (((int64_t)p.M - 1) * p.ldc + p.N) * ES + (int64_t)(sp.n - 1) * sp.cbytes);
+    // (K_QKV: C holds the columns below n_split only — the descriptor must end there, or the rows past M of a ragged
+    // last m-tile would land inside it)
+    const int c_cols = KIND == K_QKV ? p.n_split : p.N;
+    const __amdgpu_buffer_rsrc_t rc = rsrc_of(p.C, (((int64_t)p.M - 1) * p.ldc + c_cols) * ES + (int64_t)(sp.n - 1) * sp.cbytes);
+    // K_QKV, columns >= n_split: out^T [N - n_split, ldaux] bf16 in aux; lane (r, h) of wave (wm, wn) starts at row
+    // wn * 192 + r, column wm * 128 + 8 h of the tile's patch; a lane's bias is that of its row
+    const __amdgpu_buffer_rsrc_t rvt = rsrc_of(p.aux, KIND == K_QKV ? (((int64_t)(p.N - p.n_split) - 1) * p.ldaux + p.M) * 2 : 0);
+    // (the stream derives the lane's part from vlane; the wave's part goes into the tile origin below)
     const __amdgpu_buffer_rsrc_t rbias = rsrc_of(p.bias, (p.bias && p.bias_mode == OMH_BIAS_N) ? (int64_t)p.N * 4 : 0);
     // K_BF16M: per-ROW bias (OMH_BIAS_M: the V^T projection, weights in the row slot)
     const __amdgpu_buffer_rsrc_t rbm = rsrc_of(p.bias, (KIND == K_BF16M && p.bias) ? (int64_t)p.M * 4 : 0);
@@ -110,7 +119,7 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
 
     int idx = blockIdx.x;
     W64Tile t = w64_tile<TNW>(p, idx, tiles_m, tiles_n, w, sp);
-    if (KIND >= K_RESID192) {
+    if (is_n192(KIND)) {
         const uint64_t p8 = pack2(t.sxb, t.swb);
         asm volatile(OMH_GEMM_W64_ASM_PRO192
                      :
@@ -184,6 +193,33 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
                    [p2] "{s[64:65]}"(p2), [p3] "{s[66:67]}"(p3), [p4] "{s[68:69]}"(p4), [p5] "{s[70:71]}"(p5),
                    [p6] "{s[72:73]}"(p6), [p7] "{s[74:75]}"(p7), [p8] "{s[76:77]}"(p8), [p9] "{s[78:79]}"(p9)
                  : OMH_GEMM_W64_CLOBBERS);
+        else if (KIND == K_QKV) {
+            // (neither stream reads the gate descriptors: rbias stands in for them, so that they cost no SGPRs here)
+            if (t.n0 < p.n_split) {
+                asm volatile(OMH_GEMM_W64_ASM_BF16
+                     :
+                     : [xab] "v"(xab), [wab] "v"(wab), [xh] "v"(xh), [vox0] "v"(vox0), [vox1] "v"(vox1), [vow0] "v"(vow0),
+                       [vow1] "v"(vow1), [voc] "v"(voc), [vlane] "v"(vlane), [ra] "s"(ra), [rb] "s"(rb), [rc] "s"(rc),
+                       [rbias] "s"(rbias), [rg0] "s"(rbias), [rg1] "s"(rbias), [p0] "{s[60:61]}"(p0), [p1] "{s[62:63]}"(p1),
+                       [p2] "{s[64:65]}"(p2), [p3] "{s[66:67]}"(p3), [p4] "{s[68:69]}"(p4), [p5] "{s[70:71]}"(p5),
+                       [p6] "{s[72:73]}"(p6), [p7] "{s[74:75]}"(p7), [p8] "{s[76:77]}"(p8), [p9] "{s[78:79]}"(p9)
+                     : OMH_GEMM_W64_CLOBBERS);
+            } else {
+                const int left = p.M - mw;                                  // rows of the wave's patch inside M
+                const uint64_t p3v = pack2(nk, (uint32_t)(((int64_t)(nw - p.n_split) * p.ldaux + mw) * 2));
+                const uint64_t p4v = pack2((uint32_t)(32 * p.ldaux * 2), (uint32_t)p.N);
+                const uint64_t p5v = pack2((uint32_t)(left > 0 ? left : 0), 0u);
+                asm volatile(OMH_GEMM_W64_ASM_BF16VT
+                     :
+                     : [xab] "v"(xab), [wab] "v"(wab), [xh] "v"(xh), [vox0] "v"(vox0), [vox1] "v"(vox1), [vow0] "v"(vow0),
+                       [vow1] "v"(vow1), [vlane] "v"(vlane), [ra] "s"(ra), [rb] "s"(rb),
+                       [rc] "s"(rvt), [rbias] "s"(rbias), [rg0] "s"(rbias), [rg1] "s"(rbias),
+                       [p0] "{s[60:61]}"(p0), [p1] "{s[62:63]}"(p1),
+                       [p2] "{s[64:65]}"(p2), [p3] "{s[66:67]}"(p3v), [p4] "{s[68:69]}"(p4v), [p5] "{s[70:71]}"(p5v),
+                       [p6] "{s[72:73]}"(p6), [p7] "{s[74:75]}"(p7), [p8] "{s[76:77]}"(p8), [p9] "{s[78:79]}"(p9)
+                     : OMH_GEMM_W64_CLOBBERS);
+            }
+        }
         else if (KIND == K_F32_192) OMH_GW64_RUN(OMH_GEMM_W64_ASM_F32_192);
         else if (KIND == K_BF16_192) OMH_GW64_RUN(OMH_GEMM_W64_ASM_BF16_192);
         else
@@ -205,7 +241,7 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
 
 template <int KIND>
 int launch_w64(const omh_gemm_args& a, hipStream_t stream, const W64Split sp = W64Split{1, 0u, 0u}) {
-    constexpr int TNW = KIND >= K_RESID192 ? TN192 : TN;
+    constexpr int TNW = is_n192(KIND) ? TN192 : TN;
     const int tiles_m = (a.M + TM - 1) / TM, tiles_n = (a.N + TNW - 1) / TNW;
     const int total = tiles_m * tiles_n * sp.n;
     static int ncu = 0;
@@ -269,6 +305,20 @@ bool omh_gemm_w64_n192_takes(const omh_gemm_args& a) {
 int omh_launch_gemm_w64_n192(const omh_gemm_args& a, hipStream_t stream) {
     return a.epilogue == OMH_EPI_F32 ? launch_w64<K_F32_192>(a, stream) : launch_w64<K_BF16_192>(a, stream);
 }
+
+// The fused q | k | v projection (OMH_EPI_BF16_SPLIT_T, ABI v10): one launch over N = 3 dim columns; tiles below n_split
+// run the BF16 stream into C, tiles from n_split on run the operand-swapped stream and store their result transposed
+// into aux (V^T [dim, ld]).  h is read once and 128 x 12 = 1 536 tiles are six whole rounds of the chip where the
+// separate V^T launch had 516 tiles of 256 x 384 = two rounds + four tiles (or three rounds of 256 x 256).
+bool omh_gemm_w64_qkv_takes(const omh_gemm_args& a) {
+    if (a.epilogue != OMH_EPI_BF16_SPLIT_T || !a.aux || a.n_split <= 0 || a.n_split >= a.N) return false;
+    if ((a.n_split % TN) || (a.M & 7) || a.ldaux < a.M || (a.ldaux & 7) || ((uintptr_t)a.aux & 15)) return false;
+    if ((int64_t)(a.N - a.n_split) * a.ldaux * 2 >= 0x7fffffffLL) return false;
+    omh_gemm_args b = a;
+    b.epilogue = OMH_EPI_BF16; b.aux = nullptr;
+    return omh_gemm_w64_takes(b);
+}
+int omh_launch_gemm_w64_qkv(const omh_gemm_args& a, hipStream_t stream) { return launch_w64<K_QKV>(a, stream); }
 
 int omh_launch_gemm_w64(const omh_gemm_args& a, hipStream_t stream) {
     switch (a.epilogue) {

@@ -115,12 +115,16 @@ def frag_reads(stage, kk, buf):
     return out
 
 
+SWAP = False                    # "bf16vt": activations in the MFMA A slot, weights in the B slot -> a lane holds 4 consecutive m
+
+
 def group_mfmas(buf, first=False):
     out = []
     for i in range(NI):
         for j in range(NJ):
             c = "0" if first else acc(i, j)
-            out.append(("m", f"v_mfma_f32_32x32x16_bf16 {acc(i, j)}, {vr(wfrag(buf, i), 4)}, {vr(xfrag(buf, j), 4)}, {c}",
+            a_, b_ = (xfrag(buf, j), wfrag(buf, i)) if SWAP else (wfrag(buf, i), xfrag(buf, j))
+            out.append(("m", f"v_mfma_f32_32x32x16_bf16 {acc(i, j)}, {vr(a_, 4)}, {vr(b_, 4)}, {c}",
                         [f"W{buf}.{i}", f"X{buf}.{j}"]))
     return out
 
@@ -759,15 +763,72 @@ def epilogue_resid192(e):
             e("s_mov_b64 exec, s[86:87]")
 
 
+def epilogue_vt(e):
+    """C^T bf16: out[n][m] = bf16(acc + bias[n]) — the V third of the fused q | k | v projection (model.py:144-146,
+    152-153: V^T [d, S] is what the attention kernel reads).  The main loop ran with the MFMA operands swapped (SWAP), so
+    after the permlane widening lane (r, h) holds, per accumulator tile (i, j) and run p, the 8 ROWS m = 32 j + 16 p +
+    8 h .. of COLUMN n = 32 i + r of the wave's patch: 16 contiguous bytes of output row n.  S_SCB = the origin of the
+    WAVE's patch in the output ((first n) * ld + first m) * 2, S_SCJ = 32 * ld * 2 (one i step; the lane adds r * ld * 2 + 16 h),
+    S_MB = rows m left from the wave's first row (runs at or past it are masked: they would land in the pad columns),
+    output rows past N fall outside the descriptor.  The bias is per lane: six registers (one per i)."""
+    VBM, VOCT = "v15", "v16"
+    e(f"v_and_b32 {VBM}, 31, %[vlane]")
+    e(f"v_lshlrev_b32 {VBM}, 2, {VBM}")                          # 4 r: the lane's bias offset inside the wave's columns
+    for i in range(NI):                # older than the next tile's prologue DMA: column_vectors' wait covers them
+        e(f"buffer_load_dword v{RBM + i}, {VBM}, %[rbias], {S_COL0} offen offset:{i * 128}")
+    column_vectors(e, "bf16")
+    V8H, RB2 = "v14", 96                                         # v[96:107]: the lane's bias as a register PAIR per i
+    e(f"v_lshrrev_b32 {V8H}, 2, {VH}")                           # 8 h
+    # the lane's output offset: r rows of the output (pitch = S_SCJ / 32 bytes) + 8 h columns of 2 bytes
+    e(f"s_lshr_b32 s88, {S_SCJ}, 5")
+    e(f"v_and_b32 {VOCT}, 31, %[vlane]")
+    e(f"v_mul_lo_u32 {VOCT}, {VOCT}, s88")
+    e(f"v_lshl_add_u32 {VOCT}, {V8H}, 1, {VOCT}")
+    for i in range(NI):
+        e(f"v_mov_b32 v{RB2 + 2 * i}, v{RBM + i}")
+        e(f"v_mov_b32 v{RB2 + 2 * i + 1}, v{RBM + i}")
+    for n in range(NTILES):
+        j, i = divmod(n, NI)
+        t = i * NJ + j
+        e(f"s_mul_i32 s85, {S_SCJ}, {i}")
+        e(f"s_add_u32 s85, s85, {S_SCB}")
+        for r_ in range(16):
+            if t < 16:
+                e(f"v_accvgpr_read_b32 v{T + r_}, a{t * 16 + r_}")
+            else:
+                e(f"v_mov_b32 v{T + r_}, v{128 + (t - 16) * 16 + r_}")
+        e("s_nop 1")
+        for q0 in (0, 2):                                        # quads (0,1), (2,3) -> two runs of 8 consecutive m
+            for r_ in range(4):
+                e(f"v_permlane32_swap_b32 v{T + 4 * q0 + r_}, v{T + 4 * (q0 + 1) + r_}")
+        for p in range(2):
+            v0 = T + 8 * p
+            e(f"v_add_u32 v{VCOLT}, {32 * j + 16 * p}, {V8H}")
+            e(f"v_cmp_gt_u32 vcc, {S_MB}, v{VCOLT}")
+            e("s_and_saveexec_b64 s[86:87], vcc")
+            for r_ in range(0, 8, 2):
+                e(f"v_pk_add_f32 {vr(v0 + r_, 2)}, {vr(v0 + r_, 2)}, {vr(RB2 + 2 * i, 2)}")
+            for r_ in range(4):
+                e(f"v_cvt_pk_bf16_f32 v{v0 + r_}, v{v0 + 2 * r_}, v{v0 + 2 * r_ + 1}")
+            e(f"buffer_store_dwordx4 {vr(v0, 4)}, {VOCT}, %[rc], s85 offen offset:{(32 * j + 16 * p) * 2}")
+            e("s_nop 1")
+            e("s_mov_b64 exec, s[86:87]")
+
+
 # VMEM instructions PER ACCUMULATOR TILE an epilogue issues after the next tile's prologue DMA (the k loop's first wait
 # counts them: an over-estimate would let k tile 0 be read before it has landed)
-EPI_VMEM_TILE = {"f32": 4, "bf16": 2, "gelu": 2, "geluaux": 4, "resid": 8, "resid192": 6, "gelubwd": 4, "bf16m": 2}
+EPI_VMEM_TILE = {"f32": 4, "bf16": 2, "gelu": 2, "geluaux": 4, "resid": 8, "resid192": 6, "gelubwd": 4, "bf16m": 2, "bf16vt": 2}
 
 
 def generate(kind, tag=None):
+    global SWAP
     e = Emit(tag or kind)
+    SWAP = kind == "bf16vt"
     main_loop(e, EPI_VMEM_TILE[kind] * NTILES, cpre=(kind == "resid192"))
-    if kind == "resid":
+    SWAP = False
+    if kind == "bf16vt":
+        epilogue_vt(e)
+    elif kind == "resid":
         epilogue_resid(e)
     elif kind == "resid192":
         epilogue_resid192(e)
@@ -788,7 +849,7 @@ def first_prologue(tag="pro"):
 
 def main():
     print("// GENERATED by gen_gemm_w64.py — do not edit; edit the generator.")
-    streams = [("PRO", first_prologue())] + [(kind.upper(), generate(kind)) for kind in KINDS + ("gelubwd", "bf16m", "geluaux")]
+    streams = [("PRO", first_prologue())] + [(kind.upper(), generate(kind)) for kind in KINDS + ("gelubwd", "bf16m", "geluaux", "bf16vt")]
     configure(3)                                                 # the 256 x 192 gated-residual stream (old C prefetched)
     streams += [("PRO192", first_prologue("pro192")), ("RESID192", generate("resid192")),
                 ("F32_192", generate("f32", "f32n3")), ("BF16_192", generate("bf16", "bf16n3"))]

@@ -10,8 +10,8 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (ATTN_ALLOW_SPLIT, ATTN_SHORT_KERNEL, BIAS_M, BIAS_N, BIAS_NONE, EPI_BF16, EPI_F32, EPI_F32_ACCUM, EPI_GELU_BF16, EPI_GELU_BWD_BF16,
-                   EPI_GELU_ERF_BF16, EPI_RESID, AttnArgs, GemmArgs, OmhError, check, lib)
+from ._lib import (ATTN_ALLOW_SPLIT, ATTN_SHORT_KERNEL, BIAS_M, BIAS_N, BIAS_NONE, EPI_BF16, EPI_BF16_SPLIT_T, EPI_F32, EPI_F32_ACCUM, EPI_GELU_BF16,
+                   EPI_GELU_BWD_BF16, EPI_GELU_ERF_BF16, EPI_RESID, AttnArgs, GemmArgs, OmhError, check, lib)
 
 __all__ = ["gemm", "flash_attn", "layernorm_modulate", "rmsnorm_rope", "cast_bf16", "patchify", "unpatchify",
            "dense_f32", "sinusoidal_embedding", "cfg_unipc_step", "conv_cl", "rms_silu_cl", "nchw_to_cl", "cl_to_nchw",
@@ -49,14 +49,15 @@ def ptr(t: torch.Tensor, elem_off: int = 0):
 
 def gemm_raw(A, B, Cp, M, N, K, lda, ldb, ldc, epilogue, bias=None, bias_mode=BIAS_NONE, batch=1,
              strideA=0, strideB=0, strideC=0, gate0=None, gate1=None, gate1_stride=0, gate_rows=1,
-             gate_const=0.0, b_kmajor=False, c_in=None, aux=None, ldaux=0, split_k=False):
+             gate_const=0.0, b_kmajor=False, c_in=None, aux=None, ldaux=0, split_k=False, n_split=0):
     """C[m][n] = epi(sum_k A[m][k] B[n][k])  (b_kmajor: B[k][n], [K, N] row-major); all pointers are c_void_p.
     ``c_in`` / ``aux`` / ``ldaux``: the fused training epilogues of include/omh.h (ABI v5).  ``split_k``: hand the
     library a workspace so that it may cut a few-row, long contraction into slices (ABI v9: the FFN-down projection and
     the FFN-up input gradient at one or two clips; another fp32 summation order than the unsplit kernels, so only
-    callers that do not need batch-invariant bits for that product ask for it)."""
+    callers that do not need batch-invariant bits for that product ask for it).  ``n_split`` (EPI_BF16_SPLIT_T, ABI v10):
+    columns from n_split on go transposed to ``aux`` (row pitch ``ldaux``) — the fused q | k | v projection."""
     a = GemmArgs(A, B, Cp, M, N, K, lda, ldb, ldc, batch, strideA, strideB, strideC, epilogue, bias_mode, bias,
-                 gate0, gate1, gate1_stride, gate_rows, gate_const, int(b_kmajor), c_in, aux, ldaux, None, 0)
+                 gate0, gate1, gate1_stride, gate_rows, gate_const, int(b_kmajor), c_in, aux, ldaux, None, 0, int(n_split))
     ws = None
     # (the library's own rule again below; this is only to skip the query where it cannot say anything but 0)
     if split_k and K >= 4096 and batch == 1 and ((M + 255) // 256) * ((N + 191) // 192) <= 128:

@@ -33,6 +33,7 @@ from .._backend import ops
 
 BIAS_M, BIAS_N, BIAS_NONE = ops.BIAS_M, ops.BIAS_N, ops.BIAS_NONE
 EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID = ops.EPI_BF16, ops.EPI_F32, ops.EPI_GELU_BF16, ops.EPI_RESID
+EPI_BF16_SPLIT_T = ops.EPI_BF16_SPLIT_T
 ptr = ops.ptr
 
 __all__ = ["WanModel"]
@@ -176,6 +177,13 @@ class WanSelfAttention(nn.Module):
             _bf16(torch.cat([self.q.weight.detach(), self.k.weight.detach()], 0)),
             torch.cat([self.q.bias.detach(), self.k.bias.detach()], 0).float().contiguous()))
 
+    def _w_qkv(self):
+        return self._packed.get("qkv", (self.q.weight, self.k.weight, self.v.weight, self.q.bias, self.k.bias, self.v.bias),
+                                lambda: (_bf16(torch.cat([self.q.weight.detach(), self.k.weight.detach(),
+                                                          self.v.weight.detach()], 0)),
+                                         torch.cat([self.q.bias.detach(), self.k.bias.detach(), self.v.bias.detach()],
+                                                   0).float().contiguous()))
+
     def _w(self, name):
         lin = getattr(self, name)
         return self._packed.get(name, (lin.weight, lin.bias),
@@ -189,11 +197,24 @@ class WanSelfAttention(nn.Module):
         """h bf16 [B*S, dim] -> attention output bf16 [B*S, dim] (before o-proj)."""
         B, S, d, N, D = fc.B, fc.S, self.dim, self.num_heads, self.head_dim
         R = B * S
-        wqk, bqk = self._w_qk()
         # q|k projection kept in bf16 (fp32 accumulate): the normalisation statistics are taken in fp32 from
         # it; measured effect on the 30-layer output < 1e-3 relative RMS, and it halves this step's traffic
         qk = torch.empty(R, 2 * d, dtype=torch.bfloat16, device=h.device)
-        ops.gemm_raw(ptr(h), ptr(wqk), ptr(qk), R, 2 * d, d, d, d, 2 * d, EPI_BF16, bias=ptr(bqk), bias_mode=BIAS_N)
+        Sp = _round_up(S, 64)
+        vt = torch.empty(B, d, Sp, dtype=torch.bfloat16, device=h.device)
+        if Sp != S:
+            vt[:, :, S:].zero_()                       # pad columns only (0 x P = 0 needs them finite); the GEMM writes the rest
+        # one clip of a long sequence: q | k | v as ONE product over the concatenated weights (ABI v10) — h is read once,
+        # the V third leaves the kernel transposed (V^T [dim, Sp], what the attention kernel reads); the same bits as the
+        # two products below, which short sequences / batches keep (their rows fill the chip only together)
+        fused = B == 1 and S >= 8192 and S % 8 == 0
+        if fused:
+            wqkv, bqkv = self._w_qkv()
+            ops.gemm_raw(ptr(h), ptr(wqkv), ptr(qk), R, 3 * d, d, d, d, 2 * d, EPI_BF16_SPLIT_T, bias=ptr(bqkv),
+                         bias_mode=BIAS_N, aux=ptr(vt), ldaux=Sp, n_split=2 * d)
+        else:
+            wqk, bqk = self._w_qk()
+            ops.gemm_raw(ptr(h), ptr(wqk), ptr(qk), R, 2 * d, d, d, d, 2 * d, EPI_BF16, bias=ptr(bqk), bias_mode=BIAS_N)
         q = torch.empty(R, d, dtype=torch.bfloat16, device=h.device)
         k = torch.empty(R, d, dtype=torch.bfloat16, device=h.device)
         # q leaves the norm kernel already multiplied by softmax_scale * log2(e) (attention.py:96-127), in fp32
@@ -205,14 +226,11 @@ class WanSelfAttention(nn.Module):
                                        ptr(fc.rope_sin), fc.rope_cos.shape[0], D, ptr(fc.grid32), S, out_scale0=q_scale,
                                        out_scale1=1.0)
         del qk
-        # V^T[b] = Wv h_b^T + bv  ->  [B, dim, Sp]   (pad columns stay zero)
-        Sp = _round_up(S, 64)
-        wv, bv = self._w("v")
-        vt = torch.empty(B, d, Sp, dtype=torch.bfloat16, device=h.device)
-        if Sp != S:
-            vt[:, :, S:].zero_()                       # pad columns only (0 x P = 0 needs them finite); the GEMM writes the rest
-        ops.gemm_raw(ptr(wv), ptr(h), ptr(vt), d, S, d, d, d, Sp, EPI_BF16, bias=ptr(bv), bias_mode=BIAS_M, batch=B,
-                     strideA=0, strideB=S * d, strideC=d * Sp)
+        if not fused:
+            # V^T[b] = Wv h_b^T + bv  ->  [B, dim, Sp]   (pad columns stay zero)
+            wv, bv = self._w("v")
+            ops.gemm_raw(ptr(wv), ptr(h), ptr(vt), d, S, d, d, d, Sp, EPI_BF16, bias=ptr(bv), bias_mode=BIAS_M, batch=B,
+                         strideA=0, strideB=S * d, strideC=d * Sp)
         o = torch.empty(R, d, dtype=torch.bfloat16, device=h.device)
         ops.flash_attn_raw(ptr(q), ptr(k), ptr(vt), ptr(o), ptr(fc.seq_lens32), B, N, S, S, S * d, d, S * d, d,
                            d * Sp, S * d, d, Sp, D ** -0.5, q_prescaled=1)

@@ -229,10 +229,29 @@ def test_batch_invariant_flag_pins_the_summation_order(wan_model_mod):
     assert m.batch_invariant is False
     alone = m([x0], t1, [c0], 1560)[0]
     both = m([x0, x1], t2, [c0, c1], 1560)[0]
-    assert rel_rms(both, alone) < 1e-3
+    assert rel_rms(both, alone) < 4e-3            # another fp32 summation order flips bf16 roundings downstream: bf16 noise
     assert not torch.equal(both, alone), "the default takes the k slices: 4 for one clip, 2 for two"
     m.batch_invariant = True
     alone_i = m([x0], t1, [c0], 1560)[0]
     both_i = m([x0, x1], t2, [c0, c1], 1560)[0]
     assert torch.equal(both_i, alone_i)
-    assert rel_rms(alone_i, alone) < 1e-3
+    assert rel_rms(alone_i, alone) < 4e-3
+
+
+def test_fused_qkv_projection_in_the_forward_changes_no_bit(wan_model_mod):
+    """One clip of a long sequence takes q | k | v as ONE product (OMH_EPI_BF16_SPLIT_T, V^T written transposed by the
+    stream); GEMM_QKV = 0 routes the same call through the two separate products: the forward must not move by a bit."""
+    torch.manual_seed(9)
+    m = wan_model_mod.WanModel(dim=1536, ffn_dim=8960, num_heads=12, num_layers=2, text_dim=4096, text_len=512,
+                               freq_dim=256)
+    with torch.no_grad():
+        torch.nn.init.xavier_uniform_(m.head.head.weight)
+    m = m.cuda().eval().requires_grad_(False)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.randn(16, 6, 60, 104, device="cuda", generator=g)          # S = 9 360 >= the fused path's threshold
+    c = torch.randn(50, 4096, device="cuda", generator=g)
+    t = torch.tensor([300.0], device="cuda")
+    fused = m([x], t, [c], 9360)[0]
+    set_option("GEMM_QKV", "0")
+    plain = m([x], t, [c], 9360)[0]
+    assert torch.isfinite(fused).all() and torch.equal(fused, plain)

@@ -383,6 +383,45 @@ def test_gemm_w64_is_the_default_on_the_large_shapes(ops, monkeypatch):
     assert torch.equal(d, ops.gemm(a, w))
 
 
+@pytest.mark.parametrize("M,d,K", [(520, 384, 384), (1032, 768, 512), (32760, 1536, 1536), (8200, 1536, 1536)])
+def test_gemm_fused_qkv_projection_with_transposed_v(ops, M, d, K):
+    """ABI v10, OMH_EPI_BF16_SPLIT_T: q | k | v as ONE product over the concatenated weights on the 256 x 384 stream —
+    columns below n_split = 2 d to C (the BF16 stream), the V third through the operand-swapped stream, stored TRANSPOSED
+    into V^T [d, ld] with a per-row bias.  Bit for bit against the two products it replaces (GEMM_QKV = 0 routes the
+    same call through them), against fp32 arithmetic, ragged M (rows past M never written: the pad columns of V^T and
+    the guard rows of q | k keep their sentinel), several tiles per persistent workgroup at the real size."""
+    torch.manual_seed(M + d)
+    h = _bf(torch.randn(M, K, device="cuda"))
+    w = _bf(torch.randn(3 * d, K, device="cuda") / math.sqrt(K))
+    bias = torch.randn(3 * d, device="cuda")
+    ld = (M + 63) // 64 * 64 + 64
+
+    def run(mode):
+        set_option("GEMM_QKV", mode)
+        qk = torch.full((M + 8, 2 * d), 7.0, dtype=torch.bfloat16, device="cuda")
+        vt = torch.full((d + 8, ld), 7.0, dtype=torch.bfloat16, device="cuda")
+        ops.gemm_raw(ops.ptr(h), ops.ptr(w), ops.ptr(qk), M, 3 * d, K, K, K, 2 * d, ops.EPI_BF16_SPLIT_T, bias=ops.ptr(bias),
+                     bias_mode=ops.BIAS_N, aux=ops.ptr(vt), ldaux=ld, n_split=2 * d)
+        return qk, vt
+    got, again, old = run("1"), run("1"), run("0")
+    dflt = run(None)
+    for a_, b_ in ((got, again), (got, old), (got, dflt)):
+        assert torch.equal(a_[0], b_[0]) and torch.equal(a_[1], b_[1])
+    qk, vt = got
+    assert float((qk[M:].float() - 7.0).abs().max()) == 0 and float((vt[:d, M:].float() - 7.0).abs().max()) == 0
+    assert float((vt[d:].float() - 7.0).abs().max()) == 0
+    ref = h.float() @ w.float().t() + bias
+    assert rel_rms(qk[:M].float(), ref[:, :2 * d]) < 4e-3
+    assert rel_rms(vt[:d, :M].float(), ref[:, 2 * d:].t()) < 4e-3
+    # without a bias
+    set_option("GEMM_QKV", "1")
+    qk2 = torch.empty(M, 2 * d, dtype=torch.bfloat16, device="cuda")
+    vt2 = torch.zeros(d, ld, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_raw(ops.ptr(h), ops.ptr(w), ops.ptr(qk2), M, 3 * d, K, K, K, 2 * d, ops.EPI_BF16_SPLIT_T, aux=ops.ptr(vt2),
+                 ldaux=ld, n_split=2 * d)
+    assert rel_rms(vt2[:, :M].float(), (h.float() @ w.float().t())[:, 2 * d:].t()) < 4e-3
+
+
 def _attn_ref(q, k, v, k_lens, scale):
     B, Lq, H, D = q.shape
     out = torch.zeros(B, Lq, H, D, device=q.device)
