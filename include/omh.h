@@ -604,6 +604,11 @@ int omh_adamw_pack_multi(const int64_t* table, int32_t n_entries, int64_t total_
                          float eps, float weight_decay, int32_t step, float grad_scale, omh_stream_t stream);
 /* EMA of the weights, ema = decay*ema + (1-decay)*p (distilled_trainer.py:319-334). */
 int omh_ema_update(float* ema, const float* p, int64_t n, float decay, omh_stream_t stream);
+/* ABI v10: the same update for every parameter of a model in ONE launch (the loop of distilled_trainer.py:319-334 is
+ * ~825 tensors for Wan2.1-1.3B).  table: DEVICE array of n_entries x 4 int64 {ema, p (fp32), numel, first_chunk}, one
+ * workgroup per 4096-element chunk, first_chunk = running sum of ceil(numel / 4096); total_chunks = its final value.
+ * Same arithmetic per element as omh_ema_update. */
+int omh_ema_update_multi(const int64_t* table, int32_t n_entries, int64_t total_chunks, float decay, omh_stream_t stream);
 
 /* ========================================================================
  * Prompt-side encoders (run once per prompt): the umT5 text encoder of seaweed_apt/wan/modules/t5.py:272-322 and

@@ -220,6 +220,7 @@ _SIGS = {
     "omh_adamw_multi": (i32, [vp, i32, f32, f32, f32, f32, f32, i32, f32, vp]),
     "omh_adamw_pack_multi": (i32, [vp, i32, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
     "omh_ema_update": (i32, [vp, vp, i64, f32, vp]),
+    "omh_ema_update_multi": (i32, [vp, i32, i64, f32, vp]),
     "omh_pack_weights_multi": (i32, [vp, i32, i64, vp]),
     "omh_gather_rows_f32": (i32, [vp, vp, vp, i64, i32, i64, vp]),
     "omh_gather_rows_bf16": (i32, [vp, vp, vp, i64, i32, i64, vp]),

@@ -50,6 +50,37 @@ void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, int64_t n,
         ema[i] = ema[i] * decay + p[i] * (1.0f - decay);
 }
 
+// all parameters of a model in ONE launch (distilled_trainer.py:319-334 is a Python loop over ~825 tensors): table[t] =
+// {ema, p, numel, first chunk} (device int64 x 4), one workgroup per 4096-element chunk, binary search for its tensor;
+// ema_kernel's arithmetic on every element (same bits)
+__global__ __launch_bounds__(256)
+void ema_multi_kernel(const int64_t* __restrict__ table, int n_entries, float decay) {
+    const int64_t t = blockIdx.x;
+    int lo = 0, hi = n_entries - 1;                               // last entry whose first chunk is <= t
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[(int64_t)mid * 4 + 3] <= t) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* e = table + (int64_t)lo * 4;
+    float* ema = (float*)e[0];
+    const float* p = (const float*)e[1];
+    const int64_t n = e[2], i0 = (t - e[3]) * 4096;
+    const int64_t i1 = i0 + 4096 < n ? i0 + 4096 : n;
+    if (((((uintptr_t)ema) | ((uintptr_t)p)) & 15) == 0) {
+        for (int64_t i = i0 + 4 * (int64_t)threadIdx.x; i + 3 < i1; i += 1024) {
+            float4 a = *(const float4*)(ema + i);
+            const float4 b = *(const float4*)(p + i);
+            a.x = a.x * decay + b.x * (1.0f - decay); a.y = a.y * decay + b.y * (1.0f - decay);
+            a.z = a.z * decay + b.z * (1.0f - decay); a.w = a.w * decay + b.w * (1.0f - decay);
+            *(float4*)(ema + i) = a;
+        }
+        for (int64_t i = i0 + ((i1 - i0) & ~(int64_t)3) + threadIdx.x; i < i1; i += 256)
+            ema[i] = ema[i] * decay + p[i] * (1.0f - decay);
+    } else {
+        for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) ema[i] = ema[i] * decay + p[i] * (1.0f - decay);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- weight packing
 // After an optimizer step every bf16 operand copy of the fp32 master weights is stale.  The training step used to
 // rebuild them per block with ~20 small cast / transpose launches (11 600 transposes + 8 200 casts per bench run);
@@ -292,6 +323,15 @@ extern "C" int omh_ema_update(float* ema, const float* p, int64_t n, float decay
     if (!ema || !p || n <= 0) return OMH_E_BADARG;
     omh_clear_status();
     hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, ema, p, n, decay);
+    return omh_launch_status();
+}
+
+extern "C" int omh_ema_update_multi(const int64_t* table, int32_t n_entries, int64_t total_chunks, float decay,
+                                    omh_stream_t stream) {
+    if (!table || n_entries <= 0 || total_chunks <= 0 || total_chunks > 0x7fffffffLL) return OMH_E_BADARG;
+    omh_clear_status();
+    hipLaunchKernelGGL(ema_multi_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)stream, table, n_entries,
+                       decay);
     return omh_launch_status();
 }
 

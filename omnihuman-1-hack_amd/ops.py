@@ -775,6 +775,13 @@ def ema_update(ema, p, decay):
     check(lib.omh_ema_update(_p(ema), _p(p), p.numel(), decay, _stream()), "omh_ema_update")
 
 
+def ema_update_multi(table, n_entries, total_chunks, decay):
+    """table: device int64 [n, 4] = {ema, p, numel, first 4096-element chunk} (include/omh.h: omh_ema_update_multi)."""
+    _dev(table)
+    check(lib.omh_ema_update_multi(_p(table), int(n_entries), int(total_chunks), float(decay), _stream()),
+          "omh_ema_update_multi")
+
+
 # ----------------------------------------------------------------------------- prompt-side encoders (t5.py / clip.py)
 import os as _os
 _CHECK_IDS = _os.environ.get("OMH_CHECK_IDS", "1") != "0"

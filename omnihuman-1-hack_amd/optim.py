@@ -106,9 +106,40 @@ class AdamW(torch.optim.Optimizer):
         return loss
 
 
+_EMA_TABLES = {}
+
+
 @torch.no_grad()
 def update_ema_model(ema_model, model, decay):
-    """distilled_trainer.py:319-334 without the GPU->CPU round trip (the EMA copy lives in HBM)."""
+    """distilled_trainer.py:319-334 without the GPU->CPU round trip (the EMA copy lives in HBM), and as ONE launch for all
+    parameters (omh_ema_update_multi) instead of one per tensor; the pointer table is rebuilt only when an address or a
+    size changes."""
+    rows, touched, keep = [], [], []
+    dev = None
     for target, source in zip(ema_model.parameters(), model.parameters()):
-        ops.ema_update(target.data, source.data.to(target.device), decay)
-        torch.autograd.graph.increment_version(target)
+        src = source.data
+        if src.device != target.device or src.dtype != torch.float32 or not src.is_contiguous():
+            src = src.to(device=target.device, dtype=torch.float32).contiguous()
+            keep.append(src)
+        if target.dtype != torch.float32 or not target.is_contiguous() or target.numel() == 0:
+            if target.numel():
+                ops.ema_update(target.data, src, decay)             # an odd one out: its own launch
+                touched.append(target)
+            continue
+        dev = target.device
+        rows.append((target.data_ptr(), src.data_ptr(), target.numel()))
+        touched.append(target)
+    if rows:
+        key = (id(ema_model), id(model))
+        ent = _EMA_TABLES.get(key)
+        if ent is None or ent[0] != rows:
+            full, chunk0 = [], 0
+            for t_, s_, n_ in rows:
+                full.append([t_, s_, n_, chunk0])
+                chunk0 += (n_ + 4095) // 4096
+            ent = _EMA_TABLES[key] = (rows, torch.tensor(full, dtype=torch.int64).to(dev), chunk0)
+            if len(_EMA_TABLES) > 8:
+                _EMA_TABLES.pop(next(iter(_EMA_TABLES)))
+        ops.ema_update_multi(ent[1], len(rows), ent[2], decay)
+    if touched:
+        torch.autograd.graph.increment_version(touched)

@@ -204,14 +204,16 @@ class WanSelfAttention(nn.Module):
         vt = torch.empty(B, d, Sp, dtype=torch.bfloat16, device=h.device)
         if Sp != S:
             vt[:, :, S:].zero_()                       # pad columns only (0 x P = 0 needs them finite); the GEMM writes the rest
-        # one clip of a long sequence: q | k | v as ONE product over the concatenated weights (ABI v10) — h is read once,
+        # long sequences: q | k | v as ONE product per clip over the concatenated weights (ABI v10) — h is read once,
         # the V third leaves the kernel transposed (V^T [dim, Sp], what the attention kernel reads); the same bits as the
         # two products below, which short sequences / batches keep (their rows fill the chip only together)
-        fused = B == 1 and S >= 8192 and S % 8 == 0
+        fused = S >= 8192 and S % 8 == 0
         if fused:
             wqkv, bqkv = self._w_qkv()
-            ops.gemm_raw(ptr(h), ptr(wqkv), ptr(qk), R, 3 * d, d, d, d, 2 * d, EPI_BF16_SPLIT_T, bias=ptr(bqkv),
-                         bias_mode=BIAS_N, aux=ptr(vt), ldaux=Sp, n_split=2 * d)
+            for b in range(B):                         # one launch per clip: V^T is [B, dim, Sp], a clip's rows fill the chip
+                ops.gemm_raw(ptr(h, b * S * d), ptr(wqkv), ptr(qk, b * S * 2 * d), S, 3 * d, d, d, d, 2 * d,
+                             EPI_BF16_SPLIT_T, bias=ptr(bqkv), bias_mode=BIAS_N, aux=ptr(vt, b * d * Sp), ldaux=Sp,
+                             n_split=2 * d)
         else:
             wqk, bqk = self._w_qk()
             ops.gemm_raw(ptr(h), ptr(wqk), ptr(qk), R, 2 * d, d, d, d, 2 * d, EPI_BF16, bias=ptr(bqk), bias_mode=BIAS_N)

@@ -226,7 +226,11 @@ class _ConvState:
     # convolution: 2 frames x 35 layers x 21 chunks — 6.6 % of the VAE's GPU time in `__amd_rocclr_copyBuffer`,
     # profiles/r01_v7_kernel_stats_full_bench.csv.)  Window size: 8 chunks, capped at OMH_VAE_WINDOW_MB (default
     # 1024) per layer — 288 GB of HBM make that an easy trade.
+    # fp32-faithful mode: a frame is three channel blocks (480x832 x 288 channels = 230 MB), 1 GB would be a window of
+    # [history | one chunk] and the history would be copied back after EVERY convolution (982 copies = 3.6 % of a decode,
+    # profiles/r05_vae_fp32_kernel_stats.csv): 8 GB per layer there — 288 GB of HBM make that an easy trade too.
     _WINDOW_BYTES = int(os.environ.get("OMH_VAE_WINDOW_MB", "1024")) << 20
+    _WINDOW_BYTES_F32 = int(os.environ.get("OMH_VAE_WINDOW_F32_MB", "8192")) << 20
 
     def slot(self, T, H, W, device):
         """View [T, H, W, Cin] the producer writes the current chunk into."""
@@ -235,7 +239,8 @@ class _ConvState:
         if fresh or self.buf.shape[0] < need:
             old, old_off = (None, 0) if fresh else (self.buf, self.off)
             frame_bytes = H * W * self.Cin * 2
-            cap = need if not self.hist else max(need, min(self.hist + 8 * max(T, 4), self._WINDOW_BYTES // frame_bytes))
+            window = self._WINDOW_BYTES_F32 if self.f32 else self._WINDOW_BYTES
+            cap = need if not self.hist else max(need, min(self.hist + 8 * max(T, 4), window // frame_bytes))
             self.buf = torch.empty(cap, H, W, self.Cin, dtype=torch.bfloat16, device=device)
             self.off = 0
             if self.hist:

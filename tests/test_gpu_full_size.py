@@ -566,3 +566,115 @@ def test_gradient_accumulation_full_size_in_place_equals_autograd(clips):
     print(f"[measured] accumulation cycle at 1.3B, {clips} clip(s): block matrices bit-identical to autograd's accumulation, "
           f"worst 1-D / embedding / head difference {worst:.2e}")
     assert worst < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The headline configuration end to end against the REFERENCE ("weak" 1 / item 4): golden vectors of
+# oracle/make_golden_full_size.py — the real WanModel.forward (model.py:502-563) at S = 32 760 with all 30 layers, and
+# 50-step CFG trajectories driven as text2video.py:206-252 drives them, on detgen weights / inputs regenerated here.
+# Bounds = 2 x the figures measured on MI355X (profiles/r05_full_forward_parity.json).
+TOL_HEADLINE_FORWARD = 1.4e-2        # 30 layers, S = 32 760, the long-sequence attention stream in the loop
+TOL_TRAJECTORY = {1: 2.0e-3, 10: 1.5e-2, 25: 3.0e-2, 50: 6.0e-2}       # relative RMS of the latent after k steps
+
+
+@pytest.fixture(scope="module")
+def wan_1_3b_detgen():
+    """Wan2.1-T2V-1.3B with the detgen weight set of the golden vectors ("wan1.3b": 1.42 G values, ~1 min to generate)."""
+    from oracle import wan_dit_oracle as O, make_golden_full_size as F
+    model_mod = importlib.import_module(PKG + ".wan.modules.model")
+    cfg = O.DiTConfig.wan_t2v_1_3b()
+    sd = O.synth_state_dict(cfg, F.TAG)
+    m = model_mod.WanModel(**{k: getattr(cfg, k) for k in ("model_type", "patch_size", "text_len", "in_dim", "dim", "ffn_dim",
+                                                            "freq_dim", "text_dim", "out_dim", "num_heads", "num_layers",
+                                                            "qk_norm", "cross_attn_norm", "eps")})
+    m.load_state_dict(sd)
+    del sd
+    return m.cuda().eval().requires_grad_(False)
+
+
+def _golden(name):
+    import numpy as np
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)
+    if not os.path.exists(path):
+        pytest.skip(f"{name} not generated (oracle/make_golden_full_size.py)")
+    return np.load(path)
+
+
+def test_headline_forward_all_30_layers_against_the_reference(wan_1_3b_detgen):
+    """One whole DiT forward of BASELINE config 2 — latent [16,21,60,104], S = 32 760, 30 layers, the generated
+    long-sequence attention stream, the fused q|k|v projection, every GEMM stream — against the reference's own output
+    on the same weights and inputs (1/8 lattice of the output, 4 096 probes, the mean).  Writes the measured figures to
+    gpurun_out/ for profiles/r05_full_forward_parity.json."""
+    import json
+    import numpy as np
+    from oracle import make_golden_full_size as F
+    g = _golden("dit_wan1_3b_c2_full_forward.npz")
+    noise, t, ctx, seq_len = F.case_forward()
+    m = wan_1_3b_detgen
+    with torch.no_grad():
+        out = m([noise.cuda()], t.cuda(), [ctx.cuda()], seq_len)[0].float().cpu()
+    assert out.shape == (16, 21, 60, 104) and bool(torch.isfinite(out).all())
+    lat = torch.from_numpy(g["lattice"])
+    e_lat = rel_rms(out[F.LATTICE], lat)
+    e_probe = rel_rms(out.flatten()[torch.from_numpy(g["probe_idx"])], torch.from_numpy(g["probe"]))
+    max_abs = float((out[F.LATTICE] - lat).abs().max())
+    rec = {"config": "Wan2.1-T2V-1.3B, latent [16,21,60,104], S = 32760, 30 layers, t = 625, 77 context tokens",
+           "against": "the reference WanModel.forward (oracle/make_golden_full_size.py, tests/golden/dit_wan1_3b_c2_full_forward.npz)",
+           "rel_rms_lattice_1_8": e_lat, "rel_rms_4096_probes": e_probe, "max_abs_lattice": max_abs,
+           "reference_rms": float(g["rms"]), "mean": float(out.double().mean()), "reference_mean": float(g["mean"]),
+           "oracle_vs_reference_rel_rms": float(g["oracle_vs_reference_rel_rms"]), "bound": TOL_HEADLINE_FORWARD}
+    print("[measured] headline forward:", json.dumps(rec))
+    os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
+                           "r05_full_forward_parity.json"), "w") as fh:
+        json.dump(rec, fh, indent=1)
+    assert e_lat < TOL_HEADLINE_FORWARD and e_probe < TOL_HEADLINE_FORWARD
+    assert abs(float(out.double().mean()) - float(g["mean"])) < 3e-3 * float(g["abs_mean"])
+    assert abs(float(out.double().abs().mean()) - float(g["abs_mean"])) < 3e-3 * float(g["abs_mean"])
+
+
+@pytest.mark.parametrize("solver", ["unipc", "dpm++"])
+def test_50_step_cfg_trajectory_against_the_reference(wan_1_3b_detgen, solver):
+    """50 sampling steps with classifier-free guidance on a reduced clip ([16,5,30,52], S = 1 950, all 30 layers), the
+    sampling loop of WanT2V.generate (text2video.py:206-252: two forwards + the fused CFG / solver step), against the
+    latents the reference's WanModel + FlowUniPCMultistepScheduler / FlowDPMSolverMultistepScheduler produce after
+    steps 1, 10, 25 and 50: the drift of the bf16 path over a whole trajectory, both solvers."""
+    import json
+    from oracle import make_golden_full_size as F
+    unipc = importlib.import_module(PKG + ".wan.utils.fm_solvers_unipc")
+    dpm = importlib.import_module(PKG + ".wan.utils.fm_solvers")
+    g = _golden("wan1_3b_trajectory_50steps.npz")
+    noise, ctx, ctx_null, seq_len, steps, shift, guide = F.case_trajectory()
+    m = wan_1_3b_detgen
+    dev = torch.device("cuda")
+    if solver == "unipc":
+        sch = unipc.FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+        sch.set_timesteps(steps, device=dev, shift=shift)
+        timesteps = sch.timesteps
+    else:
+        sch = dpm.FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+        timesteps, _ = dpm.retrieve_timesteps(sch, device=dev, sigmas=dpm.get_sampling_sigmas(steps, shift))
+    key = "unipc" if solver == "unipc" else "dpmpp"
+    assert torch.allclose(timesteps.float().cpu(), torch.from_numpy(g[key + "_timesteps"]).float())
+    sch.set_begin_index(0)
+    keep = {int(k): i for i, k in enumerate(g["keep_steps"])}
+    with torch.no_grad():
+        c_state, u_state = m.encode_context([ctx.cuda()]), m.encode_context([ctx_null.cuda()])
+        x = noise.cuda()
+        errs = {}
+        for k, t in enumerate(timesteps):
+            ts = torch.stack([t])
+            cond = m([x], t=ts, context=c_state, seq_len=seq_len)[0]
+            uncond = m([x], t=ts, context=u_state, seq_len=seq_len)[0]
+            x = sch.step_cfg(cond, uncond, guide, x)
+            if k + 1 in keep:
+                errs[k + 1] = rel_rms(x, torch.from_numpy(g[key][keep[k + 1]]))
+    print(f"[measured] 50-step trajectory ({solver}):", json.dumps(errs))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", f"r05_trajectory_parity_{key}.json"), "w") as fh:
+        json.dump({"solver": solver, "clip": [16, 5, 30, 52], "steps": steps, "guide_scale": guide, "shift": shift,
+                   "rel_rms_after_step": errs, "bounds": TOL_TRAJECTORY}, fh, indent=1)
+    assert bool(torch.isfinite(x).all())
+    for k, e in errs.items():
+        assert e < TOL_TRAJECTORY[k], (k, e)

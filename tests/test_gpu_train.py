@@ -200,6 +200,29 @@ def test_adamw_and_ema_match_torch(omh):
     optim.update_ema_model(ema, src, 0.995)
     for t, r in zip(ema.parameters(), ref):
         assert torch.allclose(t, r, atol=1e-7)
+    # ONE launch for all tensors (omh_ema_update_multi) == the per-tensor kernel bit for bit: odd sizes, several chunks,
+    # a tensor that starts 4 bytes off the 16-byte grid (the scalar route), twice in a row (cached pointer table)
+    ops = importlib.import_module("omnihuman-1-hack_amd.ops")
+
+    class Bag(torch.nn.Module):
+        def __init__(self, sizes, seed):
+            super().__init__()
+            g = torch.Generator().manual_seed(seed)
+            base = torch.randn(20000, generator=g).cuda()
+            self.ps = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(n, generator=g).cuda()) for n in sizes]
+                                             + [torch.nn.Parameter(base[1:1 + 4099])])
+    sizes = [1, 3, 4096, 4097, 8192 + 3, 70001]
+    ema2, src2 = Bag(sizes, 1), Bag(sizes, 2)
+    for _ in range(2):
+        want = []
+        for t, s_ in zip(ema2.parameters(), src2.parameters()):
+            w = t.detach().clone()
+            ops.ema_update(w, s_.detach().contiguous(), 0.9)
+            want.append(w)
+        v0 = [t._version for t in ema2.parameters()]
+        optim.update_ema_model(ema2, src2, 0.9)
+        for t, w, v in zip(ema2.parameters(), want, v0):
+            assert torch.equal(t.detach(), w) and t._version > v
 
 
 def test_training_step_function_matches_reference_loss(wan_model_mod):
