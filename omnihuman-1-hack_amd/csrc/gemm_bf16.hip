@@ -481,8 +481,6 @@ int omh_launch_gemm_w64(const omh_gemm_args& a, hipStream_t stream);
 // ... and its 256 x 192 gated-residual variant with the old C tile prefetched during the k loop
 bool omh_gemm_w64_r192_takes(const omh_gemm_args& a);
 int omh_launch_gemm_w64_r192(const omh_gemm_args& a, hipStream_t stream);
-bool omh_gemm_w64_r256_takes(const omh_gemm_args& a);
-int omh_launch_gemm_w64_r256(const omh_gemm_args& a, hipStream_t stream);
 bool omh_gemm_w64_bf16m_takes(const omh_gemm_args& a);
 int omh_launch_gemm_w64_bf16m(const omh_gemm_args& a, hipStream_t stream);
 bool omh_gemm_w64_n192_takes(const omh_gemm_args& a);
@@ -607,22 +605,6 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
             const char* r192 = omh_opt(OMH_OPT_GEMM_W64_R192);
             const bool off = r192 && r192[0] == '0', on = r192 && r192[0] == '1';
             const bool never192 = (gk && gk[0] == '8') || (!force && omh_opt(OMH_OPT_GEMM_TILE));
-            // ... and its 256 x 256 sibling (round 5: 10 of the 16 old-C tiles requested during the k loop, the other 6
-            // in the epilogue into the registers finished tiles have left): 128 flop per staged byte instead of 110, and
-            // at the o-projection's size 768 tiles = three whole rounds instead of 1 024 = four.  Where it has at least
-            // two rounds of tiles; OMH GEMM_W64_R256 = 0 / 1 forces it off / on.
-            {
-                const char* r256 = omh_opt(OMH_OPT_GEMM_W64_R256);
-                const bool off6 = r256 && r256[0] == '0', on6 = r256 && r256[0] == '1';
-                if (!never192 && !off6 && !on && omh_gemm_w64_r256_takes(a)) {
-                    const int64_t t256 = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256);
-                    if (on6 || (!off && t256 >= 512 && a.K <= 3072)) {
-                        omh_clear_status();
-                        omh_launch_gemm_w64_r256(a, s);
-                        return omh_launch_status();
-                    }
-                }
-            }
             if (!never192 && !off && omh_gemm_w64_r192_takes(a)) {          // (also the training epilogues: c_in, aux)
                 // measured (round 4, one box, R192 = 0 / 1): 32760 x 1536 x 1536 206 -> 186 us, 21840 rows 148 -> 119,
                 // 6240 rows 51 -> 39 (K = 8960: 177 -> 151), 3120 rows 33.5 -> 35.4 (too few tiles), 32760 x 1536 x 8960

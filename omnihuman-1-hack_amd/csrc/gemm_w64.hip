@@ -18,10 +18,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, int64_t
 
 enum { K_F32 = 0, K_BF16 = 1, K_GELU = 2, K_RESID = 3, K_GELUBWD = 4, K_BF16M = 5, K_GELUAUX = 6,
        K_RESID192 = 7, K_F32_192 = 8, K_BF16_192 = 9,                        // K_RESID192 .. K_BF16_192: the 256 x 192 tile
-       K_QKV = 10,          // 256 x 384: columns < n_split -> C bf16 (the BF16 stream), columns >= n_split -> aux TRANSPOSED (BF16VT)
-       K_RESID256 = 11 };   // 256 x 256: the gated residual with 10 of its 16 old-C tiles requested during the k loop (round 5)
+       K_QKV = 10 };        // 256 x 384: columns < n_split -> C bf16 (the BF16 stream), columns >= n_split -> aux TRANSPOSED (BF16VT)
 constexpr bool is_n192(int kind) { return kind >= K_RESID192 && kind <= K_BF16_192; }
-constexpr int tile_n_of(int kind) { return is_n192(kind) ? 192 : (kind == K_RESID256 ? 256 : 384); }
 
 // two wave-uniform 32-bit scalars in one SGPR pair (inline asm takes at most 30 operands)
 __device__ __forceinline__ uint64_t pack2(uint32_t lo, uint32_t hi) {
@@ -57,7 +55,7 @@ __device__ __forceinline__ W64Tile w64_tile(const omh_gemm_args& p, int idx, int
 template <int KIND>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int tiles_n, const W64Split sp) {
-    constexpr int TNW = tile_n_of(KIND);                                    // tile width; a wave owns TNW / 2 columns
+    constexpr int TNW = is_n192(KIND) ? TN192 : TN;                         // tile width; a wave owns TNW / 2 columns
     constexpr int WBYTES = TNW * 128, STAGE_B = 32768 + WBYTES;             // W tile, one stage (X 32 KiB | W)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_B];
     constexpr int ES = (KIND == K_BF16 || KIND == K_GELU || KIND == K_BF16_192 || KIND == K_GELUBWD || KIND == K_BF16M ||
@@ -101,7 +99,7 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
     const __amdgpu_buffer_rsrc_t rbias = rsrc_of(p.bias, (p.bias && p.bias_mode == OMH_BIAS_N) ? (int64_t)p.N * 4 : 0);
     // K_BF16M: per-ROW bias (OMH_BIAS_M: the V^T projection, weights in the row slot)
     const __amdgpu_buffer_rsrc_t rbm = rsrc_of(p.bias, (KIND == K_BF16M && p.bias) ? (int64_t)p.M * 4 : 0);
-    constexpr bool RES = KIND == K_RESID || KIND == K_RESID192 || KIND == K_RESID256;
+    constexpr bool RES = KIND == K_RESID || KIND == K_RESID192;
     const __amdgpu_buffer_rsrc_t rg0 = rsrc_of(p.gate0, (RES && p.gate0) ? (int64_t)p.N * 4 : 0);
     const bool has_g1 = RES && p.gate1 != nullptr;
     const int grows = has_g1 ? p.gate_rows : 1;
@@ -121,14 +119,7 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
 
     int idx = blockIdx.x;
     W64Tile t = w64_tile<TNW>(p, idx, tiles_m, tiles_n, w, sp);
-    if (KIND == K_RESID256) {
-        const uint64_t p8 = pack2(t.sxb, t.swb);
-        asm volatile(OMH_GEMM_W64_ASM_PRO256
-                     :
-                     : [vox0] "v"(vox0), [vox1] "v"(vox1), [vow0] "v"(vow0), [vow1] "v"(vow1), [ra] "s"(ra), [rb] "s"(rb),
-                       [p0] "{s[60:61]}"(p0), [p2] "{s[64:65]}"(p2), [p8] "{s[76:77]}"(p8)
-                     : "memory", "scc", "s80", "s81", "s82");
-    } else if (is_n192(KIND)) {
+    if (is_n192(KIND)) {
         const uint64_t p8 = pack2(t.sxb, t.swb);
         asm volatile(OMH_GEMM_W64_ASM_PRO192
                      :
@@ -229,16 +220,6 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
                      : OMH_GEMM_W64_CLOBBERS);
             }
         }
-        else if (KIND == K_RESID256)
-            asm volatile(OMH_GEMM_W64_ASM_RESID256
-                 :
-                 : [xab] "v"(xab), [wab] "v"(wab), [xh] "v"(xh), [vox0] "v"(vox0), [vox1] "v"(vox1), [vow0] "v"(vow0),
-                   [vow1] "v"(vow1), [voc] "v"(voc), [vlane] "v"(vlane), [ra] "s"(ra), [rb] "s"(rb), [rc] "s"(rc),
-                   [rbias] "s"(rbias), [rg0] "s"(rg0), [rg1] "s"(rg1), [rcin] "s"(rcin), [raux] "s"(raux),
-                   [p0] "{s[60:61]}"(p0), [p1] "{s[62:63]}"(p1),
-                   [p2] "{s[64:65]}"(p2), [p3] "{s[66:67]}"(p3), [p4] "{s[68:69]}"(p4), [p5] "{s[70:71]}"(p5),
-                   [p6] "{s[72:73]}"(p6), [p7] "{s[74:75]}"(p7), [p8] "{s[76:77]}"(p8), [p9] "{s[78:79]}"(p9)
-                 : OMH_GEMM_W64_CLOBBERS);
         else if (KIND == K_F32_192) OMH_GW64_RUN(OMH_GEMM_W64_ASM_F32_192);
         else if (KIND == K_BF16_192) OMH_GW64_RUN(OMH_GEMM_W64_ASM_BF16_192);
         else
@@ -260,7 +241,7 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
 
 template <int KIND>
 int launch_w64(const omh_gemm_args& a, hipStream_t stream, const W64Split sp = W64Split{1, 0u, 0u}) {
-    constexpr int TNW = tile_n_of(KIND);
+    constexpr int TNW = is_n192(KIND) ? TN192 : TN;
     const int tiles_m = (a.M + TM - 1) / TM, tiles_n = (a.N + TNW - 1) / TNW;
     const int total = tiles_m * tiles_n * sp.n;
     static int ncu = 0;
@@ -308,9 +289,6 @@ bool omh_gemm_w64_r192_takes(const omh_gemm_args& a) {
     return a.epilogue == OMH_EPI_RESID && omh_gemm_w64_takes(a) && a.K >= 16 * BK;
 }
 int omh_launch_gemm_w64_r192(const omh_gemm_args& a, hipStream_t stream) { return launch_w64<K_RESID192>(a, stream); }
-// The 256 x 256 gated-residual stream (round 5): same shapes (its 10 peeled k steps + the tail logic fit in 16 k tiles)
-bool omh_gemm_w64_r256_takes(const omh_gemm_args& a) { return omh_gemm_w64_r192_takes(a); }
-int omh_launch_gemm_w64_r256(const omh_gemm_args& a, hipStream_t stream) { return launch_w64<K_RESID256>(a, stream); }
 // bf16 output with a per-ROW bias (the V^T projection) on the 256 x 384 stream
 bool omh_gemm_w64_bf16m_takes(const omh_gemm_args& a) {
     if (a.epilogue != OMH_EPI_BF16 || !a.bias || a.bias_mode != OMH_BIAS_M) return false;

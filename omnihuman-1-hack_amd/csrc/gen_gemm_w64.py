@@ -41,17 +41,13 @@ KINDS = ("f32", "bf16", "gelu", "resid")
 def configure(ni):
     """Tile configuration of the streams generated next: ni = 6 -> 256 x 384 (the default), ni = 3 -> 256 x 192 (the
     "resid192" stream: 12 accumulator tiles per wave, all in AGPRs; v[96:255] + a[192:223] hold the tile's OLD C values,
-    requested during the k loop), ni = 4 -> 256 x 256 ("resid256", round 5: 16 accumulator tiles = all 256 AGPRs, the old
-    C values of the first 10 in v[96:255] from the k loop, the other 6 requested in the epilogue into registers the
-    finished tiles have left: 128 flop per staged byte instead of 110, 768 tiles = three whole rounds at the
-    o-projection's size instead of 1 024 = four)."""
-    global NI, STAGE, FB, NW, NTILES, NPRE
+    requested during the k loop)."""
+    global NI, STAGE, FB, NW, NTILES
     NI = ni
     STAGE = 32768 + ni * 8192
     FB = 4 * ni + 4 * NJ
     NW = 2 * ni
     NTILES = NI * NJ
-    NPRE = min(NTILES, 10 if ni == 4 else 12)     # accumulator tiles whose old C is requested during the k loop
 
 # fixed scalar registers (unpacked from the 64-bit operand pairs in the prologue)
 S_LDX, S_LDW, S_SXB, S_SWB, S_SXS, S_SWS, S_NK, S_SCB = "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67"
@@ -201,8 +197,7 @@ def with_dma_tail(ops, dm, start=12):
     return out
 
 
-CPRE = 96                      # resid192 / resid256: v[96:255] = old C of tiles 0..9 (resid192: a[192:223] = tiles 10, 11)
-NPRE = 12
+CPRE = 96                      # resid192: v[96:255] = old C of tiles 0..9, a[192:223] = tiles 10, 11
 
 
 def c_slot(k, lo, n=4):
@@ -299,12 +294,12 @@ def main_loop(e, epi_vmem, cpre=False):
         e(f"s_cbranch_scc1 {tail}")
 
     TAIL1, TAIL0 = e.lab("tail1"), e.lab("tail0")
-    if cpre:                                                    # k steps 0 .. NPRE-1, each with one tile's old C
-        for kt in range(NPRE):
+    if cpre:                                                    # k steps 0 .. NTILES-1, each with one tile's old C
+        for kt in range(NTILES):
             body(kt & 1, first=(kt == 0), ctile=kt)
-        assert NPRE % 2 == 0
-        body(0)                                                 # k step NPRE: the wait that lands the last C tile
-        e(f"s_mov_b32 s84, {NPRE + 1}")
+        assert NTILES % 2 == 0
+        body(0)                                                 # k step NTILES: the wait that lands the last C tile
+        e(f"s_mov_b32 s84, {NTILES + 1}")
     else:
         body(0, first=True)                                     # k step 0 (K >= 3 k tiles: it is never a tail step)
         e("s_mov_b32 s84, 1")
@@ -820,102 +815,19 @@ def epilogue_vt(e):
             e("s_mov_b64 exec, s[86:87]")
 
 
-def epilogue_resid256(e):
-    """C fp32 += (acc + bias) * gate on the 256 x 256 tile (NI = 4): epilogue_resid192's arithmetic and stores.  The old
-    C values of accumulator tiles 0 .. 9 are in v[96:255] (c_prefetch, k loop); tile 10's are requested at the head of
-    the epilogue into v[80:95], tile 11 + m's into the slot tile m has just left — every one of the six has ten tile
-    epilogues to land before it is needed (in-order vmcnt, counted)."""
-    es = 4
-    column_vectors(e, "resid")
-    VOA, AX = 24, 20
-    e(f"v_lshrrev_b32 v{VOA}, 1, %[voc]")
-    issued, slot_of = [], {}
-
-    def request(k, sl):
-        i, j = divmod(k, NJ)
-        slot_of[k] = sl
-        e(f"s_mul_i32 s88, {S_SCJ}, {j}")
-        e(f"s_add_u32 s88, s88, {S_SCB}")
-        for p in range(2):
-            for q in range(2):
-                e(f"buffer_load_dwordx4 {vr(sl + p * 8 + q * 4, 4)}, %[voc], %[rcin], s88 offen offset:{(i * 32 + 16 * p) * es + q * 16}")
-                issued.append(("L", k))
-
-    for k in range(NPRE):
-        slot_of[k] = CPRE + 16 * k
-    nxt = NPRE
-    if nxt < NTILES:
-        request(nxt, 80)
-        nxt += 1
-    for k in range(NTILES):
-        i, j = divmod(k, NJ)
-        t = i * NJ + j
-        e(f"s_mul_i32 s85, {S_SCJ}, {j}")
-        e(f"s_add_u32 s85, s85, {S_SCB}")
-        e("s_lshr_b32 s88, s85, 1")
-        e(f"v_add_u32 v{VCOLT}, {32 * j}, {VROW}")
-        e(f"v_cmp_le_u32 vcc, {S_MB}, v{VCOLT}")
-        e(f"v_add_u32 v{VCOLT}, 1536, {VLR}")
-        e(f"v_cndmask_b32 v{VSEL}, {VLR}, v{VCOLT}, vcc")
-        for p in range(2):
-            col = (i * 32 + 16 * p) * 4
-            e(f"ds_read_b128 {vr(GV + p * 8, 4)}, v{VSEL} offset:{col}")
-            e(f"ds_read_b128 {vr(GV + p * 8 + 4, 4)}, v{VSEL} offset:{col + 16}")
-            e(f"ds_read_b128 {vr(BV + p * 8, 4)}, {VLR} offset:{768 + col}")
-            e(f"ds_read_b128 {vr(BV + p * 8 + 4, 4)}, {VLR} offset:{768 + col + 16}")
-        for r_ in range(16):
-            e(f"v_accvgpr_read_b32 v{T + r_}, a{t * 16 + r_}")
-        e("s_nop 1")
-        for q0 in (0, 2):
-            for r_ in range(4):
-                e(f"v_permlane32_swap_b32 v{T + 4 * q0 + r_}, v{T + 4 * (q0 + 1) + r_}")
-        e("s_waitcnt lgkmcnt(0)")
-        sl = slot_of[k]
-        if k >= NPRE:                                            # requested in this epilogue: in-order counter
-            last = max(x for x, tag in enumerate(issued) if tag == ("L", k))
-            e(f"s_waitcnt vmcnt({min(63, len(issued) - last - 1)})")
-        for p in range(2):
-            v0 = T + 8 * p
-            e(f"v_add_u32 v{VCOLT}, {i * 32 + 16 * p}, {VCOL}")
-            e(f"v_cmp_gt_u32 vcc, {S_N}, v{VCOLT}")
-            e("s_and_saveexec_b64 s[86:87], vcc")
-            for r_ in range(0, 8, 2):
-                e(f"v_pk_add_f32 {vr(v0 + r_, 2)}, {vr(v0 + r_, 2)}, {vr(BV + p * 8 + r_, 2)}")
-            off = (i * 32 + 16 * p) * es
-            for r_ in range(4):
-                e(f"v_cvt_pk_bf16_f32 v{AX + r_}, v{v0 + 2 * r_}, v{v0 + 2 * r_ + 1}")
-            e(f"buffer_store_dwordx4 {vr(AX, 4)}, v{VOA}, %[raux], s88 offen offset:{off // 2}")
-            for r_ in range(0, 8, 2):
-                e(f"v_pk_mul_f32 {vr(v0 + r_, 2)}, {vr(v0 + r_, 2)}, {vr(GV + p * 8 + r_, 2)}")
-            for r_ in range(0, 8, 2):
-                e(f"v_pk_add_f32 {vr(v0 + r_, 2)}, {vr(sl + p * 8 + r_, 2)}, {vr(v0 + r_, 2)}")
-            e(f"buffer_store_dwordx4 {vr(v0, 4)}, %[voc], %[rc], s85 offen offset:{off}")
-            e(f"buffer_store_dwordx4 {vr(v0 + 4, 4)}, %[voc], %[rc], s85 offen offset:{off + 16}")
-            issued += [("S", k)] * 3
-            e("s_nop 1")
-            e("s_mov_b64 exec, s[86:87]")
-        if nxt < NTILES:                                         # tile k's slot is free: the next late tile's old values
-            e("s_nop 1")
-            request(nxt, sl)
-            nxt += 1
-    assert nxt == NTILES
-
-
 # VMEM instructions PER ACCUMULATOR TILE an epilogue issues after the next tile's prologue DMA (the k loop's first wait
 # counts them: an over-estimate would let k tile 0 be read before it has landed)
-EPI_VMEM_TILE = {"f32": 4, "bf16": 2, "gelu": 2, "geluaux": 4, "resid": 8, "resid192": 6, "gelubwd": 4, "bf16m": 2, "bf16vt": 2, "resid256": 8}
+EPI_VMEM_TILE = {"f32": 4, "bf16": 2, "gelu": 2, "geluaux": 4, "resid": 8, "resid192": 6, "gelubwd": 4, "bf16m": 2, "bf16vt": 2}
 
 
 def generate(kind, tag=None):
     global SWAP
     e = Emit(tag or kind)
     SWAP = kind == "bf16vt"
-    main_loop(e, EPI_VMEM_TILE[kind] * NTILES, cpre=kind in ("resid192", "resid256"))
+    main_loop(e, EPI_VMEM_TILE[kind] * NTILES, cpre=(kind == "resid192"))
     SWAP = False
     if kind == "bf16vt":
         epilogue_vt(e)
-    elif kind == "resid256":
-        epilogue_resid256(e)
     elif kind == "resid":
         epilogue_resid(e)
     elif kind == "resid192":
@@ -941,8 +853,6 @@ def main():
     configure(3)                                                 # the 256 x 192 gated-residual stream (old C prefetched)
     streams += [("PRO192", first_prologue("pro192")), ("RESID192", generate("resid192")),
                 ("F32_192", generate("f32", "f32n3")), ("BF16_192", generate("bf16", "bf16n3"))]
-    configure(4)                                                 # the 256 x 256 gated-residual stream
-    streams += [("PRO256", first_prologue("pro256")), ("RESID256", generate("resid256"))]
     configure(6)
     for name, e in streams:
         print(f"#define OMH_GEMM_W64_ASM_{name} \\")
