@@ -55,10 +55,10 @@ int omh_set_deterministic(int on);
  * (one product on every kernel that can take it) and by A/B timing — is an entry of one table:
  *   ATTN_KERNEL ("w64" / "pp" / "base")   ATTN_SPLIT ("0" / "tail")   W64_SPLIT ("0")   W64_VARIANT ("0".."2")
  *   GEMM_KERNEL ("w64" / "8w")   GEMM_TILE ("big" / "small" / "tiny")   GEMM_RULE   GEMM_GROUP_M   GEMM_SPLITK ("0")
- *   GEMM_QKV ("0")   GEMM_W64_R192 / R256 / N192 / BF16M / GBWD / GAUX ("0" / "1")
+ *   GEMM_QKV ("0" / "1")   GEMM_W64_R192 / N192 / BF16M / GBWD / GAUX ("0" / "1")
  *   GEMM_TN_W64 ("0" / "1")   GEMM_TN_TILE   GEMM_TN_GROUP_TILE ("big" / "small")   GEMM_TN_SPLIT (count)
  *   CONV_TILE ("w64" / "wide" / "small")   CONV_W64   CONV_WIDE_MIN   CONV_FUSE_NORM   CONV_KW3   CONV_PERSIST
- *   CONV_W64_UP2   CONV_EPI   LN_RPW ("1" / "2" / "4")   DETERMINISTIC ("0" / "1")
+ *   CONV_W64_UP2   LN_RPW ("1" / "2" / "4")   DETERMINISTIC ("0" / "1")
  * An unset option means "the library decides" (the shipped dispatch).  The table is seeded from the environment
  * (variable OMH_<NAME>) exactly once, at the first call into the library; afterwards only omh_set_option changes it —
  * no entry point calls getenv on the launch path.  Setting an option is not synchronised against concurrent launches.

@@ -43,11 +43,16 @@ void adamw_multi_kernel(const int64_t* __restrict__ table, float lr, float beta1
     }
 }
 
+// one expression for both EMA kernels (the compiler's fma contraction would otherwise pick per loop shape)
+__device__ __forceinline__ float ema_one(float e, float p, float decay) {
+    return __builtin_fmaf(e, decay, p * (1.0f - decay));
+}
+
 __global__ __launch_bounds__(256)
 void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, int64_t n, float decay) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        ema[i] = ema[i] * decay + p[i] * (1.0f - decay);
+        ema[i] = ema_one(ema[i], p[i], decay);
 }
 
 // all parameters of a model in ONE launch (distilled_trainer.py:319-334 is a Python loop over ~825 tensors): table[t] =
@@ -70,14 +75,14 @@ void ema_multi_kernel(const int64_t* __restrict__ table, int n_entries, float de
         for (int64_t i = i0 + 4 * (int64_t)threadIdx.x; i + 3 < i1; i += 1024) {
             float4 a = *(const float4*)(ema + i);
             const float4 b = *(const float4*)(p + i);
-            a.x = a.x * decay + b.x * (1.0f - decay); a.y = a.y * decay + b.y * (1.0f - decay);
-            a.z = a.z * decay + b.z * (1.0f - decay); a.w = a.w * decay + b.w * (1.0f - decay);
+            a.x = ema_one(a.x, b.x, decay); a.y = ema_one(a.y, b.y, decay);
+            a.z = ema_one(a.z, b.z, decay); a.w = ema_one(a.w, b.w, decay);
             *(float4*)(ema + i) = a;
         }
         for (int64_t i = i0 + ((i1 - i0) & ~(int64_t)3) + threadIdx.x; i < i1; i += 256)
-            ema[i] = ema[i] * decay + p[i] * (1.0f - decay);
+            ema[i] = ema_one(ema[i], p[i], decay);
     } else {
-        for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) ema[i] = ema[i] * decay + p[i] * (1.0f - decay);
+        for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) ema[i] = ema_one(ema[i], p[i], decay);
     }
 }
 

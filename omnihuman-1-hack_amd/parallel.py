@@ -74,6 +74,11 @@ class BucketedGradAllReduce:
             self.buckets.append(cur)
         self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
         self._flat = [None] * len(self.buckets)
+        # Layout of a bucket = the parameters that got a gradient the last time it was launched, in bucket order (the
+        # frozen FFNs never do: they take no room on the wire).  Once known, ``grad_slot`` hands the training step the
+        # parameter's slice as the DESTINATION of its weight gradient (model_train._grad_slots), so the next launch finds
+        # the gradient already in place and packs nothing (the 3.6 GB packing copy).
+        self._layout = [None] * len(self.buckets)           # per bucket: {id(p): (offset, numel)} or None
         self._wire = [None] * len(self.buckets)             # bf16 payload: the buffer that travels
         self._shard = [None] * len(self.buckets)            # reduce_scatter_all_gather: this rank's reduced 1/world
         self.bytes_on_wire = 0                              # payload bytes handed to the collectives in the last step
@@ -93,6 +98,23 @@ class BucketedGradAllReduce:
         finally:
             self.enabled = old
 
+    def grad_slot(self, p):
+        """fp32 view (the parameter's shape) of ``p``'s slice of its bucket, or None while the bucket's layout is not
+        known yet (first step), the parameter was not part of it, or the slice would not be what the next launch
+        expects.  A gradient written there needs no packing."""
+        if self.world == 1 and not self.force:
+            return None
+        i = self._bucket_of.get(id(p))
+        if i is None or self._work[i] is not None:
+            return None
+        lay, flat = self._layout[i], self._flat[i]
+        if lay is None or flat is None or id(p) not in lay or flat.dtype != torch.float32 or flat.device != p.device:
+            return None
+        off, n = lay[id(p)]
+        if n != p.numel():
+            return None
+        return flat[off:off + n].view(p.shape)
+
     def _on_grad(self, p):
         if not self.enabled or (self.world == 1 and not self.force):
             return
@@ -110,6 +132,7 @@ class BucketedGradAllReduce:
             return
         if not any(self._work):
             self.bytes_on_wire = 0
+            self.packed_elements = 0                        # elements copied into buckets this step (0: all in place)
         # The weight gradients of the block that just returned may still be in flight on the training step's second
         # stream (model_train: its join is deferred to the end of the backward pass).  The bucket is therefore packed and
         # its collective queued FROM that stream — behind the gradients it reads, and behind what the main stream has
@@ -140,6 +163,13 @@ class BucketedGradAllReduce:
         sizes = [p.numel() for p in bucket]
         views = list(flat[:n].split(sizes))
         wviews = views if wire is flat else list(wire[:n].split(sizes))
+        # a gradient that lives inside this flat buffer but NOT at its slice (the set of parameters with a gradient
+        # changed since the layout was recorded): copying it to its new place could overwrite a neighbour first
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
+        moved = [p for v, p in zip(views, bucket)
+                 if lo <= p.grad.data_ptr() < hi and p.grad.data_ptr() != v.data_ptr()]
+        for p in moved:
+            p.grad = p.grad.clone()
         dst, src = [], []
         for v, wv, p in zip(views, wviews, bucket):
             g = p.grad.reshape(-1)
@@ -148,6 +178,12 @@ class BucketedGradAllReduce:
                 src.append(g)
         if dst:
             torch._foreach_copy_(dst, src)
+        self.packed_elements = getattr(self, "packed_elements", 0) + sum(t.numel() for t in src)
+        off, lay = 0, {}
+        for p, sz in zip(bucket, sizes):
+            lay[id(p)] = (off, sz)
+            off += sz
+        self._layout[i] = lay
         # RCCL averages in the collective; gloo (CPU tests) has no AVG, so sum now and scale in finish()
         backend = dist.get_backend(self.group)
         self._avg_in_coll = self.average and backend == "nccl"

@@ -410,6 +410,39 @@ def _grad_targets(ctx, model, idx):
     return dict(have) if have else None
 
 
+def _grad_slots(ctx, model, idx, tgt):
+    """Destinations for the FRESH weight gradients of block ``idx``: {name: fp32 view of the parameter's shape} for the
+    matrices that have no ``.grad`` yet and whose reducer (this package's parallel.BucketedGradAllReduce, found through
+    its post-accumulate hook) offers their slice of a flat bucket (``grad_slot``).  The weight-gradient GEMM then writes
+    straight into the bucket — nothing to pack before the collective (the 3.6 GB packing copy)
+    — the block sets ``p.grad`` to the slice, tells the reducer, and hands autograd None, exactly as the accumulation
+    path does for gradients that already exist.  Same conditions as _grad_targets; {} whenever they do not hold."""
+    if tgt is None or not _direct_on(model) or torch.is_grad_enabled():
+        return {}
+    out, nodes = {}, None
+    for n, p in _block_params(model, idx):
+        if not p.requires_grad or p.grad is not None or p.dim() != 2 or p.dtype != torch.float32 or (tgt and n in tgt):
+            continue
+        if getattr(p, "_backward_hooks", None):
+            continue
+        hooks = list((getattr(p, "_post_accumulate_grad_hooks", None) or {}).values())
+        if len(hooks) != 1 or not getattr(getattr(hooks[0], "__self__", None), "_omh_joins_side_streams", False):
+            continue
+        red = hooks[0].__self__
+        slot = red.grad_slot(p) if hasattr(red, "grad_slot") else None
+        if slot is None:
+            continue
+        if nodes is None:
+            nodes = {id(fn.variable): fn for fn, _ in ctx.next_functions if fn is not None and hasattr(fn, "variable")}
+        try:
+            if id(p) not in nodes or not torch._C._will_engine_execute_node(nodes[id(p)]):
+                continue
+        except Exception:
+            return {}
+        out[n] = slot
+    return out
+
+
 def _may_defer_join(model):
     if not (_DEFER_JOIN and _WGRAD_STREAM):
         return False
@@ -461,8 +494,10 @@ class _WgradGroup:
     def __init__(self, dev):
         self.dev, self.items = dev, []
 
-    def add(self, dy, x, out=None):
-        acc = out is not None
+    def add(self, dy, x, out=None, store=False):
+        """``out``: added to (gradient accumulation) — or, with ``store``, simply written: a destination the caller owns
+        (the parameter's slice of a reducer bucket, _grad_slots)."""
+        acc = out is not None and not store
         if out is None:
             out = torch.empty(dy.shape[1], x.shape[1], dtype=torch.float32, device=self.dev)
         if dy.shape[1] * x.shape[1] >= 256 * 256 * 128:          # >= 128 tiles of 256 x 256 (the FFN weights): fills the
@@ -708,7 +743,7 @@ def _block_forward(model, blk, idx, st, x0, P, keep, need=True):
 
 
 # ----------------------------------------------------------------------------- block backward
-def _block_backward(model, blk, idx, st, S, dx, P, tgt=None):
+def _block_backward(model, blk, idx, st, S, dx, P, tgt=None, slots=None):
     """Back-propagate dx (fp32 [B, S, d], updated in place) through block ``idx`` given its kept tensors ``S``.
     ``tgt`` ({name: parameter}, _grad_targets): parameters whose existing ``.grad`` the gradient is ADDED to in place
     (gradient accumulation); the returned dict then holds that ``.grad`` tensor under the name."""
@@ -735,6 +770,7 @@ def _block_backward(model, blk, idx, st, S, dx, P, tgt=None):
     d_eb = arena.take(B, 6, d)                                        # grads of e = modulation + e0
     g = {}
     tgt = tgt or {}
+    slots = slots or {}                                               # fresh weight gradients written into reducer buckets
     deferred = [] if _DEFER_COLSUM else None                          # second launches of the norm backwards (main stream)
 
     def acc1(name, n):
@@ -764,17 +800,22 @@ def _block_backward(model, blk, idx, st, S, dx, P, tgt=None):
     def wgrad(dy, x, names):
         """Weight gradients dy^T x into g[names] (parameters stacked along dy's columns, ``d`` wide each): one product,
         or one per parameter — same tiles, same launch — when a parameter accumulates into its own .grad."""
+        def one(dy_, n):
+            p = tgt.get(n)
+            if p is not None:
+                return wg.add(dy_, x, out=p.grad)
+            if n in slots:
+                return wg.add(dy_, x, out=slots[n], store=True)
+            return wg.add(dy_, x)
         if len(names) == 1:
-            p = tgt.get(names[0])
-            g[names[0]] = wg.add(dy, x, out=p.grad if p is not None else None)
-        elif not any(n in tgt for n in names):
+            g[names[0]] = one(dy, names[0])
+        elif not any(n in tgt or n in slots for n in names):
             out = wg.add(dy, x)
             for j, n in enumerate(names):
                 g[n] = out[j * d:(j + 1) * d]
         else:
             for j, n in enumerate(names):
-                p = tgt.get(n)
-                g[n] = wg.add(dy[:, j * d:(j + 1) * d], x, out=p.grad if p is not None else None)
+                g[n] = one(dy[:, j * d:(j + 1) * d], n)
 
     def ln_bwd(xin, dh, shift_i, scale_i, nxt=None):
         """dx += LN+modulate backward of dh; ``nxt = (y, gate_i)``: also the next branch's gated-residual backward on
@@ -1010,6 +1051,7 @@ class _BlockFn(torch.autograd.Function):
         P = st.packs[idx]
         dev = x0.device
         tgt = _grad_targets(ctx, model, idx)                 # gradient accumulation: existing .grad tensors to add into
+        slots = _grad_slots(ctx, model, idx, tgt)            # fresh weight gradients: straight into the reducer's buckets
         with torch.no_grad():                                # (asked before no_grad: it looks at the pass's grad mode)
             S = ctx.kept
             ctx.kept = None
@@ -1057,7 +1099,7 @@ class _BlockFn(torch.autograd.Function):
                 st.no_defer, defer = True, False
             done = False
             try:
-                grads = _block_backward(model, blk, idx, st, S, dx, P, tgt)
+                grads = _block_backward(model, blk, idx, st, S, dx, P, tgt, slots)
                 done = True
             finally:
                 # (tgt None: gradients exist and autograd will add this block's to them on the main stream)
@@ -1070,10 +1112,13 @@ class _BlockFn(torch.autograd.Function):
         out = []
         for n, p in _block_params(model, idx):
             gg = grads.get(n) if p.requires_grad else None
-            if gg is not None and tgt and n in tgt:          # added to p.grad in place: nothing for autograd to do, and
-                gg = None                                    # its AccumulateGrad node — the hooks on it — does not run:
+            if gg is not None and slots and n in slots:      # written into the reducer's bucket: that slice IS the gradient
+                p.grad = slots[n]
+            if gg is not None and ((tgt and n in tgt) or (slots and n in slots)):
+                gg = None                                    # in place: nothing for autograd to do, and its AccumulateGrad
+                # node — the hooks on it — does not run: this package's reducer (only its hooks get this far) is told here
                 for h in list((getattr(p, "_post_accumulate_grad_hooks", None) or {}).values()):
-                    h(p)                                     # this package's reducer (only its hooks get this far) is told here
+                    h(p)
             out.append(None if gg is None else gg.view(p.shape).to(p.dtype))
         gdx = grads["__dx__"]
         gdx._omh_exclusive = True                             # fresh from this node: the previous block may update it in place

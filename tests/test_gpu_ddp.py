@@ -309,3 +309,65 @@ def test_gradient_accumulation_in_place_under_the_bucketed_reducer_two_ranks():
     assert sorted(r[:2] for r in res) == [(0, "ok"), (1, "ok")], res
     print(f"[measured] gradient accumulation in place vs autograd's, bucketed reducer, 2 ranks (gloo, one GPU): matrices "
           f"bit-identical, worst 1-D difference {max(r[2] for r in res):.2e}")
+
+
+def _slot_worker(rank, world, port, q):
+    """Fresh weight gradients written straight into the reducer's bucket slices (model_train._grad_slots +
+    BucketedGradAllReduce.grad_slot): from the second optimizer step on the block matrices are
+    not packed at all, and every gradient equals the packed route's — matrices bit for bit — on two ranks."""
+    try:
+        import importlib
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        par = importlib.import_module(PKG + ".parallel")
+        base, noise, context, vt = _tiny_model_and_batch(rank)
+
+        def optimizer_steps(direct):
+            m = copy.deepcopy(base)
+            m.direct_grad_accumulation = direct
+            red = par.BucketedGradAllReduce(m.parameters(), bucket_mb=1.0)
+            out, packed = [], []
+            for step, scale in enumerate((1.0, 0.5, -0.75)):
+                _reference_step(m, noise * scale, context, vt)
+                red.finish()
+                torch.cuda.synchronize()
+                packed.append(int(red.packed_elements))
+                out.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+                m.zero_grad(set_to_none=True)
+            red.remove()
+            return out, packed
+        want, packed0 = optimizer_steps(False)
+        got, packed1 = optimizer_steps(True)
+        matrices = sum(p.numel() for n, p in base.named_parameters() if n.startswith("blocks.") and p.dim() == 2)
+        total = sum(v.numel() for v in want[0].values())
+        assert packed0 == [total] * 3, (packed0, total)
+        assert packed1[0] == total and packed1[1] == packed1[2] == total - sum(
+            v.numel() for n, v in want[1].items() if n.startswith("blocks.") and v.dim() == 2), (packed1, total, matrices)
+        for a, b in zip(got, want):
+            assert set(a) == set(b)
+            for n in b:
+                if b[n].dim() >= 2 and n.startswith("blocks."):
+                    assert torch.equal(a[n], b[n]), n
+                else:
+                    assert float((a[n].double() - b[n].double()).norm() / b[n].double().norm().clamp_min(1e-30)) < 1e-4, n
+        q.put((rank, "ok", packed1))
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL " + repr(e) + traceback.format_exc()[-1500:], None))
+
+
+def test_weight_gradients_written_into_the_reducer_buckets_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_slot_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    assert sorted(r[:2] for r in res) == [(0, "ok"), (1, "ok")], res
+    print(f"[measured] elements packed per step with the weight gradients written in place: {res[0][2]}")

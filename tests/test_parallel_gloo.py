@@ -137,6 +137,57 @@ def _variant_worker(rank, world, port, q):
                             assert torch.allclose(a, b, rtol=2 ** -7, atol=2 ** -7 * float(b.abs().max())), (coll, pay)
                 if pay == torch.bfloat16:
                     assert wire * 2 <= wire32 + 64 * world * len(sizes), (wire, wire32)   # half the bytes (+ padding)
+        # ---- gradients written straight into the bucket slices (grad_slot: what model_train._grad_slots does for the
+        # weight matrices of a block): nothing is packed for them, the reduced values are the same, and a step in which
+        # the set of parameters with a gradient changes re-lays the bucket out without overwriting a neighbour
+        for coll, pay in (("all_reduce", torch.float32), ("reduce_scatter_all_gather", torch.float32),
+                          ("all_reduce", torch.bfloat16)):
+            torch.manual_seed(0)
+            params = [torch.nn.Parameter(torch.zeros(n)) for n in sizes]
+            red = par.BucketedGradAllReduce(params, bucket_mb=0.012, collective=coll, payload=pay)
+            assert all(red.grad_slot(p) is None for p in params)             # no layout before the first launch
+            for p, d in zip(params, grads):
+                p.grad = None
+            sum((p * d).sum() for p, d in zip(params, grads)).backward()
+            red.finish()
+            first = [p.grad.clone() for p in params]
+            for p in params:
+                p.grad = None
+            direct = (0, 2, 4)                                               # these write into their slot, the rest arrive fresh
+            for i, (p, d) in enumerate(zip(params, grads)):
+                if i in direct:
+                    slot = red.grad_slot(p)
+                    assert slot is not None and slot.shape == p.shape
+                    slot.copy_(d)
+                    p.grad = slot
+                else:
+                    p.grad = d.clone()
+            for p in reversed(params):
+                red._on_grad(p)
+            red.finish()
+            assert red.packed_elements == (sum(sizes[i] for i in range(len(sizes)) if i not in direct)
+                                           if pay == torch.float32 else sum(sizes))        # bf16: the cast IS the pack
+            for a, b in zip([p.grad for p in params], first):
+                assert torch.allclose(a, b, rtol=2 ** -6 if pay == torch.bfloat16 else 1e-6, atol=2 ** -6 * float(b.abs().max())
+                                      if pay == torch.bfloat16 else 1e-7), (coll, pay)
+            # the composition changes: parameter 0 gets no gradient this time, the others keep living in the flat buffer
+            keep = {i: params[i].grad.clone() for i in range(1, len(sizes))}
+            params[0].grad = None
+            for i in range(1, len(sizes)):
+                slot = red.grad_slot(params[i])
+                if slot is not None:
+                    slot.copy_(grads[i])
+                    params[i].grad = slot
+                else:
+                    params[i].grad = grads[i].clone()
+            for p in reversed(params[1:]):
+                red._on_grad(p)
+            red.finish()
+            assert params[0].grad is None
+            for i in range(1, len(sizes)):
+                assert torch.allclose(params[i].grad, keep[i], rtol=2 ** -6 if pay == torch.bfloat16 else 1e-6,
+                                      atol=2 ** -6 * float(keep[i].abs().max()) if pay == torch.bfloat16 else 1e-7), (coll, pay, i)
+            red.remove()
         # the environment selects the same variants (what bench.py / a launcher would set)
         os.environ.update(OMH_GRAD_COLLECTIVE="rs_ag", OMH_GRAD_PAYLOAD="bf16")
         red = par.BucketedGradAllReduce([torch.nn.Parameter(torch.zeros(4))])
