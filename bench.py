@@ -907,7 +907,7 @@ def main():
     roofline = None
     if attn_ms:
         ach = attn_flops / (attn_ms * 1e-3) / 1e12
-        kname = {"pp": "flash_attn_fwd_d128_pp_kernel", "base": "flash_attn_fwd_d128_kernel"}.get(
+        kname = {"base": "flash_attn_fwd_d128_kernel"}.get(
             (ops.get_option("ATTN_KERNEL") or ""), "flash_attn_fwd_d128_w64_v2_kernel")
         traffic = tsrc = None
         tj = os.path.join(ROOT, "profiles", "traffic_latest.json")

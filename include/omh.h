@@ -53,7 +53,7 @@ int omh_set_deterministic(int on);
 
 /* Process options (ABI v10).  Every dispatch switch of the library — kernel-family overrides used by the parity tests
  * (one product on every kernel that can take it) and by A/B timing — is an entry of one table:
- *   ATTN_KERNEL ("w64" / "pp" / "base")   ATTN_SPLIT ("0" / "tail")   W64_SPLIT ("0")   W64_VARIANT ("0".."2")
+ *   ATTN_KERNEL ("w64" / "base")   ATTN_SPLIT ("0" / "tail")   W64_SPLIT ("0")   W64_VARIANT (ablation builds only)
  *   GEMM_KERNEL ("w64" / "8w")   GEMM_TILE ("big" / "small" / "tiny")   GEMM_RULE   GEMM_GROUP_M   GEMM_SPLITK ("0")
  *   GEMM_QKV ("0" / "1")   GEMM_W64_R192 / N192 / BF16M / GBWD / GAUX ("0" / "1")
  *   GEMM_TN_W64 ("0" / "1")   GEMM_TN_TILE   GEMM_TN_GROUP_TILE ("big" / "small")   GEMM_TN_SPLIT (count)

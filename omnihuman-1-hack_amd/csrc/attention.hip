@@ -317,285 +317,9 @@ void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles, const 
     }
 }
 
-// ============================================================================================
-// Long-sequence kernel: 8 waves = 256 query rows per workgroup, one workgroup per CU, K/V tiles by LDS-DMA
-// (buffer_load ... lds) one tile ahead, ONE workgroup barrier per 64-key tile.
-//
-// Per tile t every wave runs
-//   softmax segment   row max of the scores of tile t (held in score set t&1), new running max
-//   wait own DMA; barrier                      -> K(t+1), V(t) visible; every wave is past the reads of tile t-1
-//   DMA  K(t+2) -> K slot t&1, V(t+1) -> V slot (t+1)&1   (their previous contents were last read in tile t-1)
-//   matrix segment
-//     phase 1  K(t+1).Q^T into the other score set   ||  exp2 + bf16 packing of tile t on the VALU
-//     phase 2  O^T += V^T(t).P^T(t)                  ||  row sum of tile t
-// The scores of tile t+1 do not depend on the softmax of tile t, so computing them first lets the 80 VALU
-// instructions of the exponentials hide under 16 MFMAs instead of serialising in front of P.V.
-//
-// History: this kernel started as a "ping-pong" — the two waves sharing a SIMD ran the
-// per-tile program half a period apart (two barriers per tile), one in its matrix segment while the other did
-// its softmax.  Once the exponentials moved under the score MFMAs the softmax segment became a few dozen
-// instructions and the enforced alternation only parked a wave at a barrier: without the offset, with one
-// barrier per tile, the two waves of a SIMD fill each other's MFMA stalls (+3.4 %).  The kernel keeps its name.
-// ============================================================================================
-constexpr int QB2 = 256;
-
-__global__ __launch_bounds__(512, 2)
-void flash_attn_fwd_d128_pp_kernel(const omh_attn_args p, const int q_tiles) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (KT_BYTES + VT_BYTES)];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-
-    const int nwg = q_tiles * p.H * p.B;
-    const int wid = xcd_remap(blockIdx.x, nwg);
-    const int bh = wid / q_tiles, qt = wid % q_tiles;
-    const int b = bh / p.H, head = bh % p.H;
-    int klen = p.k_lens ? p.k_lens[b] : p.Lk;
-    klen = min(max(klen, 0), p.Lk);
-    const int n_tiles = (klen + KB - 1) / KB;
-
-    const __bf16* __restrict__ Q = (const __bf16*)p.q + (int64_t)b * p.q_bs + head * D;
-    const __bf16* __restrict__ K = (const __bf16*)p.k + (int64_t)b * p.k_bs + head * D;
-    const __bf16* __restrict__ VT = (const __bf16*)p.vt + (int64_t)b * p.vt_bs + (int64_t)head * D * p.ldv;
-
-    // static priority for the second-dispatched half of the workgroup (the arbitration loser on every segment)
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-    const int q_row = qt * QB2 + wave * 32 + li;
-    const int q_ld = min(q_row, p.Lq - 1);
-    bf16x8 qf[8];
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk)
-        qf[kk] = *(const bf16x8*)(Q + (int64_t)q_ld * p.q_rs + kk * 16 + lh * 8);
-
-    // LDS-DMA staging: chunk c = tid + 512 j lands at byte 16 c of the tile; the XOR swizzle goes on the
-    // per-lane SOURCE slot (K: (c&15)^(row&15), V^T: (c&7)^((row>>1)&7)) and again on the read.
-    const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)K, 0, (int)((((int64_t)p.Lk - 1) * p.k_rs + D) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)VT, 0, (int)((int64_t)D * p.ldv * 2), 0x00020000);
-    uint32_t voff_k[2], voff_v[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int c = tid + 512 * j;
-        const int kr = c >> 4, vr = c >> 3;
-        voff_k[j] = (uint32_t)((kr * (int)p.k_rs + (((c & 15) ^ (kr & 15)) * 8)) * 2);
-        voff_v[j] = (uint32_t)((vr * p.ldv + (((c & 7) ^ ((vr >> 1) & 7)) * 8)) * 2);
-    }
-    const uint32_t k_tile_bytes = (uint32_t)(KB * (int)p.k_rs * 2), v_tile_bytes = KB * 2;
-    const int wave_lds = __builtin_amdgcn_readfirstlane(wave) * 1024;
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    unsigned char* const kring = smem;
-    unsigned char* const vring = smem + 2 * KT_BYTES;
-#define PP_KDMA(T, BUF)                                                                         \
-    {                                                                                           \
-        const uint32_t ko_ = (uint32_t)(T) * k_tile_bytes;                                      \
-        unsigned char* d_ = kring + (BUF) * KT_BYTES + wave_lds;                                \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, (lds_ptr_t)(d_), 16, voff_k[0] + ko_, 0, 0, 0);        \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, (lds_ptr_t)(d_ + 8192), 16, voff_k[1] + ko_, 0, 0, 0); \
-    }
-#define PP_VDMA(T, BUF)                                                                         \
-    {                                                                                           \
-        const uint32_t vo_ = (uint32_t)(T) * v_tile_bytes;                                      \
-        unsigned char* d_ = vring + (BUF) * VT_BYTES + wave_lds;                                \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lds_ptr_t)(d_), 16, voff_v[0] + vo_, 0, 0, 0);        \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lds_ptr_t)(d_ + 8192), 16, voff_v[1] + vo_, 0, 0, 0); \
-    }
-#define PP_BARRIER() asm volatile("s_barrier" ::: "memory");
-#define PP_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-
-    const int krow_l = swap_bits23(li);
-    f32x16 oacc[4], S[2][2];          // S[t & 1]: scores of tile t (then its exponentials); S[~t & 1]: tile t+1
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-    const float sc = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
-    bf16x8 pf[2][2];
-    float alpha_keep = 1.0f;
-
-// fragment reads run two MFMA pairs ahead of their use (explicit register ring): a lone wave per
-// matrix segment has nobody to hide its ds_read latency behind
-    // per-lane LDS byte offsets of this lane's K / V^T fragments inside a ring slot, computed once and made
-    // opaque to the optimiser (it otherwise re-adds row and swizzled-slot parts in front of every ds_read:
-    // 16 v_add per tile); ring slot, second 32-row block and d-block are immediate offsets on top.
-    uint32_t ka[8], va[4];
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-        ka[kk] = k_addr(krow_l, 2 * kk + lh);
-        asm volatile("" : "+v"(ka[kk]));
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        va[j] = v_addr(li, 2 * j + lh);
-        asm volatile("" : "+v"(va[j]));
-    }
-// K fragments: 2 per 16-wide d step, read two steps ahead of their MFMAs (explicit register ring)
-#define PP_QK_LOADS(KBUF, KK_)                                                                  \
-        kr_[(KK_) % 3][0] = *(const bf16x8*)(kring + (KBUF) * KT_BYTES + ka[KK_]);              \
-        kr_[(KK_) % 3][1] = *(const bf16x8*)(kring + (KBUF) * KT_BYTES + ka[KK_] + 8192);
-#define PP_QK_BODY(KBUF, DST)                                                                   \
-        bf16x8 kr_[3][2];                                                                       \
-        PP_QK_LOADS(KBUF, 0)                                                                    \
-        PP_QK_LOADS(KBUF, 1)                                                                    \
-        _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                      \
-            if (kk + 2 < 8) { PP_QK_LOADS(KBUF, kk + 2) }                                       \
-            if (kk == 0) {                                                                      \
-                const f32x16 z_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
-                S[DST][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr_[0][0], qf[0], z_, 0, 0, 0); \
-                S[DST][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr_[0][1], qf[0], z_, 0, 0, 0); \
-            } else {                                                                            \
-                S[DST][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr_[kk % 3][0], qf[kk], S[DST][0], 0, 0, 0); \
-                S[DST][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr_[kk % 3][1], qf[kk], S[DST][1], 0, 0, 0); \
-            }                                                                                   \
-        }
-// scores of the current tile -> exponentials (log2 domain) -> bf16 P fragments
-#define PP_EXP_PACK(CUR)                                                                        \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                        \
-            S[CUR][0][r] = fast_exp2(fmaf(S[CUR][0][r], sc, -m_run));                           \
-            S[CUR][1][r] = fast_exp2(fmaf(S[CUR][1][r], sc, -m_run));                           \
-        }                                                                                       \
-        _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                         \
-            u32x4 c0, c1;                                                                       \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                     \
-                c0[e] = pack_bf2(S[CUR][0][8 * a + 2 * e], S[CUR][0][8 * a + 2 * e + 1]);       \
-                c1[e] = pack_bf2(S[CUR][1][8 * a + 2 * e], S[CUR][1][8 * a + 2 * e + 1]);       \
-            }                                                                                   \
-            pf[0][a] = __builtin_bit_cast(bf16x8, c0);                                          \
-            pf[1][a] = __builtin_bit_cast(bf16x8, c1);                                          \
-        }
-
-    if (n_tiles > 0) {
-        PP_KDMA(0, 0) PP_VDMA(0, 0) PP_KDMA(1, 1)
-    }
-    PP_WAIT_DMA();
-    PP_BARRIER()
-    if (n_tiles > 0) {
-        PP_QK_BODY(0, 0)
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-        for (int g_ = 0; g_ < 6; ++g_) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-    }
-
-    // Two tiles per trip so that the LDS ring slot and the score register set are compile-time constants in each
-    // copy (fragment addresses = hoisted per-lane bases + immediate offsets).
-    //
-    // Per tile a wave runs a short softmax segment (row max of the scores of tile t, new running max) and, after
-    // the barrier, its matrix segment in two phases:
-    //   phase 1  K(t+1)·Qᵀ into the OTHER score set   ∥  exp2 / bf16 packing of tile t on the VALU
-    //   phase 2  O^T += V^T(t)·P^T(t)                 ∥  row sum of tile t
-    // The scores of tile t+1 do not depend on the softmax of tile t, so putting them first gives the 80 VALU
-    // instructions of the exponentials 16 MFMAs to hide under, instead of serialising them in front of P·V.
-    for (int t2 = 0; t2 < n_tiles; t2 += 2) {
-#pragma unroll
-        for (int par = 0; par < 2; ++par) {
-            const int t = t2 + par;
-            if (t >= n_tiles) break;                   // wave-uniform
-            // ---------------- softmax segment: row max of tile t
-            {
-                const int kv0 = t * KB;
-                if (__builtin_expect(kv0 + KB > klen, 0)) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = kv0 + ((r >> 3) << 4) + lh * 8 + (r & 7);
-                        if (key >= klen) S[par][0][r] = -INFINITY;
-                        if (key + 32 >= klen) S[par][1][r] = -INFINITY;
-                    }
-                }
-                // compiler-visible first read of both score accumulators (MFMA -> VALU wait states, see the base kernel)
-                const float mx_seed = fmaxf(S[par][0][0], S[par][1][0]);
-                float mx = mx_seed, mx2 = mx_seed;
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {                       // two independent chains
-                    mx = vmax3(mx, S[par][0][r], S[par][1][r]);
-                    mx2 = vmax3(mx2, S[par][0][r + 1], S[par][1][r + 1]);
-                }
-                { float a_, b_; xhalf(vmax3(mx, mx2, mx2), a_, b_); mx = a_; mx2 = b_; }
-                const float m_new = vmax3(m_run, mx * sc, mx2 * sc);
-                alpha_keep = fast_exp2(m_run - m_new);
-                m_run = m_new;
-            }
-            if (t > 0) PP_WAIT_DMA();                      // this wave's share of DMA(t-1), issued one tile ago
-            PP_BARRIER()
-            PP_KDMA(t + 2, par) PP_VDMA(t + 1, par ^ 1)
-            // ---------------- matrix segment
-            {
-                if (!__all(alpha_keep == 1.0f)) {          // wave-uniform: the running max rarely moves after the first tiles
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha_keep;
-                }
-                // phase 1
-                if (t + 1 < n_tiles) {
-                    PP_QK_BODY(par ^ 1, par ^ 1)
-                    PP_EXP_PACK(par)
-                    // 4 fragment reads up front, then per MFMA pair: 2 reads (while any remain) + 10 of the 80 VALU
-                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 2);
-#pragma unroll
-                    for (int g_ = 0; g_ < 8; ++g_) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 2);
-                        if (g_ < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 2);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 10, 2);
-                    }
-                } else {
-                    PP_EXP_PACK(par)
-                }
-                // phase 2
-                float rs = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) rs += S[par][0][r] + S[par][1][r];
-                { float a_, b_; xhalf(rs, a_, b_); rs = a_ + b_; }
-                l_run = l_run * alpha_keep + rs;
-                const unsigned char* vt = vring + (par) * VT_BYTES;
-                // 16 steps i = (kb, a, db); V^T fragments are read 4 steps ahead
-                bf16x8 vr_[8];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) vr_[i] = *(const bf16x8*)(vt + va[0] + i * 4096);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int kb = i >> 3, a = (i >> 2) & 1, db = i & 3;
-                    if (i + 4 < 16) {
-                        const int j = i + 4, kbj = j >> 3, aj = (j >> 2) & 1, dbj = j & 3;
-                        vr_[j & 7] = *(const bf16x8*)(vt + va[2 * kbj + aj] + dbj * 4096);
-                    }
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr_[i & 7], pf[kb][a], oacc[db], 0, 0, 0);
-                }
-                // 4 fragment reads, then per MFMA one read and 3 of the row-sum adds
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
-#pragma unroll
-                for (int g_ = 0; g_ < 12; ++g_) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 1);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
-            }
-        }
-    }
-
-    if (q_row < p.Lq) {
-        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-        uint16_t* O = (uint16_t*)p.o + (int64_t)b * p.o_bs + (int64_t)q_row * p.o_rs + head * D;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                uint2 pk;
-                pk.x = pack_bf2(oacc[db][4 * gq] * inv, oacc[db][4 * gq + 1] * inv);
-                pk.y = pack_bf2(oacc[db][4 * gq + 2] * inv, oacc[db][4 * gq + 3] * inv);
-                *(uint2*)(O + db * 32 + gq * 8 + lh * 4) = pk;
-            }
-        if (p.lse && lh == 0) {
-            const float lse = l_run > 0.f ? (m_run + log2f(l_run)) * 0.6931471805599453f : -INFINITY;
-            p.lse[((int64_t)b * p.H + head) * p.Lq + q_row] = lse;
-        }
-    }
-}
+// (Round 5: the 8-wave 256-row long-sequence kernel "pp" that preceded attention_w64.hip was retired — the generated
+// 4 x 64 stream supersedes it on every shape it took; its history is in DESIGN_HISTORY.md 4.1 / 9.1.)
+constexpr int QB2 = 256;            // query rows of a long-sequence workgroup (attention_w64.hip)
 
 // out[row] = sum_s w_s O_s[row] / sum_s w_s,  w_s = exp(lse_s - max lse)  (flash-decoding reduction over the split-KV
 // workers of a tail tile): one wave per query row, a lane per pair of channels; also the fp32 output and the lse.
@@ -638,14 +362,13 @@ void attn_split_combine_kernel(const omh_attn_args p, const int q_tiles, const A
 // attention_w64.hip: 4 waves x 64 query rows, asm-owned register file (long sequences)
 int omh_launch_attn_w64(const omh_attn_args& a, hipStream_t stream);
 
-// Which forward kernel a call takes.  OMH_ATTN_KERNEL = "w64" / "pp" / "base": test / benchmarking override (looked up
+// Which forward kernel a call takes.  Option ATTN_KERNEL = "w64" / "base": test / benchmarking override (looked up
 // per call — the tests flip it inside one process; a getenv is ~50 ns against ~3.5 us of launch).
-struct AttnChoice { bool w64, pp; };
+struct AttnChoice { bool w64; };
 static AttnChoice attn_choice(const omh_attn_args& a) {
     const char* force = omh_opt(OMH_OPT_ATTN_KERNEL);
     const int q_tiles2 = (a.Lq + QB2 - 1) / QB2;
-    // long sequences that fill the chip with 256-row workgroups take the 4 x 64 kernel (attention_w64.hip); "pp" keeps
-    // the 8-wave kernel it replaced selectable for A/B timing
+    // long sequences that fill the chip with 256-row workgroups take the 4 x 64 kernel (attention_w64.hip)
     const bool big = (int64_t)q_tiles2 * a.H * a.B >= 512 && a.Lk >= 1024;
     // 32-bit buffer offsets inside one (batch, head) slice
     const bool fits32 = ((int64_t)a.Lq * a.q_rs * 2 < 0x7fffffffLL) && ((int64_t)a.Lk * a.k_rs * 2 < 0x7fffffffLL) &&
@@ -653,7 +376,6 @@ static AttnChoice attn_choice(const omh_attn_args& a) {
     AttnChoice c;
     const bool short_only = a.o32 || a.q_lens || (a.flags & OMH_ATTN_SHORT_KERNEL);        // fp32 output / q_lens: base kernel only
     c.w64 = short_only ? false : (force ? (force[0] == 'w' && fits32) : (big && fits32));
-    c.pp = short_only ? false : (force ? (force[0] == 'p') : (big && !c.w64));
     return c;
 }
 // Split plan of the short-sequence kernel (OMH_ATTN_ALLOW_SPLIT; two workgroups per CU; >= 4 key tiles per worker)
@@ -671,7 +393,7 @@ static OmhSplitPlan base_split_plan(const omh_attn_args& a) {
 }
 int64_t omh_attn_base_workspace_bytes(const omh_attn_args& a) {
     const AttnChoice ch = attn_choice(a);
-    if (ch.w64 || ch.pp) return 0;
+    if (ch.w64) return 0;
     const OmhSplitPlan pl = base_split_plan(a);
     return (int64_t)pl.n_tail * pl.splits * QB * (D + 1) * 4;
 }
@@ -687,16 +409,14 @@ extern "C" int omh_flash_attn_fwd_d128(const omh_attn_args* args, omh_stream_t s
     if (((uintptr_t)a.q & 15) || ((uintptr_t)a.k & 15) || ((uintptr_t)a.vt & 15) || ((uintptr_t)a.o & 7))
         return OMH_E_ALIGN;
     if (a.ldv < ((a.Lk + KB - 1) / KB) * KB) return OMH_E_SHAPE;
+    // 32-bit buffer offsets inside one (batch, head) slice of K / V^T (both kernels)
+    if ((int64_t)a.Lk * a.k_rs * 2 >= 0x7fffffffLL || (int64_t)D * a.ldv * 2 >= 0x7fffffffLL) return OMH_E_SHAPE;
     if (a.o32 && (((uintptr_t)a.o32 & 15) || (a.o_rs & 3) || (a.o_bs & 3))) return OMH_E_ALIGN;
     const AttnChoice ch = attn_choice(a);
-    const bool w64 = ch.w64, pp = ch.pp;
+    const bool w64 = ch.w64;
     omh_clear_status();
     if (w64) {
         omh_launch_attn_w64(a, (hipStream_t)stream);
-    } else if (pp) {
-        const int q_tiles2 = (a.Lq + QB2 - 1) / QB2;
-        hipLaunchKernelGGL(flash_attn_fwd_d128_pp_kernel, dim3(q_tiles2 * a.H * a.B), dim3(512), 0,
-                           (hipStream_t)stream, a, q_tiles2);
     } else {
         const int q_tiles = (a.Lq + QB - 1) / QB;
         OmhSplitPlan pl = base_split_plan(a);

@@ -437,7 +437,7 @@ def _attn_ref(q, k, v, k_lens, scale):
 @pytest.mark.parametrize("B,H,Lq,Lk,klens", [
     (1, 1, 128, 64, None), (2, 2, 200, 200, [200, 77]), (1, 12, 1560, 1560, [1560]),
     (2, 3, 130, 512, [37, 512]), (1, 2, 64, 320, [257]), (2, 1, 100, 64, [0, 5])])
-@pytest.mark.parametrize("kernel", ["base", "pp", "w64"])
+@pytest.mark.parametrize("kernel", ["base", "w64"])
 def test_flash_attention(ops, B, H, Lq, Lk, klens, kernel, monkeypatch):
     set_option("OMH_ATTN_KERNEL", kernel)      # both kernels on every shape (ragged rows/keys, empty rows)
     torch.manual_seed(Lq + Lk)
@@ -512,7 +512,7 @@ def test_flash_attention_long_sequence_dispatch(ops):
     assert float((out.float() - ref).abs().max()) < 3e-2
 
 
-@pytest.mark.parametrize("kernel", ["base", "pp", "w64"])
+@pytest.mark.parametrize("kernel", ["base", "w64"])
 def test_flash_attention_peaked_rows(ops, kernel, monkeypatch):
     """Forces large online-softmax rescales: one key dominates late in the sequence."""
     set_option("OMH_ATTN_KERNEL", kernel)
@@ -529,15 +529,14 @@ def test_flash_attention_peaked_rows(ops, kernel, monkeypatch):
     assert rel_rms(out.float(), ref) < 8e-3
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2"])
-def test_flash_attention_w64_prescaled_q_lse_and_late_rescale(ops, variant, monkeypatch):
-    """The asm-owned 4 x 64 long-sequence kernel (csrc/attention_w64.hip, every stream variant) as the model drives
+def test_flash_attention_w64_prescaled_q_lse_and_late_rescale(ops, monkeypatch):
+    """The asm-owned 4 x 64 long-sequence kernel (csrc/attention_w64.hip; the shipped stream — the earlier variants are
+    built for the generator's ablation runs only, round 5) as the model drives
     it: q already multiplied by softmax_scale * log2(e) by the norm kernel (omh_attn_args.q_prescaled), log-sum-exp
     requested, ragged rows and keys, masked keys, and a key that dominates LATE in the sequence with large scores so
     that the deferred running-max update (rescale of the AGPR accumulators) runs after hundreds of tiles.  Against
     fp32 softmax attention on the same bf16 operands, and bit for bit against itself."""
     set_option("OMH_ATTN_KERNEL", "w64")
-    set_option("OMH_W64_VARIANT", variant)
     D, LOG2E = 128, 1.4426950408889634
     g = torch.Generator(device="cuda").manual_seed(11)
     for (B, H, Lq, Lk, klens, amp) in ((1, 2, 300, 200, None, 1.0), (2, 2, 777, 1000, [1000, 333], 1.0),
@@ -666,7 +665,7 @@ def test_patchify_unpatchify_dense_sinusoid(ops):
     assert torch.equal(ops.cast_bf16(c), c.to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("kernel", ["base", "pp", "w64"])
+@pytest.mark.parametrize("kernel", ["base", "w64"])
 def test_flash_attention_is_bitwise_repeatable(ops, kernel, monkeypatch):
     """Same inputs, same bits, every launch.  The base kernel once took its row max through an inline-asm v_max3
     that hipcc's hazard recognizer does not see: issued right behind the last K.Q^T MFMA it sometimes read scores

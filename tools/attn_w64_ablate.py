@@ -10,12 +10,12 @@ Sp = (S + 63) // 64 * 64
 vt = torch.zeros(1, H * D, Sp, dtype=torch.bfloat16, device="cuda")
 vt[:, :, :S] = torch.randn(1, H * D, S, device="cuda").to(torch.bfloat16)
 o = torch.empty_like(q)
-variants = sys.argv[1:] or ["pp", "0", "1", "2"]
+variants = sys.argv[1:] or ["2"]      # "0" / "1": ablation builds of the generator only (OMH_ATTN_ABL, tools/attn_abl.sh)
 res = {v: [] for v in variants}
 for rnd in range(3):
     for v in variants:
-        if v == "pp":
-            ops.set_option("OMH_ATTN_KERNEL", "pp")
+        if v == "base":
+            ops.set_option("OMH_ATTN_KERNEL", "base")
         else:
             ops.set_option("OMH_ATTN_KERNEL", "w64"); ops.set_option("OMH_W64_VARIANT", v)
         for _ in range(2):

@@ -91,7 +91,7 @@ def timeit():
     o = torch.empty_like(q)
     res = {}
     for rnd in range(3):
-        for kind in ("pp", "w64"):
+        for kind in ("w64",):
             ops.set_option("OMH_ATTN_KERNEL", kind)
             for _ in range(3):
                 ops.flash_attn(q, k, vt, None, out=o)

@@ -85,7 +85,7 @@ def main():
     q, k = rr(0), rr(d)
     vtt = vt()
     sl = torch.tensor([S], dtype=torch.int32, device=dev)
-    for kern in ("base", "pp"):
+    for kern in ("base", "w64"):
         ops.set_option("OMH_ATTN_KERNEL", kern)
         rep(f"flash_attn_self[{kern}]", lambda: ops.flash_attn(q.view(1, S, N, D), k.view(1, S, N, D), vtt, k_lens=sl), res)
     ops.set_option("OMH_ATTN_KERNEL", None)
