@@ -340,6 +340,148 @@ def main_loop(e, NA, NB, kind):
         e("s_nop 7")                                             # last MFMA results readable by VALU
 
 
+# ---------------------------------------------------------------- the split-bf16 ("pair") k loop, round 5
+# The fp32-faithful VAE mode (vae.py:619-624: the reference's VAE computes in fp32) carries every operand as a bf16 pair
+# hi = bf16(x), lo = bf16(x - hi) and needs x_hi w_hi + x_lo w_hi + x_hi w_lo per channel.  Rounds 3-4 ran that as an
+# ordinary convolution over three channel blocks ([hi | lo | hi] against [hi | hi | lo]): x_hi and w_hi staged, read from
+# LDS and masked TWICE.  Here the operands are interleaved per 16 channels — a slab row of 64 bytes is [x_hi(16) | x_lo(16)],
+# a weight row per tap [w_hi(16) | w_lo(16)], i.e. an ordinary tensor of 2 C channels to the loader — and a stage's
+# 3 taps x 3 products = 9 groups of 12 MFMAs share their fragments:
+#     (kw, 0)  W_hi . X_hi   || reads X_lo(kw)
+#     (kw, 1)  W_hi . X_lo   || reads W_lo(kw)
+#     (kw, 2)  W_lo . X_hi   || reads W_hi(kw + 1), X_hi(kw + 1)
+# 14 fragment reads, 13 LDS-DMA pieces, one barrier and at most 32 edge ANDs per 108 MFMAs where the three-block form
+# has 21 / 19.5 / 1.5 / 48 per 108 — a third less of everything that is not an MFMA.  Register sets: W_A always holds
+# w_hi, W_B w_lo; the two X sets swap roles with every tap (x_hi(kw + 1) goes where x_lo(kw) was, free after group
+# (kw, 1)), so with 3 taps per stage the stream alternates between two stage bodies (parity 0 / 1) and needs an EVEN number
+# of stages (9 taps x C / 16 blocks: always), 14 of them peeled at the head.  Accumulation order per output element:
+# stages in (kt, kh, block) order, per block kw-major and hi.hi, lo.hi, hi.lo — fp32 sums in another order than the
+# three-block form (1e-6 class, tests/test_gpu_vae.py).
+UNROLL_PAIR = 14
+
+
+def main_loop_pair(e, NA, NB, kind):
+    NP = NA + NB
+    R = 2 if kind == "bf16" else 4
+    WSET = {"A": FRAG[0], "B": FRAG[1]}
+    XSET = {0: FRAG[0] + 12, 1: FRAG[1] + 12}
+
+    def wreads(h, kw, ws):
+        return [("r", f"W{ws}.{i}", f"ds_read_b128 {vr(WSET[ws] + 4 * i, 4)}, {vr(WADDR + h)} offset:{kw * 64 + i * 6144}")
+                for i in range(NI)]
+
+    def xreads(h, kw, xs):
+        return [("r", f"X{xs}.{j}", f"ds_read_b128 {vr(XSET[xs] + 4 * j, 4)}, {vr(XADDR + 2 * kw + h)} offset:{j * 2048}")
+                for j in range(NJ)]
+
+    def xands(kw, xs, j):
+        if kw == 1:
+            return []
+        m = (EDGE0 if kw == 0 else EDGE2) + j
+        return [("m", f"v_and_b32 v{XSET[xs] + 4 * j + r_}, v{m}, v{XSET[xs] + 4 * j + r_}", [f"X{xs}.{j}"]) for r_ in range(4)]
+
+    def sched(ws, xs, first, reads_next, dma_instrs, own_kw, ands_next, read_gap0=0):
+        """12 MFMAs W[ws] . X[xs] (voxel tile major) with the rest dealt into the gaps: the next group's fragment reads
+        from gap read_gap0 on, the edge ANDs of this group's fragments j >= 1 (own_kw: the tap whose X set is fresh in this
+        group, None when it was masked by an earlier group) in the gaps of fragment j - 1, the next group's ANDs of
+        fragment 0 in gaps 9 / 10, the DMA instructions spread over all gaps."""
+        gaps = [[] for _ in range(NJ * NI)]
+        for k, r in enumerate(reads_next):
+            gaps[min(NJ * NI - 1, read_gap0 + k)].append(r)
+        if own_kw is not None:
+            for j in range(1, NJ):
+                a = xands(own_kw, xs, j)
+                gaps[NI * (j - 1)] += a[:2]
+                gaps[NI * (j - 1) + 1] += a[2:]
+        gaps[9] += ands_next[:2]
+        gaps[10] += ands_next[2:]
+        n = len(dma_instrs)
+        for t, ins in enumerate(dma_instrs):
+            gaps[min(NJ * NI - 1, (t * NJ * NI) // n)].append(ins)
+        out = []
+        for j in range(NJ):
+            for i in range(NI):
+                c = "0" if first else acc(i, j)
+                out.append(("m", f"v_mfma_f32_32x32x16_bf16 {acc(i, j)}, {vr(WSET[ws] + 4 * i, 4)}, {vr(XSET[xs] + 4 * j, 4)}, {c}",
+                            [f"W{ws}.{i}", f"X{xs}.{j}"]))
+                out += gaps[NI * j + i]
+        return out
+
+    # the lane table, written to LDS by the C++ prologue (as main_loop)
+    for k in range(11):
+        e(f"ds_read_b128 {vr(12 + 4 * k, 4)}, %[vtab] offset:{16 * k}")
+    e(f"v_mov_b32 v{TMP + 4}, 0x80000000")
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_barrier")
+    e(f"v_mov_b32 v{V_RES_OFF}, v{VOC}")
+    for s_, v_ in (("s80", 0), ("s81", 0), ("s82", 0), ("s83", 0), ("s84", 0), ("s89", 0), ("s97", STAGE),
+                   ("s98", (-(NSTAGES - 1) * STAGE) & 0xffffffff)):
+        e(f"s_mov_b32 {s_}, {v_}")
+    pieces = dma_pieces(NA, NB)
+    for _ in range(2):
+        for ops in pieces:
+            for op in ops:
+                e(op[1])
+    e(f"s_waitcnt vmcnt({NP})")
+    e("s_barrier")
+    # group (0, 0) of a stage of parity p needs W_hi(0) in W_A and X_hi(0) in X set p
+    first_ops = lambda p: wreads(0, 0, "A") + xreads(0, 0, p) + xands(0, p, 0)
+    LP = {0: linearize(e, first_ops(0), [])}
+    LP[1] = [t.replace("X0.", "X1.") for t in LP[0]]
+    e(f"s_sub_u32 s85, {S_NS}, 2")
+    # the DMA op lists of a stage over groups 0 .. 7 (group 8 sits behind the stage's barrier)
+    cut = [0, 2, 4, 6, 8, 10, 12, 14, len(pieces)]
+
+    def body(p, mode, first=False, res_tile=None, r_prev=0):
+        hi = lambda kw: (p + kw) & 1
+        pend = LP[p]
+        dm = pieces if mode == "full" else []
+        per = [[op for piece in dm[cut[g]:cut[g + 1]] for op in piece] for g in range(8)] if dm else [[]] * 8
+        for kw in range(3):
+            h, l = hi(kw), 1 - hi(kw)
+            # (kw, 0): W_hi . X_hi || X_lo(kw) -> the other X set (it held X_hi(kw - 1): its last MFMA was one group ago)
+            ops = sched("A", h, first and kw == 0, xreads(1, kw, l), per[3 * kw], kw, xands(kw, l, 0), read_gap0=2)
+            pend = linearize(e, ops, pend)
+            # (kw, 1): W_hi . X_lo || W_lo(kw) -> W_B
+            ops = sched("A", l, False, wreads(1, kw, "B"), per[3 * kw + 1], kw, [])
+            pend = linearize(e, ops, pend)
+            # (kw, 2): W_lo . X_hi || the next tap's W_hi -> W_A, X_hi -> the set X_lo(kw) has left
+            if kw < 2:
+                nxt = wreads(0, kw + 1, "A") + xreads(0, kw + 1, l)
+                ops = sched("B", h, False, nxt, per[3 * kw + 2], None, xands(kw + 1, l, 0))
+                pend = linearize(e, ops, pend)
+        h2, l2 = hi(2), 1 - hi(2)
+        if mode == "last":
+            linearize(e, sched("B", h2, False, [], [], None, []), pend)
+            return
+        e(f"s_waitcnt vmcnt({(NP if mode == 'full' else 0) + r_prev})")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_barrier")
+        advance(e)
+        req = [("x", ln) for ln in res_request(res_tile, kind)] if res_tile is not None else []
+        nxt = wreads(0, 0, "A") + xreads(0, 0, l2)              # the NEXT stage's group (0, 0): its parity is 1 - p = l2
+        pend = linearize(e, sched("B", h2, False, nxt, req, None, xands(0, l2, 0)), [])
+        assert l2 == 1 - p and pend == LP[1 - p], (pend, LP[1 - p])
+
+    LOOP, REST = e.lab("loop"), e.lab("rest")
+    for k in range(UNROLL_PAIR):
+        body(k & 1, "full", first=(k == 0), res_tile=(k if k < NTILES else None), r_prev=(R if 0 < k <= NTILES else 0))
+    e(f"s_sub_u32 s85, s85, {UNROLL_PAIR}")
+    e("s_cmp_eq_u32 s85, 0")
+    e(f"s_cbranch_scc1 {REST}")
+    e.label(LOOP)
+    body(0, "full")
+    body(1, "full")
+    e("s_sub_u32 s85, s85, 2")
+    e("s_cmp_lg_u32 s85, 0")
+    e(f"s_cbranch_scc1 {LOOP}")
+    e.label(REST)
+    body(0, "nodma")
+    body(1, "last")
+    for _ in range(3):
+        e("s_nop 7")
+
+
 def spread_keep(ops, extras):
     """Insert op lists `extras` after MFMAs 2, 5, 8, 11 ... of an already interleaved op list."""
     if not extras:
@@ -574,10 +716,10 @@ def epilogue_norm(e, kind):
         e("s_mov_b64 exec, s[86:87]")
 
 
-def generate(cfg, kind, norm=False):
-    e = Emit(cfg + kind + ("n" if norm else ""))
+def generate(cfg, kind, norm=False, pair=False):
+    e = Emit(cfg + kind + ("n" if norm else "") + ("p" if pair else ""))
     NA, NB = CONFIGS[cfg]
-    main_loop(e, NA, NB, kind)
+    (main_loop_pair if pair else main_loop)(e, NA, NB, kind)
     (epilogue_norm if norm else epilogue)(e, kind)
     return e
 
@@ -592,6 +734,12 @@ def main():
                 print(" \\\n".join(e.text().split("\n")))
                 print("")
                 print(f"// {cfg} {kind}{' norm' if norm else ''}: {len(e.lines)} lines, {sum('v_mfma' in ln for ln in e.lines)} MFMA")
+    for cfg in CONFIGS:                                          # the split-bf16 pair streams (fp32-faithful VAE mode): fp32 out
+        e = generate(cfg, "f32", False, pair=True)
+        print(f"#define OMH_CONV_W64_ASM_{cfg}_F32_PAIR \\")
+        print(" \\\n".join(e.text().split("\n")))
+        print("")
+        print(f"// {cfg} f32 pair: {len(e.lines)} lines, {sum('v_mfma' in ln for ln in e.lines)} MFMA")
     clob = ['"memory"', '"vcc"', '"scc"'] + [f'"s{i}"' for i in range(80, 100)] + [f'"v{i}"' for i in range(12, 256)] + \
            [f'"a{i}"' for i in range(256)]
     print("#define OMH_CONV_W64_CLOBBERS \\")

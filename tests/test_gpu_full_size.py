@@ -573,7 +573,7 @@ def test_gradient_accumulation_full_size_in_place_equals_autograd(clips):
 # oracle/make_golden_full_size.py — the real WanModel.forward (model.py:502-563) at S = 32 760 with all 30 layers, and
 # 50-step CFG trajectories driven as text2video.py:206-252 drives them, on detgen weights / inputs regenerated here.
 # Bounds = 2 x the figures measured on MI355X (profiles/r05_full_forward_parity.json).
-TOL_HEADLINE_FORWARD = 1.4e-2        # 30 layers, S = 32 760, the long-sequence attention stream in the loop
+TOL_HEADLINE_FORWARD = 9.0e-3        # measured 4.06e-3 (lattice) / 4.44e-3 (probes) on MI355X, round 5: 30 layers, S = 32 760
 TOL_TRAJECTORY = {1: 2.0e-3, 10: 1.5e-2, 25: 3.0e-2, 50: 6.0e-2}       # relative RMS of the latent after k steps
 
 
