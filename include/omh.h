@@ -404,9 +404,22 @@ typedef struct omh_conv_args {
      * values either way.  norm_gamma: fp32 [Cout] or NULL (no norm); norm_out: bf16 [Tout,Hout,Wout,Cout];
      * norm_only != 0: the caller does not need y itself (still a valid buffer: the un-fused route goes through it). */
     const float* norm_gamma; void* norm_out; int32_t norm_only;
+    /* ABI v10 — the fp32-faithful VAE mode's convolution (the reference's VAE computes in fp32, vae.py:619-624,649-663)
+     * on split-bf16 PAIRS: != 0 says that x and w carry, per 16 real channels c0..c0+15, the 32 values
+     * [hi(c0..c0+15) | lo(c0..c0+15)] with hi = bf16(v), lo = bf16(v - hi) (omh_split3_f32 pattern 2), i.e. Cin = 2 x the
+     * real channel count, and that the product wanted is x_hi w_hi + x_lo w_hi + x_hi w_lo per channel (= x w - x_lo w_lo,
+     * an fp32-class product with fp32 accumulation).  Served by the stream kernel only (3x3(x3) "same" convolutions of
+     * the residual blocks and the folded-upsample convolutions, fp32 output, Cin % 32 == 0, Cout = 96 or a multiple of
+     * 192): three MFMA products per channel block that share their LDS fragments — a third less staging, LDS reads and
+     * barriers per MFMA than the same product as a 3 C-channel convolution over [hi | lo | hi] x [hi | hi | lo]
+     * (pattern 0 / 1, which every other layer keeps).  omh_conv_pair_supported() says whether a call would be taken
+     * (by the layer's geometry only, never by the number of frames); omh_conv_cl_bf16 returns OMH_E_SHAPE otherwise. */
+    int32_t pair;
 } omh_conv_args;
 
 int omh_conv_cl_bf16(const omh_conv_args* args, omh_stream_t stream);
+/* 1 if omh_conv_cl_bf16 would take `args` with args->pair != 0 (the pointers are not dereferenced), else 0. */
+int omh_conv_pair_supported(const omh_conv_args* args);
 
 /* RMS_norm over channels (+ optional SiLU) per voxel (vae.py:39-54,195-197):
  *   y[p][c] = act( x[p][c] / max(||x[p]||_2, 1e-12) * sqrt(C) * gamma[c] ),  x,y bf16 [P, C]. */
@@ -450,6 +463,11 @@ int omh_split3_f32(const float* x, int64_t ldx, void* y_bf16, int64_t ldy, int64
                    int32_t pattern, omh_stream_t stream);
 int omh_rms_silu_cl_split3(const float* x_f32, const float* gamma, void* y_bf16x3, int64_t P, int32_t C,
                            int32_t do_silu, omh_stream_t stream);
+/* ABI v10 — the PAIR layout of omh_conv_args.pair: omh_split3_f32 with pattern 2 writes y bf16 [rows, 2 Cp] (pitch
+ * ldy >= 2 Cp, Cp % 16 == 0): per 16 channels c0.. the 32 values [hi(c0..c0+15) | lo(c0..c0+15)] — activations and
+ * weights alike; omh_rms_silu_cl_pair is omh_rms_silu_cl_split3 with that result layout [P, 2 C] (C % 16 == 0). */
+int omh_rms_silu_cl_pair(const float* x_f32, const float* gamma, void* y_bf16x2, int64_t P, int32_t C,
+                         int32_t do_silu, omh_stream_t stream);
 int omh_nchw_to_cl_f32(const float* x, float* y, int32_t C, int32_t T, int32_t H, int32_t W, int32_t Cp,
                        const float* mul, const float* add, int32_t t_total, int32_t t0, omh_stream_t stream);
 int omh_softmax_rows_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t R, int32_t L, float scale,

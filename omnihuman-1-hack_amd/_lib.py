@@ -151,7 +151,7 @@ class ConvArgs(C.Structure):
                 ("KT", i32), ("KH", i32), ("KW", i32),
                 ("stride_t", i32), ("stride_hw", i32), ("pad_h", i32), ("pad_w", i32),
                 ("up2", i32), ("out_f32", i32), ("split_n", i32), ("resid_f32", i32),
-                ("norm_gamma", vp), ("norm_out", vp), ("norm_only", i32)]
+                ("norm_gamma", vp), ("norm_out", vp), ("norm_only", i32), ("pair", i32)]
 
 
 EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID, EPI_F32_ACCUM, EPI_GELU_ERF_BF16, EPI_GELU_BWD_BF16, EPI_BF16_SPLIT_T = 0, 1, 2, 3, 4, 5, 6, 7
@@ -193,6 +193,8 @@ _SIGS = {
     "omh_softmax_rows_f32": (i32, [vp, i64, vp, i64, i64, i32, f32, vp]),
     "omh_split3_f32": (i32, [vp, i64, vp, i64, i64, i32, i32, i32, vp]),
     "omh_rms_silu_cl_split3": (i32, [vp, vp, vp, i64, i32, i32, vp]),
+    "omh_rms_silu_cl_pair": (i32, [vp, vp, vp, i64, i32, i32, vp]),
+    "omh_conv_pair_supported": (i32, [C.POINTER(ConvArgs)]),
     "omh_nchw_to_cl_f32": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp]),
     "omh_transpose_bf16": (i32, [vp, vp, i32, i32, i64, i64, i32, i64, i64, vp]),
     "omh_colsum_accum": (i32, [vp, i32, i64, vp, i64, i32, vp]),

@@ -37,7 +37,9 @@ __device__ __forceinline__ void divmod24(int v, int d, float rcp, int& q, int& r
 }
 
 // NORM (P only): the stream's epilogue also writes the next layer's RMS norm + SiLU of the output (omh_conv_args.norm_*)
-template <int CFG, bool OUT_F32, bool NORM>
+// PAIR (fp32 out, no norm): the split-bf16 pair stream — the loader sees an ordinary tensor of Cin = 2 C channels, the
+// stage loop pairs the 16-channel halves of a stage as hi.hi, lo.hi, hi.lo (gen_conv_w64.py: main_loop_pair)
+template <int CFG, bool OUT_F32, bool NORM, bool PAIR = false>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void conv_cl_w64_kernel(const omh_conv_args p, const int tiles_m, const int tiles_n) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[3 * STAGE + (NORM ? 512 : 0)];   // + gamma[96] for the norm
@@ -169,14 +171,15 @@ void conv_cl_w64_kernel(const omh_conv_args p, const int tiles_m, const int tile
                    [p0] "{s[60:61]}"(p0), [p1] "{s[62:63]}"(p1), [p2] "{s[64:65]}"(p2), [p3] "{s[66:67]}"(p3),          \
                    [p4] "{s[68:69]}"(p4), [p5] "{s[70:71]}"(p5), [p6] "{s[72:73]}"(p6)                                  \
                  : OMH_CONV_W64_CLOBBERS)
-    if (CFG == CFG_P && NORM) { if (OUT_F32) OMH_CW64_RUN(OMH_CONV_W64_ASM_P_F32_NORM); else OMH_CW64_RUN(OMH_CONV_W64_ASM_P_BF16_NORM); }
+    if (PAIR) { if (CFG == CFG_P) OMH_CW64_RUN(OMH_CONV_W64_ASM_P_F32_PAIR); else OMH_CW64_RUN(OMH_CONV_W64_ASM_Q_F32_PAIR); }
+    else if (CFG == CFG_P && NORM) { if (OUT_F32) OMH_CW64_RUN(OMH_CONV_W64_ASM_P_F32_NORM); else OMH_CW64_RUN(OMH_CONV_W64_ASM_P_BF16_NORM); }
     else if (CFG == CFG_P) { if (OUT_F32) OMH_CW64_RUN(OMH_CONV_W64_ASM_P_F32); else OMH_CW64_RUN(OMH_CONV_W64_ASM_P_BF16); }
     else { if (OUT_F32) OMH_CW64_RUN(OMH_CONV_W64_ASM_Q_F32); else OMH_CW64_RUN(OMH_CONV_W64_ASM_Q_BF16); }
 #undef OMH_CW64_RUN
     }
 }
 
-template <int CFG, bool OUT_F32, bool NORM = false>
+template <int CFG, bool OUT_F32, bool NORM = false, bool PAIR = false>
 int launch_cw64(const omh_conv_args& a, int64_t M, hipStream_t s) {
     constexpr int WBM = CFG == CFG_P ? 512 : 256, WBN = CFG == CFG_P ? 96 : 192;
     const int tiles_m = (int)((M + WBM - 3) / (WBM - 2)), tiles_n = a.Cout / WBN;
@@ -196,7 +199,7 @@ int launch_cw64(const omh_conv_args& a, int64_t M, hipStream_t s) {
         if (grid > cus) grid = cus;
     }
     omh_clear_status();
-    hipLaunchKernelGGL((conv_cl_w64_kernel<CFG, OUT_F32, NORM>), dim3(grid), dim3(256), 0, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((conv_cl_w64_kernel<CFG, OUT_F32, NORM, PAIR>), dim3(grid), dim3(256), 0, s, a, tiles_m, tiles_n);
     return omh_launch_status();
 }
 
@@ -218,8 +221,16 @@ bool omh_conv_w64_takes(const omh_conv_args& a) {
            (int64_t)a.Cout * a.KT * 9 * a.Cin * 2 < 0x7fffffffLL;
 }
 
+// The split-bf16 pair stream: what the stream takes, fp32 output (and residual), no fused norm, an even number of at
+// least 16 stages (14 are peeled, the rolled loop and the tail run two at a time: the X fragment sets swap roles per tap)
+bool omh_conv_w64_pair_takes(const omh_conv_args& a) {
+    const int ns = a.KT * 3 * (a.Cin >> 5);
+    return a.pair && a.out_f32 && !a.norm_gamma && (ns & 1) == 0 && ns >= 16 && omh_conv_w64_takes(a);
+}
+
 int omh_launch_conv_w64(const omh_conv_args& a, hipStream_t s) {
     const int64_t M = (int64_t)a.Tout * a.Hout * a.Wout;
+    if (a.pair) return a.Cout == 96 ? launch_cw64<CFG_P, true, false, true>(a, M, s) : launch_cw64<CFG_Q, true, false, true>(a, M, s);
     if (a.Cout == 96 && a.norm_gamma) return a.out_f32 ? launch_cw64<CFG_P, true, true>(a, M, s) : launch_cw64<CFG_P, false, true>(a, M, s);
     if (a.Cout == 96) return a.out_f32 ? launch_cw64<CFG_P, true>(a, M, s) : launch_cw64<CFG_P, false>(a, M, s);
     return a.out_f32 ? launch_cw64<CFG_Q, true>(a, M, s) : launch_cw64<CFG_Q, false>(a, M, s);

@@ -698,6 +698,7 @@ int launch_kw3(const omh_conv_args& a, int64_t M, hipStream_t s) {
 
 // conv_w64.hip: the kw-shared convolution on one wave per SIMD, generated stage loop
 bool omh_conv_w64_takes(const omh_conv_args& a);
+bool omh_conv_w64_pair_takes(const omh_conv_args& a);
 int omh_launch_conv_w64(const omh_conv_args& a, hipStream_t s);
 
 // The tile family of a call (by the layer's geometry only) and whether the stream kernel takes it
@@ -727,6 +728,14 @@ static ConvRoute conv_route(const omh_conv_args& a) {
     return {wide, w64};
 }
 
+extern "C" int omh_conv_pair_supported(const omh_conv_args* args) {
+    if (!args || !args->pair) return 0;
+    const omh_conv_args& a = *args;
+    if (a.Tin <= 0 || a.Hin <= 0 || a.Win <= 0 || a.Cin <= 0 || a.Tout <= 0 || a.Hout <= 0 || a.Wout <= 0 || a.Cout <= 0) return 0;
+    const ConvRoute route = conv_route(a);
+    return (route.w64 && omh_conv_w64_pair_takes(a)) ? 1 : 0;
+}
+
 extern "C" int omh_conv_cl_bf16(const omh_conv_args* args, omh_stream_t stream) {
     if (!args || !args->x || !args->w || !args->y) return OMH_E_BADARG;
     const omh_conv_args& a = *args;
@@ -743,6 +752,10 @@ extern "C" int omh_conv_cl_bf16(const omh_conv_args* args, omh_stream_t stream) 
     // 32-bit buffer offsets
     if ((int64_t)a.Tin * a.Hin * a.Win * a.Cin * 2 >= 0x7fffffffLL) return OMH_E_SHAPE;
     const ConvRoute route = conv_route(a);
+    if (a.pair) {                                           // split-bf16 pairs: the stream kernel or nothing (ABI v10)
+        if (!(route.w64 && omh_conv_w64_pair_takes(a))) return OMH_E_SHAPE;
+        return omh_launch_conv_w64(a, (hipStream_t)stream);
+    }
     if (a.norm_gamma) {
         // the next layer's RMS norm + SiLU (ABI v7): in the stream kernel's epilogue when one wave holds all the
         // channels of a voxel (Cout = 96), as a second launch over y otherwise — the two write the same values

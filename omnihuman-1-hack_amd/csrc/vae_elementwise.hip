@@ -13,7 +13,7 @@ namespace {
 // OUT3 (the fp32-faithful VAE mode, omh_rms_silu_cl_split3): the result is not rounded once but written as a bf16 pair
 // hi = bf16(v), lo = bf16(v - hi) in three blocks of C channels [hi | lo | hi] per voxel — the split-bf16 operand layout
 // of omh_split3_f32.
-template <int G, bool XF32, bool OUT3 = false>
+template <int G, bool XF32, int OUT3 = 0>
 __global__ __launch_bounds__(256)
 void rms_silu_kernel(const void* __restrict__ xv, const float* __restrict__ gamma, uint16_t* __restrict__ y,
                      int64_t P, int C, int do_silu) {
@@ -82,7 +82,11 @@ void rms_silu_kernel(const void* __restrict__ xv, const float* __restrict__ gamm
                 o[e] = pack_bf2(a, b);
                 if (OUT3) ol[e] = pack_bf2(a - __uint_as_float(o[e] << 16), b - __uint_as_float(o[e] & 0xffff0000u));
             }
-            if (OUT3) {
+            if (OUT3 == 2) {                                      // pairs per 16 channels: [hi(16) | lo(16)] (omh_conv_args.pair)
+                uint16_t* yo = y + p * 2 * C + (c >> 1) * 32 + (c & 1) * 8;
+                *(uint4*)yo = make_uint4(o[0], o[1], o[2], o[3]);
+                *(uint4*)(yo + 16) = make_uint4(ol[0], ol[1], ol[2], ol[3]);
+            } else if (OUT3) {
                 uint16_t* yo = y + p * 3 * C + c * 8;
                 *(uint4*)yo = make_uint4(o[0], o[1], o[2], o[3]);
                 *(uint4*)(yo + C) = make_uint4(ol[0], ol[1], ol[2], ol[3]);
@@ -184,8 +188,14 @@ void split3_kernel(const float* __restrict__ x, int64_t ldx, uint16_t* __restric
         const uint32_t h0 = pack_bf2(v[0], v[1]), h1 = pack_bf2(v[2], v[3]);
         const uint32_t l0 = pack_bf2(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u));
         const uint32_t l1 = pack_bf2(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u));
-        uint16_t* yr = y + r * ldy + c;
         const uint2 hi = make_uint2(h0, h1), lo = make_uint2(l0, l1);
+        if (pattern == 2) {                                          // pairs per 16 channels: [hi(16) | lo(16)], 2 Cp per row
+            uint16_t* yp = y + r * ldy + (c >> 4) * 32 + (c & 15);
+            *(uint2*)yp = hi;
+            *(uint2*)(yp + 16) = lo;
+            continue;
+        }
+        uint16_t* yr = y + r * ldy + c;
         *(uint2*)yr = hi;
         *(uint2*)(yr + Cp) = pattern == 0 ? lo : hi;
         *(uint2*)(yr + 2 * Cp) = pattern == 0 ? hi : lo;
@@ -304,11 +314,11 @@ static unsigned rms_grid(int64_t P, int G) {
     return (unsigned)(need < 2048 ? need : 2048);
 }
 
-template <bool XF32, bool OUT3 = false>
+template <bool XF32, int OUT3 = 0>
 static int rms_silu_launch(const void* x, const float* gamma, void* y, int64_t P, int32_t C, int32_t do_silu,
                            omh_stream_t stream) {
     if (!x || !gamma || !y || P <= 0 || C <= 0) return OMH_E_BADARG;
-    if ((C & 7) || C > 8 * 64 * 4) return OMH_E_SHAPE;
+    if ((C & 7) || C > 8 * 64 * 4 || (OUT3 == 2 && (C & 15))) return OMH_E_SHAPE;
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return OMH_E_ALIGN;
     const int nch = C >> 3;
     hipStream_t s = (hipStream_t)stream;
@@ -339,13 +349,19 @@ extern "C" int omh_rms_silu_cl_f32in(const float* x, const float* gamma, void* y
 
 extern "C" int omh_rms_silu_cl_split3(const float* x, const float* gamma, void* y, int64_t P, int32_t C,
                                       int32_t do_silu, omh_stream_t stream) {
-    return rms_silu_launch<true, true>(x, gamma, y, P, C, do_silu, stream);
+    return rms_silu_launch<true, 1>(x, gamma, y, P, C, do_silu, stream);
+}
+
+extern "C" int omh_rms_silu_cl_pair(const float* x, const float* gamma, void* y, int64_t P, int32_t C,
+                                    int32_t do_silu, omh_stream_t stream) {
+    return rms_silu_launch<true, 2>(x, gamma, y, P, C, do_silu, stream);
 }
 
 extern "C" int omh_split3_f32(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t C, int32_t Cp,
                               int32_t pattern, omh_stream_t stream) {
-    if (!x || !y || rows <= 0 || C <= 0 || Cp < C || (pattern != 0 && pattern != 1)) return OMH_E_BADARG;
-    if ((Cp & 3) || (ldy & 3) || ldy < 3 * (int64_t)Cp || ldx < C) return OMH_E_SHAPE;
+    if (!x || !y || rows <= 0 || C <= 0 || Cp < C || pattern < 0 || pattern > 2) return OMH_E_BADARG;
+    if ((Cp & 3) || (ldy & 3) || ldy < (pattern == 2 ? 2 : 3) * (int64_t)Cp || ldx < C) return OMH_E_SHAPE;
+    if (pattern == 2 && (Cp & 15)) return OMH_E_SHAPE;               // whole 16-channel blocks
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return OMH_E_ALIGN;
     omh_clear_status();
     hipLaunchKernelGGL(split3_kernel, dim3(grid_for(rows * (Cp / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,

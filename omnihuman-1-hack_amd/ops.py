@@ -382,8 +382,17 @@ def cfg_unipc_step(cond, uncond, x, last, m1, m2, mt_out, xc_out, x_next, guide,
 
 
 # ----------------------------------------------------------------------------- VAE kernels
+def conv_pair_supported(Tin, Hin, Win, Cin2, Tout, Hout, Wout, Cout, KT, KH, KW, stride_t=1, stride_hw=1, pad_h=0, pad_w=0,
+                        up2=False):
+    """Would omh_conv_cl_bf16 take this layer as a split-bf16 PAIR convolution (omh_conv_args.pair; ``Cin2`` = 2 x the real
+    channel count)?  By the layer's geometry; no pointers involved."""
+    a = _lib.ConvArgs(None, None, None, None, None, Tin, Hin, Win, Cin2, Tout, Hout, Wout, Cout, KT, KH, KW, stride_t,
+                      stride_hw, pad_h, pad_w, int(up2), 1, 0, 1, None, None, 0, 1)
+    return bool(lib.omh_conv_pair_supported(C.byref(a)))
+
+
 def conv_cl(x, w, bias, Tout, Hout, Wout, Cout, KT, KH, KW, stride_t=1, stride_hw=1, pad_h=0, pad_w=0, up2=False,
-            resid=None, out_f32=False, split_n=0, out=None, norm_gamma=None, norm_out=None, norm_only=False):
+            resid=None, out_f32=False, split_n=0, out=None, norm_gamma=None, norm_out=None, norm_only=False, pair=False):
     """Implicit-GEMM conv on channels-last bf16 ``x`` [Tin, Hin, Win, Cin] (history frames first);
     ``w`` bf16 [Cout, KT*KH*KW*Cin].  Returns [Tout*f, Hout, Wout, Cout/f] (f = Cout/split_n or 1).
     ``norm_gamma`` (fp32 [Cout]) + ``norm_out`` (bf16 [Tout, Hout, Wout, Cout]): also the next layer's RMS norm + SiLU of
@@ -403,7 +412,7 @@ def conv_cl(x, w, bias, Tout, Hout, Wout, Cout, KT, KH, KW, stride_t=1, stride_h
     a = _lib.ConvArgs(_p(x), _p(w), _p(bias), _p(resid), _p(out), Tin, Hin, Win, Cin, Tout, Hout, Wout, Cout,
                       KT, KH, KW, stride_t, stride_hw, pad_h, pad_w, int(up2), int(out_f32), split_n,
                       int(resid is not None and resid.dtype == torch.float32),
-                      _p(norm_gamma), _p(norm_out), int(bool(norm_only)))
+                      _p(norm_gamma), _p(norm_out), int(bool(norm_only)), int(bool(pair)))
     if norm_gamma is not None:
         assert split_n == 0 and norm_gamma.dtype == torch.float32 and norm_gamma.numel() == Cout and norm_gamma.is_contiguous()
         assert norm_out is not None and norm_out.dtype == torch.bfloat16 and norm_out.is_contiguous() and \
@@ -439,23 +448,28 @@ def split3(x: torch.Tensor, pattern: int, Cp: Optional[int] = None, out=None):
     else:
         assert x.is_contiguous()
         rows, ldx = x.numel() // Cc, Cc
+    nb = 2 if pattern == 2 else 3                             # pattern 2: pairs per 16 channels, [hi(16) | lo(16)] (omh.h)
     if out is None:
-        out = torch.empty(*x.shape[:-1], 3 * Cp, dtype=torch.bfloat16, device=x.device)
-    assert out.dtype == torch.bfloat16 and out.shape[-1] == 3 * Cp and out.numel() == rows * 3 * Cp and out.is_contiguous()
-    check(lib.omh_split3_f32(_p(x), ldx, _p(out), 3 * Cp, rows, Cc, Cp, int(pattern), _stream()), "omh_split3_f32")
+        out = torch.empty(*x.shape[:-1], nb * Cp, dtype=torch.bfloat16, device=x.device)
+    assert out.dtype == torch.bfloat16 and out.shape[-1] == nb * Cp and out.numel() == rows * nb * Cp and out.is_contiguous()
+    check(lib.omh_split3_f32(_p(x), ldx, _p(out), nb * Cp, rows, Cc, Cp, int(pattern), _stream()), "omh_split3_f32")
     return out
 
 
-def rms_silu_cl_split3(x, gamma, out=None, do_silu=True):
-    """x fp32 [..., C] -> pattern-0 bf16 [..., 3 C]: RMS norm (* gamma), SiLU, split."""
+def rms_silu_cl_split3(x, gamma, out=None, do_silu=True, pair=False):
+    """x fp32 [..., C] -> pattern-0 bf16 [..., 3 C]: RMS norm (* gamma), SiLU, split.  ``pair`` (or an ``out`` of 2 C
+    channels): the pair layout [..., 2 C] of omh_conv_args.pair instead."""
     _dev(x, gamma, out)
     assert x.dtype == torch.float32 and x.is_contiguous() and gamma.dtype == torch.float32
     Cc = x.shape[-1]
+    if out is not None:
+        pair = out.shape[-1] == 2 * Cc
+    nb = 2 if pair else 3
     if out is None:
-        out = torch.empty(*x.shape[:-1], 3 * Cc, dtype=torch.bfloat16, device=x.device)
-    assert out.is_contiguous() and out.dtype == torch.bfloat16 and out.shape[-1] == 3 * Cc
-    check(lib.omh_rms_silu_cl_split3(_p(x), _p(gamma), _p(out), x.numel() // Cc, Cc, int(do_silu), _stream()),
-          "omh_rms_silu_cl_split3")
+        out = torch.empty(*x.shape[:-1], nb * Cc, dtype=torch.bfloat16, device=x.device)
+    assert out.is_contiguous() and out.dtype == torch.bfloat16 and out.shape[-1] == nb * Cc
+    fn, name = (lib.omh_rms_silu_cl_pair, "omh_rms_silu_cl_pair") if pair else (lib.omh_rms_silu_cl_split3, "omh_rms_silu_cl_split3")
+    check(fn(_p(x), _p(gamma), _p(out), x.numel() // Cc, Cc, int(do_silu), _stream()), name)
     return out
 
 

@@ -195,14 +195,17 @@ class _ConvState:
             w = w.unsqueeze(2)
         self.Cout, self.Cin_raw, self.KT, self.KH, self.KW = w.shape
         self.f32 = bool(f32)
+        self.pair = False
         cp = _round_up(self.Cin_raw, 8)
         wp = w.float().permute(0, 2, 3, 4, 1)                       # [Cout, kt, kh, kw, Cin]
         if self.f32:
             # fp32-faithful mode: the weight as a bf16 pair per channel, blocks [hi | hi | lo] per tap (pattern 1 of
-            # omh_split3_f32) against activations [hi | lo | hi]: the same kernels on a contraction 3x as long
+            # omh_split3_f32) against activations [hi | lo | hi]: the same kernels on a contraction 3x as long —
+            # or, where the stream kernel takes the layer (decided at the first slot(), when H x W are known: _layout),
+            # pairs interleaved per 16 channels on both operands (omh_conv_args.pair, round 5): 2 C channels
+            self._wp = wp.contiguous()
             self.Cin = 3 * cp
-            taps = self.KT * self.KH * self.KW
-            self.w = ops.split3(wp.contiguous().view(self.Cout * taps, self.Cin_raw), 1, Cp=cp).view(self.Cout, -1)
+            self.w = None
         else:
             self.Cin = cp
             if self.Cin != self.Cin_raw:
@@ -232,8 +235,29 @@ class _ConvState:
     _WINDOW_BYTES = int(os.environ.get("OMH_VAE_WINDOW_MB", "1024")) << 20
     _WINDOW_BYTES_F32 = int(os.environ.get("OMH_VAE_WINDOW_F32_MB", "8192")) << 20
 
+    def _layout(self, H, W):
+        """fp32-faithful mode, first use: the operand layout of this layer — split-bf16 PAIRS (2 C channels) where the
+        stream kernel takes the layer, three channel blocks (3 C) everywhere else — and the weight packed to match."""
+        taps = self.KT * self.KH * self.KW
+        cp = _round_up(self.Cin_raw, 8)
+        eff_h, eff_w = (2 * H, 2 * W) if self.up2 else (H, W)
+        ok = _PAIR and self.Cin_raw % 16 == 0 and self.stride_t == 1 and self.stride_hw == 1 and \
+            ops.conv_pair_supported(self.KT + 1, H, W, 2 * self.Cin_raw, 2, eff_h, eff_w, self.Cout, self.KT, self.KH,
+                                    self.KW, pad_h=self.pad[0], pad_w=self.pad[1], up2=self.up2)
+        self.pair = bool(ok)
+        flat = self._wp.view(self.Cout * taps, self.Cin_raw)
+        if self.pair:
+            self.Cin = 2 * self.Cin_raw
+            self.w = ops.split3(flat, 2, Cp=self.Cin_raw).view(self.Cout, -1)
+        else:
+            self.Cin = 3 * cp
+            self.w = ops.split3(flat, 1, Cp=cp).view(self.Cout, -1)
+        self._wp = None
+
     def slot(self, T, H, W, device):
         """View [T, H, W, Cin] the producer writes the current chunk into."""
+        if self.w is None:
+            self._layout(H, W)
         need = self.hist + T
         fresh = self.buf is None or tuple(self.buf.shape[1:3]) != (H, W)
         if fresh or self.buf.shape[0] < need:
@@ -279,7 +303,7 @@ class _ConvState:
         y = ops.conv_cl(x, self.w, self.bias, Tout, Hout, Wout, self.Cout, self.KT, self.KH, self.KW,
                         stride_t=self.stride_t, stride_hw=self.stride_hw, pad_h=self.pad[0], pad_w=self.pad[1],
                         up2=self.up2, resid=resid, out_f32=out_f32, split_n=split_n, out=out,
-                        norm_gamma=norm_gamma, norm_out=norm_out, norm_only=norm_only)
+                        norm_gamma=norm_gamma, norm_out=norm_out, norm_only=norm_only, pair=self.pair)
         if self.hist:
             self.off += T                                   # the region slides: no copy
         return y
@@ -330,7 +354,9 @@ _GROUP2 = max(1, int(os.environ.get("OMH_VAE_GROUP2", "2")))
 def _fill(slot, x):
     """Write trunk tensor x into a convolution's bf16 input slot (a split-bf16 slot, three channel blocks, in the
     fp32-faithful mode)."""
-    if x.dtype == torch.float32 and slot.shape[-1] == 3 * _round_up(x.shape[-1], 8):
+    if x.dtype == torch.float32 and x.shape[-1] % 16 == 0 and slot.shape[-1] == 2 * x.shape[-1]:
+        ops.split3(x.contiguous(), 2, Cp=x.shape[-1], out=slot)             # split-bf16 pairs (omh_conv_args.pair)
+    elif x.dtype == torch.float32 and slot.shape[-1] == 3 * _round_up(x.shape[-1], 8):
         ops.split3(x.contiguous(), 0, Cp=slot.shape[-1] // 3, out=slot)
     elif x.dtype == torch.float32 and x.shape[-1] == slot.shape[-1]:
         ops.cast_bf16(x.contiguous(), out=slot)
@@ -351,6 +377,9 @@ def _conv_on(st: _Stream, key, module, x, **run_kw):
 # first norm of the next block (or of the head) from conv2, straight into that layer's convolution input slot.  The
 # stand-alone kernel computes the same bits, so this is speed only (OMH_VAE_FUSE_NORM=0: always stand-alone).
 _FUSE_NORM = os.environ.get("OMH_VAE_FUSE_NORM", "1") != "0"
+# fp32-faithful mode: split-bf16 pairs on the stream kernel wherever it takes the layer (round 5); "0": three channel blocks
+# everywhere (rounds 3-4; A/B timing, tests)
+_PAIR = os.environ.get("OMH_VAE_PAIR", "1") != "0"
 
 
 def _res_block(st, key, blk: ResidualBlock, x, pre=False, nxt=None):
@@ -582,7 +611,9 @@ class WanVAE_(nn.Module):
             # of 4 frames per step (causal convolutions over [history | frames]: same values as chunk by chunk)
             # (fp32 mode: one chunk — a [history | 8 frames] region of 3 x 96 channels at 480x832 would pass the 2 GiB
             # of 32-bit buffer offsets)
-            g = 1 if i == 0 else min(1 if st.f32 else _GROUP2, n_chunks - i)
+            # (... with the pair layout of round 5 a full-resolution frame is 2 x 96 channels = 153 MB: [history | 8 frames]
+            # fits again, and so does the stride-2 Resample's three-block input of 8 frames)
+            g = 1 if i == 0 else min(1 if (st.f32 and not _PAIR) else _GROUP2, n_chunks - i)
             t0, tn = (0, 1) if i == 0 else (1 + 4 * (i - 1), 4 * g)
             c1 = st.conv("encoder.conv1", enc.conv1)
             if st.f32:
@@ -650,17 +681,21 @@ class WanVAE_(nn.Module):
         n_mid = res_idx[1] + 1 if len(res_idx) > 1 else len(dec.upsamples)
         i = 0
         while i < Tl:
-            g = 1 if i == 0 else min(2 if st.f32 else _GROUP, Tl - i)
+            g = 1 if i == 0 else min(2 if (st.f32 and not _PAIR) else _GROUP, Tl - i)
             ymid = _run_sequential(st, "decoder.upsamples", dec.upsamples, y_all[i:i + g], start=n_front, stop=n_mid)
             per = ymid.shape[0] // g
             j = 0
             while j < g:                                      # the full-resolution rest: _GROUP2 latent frames per step
-                g2 = min(1 if st.f32 else _GROUP2, g - j)
+                g2 = min(1 if (st.f32 and not _PAIR) else _GROUP2, g - j)
                 y, pre = _run_sequential(st, "decoder.upsamples", dec.upsamples, ymid[j * per:(j + g2) * per], start=n_mid,
                                          head=("decoder.head", dec.head))
-                y = _head(st, "decoder.head", dec.head, y, out_f32=True, pre=pre)        # fp32 [t, 8h, 8w, 3]
-                ops.cl_to_nchw(y, out, t_pix, 3, lo=lo, hi=hi)
-                t_pix += y.shape[0]
+                # (fp32 mode: the head's input stays in three channel blocks — 96 -> 3 channels is not a stream layer —
+                # and [history | 8 frames] of those would pass 2 GiB: four frames per call, same values)
+                hstep = 4 if (st.f32 and y.shape[0] > 4) else y.shape[0]
+                for h0 in range(0, y.shape[0], hstep):
+                    yh = _head(st, "decoder.head", dec.head, y[h0:h0 + hstep], out_f32=True, pre=pre)   # fp32 [t, 8h, 8w, 3]
+                    ops.cl_to_nchw(yh, out, t_pix, 3, lo=lo, hi=hi)
+                    t_pix += yh.shape[0]
                 j += g2
             i += g
         assert t_pix == T_out

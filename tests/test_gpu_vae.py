@@ -99,6 +99,58 @@ def test_conv_cl_w64_equals_the_kw_shared_kernel(ops, cfg, monkeypatch):
         assert torch.isfinite(g.float()).all() and torch.equal(g, r)
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(Cin=96, Cout=96, T=2, H=12, W=20, KT=3, up2=False),      # P: 54 stages, one ragged tile
+    dict(Cin=96, Cout=96, T=3, H=24, W=27, KT=3, up2=False),      # P: several tiles per workgroup at grid < tiles? (3.8 tiles)
+    dict(Cin=192, Cout=192, T=1, H=20, W=31, KT=3, up2=False),    # Q
+    dict(Cin=384, Cout=384, T=1, H=9, W=29, KT=3, up2=False),     # Q: 216 stages, two cout tiles
+    dict(Cin=384, Cout=192, T=2, H=9, W=14, KT=1, up2=True),      # Q through the folded 2x upsample (Conv2d): 72 stages
+    dict(Cin=96, Cout=96, T=4, H=30, W=52, KT=3, up2=False),      # P: 6240 voxels
+    dict(Cin=128, Cout=96, T=1, H=7, W=5, KT=1, up2=False),       # P: 24 stages: the shortest rolled loop (14 + 8 + 2), tiny volume
+    dict(Cin=96, Cout=96, T=1, H=5, W=3, KT=1, up2=False),        # P: 18 stages (14 + 2 + 2), image rows of 3 voxels
+])
+def test_conv_pair_stream_matches_the_three_block_form(ops, cfg):
+    """Round 5, omh_conv_args.pair: the fp32-faithful convolution on split-bf16 PAIRS interleaved per 16 channels — three
+    MFMA products per channel block that share their LDS fragments (gen_conv_w64.py: main_loop_pair) — against the same
+    product as a 3 C-channel convolution over [hi | lo | hi] x [hi | hi | lo] (rounds 3-4: other fp32 summation order,
+    2e-6) and against fp64 convolution of the fp32 operands (fp32 class: 2e-5); with bias and fp32 residual, without;
+    repeatable bit for bit; the query says no where the stream does not take the layer."""
+    Cin, Cout, T, H, W, KT, up2 = (cfg[k] for k in ("Cin", "Cout", "T", "H", "W", "KT", "up2"))
+    torch.manual_seed(Cin + Cout + H + W)
+    Ho, Wo = (2 * H, 2 * W) if up2 else (H, W)
+    x = torch.randn(KT - 1 + T, H, W, Cin, device="cuda")
+    w = torch.randn(Cout, KT, 3, 3, Cin, device="cuda") / (Cin * KT * 9) ** 0.5
+    bias = torch.randn(Cout, device="cuda")
+    res = torch.randn(T, Ho, Wo, Cout, device="cuda")
+    taps = KT * 9
+    set_option("OMH_CONV_TILE", "w64")                       # (these volumes are below the stream's default threshold)
+    assert ops.conv_pair_supported(KT - 1 + T, H, W, 2 * Cin, T, Ho, Wo, Cout, KT, 3, 3, pad_h=1, pad_w=1, up2=up2)
+    x3, w3 = ops.split3(x, 0), ops.split3(w.view(Cout * taps, Cin), 1).view(Cout, -1)
+    x2, w2 = ops.split3(x, 2, Cp=Cin), ops.split3(w.view(Cout * taps, Cin), 2, Cp=Cin).view(Cout, -1)
+    assert x2.shape[-1] == 2 * Cin and w2.shape == (Cout, taps * 2 * Cin)
+    kw = dict(pad_h=1, pad_w=1, up2=up2, out_f32=True)
+    for b_, r_ in ((bias, res), (None, None)):
+        want = ops.conv_cl(x3, w3, b_, T, Ho, Wo, Cout, KT, 3, 3, resid=r_, **kw)
+        got = ops.conv_cl(x2, w2, b_, T, Ho, Wo, Cout, KT, 3, 3, resid=r_, pair=True, **kw)
+        again = ops.conv_cl(x2, w2, b_, T, Ho, Wo, Cout, KT, 3, 3, resid=r_, pair=True, **kw)
+        assert torch.isfinite(got).all() and torch.equal(got, again)
+        assert rel_rms(got, want) < 2e-6, rel_rms(got, want)
+        xin = x.permute(3, 0, 1, 2).unsqueeze(0).double()               # [1, C, T, H, W]
+        if up2:
+            xin = xin.repeat_interleave(2, dim=3).repeat_interleave(2, dim=4)
+        ref = torch.nn.functional.conv3d(xin, w.permute(0, 4, 1, 2, 3).double(), None if b_ is None else b_.double(),
+                                         padding=(0, 1, 1))[0].permute(1, 2, 3, 0)
+        if r_ is not None:
+            ref = ref + r_.double()
+        assert rel_rms(got, ref) < 2e-5, rel_rms(got, ref)
+    # not a stream layer (stride 2 / 48 channels): the query says so and the call is refused, not silently mis-computed
+    assert not ops.conv_pair_supported(3, H, W, 2 * 48, 1, H, W, Cout, KT, 3, 3, pad_h=1, pad_w=1)
+    assert not ops.conv_pair_supported(3, H, W, 2 * Cin, 1, H // 2, W // 2, Cout, KT, 3, 3, stride_hw=2)
+    set_option("OMH_CONV_TILE", "wide")
+    with pytest.raises(ops.OmhError):
+        ops.conv_cl(x2, w2, None, T, Ho, Wo, Cout, KT, 3, 3, pair=True, **kw)
+
+
 def test_conv_cl_w64_random_shapes_equal_the_kw_shared_kernel(ops, monkeypatch):
     """Seeded sweep: 24 random (Cin, Cout, T, H, W, KT) within the stream kernel's domain — image rows as short as 3
     voxels, volumes smaller than one tile, ragged last tiles, 15 to 36 stages — bit for bit against the 8-wave
