@@ -380,6 +380,9 @@ _FUSE_NORM = os.environ.get("OMH_VAE_FUSE_NORM", "1") != "0"
 # fp32-faithful mode: split-bf16 pairs on the stream kernel wherever it takes the layer (round 5); "0": three channel blocks
 # everywhere (rounds 3-4; A/B timing, tests)
 _PAIR = os.environ.get("OMH_VAE_PAIR", "1") != "0"
+# ... with pairs a frame is 2 C channels, so the fp32 mode could take the bf16 mode's frame groups again (encoder chunks,
+# decoder 2h x 2w stage, decoder full-resolution stage: "e", "m", "f" in OMH_VAE_F32_GROUPS); measured per stage below
+_F32_GROUPS = tuple(c in os.environ.get("OMH_VAE_F32_GROUPS", "") for c in "emf")
 
 
 def _res_block(st, key, blk: ResidualBlock, x, pre=False, nxt=None):
@@ -613,7 +616,7 @@ class WanVAE_(nn.Module):
             # of 32-bit buffer offsets)
             # (... with the pair layout of round 5 a full-resolution frame is 2 x 96 channels = 153 MB: [history | 8 frames]
             # fits again, and so does the stride-2 Resample's three-block input of 8 frames)
-            g = 1 if i == 0 else min(1 if (st.f32 and not _PAIR) else _GROUP2, n_chunks - i)
+            g = 1 if i == 0 else min(1 if (st.f32 and not (_PAIR and _F32_GROUPS[0])) else _GROUP2, n_chunks - i)
             t0, tn = (0, 1) if i == 0 else (1 + 4 * (i - 1), 4 * g)
             c1 = st.conv("encoder.conv1", enc.conv1)
             if st.f32:
@@ -681,12 +684,12 @@ class WanVAE_(nn.Module):
         n_mid = res_idx[1] + 1 if len(res_idx) > 1 else len(dec.upsamples)
         i = 0
         while i < Tl:
-            g = 1 if i == 0 else min(2 if (st.f32 and not _PAIR) else _GROUP, Tl - i)
+            g = 1 if i == 0 else min(2 if (st.f32 and not (_PAIR and _F32_GROUPS[1])) else _GROUP, Tl - i)
             ymid = _run_sequential(st, "decoder.upsamples", dec.upsamples, y_all[i:i + g], start=n_front, stop=n_mid)
             per = ymid.shape[0] // g
             j = 0
             while j < g:                                      # the full-resolution rest: _GROUP2 latent frames per step
-                g2 = min(1 if (st.f32 and not _PAIR) else _GROUP2, g - j)
+                g2 = min(1 if (st.f32 and not (_PAIR and _F32_GROUPS[2])) else _GROUP2, g - j)
                 y, pre = _run_sequential(st, "decoder.upsamples", dec.upsamples, ymid[j * per:(j + g2) * per], start=n_mid,
                                          head=("decoder.head", dec.head))
                 # (fp32 mode: the head's input stays in three channel blocks — 96 -> 3 channels is not a stream layer —
