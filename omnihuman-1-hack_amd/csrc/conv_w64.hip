@@ -148,7 +148,7 @@ void conv_cl_w64_kernel(const omh_conv_args p, const int tiles_m, const int tile
     const __amdgpu_buffer_rsrc_t rx = rsrc_of(p.x, (int64_t)p.Tin * HW * p.Cin * 2);
     const __amdgpu_buffer_rsrc_t rw = rsrc_of(p.w, (int64_t)p.Cout * K * 2);
     const __amdgpu_buffer_rsrc_t ry = rsrc_of(p.y, (NORM && p.norm_only) ? 0 : (int64_t)M * p.Cout * ES);   // norm_only: y's stores fall outside
-    const __amdgpu_buffer_rsrc_t rnorm = rsrc_of(p.norm_out, NORM ? (int64_t)M * p.Cout * 2 : 0);
+    const __amdgpu_buffer_rsrc_t rnorm = rsrc_of(p.norm_out, NORM ? (int64_t)M * p.Cout * (PAIR ? 4 : 2) : 0);   // pair: [M, 2 Cout] bf16
     const __amdgpu_buffer_rsrc_t rres = rsrc_of(p.resid, p.resid ? (int64_t)M * p.Cout * ES : 0);
     const int col0 = n0 + wn * 96;
     const __amdgpu_buffer_rsrc_t rbias = rsrc_of(p.bias ? p.bias + col0 : nullptr, p.bias ? (int64_t)(p.Cout - col0) * 4 : 0);
@@ -171,7 +171,11 @@ void conv_cl_w64_kernel(const omh_conv_args p, const int tiles_m, const int tile
                    [p0] "{s[60:61]}"(p0), [p1] "{s[62:63]}"(p1), [p2] "{s[64:65]}"(p2), [p3] "{s[66:67]}"(p3),          \
                    [p4] "{s[68:69]}"(p4), [p5] "{s[70:71]}"(p5), [p6] "{s[72:73]}"(p6)                                  \
                  : OMH_CONV_W64_CLOBBERS)
-    if (PAIR) { if (CFG == CFG_P) OMH_CW64_RUN(OMH_CONV_W64_ASM_P_F32_PAIR); else OMH_CW64_RUN(OMH_CONV_W64_ASM_Q_F32_PAIR); }
+    if (PAIR) {
+        if (CFG == CFG_P && NORM) OMH_CW64_RUN(OMH_CONV_W64_ASM_P_F32_PAIR_NORM);
+        else if (CFG == CFG_P) OMH_CW64_RUN(OMH_CONV_W64_ASM_P_F32_PAIR);
+        else OMH_CW64_RUN(OMH_CONV_W64_ASM_Q_F32_PAIR);
+    }
     else if (CFG == CFG_P && NORM) { if (OUT_F32) OMH_CW64_RUN(OMH_CONV_W64_ASM_P_F32_NORM); else OMH_CW64_RUN(OMH_CONV_W64_ASM_P_BF16_NORM); }
     else if (CFG == CFG_P) { if (OUT_F32) OMH_CW64_RUN(OMH_CONV_W64_ASM_P_F32); else OMH_CW64_RUN(OMH_CONV_W64_ASM_P_BF16); }
     else { if (OUT_F32) OMH_CW64_RUN(OMH_CONV_W64_ASM_Q_F32); else OMH_CW64_RUN(OMH_CONV_W64_ASM_Q_BF16); }
@@ -225,11 +229,13 @@ bool omh_conv_w64_takes(const omh_conv_args& a) {
 // least 16 stages (14 are peeled, the rolled loop and the tail run two at a time: the X fragment sets swap roles per tap)
 bool omh_conv_w64_pair_takes(const omh_conv_args& a) {
     const int ns = a.KT * 3 * (a.Cin >> 5);
-    return a.pair && a.out_f32 && !a.norm_gamma && (ns & 1) == 0 && ns >= 16 && omh_conv_w64_takes(a);
+    // (a fused next-layer norm — written in the pair layout too — at Cout = 96 only, as for the bf16 streams)
+    return a.pair && a.out_f32 && (!a.norm_gamma || a.Cout == 96) && (ns & 1) == 0 && ns >= 16 && omh_conv_w64_takes(a);
 }
 
 int omh_launch_conv_w64(const omh_conv_args& a, hipStream_t s) {
     const int64_t M = (int64_t)a.Tout * a.Hout * a.Wout;
+    if (a.pair && a.Cout == 96 && a.norm_gamma) return launch_cw64<CFG_P, true, true, true>(a, M, s);
     if (a.pair) return a.Cout == 96 ? launch_cw64<CFG_P, true, false, true>(a, M, s) : launch_cw64<CFG_Q, true, false, true>(a, M, s);
     if (a.Cout == 96 && a.norm_gamma) return a.out_f32 ? launch_cw64<CFG_P, true, true>(a, M, s) : launch_cw64<CFG_P, false, true>(a, M, s);
     if (a.Cout == 96) return a.out_f32 ? launch_cw64<CFG_P, true>(a, M, s) : launch_cw64<CFG_P, false>(a, M, s);

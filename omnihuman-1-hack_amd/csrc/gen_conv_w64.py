@@ -589,7 +589,7 @@ def silu_norm(e, regs, gam, inv):
             e(f"v_mul_f32 v{a[x]}, v{a[x]}, v{t[x]}")
 
 
-def epilogue_norm(e, kind):
+def epilogue_norm(e, kind, pair_out=False):
     """epilogue() followed, per row block j, by the NEXT layer's RMS norm + SiLU of the 96 output channels (vae.py:39-54
     under :195-197 / :203-205): bf16 [voxel][96] to %[rnorm].  A voxel row's 96 values sit in two lanes (r, h = 0 / 1),
     48 each: sums of squares as one fma chain per run p (channel order, like rms_silu_kernel's lane p + 2... see there),
@@ -681,7 +681,15 @@ def epilogue_norm(e, kind):
         e(f"v_cmp_ne_u32 vcc, 0, v{V_ROWBIT}")
         e("s_and_saveexec_b64 s[86:87], vcc")
         noff = V_ST_OFF
-        if kind != "bf16":
+        if pair_out:
+            # split-bf16 PAIR output [voxel][2 x 96] (omh_conv_args.pair: the next convolution's input): 384 bytes per
+            # voxel like the fp32 y, the lane's 8 channels of block 2 i + p at + 16 h instead of + 32 h
+            # (32 h from the gamma address: v251 = V_LANE has become V_INV by now)
+            e(f"v_subrev_u32 v{V_NOFF}, {S_GAMMA_LDS}, v{V_GADDR}")
+            e(f"v_lshrrev_b32 v{V_NOFF}, 1, v{V_NOFF}")
+            e(f"v_sub_u32 v{V_NOFF}, v{V_ST_OFF}, v{V_NOFF}")
+            noff = V_NOFF
+        elif kind != "bf16":
             e(f"v_lshrrev_b32 v{V_NOFF}, 1, v{V_ST_OFF}")         # bf16 output: half the fp32 output's byte offset
             noff = V_NOFF
         for i2 in range(NI):
@@ -708,6 +716,22 @@ def epilogue_norm(e, kind):
                         e(f"ds_read_b128 {vr(T + 8 * p + 4 * q, 4)}, v{V_GADDR} offset:{(32 * i2 + 16 * p) * 4 + 16 * q}")
                 e("s_waitcnt lgkmcnt(0)")
                 silu_norm(e, [sr + r_ for r_ in range(16)], [T + r_ for r_ in range(16)], V_INV)
+                if pair_out:
+                    # hi = bf16(v) -> v[T:T+7], lo = bf16(v - hi) -> v[T+8:T+15] (omh_rms_silu_cl_pair's operations)
+                    for r_ in range(8):
+                        e(f"v_cvt_pk_bf16_f32 v{T + r_}, v{sr + 2 * r_}, v{sr + 2 * r_ + 1}")
+                    for r_ in range(8):
+                        e(f"v_lshlrev_b32 v{V_PAIR}, 16, v{T + r_}")
+                        e(f"v_and_b32 v{V_PAIR + 1}, 0xffff0000, v{T + r_}")
+                        e(f"v_sub_f32 v{sr + 2 * r_}, v{sr + 2 * r_}, v{V_PAIR}")
+                        e(f"v_sub_f32 v{sr + 2 * r_ + 1}, v{sr + 2 * r_ + 1}, v{V_PAIR + 1}")
+                        e(f"v_cvt_pk_bf16_f32 v{T + 8 + r_}, v{sr + 2 * r_}, v{sr + 2 * r_ + 1}")
+                    for p in range(2):
+                        blk = 2 * i2 + p
+                        e(f"buffer_store_dwordx4 {vr(T + 4 * p, 4)}, v{noff}, %[rnorm], 0 offen offset:{blk * 64}")
+                        e(f"buffer_store_dwordx4 {vr(T + 8 + 4 * p, 4)}, v{noff}, %[rnorm], 0 offen offset:{blk * 64 + 32}")
+                    e("s_nop 1")                                 # the stores' data registers are rewritten by the next tile
+                    continue
                 for r_ in range(8):
                     e(f"v_cvt_pk_bf16_f32 v{sr + r_}, v{sr + 2 * r_}, v{sr + 2 * r_ + 1}")
                 for p in range(2):
@@ -720,7 +744,10 @@ def generate(cfg, kind, norm=False, pair=False):
     e = Emit(cfg + kind + ("n" if norm else "") + ("p" if pair else ""))
     NA, NB = CONFIGS[cfg]
     (main_loop_pair if pair else main_loop)(e, NA, NB, kind)
-    (epilogue_norm if norm else epilogue)(e, kind)
+    if norm:
+        epilogue_norm(e, kind, pair_out=pair)
+    else:
+        epilogue(e, kind)
     return e
 
 
@@ -734,12 +761,12 @@ def main():
                 print(" \\\n".join(e.text().split("\n")))
                 print("")
                 print(f"// {cfg} {kind}{' norm' if norm else ''}: {len(e.lines)} lines, {sum('v_mfma' in ln for ln in e.lines)} MFMA")
-    for cfg in CONFIGS:                                          # the split-bf16 pair streams (fp32-faithful VAE mode): fp32 out
-        e = generate(cfg, "f32", False, pair=True)
-        print(f"#define OMH_CONV_W64_ASM_{cfg}_F32_PAIR \\")
+    for cfg, norm in (("P", False), ("P", True), ("Q", False)):   # the split-bf16 pair streams (fp32-faithful VAE mode): fp32 out
+        e = generate(cfg, "f32", norm, pair=True)
+        print(f"#define OMH_CONV_W64_ASM_{cfg}_F32_PAIR{'_NORM' if norm else ''} \\")
         print(" \\\n".join(e.text().split("\n")))
         print("")
-        print(f"// {cfg} f32 pair: {len(e.lines)} lines, {sum('v_mfma' in ln for ln in e.lines)} MFMA")
+        print(f"// {cfg} f32 pair{' norm' if norm else ''}: {len(e.lines)} lines, {sum('v_mfma' in ln for ln in e.lines)} MFMA")
     clob = ['"memory"', '"vcc"', '"scc"'] + [f'"s{i}"' for i in range(80, 100)] + [f'"v{i}"' for i in range(12, 256)] + \
            [f'"a{i}"' for i in range(256)]
     print("#define OMH_CONV_W64_CLOBBERS \\")

@@ -753,6 +753,20 @@ extern "C" int omh_conv_cl_bf16(const omh_conv_args* args, omh_stream_t stream) 
     if ((int64_t)a.Tin * a.Hin * a.Win * a.Cin * 2 >= 0x7fffffffLL) return OMH_E_SHAPE;
     const ConvRoute route = conv_route(a);
     if (a.pair) {                                           // split-bf16 pairs: the stream kernel or nothing (ABI v10)
+        if (a.norm_gamma) {
+            // the next layer's RMS norm + SiLU, written as pairs too ([M, 2 Cout]): in the stream's epilogue at Cout = 96,
+            // as omh_rms_silu_cl_pair on y behind the convolution otherwise — the same values either way
+            if (!a.norm_out || a.split_n > 0) return OMH_E_BADARG;
+            if (((uintptr_t)a.norm_out & 15) || ((uintptr_t)a.norm_gamma & 3)) return OMH_E_ALIGN;
+            const char* fe = omh_opt(OMH_OPT_CONV_FUSE_NORM);
+            if (!(a.Cout == 96 && !(fe && fe[0] == '0'))) {
+                omh_conv_args b = a;
+                b.norm_gamma = nullptr; b.norm_out = nullptr; b.norm_only = 0;
+                const int rc = omh_conv_cl_bf16(&b, stream);
+                if (rc) return rc;
+                return omh_rms_silu_cl_pair((const float*)a.y, a.norm_gamma, a.norm_out, M, a.Cout, 1, stream);
+            }
+        }
         if (!(route.w64 && omh_conv_w64_pair_takes(a))) return OMH_E_SHAPE;
         return omh_launch_conv_w64(a, (hipStream_t)stream);
     }

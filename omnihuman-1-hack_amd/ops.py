@@ -416,7 +416,7 @@ def conv_cl(x, w, bias, Tout, Hout, Wout, Cout, KT, KH, KW, stride_t=1, stride_h
     if norm_gamma is not None:
         assert split_n == 0 and norm_gamma.dtype == torch.float32 and norm_gamma.numel() == Cout and norm_gamma.is_contiguous()
         assert norm_out is not None and norm_out.dtype == torch.bfloat16 and norm_out.is_contiguous() and \
-            norm_out.numel() == Tout * Hout * Wout * Cout
+            norm_out.numel() == Tout * Hout * Wout * Cout * (2 if pair else 1)
     check(lib.omh_conv_cl_bf16(C.byref(a), _stream()), "omh_conv_cl_bf16")
     return out
 

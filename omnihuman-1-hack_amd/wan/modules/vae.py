@@ -381,8 +381,9 @@ _FUSE_NORM = os.environ.get("OMH_VAE_FUSE_NORM", "1") != "0"
 # everywhere (rounds 3-4; A/B timing, tests)
 _PAIR = os.environ.get("OMH_VAE_PAIR", "1") != "0"
 # ... with pairs a frame is 2 C channels, so the fp32 mode could take the bf16 mode's frame groups again (encoder chunks,
-# decoder 2h x 2w stage, decoder full-resolution stage: "e", "m", "f" in OMH_VAE_F32_GROUPS); measured per stage below
-_F32_GROUPS = tuple(c in os.environ.get("OMH_VAE_F32_GROUPS", "") for c in "emf")
+# decoder 2h x 2w stage: "e", "m" in OMH_VAE_F32_GROUPS).  Measured on one box (decode / encode frames/s): none 108.1 /
+# 177.8, "e" 96.8 / 177.8, "m" 101.1 / 171.4: the larger groups do not pay in this mode — off by default
+_F32_GROUPS = tuple(c in os.environ.get("OMH_VAE_F32_GROUPS", "") for c in "em")
 
 
 def _res_block(st, key, blk: ResidualBlock, x, pre=False, nxt=None):
@@ -393,21 +394,30 @@ def _res_block(st, key, blk: ResidualBlock, x, pre=False, nxt=None):
     dev = x.device
     h = x
     tf = st.trunk_f32
-    fuse = _FUSE_NORM and not st.f32
+    fuse = _FUSE_NORM
     if not isinstance(blk.shortcut, nn.Identity):
         h = _conv_on(st, key + ".shortcut", blk.shortcut, x, out_f32=tf)
     ca = st.conv(key + ".residual.2", blk.residual[2])
     if not pre:
         st.norm(x, _gamma(blk.residual[0]), ca.slot(T, H, W, dev))
     cb = st.conv(key + ".residual.6", blk.residual[6])
-    if fuse and ca.Cout == 96:                       # inside the block: bf16 (rounded once, feeds one norm + conv)
-        ca.run(norm_gamma=_gamma(blk.residual[3]), norm_out=cb.slot(T, H, W, dev), norm_only=True)
+    slot_b = cb.slot(T, H, W, dev)
+    # fp32-faithful mode (round 5): the fused norm writes split-bf16 pairs, so both the producing convolution and the
+    # consumer of the norm have to be pair layers of the stream kernel
+    if fuse and ca.Cout == 96 and (not st.f32 or (ca.pair and cb.pair)):
+        # inside the block: rounded once (bf16, or a bf16 pair), feeds one norm + conv
+        ca.run(out_f32=st.f32, norm_gamma=_gamma(blk.residual[3]), norm_out=slot_b, norm_only=True)
     else:
         y = ca.run(out_f32=st.f32)
-        st.norm(y, _gamma(blk.residual[3]), cb.slot(T, H, W, dev))
+        st.norm(y, _gamma(blk.residual[3]), slot_b)
     if fuse and nxt is not None and cb.Cout == 96:
         gamma, cn = nxt
-        return cb.run(resid=h, out_f32=tf, norm_gamma=gamma, norm_out=cn.slot(T, H, W, dev)), True
+        slot_n = cn.slot(T, H, W, dev)
+        if not st.f32 or (cb.pair and cn.pair):
+            return cb.run(resid=h, out_f32=tf, norm_gamma=gamma, norm_out=slot_n), True
+        y = cb.run(resid=h, out_f32=tf)
+        st.norm(y, gamma, slot_n)                    # the slot is claimed: fill it here (the caller sees pre = True)
+        return y, True
     return cb.run(resid=h, out_f32=tf), False
 
 
@@ -689,16 +699,12 @@ class WanVAE_(nn.Module):
             per = ymid.shape[0] // g
             j = 0
             while j < g:                                      # the full-resolution rest: _GROUP2 latent frames per step
-                g2 = min(1 if (st.f32 and not (_PAIR and _F32_GROUPS[2])) else _GROUP2, g - j)
+                g2 = min(1 if st.f32 else _GROUP2, g - j)     # (fp32 mode: the head's three-block input of 8 frames would pass 2 GiB)
                 y, pre = _run_sequential(st, "decoder.upsamples", dec.upsamples, ymid[j * per:(j + g2) * per], start=n_mid,
                                          head=("decoder.head", dec.head))
-                # (fp32 mode: the head's input stays in three channel blocks — 96 -> 3 channels is not a stream layer —
-                # and [history | 8 frames] of those would pass 2 GiB: four frames per call, same values)
-                hstep = 4 if (st.f32 and y.shape[0] > 4) else y.shape[0]
-                for h0 in range(0, y.shape[0], hstep):
-                    yh = _head(st, "decoder.head", dec.head, y[h0:h0 + hstep], out_f32=True, pre=pre)   # fp32 [t, 8h, 8w, 3]
-                    ops.cl_to_nchw(yh, out, t_pix, 3, lo=lo, hi=hi)
-                    t_pix += yh.shape[0]
+                y = _head(st, "decoder.head", dec.head, y, out_f32=True, pre=pre)        # fp32 [t, 8h, 8w, 3]
+                ops.cl_to_nchw(y, out, t_pix, 3, lo=lo, hi=hi)
+                t_pix += y.shape[0]
                 j += g2
             i += g
         assert t_pix == T_out

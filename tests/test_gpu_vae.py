@@ -217,6 +217,48 @@ def test_conv_cl_fused_norm_equals_conv_then_rms_silu(ops, shape, monkeypatch):
     assert torch.equal(n, n0) and bool((sentinel == 7.0).all())
 
 
+@pytest.mark.parametrize("shape", [dict(Cin=96, T=2, H=12, W=20), dict(Cin=96, T=3, H=24, W=27), dict(Cin=192, T=2, H=40, W=52)])
+def test_conv_pair_fused_norm_equals_conv_then_rms_silu_pair(ops, shape):
+    """Round 5: the next layer's RMS norm + SiLU in the PAIR stream's epilogue (fp32-faithful mode, Cout = 96), written as
+    split-bf16 pairs [voxel][2 x 96], against the same convolution followed by omh_rms_silu_cl_pair (CONV_FUSE_NORM = 0
+    routes through it): equal bit for bit — y (fp32, with the trunk's residual) and the normalised pairs; with norm_only
+    no y is written; hi + lo of the normalised output reproduce the fp32 norm to 2^-16."""
+    Cin, T, H, W = (shape[k] for k in ("Cin", "T", "H", "W"))
+    Cout, KT = 96, 3
+    torch.manual_seed(Cin + H + 1)
+    x = torch.randn(KT - 1 + T, H, W, Cin, device="cuda")
+    w = torch.randn(Cout, KT * 9, Cin, device="cuda") / (Cin * KT * 9) ** 0.5
+    bias = torch.randn(Cout, device="cuda")
+    gamma = torch.rand(Cout, device="cuda") + 0.5
+    rf = torch.randn(T, H, W, Cout, device="cuda")
+    x2, w2 = ops.split3(x, 2, Cp=Cin), ops.split3(w.view(Cout * KT * 9, Cin), 2, Cp=Cin).view(Cout, -1)
+    set_option("OMH_CONV_TILE", "w64")
+
+    def run(fuse, **kw):
+        set_option("OMH_CONV_FUSE_NORM", "1" if fuse else "0")
+        n = torch.full((T, H, W, 2 * Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+        y = ops.conv_cl(x2, w2, bias, T, H, W, Cout, KT, 3, 3, pad_h=1, pad_w=1, out_f32=True, pair=True, norm_gamma=gamma,
+                        norm_out=n, **kw)
+        return y, n
+    for kw in (dict(resid=rf), dict()):
+        (y1, n1), (y0, n0) = run(True, **kw), run(False, **kw)
+        assert torch.equal(y1, y0)
+        assert bool(torch.isfinite(n0.float()).all()) and torch.equal(n1, n0), float((n1.float() - n0.float()).abs().max())
+        assert torch.equal(n0, ops.rms_silu_cl_split3(y0, gamma, pair=True))
+        # the pairs: [hi(16) | lo(16)] per 16 channels; hi + lo = the fp32 norm to 2^-16 relative
+        pr = n0.float().view(T, H, W, Cout // 16, 2, 16)
+        yn = y0 * torch.rsqrt(y0.pow(2).sum(-1, keepdim=True).clamp_min(1e-24)) * (Cout ** 0.5) * gamma
+        ref = torch.nn.functional.silu(yn).view(T, H, W, Cout // 16, 16)
+        assert rel_rms(pr[..., 0, :] + pr[..., 1, :], ref) < 3e-5
+    set_option("OMH_CONV_FUSE_NORM", "1")
+    n = torch.empty(T, H, W, 2 * Cout, dtype=torch.bfloat16, device="cuda")
+    sentinel = torch.full((T, H, W, Cout), 7.0, dtype=torch.float32, device="cuda")
+    ops.conv_cl(x2, w2, bias, T, H, W, Cout, KT, 3, 3, pad_h=1, pad_w=1, out_f32=True, pair=True, norm_gamma=gamma, norm_out=n,
+                norm_only=True, out=sentinel)
+    _, n0 = run(False)
+    assert torch.equal(n, n0) and bool((sentinel == 7.0).all())
+
+
 @pytest.mark.parametrize("Cin,Cout,T,H,W", [(192, 96, 2, 13, 21), (384, 192, 1, 9, 17), (160, 96, 3, 6, 5)])
 def test_conv_cl_w64_folded_upsample(ops, Cin, Cout, T, H, W, monkeypatch):
     """The decoder's upsample convolutions (nearest-2x + Conv2d 3x3, vae.py:76-79) on the stream kernel (round 3: the slab
