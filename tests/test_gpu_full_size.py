@@ -574,7 +574,8 @@ def test_gradient_accumulation_full_size_in_place_equals_autograd(clips):
 # 50-step CFG trajectories driven as text2video.py:206-252 drives them, on detgen weights / inputs regenerated here.
 # Bounds = 2 x the figures measured on MI355X (profiles/r05_full_forward_parity.json).
 TOL_HEADLINE_FORWARD = 9.0e-3        # measured 4.06e-3 (lattice) / 4.44e-3 (probes) on MI355X, round 5: 30 layers, S = 32 760
-TOL_TRAJECTORY = {1: 2.0e-3, 10: 1.5e-2, 25: 3.0e-2, 50: 6.0e-2}       # relative RMS of the latent after k steps
+TOL_TRAJECTORY = {1: 4.0e-4, 10: 3.0e-3, 25: 8.0e-3, 50: 1.2e-2}       # relative RMS of the latent after k steps; measured
+#   1.6e-4 / 1.5e-3 / 3.9e-3 / 5.8e-3 on MI355X with either solver (profiles/r05_trajectory_parity_*.json)
 
 
 @pytest.fixture(scope="module")
