@@ -819,6 +819,8 @@ def main():
             return "ffn_up_gemm_gelu"
         if M == MS and K == FF and N == DM:
             return "ffn_down_gate_resid"
+        if M == seq_len and K == DM and N == 3 * DM and epi == ops.EPI_BF16_SPLIT_T:
+            return "qkv_proj_fused"          # round 5: q | k | v as one launch per clip, V^T stored transposed
         if M == MS and K == DM and N == 2 * DM:
             return "qk_proj"
         if M == DM and N == seq_len and K == DM and k.get("batch", 1) == nb:
@@ -935,7 +937,8 @@ def main():
     l_ms = ln_timer.avg_ms()
     # the GEMM shapes of a block at M = S, each timed in situ (HIP events on the launch stream, every launch of the
     # timed steps): flops = 2 M N K, fraction of the 2.5 PFLOP/s dense bf16 MFMA peak
-    shapes = {"qk_proj": (MS, 2 * DM, DM, "q|k projection + bias, bf16 out"),
+    shapes = {"qkv_proj_fused": (seq_len, 3 * DM, DM, "q|k|v projection + bias in ONE launch per clip (OMH_EPI_BF16_SPLIT_T): q|k bf16, V^T transposed"),
+              "qk_proj": (MS, 2 * DM, DM, "q|k projection + bias, bf16 out"),
               "v_proj_transposed": (MS, DM, DM, "V^T = Wv h^T + bias (operands swapped), bf16 out"),
               "o_proj_gate_resid": (MS, DM, DM, "x += (o Wo^T + b) * gate: fp32 read-modify-write of the residual"),
               "cross_q_proj": (MS, DM, DM, "cross-attention q projection + bias, bf16 out"),
@@ -948,17 +951,19 @@ def main():
         if not ms_:
             continue
         gf = 2.0 * M_ * N_ * K_
+        per_block = nb if name == "qkv_proj_fused" else 1            # (one launch per clip; the other shapes carry the batch)
         secondary[name] = {"avg_launch_ms": round(ms_, 4), "tflops": round(gf / ms_ / 1e9, 1),
                            "mfma_frac": round(gf / ms_ / 1e9 / PEAK_BF16_TFLOPS, 4),
                            "launches_timed": gemm_timer.count(name), "M_N_K": [M_, N_, K_], "what": what}
-        tot_f, tot_ms = tot_f + gf, tot_ms + ms_
+        tot_f, tot_ms = tot_f + per_block * gf, tot_ms + per_block * ms_
         if not name.startswith("cross_"):
-            five_f, five_ms = five_f + gf, five_ms + ms_
+            five_f, five_ms = five_f + per_block * gf, five_ms + per_block * ms_
     gemm_aggregate = None
     if tot_ms:
         gemm_aggregate = {"gemm_aggregate_frac": round(five_f / five_ms / 1e9 / PEAK_BF16_TFLOPS, 4),
-                          "shapes": "q|k, V^T, o-proj+gate+residual, FFN-up+GELU, FFN-down+gate+residual: sum of flops "
-                                    "/ sum of average launch times (one of each per block)",
+                          "shapes": "q|k|v (one fused launch; or q|k + V^T where the two products run), o-proj+gate+residual, "
+                                    "FFN-up+GELU, FFN-down+gate+residual: sum of flops / sum of average launch times (one of "
+                                    "each per block)",
                           "tflop_per_block": round(five_f / 1e12, 3), "ms_per_block": round(five_ms, 4),
                           "with_cross_attention_projections_frac": round(tot_f / tot_ms / 1e9 / PEAK_BF16_TFLOPS, 4)}
     c_ms = cross_timer.avg_ms()
