@@ -366,8 +366,9 @@ extern "C" int omh_layernorm_modulate(const float* x, void* y, int64_t rows, int
     // OMH_LN_RPW = 1 / 2 / 4 forces it (timing).  Same per-row arithmetic: same bits.
     const char* force = omh_opt(OMH_OPT_LN_RPW);
     int rpw = rows <= 4096 ? 1 : (rows < 16384 ? 2 : 4);
-    if (force) rpw = atoi(force) == 1 ? 1 : (atoi(force) == 2 ? 2 : 4);
-#define OMH_LN_PICK(MV) (rpw == 1 ? layernorm_modulate_kernel<MV, 1> : (rpw == 2 ? layernorm_modulate_kernel<MV, 2> : layernorm_modulate_kernel<MV, 4>))
+    if (force) { const int f = atoi(force); rpw = (f == 1 || f == 2 || f == 8 || f == 16) ? f : 4; }
+#define OMH_LN_PICK(MV) (rpw == 1 ? layernorm_modulate_kernel<MV, 1> : (rpw == 2 ? layernorm_modulate_kernel<MV, 2> : \
+                         (rpw == 8 ? layernorm_modulate_kernel<MV, 8> : (rpw == 16 ? layernorm_modulate_kernel<MV, 16> : layernorm_modulate_kernel<MV, 4>))))
     auto kern = dim <= 6 * 256 ? OMH_LN_PICK(6) : (dim <= 20 * 256 ? OMH_LN_PICK(20) : OMH_LN_PICK(MAXV_GENERIC));
 #undef OMH_LN_PICK
     hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))), dim3(256), 0,
