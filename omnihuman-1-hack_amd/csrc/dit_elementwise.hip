@@ -365,7 +365,9 @@ extern "C" int omh_layernorm_modulate(const float* x, void* y, int64_t rows, int
     // 1 560 rows 6.6 / 7.7 / 10.9, 3 120 rows 8.0 / 8.8 / 11.4, 6 240 rows 19.4 / 16.3 / 17.5, 24 960 rows 69 / 58 / 52.
     // OMH_LN_RPW = 1 / 2 / 4 forces it (timing).  Same per-row arithmetic: same bits.
     const char* force = omh_opt(OMH_OPT_LN_RPW);
-    int rpw = rows <= 4096 ? 1 : (rows < 16384 ? 2 : 4);
+    // Round 5: 16 rows per wave from 24 576 rows on (one clip of 81 frames: 32 760) — us at 1 / 2 / 4 / 8 / 16 rows per wave:
+    // 24 960 rows 69 / 58 / 52 / 53 / 48, 32 760 rows 87 / 73 / 62 / 60 / 60, 65 520 rows 186 / 152 / 136 / 123 / 124.
+    int rpw = rows <= 4096 ? 1 : (rows < 16384 ? 2 : (rows < 24576 ? 4 : 16));
     if (force) { const int f = atoi(force); rpw = (f == 1 || f == 2 || f == 8 || f == 16) ? f : 4; }
 #define OMH_LN_PICK(MV) (rpw == 1 ? layernorm_modulate_kernel<MV, 1> : (rpw == 2 ? layernorm_modulate_kernel<MV, 2> : \
                          (rpw == 8 ? layernorm_modulate_kernel<MV, 8> : (rpw == 16 ? layernorm_modulate_kernel<MV, 16> : layernorm_modulate_kernel<MV, 4>))))
