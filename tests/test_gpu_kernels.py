@@ -584,6 +584,20 @@ def test_layernorm_modulate(ops):
         xh = torch.nn.functional.layer_norm(x, (d,), eps=1e-6)
         ref = xh * (1 + (mod[1][None] + e0[:, 1]).repeat_interleave(S, 0)) + (mod[0][None] + e0[:, 0]).repeat_interleave(S, 0)
         assert rel_rms(y.float(), ref) < 4e-3
+    # rows per wave (1 / 2 / 4 / 8 / 16, picked by the row count; round 5 added 8 and 16): the same bits whichever runs —
+    # batch boundaries inside a wave's rows (101 rows per batch), a ragged last wave
+    B, S, d = 3, 101, 1536
+    x = torch.randn(B * S, d, device="cuda") * 3 + 0.5
+    mod, e0 = torch.randn(6, d, device="cuda"), torch.randn(B, 6, d, device="cuda")
+    outs = []
+    for rpw in ("1", "2", "4", "8", "16"):
+        set_option("LN_RPW", rpw)
+        y = torch.empty(B * S, d, dtype=torch.bfloat16, device="cuda")
+        ops.layernorm_modulate_raw(ops.ptr(x), ops.ptr(y), B * S, d, 1e-6, 1.0, ops.ptr(mod, d), ops.ptr(e0, d), 6 * d,
+                                   ops.ptr(mod, 0), ops.ptr(e0, 0), 6 * d, S)
+        outs.append(y)
+    set_option("LN_RPW", None)
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
     B, S, d = 2, 50, 1536
     x = torch.randn(B * S, d, device="cuda") * 3 + 0.5
     w, b = torch.randn(d, device="cuda"), torch.randn(d, device="cuda")
