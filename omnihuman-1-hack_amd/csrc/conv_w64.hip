@@ -42,7 +42,8 @@ __device__ __forceinline__ void divmod24(int v, int d, float rcp, int& q, int& r
 template <int CFG, bool OUT_F32, bool NORM, bool PAIR = false>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void conv_cl_w64_kernel(const omh_conv_args p, const int tiles_m, const int tiles_n) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * STAGE + (NORM ? 512 : 0)];   // + gamma[96] for the norm
+    // + per wave [gamma(96) | bias(96)] fp32 (768 bytes): the epilogue's per-cout vectors come from LDS
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * STAGE + 4 * 768];
     constexpr int WBM = CFG == CFG_P ? 512 : 256, WBN = CFG == CFG_P ? 96 : 192, VM = WBM - 2;
     constexpr int A_BYTES = WBM * 64;
     constexpr int NA = CFG == CFG_P ? 8 : 4, NB = CFG == CFG_P ? 5 : 9;
@@ -143,7 +144,14 @@ void conv_cl_w64_kernel(const omh_conv_args p, const int tiles_m, const int tile
     tab[42] = rowmask;
     tab[43] = 0;
     const uint32_t vtab = lds0 + (uint32_t)tid * 176u;
-    if (NORM && tid < 96) ((float*)(smem + 3 * STAGE))[tid] = p.norm_gamma[tid];   // ordered by the stream's first barrier
+    {   // this wave's gamma (norm kinds) and bias runs; ordered by the stream's first barrier
+        float* vec = (float*)(smem + 3 * STAGE + w * 768);
+        const int c0 = n0 + wn * 96;
+        for (int c = lane; c < 96; c += 64) {
+            if (NORM) vec[c] = p.norm_gamma[c];
+            vec[96 + c] = (p.bias && c0 + c < p.Cout) ? p.bias[c0 + c] : 0.0f;
+        }
+    }
 
     const __amdgpu_buffer_rsrc_t rx = rsrc_of(p.x, (int64_t)p.Tin * HW * p.Cin * 2);
     const __amdgpu_buffer_rsrc_t rw = rsrc_of(p.w, (int64_t)p.Cout * K * 2);
@@ -161,7 +169,7 @@ void conv_cl_w64_kernel(const omh_conv_args p, const int tiles_m, const int tile
     const uint64_t p3 = pack2((uint32_t)(HW * p.Cin * 2), (uint32_t)(64 - p.Cin * 2));
     const uint64_t p4 = pack2((uint32_t)(4 * p.Cin + 64), lds0 + blast_rel);
     const uint64_t p5 = pack2((uint32_t)(32 * p.Cout * ES), (uint32_t)up);
-    const uint64_t p6 = pack2(lds0 + 3u * STAGE, __float_as_uint(sqrtf((float)p.Cout)));   // gamma in LDS, sqrt(C)
+    const uint64_t p6 = pack2(lds0 + 3u * STAGE + (uint32_t)w * 768u, __float_as_uint(sqrtf((float)p.Cout)));   // the wave's [gamma | bias] in LDS, sqrt(C)
 
 #define OMH_CW64_RUN(ASM)                                                                                              \
     asm volatile(ASM                                                                                                   \

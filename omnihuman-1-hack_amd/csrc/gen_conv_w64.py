@@ -503,6 +503,22 @@ def spread_keep(ops, extras):
 NTILES = NI * NJ
 
 
+BIAS_LDS = 384                                     # the wave's 96 bias values sit behind its 96 gamma values in LDS
+
+
+def bias_runs(e):
+    """The lane's bias runs (8 couts 32 i + 16 p + 8 h ..) -> v[BIASV ...]: from the wave's block in LDS
+    ([gamma(96) | bias(96)] fp32 above the stages, written by the C++ prologue: zeros where there is no bias / no such
+    cout).  Round 5: they were twelve buffer loads issued here and waited for at once — ~1.5 us of exposed memory latency
+    per tile with the matrix pipe idle."""
+    e(f"v_add_u32 v{V_ST_OFF}, {S_GAMMA_LDS}, v{V_LANE}")         # (v249 is free until the row-block loop sets it)
+    for i in range(NI):
+        for p in range(2):
+            for q in range(2):
+                e(f"ds_read_b128 {vr(BIASV + (2 * i + p) * 8 + 4 * q, 4)}, v{V_ST_OFF} "
+                  f"offset:{BIAS_LDS + (32 * i + 16 * p) * 4 + 16 * q}")
+
+
 def epilogue(e, kind):
     """y = acc + bias (+ residual), bf16 or fp32 (wide_epilogue's order).  After the permlane widening lane (r, h)
     holds, per tile (i, j) and run p, the 8 couts 32 i + 16 p + 8 h .. of voxel row 32 j + r of the wave's patch.
@@ -512,11 +528,7 @@ def epilogue(e, kind):
     e(f"v_mbcnt_hi_u32_b32 v{V_LANE}, -1, v{V_LANE}")             # lane
     e(f"v_lshrrev_b32 v{V_LANE}, 5, v{V_LANE}")
     e(f"v_lshlrev_b32 v{V_LANE}, 5, v{V_LANE}")                   # 32 h bytes = 8 h floats
-    for i in range(NI):
-        for p in range(2):
-            for q in range(2):
-                e(f"buffer_load_dwordx4 {vr(BIASV + (2 * i + p) * 8 + 4 * q, 4)}, v{V_LANE}, %[rbias], 0 offen "
-                  f"offset:{(32 * i + 16 * p) * 4 + 16 * q}")
+    bias_runs(e)
     e(f"v_mov_b32 v{V_ST_OFF}, v{VOC}")                           # store offset of the lane's row in row block j
     for n in range(NTILES):
         j, i = divmod(n, NI)
@@ -535,7 +547,8 @@ def epilogue(e, kind):
                 e(f"v_accvgpr_read_b32 v{120 + 16 * (n - 8) + r_}, a{rbase + r_}")
             rbase = 120 + 16 * (n - 8)
         if n == 0:
-            e("s_waitcnt vmcnt(0)")                              # the bias runs (and, older, every residual tile)
+            e("s_waitcnt vmcnt(0)")                              # every residual tile (requested during the k loop)
+            e("s_waitcnt lgkmcnt(0)")                            # the bias runs (LDS)
         e(f"v_bfe_u32 v{V_ROWBIT}, v{ROWMASK}, {j}, 1")           # this lane's row of the strip is an output row
         e(f"v_cmp_ne_u32 vcc, 0, v{V_ROWBIT}")
         e("s_and_saveexec_b64 s[86:87], vcc")
@@ -602,11 +615,7 @@ def epilogue_norm(e, kind, pair_out=False):
     e(f"v_mbcnt_hi_u32_b32 v{V_LANE}, -1, v{V_LANE}")
     e(f"v_lshrrev_b32 v{V_LANE}, 5, v{V_LANE}")
     e(f"v_lshlrev_b32 v{V_LANE}, 5, v{V_LANE}")                   # 32 h bytes = 8 h floats
-    for i in range(NI):
-        for p in range(2):
-            for q in range(2):
-                e(f"buffer_load_dwordx4 {vr(BIASV + (2 * i + p) * 8 + 4 * q, 4)}, v{V_LANE}, %[rbias], 0 offen "
-                  f"offset:{(32 * i + 16 * p) * 4 + 16 * q}")
+    bias_runs(e)
     e(f"v_add_u32 v{V_GADDR}, {S_GAMMA_LDS}, v{V_LANE}")          # this lane's gamma runs in LDS
     e(f"v_mov_b32 v{V_ST_OFF}, v{VOC}")
     for n in range(NTILES):
@@ -627,6 +636,7 @@ def epilogue_norm(e, kind, pair_out=False):
             rbase = 120 + 16 * (n - 8)
         if n == 0:
             e("s_waitcnt vmcnt(0)")
+            e("s_waitcnt lgkmcnt(0)")                            # the bias runs (LDS)
         e(f"v_bfe_u32 v{V_ROWBIT}, v{ROWMASK}, {j}, 1")
         e(f"v_cmp_ne_u32 vcc, 0, v{V_ROWBIT}")
         e("s_and_saveexec_b64 s[86:87], vcc")
