@@ -24,6 +24,7 @@
 //     2..3 (conflict-free transposing reads of 4 rows x 64 bytes).
 #include "omh_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -43,14 +44,22 @@ __device__ __forceinline__ uint4 ld16(const uint16_t* p, bool ok) {
     return ok ? *(const uint4*)p : make_uint4(0u, 0u, 0u, 0u);
 }
 
-// P and dS of one 32x32 block (see attention_bwd.hip)
-__device__ __forceinline__ void p_and_ds(const f32x16& s, const f32x16& dp, const float* lv, const float* dl,
-                                         const bool* ok, float sc, float scale, bf16x8* pf, bf16x8* dsf) {
+// P and dS of one 32x32 block (see attention_bwd.hip), WITHOUT the factor `scale` of dS: the callers multiply their dQ /
+// dK accumulators by it once, after the last tile (round 5; it was one multiply per score).
+//   PRE   q carries scale * log2(e): the scores need no factor
+//   FOLD  the score accumulators started from -lse / sc and the dP accumulators from -delta (MFMA C operand of the first
+//         product): P = exp2(sc s), dS = P dp — the fma and the subtraction per score are gone
+//   MASK  keys key_base + 16 (r >> 3) + (r & 7) at or past `klen` get P = 0 (the dQ kernel's last key tile only)
+template <bool PRE, bool FOLD, bool MASK>
+__device__ __forceinline__ void p_and_ds(const f32x16& s, const f32x16& dp, float lv, float dl, int key_base, int klen,
+                                         float sc, bf16x8* pf, bf16x8* dsf) {
     float p[16], ds[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        p[r] = ok[r] ? __builtin_amdgcn_exp2f(fmaf(s[r], sc, -lv[r])) : 0.f;
-        ds[r] = p[r] * (dp[r] - dl[r]) * scale;
+        const float x = FOLD ? (PRE ? s[r] : s[r] * sc) : (PRE ? s[r] - lv : fmaf(s[r], sc, -lv));
+        p[r] = __builtin_amdgcn_exp2f(x);
+        if (MASK) p[r] = (key_base + ((r >> 3) << 4) + (r & 7) < klen) ? p[r] : 0.f;
+        ds[r] = p[r] * (FOLD ? dp[r] : dp[r] - dl);
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
@@ -100,14 +109,15 @@ __device__ __forceinline__ bf16x8 tr_frag2(const unsigned char* tile, uint32_t a
 // LDS-DMA of one [64][128] bf16 tile: chunk c = tid + 256 j lands at byte 16 c (row c >> 4, physical slot c & 15)
 // and is fetched from logical slot (c & 15) ^ swz(row) of source row `first_row + row`
 struct TileSrc {
-    __amdgpu_buffer_rsrc_t rsrc;
+    u32x4 rsrc;                     // raw buffer descriptor: base, stride 0, bytes, 0x00020000
     uint32_t voff[8];               // 1024 / THREADS chunks per thread (4 for 256 threads, 8 for 128)
     uint32_t tile_bytes;            // 64 rows of the source
 };
 template <int THREADS = 256>
 __device__ __forceinline__ TileSrc tile_src(const uint16_t* base, int64_t rows, int64_t rs, int tid) {
     TileSrc t;
-    t.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(((rows - 1) * rs + D) * 2), 0x00020000);
+    const uint64_t a = (uint64_t)base;
+    t.rsrc = u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, (uint32_t)(((rows - 1) * rs + D) * 2), 0x00020000u};
 #pragma unroll
     for (int j = 0; j < 1024 / THREADS; ++j) {
         const int c = tid + THREADS * j;
@@ -117,13 +127,23 @@ __device__ __forceinline__ TileSrc tile_src(const uint16_t* base, int64_t rows, 
     t.tile_bytes = (uint32_t)(TB * rs * 2);
     return t;
 }
+// The loads are written as asm ON PURPOSE (round 5).  Through the builtin the compiler knows that a load into LDS is
+// outstanding, cannot tell which bytes it will write, and puts `s_waitcnt vmcnt(0)` in front of the next LDS read —
+// the first fragment read of the very iteration that issued the prefetch.  The "double buffer" then never overlapped
+// anything: each 64-position tile paid one full memory round trip (measured: 5 700 cycles per tile of the dK / dV
+// kernel with the LDS reads AND the softmax removed it was still 4 500, for 2 048 cycles of MFMA work).  As asm the
+// loads are invisible to the compiler's counter bookkeeping; the kernels wait for them explicitly, at the end of the
+// iteration (s_waitcnt vmcnt(0) + barrier).  Hidden loads can only make a compiler-placed vmcnt(N) wait longer, never
+// shorter: the counter retires in order.  `lds_dst` is the wave-uniform LDS byte address of chunk row 0 of this wave.
 template <int THREADS = 256>
-__device__ __forceinline__ void tile_dma(const TileSrc& t, int tile, unsigned char* dst, int wave_lds) {
+__device__ __forceinline__ void tile_dma(const TileSrc& t, int tile, uint32_t lds_dst) {
 #pragma unroll
     for (int j = 0; j < 1024 / THREADS; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(t.rsrc, (lds_vptr)(dst + wave_lds + j * (THREADS * 16)), 16,
-                                                 t.voff[j] + (uint32_t)tile * t.tile_bytes, 0, 0, 0);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                     :: "s"(lds_dst + (uint32_t)(j * (THREADS * 16))), "v"(t.voff[j] + (uint32_t)tile * t.tile_bytes), "s"(t.rsrc)
+                     : "memory");
 }
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(lds_u8_ptr)p; }
 
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
@@ -175,12 +195,15 @@ struct BwdSplit {
     float* ws;            // dQ: [n_tail][splits][128][128];  dK, dV: [n_tail][splits][2][128][128]  fp32
 };
 
+template <bool PRE>
 __global__ __launch_bounds__(256, 2)
 void attn_bwd2_dq_kernel(const omh_attn_bwd_args p, const int q_blocks, const BwdSplit wk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // [2 stages][K tile | V tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const bool worker = (int)blockIdx.x >= wk.n_regular;
-    const int wid = worker ? wk.n_regular + ((int)blockIdx.x - wk.n_regular) / wk.splits : (int)blockIdx.x;
+    // regular ids go through xcd_remap: the 13 query blocks of one (batch, head) then run on ONE XCD and its K / V
+    // (400 KB each at S = 1560) is fetched into one 4 MiB L2 instead of eight
+    const int wid = worker ? wk.n_regular + ((int)blockIdx.x - wk.n_regular) / wk.splits : xcd_remap((int)blockIdx.x, wk.n_regular);
     const int split = worker ? ((int)blockIdx.x - wk.n_regular) % wk.splits : 0;
     const int qb = wid % q_blocks, bh = wid / q_blocks;
     const int b = bh / p.H, head = bh % p.H;
@@ -213,14 +236,11 @@ void attn_bwd2_dq_kernel(const omh_attn_bwd_args p, const int q_blocks, const Bw
         l2 = (l > -INFINITY) ? l * LOG2E : INFINITY;
         del = p.delta[row_i];                                        // attn_bwd2_delta_kernel ran before (every phase)
     }
-    const float sc = p.q_prescaled ? 1.0f : p.scale * LOG2E;
-    float lv[16], dl[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { lv[r] = l2; dl[r] = del; }
+    const float sc = PRE ? 1.0f : p.scale * LOG2E;
 
     const FragAddr fa = frag_addr(lane);
     const TileSrc ks = tile_src(K, p.Lk, p.k_rs, tid), vs = tile_src(V, p.Lk, p.k_rs, tid);
-    const int wave_lds = __builtin_amdgcn_readfirstlane(wave) * 1024;
+    const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 1024);   // stage 0, K tile, this wave's rows
 
     f32x16 dq[4];
 #pragma unroll
@@ -229,19 +249,14 @@ void attn_bwd2_dq_kernel(const omh_attn_bwd_args p, const int q_blocks, const Bw
         for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
 
     if (n_tiles > 0) {
-        tile_dma(ks, t_first, smem, wave_lds);
-        tile_dma(vs, t_first, smem + TILE_BYTES, wave_lds);
+        tile_dma(ks, t_first, wave_lds);
+        tile_dma(vs, t_first, wave_lds + TILE_BYTES);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    for (int t = 0; t < n_tiles; ++t) {
-        const unsigned char* kt = smem + (t & 1) * 2 * TILE_BYTES;
-        const unsigned char* vt = kt + TILE_BYTES;
-        if (t + 1 < n_tiles) {                                       // the other stage was last read before the barrier
-            unsigned char* nk = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
-            tile_dma(ks, t_first + t + 1, nk, wave_lds);
-            tile_dma(vs, t_first + t + 1, nk + TILE_BYTES, wave_lds);
-        }
-        const int k0 = (t_first + t) * TB;
+    // one tile of 64 keys; `masked`: the tile reaches past klen (the last one at most — every other tile skips the
+    // compare + select per score)
+    auto tile_body = [&](const unsigned char* kt, const unsigned char* vt, int k0, auto masked) {
+        constexpr bool MASK = decltype(masked)::value;
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
             // S^T = K Q^T and dP^T = V dO^T as [key][query], lane = query; register r <-> key k0 + 32hb + 16(r>>3) + 8lh + (r&7)
@@ -255,11 +270,8 @@ void attn_bwd2_dq_kernel(const omh_attn_bwd_args p, const int q_blocks, const Bw
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[kk], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[kk], dp, 0, 0, 0);
             }
-            bool ok[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ok[r] = (k0 + 32 * hb + ((r >> 3) << 4) + lh * 8 + (r & 7)) < klen;
             bf16x8 pf[2], dsf[2];
-            p_and_ds(s, dp, lv, dl, ok, sc, p.scale, pf, dsf);
+            p_and_ds<PRE, false, MASK>(s, dp, l2, del, k0 + 32 * hb + lh * 8, klen, sc, pf, dsf);
             // dQ^T += K^T dS^T   ([d][query], lane = query): K^T gathered from the row-major K tile
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -269,8 +281,29 @@ void attn_bwd2_dq_kernel(const omh_attn_bwd_args p, const int q_blocks, const Bw
                     dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tk, dsf[a], dq[db], 0, 0, 0);
                 }
         }
+    };
+    // the tile that reaches past klen (the last one of the sequence, if any) is peeled off the loop: two bodies inside
+    // one loop keep both sets of hoisted addresses live and spill
+    const bool edge = n_tiles > 0 && (t_first + n_tiles) * TB > klen;
+    const int n_plain = n_tiles - (edge ? 1 : 0);
+    for (int t = 0; t < n_plain; ++t) {
+        const unsigned char* kt = smem + (t & 1) * 2 * TILE_BYTES;
+        if (t + 1 < n_tiles) {                                       // the other stage was last read before the barrier
+            const uint32_t nk = wave_lds + ((t + 1) & 1) * 2 * TILE_BYTES;
+            tile_dma(ks, t_first + t + 1, nk);
+            tile_dma(vs, t_first + t + 1, nk + TILE_BYTES);
+        }
+        tile_body(kt, kt + TILE_BYTES, (t_first + t) * TB, std::false_type());
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
+    if (edge) {
+        const unsigned char* kt = smem + (n_plain & 1) * 2 * TILE_BYTES;
+        tile_body(kt, kt + TILE_BYTES, (t_first + n_plain) * TB, std::true_type());
+    }
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[db][r] *= p.scale;             // dQ = scale dS K
     if (worker) {                                                    // partial sums over this worker's keys
         float* W = wk.ws + (((int64_t)(wid - wk.n_regular) * wk.splits + split) * 128 + wave * 32 + li) * D;
 #pragma unroll
@@ -311,7 +344,7 @@ void attn_bwd2_dq_kernel(const omh_attn_bwd_args p, const int q_blocks, const Bw
 // operand registers + 64 score + 32 packed P / dS + fragments + addresses) is ~290 > 256 arch VGPRs, and hipcc spills
 // 334 registers (812 bytes of scratch per lane).  It needs an asm-owned register map with P / dS overlaid on the score
 // registers and lse / delta folded into the MFMA C operand.
-template <int WAVES, int KPW>
+template <int WAVES, int KPW, bool PRE>
 __global__ __launch_bounds__(64 * WAVES, 1)
 void attn_bwd2_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks, const BwdSplit wk) {
     constexpr int THREADS = 64 * WAVES;
@@ -320,7 +353,7 @@ void attn_bwd2_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks, const 
     float* stat = (float*)(smem + 4 * TILE_BYTES);                              // [2 stages][lse 64 | delta 64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const bool worker = (int)blockIdx.x >= wk.n_regular;
-    const int wid = worker ? wk.n_regular + ((int)blockIdx.x - wk.n_regular) / wk.splits : (int)blockIdx.x;
+    const int wid = worker ? wk.n_regular + ((int)blockIdx.x - wk.n_regular) / wk.splits : xcd_remap((int)blockIdx.x, wk.n_regular);
     const int split = worker ? ((int)blockIdx.x - wk.n_regular) % wk.splits : 0;
     const int kb = wid % k_blocks, bh = wid / k_blocks;
     const int b = bh / p.H, head = bh % p.H;
@@ -352,12 +385,13 @@ void attn_bwd2_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks, const 
             kf[c][kk] = __builtin_bit_cast(bf16x8, ld16(K + off, key < p.Lk));
             vf[c][kk] = __builtin_bit_cast(bf16x8, ld16(V + off, key < p.Lk));
         }
-    const float sc = p.q_prescaled ? 1.0f : p.scale * LOG2E;
-    const float ds_scale = p.q_prescaled ? (1.0f / LOG2E) : p.scale;     // dK = dS^T q' / log2(e) on a pre-scaled q
+    const float sc = PRE ? 1.0f : p.scale * LOG2E;
+    const float neg_inv_sc = PRE ? -LOG2E : -1.0f / p.scale;             // -lse log2(e) / sc: the scores' starting value
+    const float ds_scale = PRE ? (1.0f / LOG2E) : p.scale;               // dK = dS^T q' / log2(e) on a pre-scaled q
 
     const FragAddr fa = frag_addr(lane);
     const TileSrc qs = tile_src<THREADS>(Q, p.Lq, p.q_rs, tid), dos = tile_src<THREADS>(DO, p.Lq, p.o_rs, tid);
-    const int wave_lds = __builtin_amdgcn_readfirstlane(wave) * 1024;
+    const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 1024);   // stage 0, Q tile, this wave's rows
 
     f32x16 dv[KPW][4], dk[KPW][4];
 #pragma unroll
@@ -367,18 +401,25 @@ void attn_bwd2_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks, const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dv[c][i][r] = 0.f; dk[c][i][r] = 0.f; }
 
-    // lse / delta of a tile's 64 queries: threads 0..63 fetch them one tile ahead and park them in LDS
-    auto stat_load = [&](int tile, float& l, float& dd) {
-        const int q = tile * TB + tid;
-        const bool in = q < p.Lq;
-        const float lraw = in ? LSE[q] : 0.f;
-        l = (in && lraw > -INFINITY) ? lraw * LOG2E : INFINITY;           // no keys / past the end: P = 0
-        dd = in ? DEL[q] : 0.f;
+    // lse / delta of a tile's 64 queries, fetched one tile ahead and parked in LDS — negated, as the values the score /
+    // dP accumulators START from (p_and_ds FOLD).  stat_load only ISSUES the loads (every wave, clamped index: no
+    // branch, no arithmetic on the result — either would put the wait for them right here); stat_value turns the raw
+    // numbers into the parked ones when they are stored, a tile later.
+    auto stat_load = [&](int tile, float& lraw, float& draw) {
+        const int q = min(tile * TB + lane, p.Lq - 1);
+        lraw = LSE[q];
+        draw = DEL[q];
+    };
+    auto stat_store = [&](int tile, float lraw, float draw, float* dst) {
+        const bool in = tile * TB + lane < p.Lq;
+        dst[lane] = (in && lraw > -INFINITY) ? lraw * neg_inv_sc : -INFINITY;   // no keys / past the end: P = exp2(-inf) = 0
+        dst[64 + lane] = in ? -draw : 0.f;
     };
     float gl = 0.f, gd = 0.f;
-    tile_dma<THREADS>(qs, t_first, smem, wave_lds);                  // (a tile index past the end arrives as zeros)
-    tile_dma<THREADS>(dos, t_first, smem + TILE_BYTES, wave_lds);
-    if (tid < 64) { stat_load(t_first, gl, gd); stat[tid] = gl; stat[64 + tid] = gd; }
+    tile_dma<THREADS>(qs, t_first, wave_lds);                        // (a tile index past the end arrives as zeros)
+    tile_dma<THREADS>(dos, t_first, wave_lds + TILE_BYTES);
+    stat_load(t_first, gl, gd);
+    if (tid < 64) stat_store(t_first, gl, gd, stat);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     for (int t = 0; t < n_tiles; ++t) {
         const unsigned char* qt = smem + (t & 1) * 2 * TILE_BYTES;
@@ -386,71 +427,121 @@ void attn_bwd2_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks, const 
         const float* st = stat + (t & 1) * 128;
         const bool more = t + 1 < n_tiles;
         if (more) {
-            unsigned char* nq = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
-            tile_dma<THREADS>(qs, t_first + t + 1, nq, wave_lds);
-            tile_dma<THREADS>(dos, t_first + t + 1, nq + TILE_BYTES, wave_lds);
-            if (tid < 64) stat_load(t_first + t + 1, gl, gd);
+            const uint32_t nq = wave_lds + ((t + 1) & 1) * 2 * TILE_BYTES;
+            tile_dma<THREADS>(qs, t_first + t + 1, nq);
+            tile_dma<THREADS>(dos, t_first + t + 1, nq + TILE_BYTES);
+            stat_load(t_first + t + 1, gl, gd);
         }
+        // One tile = two halves of 32 queries, each with three stages: A  S = Q K^T and dP = dO V^T (16 products,
+        // [query][key], lane = key; register r <-> query 64t + 32hb + 16(r>>3) + 8lh + (r&7)); B  the softmax
+        // arithmetic (VALU); C  dV^T += dO^T P, dK^T += Q^T dS (16 products, [d][key]).  With ONE wave per SIMD nothing
+        // else covers a stage's latency, so the halves are software-pipelined:  A0 | A1 + B0 | C0 + B1 | C1  — the
+        // sched_group_barrier sequences put ~5 VALU instructions into the shadow of each 8-pass MFMA, and every stage's
+        // LDS fragments are requested one stage ahead (hipcc's own order was read, wait, MFMA, ... then all the VALU:
+        // 6 500 cycles per tile for 2 048 cycles of MFMA work — profiles/r05_pmc_attn_bwd.json).
+        static_assert(KPW == 1, "the pipelined body is written for one key block per wave");
+        f32x16 s[2], dp[2];                                          // start from -lse / sc and -delta (p_and_ds FOLD)
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
-            // S = Q K^T and dP = dO V^T as [query][key], lane = key; register r <-> query 64t + 32hb + 16(r>>3) + 8lh + (r&7)
-            f32x16 s[KPW], dp[KPW];
-#pragma unroll
-            for (int c = 0; c < KPW; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { s[c][r] = 0.f; dp[c][r] = 0.f; }
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                const bf16x8 qa = *(const bf16x8*)(qt + fa.row[kk] + hb * 32 * 256);
-                const bf16x8 da = *(const bf16x8*)(dot + fa.row[kk] + hb * 32 * 256);
-#pragma unroll
-                for (int c = 0; c < KPW; ++c) {
-                    s[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[c][kk], s[c], 0, 0, 0);
-                    dp[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[c][kk], dp[c], 0, 0, 0);
-                }
-            }
-            float lv[16], dl[16];
+        for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    lv[8 * a + e] = st[32 * hb + 16 * a + 8 * lh + e];
-                    dl[8 * a + e] = st[64 + 32 * hb + 16 * a + 8 * lh + e];
+                    s[hb][8 * a + e] = st[32 * hb + 16 * a + 8 * lh + e];
+                    dp[hb][8 * a + e] = st[64 + 32 * hb + 16 * a + 8 * lh + e];
                 }
-            bf16x8 pf[KPW][2], dsf[KPW][2];
+        bf16x8 qa[8], da[8], ta[2][4], tq[2][4], pf[2][2], dsf[2][2];
+        auto load_rows = [&](int hb) {
 #pragma unroll
-            for (int c = 0; c < KPW; ++c) {
-                bool ok[16];
-                const bool key_ok = key0 + 32 * c < klen;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ok[r] = key_ok;
-                p_and_ds(s[c], dp[c], lv, dl, ok, sc, ds_scale, pf[c], dsf[c]);
+            for (int kk = 0; kk < 8; ++kk) {
+                qa[kk] = *(const bf16x8*)(qt + fa.row[kk] + hb * 32 * 256);
+                da[kk] = *(const bf16x8*)(dot + fa.row[kk] + hb * 32 * 256);
             }
-            // dV^T += dO^T P ,  dK^T += Q^T dS   ([d][key], lane = key): dO^T, Q^T gathered from the row-major tiles
+        };
+        auto load_tr = [&](int hb, int a) {
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int db = 0; db < 4; ++db) {
+                const uint32_t ad = fa.tr[db] + (32 * hb + 16 * a) * 256;
+                ta[a][db] = tr_frag2(dot, ad);
+                tq[a][db] = tr_frag2(qt, ad);
+            }
+        };
+        auto stage_a = [&](int hb) {
 #pragma unroll
-                for (int db = 0; db < 4; ++db) {
-                    const uint32_t ad = fa.tr[db] + (32 * hb + 16 * a) * 256;
-                    const bf16x8 ta = tr_frag2(dot, ad);
-                    const bf16x8 tq = tr_frag2(qt, ad);
+            for (int kk = 0; kk < 8; ++kk) {
+                s[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[kk], kf[0][kk], s[hb], 0, 0, 0);
+                dp[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[kk], vf[0][kk], dp[hb], 0, 0, 0);
+            }
+        };
+        auto stage_c = [&](int hb, int a) {
 #pragma unroll
-                    for (int c = 0; c < KPW; ++c) {
-                        dv[c][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta, pf[c][a], dv[c][db], 0, 0, 0);
-                        dk[c][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq, dsf[c][a], dk[c][db], 0, 0, 0);
-                    }
-                }
+            for (int db = 0; db < 4; ++db) {
+                dv[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[a][db], pf[hb][a], dv[0][db], 0, 0, 0);
+                dk[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[a][db], dsf[hb][a], dk[0][db], 0, 0, 0);
+            }
+        };
+        // no key mask: a lane is ONE key, and a key at or past klen only spoils its own dK / dV column (zeroed after the loop)
+        u32x4 cp[2][2], cd[2][2];                                    // packed P / dS: [half][16-query group]
+        auto slice_b = [&](int hb, int i) {                          // scores 2i, 2i+1 of a half (p_and_ds FOLD, no mask)
+            const float p0 = __builtin_amdgcn_exp2f(PRE ? s[hb][2 * i] : s[hb][2 * i] * sc);
+            const float p1 = __builtin_amdgcn_exp2f(PRE ? s[hb][2 * i + 1] : s[hb][2 * i + 1] * sc);
+            cp[hb][i >> 2][i & 3] = pack_bf2(p0, p1);
+            cd[hb][i >> 2][i & 3] = pack_bf2(p0 * dp[hb][2 * i], p1 * dp[hb][2 * i + 1]);
+        };
+        load_rows(0);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_a(0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_rows(1);
+        load_tr(0, 0);
+        load_tr(0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {                             // A1 + B0: two products, one slice (2 exp2 + 2 mul + 2 cvt)
+            s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[kk], kf[0][kk], s[1], 0, 0, 0);
+            dp[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[kk], vf[0][kk], dp[1], 0, 0, 0);
+            slice_b(0, kk);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (more && tid < 64) {                                      // the other stage's statistics: last read a tile ago
-            float* nst = stat + ((t + 1) & 1) * 128;
-            nst[tid] = gl;
-            nst[64 + tid] = gd;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            pf[0][a] = __builtin_bit_cast(bf16x8, cp[0][a]);
+            dsf[0][a] = __builtin_bit_cast(bf16x8, cd[0][a]);
         }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)                                  // C0 + B1
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                dv[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[a][db], pf[0][a], dv[0][db], 0, 0, 0);
+                dk[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[a][db], dsf[0][a], dk[0][db], 0, 0, 0);
+                slice_b(1, 4 * a + db);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            pf[1][a] = __builtin_bit_cast(bf16x8, cp[1][a]);
+            dsf[1][a] = __builtin_bit_cast(bf16x8, cd[1][a]);
+        }
+        load_tr(1, 0);
+        load_tr(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_c(1, 0);
+        stage_c(1, 1);
+        if (more && tid < 64)                                        // the other stage's statistics: last read a tile ago
+            stat_store(t_first + t + 1, gl, gd, stat + ((t + 1) & 1) * 128);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 #pragma unroll
     for (int c = 0; c < KPW; ++c) {
         const int key = key0 + 32 * c;
+        const bool key_in = key < klen;                              // keys past klen: zeros, whatever the loop left there
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dk[c][db][r] = key_in ? dk[c][db][r] * ds_scale : 0.f;   // (a select: the column may hold NaN)
+                dv[c][db][r] = key_in ? dv[c][db][r] : 0.f;
+            }
         if (worker) {                                                // partial sums over this worker's queries
             float* W = wk.ws + ((((int64_t)(wid - wk.n_regular) * wk.splits + split) * 2) * 128 + wave * (32 * KPW) + 32 * c + li) * D;
 #pragma unroll
@@ -556,8 +647,10 @@ int omh_launch_attn_bwd2(const omh_attn_bwd_args& a, hipStream_t s) {
     constexpr int LDS_DQ = 4 * TILE_BYTES, LDS_KV = 4 * TILE_BYTES + 2 * 128 * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd2_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
-        (void)hipFuncSetAttribute((const void*)attn_bwd2_dkdv_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV);
+        (void)hipFuncSetAttribute((const void*)attn_bwd2_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
+        (void)hipFuncSetAttribute((const void*)attn_bwd2_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
+        (void)hipFuncSetAttribute((const void*)attn_bwd2_dkdv_kernel<4, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV);
+        (void)hipFuncSetAttribute((const void*)attn_bwd2_dkdv_kernel<4, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV);
         attr_set = true;
     }
     const int k_blocks = (a.Lk + 127) / 128, q_blocks = (a.Lq + 127) / 128;
@@ -579,12 +672,16 @@ int omh_launch_attn_bwd2(const omh_attn_bwd_args& a, hipStream_t s) {
     BwdSplit wq = {pq.n_regular, pq.n_tail, pq.splits, (float*)a.workspace};
     BwdSplit wkv = {pk.n_regular, pk.n_tail, pk.splits, (float*)((char*)a.workspace + (pq.n_tail ? need_q : 0))};
     if (run_q) {                                                                                               // phase 0: writes delta
-        hipLaunchKernelGGL(attn_bwd2_dq_kernel, dim3(wq.n_regular + wq.n_tail * wq.splits), dim3(256), LDS_DQ, s, a, q_blocks, wq);
+        const dim3 grid(wq.n_regular + wq.n_tail * wq.splits);
+        if (a.q_prescaled) hipLaunchKernelGGL(attn_bwd2_dq_kernel<true>, grid, dim3(256), LDS_DQ, s, a, q_blocks, wq);
+        else hipLaunchKernelGGL(attn_bwd2_dq_kernel<false>, grid, dim3(256), LDS_DQ, s, a, q_blocks, wq);
         if (wq.n_tail)
             hipLaunchKernelGGL(attn_bwd2_sum_kernel<1>, dim3((wq.n_tail * 128 + 3) / 4), dim3(256), 0, s, a, q_blocks, wq);
     }
     if (run_k) {                                                                                               // reads delta
-        hipLaunchKernelGGL((attn_bwd2_dkdv_kernel<4, 1>), dim3(wkv.n_regular + wkv.n_tail * wkv.splits), dim3(256), LDS_KV, s, a, k_blocks, wkv);
+        const dim3 grid(wkv.n_regular + wkv.n_tail * wkv.splits);
+        if (a.q_prescaled) hipLaunchKernelGGL((attn_bwd2_dkdv_kernel<4, 1, true>), grid, dim3(256), LDS_KV, s, a, k_blocks, wkv);
+        else hipLaunchKernelGGL((attn_bwd2_dkdv_kernel<4, 1, false>), grid, dim3(256), LDS_KV, s, a, k_blocks, wkv);
         if (wkv.n_tail)
             hipLaunchKernelGGL(attn_bwd2_sum_kernel<2>, dim3((wkv.n_tail * 128 + 3) / 4), dim3(256), 0, s, a, k_blocks, wkv);
     }

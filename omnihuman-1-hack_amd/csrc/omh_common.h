@@ -40,12 +40,17 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
 }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
-// two fp32 -> packed bf16x2 with the gfx950 hardware convert (RNE, NaN-safe);
-// there is no builtin for v_cvt_pk_bf16_f32, hence the one-line asm.
+// two fp32 -> packed bf16x2 with the gfx950 hardware convert v_cvt_pk_bf16_f32 (RNE, NaN-safe), through the vector
+// conversion the compiler selects it for.  Rounds 1-4 had a one-line asm here; inline asm is opaque to the compiler's
+// hazard recognizer, and on gfx950 a VALU instruction that reads the result of a transcendental one (v_exp_f32,
+// v_rcp_f32, ...) in the very next issue slot gets the OLD register contents ("trans forwarding" hazard, 1 wait
+// state).  Round 5's attention backward put exp2 -> pack back to back and produced garbage in dV; the conversion below
+// lets the compiler insert the s_nop where needed (and schedule the convert like any other VALU instruction).
+typedef float omh_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 omh_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    const omh_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, omh_bf16x2));
 }
 // raw v_exp_f32 (2^x): no denormal fix-up sequence; inputs here are <= 0 and
 // results below 2^-126 may flush to zero, which is what a softmax wants.
