@@ -37,7 +37,8 @@ def _hipcc():
 def _generate():
     """Generated instruction streams: csrc/gen_*.py -> csrc/*_asm.inc (rewritten only when the text changes)."""
     for gname, oname in (("gen_attn_w64.py", "attention_w64_asm.inc"), ("gen_gemm_w64.py", "gemm_w64_asm.inc"),
-                         ("gen_conv_w64.py", "conv_w64_asm.inc"), ("gen_gemm_tn_w64.py", "gemm_tn_w64_asm.inc")):
+                         ("gen_conv_w64.py", "conv_w64_asm.inc"), ("gen_gemm_tn_w64.py", "gemm_tn_w64_asm.inc"),
+                         ("gen_attn_bwd_w64.py", "attention_bwd2_asm.inc")):
         gen, out = os.path.join(CSRC, gname), os.path.join(CSRC, oname)
         if os.path.exists(gen):
             txt = subprocess.run([sys.executable, gen], check=True, capture_output=True, text=True).stdout

@@ -23,6 +23,7 @@
 //     different values (conflict-free ds_read_b128 of 16 rows at one column) and 4 consecutive rows differ in bits
 //     2..3 (conflict-free transposing reads of 4 rows x 64 bytes).
 #include "omh_common.h"
+#include "attention_bwd2_asm.inc"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -336,6 +337,57 @@ void attn_bwd2_dq_kernel(const omh_attn_bwd_args p, const int q_blocks, const Bw
     }
 }
 
+// dK (x ds_scale) and dV of one key (= one lane; `row` = the key's index in its 128-key block) -> bf16 / fp32 rows, or
+// the fp32 slab of a split worker; keys past klen get zeros whatever the loop left in their column
+__device__ __forceinline__ void dkdv_store(const omh_attn_bwd_args& p, const BwdSplit& wk, bool worker, int wid, int split, int b,
+                                           int head, int row, int lh, int key, int klen, float ds_scale, f32x16* dk, f32x16* dv) {
+    const bool key_in = key < klen;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dk[db][r] = key_in ? dk[db][r] * ds_scale : 0.f;          // (a select: the column may hold NaN)
+            dv[db][r] = key_in ? dv[db][r] : 0.f;
+        }
+    if (worker) {                                                    // partial sums over this worker's queries
+        float* W = wk.ws + ((((int64_t)(wid - wk.n_regular) * wk.splits + split) * 2) * 128 + row) * D;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = db * 32 + g * 8 + lh * 4;
+                *(float4*)(W + d0) = make_float4(dk[db][4 * g], dk[db][4 * g + 1], dk[db][4 * g + 2], dk[db][4 * g + 3]);
+                *(float4*)(W + 128 * D + d0) = make_float4(dv[db][4 * g], dv[db][4 * g + 1], dv[db][4 * g + 2], dv[db][4 * g + 3]);
+            }
+        return;
+    }
+    if (key >= p.Lk) return;
+    const int64_t eo = (int64_t)b * p.dk_bs + (int64_t)key * p.dk_rs + head * D;
+    if (p.out_bf16) {
+        uint16_t* DK = (uint16_t*)p.dk + eo;
+        uint16_t* DV = (uint16_t*)p.dv + eo;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = db * 32 + g * 8 + lh * 4;
+                *(uint2*)(DK + d0) = make_uint2(pack_bf2(dk[db][4 * g], dk[db][4 * g + 1]), pack_bf2(dk[db][4 * g + 2], dk[db][4 * g + 3]));
+                *(uint2*)(DV + d0) = make_uint2(pack_bf2(dv[db][4 * g], dv[db][4 * g + 1]), pack_bf2(dv[db][4 * g + 2], dv[db][4 * g + 3]));
+            }
+    } else {
+        float* DK = (float*)p.dk + eo;
+        float* DV = (float*)p.dv + eo;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = db * 32 + g * 8 + lh * 4;
+                *(float4*)(DK + d0) = make_float4(dk[db][4 * g], dk[db][4 * g + 1], dk[db][4 * g + 2], dk[db][4 * g + 3]);
+                *(float4*)(DV + d0) = make_float4(dv[db][4 * g], dv[db][4 * g + 1], dv[db][4 * g + 2], dv[db][4 * g + 3]);
+            }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- dK, dV
 // WAVES x KPW = 4 x 1: 4 waves of 32 keys.  The kernel is bound by the LDS pipe (1.5 LDS instructions per MFMA: each
 // of the 4 waves re-reads the whole shared Q / dO tile for its 32 keys).  The template also expresses 2 waves of 64
@@ -532,54 +584,105 @@ void attn_bwd2_dkdv_kernel(const omh_attn_bwd_args p, const int k_blocks, const 
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 #pragma unroll
-    for (int c = 0; c < KPW; ++c) {
-        const int key = key0 + 32 * c;
-        const bool key_in = key < klen;                              // keys past klen: zeros, whatever the loop left there
+    for (int c = 0; c < KPW; ++c)
+        dkdv_store(p, wk, worker, wid, split, b, head, wave * (32 * KPW) + 32 * c + li, lh, key0 + 32 * c, klen, ds_scale, dk[c], dv[c]);
+}
+
+// ---------------------------------------------------------------------------------------------- dK, dV: the stream
+// The same work decomposition, tiles, LDS layout and arithmetic as attn_bwd2_dkdv_kernel<4, 1>, with the loop written
+// out instruction by instruction (gen_attn_bwd_w64.py -> attention_bwd2_asm.inc; that file's header has the schedule
+// and the register map).  This function computes addresses and descriptors, hands them to the stream, takes the
+// accumulators back through LDS and stores them like the HIP kernel does.
+template <bool PRE>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void attn_bwd2_dkdv_w64_kernel(const omh_attn_bwd_args p, const int k_blocks, const BwdSplit wk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // 4 x [Q tile | dO tile] + statistics
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool worker = (int)blockIdx.x >= wk.n_regular;
+    const int wid = worker ? wk.n_regular + ((int)blockIdx.x - wk.n_regular) / wk.splits : xcd_remap((int)blockIdx.x, wk.n_regular);
+    const int split = worker ? ((int)blockIdx.x - wk.n_regular) % wk.splits : 0;
+    const int kb = wid % k_blocks, bh = wid / k_blocks;
+    const int b = bh / p.H, head = bh % p.H;
+    int klen = p.k_lens ? p.k_lens[b] : p.Lk;
+    klen = min(max(klen, 0), p.Lk);
+    const int n_tiles_all = (p.Lq + TB - 1) / TB;
+    int t_first = 0, n_tiles = n_tiles_all;
+    if (worker) {
+        const int per = (n_tiles_all + wk.splits - 1) / wk.splits;
+        t_first = min(split * per, n_tiles_all);
+        n_tiles = min(t_first + per, n_tiles_all) - t_first;
+    }
+    const int key = kb * 128 + wave * 32 + li;
+    f32x16 dv[1][4], dk[1][4];
+    if (n_tiles > 0) {
+        const uint16_t* Q = (const uint16_t*)p.q + (int64_t)b * p.q_bs + head * D;
+        const uint16_t* DO = (const uint16_t*)p.dout + (int64_t)b * p.o_bs + head * D;
+        const uint16_t* K = (const uint16_t*)p.k + (int64_t)b * p.k_bs + head * D;
+        const uint16_t* V = (const uint16_t*)p.v + (int64_t)b * p.k_bs + head * D;
+        const float* LSE = p.lse + ((int64_t)b * p.H + head) * p.Lq;
+        const float* DEL = p.delta + ((int64_t)b * p.H + head) * p.Lq;
+        auto rsrc = [](const void* base, int64_t bytes) {
+            const uint64_t a = (uint64_t)base;
+            return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, (uint32_t)bytes, 0x00020000u};
+        };
+        // rows past the end read as zeros (the range check covers voffset + soffset + immediate)
+        const u32x4 rq = rsrc(Q, (((int64_t)p.Lq - 1) * p.q_rs + D) * 2), rdo = rsrc(DO, (((int64_t)p.Lq - 1) * p.o_rs + D) * 2);
+        const u32x4 rk = rsrc(K, (((int64_t)p.Lk - 1) * p.k_rs + D) * 2), rv = rsrc(V, (((int64_t)p.Lk - 1) * p.k_rs + D) * 2);
+        const u32x4 rlse = rsrc(LSE, (int64_t)p.Lq * 4), rdel = rsrc(DEL, (int64_t)p.Lq * 4);
+        const uint32_t lds0 = lds_addr(smem);
+        // LDS-DMA sources: chunk c = tid (+ 256 j: 16 rows further, same swizzle) -> row tid >> 4, logical slot (tid & 15) ^ swz(row)
+        const int drow = tid >> 4;
+        uint32_t vodq = (uint32_t)((drow * (int)p.q_rs + (((tid & 15) ^ (int)swz(drow)) << 3)) * 2);
+        uint32_t vodo = (uint32_t)((drow * (int)p.o_rs + (((tid & 15) ^ (int)swz(drow)) << 3)) * 2);
+        uint32_t vokv = key < p.Lk ? (uint32_t)(((int64_t)key * p.k_rs + lh * 8) * 2) : 0x80000000u;   // out of range: zeros
+        // fragment addresses (frag_addr): row fragments r0 = swap_bits23(li), slot (2 kk + lh) ^ swz(r0); transposed ones
+        const int r0 = swap_bits23(li), z0 = (int)swz(r0);
+        uint32_t kab = lds0 + (uint32_t)(r0 * 256 + ((lh ^ (z0 & 1)) << 4)), xh = (uint32_t)(z0 >> 1);
+        const int gq = lane >> 4, i15 = lane & 15, fe = i15 >> 2, fq = i15 & 3;
+        const int rlo = 8 * (gq >> 1) + fe, z1 = (int)swz(rlo), low2 = 2 * (gq & 1) + (fq >> 1);
+        uint32_t tab = lds0 + (uint32_t)(rlo * 256 + ((low2 ^ (z1 & 3)) << 4) + (fq & 1) * 8), th = (uint32_t)(z1 >> 2);
+        uint32_t vstr = lds0 + OMH_ATTN_BWD_W64_STAT_FIN + (uint32_t)(8 * lh * 4);
+        uint32_t vraw = lds0 + OMH_ATTN_BWD_W64_STAT_RAW + (uint32_t)(lane * 4);
+        uint32_t vost = (uint32_t)(lane * 4);
+        uint32_t vdump = lds0 + (uint32_t)(wave * OMH_ATTN_BWD_W64_SLOT + lane * 16);
+        // wave-uniform scalars
+        const uint32_t ldsw = lds0 + (uint32_t)wave * 1024u, sraw = lds0 + OMH_ATTN_BWD_W64_STAT_RAW;
+        const uint32_t sqp = (uint32_t)(16 * (int)p.q_rs * 2), sop = (uint32_t)(16 * (int)p.o_rs * 2);
+        uint32_t sqn = (uint32_t)t_first * 4u * sqp, son = (uint32_t)t_first * 4u * sop, sstn = (uint32_t)t_first * 256u;
+        const uint32_t ntiles = (uint32_t)n_tiles;
+        const uint32_t k1 = __builtin_amdgcn_readfirstlane(__float_as_uint(PRE ? -LOG2E : -1.0f / p.scale));
+        const uint32_t sc = __builtin_amdgcn_readfirstlane(__float_as_uint(PRE ? 1.0f : p.scale * LOG2E));
+#define OMH_BWD_W64_OPERANDS                                                                                          \
+                 : [sqn] "+s"(sqn), [son] "+s"(son), [sstn] "+s"(sstn), [vodq] "+v"(vodq), [vodo] "+v"(vodo),         \
+                   [vokv] "+v"(vokv), [kab] "+v"(kab), [xh] "+v"(xh), [tab] "+v"(tab), [th] "+v"(th), [vstr] "+v"(vstr),\
+                   [vraw] "+v"(vraw), [vost] "+v"(vost), [vdump] "+v"(vdump)                                          \
+                 : [rq] "s"(rq), [rdo] "s"(rdo), [rk] "s"(rk), [rv] "s"(rv), [rlse] "s"(rlse), [rdel] "s"(rdel),      \
+                   [sqp] "s"(sqp), [sop] "s"(sop), [ldsw] "s"(ldsw), [sraw] "s"(sraw), [ntiles] "s"(ntiles),          \
+                   [k1] "s"(k1), [sc] "s"(sc)                                                                         \
+                 : OMH_ATTN_BWD_W64_CLOBBERS
+        if constexpr (PRE) asm volatile(OMH_ATTN_BWD_W64_ASM_PRE OMH_BWD_W64_OPERANDS);
+        else asm volatile(OMH_ATTN_BWD_W64_ASM_GEN OMH_BWD_W64_OPERANDS);
+        // the accumulators, parked by the stream in this wave's 32 KiB of the ring: block (x, g) = registers 4g .. 4g+3 of
+        // accumulator x (0..3 dV, 4..7 dK), 16 bytes per lane
+        const unsigned char* park = smem + wave * OMH_ATTN_BWD_W64_SLOT + lane * 16;
 #pragma unroll
         for (int db = 0; db < 4; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                dk[c][db][r] = key_in ? dk[c][db][r] * ds_scale : 0.f;   // (a select: the column may hold NaN)
-                dv[c][db][r] = key_in ? dv[c][db][r] : 0.f;
+            for (int g = 0; g < 4; ++g) {
+                const float4 a = *(const float4*)(park + (db * 4 + g) * 1024);
+                const float4 c = *(const float4*)(park + ((4 + db) * 4 + g) * 1024);
+                dv[0][db][4 * g] = a.x; dv[0][db][4 * g + 1] = a.y; dv[0][db][4 * g + 2] = a.z; dv[0][db][4 * g + 3] = a.w;
+                dk[0][db][4 * g] = c.x; dk[0][db][4 * g + 1] = c.y; dk[0][db][4 * g + 2] = c.z; dk[0][db][4 * g + 3] = c.w;
             }
-        if (worker) {                                                // partial sums over this worker's queries
-            float* W = wk.ws + ((((int64_t)(wid - wk.n_regular) * wk.splits + split) * 2) * 128 + wave * (32 * KPW) + 32 * c + li) * D;
+    } else {
 #pragma unroll
-            for (int db = 0; db < 4; ++db)
+        for (int db = 0; db < 4; ++db)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int d0 = db * 32 + g * 8 + lh * 4;
-                    *(float4*)(W + d0) = make_float4(dk[c][db][4 * g], dk[c][db][4 * g + 1], dk[c][db][4 * g + 2], dk[c][db][4 * g + 3]);
-                    *(float4*)(W + 128 * D + d0) = make_float4(dv[c][db][4 * g], dv[c][db][4 * g + 1], dv[c][db][4 * g + 2], dv[c][db][4 * g + 3]);
-                }
-            continue;
-        }
-        if (key >= p.Lk) continue;
-        const int64_t eo = (int64_t)b * p.dk_bs + (int64_t)key * p.dk_rs + head * D;
-        if (p.out_bf16) {
-            uint16_t* DK = (uint16_t*)p.dk + eo;
-            uint16_t* DV = (uint16_t*)p.dv + eo;
-#pragma unroll
-            for (int db = 0; db < 4; ++db)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int d0 = db * 32 + g * 8 + lh * 4;
-                    *(uint2*)(DK + d0) = make_uint2(pack_bf2(dk[c][db][4 * g], dk[c][db][4 * g + 1]), pack_bf2(dk[c][db][4 * g + 2], dk[c][db][4 * g + 3]));
-                    *(uint2*)(DV + d0) = make_uint2(pack_bf2(dv[c][db][4 * g], dv[c][db][4 * g + 1]), pack_bf2(dv[c][db][4 * g + 2], dv[c][db][4 * g + 3]));
-                }
-        } else {
-            float* DK = (float*)p.dk + eo;
-            float* DV = (float*)p.dv + eo;
-#pragma unroll
-            for (int db = 0; db < 4; ++db)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int d0 = db * 32 + g * 8 + lh * 4;
-                    *(float4*)(DK + d0) = make_float4(dk[c][db][4 * g], dk[c][db][4 * g + 1], dk[c][db][4 * g + 2], dk[c][db][4 * g + 3]);
-                    *(float4*)(DV + d0) = make_float4(dv[c][db][4 * g], dv[c][db][4 * g + 1], dv[c][db][4 * g + 2], dv[c][db][4 * g + 3]);
-                }
-        }
+            for (int r = 0; r < 16; ++r) { dv[0][db][r] = 0.f; dk[0][db][r] = 0.f; }
     }
+    const float ds_scale = PRE ? (1.0f / LOG2E) : p.scale;
+    dkdv_store(p, wk, worker, wid, split, b, head, wave * 32 + li, lh, key, klen, ds_scale, dk[0], dv[0]);
 }
 
 // out[row] = sum_s slab_s[row] in the order of s (fixed: repeatable bit for bit).  One wave per (tail tile, row);
@@ -640,8 +743,9 @@ extern "C" int64_t omh_flash_attn_bwd_workspace_bytes(const omh_attn_bwd_args* a
 // called by omh_flash_attn_bwd_d128 (attention_bwd.hip) when args->o32 is set; arguments already validated there
 int omh_launch_attn_bwd2(const omh_attn_bwd_args& a, hipStream_t s) {
     // 32-bit buffer offsets inside one (batch, head) slice
-    if ((int64_t)a.Lq * a.q_rs * 2 >= 0x7fffffffLL || (int64_t)a.Lk * a.k_rs * 2 >= 0x7fffffffLL ||
-        (int64_t)a.Lq * a.o_rs * 2 >= 0x7fffffffLL)
+    // (+ 4 tiles: the dK / dV stream requests up to three tiles past the end, which must stay out of range, not wrap)
+    if (((int64_t)a.Lq + 4 * TB) * a.q_rs * 2 >= 0x7fffffffLL || (int64_t)a.Lk * a.k_rs * 2 >= 0x7fffffffLL ||
+        ((int64_t)a.Lq + 4 * TB) * a.o_rs * 2 >= 0x7fffffffLL)
         return OMH_E_SHAPE;
     if (((uintptr_t)a.o32 & 15) || (a.o_rs & 3) || (a.o_bs & 3)) return OMH_E_ALIGN;
     constexpr int LDS_DQ = 4 * TILE_BYTES, LDS_KV = 4 * TILE_BYTES + 2 * 128 * 4;
@@ -651,6 +755,8 @@ int omh_launch_attn_bwd2(const omh_attn_bwd_args& a, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)attn_bwd2_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
         (void)hipFuncSetAttribute((const void*)attn_bwd2_dkdv_kernel<4, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV);
         (void)hipFuncSetAttribute((const void*)attn_bwd2_dkdv_kernel<4, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV);
+        (void)hipFuncSetAttribute((const void*)attn_bwd2_dkdv_w64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, OMH_ATTN_BWD_W64_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_bwd2_dkdv_w64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, OMH_ATTN_BWD_W64_LDS);
         attr_set = true;
     }
     const int k_blocks = (a.Lk + 127) / 128, q_blocks = (a.Lq + 127) / 128;
@@ -680,7 +786,11 @@ int omh_launch_attn_bwd2(const omh_attn_bwd_args& a, hipStream_t s) {
     }
     if (run_k) {                                                                                               // reads delta
         const dim3 grid(wkv.n_regular + wkv.n_tail * wkv.splits);
-        if (a.q_prescaled) hipLaunchKernelGGL((attn_bwd2_dkdv_kernel<4, 1, true>), grid, dim3(256), LDS_KV, s, a, k_blocks, wkv);
+        const char* e = omh_opt(OMH_OPT_ATTN_BWD_W64);                // "0": the HIP kernel (A/B timing, tests)
+        if (!(e && e[0] == '0')) {
+            if (a.q_prescaled) hipLaunchKernelGGL(attn_bwd2_dkdv_w64_kernel<true>, grid, dim3(256), OMH_ATTN_BWD_W64_LDS, s, a, k_blocks, wkv);
+            else hipLaunchKernelGGL(attn_bwd2_dkdv_w64_kernel<false>, grid, dim3(256), OMH_ATTN_BWD_W64_LDS, s, a, k_blocks, wkv);
+        } else if (a.q_prescaled) hipLaunchKernelGGL((attn_bwd2_dkdv_kernel<4, 1, true>), grid, dim3(256), LDS_KV, s, a, k_blocks, wkv);
         else hipLaunchKernelGGL((attn_bwd2_dkdv_kernel<4, 1, false>), grid, dim3(256), LDS_KV, s, a, k_blocks, wkv);
         if (wkv.n_tail)
             hipLaunchKernelGGL(attn_bwd2_sum_kernel<2>, dim3((wkv.n_tail * 128 + 3) / 4), dim3(256), 0, s, a, k_blocks, wkv);
