@@ -613,9 +613,8 @@ void attn_bwd2_dkdv_w64_kernel(const omh_attn_bwd_args p, const int k_blocks, co
         t_first = min(split * per, n_tiles_all);
         n_tiles = min(t_first + per, n_tiles_all) - t_first;
     }
-    const int key = kb * 128 + wave * 32 + li;
-    f32x16 dv[1][4], dk[1][4];
     if (n_tiles > 0) {
+        const int key = kb * 128 + wave * 32 + li;
         const uint16_t* Q = (const uint16_t*)p.q + (int64_t)b * p.q_bs + head * D;
         const uint16_t* DO = (const uint16_t*)p.dout + (int64_t)b * p.o_bs + head * D;
         const uint16_t* K = (const uint16_t*)p.k + (int64_t)b * p.k_bs + head * D;
@@ -624,8 +623,11 @@ void attn_bwd2_dkdv_w64_kernel(const omh_attn_bwd_args p, const int k_blocks, co
         const float* DEL = p.delta + ((int64_t)b * p.H + head) * p.Lq;
         auto rsrc = [](const void* base, int64_t bytes) {
             const uint64_t a = (uint64_t)base;
-            return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, (uint32_t)bytes, 0x00020000u};
+            return u32x4{(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a),
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xffffu)),
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bytes), 0x00020000u};
         };
+        auto uni = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };   // (all of these are wave-uniform)
         // rows past the end read as zeros (the range check covers voffset + soffset + immediate)
         const u32x4 rq = rsrc(Q, (((int64_t)p.Lq - 1) * p.q_rs + D) * 2), rdo = rsrc(DO, (((int64_t)p.Lq - 1) * p.o_rs + D) * 2);
         const u32x4 rk = rsrc(K, (((int64_t)p.Lk - 1) * p.k_rs + D) * 2), rv = rsrc(V, (((int64_t)p.Lk - 1) * p.k_rs + D) * 2);
@@ -645,12 +647,12 @@ void attn_bwd2_dkdv_w64_kernel(const omh_attn_bwd_args p, const int k_blocks, co
         uint32_t vstr = lds0 + OMH_ATTN_BWD_W64_STAT_FIN + (uint32_t)(8 * lh * 4);
         uint32_t vraw = lds0 + OMH_ATTN_BWD_W64_STAT_RAW + (uint32_t)(lane * 4);
         uint32_t vost = (uint32_t)(lane * 4);
-        uint32_t vdump = lds0 + (uint32_t)(wave * OMH_ATTN_BWD_W64_SLOT + lane * 16);
+        uint32_t vdump = lds0 + (uint32_t)(wave * OMH_ATTN_BWD_W64_PARK_WAVE + lane * 16);
         // wave-uniform scalars
-        const uint32_t ldsw = lds0 + (uint32_t)wave * 1024u, sraw = lds0 + OMH_ATTN_BWD_W64_STAT_RAW;
-        const uint32_t sqp = (uint32_t)(16 * (int)p.q_rs * 2), sop = (uint32_t)(16 * (int)p.o_rs * 2);
-        uint32_t sqn = (uint32_t)t_first * 4u * sqp, son = (uint32_t)t_first * 4u * sop, sstn = (uint32_t)t_first * 256u;
-        const uint32_t ntiles = (uint32_t)n_tiles;
+        const uint32_t ldsw = uni(lds0 + (uint32_t)wave * 1024u), sraw = uni(lds0 + OMH_ATTN_BWD_W64_STAT_RAW);
+        const uint32_t sqp = uni((uint32_t)(16 * (int)p.q_rs * 2)), sop = uni((uint32_t)(16 * (int)p.o_rs * 2));
+        uint32_t sqn = uni((uint32_t)t_first * 4u * sqp), son = uni((uint32_t)t_first * 4u * sop), sstn = uni((uint32_t)t_first * 256u);
+        const uint32_t ntiles = uni((uint32_t)n_tiles);
         const uint32_t k1 = __builtin_amdgcn_readfirstlane(__float_as_uint(PRE ? -LOG2E : -1.0f / p.scale));
         const uint32_t sc = __builtin_amdgcn_readfirstlane(__float_as_uint(PRE ? 1.0f : p.scale * LOG2E));
 #define OMH_BWD_W64_OPERANDS                                                                                          \
@@ -663,26 +665,55 @@ void attn_bwd2_dkdv_w64_kernel(const omh_attn_bwd_args p, const int k_blocks, co
                  : OMH_ATTN_BWD_W64_CLOBBERS
         if constexpr (PRE) asm volatile(OMH_ATTN_BWD_W64_ASM_PRE OMH_BWD_W64_OPERANDS);
         else asm volatile(OMH_ATTN_BWD_W64_ASM_GEN OMH_BWD_W64_OPERANDS);
-        // the accumulators, parked by the stream in this wave's 32 KiB of the ring: block (x, g) = registers 4g .. 4g+3 of
-        // accumulator x (0..3 dV, 4..7 dK), 16 bytes per lane
-        const unsigned char* park = smem + wave * OMH_ATTN_BWD_W64_SLOT + lane * 16;
+    }
+    // The accumulators come back through LDS: the stream parked them in this wave's part of the ring, block (x, g) =
+    // registers 4g .. 4g+3 of accumulator x (0..3 dV, 4..7 dK) as 16 bytes per lane (lane = key li + 32 lh; the registers are
+    // d = 32 db + 8 g + 4 lh + 0..3).  They are read back ROW-major — 16 lanes per key for bf16 rows (256 bytes), 32 for
+    // fp32 — so that a store instruction writes whole rows instead of 64 pieces of 8 bytes in 64 rows (that epilogue cost
+    // 18 of the kernel's 147 us at 4 clips).
+    const unsigned char* park = smem + wave * OMH_ATTN_BWD_W64_PARK_WAVE;
+    const float ds_scale = PRE ? (1.0f / LOG2E) : p.scale;
+    const bool have = n_tiles > 0;
+    auto take = [&](int x, int db, int g, int src_lane) {              // x: 0 dV, 1 dK
+        return have ? *(const float4*)(park + ((x * 4 + db) * 4 + g) * OMH_ATTN_BWD_W64_PARK_BLOCK + src_lane * 16)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    if (!worker && p.out_bf16) {
+        const int c = lane & 15, db = c >> 2, g = c & 3;
 #pragma unroll
-        for (int db = 0; db < 4; ++db)
+        for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 a = *(const float4*)(park + (db * 4 + g) * 1024);
-                const float4 c = *(const float4*)(park + ((4 + db) * 4 + g) * 1024);
-                dv[0][db][4 * g] = a.x; dv[0][db][4 * g + 1] = a.y; dv[0][db][4 * g + 2] = a.z; dv[0][db][4 * g + 3] = a.w;
-                dk[0][db][4 * g] = c.x; dk[0][db][4 * g + 1] = c.y; dk[0][db][4 * g + 2] = c.z; dk[0][db][4 * g + 3] = c.w;
+            for (int it = 0; it < 8; ++it) {
+                const int row = 4 * it + (lane >> 4), key = kb * 128 + wave * 32 + row;
+                float4 lo = take(x, db, g, row), hi = take(x, db, g, 32 + row);
+                const float f = x == 1 ? ds_scale : 1.0f;
+                const bool in = key < klen;                           // (a select: the column may hold NaN)
+                lo = in ? make_float4(lo.x * f, lo.y * f, lo.z * f, lo.w * f) : make_float4(0.f, 0.f, 0.f, 0.f);
+                hi = in ? make_float4(hi.x * f, hi.y * f, hi.z * f, hi.w * f) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (key < p.Lk) {
+                    uint16_t* dst = (uint16_t*)(x == 1 ? p.dk : p.dv) + (int64_t)b * p.dk_bs + (int64_t)key * p.dk_rs + head * D + c * 8;
+                    *(uint4*)dst = make_uint4(pack_bf2(lo.x, lo.y), pack_bf2(lo.z, lo.w), pack_bf2(hi.x, hi.y), pack_bf2(hi.z, hi.w));
+                }
             }
     } else {
+        const int c4 = lane & 31, db = c4 >> 3, g = (c4 >> 1) & 3, half = c4 & 1;
 #pragma unroll
-        for (int db = 0; db < 4; ++db)
+        for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { dv[0][db][r] = 0.f; dk[0][db][r] = 0.f; }
+            for (int it = 0; it < 16; ++it) {
+                const int row = 2 * it + (lane >> 5), key = kb * 128 + wave * 32 + row;
+                float4 v = take(x, db, g, half * 32 + row);
+                const float f = x == 1 ? ds_scale : 1.0f;
+                v = key < klen ? make_float4(v.x * f, v.y * f, v.z * f, v.w * f) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (worker) {                                        // partial sums over this worker's queries: [dK | dV] slabs
+                    float* W = wk.ws + ((((int64_t)(wid - wk.n_regular) * wk.splits + split) * 2 + (x == 1 ? 0 : 1)) * 128 + wave * 32 + row) * D;
+                    *(float4*)(W + c4 * 4) = v;
+                } else if (key < p.Lk) {
+                    float* dst = (float*)(x == 1 ? p.dk : p.dv) + (int64_t)b * p.dk_bs + (int64_t)key * p.dk_rs + head * D + c4 * 4;
+                    *(float4*)dst = v;
+                }
+            }
     }
-    const float ds_scale = PRE ? (1.0f / LOG2E) : p.scale;
-    dkdv_store(p, wk, worker, wid, split, b, head, wave * 32 + li, lh, key, klen, ds_scale, dk[0], dv[0]);
 }
 
 // out[row] = sum_s slab_s[row] in the order of s (fixed: repeatable bit for bit).  One wave per (tail tile, row);

@@ -45,6 +45,9 @@ NSLOT = 4
 STAT_RAW = NSLOT * SLOT           # raw statistics: 4 slots x [lse 64 | delta 64] fp32
 STAT_FIN = STAT_RAW + NSLOT * 512 # fixed-up statistics, same shape
 LDS_BYTES = STAT_FIN + NSLOT * 512
+PARK_BLOCK = 1040                 # the epilogue parks 4 accumulator registers x 64 lanes per block; 16 bytes of padding: the
+PARK_WAVE = 32 * PARK_BLOCK       # row-major read-back (16 lanes = 16 blocks of one row) then hits 64 different banks
+ABL = os.environ.get("OMH_BWD_ABL", "").split(",")     # timing-only ablations (wrong numerics by construction; never shipped)
 LEAD_A, LEAD_C = 12, 6            # a fragment is requested this many MFMAs ahead (stage A: one read each; C: two) — the
                                   # LDS counter holds 15 outstanding operations
 
@@ -109,21 +112,23 @@ def mfma_of(i):
         hb, kk = i // 16, (i % 16) // 2
         acc = vr((S(hb) if w == 0 else DP(hb)), 16)
         b = ar((KF(kk) if w == 0 else VF(kk)), 4)
-        needs = [f"F{i}"]
-        if kk == 0:
+        needs = [] if "norow" in ABL else [f"F{i}"]
+        if kk == 0 and "nostat" not in ABL:
             needs += [f"ST{hb}.{w}.{g}" for g in range(4)]
         return f"v_mfma_f32_32x32x16_bf16 {acc}, {frag}, {b}, {acc}", needs
     j = i - 32
     hb, a, db = j // 16, (j % 16) // 8, (j % 8) // 2
     acc = ar((DV(db) if w == 0 else DK(db)), 16)
     b = vr(PK(hb, w, a), 4)
-    return f"v_mfma_f32_32x32x16_bf16 {acc}, {frag}, {b}, {acc}", [f"F{i}a", f"F{i}b"]
+    return f"v_mfma_f32_32x32x16_bf16 {acc}, {frag}, {b}, {acc}", ([] if "notr" in ABL else [f"F{i}a", f"F{i}b"])
 
 
 def frag_reads(i, prep):
     """The LDS reads that feed MFMA i (issued PF pairs earlier)."""
     pr, w = i // 2, i % 2
     st = pr % 8
+    if ("norow" in ABL and i < 32) or ("notr" in ABL and i >= 32):
+        return []
     if i < 32:
         hb, kk = i // 16, (i % 16) // 2
         off = hb * 8192 + (16384 if w == 1 else 0)              # S: Q rows;  dP: dO rows
@@ -209,11 +214,14 @@ def tile_ops(pre):
     for tgt in range(64):                                            # ring stage re-use: the previous user (pair - 8) has been issued
         lead = LEAD_A if tgt < 32 else LEAD_C
         assert 2 * (tgt // 2 - 8) + 1 <= tgt - lead, tgt
-    # stage B
-    for g, lst in enumerate(spread(stage_b(0, pre), 64, 18, 32)):
-        gaps[g] += lst
-    for g, lst in enumerate(spread(stage_b(1, pre), 64, 34, 48)):
-        gaps[g] += lst
+    # stage B, half of it at a time: pairs 0..3 make the a = 0 operands (first read by the 1st MFMA of stage C), pairs 4..7
+    # the a = 1 operands (first read by the 9th) — spread as widely as those deadlines allow: ~2 VALU per gap
+    b0, b1 = stage_b(0, pre), stage_b(1, pre)
+    if "nob" in ABL:
+        b0, b1 = [], []
+    for lst, lo, hi in ((b0[:len(b0) // 2], 17, 30), (b0[len(b0) // 2:], 30, 38), (b1[:len(b1) // 2], 34, 46), (b1[len(b1) // 2:], 46, 54)):
+        for g, ops_ in enumerate(spread(lst, 64, lo, hi)):
+            gaps[g] += ops_
     # address groups: row addresses -> next slot once the last row read of this tile is out (gap 19), the transposed
     # ones after gap 51, the statistics ones right before their use
     # (the four scalar instructions of an advance stay together: s_cmp -> s_cselect must not see a foreign SCC write)
@@ -230,16 +238,21 @@ def tile_ops(pre):
     # done with tile t-1, whose slot the loads of tile t+3 now overwrite
     gaps[47] += [op("x", "s_waitcnt vmcnt(10)"), op("x", "s_barrier")]
     gaps[48] += [op("x", ln) for ln in advance(S_DMA, S_OFF, C_STEP, C_WRAP, NSLOT * SLOT)[:2] + [f"s_cselect_b32 {S_DMA}, 0, {S_DMA}"]]
-    for g, lst in enumerate(spread([op("x", ln) for ln in dma_group(S_DMA)], 64, 48, 60)):
+    for g, lst in enumerate(spread([op("x", ln) for ln in dma_group(S_DMA) if not ("nodma" in ABL and ln.startswith("buffer_load"))], 64, 48, 60)):
         gaps[g] += lst
+    if "nodma" in ABL:
+        gaps[47][-2] = op("x", "s_nop 0")
+    if "nobar" in ABL:
+        gaps[47][-1] = op("x", "s_nop 0")
     # statistics of tile t+1
-    fix = stat_fixup()
-    gaps[48] += fix[:2]
-    gaps[50] += fix[2:]
-    gaps[52] += stat_reads(0)[:4]
-    gaps[53] += stat_reads(0)[4:]
-    gaps[56] += stat_reads(1)[:4]
-    gaps[57] += stat_reads(1)[4:]
+    if "nostat" not in ABL:
+        fix = stat_fixup()
+        gaps[48] += fix[:2]
+        gaps[50] += fix[2:]
+        gaps[52] += stat_reads(0)[:4]
+        gaps[53] += stat_reads(0)[4:]
+        gaps[56] += stat_reads(1)[:4]
+        gaps[57] += stat_reads(1)[4:]
     return gaps
 
 
@@ -292,7 +305,7 @@ def generate(pre):
     # what is still outstanding where the loop closes (the last MFMAs' waits retired everything older): enter the same way
     loop_pending = linearize(Emit("dry"), ops, full)
     assert full[len(full) - len(loop_pending):] == loop_pending, (full, loop_pending)
-    e(f"s_waitcnt lgkmcnt({len(loop_pending)})")
+    e(f"s_waitcnt lgkmcnt({min(len(loop_pending), 15)})")
     # ---------------- the loop: one tile per iteration
     LOOP = e.lab("loop")
     e.label(LOOP)
@@ -301,14 +314,14 @@ def generate(pre):
     e(f"s_sub_u32 {S_CNT}, {S_CNT}, 1")
     e(f"s_cmp_lg_u32 {S_CNT}, 0")
     e(f"s_cbranch_scc1 {LOOP}")
-    # ---------------- epilogue: accumulators -> this wave's 32 KiB of the (now idle) ring; the HIP code takes them from there
+    # ---------------- epilogue: accumulators -> this wave's part of the (now idle) ring; the HIP code takes them from there
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
     e("s_barrier")
     e("s_nop 7")
     e("s_nop 7")
     for x in range(8):
         for g in range(4):
-            e(f"ds_write_b128 %[vdump], {ar(x * 16 + 4 * g, 4)} offset:{(x * 4 + g) * 1024}")
+            e(f"ds_write_b128 %[vdump], {ar(x * 16 + 4 * g, 4)} offset:{(x * 4 + g) * PARK_BLOCK}")
     e("s_waitcnt lgkmcnt(0)")
     return e
 
@@ -331,6 +344,9 @@ def main():
     print(f"#define OMH_ATTN_BWD_W64_SLOT {SLOT}")
     print(f"#define OMH_ATTN_BWD_W64_STAT_RAW {STAT_RAW}")
     print(f"#define OMH_ATTN_BWD_W64_STAT_FIN {STAT_FIN}")
+    print(f"#define OMH_ATTN_BWD_W64_PARK_BLOCK {PARK_BLOCK}")
+    print(f"#define OMH_ATTN_BWD_W64_PARK_WAVE {PARK_WAVE}")
+    assert 4 * PARK_WAVE <= LDS_BYTES
     clob = ['"memory"', '"vcc"', '"scc"'] + [f'"s{i}"' for i in CLOBBER_S] + [f'"v{i}"' for i in CLOBBER_V] + \
            [f'"a{i}"' for i in CLOBBER_A]
     print("#define OMH_ATTN_BWD_W64_CLOBBERS \\")

@@ -584,6 +584,49 @@ def test_attention_tail_split_matches_the_unsplit_launch(ops, monkeypatch, B, H,
     assert torch.equal(od, o0) and torch.equal(lsed, lse0)               # 25 / 8 key tiles: the forward is not split
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,lens", [(2, 2, 200, 300, [300, 170]), (1, 2, 64, 40, None), (4, 12, 1560, 1560, None), (1, 12, 1560, 1560, None),
+                                            (2, 3, 700, 512, [512, 0]), (1, 1, 3000, 129, [129])])
+def test_attention_backward_dkdv_stream_equals_the_hip_kernel(ops, B, H, Lq, Lk, lens):
+    """The generated dK / dV instruction stream (gen_attn_bwd_w64.py, the default) performs the operations of
+    attn_bwd2_dkdv_kernel<4, 1> in the same order: the results are the same BITS — fp32 and bf16 outputs, plain and
+    pre-scaled q, key lengths (including 0: lse = -inf), the split workers of a launch that does not fill the chip, the
+    phases."""
+    D = 128
+    d = H * D
+    scale = D ** -0.5
+    g = torch.Generator(device="cuda").manual_seed(5)
+    k, v = [torch.randn(B * Lk, d, device="cuda", generator=g).bfloat16() for _ in range(2)]
+    q32 = torch.randn(B * Lq, d, device="cuda", generator=g)
+    do = torch.randn(B * Lq, d, device="cuda", generator=g).bfloat16()
+    klens = None if lens is None else torch.tensor(lens, dtype=torch.int32, device="cuda")
+    for pres in (False, True):
+        q = (q32 * (scale * 1.4426950408889634)).bfloat16() if pres else q32.bfloat16()
+        s = q.float().view(B, Lq, H, D).transpose(1, 2) @ k.float().view(B, Lk, H, D).transpose(1, 2).transpose(-1, -2)
+        s = s * (1 / 1.4426950408889634 if pres else scale)
+        if klens is not None:
+            s = s.masked_fill((torch.arange(Lk, device="cuda")[None, :] >= klens[:, None])[:, None, None, :], float("-inf"))
+        lse = torch.logsumexp(s, -1).contiguous()
+        o32 = (torch.nan_to_num(s.softmax(-1)) @ v.float().view(B, Lk, H, D).transpose(1, 2)).transpose(1, 2).reshape(B * Lq, d).contiguous()
+        res = {}
+        for opt in ("0", "1"):
+            set_option("OMH_ATTN_BWD_W64", opt)
+            kw = dict(q_prescaled=pres, o32=o32)
+            f32 = ops.flash_attn_bwd(q, k, v, None, do, lse, klens, B, H, Lq, Lk, scale, **kw)
+            nosplit = ops.flash_attn_bwd(q, k, v, None, do, lse, klens, B, H, Lq, Lk, scale, split=False, **kw)
+            kvb = torch.full((B * Lk, 2 * d), 3.0, device="cuda", dtype=torch.bfloat16)
+            dqb = torch.empty(B * Lq, d, device="cuda", dtype=torch.bfloat16)
+            ops.flash_attn_bwd(q, k, v, None, do, lse, klens, B, H, Lq, Lk, scale, out=(dqb, kvb[:, :d], kvb[:, d:]), **kw)
+            delta = torch.empty(B, H, Lq, device="cuda")
+            ops.flash_attn_bwd(q, k, v, None, do, lse, klens, B, H, Lq, Lk, scale, phase=1, delta=delta, **kw)
+            ph3 = ops.flash_attn_bwd(q, k, v, None, do, lse, klens, B, H, Lq, Lk, scale, phase=3, delta=delta, **kw)
+            res[opt] = (f32[1], f32[2], nosplit[1], nosplit[2], kvb, ph3[1], ph3[2])
+        set_option("OMH_ATTN_BWD_W64", None)
+        for a_, b_ in zip(res["0"], res["1"]):
+            assert bool(torch.isfinite(b_.float()).all()) and torch.equal(a_, b_), (pres, rel_rms(b_.float(), a_.float()))
+        assert torch.equal(res["1"][4], torch.cat([res["1"][0], res["1"][1]], 1).bfloat16())      # the bf16 rows = the fp32 rows, rounded
+        assert torch.equal(res["1"][5], res["1"][0]) and torch.equal(res["1"][6], res["1"][1])      # phase 3 alone
+
+
 @pytest.mark.parametrize("B,H,Lq,Lk,lens", [(2, 2, 200, 136, [136, 77]), (1, 3, 1560, 1560, [1560]), (3, 1, 130, 512, [512, 0, 300]),
                                             (2, 2, 64, 64, [64, 33]), (1, 1, 257, 70, [70])])
 def test_attention_backward_round3_kernels(ops, B, H, Lq, Lk, lens):
