@@ -716,6 +716,110 @@ void attn_bwd2_dkdv_w64_kernel(const omh_attn_bwd_args p, const int k_blocks, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------- dQ: the stream
+// attn_bwd2_dq_kernel's work decomposition and arithmetic (4 waves x 32 queries, tiles of 64 keys), the loop as an
+// instruction stream (gen_attn_bwd_w64.py, "the dQ stream"): one wave per SIMD, so ONE workgroup per CU where the HIP
+// kernel runs two.  S starts from -lse' (16 copies: MFMA C operand) instead of subtracting it per score, which changes
+// the rounding of the exponent by an ulp: equal to the HIP kernel within 1e-5, not bit for bit.
+template <bool PRE>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void attn_bwd2_dq_w64_kernel(const omh_attn_bwd_args p, const int q_blocks, const BwdSplit wk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // 4 x [K tile | V tile]
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool worker = (int)blockIdx.x >= wk.n_regular;
+    const int wid = worker ? wk.n_regular + ((int)blockIdx.x - wk.n_regular) / wk.splits : xcd_remap((int)blockIdx.x, wk.n_regular);
+    const int split = worker ? ((int)blockIdx.x - wk.n_regular) % wk.splits : 0;
+    const int qb = wid % q_blocks, bh = wid / q_blocks;
+    const int b = bh / p.H, head = bh % p.H;
+    int klen = p.k_lens ? p.k_lens[b] : p.Lk;
+    klen = min(max(klen, 0), p.Lk);
+    const int n_tiles_all = (klen + TB - 1) / TB;
+    int t_first = 0, n_tiles = n_tiles_all;
+    if (worker) {
+        const int per = (n_tiles_all + wk.splits - 1) / wk.splits;
+        t_first = min(split * per, n_tiles_all);
+        n_tiles = min(t_first + per, n_tiles_all) - t_first;
+    }
+    constexpr int PARK_WAVE = 16 * OMH_ATTN_BWD_W64_PARK_BLOCK;
+    if (n_tiles > 0) {
+        const uint16_t* Q = (const uint16_t*)p.q + (int64_t)b * p.q_bs + head * D;
+        const uint16_t* DO = (const uint16_t*)p.dout + (int64_t)b * p.o_bs + head * D;
+        const uint16_t* K = (const uint16_t*)p.k + (int64_t)b * p.k_bs + head * D;
+        const uint16_t* V = (const uint16_t*)p.v + (int64_t)b * p.k_bs + head * D;
+        auto uni = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };   // (all of these are wave-uniform)
+        auto rsrc = [&](const void* base, int64_t bytes) {
+            const uint64_t a = (uint64_t)base;
+            return u32x4{uni((uint32_t)a), uni((uint32_t)(a >> 32) & 0xffffu), uni((uint32_t)bytes), 0x00020000u};
+        };
+        const u32x4 rq = rsrc(Q, (((int64_t)p.Lq - 1) * p.q_rs + D) * 2), rdo = rsrc(DO, (((int64_t)p.Lq - 1) * p.o_rs + D) * 2);
+        const u32x4 rk = rsrc(K, (((int64_t)p.Lk - 1) * p.k_rs + D) * 2), rv = rsrc(V, (((int64_t)p.Lk - 1) * p.k_rs + D) * 2);
+        const uint32_t lds0 = lds_addr(smem);
+        const int q_row = qb * 128 + wave * 32 + li;
+        const bool q_ok = q_row < p.Lq;
+        const int64_t row_i = ((int64_t)b * p.H + head) * p.Lq + q_row;
+        const float l = q_ok ? p.lse[row_i] : 0.f;
+        const float k1f = PRE ? -LOG2E : -1.0f / p.scale;                 // -lse log2(e) / sc
+        float negl = (q_ok && l > -INFINITY) ? l * k1f : -INFINITY;      // no keys / past the end: P = exp2(-inf) = 0
+        float negd = q_ok ? -p.delta[row_i] : 0.f;
+        uint32_t voq = q_ok ? (uint32_t)(((int64_t)q_row * p.q_rs + lh * 8) * 2) : 0x80000000u;    // out of range: zeros
+        uint32_t vodof = q_ok ? (uint32_t)(((int64_t)q_row * p.o_rs + lh * 8) * 2) : 0x80000000u;
+        const int drow = tid >> 4;
+        uint32_t vodk = (uint32_t)((drow * (int)p.k_rs + (((tid & 15) ^ (int)swz(drow)) << 3)) * 2);
+        const int r0 = swap_bits23(li), z0 = (int)swz(r0);
+        uint32_t kab = lds0 + (uint32_t)(r0 * 256 + ((lh ^ (z0 & 1)) << 4)), xh = (uint32_t)(z0 >> 1);
+        const int gq = lane >> 4, i15 = lane & 15, fe = i15 >> 2, fq = i15 & 3;
+        const int rlo = 8 * (gq >> 1) + fe, z1 = (int)swz(rlo), low2 = 2 * (gq & 1) + (fq >> 1);
+        uint32_t tab = lds0 + (uint32_t)(rlo * 256 + ((low2 ^ (z1 & 3)) << 4) + (fq & 1) * 8), th = (uint32_t)(z1 >> 2);
+        uint32_t lh8 = (uint32_t)(8 * lh);
+        uint32_t vdump = lds0 + (uint32_t)(wave * PARK_WAVE + lane * 16);
+        const uint32_t ldsw = uni(lds0 + (uint32_t)wave * 1024u);
+        const uint32_t skp = uni((uint32_t)(16 * (int)p.k_rs * 2));
+        uint32_t skn = uni((uint32_t)t_first * 4u * skp), srem = uni((uint32_t)(klen - t_first * TB));
+        const uint32_t ntiles = uni((uint32_t)n_tiles);
+        const uint32_t sc = uni(__float_as_uint(PRE ? 1.0f : p.scale * LOG2E));
+#define OMH_BWD_DQ_W64_OPERANDS                                                                                       \
+                 : [skn] "+s"(skn), [srem] "+s"(srem), [vodk] "+v"(vodk), [voq] "+v"(voq), [vodof] "+v"(vodof),       \
+                   [kab] "+v"(kab), [xh] "+v"(xh), [tab] "+v"(tab), [th] "+v"(th), [negl] "+v"(negl), [negd] "+v"(negd),\
+                   [lh8] "+v"(lh8), [vdump] "+v"(vdump)                                                               \
+                 : [rq] "s"(rq), [rdo] "s"(rdo), [rk] "s"(rk), [rv] "s"(rv), [skp] "s"(skp), [ldsw] "s"(ldsw),        \
+                   [ntiles] "s"(ntiles), [sc] "s"(sc)                                                                 \
+                 : OMH_ATTN_BWD_W64_CLOBBERS
+        if constexpr (PRE) asm volatile(OMH_ATTN_BWD_DQ_W64_ASM_PRE OMH_BWD_DQ_W64_OPERANDS);
+        else asm volatile(OMH_ATTN_BWD_DQ_W64_ASM_GEN OMH_BWD_DQ_W64_OPERANDS);
+    }
+    // accumulators back through LDS, row-major (see the dK / dV kernel): block (db, g) = dQ^T registers 4g .. 4g+3 of
+    // accumulator db, 16 bytes per lane (lane = query li + 32 lh; d = 32 db + 8 g + 4 lh + 0..3); dQ = scale dS K
+    const unsigned char* park = smem + wave * PARK_WAVE;
+    const bool have = n_tiles > 0;
+    auto take = [&](int db, int g, int src_lane) {
+        float4 v = have ? *(const float4*)(park + (db * 4 + g) * OMH_ATTN_BWD_W64_PARK_BLOCK + src_lane * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+        return make_float4(v.x * p.scale, v.y * p.scale, v.z * p.scale, v.w * p.scale);
+    };
+    if (!worker && p.out_bf16) {
+        const int c = lane & 15, db = c >> 2, g = c & 3;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = 4 * it + (lane >> 4), q_row = qb * 128 + wave * 32 + row;
+            const float4 lo = take(db, g, row), hi = take(db, g, 32 + row);
+            if (q_row < p.Lq)
+                *(uint4*)((uint16_t*)p.dq + (int64_t)b * p.dq_bs + (int64_t)q_row * p.dq_rs + head * D + c * 8) =
+                    make_uint4(pack_bf2(lo.x, lo.y), pack_bf2(lo.z, lo.w), pack_bf2(hi.x, hi.y), pack_bf2(hi.z, hi.w));
+        }
+    } else {
+        const int c4 = lane & 31, db = c4 >> 3, g = (c4 >> 1) & 3, half = c4 & 1;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int row = 2 * it + (lane >> 5), q_row = qb * 128 + wave * 32 + row;
+            const float4 v = take(db, g, half * 32 + row);
+            if (worker)                                              // partial sums over this worker's keys
+                *(float4*)(wk.ws + (((int64_t)(wid - wk.n_regular) * wk.splits + split) * 128 + wave * 32 + row) * D + c4 * 4) = v;
+            else if (q_row < p.Lq)
+                *(float4*)((float*)p.dq + (int64_t)b * p.dq_bs + (int64_t)q_row * p.dq_rs + head * D + c4 * 4) = v;
+        }
+    }
+}
+
 // out[row] = sum_s slab_s[row] in the order of s (fixed: repeatable bit for bit).  One wave per (tail tile, row);
 // NOUT = 1: dQ rows; NOUT = 2: dK and dV rows of the same key.
 template <int NOUT>
@@ -750,6 +854,11 @@ void attn_bwd2_sum_kernel(const omh_attn_bwd_args p, const int blocks, const Bwd
 
 // Split plans: the dQ kernel runs two workgroups per CU (250 VGPRs), the dK / dV kernel one (214 VGPRs + 158 AGPRs:
 // forcing two spills 179 registers); at least 4 tiles of 64 positions per worker
+// option OMH_ATTN_BWD_W64: "0" both HIP kernels, "k" the dK / dV stream only, otherwise (default) both streams
+static bool bwd2_dq_stream() {
+    const char* e = omh_opt(OMH_OPT_ATTN_BWD_W64);
+    return !(e && (e[0] == '0' || e[0] == 'k'));
+}
 static OmhSplitPlan bwd2_plan(const omh_attn_bwd_args& a, bool dq) {
     const int blocks = dq ? (a.Lq + 127) / 128 : (a.Lk + 127) / 128;
     const int nwg = blocks * a.H * a.B;
@@ -758,7 +867,7 @@ static OmhSplitPlan bwd2_plan(const omh_attn_bwd_args& a, bool dq) {
     if (e && e[0] == '0') return none;
     // OMH_ATTN_SPLIT=tail: also the last round of a launch that fills the chip (measured: no gain, omh_common.h)
     const bool tail = e && e[0] == 't';
-    return omh_tail_split_plan(nwg, (dq ? 2 : 1) * omh_cu_count(), ((dq ? a.Lk : a.Lq) + TB - 1) / TB, 4, !tail, tail ? 0.8 : 0.67);
+    return omh_tail_split_plan(nwg, (dq && !bwd2_dq_stream() ? 2 : 1) * omh_cu_count(), ((dq ? a.Lk : a.Lq) + TB - 1) / TB, 4, !tail, tail ? 0.8 : 0.67);
 }
 static int64_t bwd2_ws_bytes(const OmhSplitPlan& pl, int nout) {
     return (int64_t)pl.n_tail * pl.splits * nout * 128 * D * 4;
@@ -775,7 +884,7 @@ extern "C" int64_t omh_flash_attn_bwd_workspace_bytes(const omh_attn_bwd_args* a
 int omh_launch_attn_bwd2(const omh_attn_bwd_args& a, hipStream_t s) {
     // 32-bit buffer offsets inside one (batch, head) slice
     // (+ 4 tiles: the dK / dV stream requests up to three tiles past the end, which must stay out of range, not wrap)
-    if (((int64_t)a.Lq + 4 * TB) * a.q_rs * 2 >= 0x7fffffffLL || (int64_t)a.Lk * a.k_rs * 2 >= 0x7fffffffLL ||
+    if (((int64_t)a.Lq + 4 * TB) * a.q_rs * 2 >= 0x7fffffffLL || ((int64_t)a.Lk + 4 * TB) * a.k_rs * 2 >= 0x7fffffffLL ||
         ((int64_t)a.Lq + 4 * TB) * a.o_rs * 2 >= 0x7fffffffLL)
         return OMH_E_SHAPE;
     if (((uintptr_t)a.o32 & 15) || (a.o_rs & 3) || (a.o_bs & 3)) return OMH_E_ALIGN;
@@ -788,6 +897,8 @@ int omh_launch_attn_bwd2(const omh_attn_bwd_args& a, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)attn_bwd2_dkdv_kernel<4, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV);
         (void)hipFuncSetAttribute((const void*)attn_bwd2_dkdv_w64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, OMH_ATTN_BWD_W64_LDS);
         (void)hipFuncSetAttribute((const void*)attn_bwd2_dkdv_w64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, OMH_ATTN_BWD_W64_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_bwd2_dq_w64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, OMH_ATTN_BWD_DQ_W64_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_bwd2_dq_w64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, OMH_ATTN_BWD_DQ_W64_LDS);
         attr_set = true;
     }
     const int k_blocks = (a.Lk + 127) / 128, q_blocks = (a.Lq + 127) / 128;
@@ -810,7 +921,10 @@ int omh_launch_attn_bwd2(const omh_attn_bwd_args& a, hipStream_t s) {
     BwdSplit wkv = {pk.n_regular, pk.n_tail, pk.splits, (float*)((char*)a.workspace + (pq.n_tail ? need_q : 0))};
     if (run_q) {                                                                                               // phase 0: writes delta
         const dim3 grid(wq.n_regular + wq.n_tail * wq.splits);
-        if (a.q_prescaled) hipLaunchKernelGGL(attn_bwd2_dq_kernel<true>, grid, dim3(256), LDS_DQ, s, a, q_blocks, wq);
+        if (bwd2_dq_stream()) {
+            if (a.q_prescaled) hipLaunchKernelGGL(attn_bwd2_dq_w64_kernel<true>, grid, dim3(256), OMH_ATTN_BWD_DQ_W64_LDS, s, a, q_blocks, wq);
+            else hipLaunchKernelGGL(attn_bwd2_dq_w64_kernel<false>, grid, dim3(256), OMH_ATTN_BWD_DQ_W64_LDS, s, a, q_blocks, wq);
+        } else if (a.q_prescaled) hipLaunchKernelGGL(attn_bwd2_dq_kernel<true>, grid, dim3(256), LDS_DQ, s, a, q_blocks, wq);
         else hipLaunchKernelGGL(attn_bwd2_dq_kernel<false>, grid, dim3(256), LDS_DQ, s, a, q_blocks, wq);
         if (wq.n_tail)
             hipLaunchKernelGGL(attn_bwd2_sum_kernel<1>, dim3((wq.n_tail * 128 + 3) / 4), dim3(256), 0, s, a, q_blocks, wq);

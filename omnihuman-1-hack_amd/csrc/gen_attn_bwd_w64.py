@@ -326,6 +326,188 @@ def generate(pre):
     return e
 
 
+
+# ================================================================================================ the dQ stream
+# attn_bwd2_dq_w64_kernel: 4 waves x 32 queries (lane = query), loop over tiles of 64 keys whose K and V rows are LDS-DMA
+# staged like Q / dO above.  Per 32-key half:  A  S^T = K Q^T, dP^T = V dO^T (16 MFMA; the accumulators start from 16
+# copies of -lse' / -delta: MFMA C operand, no statistics traffic);  B  dS = exp2(S) dP (P itself is not needed);
+# C  dQ^T += K^T dS^T (8 MFMA, transposed fragments of the K tile).  48 MFMAs per tile:  A0 | A1 + B0 | C0 + B1 | C1 + B1.
+# The keys past klen of the LAST tile get S = -inf (a block of 32 v_cndmask per half, skipped by every other tile).
+#   a[0:63] dQ^T accumulators   a[64:95] Q fragments   a[96:127] dO fragments
+#   v[160:175] -lse' x 16   v[176:191] -delta x 16   v[128:143] packed dS [half][a]   v[192:255] fragment ring, 16 slots of 4
+def DQA(db):       return db * 16
+def QF(kk):        return 64 + kk * 4
+def DOF(kk):       return 96 + kk * 4
+NEGL, NEGD = 160, 176
+def PKD(hb, a):    return 128 + hb * 8 + a * 4
+def SLOT16(i):     return 192 + (i % 16) * 4
+VLIM = 40
+S_REM = "%[srem]"
+DQ_LEAD_A, DQ_LEAD_C = 12, 6
+
+
+def dq_mfma_of(i):
+    frag = vr(SLOT16(i), 4)
+    if i < 32:
+        hb, kk, w = i // 16, (i % 16) // 2, i % 2
+        acc = vr((S(hb) if w == 0 else DP(hb)), 16)
+        c = vr((NEGL if w == 0 else NEGD), 16) if kk == 0 else acc
+        b = ar((QF(kk) if w == 0 else DOF(kk)), 4)
+        return f"v_mfma_f32_32x32x16_bf16 {acc}, {frag}, {b}, {c}", [f"F{i}"]
+    j = i - 32
+    hb, a, db = j // 8, (j % 8) // 4, j % 4
+    acc = ar(DQA(db), 16)
+    return f"v_mfma_f32_32x32x16_bf16 {acc}, {frag}, {vr(PKD(hb, a), 4)}, {acc}", [f"F{i}a", f"F{i}b"]
+
+
+def dq_frag_reads(i, prep):
+    if i < 32:
+        hb, kk, w = i // 16, (i % 16) // 2, i % 2
+        off = hb * 8192 + (16384 if w == 1 else 0)              # S: K rows;  dP: V rows
+        return [op("r", f"ds_read_b128 {vr(SLOT16(i), 4)}, {vr(ROW[kk])} offset:{off}", tag=f"F{i}", prep=prep)]
+    j = i - 32
+    hb, a, db = j // 8, (j % 8) // 4, j % 4
+    off = hb * 8192 + a * 4096                                  # K^T of keys 32 hb + 16 a ..
+    return [op("r", f"ds_read_b64_tr_b16 {vr(SLOT16(i), 2)}, {vr(TRA[db])} offset:{off}", tag=f"F{i}a", prep=prep),
+            op("r", f"ds_read_b64_tr_b16 {vr(SLOT16(i) + 2, 2)}, {vr(TRB[db])} offset:{off}", tag=f"F{i}b", prep=prep)]
+
+
+def dq_stage_b(hb, pre):
+    out = []
+    for ee in range(8):
+        r0, r1 = 2 * ee, 2 * ee + 1
+        if not pre:
+            out += [f"v_mul_f32 {vr(S(hb) + r0)}, %[sc], {vr(S(hb) + r0)}", f"v_mul_f32 {vr(S(hb) + r1)}, %[sc], {vr(S(hb) + r1)}"]
+        out += [f"v_exp_f32 {vr(S(hb) + r0)}, {vr(S(hb) + r0)}",
+                f"v_exp_f32 {vr(S(hb) + r1)}, {vr(S(hb) + r1)}",
+                f"v_mul_f32 {vr(DP(hb) + r0)}, {vr(S(hb) + r0)}, {vr(DP(hb) + r0)}",
+                f"v_mul_f32 {vr(DP(hb) + r1)}, {vr(S(hb) + r1)}, {vr(DP(hb) + r1)}",
+                f"v_cvt_pk_bf16_f32 {vr(PKD(hb, ee // 4) + ee % 4)}, {vr(DP(hb) + r0)}, {vr(DP(hb) + r1)}"]
+    return [op("x", ln) for ln in out]
+
+
+def dq_mask_block(e, hb, tag):
+    """Last tile only: keys at or past klen of half hb get S = -inf (register r <-> key 32 hb + 16 (r>>3) + 8 lh + (r&7))."""
+    skip = e.lab(f"nomask_{tag}")
+    out = [f"s_cmp_ge_i32 {S_REM}, 64", f"s_cbranch_scc1 {skip}", "s_nop 7", "s_nop 7",
+           f"v_sub_u32 {vr(VLIM)}, {S_REM}, %[lh8]"]              # keys left, seen from this lane's 8 lh offset
+    for r in range(16):
+        base = 32 * hb + 16 * (r >> 3) + (r & 7)
+        out += [f"v_cmp_gt_i32 vcc, {vr(VLIM)}, {vr(T2)}" if False else f"v_cmp_lt_i32 vcc, {base}, {vr(VLIM)}",
+                f"v_cndmask_b32 {vr(S(hb) + r)}, {vr(NEGINF)}, {vr(S(hb) + r)}, vcc"]
+    out.append(f"{skip}:")
+    return out
+
+
+def dq_dma_group(slot_expr):
+    out = []
+    for which, rs in enumerate(("%[rk]", "%[rv]")):
+        for j in range(4):
+            if j == 0:
+                out.append(f"s_add_u32 m0, %[ldsw], {slot_expr}" if which == 0 else "s_add_u32 m0, m0, 0x1000")
+                out.append(f"s_mov_b32 {S_OFF}, %[skn]")
+            else:
+                out.append("s_add_u32 m0, m0, 0x1000")
+                out.append(f"s_add_u32 {S_OFF}, {S_OFF}, %[skp]")
+            out.append(f"buffer_load_dwordx4 %[vodk], {rs}, {S_OFF} offen lds")
+    out.append(f"s_add_u32 %[skn], {S_OFF}, %[skp]")                # next tile
+    return out
+
+
+def dq_tile_ops(pre, e):
+    gaps = [[] for _ in range(48)]
+    for tgt in range(48, 96):
+        lead = DQ_LEAD_A if tgt % 48 < 32 else DQ_LEAD_C
+        g = tgt - lead
+        gaps[g % 48] += dq_frag_reads(tgt % 48, prep=g < 48)
+        assert (tgt % 48) - 16 <= (tgt % 48) - lead
+    b0, b1 = dq_stage_b(0, pre), dq_stage_b(1, pre)
+    h0, h1 = len(b0) // 2, len(b1) // 2
+    for lst, lo, hi in ((b0[:h0], 17, 28), (b0[h0:], 28, 35), (b1[:h1], 33, 39), (b1[h1:], 39, 43)):
+        for g, ops_ in enumerate(spread(lst, 48, lo, hi)):
+            gaps[g] += ops_
+    # the edge masks sit right in front of each half's stage B (multi-line ops keep the labels with their branches)
+    gaps[16] += [op("x", "\\n\\t\"\n    \"".join(dq_mask_block(e, 0, "h0")))]
+    gaps[32] += [op("x", "\\n\\t\"\n    \"".join(dq_mask_block(e, 1, "h1")))]
+    gaps[20] += [op("x", ln) for ln in advance(S_ROW, D_ROW, C_STEP, C_WRAP, NSLOT * SLOT)]
+    for g, lst in enumerate(spread([op("x", f"v_add_u32 {vr(r)}, {D_ROW}, {vr(r)}") for r in ROW], 48, 21, 33)):
+        gaps[g] += lst
+    gaps[43] += [op("x", ln) for ln in advance(S_TR, D_TR, C_STEP, C_WRAP, NSLOT * SLOT)]
+    for g, lst in enumerate(spread([op("x", f"v_add_u32 {vr(r)}, {D_TR}, {vr(r)}") for r in TRA + TRB], 48, 44, 48)):
+        gaps[g] += lst
+    # barrier where the next tile's first fragments are requested (gap 36 = 48 - 12); the 8 loads of tile t+2 may still fly
+    gaps[35] += [op("x", "s_waitcnt vmcnt(8)"), op("x", "s_barrier"), op("x", f"s_sub_u32 {S_REM}, {S_REM}, 64")]
+    gaps[36] += [op("x", ln) for ln in advance(S_DMA, S_OFF, C_STEP, C_WRAP, NSLOT * SLOT)[:2] + [f"s_cselect_b32 {S_DMA}, 0, {S_DMA}"]]
+    for g, lst in enumerate(spread([op("x", ln) for ln in dq_dma_group(S_DMA)], 48, 36, 46)):
+        gaps[g] += lst
+    return gaps
+
+
+def generate_dq(pre):
+    e = Emit("bq%d" % (0 if pre else 1))
+    for kk in range(8):                                              # Q / dO fragments of this lane's query (rows past Lq: out of range -> 0)
+        e(f"buffer_load_dwordx4 {vr(S(0) + 4 * kk, 4)}, %[voq], %[rq], 0 offen offset:{kk * 32}")
+    for kk in range(8):
+        e(f"buffer_load_dwordx4 {vr(S(1) + 4 * kk, 4)}, %[vodof], %[rdo], 0 offen offset:{kk * 32}")
+    e(f"s_mov_b32 {C_STEP}, {SLOT}")
+    e(f"s_mov_b32 {C_WRAP}, {(-(NSLOT - 1) * SLOT) & 0xffffffff:#x}")
+    for s_ in (S_ROW, S_TR):
+        e(f"s_mov_b32 {s_}, 0")
+    e(f"s_mov_b32 {S_CNT}, %[ntiles]")
+    for g in range(3):
+        for ln in dq_dma_group(g * SLOT):
+            e(ln)
+    e(f"s_mov_b32 {S_DMA}, {2 * SLOT}")
+    for kk in range(8):
+        e(f"v_xor_b32 {vr(T0)}, {kk}, %[xh]")
+        e(f"v_lshl_add_u32 {vr(ROW[kk])}, {vr(T0)}, 5, %[kab]")
+    for db in range(4):
+        e(f"v_xor_b32 {vr(T0)}, {db}, %[th]")
+        e(f"v_lshl_add_u32 {vr(TRA[db])}, {vr(T0)}, 6, %[tab]")
+        e(f"v_add_u32 {vr(TRB[db])}, 1024, {vr(TRA[db])}")
+        e(f"v_xor_b32 {vr(TRB[db])}, 16, {vr(TRB[db])}")
+    e(f"v_mov_b32 {vr(NEGINF)}, 0xff800000")
+    for r in range(16):
+        e(f"v_mov_b32 {vr(NEGL + r)}, %[negl]")
+        e(f"v_mov_b32 {vr(NEGD + r)}, %[negd]")
+    for i in range(64):
+        e(f"v_accvgpr_write_b32 {ar(i)}, 0")
+    e("s_waitcnt vmcnt(24)")                                        # the 16 fragment loads (issued first) have landed
+    for i in range(32):
+        e(f"v_accvgpr_write_b32 {ar(QF(0) + i)}, {vr(S(0) + i)}")
+    for i in range(32):
+        e(f"v_accvgpr_write_b32 {ar(DOF(0) + i)}, {vr(S(1) + i)}")
+    e("s_waitcnt vmcnt(16)")                                        # tile 0
+    e("s_barrier")
+    gaps = dq_tile_ops(pre, e)
+    prep = [o for g in range(36, 48) for o in gaps[g] if o[4]]
+    full = linearize(e, prep, [])
+    ops = []
+    for i in range(48):
+        text, needs = dq_mfma_of(i)
+        ops.append(op("m", text, needs))
+        ops += gaps[i]
+    loop_pending = linearize(Emit("dry"), ops, full)
+    assert full[len(full) - len(loop_pending):] == loop_pending, (full, loop_pending)
+    e(f"s_waitcnt lgkmcnt({min(len(loop_pending), 15)})")
+    LOOP = e.lab("loop")
+    e.label(LOOP)
+    end = linearize(e, ops, loop_pending)
+    assert end == loop_pending, (end, loop_pending)
+    e(f"s_sub_u32 {S_CNT}, {S_CNT}, 1")
+    e(f"s_cmp_lg_u32 {S_CNT}, 0")
+    e(f"s_cbranch_scc1 {LOOP}")
+    e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    e("s_barrier")
+    e("s_nop 7")
+    e("s_nop 7")
+    for x in range(4):
+        for g in range(4):
+            e(f"ds_write_b128 %[vdump], {ar(x * 16 + 4 * g, 4)} offset:{(x * 4 + g) * PARK_BLOCK}")
+    e("s_waitcnt lgkmcnt(0)")
+    return e
+
+
 CLOBBER_V = range(16, 256)
 CLOBBER_A = range(0, 256)
 CLOBBER_S = range(80, 93)
@@ -340,6 +522,13 @@ def main():
         print("")
         n_mfma = sum("v_mfma" in ln for ln in e.lines)
         print(f"// {name}: {len(e.lines)} lines, {n_mfma} MFMA in the loop body")
+    for name, pre in (("PRE", True), ("GEN", False)):
+        e = generate_dq(pre)
+        print(f"#define OMH_ATTN_BWD_DQ_W64_ASM_{name} \\")
+        print(" \\\n".join(e.text().split("\n")))
+        print("")
+        print(f"// dQ {name}: {len(e.lines)} lines")
+    print(f"#define OMH_ATTN_BWD_DQ_W64_LDS {NSLOT * SLOT}")
     print(f"#define OMH_ATTN_BWD_W64_LDS {LDS_BYTES}")
     print(f"#define OMH_ATTN_BWD_W64_SLOT {SLOT}")
     print(f"#define OMH_ATTN_BWD_W64_STAT_RAW {STAT_RAW}")
