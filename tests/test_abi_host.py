@@ -276,7 +276,8 @@ def test_attention_split_plans_without_a_gpu(omh):
     assert bwd_bytes(1, 12, 1560, 1560, phase=1) == 0
     assert bwd_bytes(4, 12, 1560, 1560) == 0                        # 624 workgroups: more than a round, no split
     assert bwd_bytes(4, 12, 1560, 512) == 0                         # cross-attention dK / dV: 192 on 256, < 1/3 to gain
-    assert bwd_bytes(1, 12, 1560, 512) == 156 * 2 * tile + 48 * 5 * 2 * tile      # dQ: 8 key tiles -> 2 workers; dK/dV: 48 x 5 = 240 <= 256
+    # dQ (the stream: ONE workgroup per CU since round 5): 8 key tiles -> 2 workers would be 312 > 256, not split; dK/dV: 48 x 5 = 240 <= 256
+    assert bwd_bytes(1, 12, 1560, 512) == 48 * 5 * 2 * tile
 
     def fwd_bytes(B, H, Lq, Lk, flags):
         a = binding.AttnArgs()
