@@ -3,8 +3,8 @@ S = 1560 — for rocprofv3 --pmc passes (tools/pmc_generic.sh) or, with TIME=1, 
 import importlib, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ops = importlib.import_module("omnihuman-1-hack_amd.ops")
-B, S, d, H = int(os.environ.get("B", 4)), 1560, 1536, 12
-SQ = int(os.environ.get("LQ", S))                           # queries per clip (the keys stay at S): the dK / dV loop length
+B, S, d, H = int(os.environ.get("B", 4)), int(os.environ.get("LK", 1560)), 1536, 12
+SQ = int(os.environ.get("LQ", 1560))                           # queries per clip (the keys stay at S): the dK / dV loop length
 R = B * S
 g = torch.Generator(device="cuda").manual_seed(1)
 k, v = [(torch.randn(R, d, device="cuda", generator=g) * 0.5).bfloat16() for _ in range(2)]
