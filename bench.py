@@ -932,6 +932,20 @@ def main():
                     "(" + str(tsrc) + ")",
                     "launches_timed": len(timer.pairs), "avg_launch_ms": round(attn_ms, 4),
                     "algorithmic_flops_per_launch": attn_flops}
+        # what the matrix pipe of THIS box sustains with no memory traffic at all (omh_probe_mfma_tflops: back-to-back
+        # v_mfma_f32_32x32x16_bf16, one wave per SIMD, measured here, outside the timed region): `peak` stays the data
+        # sheet's dense figure; on operands that toggle like data the clock follows the multipliers' power
+        try:
+            ops.probe_mfma_tflops(True, 50)
+            p_const = max(ops.probe_mfma_tflops(False, 400) for _ in range(2))
+            p_rand = max(ops.probe_mfma_tflops(True, 400) for _ in range(2))
+            roofline["mfma_sustained_constant_operands_tflops"] = round(p_const, 1)
+            roofline["mfma_sustained_random_operands_tflops"] = round(p_rand, 1)
+            roofline["frac_of_mfma_sustained_random_operands"] = round(ach / p_rand, 4)
+            roofline["mfma_sustained_note"] = ("back-to-back bf16 MFMAs from registers on all CUs, no memory traffic (csrc/probes.hip), measured in "
+                                               "this process after the timed steps: the practical ceiling of the matrix pipe on this box")
+        except Exception as ex:                                       # pragma: no cover
+            roofline["mfma_sustained_note"] = "probe failed: %r" % (ex,)
 
     secondary = {}
     l_ms = ln_timer.avg_ms()

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define OMH_ABI_VERSION 10
+#define OMH_ABI_VERSION 11
 
 #define OMH_E_BADARG   (-1)   /* null pointer / non-positive size             */
 #define OMH_E_ALIGN    (-2)   /* pointer or leading dimension not aligned     */
@@ -374,6 +374,19 @@ int omh_cfg_unipc_step(const float* cond, const float* uncond, const float* x, c
                        int64_t n, float guide, float sigma, int32_t use_corr,
                        float ca_last, float ca_m1, float ca_m2, float ca_mt,
                        float pb_x, float pb_mt, float pb_m1, omh_stream_t stream);
+
+/* ----------------------------------------------------------------------
+ * ABI v11.  Measurement, not product: TFLOP/s this GPU sustains on back-to-back
+ * v_mfma_f32_32x32x16_bf16 with one wave per SIMD and no memory traffic
+ * (one workgroup of 4 waves per CU, iters x 64 MFMAs each), with constant
+ * operands (random_operands = 0) or with operands that toggle like data (1):
+ * the clock follows the power the multipliers draw, so the second figure is
+ * the matrix-pipe ceiling a kernel on real data can be measured against.
+ * bench.py reports both beside the data-sheet peak.  scratch: >= 256 floats
+ * per CU of device memory (overwritten).  Synchronises `stream`.
+ * ---------------------------------------------------------------------- */
+int omh_probe_mfma_tflops(int32_t random_operands, int32_t iters, float* scratch, int64_t scratch_floats,
+                          float* tflops_out, omh_stream_t stream);
 
 /* ========================================================================
  * 3D causal VAE (seaweed_apt/wan/modules/vae.py).  Activations are

@@ -21,7 +21,7 @@ class OmhError(RuntimeError):
     pass
 
 
-ABI_VERSION = 10         # == OMH_ABI_VERSION of include/omh.h; checked against the loaded library below
+ABI_VERSION = 11         # == OMH_ABI_VERSION of include/omh.h; checked against the loaded library below
 
 
 def _load():
@@ -231,6 +231,7 @@ _SIGS = {
     "omh_softmax_bias_rows": (i32, [vp, i64, vp, i64, i32, i32, f32, vp, vp, i32, vp]),
     "omh_mul_bf16": (i32, [vp, vp, vp, i64, vp]),
     "omh_vit_embed": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "omh_probe_mfma_tflops": (i32, [i32, i32, vp, i64, vp, vp]),
     "omh_cfg_unipc_step": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, i32, f32, f32, f32, f32, f32,
                                  f32, f32, vp]),
 }

@@ -1,0 +1,77 @@
+// Measurement entry point, not part of the product path: the rate at which this GPU sustains back-to-back
+// v_mfma_f32_32x32x16_bf16 (the instruction every GEMM / attention / convolution stream of this library is made of),
+// one wave per SIMD, no memory traffic at all — once with constant operands and once with operands that toggle like data.
+// bench.py reports both next to the 2.5 PFLOP/s of the data sheet: on the boxes of round 5 the chip sustained 2.2 PFLOP/s
+// on constant operands and 1.3 PFLOP/s on random ones (the clock follows the power the multipliers draw) — the attention
+// stream's 1.4 PFLOP/s is to be read against THAT (profiles/r05_rate_probes.txt; tools/probes/mfma_rate_probe.hip is the
+// stand-alone form with the issue-rate experiments).
+#include "omh_common.h"
+
+namespace {
+
+template <bool RND>
+__global__ __launch_bounds__(256, 1) void mfma_rate_kernel(float* out, int iters, int salt) {
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    bf16x8 ra[8], rb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (RND) {                                               // hashed values in [-2, 2): every operand bit toggles
+                uint32_t h = (threadIdx.x * 2654435761u) ^ ((i * 8 + e + salt) * 40503u + blockIdx.x * 977u);
+                h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+                uint32_t g = h * 3266489917u; g ^= g >> 16;
+                ra[i][e] = (__bf16)(((int)(h & 0xffff) - 32768) * (1.0f / 16384.0f));
+                rb[i][e] = (__bf16)(((int)(g & 0xffff) - 32768) * (1.0f / 16384.0f));
+            } else {
+                ra[i][e] = (__bf16)(float)((threadIdx.x & 63) + e + salt);
+                rb[i][e] = (__bf16)(float)(e + salt);
+            }
+        }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 64; ++j)
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[j & 7]) : "v"(ra[RND ? (j & 7) : 0]), "v"(rb[RND ? ((j >> 3) & 7) : 0]));
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+}  // namespace
+
+extern "C" int omh_probe_mfma_tflops(int32_t random_operands, int32_t iters, float* scratch, int64_t scratch_floats,
+                                     float* tflops_out, omh_stream_t stream) {
+    if (!scratch || !tflops_out || iters <= 0) return OMH_E_BADARG;
+    const int grid = omh_cu_count();
+    if (scratch_floats < (int64_t)grid * 256) return OMH_E_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    hipError_t err = hipEventCreate(&e0);
+    if (err != hipSuccess) return (int)err;
+    err = hipEventCreate(&e1);
+    if (err != hipSuccess) { (void)hipEventDestroy(e0); return (int)err; }
+    auto launch = [&](int n) {
+        if (random_operands) hipLaunchKernelGGL(mfma_rate_kernel<true>, dim3(grid), dim3(256), 0, s, scratch, n, 1);
+        else hipLaunchKernelGGL(mfma_rate_kernel<false>, dim3(grid), dim3(256), 0, s, scratch, n, 1);
+    };
+    launch(iters / 8 + 1);                                           // warm the clocks
+    (void)hipEventRecord(e0, s);
+    launch(iters);
+    (void)hipEventRecord(e1, s);
+    err = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (err != hipSuccess) return (int)err;
+    *tflops_out = (float)((double)grid * 4 * 64.0 * iters * 32768.0 / (ms * 1e-3) * 1e-12);
+    return 0;
+}

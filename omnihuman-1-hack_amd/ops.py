@@ -789,6 +789,16 @@ def ema_update(ema, p, decay):
     check(lib.omh_ema_update(_p(ema), _p(p), p.numel(), decay, _stream()), "omh_ema_update")
 
 
+def probe_mfma_tflops(random_operands: bool, iters: int = 400) -> float:
+    """Measurement only (include/omh.h: omh_probe_mfma_tflops): TFLOP/s of back-to-back bf16 MFMAs, one wave per SIMD."""
+    import ctypes as _C
+    scratch = torch.empty(1024 * 256, device="cuda", dtype=torch.float32)
+    out = _C.c_float(0.0)
+    check(lib.omh_probe_mfma_tflops(int(bool(random_operands)), int(iters), _p(scratch), scratch.numel(),
+                                    _C.cast(_C.byref(out), _C.c_void_p), _stream()), "omh_probe_mfma_tflops")
+    return float(out.value)
+
+
 def ema_update_multi(table, n_entries, total_chunks, decay):
     """table: device int64 [n, 4] = {ema, p, numel, first 4096-element chunk} (include/omh.h: omh_ema_update_multi)."""
     _dev(table)
