@@ -936,9 +936,9 @@ def main():
         # v_mfma_f32_32x32x16_bf16, one wave per SIMD, measured here, outside the timed region): `peak` stays the data
         # sheet's dense figure; on operands that toggle like data the clock follows the multipliers' power
         try:
-            ops.probe_mfma_tflops(True, 50)
-            p_const = max(ops.probe_mfma_tflops(False, 400) for _ in range(2))
-            p_rand = max(ops.probe_mfma_tflops(True, 400) for _ in range(2))
+            ops.probe_mfma_tflops(True, 2000)                      # (50 ms per launch below: the sustained clock, not a burst)
+            p_const = ops.probe_mfma_tflops(False, 30000)
+            p_rand = ops.probe_mfma_tflops(True, 30000)
             roofline["mfma_sustained_constant_operands_tflops"] = round(p_const, 1)
             roofline["mfma_sustained_random_operands_tflops"] = round(p_rand, 1)
             roofline["frac_of_mfma_sustained_random_operands"] = round(ach / p_rand, 4)

@@ -207,6 +207,8 @@ class WanSelfAttention(nn.Module):
         # long sequences: q | k | v as ONE product per clip over the concatenated weights (ABI v10) — h is read once,
         # the V third leaves the kernel transposed (V^T [dim, Sp], what the attention kernel reads); the same bits as the
         # two products below, which short sequences / batches keep (their rows fill the chip only together)
+        # (tried at S = 1 560 in round 5: one launch instead of two is the same 19.7 ms per single-frame forward, and the
+        # batched CFG pair gets slower, 14.8 -> 15.4 ms: one launch per clip against two over both clips)
         fused = S >= 8192 and S % 8 == 0
         if fused:
             wqkv, bqkv = self._w_qkv()
