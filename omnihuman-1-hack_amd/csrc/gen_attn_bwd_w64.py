@@ -38,7 +38,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from gen_attn_w64 import Emit, spread, X, vr, ar          # noqa: E402
+from gen_attn_w64 import Emit, spread, vr, ar             # noqa: E402
 
 SLOT = 32768                      # one ring slot: Q tile 16 KiB | dO tile 16 KiB
 NSLOT = 4
@@ -61,7 +61,7 @@ ROW = list(range(16, 24))
 TRA = list(range(24, 28))
 TRB = list(range(28, 32))
 STR, RAW = 32, 33
-T0, T1, T2 = 36, 37, 38
+T0, T1 = 36, 37
 NEGINF = 42
 def S(hb):         return 64 + hb * 32
 def DP(hb):        return 80 + hb * 32
@@ -124,7 +124,7 @@ def mfma_of(i):
 
 
 def frag_reads(i, prep):
-    """The LDS reads that feed MFMA i (issued PF pairs earlier)."""
+    """The LDS reads that feed MFMA i (issued LEAD_A / LEAD_C MFMAs earlier)."""
     pr, w = i // 2, i % 2
     st = pr % 8
     if ("norow" in ABL and i < 32) or ("notr" in ABL and i >= 32):
@@ -180,8 +180,9 @@ def stat_reads(hb):
     return out
 
 
-def dma_group(slot_expr, first=False):
-    """Statistics (2 dwords per lane... one per lane each) + the 8 pieces of the Q and dO tiles of one tile -> ring slot."""
+def dma_group(slot_expr):
+    """One tile's group of 10 loads: lse and delta of its 64 queries (one dword per lane each) + the 8 pieces of its Q and dO
+    rows -> ring slot."""
     out = [f"s_lshr_b32 {S_OFF}, {slot_expr}, 6" if not isinstance(slot_expr, int) else f"s_mov_b32 {S_OFF}, {slot_expr >> 6}",
            f"s_add_u32 m0, %[sraw], {S_OFF}",
            "s_nop 0",
@@ -393,7 +394,7 @@ def dq_mask_block(e, hb, tag):
            f"v_sub_u32 {vr(VLIM)}, {S_REM}, %[lh8]"]              # keys left, seen from this lane's 8 lh offset
     for r in range(16):
         base = 32 * hb + 16 * (r >> 3) + (r & 7)
-        out += [f"v_cmp_gt_i32 vcc, {vr(VLIM)}, {vr(T2)}" if False else f"v_cmp_lt_i32 vcc, {base}, {vr(VLIM)}",
+        out += [f"v_cmp_lt_i32 vcc, {base}, {vr(VLIM)}",            # key in range: keep; else -inf
                 f"v_cndmask_b32 {vr(S(hb) + r)}, {vr(NEGINF)}, {vr(S(hb) + r)}, vcc"]
     out.append(f"{skip}:")
     return out
