@@ -213,7 +213,8 @@ def softmax_lines(cur, poly=False):
 def rowsum_lines(cur):
     # (round 5: the same sums as 32 v_pk_add_f32 on (L_A, L_B) register pairs — bit-identical, 32 VALU instructions fewer per
     #  tile — measured SLOWER, 4.88 -> 5.07 ms per launch on one box: packed fp32 adds do not issue faster here and the two
-    #  accumulator chains end up two instructions apart instead of four)
+    #  accumulator chains end up two instructions apart instead of four).  Likewise 32 v_dot2_f32_bf16 on the PACKED bf16 pairs
+    #  (P.lo * 1 + P.hi * 1 + acc): 4.82 -> 4.99 ms.  VOP3P instructions cost ~3x a plain VALU instruction in this stream.)
     a, b = [], []
     for qb, dst in ((0, a), (1, b)):
         regs = [S(cur, qb, kb) + r for kb in range(2) for r in range(16)]
