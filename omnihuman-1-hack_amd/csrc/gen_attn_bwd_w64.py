@@ -354,14 +354,16 @@ def dq_mfma_of(i):
         acc = vr((S(hb) if w == 0 else DP(hb)), 16)
         c = vr((NEGL if w == 0 else NEGD), 16) if kk == 0 else acc
         b = ar((QF(kk) if w == 0 else DOF(kk)), 4)
-        return f"v_mfma_f32_32x32x16_bf16 {acc}, {frag}, {b}, {c}", [f"F{i}"]
+        return f"v_mfma_f32_32x32x16_bf16 {acc}, {frag}, {b}, {c}", ([] if "norow" in ABL else [f"F{i}"])
     j = i - 32
     hb, a, db = j // 8, (j % 8) // 4, j % 4
     acc = ar(DQA(db), 16)
-    return f"v_mfma_f32_32x32x16_bf16 {acc}, {frag}, {vr(PKD(hb, a), 4)}, {acc}", [f"F{i}a", f"F{i}b"]
+    return f"v_mfma_f32_32x32x16_bf16 {acc}, {frag}, {vr(PKD(hb, a), 4)}, {acc}", ([] if "notr" in ABL else [f"F{i}a", f"F{i}b"])
 
 
 def dq_frag_reads(i, prep):
+    if ("norow" in ABL and i < 32) or ("notr" in ABL and i >= 32):
+        return []
     if i < 32:
         hb, kk, w = i // 16, (i % 16) // 2, i % 2
         off = hb * 8192 + (16384 if w == 1 else 0)              # S: K rows;  dP: V rows
@@ -423,13 +425,16 @@ def dq_tile_ops(pre, e):
         gaps[g % 48] += dq_frag_reads(tgt % 48, prep=g < 48)
         assert (tgt % 48) - 16 <= (tgt % 48) - lead
     b0, b1 = dq_stage_b(0, pre), dq_stage_b(1, pre)
+    if "nob" in ABL:
+        b0, b1 = [], []
     h0, h1 = len(b0) // 2, len(b1) // 2
     for lst, lo, hi in ((b0[:h0], 17, 28), (b0[h0:], 28, 35), (b1[:h1], 33, 39), (b1[h1:], 39, 43)):
         for g, ops_ in enumerate(spread(lst, 48, lo, hi)):
             gaps[g] += ops_
     # the edge masks sit right in front of each half's stage B (multi-line ops keep the labels with their branches)
-    gaps[16] += [op("x", "\\n\\t\"\n    \"".join(dq_mask_block(e, 0, "h0")))]
-    gaps[32] += [op("x", "\\n\\t\"\n    \"".join(dq_mask_block(e, 1, "h1")))]
+    if "nomask" not in ABL:
+        gaps[16] += [op("x", "\\n\\t\"\n    \"".join(dq_mask_block(e, 0, "h0")))]
+        gaps[32] += [op("x", "\\n\\t\"\n    \"".join(dq_mask_block(e, 1, "h1")))]
     gaps[20] += [op("x", ln) for ln in advance(S_ROW, D_ROW, C_STEP, C_WRAP, NSLOT * SLOT)]
     for g, lst in enumerate(spread([op("x", f"v_add_u32 {vr(r)}, {D_ROW}, {vr(r)}") for r in ROW], 48, 21, 33)):
         gaps[g] += lst
@@ -439,8 +444,10 @@ def dq_tile_ops(pre, e):
     # barrier where the next tile's first fragments are requested (gap 36 = 48 - 12); the 8 loads of tile t+2 may still fly
     gaps[35] += [op("x", "s_waitcnt vmcnt(8)"), op("x", "s_barrier"), op("x", f"s_sub_u32 {S_REM}, {S_REM}, 64")]
     gaps[36] += [op("x", ln) for ln in advance(S_DMA, S_OFF, C_STEP, C_WRAP, NSLOT * SLOT)[:2] + [f"s_cselect_b32 {S_DMA}, 0, {S_DMA}"]]
-    for g, lst in enumerate(spread([op("x", ln) for ln in dq_dma_group(S_DMA)], 48, 36, 46)):
+    for g, lst in enumerate(spread([op("x", ln) for ln in dq_dma_group(S_DMA) if not ("nodma" in ABL and ln.startswith("buffer_load"))], 48, 36, 46)):
         gaps[g] += lst
+    if "nodma" in ABL:
+        gaps[35][0] = op("x", "s_nop 0")
     return gaps
 
 

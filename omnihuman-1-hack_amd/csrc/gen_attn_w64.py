@@ -319,14 +319,27 @@ def slow_path(e, st, qb, first):
 
 
 def check_and_rescale(e, st, tag, first=False):
+    """Per query block: move the running max when the new row max exceeds it by more than THR.  ONE branch skips both
+    blocks' checks in the common case (round 5: a taken branch costs a one-wave-per-SIMD stream ~40 cycles of instruction
+    fetch, and there were two per tile); vccz is stale after a scalar write of vcc, so the merged test goes through scc."""
+    if first:
+        for qb in range(2):
+            slow_path(e, st, qb, True)
+        return
+    both = e.lab(f"nores_{tag}")
+    e(f"v_cmp_lt_f32 vcc, {THR}, {vr(MXA[0])}")
+    e("s_mov_b64 s[96:97], vcc")
+    e(f"v_cmp_lt_f32 vcc, {THR}, {vr(MXA[1])}")
+    e("s_or_b64 s[96:97], s[96:97], vcc")
+    e("s_cmp_eq_u64 s[96:97], 0")
+    e(f"s_cbranch_scc1 {both}")
     for qb in range(2):
         skip = e.lab(f"nores_{tag}_{qb}")
-        if not first:
-            e(f"v_cmp_lt_f32 vcc, {THR}, {vr(MXA[qb])}")
-            e(f"s_cbranch_vccz {skip}")
-        slow_path(e, st, qb, first)
-        if not first:
-            e.label(skip)
+        e(f"v_cmp_lt_f32 vcc, {THR}, {vr(MXA[qb])}")
+        e(f"s_cbranch_vccz {skip}")
+        slow_path(e, st, qb, False)
+        e.label(skip)
+    e.label(both)
 
 
 def rotate(sreg, nslots):
