@@ -11,6 +11,22 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _line_and_detail(stdout):
+    """The ONE compact stdout line (< 8 KB, flat `config` / `roofline` / `cpu_baseline`) and the full record the run left in
+    the side file the line names."""
+    lines = [ln for ln in stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    assert len(lines[0]) < 8192, len(lines[0])
+    d = json.loads(lines[0])
+    for obj in ("config", "roofline", "cpu_baseline"):
+        for k, v in (d.get(obj) or {}).items():
+            assert not isinstance(v, dict), (obj, k)
+    with open(os.path.join(ROOT, d["detail"])) as fh:
+        full = json.load(fh)
+    assert full["value"] == d["value"] and full["n_gpus"] == d["n_gpus"]
+    return d, full
+
+
 @pytest.mark.parametrize("forced_rccl", [False, True])
 def test_bench_prints_one_json_line(forced_rccl):
     env = dict(os.environ)
@@ -22,9 +38,8 @@ def test_bench_prints_one_json_line(forced_rccl):
                         "--no-single-frame", "--no-train", "--no-cpu-baseline", "--no-encoders"], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, lines
-    d = json.loads(lines[0])
+    d, full = _line_and_detail(r.stdout)
+    assert "kernels" in full["dit"] and "dit" not in d          # the per-kernel table lives in the side file
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
@@ -45,13 +60,16 @@ def test_bench_gpus_2_launches_itself():
                         "--no-vae", "--no-single-frame", "--no-cpu-baseline", "--no-encoders"], env=env, capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, lines
-    d = json.loads(lines[0])
+    d, full = _line_and_detail(r.stdout)
     assert d["n_gpus"] == 2 and d["steps"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
-    assert d["train"]["rccl_world_size"] == 2 and d["train"]["finite_loss"]
-    assert "all-reduce over 2 rank(s)" in d["train"]["work"]
+    assert full["train"]["rccl_world_size"] == 2 and full["train"]["finite_loss"]
+    assert "all-reduce over 2 rank(s)" in full["train"]["work"]
     assert d["cpu_baseline"] is None                      # rank 0 times the CPU oracle at N = 1 only
+    # the multi-rank facts as flat scalars of the compact line
+    rf = d["roofline"]
+    assert rf["train_rccl_world_size"] == 2 and len(d["per_rank_ms_per_step"]) == 2 and len(rf["train_per_rank_ms_per_step"]) == 2
+    assert rf["train_allreduce_exposed_ms"] is not None and rf["train_reducer_collective"] and rf["train_reducer_payload"]
+    assert d["config"]["parallelism"].startswith("dp2")
 
 
 @pytest.mark.parametrize("mode", ["replicas", "cfg_split"])
@@ -71,13 +89,14 @@ def test_bench_gpus_8_launches_itself(mode):
         cmd += ["--cfg", "split", "--no-train"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, lines
-    d = json.loads(lines[0])
+    d, full = _line_and_detail(r.stdout)
     assert d["n_gpus"] == 8 and d["steps"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["cpu_baseline"] is None
     if mode == "replicas":
-        tr = d["train"]
+        tr = full["train"]
+        rf = d["roofline"]
+        assert rf["train_rccl_world_size"] == 8 and rf["train_reducer_collective"] == "reduce_scatter_all_gather"
+        assert rf["train_reducer_payload"] == "bfloat16" and len(d["per_rank_ms_per_step"]) == 8
         assert tr["rccl_world_size"] == 8 and tr["finite_loss"] and "all-reduce over 8 rank(s)" in tr["work"]
         assert tr["reducer"] == {"collective": "reduce_scatter_all_gather", "payload": "bfloat16", "bucket_mb": 256.0,
                                  "bytes_on_wire_per_step": tr["reducer"]["bytes_on_wire_per_step"]}
