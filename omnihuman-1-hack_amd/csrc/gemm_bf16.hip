@@ -518,6 +518,8 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
         if (!a.aux || a.batch != 1 || a.b_kmajor || a.c_in || a.n_split <= 0 || a.n_split >= a.N) return OMH_E_BADARG;
         if (a.bias && a.bias_mode != OMH_BIAS_N) return OMH_E_BADARG;
         if ((a.n_split & 7) || (a.M & 7) || (a.ldaux & 7) || a.ldaux < a.M || ((uintptr_t)a.aux & 15)) return OMH_E_ALIGN;
+        if ((a.ldc & 7) || ((uintptr_t)a.C & 15)) return OMH_E_ALIGN;
+        if (a.ldc < a.n_split) return OMH_E_SHAPE;                        // C rows are n_split wide: a narrower pitch would overlap them
         const char* q = omh_opt(OMH_OPT_GEMM_QKV);
         const char* gk = omh_opt(OMH_OPT_GEMM_KERNEL);
         const bool off = (q && q[0] == '0') || (gk && gk[0] == '8') || omh_opt(OMH_OPT_GEMM_TILE);

@@ -136,15 +136,23 @@ def reset_options():
 
 
 class options:
-    """``with ops.options(GEMM_KERNEL="8w", GEMM_TILE=None): ...`` — set, run, restore."""
+    """``with ops.options(GEMM_KERNEL="8w", GEMM_TILE=None): ...`` — set, run, restore.
+
+    Options are process-wide and omh_set_option is not synchronised against launches: do not change them while a
+    backward pass is running (the reducer and the weight-gradient stream launch from autograd's worker threads)."""
 
     def __init__(self, **kv):
         self.kv, self.old = kv, {}
 
     def __enter__(self):
-        for k, v in self.kv.items():
-            self.old[k] = get_option(k)
-            set_option(k, v)
+        try:
+            for k, v in self.kv.items():
+                old = get_option(k)
+                set_option(k, v)                    # raises on an unknown key / a value over 47 characters ...
+                self.old[k] = old
+        except Exception:
+            self.__exit__()                         # ... and the keys already set go back (__exit__ is not called then)
+            raise
         return self
 
     def __exit__(self, *exc):

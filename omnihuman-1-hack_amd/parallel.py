@@ -101,7 +101,8 @@ class BucketedGradAllReduce:
     def grad_slot(self, p):
         """fp32 view (the parameter's shape) of ``p``'s slice of its bucket, or None while the bucket's layout is not
         known yet (first step), the parameter was not part of it, or the slice would not be what the next launch
-        expects.  A gradient written there needs no packing."""
+        expects.  A gradient written there needs no packing.  NOTE: such a ``p.grad`` is a view of the persistent bucket —
+        valid until the next backward pass writes the bucket again (copy it to keep a step's gradient for logging)."""
         if self.world == 1 and not self.force:
             return None
         i = self._bucket_of.get(id(p))
@@ -119,8 +120,15 @@ class BucketedGradAllReduce:
         if not self.enabled or (self.world == 1 and not self.force):
             return
         i = self._bucket_of[id(p)]
+        if self._work[i] is not None:
+            # The bucket's collective is already in flight and (with grad_slot) p.grad IS a slice of the buffer that
+            # travels: a second contribution now — the model forwarded twice before one backward, or a backward() without
+            # finish() in between — would be added into that buffer under the collective.  Loud, not silent.
+            raise RuntimeError("BucketedGradAllReduce: a gradient arrived for a bucket whose collective is already in "
+                               "flight (two backward passes without finish() in between, or the model forwarded twice "
+                               "before one backward): wrap all but the last backward in no_sync()")
         self._ready[i].add(id(p))
-        if len(self._ready[i]) == len(self.buckets[i]) and self._work[i] is None:
+        if len(self._ready[i]) == len(self.buckets[i]):
             self._launch(i)
 
     _omh_joins_side_streams = True      # model_train._may_defer_join: this hook orders itself behind the weight-gradient stream

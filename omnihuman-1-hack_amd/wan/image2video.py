@@ -93,7 +93,7 @@ class WanI2V:
         self.patch_size = config.patch_size
         if vae is None:
             vae = WanVAE(vae_pth=os.path.join(checkpoint_dir, config.vae_checkpoint), device=self.device,
-                         dtype=getattr(config, "vae_dtype", torch.bfloat16))    # bf16 operands; torch.float: fp32-faithful
+                         dtype=getattr(config, "vae_dtype", torch.float))     # the reference's arithmetic (text2video.py:81-83, vae.py:619-624); config.vae_dtype = torch.bfloat16 opts into bf16 operands
         self.vae = vae
         if model is None:
             logging.info(f"Creating WanModel from {checkpoint_dir}")

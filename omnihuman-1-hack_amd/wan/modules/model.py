@@ -209,7 +209,9 @@ class WanSelfAttention(nn.Module):
         # two products below, which short sequences / batches keep (their rows fill the chip only together)
         # (tried at S = 1 560 in round 5: one launch instead of two is the same 19.7 ms per single-frame forward, and the
         # batched CFG pair gets slower, 14.8 -> 15.4 ms: one launch per clip against two over both clips)
-        fused = S >= 8192 and S % 8 == 0
+        # (the library takes the one-launch form only when the q|k part is whole 384-column tiles: true at dim 1 536, not
+        # at dim 5 120, where asking for it would cost B launches and a third weight copy for nothing — ADVICE round 5)
+        fused = S >= 8192 and S % 8 == 0 and (2 * d) % 384 == 0
         if fused:
             wqkv, bqkv = self._w_qkv()
             for b in range(B):                         # one launch per clip: V^T is [B, dim, Sp], a clip's rows fill the chip

@@ -419,6 +419,11 @@ def _grad_slots(ctx, model, idx, tgt):
     path does for gradients that already exist.  Same conditions as _grad_targets; {} whenever they do not hold."""
     if tgt is None or not _direct_on(model) or torch.is_grad_enabled():
         return {}
+    st = getattr(ctx, "st", None)
+    if any(o is not st and not o.__dict__.get("bwd_done", False) for o in model.__dict__.get("_omh_live_states", ())):
+        # another forward of this model still awaits its backward (ADVICE round 5): its contribution would be added in
+        # place into a bucket slice whose collective this pass may already have started — no slots, autograd sums
+        return {}
     out, nodes = {}, None
     for n, p in _block_params(model, idx):
         if not p.requires_grad or p.grad is not None or p.dim() != 2 or p.dtype != torch.float32 or (tgt and n in tgt):

@@ -264,8 +264,16 @@ class _ConvState:
             old, old_off = (None, 0) if fresh else (self.buf, self.off)
             frame_bytes = H * W * self.Cin * 2
             window = self._WINDOW_BYTES_F32 if self.f32 else self._WINDOW_BYTES
+            if self.f32 and torch.device(device).type == "cuda":
+                # the 8 GB windows are a trade against FREE memory: next to a DiT, an encoder and
+                # training state a layer takes at most 1/32 of what is left (and never less than the 1 GB of the bf16 mode)
+                free = torch.cuda.mem_get_info(device)[0]
+                window = min(window, max(self._WINDOW_BYTES, free // 32))
             cap = need if not self.hist else max(need, min(self.hist + 8 * max(T, 4), window // frame_bytes))
-            self.buf = torch.empty(cap, H, W, self.Cin, dtype=torch.bfloat16, device=device)
+            try:
+                self.buf = torch.empty(cap, H, W, self.Cin, dtype=torch.bfloat16, device=device)
+            except torch.cuda.OutOfMemoryError:                    # no room for a window: exactly [history | chunk]
+                self.buf = torch.empty(need, H, W, self.Cin, dtype=torch.bfloat16, device=device)
             self.off = 0
             if self.hist:
                 if old is not None:
