@@ -722,7 +722,7 @@ def train_legs(model, device, world, dist):
             out["accumulation_4"]["batch_1"]["autograd_route"] = train_bench(model, device, world, dist, bsz=1, accum=4,
                                                                              direct_accum=False, **ak)
     except Exception as e:
-        out["extra_legs_error"] = repr(e)[:300]
+        out["extra_legs_error"] = repr(e)[:700]
     return out
 
 

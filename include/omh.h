@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define OMH_ABI_VERSION 11
+#define OMH_ABI_VERSION 12
 
 #define OMH_E_BADARG   (-1)   /* null pointer / non-positive size             */
 #define OMH_E_ALIGN    (-2)   /* pointer or leading dimension not aligned     */
@@ -218,6 +218,13 @@ typedef struct omh_attn_args {
        (attention.py:24-60,79-80: queries past q_lens[b] are cut out of the packed varlen batch): output rows
        i >= q_lens[b] are written as ZERO (o, o32; lse = -inf).  Served by the short-sequence kernel, unsplit. */
     const int32_t* q_lens;
+    /* ABI v12: the band of flash_attention(causal=, window_size=(left, right)) (attention.py:24-60,96-127, flash-attn's
+       bottom-right aligned local attention): query i of a sample with qlen = q_lens[b] (or Lq) queries and
+       klen = k_lens[b] (or Lk) keys attends key j iff  i + klen - qlen - window_left <= j <= i + klen - qlen + window_right.
+       A side < 0 is unbounded: (-1, -1) = full attention (the only setting the reference's own callers use; the one
+       the long-sequence stream and the backward serve), causal = (left, 0).  Rows whose band holds no key are written as
+       zero (lse = -inf).  A bounded side selects the short-sequence kernel, unsplit; forward only. */
+    int32_t window_left, window_right;
 } omh_attn_args;
 #define OMH_ATTN_SHORT_KERNEL 1
 #define OMH_ATTN_ALLOW_SPLIT  2

@@ -21,7 +21,7 @@ class OmhError(RuntimeError):
     pass
 
 
-ABI_VERSION = 11         # == OMH_ABI_VERSION of include/omh.h; checked against the loaded library below
+ABI_VERSION = 12         # == OMH_ABI_VERSION of include/omh.h; checked against the loaded library below
 
 
 def _load():
@@ -97,7 +97,14 @@ class AttnArgs(C.Structure):
                 ("q_bs", i64), ("q_rs", i64), ("k_bs", i64), ("k_rs", i64),
                 ("vt_bs", i64), ("o_bs", i64), ("o_rs", i64),
                 ("ldv", i32), ("scale", f32), ("lse", vp), ("q_prescaled", i32), ("workspace", vp), ("workspace_bytes", i64),
-                ("o32", vp), ("flags", i32), ("q_lens", vp)]
+                ("o32", vp), ("flags", i32), ("q_lens", vp), ("window_left", i32), ("window_right", i32)]
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        if len(a) < 26 and "window_left" not in k:      # unbounded band unless the caller says otherwise (0 is a bound)
+            self.window_left = -1
+        if len(a) < 27 and "window_right" not in k:
+            self.window_right = -1
 
 
 class AttnBwdArgs(C.Structure):

@@ -72,6 +72,12 @@ struct AttnSplit {
     float* ws_lse;        // [n_tail][splits][128]      fp32 (-inf: no keys in the worker's range)
 };
 
+// WIN: the reference's flash_attention(causal=..., window_size=(left, right)) (attention.py:24-60,96-127 -> flash-attn's
+// bottom-right aligned band): query i of a sample with qlen queries and klen keys sees key j iff
+//   i + (klen - qlen) - left <= j <= i + (klen - qlen) + right     (a side < 0: unbounded; causal: right = 0);
+// a row with no key in its band is written as zero.  The band limits the workgroup's key-tile range and masks the
+// tiles on its edges; a separate instantiation, so the unlimited kernel keeps its instruction stream.
+template <bool WIN>
 __global__ __launch_bounds__(256, 2)
 void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles, const AttnSplit wk) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (KT_BYTES + VT_BYTES)];
@@ -97,6 +103,21 @@ void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles, const 
     klen = min(max(klen, 0), p.Lk);
     const int n_tiles_all = (klen + KB - 1) / KB;
     int t_first = 0, n_tiles = n_tiles_all;
+    int band_shift = 0;                                   // WIN: key index of the band's centre for query row 0
+    if constexpr (WIN) {
+        int qlen = p.q_lens ? p.q_lens[b] : p.Lq;
+        qlen = min(max(qlen, 0), p.Lq);
+        band_shift = klen - qlen;
+        const int q0 = qt * QB, q1 = min(q0 + QB, qlen) - 1;                  // live query rows of this workgroup
+        const int lo = p.window_left < 0 ? 0 : max(0, q0 + band_shift - p.window_left);
+        const int hi = p.window_right < 0 ? klen - 1 : min(klen - 1, q1 + band_shift + p.window_right);
+        if (q1 < q0 || hi < lo) {
+            n_tiles = 0;
+        } else {
+            t_first = lo / KB;
+            n_tiles = hi / KB - t_first + 1;
+        }
+    }
     if (worker) {
         const int per = (n_tiles_all + wk.splits - 1) / wk.splits;
         t_first = min(split * per, n_tiles_all);
@@ -110,6 +131,11 @@ void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles, const 
     // ---- Q fragments (MFMA B operand): lane (q = li, h) holds Q[q][16kk + 8h .. +7]
     const int q_row = qt * QB + wave * 32 + li;
     const int q_ld = min(q_row, p.Lq - 1);
+    int key_lo = 0, key_hi = klen - 1;                    // WIN: this lane's (query row's) band of keys
+    if constexpr (WIN) {
+        if (p.window_left >= 0) key_lo = max(0, q_row + band_shift - p.window_left);
+        if (p.window_right >= 0) key_hi = min(klen - 1, q_row + band_shift + p.window_right);
+    }
     bf16x8 qf[8];
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk)
@@ -196,7 +222,15 @@ void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles, const 
         }
         // register r of block kb  <->  key kv0 + 32kb + 16(r>>3) + 8h + (r&7)
         const int kv0 = t * KB;
-        if (__builtin_expect(kv0 + KB > klen, 0)) {   // only the last tile of a sequence
+        if constexpr (WIN) {                          // (key_hi <= klen - 1: the band mask covers the sequence end too)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + kb * 32 + ((r >> 3) << 4) + lh * 8 + (r & 7);
+                    if (key < key_lo || key > key_hi) s[kb][r] = -INFINITY;
+                }
+        } else if (__builtin_expect(kv0 + KB > klen, 0)) {   // only the last tile of a sequence
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -220,14 +254,16 @@ void flash_attn_fwd_d128_kernel(const omh_attn_args p, const int q_tiles, const 
         }
         { float a_, b_; xhalf(vmax3(mx, mx2, mx2), a_, b_); mx = a_; mx2 = b_; }
         const float m_new = vmax3(m_run, mx * sc, mx2 * sc);
-        const float alpha = fast_exp2(m_run - m_new);
+        // WIN: a row may have seen no key of its band yet (m_new = -inf): exponentials against 0 then, all of them 0
+        const float m_use = (WIN && m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = fast_exp2(m_run - m_use);
         m_run = m_new;
         float rs = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = fast_exp2(fmaf(s[kb][r], sc, -m_new));
+                const float pv = fast_exp2(fmaf(s[kb][r], sc, -m_use));
                 s[kb][r] = pv;
                 rs += pv;
             }
@@ -362,6 +398,8 @@ void attn_split_combine_kernel(const omh_attn_args p, const int q_tiles, const A
 // attention_w64.hip: 4 waves x 64 query rows, asm-owned register file (long sequences)
 int omh_launch_attn_w64(const omh_attn_args& a, hipStream_t stream);
 
+static inline bool omh_attn_windowed(const omh_attn_args& a) { return a.window_left >= 0 || a.window_right >= 0; }
+
 // Which forward kernel a call takes.  Option ATTN_KERNEL = "w64" / "base": test / benchmarking override (looked up
 // per call — the tests flip it inside one process; a getenv is ~50 ns against ~3.5 us of launch).
 struct AttnChoice { bool w64; };
@@ -374,7 +412,7 @@ static AttnChoice attn_choice(const omh_attn_args& a) {
     const bool fits32 = ((int64_t)a.Lq * a.q_rs * 2 < 0x7fffffffLL) && ((int64_t)a.Lk * a.k_rs * 2 < 0x7fffffffLL) &&
                         ((int64_t)a.Lq * a.o_rs * 2 < 0x7fffffffLL) && ((int64_t)D * a.ldv * 2 < 0x7fffffffLL);
     AttnChoice c;
-    const bool short_only = a.o32 || a.q_lens || (a.flags & OMH_ATTN_SHORT_KERNEL);        // fp32 output / q_lens: base kernel only
+    const bool short_only = a.o32 || a.q_lens || (a.flags & OMH_ATTN_SHORT_KERNEL) || omh_attn_windowed(a);   // fp32 output / q_lens / band: base kernel only
     c.w64 = short_only ? false : (force ? (force[0] == 'w' && fits32) : (big && fits32));
     return c;
 }
@@ -384,7 +422,7 @@ static OmhSplitPlan base_split_plan(const omh_attn_args& a) {
     const int nwg = q_tiles * a.H * a.B;
     OmhSplitPlan none = {nwg, 0, 1};
     const char* e = omh_opt(OMH_OPT_ATTN_SPLIT);                      // "0": never split (A/B timing; tests flip it in-process)
-    if (!(a.flags & OMH_ATTN_ALLOW_SPLIT) || a.q_lens || (e && e[0] == '0')) return none;
+    if (!(a.flags & OMH_ATTN_ALLOW_SPLIT) || a.q_lens || omh_attn_windowed(a) || (e && e[0] == '0')) return none;
     // measured at one clip x 1560 keys: 32.1 -> 24.8 us + 12.8 us of combine (the workers' fp32 results + the bf16 / fp32 /
     // lse outputs are all HBM traffic): the forward's split only pays on long key loops — 16 key tiles per worker, and
     // only launches that do not fill the chip once.  OMH_ATTN_SPLIT=tail: 4 tiles per worker, any launch (tests, A/B).
@@ -428,8 +466,12 @@ extern "C" int omh_flash_attn_fwd_d128(const omh_attn_args* args, omh_stream_t s
         wk.n_regular = pl.n_regular; wk.n_tail = pl.n_tail; wk.splits = pl.splits;
         wk.ws_o = pl.n_tail ? (float*)a.workspace : nullptr;
         wk.ws_lse = pl.n_tail ? wk.ws_o + (int64_t)pl.n_tail * pl.splits * QB * D : nullptr;
-        hipLaunchKernelGGL(flash_attn_fwd_d128_kernel, dim3(pl.n_regular + pl.n_tail * pl.splits), dim3(256), 0,
-                           (hipStream_t)stream, a, q_tiles, wk);
+        if (omh_attn_windowed(a))
+            hipLaunchKernelGGL(flash_attn_fwd_d128_kernel<true>, dim3(pl.n_regular), dim3(256), 0, (hipStream_t)stream, a,
+                               q_tiles, wk);
+        else
+            hipLaunchKernelGGL(flash_attn_fwd_d128_kernel<false>, dim3(pl.n_regular + pl.n_tail * pl.splits), dim3(256), 0,
+                               (hipStream_t)stream, a, q_tiles, wk);
         if (pl.n_tail)
             hipLaunchKernelGGL(attn_split_combine_kernel, dim3((pl.n_tail * QB + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                                a, q_tiles, wk);

@@ -162,12 +162,14 @@ class options:
 
 
 def flash_attn_raw(q, k, vt, o, k_lens, B, H, Lq, Lk, q_bs, q_rs, k_bs, k_rs, vt_bs, o_bs, o_rs, ldv, scale,
-                   lse=None, q_prescaled=0, o32=None, flags=0, q_lens=None):
+                   lse=None, q_prescaled=0, o32=None, flags=0, q_lens=None, window=(-1, -1)):
     """``flags``: ATTN_SHORT_KERNEL | ATTN_ALLOW_SPLIT (include/omh.h, ABI v8): the training step pins the short-sequence
     kernel (forward and re-run take the same one) and lets it split its last round of workgroups over the keys.
-    ``q_lens`` (ABI v10): int32 [B] device pointer; output rows past a sample's query length are written as zero."""
+    ``q_lens`` (ABI v10): int32 [B] device pointer; output rows past a sample's query length are written as zero.
+    ``window`` (ABI v12): (left, right) band around the bottom-right aligned diagonal, a side < 0 unbounded (causal =
+    (left, 0)); a bounded side runs the short-sequence kernel."""
     a = AttnArgs(q, k, vt, o, k_lens, B, H, Lq, Lk, q_bs, q_rs, k_bs, k_rs, vt_bs, o_bs, o_rs, ldv, scale, lse,
-                 int(q_prescaled), None, 0, o32, int(flags), q_lens)
+                 int(q_prescaled), None, 0, o32, int(flags), q_lens, int(window[0]), int(window[1]))
     need = lib.omh_flash_attn_workspace_bytes(C.byref(a))          # split-KV tail (long-sequence kernel; short one if allowed)
     ws = None
     if need > 0:
@@ -177,9 +179,11 @@ def flash_attn_raw(q, k, vt, o, k_lens, B, H, Lq, Lk, q_bs, q_rs, k_bs, k_rs, vt
 
 
 def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, k_lens: Optional[torch.Tensor] = None,
-               scale: Optional[float] = None, out: Optional[torch.Tensor] = None, q_lens: Optional[torch.Tensor] = None):
+               scale: Optional[float] = None, out: Optional[torch.Tensor] = None, q_lens: Optional[torch.Tensor] = None,
+               window=(-1, -1)):
     """q [B,Lq,H,128], k [B,Lk,H,128] bf16; vt [B,H*128,ldv] bf16 (V transposed,
-    ldv >= roundup(Lk,64)); k_lens / q_lens int32 [B] or None.  Returns [B,Lq,H,128] bf16 (rows past q_lens: zero)."""
+    ldv >= roundup(Lk,64)); k_lens / q_lens int32 [B] or None.  Returns [B,Lq,H,128] bf16 (rows past q_lens: zero).
+    ``window`` = (left, right): flash-attn's bottom-right aligned band (causal = (-1, 0)); (-1, -1): full attention."""
     _dev(q, k, vt, k_lens, out, q_lens)
     if q_lens is not None:
         assert q_lens.dtype == torch.int32 and q_lens.numel() == q.shape[0]
@@ -194,7 +198,7 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, k_lens: Optio
         out = torch.empty(B, Lq, H, D, dtype=torch.bfloat16, device=q.device)
     flash_attn_raw(_p(q), _p(k), _p(vt), _p(out), _p(k_lens), B, H, Lq, Lk, q.stride(0), q.stride(1), k.stride(0),
                    k.stride(1), vt.stride(0), out.stride(0), out.stride(1), vt.stride(1),
-                   float(scale if scale is not None else D ** -0.5), q_lens=_p(q_lens))
+                   float(scale if scale is not None else D ** -0.5), q_lens=_p(q_lens), window=window)
     return out
 
 

@@ -121,12 +121,13 @@ class BucketedGradAllReduce:
             return
         i = self._bucket_of[id(p)]
         if self._work[i] is not None:
-            # The bucket's collective is already in flight and (with grad_slot) p.grad IS a slice of the buffer that
-            # travels: a second contribution now — the model forwarded twice before one backward, or a backward() without
-            # finish() in between — would be added into that buffer under the collective.  Loud, not silent.
-            raise RuntimeError("BucketedGradAllReduce: a gradient arrived for a bucket whose collective is already in "
-                               "flight (two backward passes without finish() in between, or the model forwarded twice "
-                               "before one backward): wrap all but the last backward in no_sync()")
+            # Already launched in this pass.  The engine runs a parameter's post-accumulate hooks again after the block
+            # node has told the reducer itself (torch 2.10 fires them for an undefined gradient too — measured,
+            # tools/dbg_train.py), so a repeat is normal and carries no new contribution.  What must never happen is a
+            # SECOND contribution landing in a bucket under its collective: the block nodes therefore take neither a
+            # bucket slot (model_train._grad_slots) nor the in-place route (_grad_targets) while another forward of the
+            # model awaits its backward — autograd then sums the contributions BEFORE this hook fires.
+            return
         self._ready[i].add(id(p))
         if len(self._ready[i]) == len(self.buckets[i]):
             self._launch(i)

@@ -6,7 +6,9 @@ The reference packs variable-length sequences and calls flash-attn's varlen
 kernel; the result is softmax(q k^T * scale) v per head over the first
 ``k_lens[b]`` keys of each sample, for every one of the first ``q_lens[b]``
 query rows (rows past it are zero; ``q_lens`` is never passed by model.py).  This wrapper keeps that contract
-for head_dim 128.  The DiT blocks do not go through it (they hand the kernel
+for head_dim 128, including flash-attn's ``causal`` / ``window_size`` band (bottom-right aligned: query i sees key j
+iff i + klen - qlen - left <= j <= i + klen - qlen + right; rows with an empty band are zero) — forward only, on the
+short-sequence kernel; ``dropout_p`` > 0 is rejected (a random mask has no parity to hold).  The DiT blocks do not go through it (they hand the kernel
 pre-laid-out q / k / V^T buffers); it exists for callers of the reference API.
 """
 import torch
@@ -21,11 +23,20 @@ def flash_attention(q, k, v, q_lens=None, k_lens=None, dropout_p=0., softmax_sca
     """q [B, Lq, N, 128], k/v [B, Lk, N, 128]; returns [B, Lq, N, 128] in q's dtype."""
     assert dtype in (torch.float16, torch.bfloat16)
     assert q.device.type == "cuda" and q.size(-1) <= 256
-    if causal or dropout_p != 0. or tuple(window_size) != (-1, -1):
-        # the reference forwards these to flash-attn (attention.py:96-127) but no caller in the repository sets them
-        # (model.py:151-156,181,221-223): rejected here rather than silently ignored (INTEGRATION.md)
-        raise NotImplementedError("flash_attention on gfx950: causal / window_size / dropout_p are not built "
-                                  "(no caller in the reference uses them); q_lens and k_lens are")
+    if dropout_p != 0.:
+        # the reference forwards it to flash-attn (attention.py:96-127); no caller in the repository sets it
+        # (model.py:151-156,181,221-223) and a random mask cannot be held to parity: rejected, not silently ignored
+        raise NotImplementedError("flash_attention on gfx950: dropout_p > 0 is not built (no caller in the reference "
+                                  "uses it); q_lens, k_lens, causal and window_size are")
+    # flash-attn's window (attention.py:121-126): causal bounds the right side at 0 (flash_attn_varlen_func sets
+    # window_size = (left, 0) for causal=True); a negative side is unbounded
+    wl, wr = int(window_size[0]), int(window_size[1])
+    if causal:
+        wr = 0
+    window = (wl if wl >= 0 else -1, wr if wr >= 0 else -1)
+    if window != (-1, -1) and torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+        raise NotImplementedError("flash_attention on gfx950: causal / window_size are forward-only (the attention "
+                                  "backward streams serve full attention, the only form model.py uses)")
     B, Lq, N, D = q.shape
     Lk = k.shape[1]
     if D != 128:
@@ -42,7 +53,7 @@ def flash_attention(q, k, v, q_lens=None, k_lens=None, dropout_p=0., softmax_sca
     # q_lens (attention.py:55-60,79): the reference cuts the queries past q_lens[b] out of the packed batch — and can only
     # un-flatten the result when every q_lens[b] == Lq (attention.py:110); here those rows come back as zeros
     ql = None if q_lens is None else q_lens.to(device=q.device, dtype=torch.int32).contiguous()
-    o = ops.flash_attn(qb, kb, vt, kl, scale=softmax_scale, q_lens=ql)
+    o = ops.flash_attn(qb, kb, vt, kl, scale=softmax_scale, q_lens=ql, window=window)
     return o.type(out_dtype)
 
 

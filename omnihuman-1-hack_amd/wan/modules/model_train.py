@@ -392,6 +392,11 @@ def _grad_targets(ctx, model, idx):
         return {}
     if not _direct_on(model) or torch.is_grad_enabled():
         return None
+    st = getattr(ctx, "st", None)
+    if any(o is not st and not o.__dict__.get("bwd_done", False) for o in model.__dict__.get("_omh_live_states", ())):
+        # another forward of this model awaits its backward in the same pass: a reducer may launch a bucket after the first
+        # contribution and the second would be added under its collective — autograd's route sums first
+        return None
     ours = False
     for _, p in have:
         if not _direct_usable(p) or getattr(p, "_backward_hooks", None):

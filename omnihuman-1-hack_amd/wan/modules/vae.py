@@ -267,8 +267,11 @@ class _ConvState:
             if self.f32 and torch.device(device).type == "cuda":
                 # the 8 GB windows are a trade against FREE memory: next to a DiT, an encoder and
                 # training state a layer takes at most 1/32 of what is left (and never less than the 1 GB of the bf16 mode)
-                free = torch.cuda.mem_get_info(device)[0]
-                window = min(window, max(self._WINDOW_BYTES, free // 32))
+                # (what the caching allocator holds but has not handed out counts as available: the windows of the
+                # previous decode are exactly that; whole powers of two, so that repeated decodes ask for the same sizes)
+                avail = torch.cuda.mem_get_info(device)[0] + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+                if avail // 32 < window:
+                    window = max(self._WINDOW_BYTES, 1 << max(0, (avail // 32).bit_length() - 1))
             cap = need if not self.hist else max(need, min(self.hist + 8 * max(T, 4), window // frame_bytes))
             try:
                 self.buf = torch.empty(cap, H, W, self.Cin, dtype=torch.bfloat16, device=device)

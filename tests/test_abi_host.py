@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(omh):
         assert hasattr(lib, name), f"{name} declared in include/omh.h but not exported by libomh.so"
     binding = importlib.import_module(PKG + "._lib")
     assert sorted(binding.EXPORTED) == decl, "ctypes signatures out of sync with the header"
-    assert binding.lib.omh_abi_version() == 11 and binding.lib.omh_build_arch() == b"gfx950"
+    assert binding.lib.omh_abi_version() == 12 and binding.lib.omh_build_arch() == b"gfx950"
 
 
 def test_argument_validation_without_gpu(omh):
