@@ -395,6 +395,14 @@ int omh_cfg_unipc_step(const float* cond, const float* uncond, const float* x, c
 int omh_probe_mfma_tflops(int32_t random_operands, int32_t iters, float* scratch, int64_t scratch_floats,
                           float* tflops_out, omh_stream_t stream);
 
+/* ABI v12.  A HIP stream confined to a subset of the CUs (hipExtStreamCreateWithCUMask), for the training step's
+ * second stream (the weight-gradient GEMMs that run beside the backward of distilled_trainer.py:289-301): cus_per_32 of
+ * every 32 consecutive CU-mask bits are enabled, from the low end (high = 0) or the high end (high != 0), so that a
+ * "low k" and a "high 32 - k" stream partition the chip and every XCD contributes equally.  The caller owns the stream
+ * (omh_stream_destroy).  Measurement / scheduling aid: no kernel of the library depends on it. */
+int omh_stream_create_cu_mask(int32_t cus_per_32, int32_t high, omh_stream_t* stream_out);
+int omh_stream_destroy(omh_stream_t stream);
+
 /* ========================================================================
  * 3D causal VAE (seaweed_apt/wan/modules/vae.py).  Activations are
  * channels-last bf16 [T, H, W, C]; a causal conv's temporal history (the

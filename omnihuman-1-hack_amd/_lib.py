@@ -239,6 +239,8 @@ _SIGS = {
     "omh_mul_bf16": (i32, [vp, vp, vp, i64, vp]),
     "omh_vit_embed": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "omh_probe_mfma_tflops": (i32, [i32, i32, vp, i64, vp, vp]),
+    "omh_stream_create_cu_mask": (i32, [i32, i32, vp]),
+    "omh_stream_destroy": (i32, [vp]),
     "omh_cfg_unipc_step": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, i32, f32, f32, f32, f32, f32,
                                  f32, f32, vp]),
 }

@@ -75,3 +75,27 @@ extern "C" int omh_probe_mfma_tflops(int32_t random_operands, int32_t iters, flo
     *tflops_out = (float)((double)grid * 4 * 64.0 * iters * 32768.0 / (ms * 1e-3) * 1e-12);
     return 0;
 }
+
+
+// A HIP stream confined to a subset of the CUs (hipExtStreamCreateWithCUMask): the training step's weight-gradient stream
+// can be kept off the CUs the main stream's latency-critical kernels run on (model_train.OMH_WGRAD_CU_MASK, an A/B
+// switch; measured in DESIGN.md 4.2).  ``cus_per_32``: how many of every 32 consecutive mask bits are set (1..32), taken
+// from the low end (``high`` != 0: from the high end — the complement of a low mask of 32 - cus_per_32) — whatever the
+// driver's bit -> (XCD, CU) interleave is, every XCD then contributes the same number of CUs.
+extern "C" int omh_stream_create_cu_mask(int32_t cus_per_32, int32_t high, omh_stream_t* stream_out) {
+    if (!stream_out || cus_per_32 < 1 || cus_per_32 > 32) return OMH_E_BADARG;
+    const int words = (omh_cu_count() + 31) / 32;
+    uint32_t mask[32];
+    if (words > 32) return OMH_E_SHAPE;
+    uint32_t w = cus_per_32 == 32 ? 0xffffffffu : ((1u << cus_per_32) - 1u);
+    if (high) w <<= (32 - cus_per_32);
+    for (int i = 0; i < words; ++i) mask[i] = w;
+    hipStream_t s = nullptr;
+    const hipError_t err = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
+    if (err != hipSuccess) return -100 - (int)err;
+    *stream_out = (omh_stream_t)s;
+    return 0;
+}
+extern "C" int omh_stream_destroy(omh_stream_t stream) {
+    return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? 0 : OMH_E_BADARG;
+}

@@ -801,6 +801,15 @@ def ema_update(ema, p, decay):
     check(lib.omh_ema_update(_p(ema), _p(p), p.numel(), decay, _stream()), "omh_ema_update")
 
 
+def cu_masked_stream(cus_per_32: int, high: bool = False) -> "torch.cuda.Stream":
+    """A stream confined to ``cus_per_32`` of every 32 CUs (include/omh.h: omh_stream_create_cu_mask), wrapped for torch.
+    The HIP stream lives as long as the process (a handful of them at most: the training step's second stream)."""
+    h = C.c_void_p()
+    check(lib.omh_stream_create_cu_mask(int(cus_per_32), int(bool(high)), C.cast(C.byref(h), C.c_void_p)),
+          "omh_stream_create_cu_mask")
+    return torch.cuda.ExternalStream(h.value, device=torch.device("cuda", torch.cuda.current_device()))
+
+
 def probe_mfma_tflops(random_operands: bool, iters: int = 400) -> float:
     """Measurement only (include/omh.h: omh_probe_mfma_tflops): TFLOP/s of back-to-back bf16 MFMAs, one wave per SIMD."""
     import ctypes as _C

@@ -284,10 +284,21 @@ def _attn_bwd(q, k, v, o, do, lse, lens, B, N, Lq, Lk, scale, out, o32, q_presca
     return out
 
 
+# OMH_WGRAD_CU_MASK = k (1..31): the weight-gradient stream is confined to k of every 32 CUs (hipExtStreamCreateWithCUMask
+# through ops.cu_masked_stream) — an A/B switch for the interference of that stream with the main stream's attention
+# backward (measured and NOT adopted, DESIGN.md 4.2: the default is an ordinary stream).
+_WGRAD_CU_MASK = int(os.environ.get("OMH_WGRAD_CU_MASK", "0") or 0)
+_WG_LATE = os.environ.get("OMH_WG_LATE", "0") == "1"
+
+
 def _side_stream(dev):
     s = _side.get(dev)
     if s is None:
-        s = _side[dev] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("OMH_WGRAD_PRIO", "0")))
+        if 0 < _WGRAD_CU_MASK < 32:
+            with torch.cuda.device(dev):
+                s = _side[dev] = ops.cu_masked_stream(_WGRAD_CU_MASK)
+        else:
+            s = _side[dev] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("OMH_WGRAD_PRIO", "0")))
     return s
 
 
@@ -953,7 +964,10 @@ def _block_backward(model, blk, idx, st, S, dx, P, tgt=None, slots=None):
     wgrad(dy1, o, ["self_attn.o.weight"]), bgrad(dy1, ["self_attn.o.bias"])
     # the cross-attention's weight gradients + the self-attention's o: 3 x 144 full-K tiles + 288 short ones = about one
     # round of the 512 resident 128 x 128 tiles (with q|k|v's 432 tiles in the same launch it would be 2.2 rounds = 3)
-    wg.launch()
+    # OMH_WG_LATE=1 (A/B): not here but together with q|k|v's BEHIND the self-attention backward —
+    # one group of 192 tiles of the k-major stream — so that the attention backward streams have the chip to themselves
+    if not _WG_LATE:
+        wg.launch()
     do = _dgrad(dy1, P["woT"], epilogue=EPI_BF16)
     v = ops.transpose_bf16_batched(S["vt"], Sq)                       # [B*S, d]
     dqkv = bf(R, 3 * d)                                               # dq | dk | dv, one buffer
