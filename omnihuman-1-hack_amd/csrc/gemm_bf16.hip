@@ -493,6 +493,8 @@ int omh_launch_gemm_splitk(const omh_gemm_args& a, int S, hipStream_t stream);
 // ... the fused q | k | v projection: columns below n_split to C, the rest transposed to aux (ABI v10)
 bool omh_gemm_w64_qkv_takes(const omh_gemm_args& a);
 int omh_launch_gemm_w64_qkv(const omh_gemm_args& a, hipStream_t stream);
+bool omh_gemm_w64_p256_takes(const omh_gemm_args& a);
+int omh_launch_gemm_w64_p256(const omh_gemm_args& a, hipStream_t stream);
 
 static int launch_8w(const omh_gemm_args& a, hipStream_t s) {
     switch (a.epilogue) {
@@ -601,6 +603,18 @@ extern "C" int omh_gemm_bf16(const omh_gemm_args* args, omh_stream_t stream) {
         const bool gelu_aux = a.epilogue == OMH_EPI_GELU_BF16 && a.aux && !a.c_in && !(gaux && gaux[0] == '0');
         const bool v5_8w = v5 && !gelu_aux && !(a.epilogue == OMH_EPI_GELU_BWD_BF16 && !a.c_in && gbwd && gbwd[0] == '1');
         const bool force = gk && gk[0] == 'w', never = v5_8w || (gk && gk[0] == '8') || (!force && omh_opt(OMH_OPT_GEMM_TILE));
+        // round 6 experiment (builds with OMH_GW64_P256=1 only; measured slower, never the default): the 256 x 256 streams
+        // with two k tiles of operands in flight in registers (gemm_w64.hip: K_*_P).  GEMM_W64_P256 = "1": wherever they apply.
+        {
+            const char* p2 = omh_opt(OMH_OPT_GEMM_W64_P256);
+            const bool off = (gk && gk[0] == '8') || (!force && omh_opt(OMH_OPT_GEMM_TILE));
+            const bool on = p2 && p2[0] != '0';
+            if (on && !off && !v5 && omh_gemm_w64_p256_takes(a)) {
+                omh_clear_status();
+                omh_launch_gemm_w64_p256(a, s);
+                return omh_launch_status();
+            }
+        }
         // gated residual with a short contraction (o-projections: K = dim): the 256 x 192 stream that requests the old C
         // tile during its k loop.  OMH_GEMM_W64_R192 = 0 / 1 forces it off / on (A/B timing, tests).
         {

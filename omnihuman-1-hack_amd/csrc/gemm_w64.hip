@@ -18,8 +18,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, int64_t
 
 enum { K_F32 = 0, K_BF16 = 1, K_GELU = 2, K_RESID = 3, K_GELUBWD = 4, K_BF16M = 5, K_GELUAUX = 6,
        K_RESID192 = 7, K_F32_192 = 8, K_BF16_192 = 9,                        // K_RESID192 .. K_BF16_192: the 256 x 192 tile
-       K_QKV = 10 };        // 256 x 384: columns < n_split -> C bf16 (the BF16 stream), columns >= n_split -> aux TRANSPOSED (BF16VT)
+       K_QKV = 10,          // 256 x 384: columns < n_split -> C bf16 (the BF16 stream), columns >= n_split -> aux TRANSPOSED (BF16VT)
+       // round 6: 256 x 256, the k loop with two k tiles of operands in flight in registers (gen_gemm_w64.py: main_loop_pgr)
+       K_F32_P = 11, K_BF16_P = 12, K_GELU_P = 13, K_RESID_P = 14,
+       K_ABL_A = 15, K_ABL_B = 16, K_ABL_C = 17, K_ABL_D = 18, K_ABL_E = 19 };      // timing-only ablation builds of K_F32_P
 constexpr bool is_n192(int kind) { return kind >= K_RESID192 && kind <= K_BF16_192; }
+constexpr bool is_p256(int kind) { return kind >= K_F32_P && kind <= K_ABL_E; }
+constexpr int TN256 = 256;
+constexpr int tnw_of(int kind) { return is_n192(kind) ? TN192 : is_p256(kind) ? TN256 : TN; }
 
 // two wave-uniform 32-bit scalars in one SGPR pair (inline asm takes at most 30 operands)
 __device__ __forceinline__ uint64_t pack2(uint32_t lo, uint32_t hi) {
@@ -55,11 +61,12 @@ __device__ __forceinline__ W64Tile w64_tile(const omh_gemm_args& p, int idx, int
 template <int KIND>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int tiles_n, const W64Split sp) {
-    constexpr int TNW = is_n192(KIND) ? TN192 : TN;                         // tile width; a wave owns TNW / 2 columns
+    constexpr int TNW = tnw_of(KIND);                                       // tile width; a wave owns TNW / 2 columns
     constexpr int WBYTES = TNW * 128, STAGE_B = 32768 + WBYTES;             // W tile, one stage (X 32 KiB | W)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_B];
+    // (p256: both stages are filled whole by a tile's prologue, so the epilogue's column vectors get 16 KiB of their own)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_B + (is_p256(KIND) ? 16384 : 0)];
     constexpr int ES = (KIND == K_BF16 || KIND == K_GELU || KIND == K_BF16_192 || KIND == K_GELUBWD || KIND == K_BF16M ||
-                        KIND == K_GELUAUX || KIND == K_QKV) ? 2 : 4;
+                        KIND == K_GELUAUX || KIND == K_QKV || KIND == K_BF16_P || KIND == K_GELU_P) ? 2 : 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1;
@@ -99,7 +106,7 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
     const __amdgpu_buffer_rsrc_t rbias = rsrc_of(p.bias, (p.bias && p.bias_mode == OMH_BIAS_N) ? (int64_t)p.N * 4 : 0);
     // K_BF16M: per-ROW bias (OMH_BIAS_M: the V^T projection, weights in the row slot)
     const __amdgpu_buffer_rsrc_t rbm = rsrc_of(p.bias, (KIND == K_BF16M && p.bias) ? (int64_t)p.M * 4 : 0);
-    constexpr bool RES = KIND == K_RESID || KIND == K_RESID192;
+    constexpr bool RES = KIND == K_RESID || KIND == K_RESID192 || KIND == K_RESID_P;
     const __amdgpu_buffer_rsrc_t rg0 = rsrc_of(p.gate0, (RES && p.gate0) ? (int64_t)p.N * 4 : 0);
     const bool has_g1 = RES && p.gate1 != nullptr;
     const int grows = has_g1 ? p.gate_rows : 1;
@@ -115,10 +122,20 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
     const uint64_t p4 = pack2((uint32_t)(32 * p.ldc * ES), (uint32_t)p.N);
     const uint64_t p6 = pack2((uint32_t)(p.gate1_stride * 4), __float_as_uint(p.gate_const));
     const uint32_t nk = (uint32_t)(p.K / BK);
-    const uint32_t region = lds0 + (uint32_t)(STAGE_B + 32768) + (uint32_t)w * 4096u;   // column vectors: stage 1's W region
+    const uint32_t region = lds0 + (uint32_t)(is_p256(KIND) ? 2 * STAGE_B : STAGE_B + 32768) + (uint32_t)w * 4096u;   // column vectors: stage 1's W region
 
     int idx = blockIdx.x;
     W64Tile t = w64_tile<TNW>(p, idx, tiles_m, tiles_n, w, sp);
+#ifdef OMH_GEMM_W64_ASM_PRO256
+    if (is_p256(KIND)) {
+        const uint64_t p8 = pack2(t.sxb, t.swb);
+        asm volatile(OMH_GEMM_W64_ASM_PRO256
+                     :
+                     : [vox0] "v"(vox0), [vox1] "v"(vox1), [vow0] "v"(vow0), [vow1] "v"(vow1), [ra] "s"(ra), [rb] "s"(rb),
+                       [p0] "{s[60:61]}"(p0), [p2] "{s[64:65]}"(p2), [p8] "{s[76:77]}"(p8)
+                     : "memory", "scc", "s80", "s81", "s82");
+    } else
+#endif
     if (is_n192(KIND)) {
         const uint64_t p8 = pack2(t.sxb, t.swb);
         asm volatile(OMH_GEMM_W64_ASM_PRO192
@@ -220,6 +237,19 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
                      : OMH_GEMM_W64_CLOBBERS);
             }
         }
+#ifdef OMH_GEMM_W64_ASM_PRO256
+        else if (KIND == K_F32_P) OMH_GW64_RUN(OMH_GEMM_W64_ASM_F32_P256);
+        else if (KIND == K_BF16_P) OMH_GW64_RUN(OMH_GEMM_W64_ASM_BF16_P256);
+        else if (KIND == K_GELU_P) OMH_GW64_RUN(OMH_GEMM_W64_ASM_GELU_P256);
+        else if (KIND == K_RESID_P) OMH_GW64_RUN(OMH_GEMM_W64_ASM_RESID_P256);
+#endif
+#ifdef OMH_GEMM_W64_ASM_F32_P256_A
+        else if (KIND == K_ABL_A) OMH_GW64_RUN(OMH_GEMM_W64_ASM_F32_P256_A);
+        else if (KIND == K_ABL_B) OMH_GW64_RUN(OMH_GEMM_W64_ASM_F32_P256_B);
+        else if (KIND == K_ABL_C) OMH_GW64_RUN(OMH_GEMM_W64_ASM_F32_P256_C);
+        else if (KIND == K_ABL_D) OMH_GW64_RUN(OMH_GEMM_W64_ASM_F32_P256_D);
+        else if (KIND == K_ABL_E) OMH_GW64_RUN(OMH_GEMM_W64_ASM_F32_P256_E);
+#endif
         else if (KIND == K_F32_192) OMH_GW64_RUN(OMH_GEMM_W64_ASM_F32_192);
         else if (KIND == K_BF16_192) OMH_GW64_RUN(OMH_GEMM_W64_ASM_BF16_192);
         else
@@ -241,7 +271,7 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
 
 template <int KIND>
 int launch_w64(const omh_gemm_args& a, hipStream_t stream, const W64Split sp = W64Split{1, 0u, 0u}) {
-    constexpr int TNW = is_n192(KIND) ? TN192 : TN;
+    constexpr int TNW = tnw_of(KIND);
     const int tiles_m = (a.M + TM - 1) / TM, tiles_n = (a.N + TNW - 1) / TNW;
     const int total = tiles_m * tiles_n * sp.n;
     static int ncu = 0;
@@ -319,6 +349,45 @@ bool omh_gemm_w64_qkv_takes(const omh_gemm_args& a) {
     return omh_gemm_w64_takes(b);
 }
 int omh_launch_gemm_w64_qkv(const omh_gemm_args& a, hipStream_t stream) { return launch_w64<K_QKV>(a, stream); }
+
+// The 256 x 256 streams whose k loop keeps two k tiles of operands in flight in registers (round 6 EXPERIMENT: compiled
+// only from a gemm_w64_asm.inc generated with OMH_GW64_P256=1; measured slower than the shipped streams and not part of
+// the library — gen_gemm_w64.py, profiles/r06_gemm_p256.txt): the plain epilogues of the big stream, in place.
+bool omh_gemm_w64_p256_takes(const omh_gemm_args& a) {
+#ifndef OMH_GEMM_W64_ASM_PRO256
+    (void)a;
+    return false;
+#else
+    if (a.aux || a.c_in) return false;
+    if (!(a.epilogue == OMH_EPI_F32 || a.epilogue == OMH_EPI_BF16 || a.epilogue == OMH_EPI_GELU_BF16 || a.epilogue == OMH_EPI_RESID))
+        return false;
+    return omh_gemm_w64_takes(a);
+#endif
+}
+int omh_launch_gemm_w64_p256(const omh_gemm_args& a, hipStream_t stream) {
+#ifndef OMH_GEMM_W64_ASM_PRO256
+    (void)a; (void)stream;
+    return OMH_E_SHAPE;
+#else
+#ifdef OMH_GEMM_W64_ASM_F32_P256_A
+    const char* ab = omh_opt(OMH_OPT_GEMM_W64_P256);             // "a".."e": the timing-only ablations (results are garbage)
+    if (ab && a.epilogue == OMH_EPI_F32) switch (ab[0]) {
+        case 'a': return launch_w64<K_ABL_A>(a, stream);
+        case 'b': return launch_w64<K_ABL_B>(a, stream);
+        case 'c': return launch_w64<K_ABL_C>(a, stream);
+        case 'd': return launch_w64<K_ABL_D>(a, stream);
+        case 'e': return launch_w64<K_ABL_E>(a, stream);
+        default: break;
+    }
+#endif
+    switch (a.epilogue) {
+        case OMH_EPI_F32:       return launch_w64<K_F32_P>(a, stream);
+        case OMH_EPI_BF16:      return launch_w64<K_BF16_P>(a, stream);
+        case OMH_EPI_GELU_BF16: return launch_w64<K_GELU_P>(a, stream);
+        default:                return launch_w64<K_RESID_P>(a, stream);
+    }
+#endif
+}
 
 int omh_launch_gemm_w64(const omh_gemm_args& a, hipStream_t stream) {
     switch (a.epilogue) {

@@ -38,11 +38,18 @@ NW = 12                         # W pieces (1 KiB) per wave and k tile: 2 NI
 KINDS = ("f32", "bf16", "gelu", "resid")
 
 
-def configure(ni):
+PGR = False                     # configure(4, pgr=True): the "p256" streams (main_loop_pgr)
+SET = (96, 160)                 # p256: v[96:159] / v[160:223] = the 16 pieces (4 registers each) of a k tile in flight
+VDW = (224, 225)                # p256: LDS write address of the lane in stage 0 / 1 (X region; W: + WOFF)
+
+
+def configure(ni, pgr=False):
     """Tile configuration of the streams generated next: ni = 6 -> 256 x 384 (the default), ni = 3 -> 256 x 192 (the
     "resid192" stream: 12 accumulator tiles per wave, all in AGPRs; v[96:255] + a[192:223] hold the tile's OLD C values,
-    requested during the k loop)."""
-    global NI, STAGE, FB, NW, NTILES
+    requested during the k loop), ni = 4 with ``pgr`` -> 256 x 256, all 16 accumulator tiles in AGPRs and the 128 free
+    registers holding two k tiles of operands IN FLIGHT (main_loop_pgr)."""
+    global NI, STAGE, FB, NW, NTILES, PGR
+    PGR = pgr
     NI = ni
     STAGE = 32768 + ni * 8192
     FB = 4 * ni + 4 * NJ
@@ -162,9 +169,14 @@ def tile_prologue(e, xb, wb):
         for op in ops:
             e(op[1])
     e("s_mov_b32 s80, 128")
-    for ops in all_pieces(1, xb, wb)[:8]:
+    for ops in (all_pieces(1, xb, wb) if PGR else all_pieces(1, xb, wb)[:8]):   # p256: k tile 1 whole (its k loop fetches to registers)
         for op in ops:
             e(op[1])
+
+
+def pro_pieces():
+    """LDS-DMA pieces of a tile's prologue that are younger than k tile 0's."""
+    return 8 + NW if PGR else 8
 
 
 def spread_after(mfmas, extras, start=0, end=None):
@@ -326,6 +338,196 @@ def main_loop(e, epi_vmem, cpre=False):
         e("s_nop 7")                                            # last MFMA results readable by VALU
 
 
+VOX, VOW = 226, 234             # p256: v[226:233] / v[234:241] = the lane's source offset of X / W piece q (swizzle + q row blocks)
+
+
+def load_piece(vset, operand, q):
+    """p256: one 1 KiB piece of a k tile as an ordinary buffer load into registers (piece index: X 0..7, W 8..15); the
+    same source addresses as dma_piece (swizzle on the lane's offset), the piece's row block in a per-piece offset
+    register, the tile's k offset in s81 (X) / s82 (W)."""
+    dst = SET[vset] + 4 * (q if operand == "x" else 8 + q)
+    vo = (VOW if operand == "w" else VOX) + q
+    rs, sreg = ("%[rb]", "s82") if operand == "w" else ("%[ra]", "s81")
+    return ("v", f"buffer_load_dwordx4 {vr(dst, 4)}, v{vo}, {rs}, {sreg} offen{LDMOD}")
+
+
+def write_piece(vset, stage, idx):
+    """p256: piece idx of the k tile held in register set vset -> LDS stage `stage`, where the LDS-DMA would have put it
+    (lane-linear inside the wave's 1 KiB piece)."""
+    off = idx * 1024 if idx < 8 else WOFF + (idx - 8) * 1024
+    return ("w", f"P{idx}", f"ds_write_b128 v{VDW[stage]}, {vr(SET[vset] + 4 * idx, 4)} offset:{off}", idx)
+
+
+LDMOD = ""                      # cache-policy bits of the p256 loads (experiment: " nt", " sc1", ...)
+PABL = ""                       # timing-only ablation of main_loop_pgr (OMH_GEMM_W64_P256 = a..e, tools/gemm_p256_abl.py):
+#   "noload" no global loads, "nowrite" no LDS writes, "nomem" neither, "nobar" no barrier, "noread" no fragment reads
+
+
+def linearize_pgr(e, ops, pending, vm):
+    """linearize + the in-order VMEM counter.  ``vm`` = [loads outstanding that are OLDER than piece 0 of the k tile
+    being written — none — then: loads of that tile and younger ones issued before this op list, loads issued in it]:
+    a ds_write of piece i waits until at most (vm[0] - 1 - i) + vm[1] loads are outstanding."""
+    pending = list(pending)
+    for op in ops:
+        if op[0] == "r":
+            if PABL == "noread":
+                continue
+            e(op[2])
+            pending.append(op[1])
+        elif op[0] == "w":
+            if PABL in ("nowrite", "nomem"):
+                continue
+            if PABL != "noload":
+                e(f"s_waitcnt vmcnt({vm[0] - 1 - op[3] + vm[1]})")
+            e(op[2])
+            pending.append(op[1])
+        elif op[0] == "v":
+            if PABL in ("noload", "nomem"):
+                continue
+            e(op[1])
+            vm[1] += 1
+        elif op[0] == "m":
+            need = [t for t in op[2] if t in pending]
+            if need:
+                last = max(pending.index(t) for t in need)
+                allowed = len(pending) - last - 1
+                e(f"s_waitcnt lgkmcnt({min(allowed, 15)})")
+                pending = pending[last + 1:]
+            e(op[1])
+        else:
+            e(op[1])
+    return pending
+
+
+def slots(mfmas, first_half, second_half):
+    """One extra per MFMA gap: ``first_half`` after MFMAs 0.., ``second_half`` after MFMAs 8.. of the group of 16 (a
+    single wave per SIMD issues in order: a gap with two or three memory instructions is a gap in which the matrix pipe
+    runs dry — measured, tools/gemm_p256_abl.py)."""
+    assert len(mfmas) == 16 and len(first_half) <= 8 and len(second_half) <= 8
+    ops = []
+    for k, m in enumerate(mfmas):
+        ops.append(m)
+        if k < 8 and k < len(first_half):
+            ops.append(first_half[k])
+        if k >= 8 and k - 8 < len(second_half):
+            ops.append(second_half[k - 8])
+    return ops
+
+
+def main_loop_pgr(e, epi_vmem):
+    """The k loop of one 256 x 256 output tile with the operands of two k tiles in flight in REGISTERS.
+
+    The LDS-DMA loop above can only request a k tile when an LDS stage is free for it: 80 of the 160 KiB hold the tile
+    being multiplied, so at most one k tile (less, on average) is on its way, and the W pieces of tile kt+1 have half a
+    k step to arrive.  Here a k tile is 16 ordinary 1 KiB loads per wave into v[96:159] / v[160:223] (the accumulators
+    are all AGPRs), issued TWO steps before the tile is multiplied, and written to the LDS stage one step later, when
+    the stage has been read for the last time: every load has a whole k step (>= 2 048 MFMA cycles) to land.  Every gap
+    between two MFMAs carries exactly ONE memory instruction (64 MFMAs, 32 fragment reads, 16 loads, 16 LDS writes per
+    step).  Step tau on stage s = tau & 1, register set of k tile t = t & 1:
+        groups 0..2  MFMAs kk = 0..2 || gaps 0-7: fragment reads of kk + 1 || gaps 8-15: ds_write of k tile tau+1
+                     (set s^1 -> stage s^1; 16 in 24 gaps) and the 8 W pieces of k tile tau+2 (-> set s)
+        lgkmcnt(0), barrier                      (stage s^1 complete, stage s read for the last time, set s^1 free)
+        group 3      MFMAs kk = 3 || gaps 0-7: fragment reads kk = 0 of stage s^1 || gaps 8-15: the 8 X pieces of k tile
+                     tau+3 (-> set s^1)
+    Same MFMA, same order over k as every other GEMM kernel of the library: identical bits.  The prologue (k tiles 0
+    and 1, LDS-DMA, issued from the previous tile's epilogue) and the epilogues are the LDS-DMA streams'."""
+    unpack(e)
+    for kk in range(4):
+        e(f"v_xor_b32 v112, {kk}, %[xh]")
+        e(f"v_lshl_add_u32 {vr(XA(0, kk))}, v112, 5, %[xab]")
+        e(f"v_lshl_add_u32 {vr(WA(0, kk))}, v112, 5, %[wab]")
+        e(f"v_add_u32 {vr(XA(1, kk))}, {STAGE}, {vr(XA(0, kk))}")
+        e(f"v_add_u32 {vr(WA(1, kk))}, {STAGE}, {vr(WA(0, kk))}")
+    e(f"v_lshl_add_u32 v{VDW[0]}, %[vlane], 4, {S_LDX}")          # the wave's X piece 0 + 16 lane
+    e(f"v_add_u32 v{VDW[1]}, {STAGE}, v{VDW[0]}")
+    for q in range(8):                                          # per-piece source offsets: row block q of the wave's rows
+        e(f"s_mul_i32 s88, {S_SXS}, {q}")
+        e(f"v_add_u32 v{VOX + q}, s88, {'%[vox1]' if q & 1 else '%[vox0]'}")
+        e(f"s_mul_i32 s88, {S_SWS}, {q}")
+        e(f"v_add_u32 v{VOW + q}, s88, {'%[vow1]' if q & 1 else '%[vow0]'}")
+    # the X pieces of k tile 2 (what a step's group 3 does for the step after the next)
+    e(f"s_add_u32 s81, {S_SXB}, 256")
+    n_pre = 0
+    if PABL not in ("noload", "nomem"):
+        for q in range(8):
+            e(load_piece(0, "x", q)[1])
+        n_pre = 8
+    e(f"s_add_u32 s82, {S_SWB}, 256")                           # W pieces: k tile 2 next
+    e(f"s_add_u32 s81, {S_SXB}, 384")                           # X pieces: k tile 3 next
+    e(f"s_waitcnt vmcnt({min(63, 16 + epi_vmem + n_pre)})")      # k tile 0 has landed (in-order counter)
+    e("s_barrier")
+    pend = linearize_pgr(e, frag_reads(0, 0, 0), [], [0, 0])
+    LOOP_PENDING = list(pend)
+    LOOP, DONE = e.lab("loop"), e.lab("done")
+
+    def body(s, first=False, left=3):
+        """``left``: k steps after this one (>= 3: the steady state).  ``first``: step 0 — k tile 1 came by LDS-DMA, there
+        is nothing to write."""
+        wl = [load_piece(s, "w", q) for q in range(8)] if left >= 2 else []             # W pieces of k tile tau+2
+        xl = [load_piece(s ^ 1, "x", q) for q in range(8)] if left >= 3 else []         # X pieces of k tile tau+3
+        wr = [write_piece(s ^ 1, s ^ 1, i) for i in range(16)] if (left >= 1 and not first) else []
+        # second halves of groups 0..2: W W L, W W L, ... (16 writes, 8 loads in 24 gaps)
+        mix = []
+        for k in range(8):
+            mix += wr[2 * k:2 * k + 2] + wl[k:k + 1]
+        mix += [None] * (24 - len(mix))
+        # loads older than piece 0 of the k tile being written do not exist; counted from it: its own 16, the 8 X pieces
+        # of the next k tile (previous step's group 3)
+        vm = [16 + (8 if left >= 2 else 0), 0]
+        pend = LOOP_PENDING
+        for kk in range(3):
+            mf = group_mfmas(kk & 1, first=(first and kk == 0))
+            rd = frag_reads(s, kk + 1, (kk + 1) & 1)
+            pend = linearize_pgr(e, slots(mf, rd, [m for m in mix[8 * kk:8 * kk + 8] if m is not None]), pend, vm)
+        if left == 0:
+            linearize_pgr(e, group_mfmas(1), pend, [0, 0])
+            return
+        if first:
+            e(f"s_waitcnt vmcnt({8 + vm[1]})")                   # k tile 1 (LDS-DMA) is in stage 1: only k tile 2's loads may be out
+        e("s_waitcnt lgkmcnt(0)")
+        if PABL != "nobar":
+            e("s_barrier")
+        if left >= 2:
+            e("s_add_u32 s82, s82, 128")
+        ops = slots(group_mfmas(1), frag_reads(s ^ 1, 0, 0), xl)
+        pend = linearize_pgr(e, ops, [], [0, 0])
+        if left >= 3:
+            e("s_add_u32 s81, s81, 128")
+        assert pend == LOOP_PENDING or PABL == "noread", (pend, LOOP_PENDING)
+
+    def step_check(tail):
+        e(f"s_sub_u32 s83, {S_NK}, s84")                        # k steps left, this one included (>= 3 here)
+        e("s_cmp_eq_u32 s83, 3")
+        e(f"s_cbranch_scc1 {tail}")
+
+    TAIL1, TAIL0 = e.lab("tail1"), e.lab("tail0")
+    body(0, first=True)                                         # k step 0 (K >= 4 k tiles: 3 steps follow)
+    e("s_mov_b32 s84, 1")
+    e.label(LOOP)
+    step_check(TAIL1)
+    body(1)
+    e("s_add_u32 s84, s84, 1")
+    step_check(TAIL0)
+    body(0)
+    e("s_add_u32 s84, s84, 1")
+    e(f"s_branch {LOOP}")
+    e.label(TAIL1)
+    body(1, left=2)
+    body(0, left=1)
+    body(1, left=0)
+    e(f"s_branch {DONE}")
+    e.label(TAIL0)
+    body(0, left=2)
+    body(1, left=1)
+    body(0, left=0)
+    e.label(DONE)
+    e("s_waitcnt vmcnt(0)")
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_barrier")                                              # every wave is done with the LDS stages
+    for _ in range(3):
+        e("s_nop 7")                                            # last MFMA results readable by VALU
+
+
 # ---------------------------------------------------------------- epilogues
 T = 32                       # v[32:47] tile values
 GV, BV = 48, 64              # v[48:63] gate runs (GELU: temporaries), v[64:79] bias runs
@@ -364,7 +566,7 @@ def column_vectors(e, kind):
     e(f"s_cmp_eq_u32 {S_NEXT}, 0")
     e(f"s_cbranch_scc1 {NONE}")
     tile_prologue(e, S_NXB, S_NWB)
-    e(f"s_waitcnt vmcnt({16 + NW})")                              # the column vectors (older than the 16 + NW DMA pieces)
+    e(f"s_waitcnt vmcnt({8 + NW + pro_pieces()})")                # the column vectors (older than the prologue's DMA pieces)
     e(f"s_branch {JOIN}")
     e.label(NONE)
     e("s_waitcnt vmcnt(0)")
@@ -824,11 +1026,14 @@ def generate(kind, tag=None):
     global SWAP
     e = Emit(tag or kind)
     SWAP = kind == "bf16vt"
-    main_loop(e, EPI_VMEM_TILE[kind] * NTILES, cpre=(kind == "resid192"))
+    if PGR:
+        main_loop_pgr(e, EPI_VMEM_TILE[kind] * NTILES)
+    else:
+        main_loop(e, EPI_VMEM_TILE[kind] * NTILES, cpre=(kind == "resid192"))
     SWAP = False
     if kind == "bf16vt":
         epilogue_vt(e)
-    elif kind == "resid":
+    elif kind == "resid" and NI == 6:
         epilogue_resid(e)
     elif kind == "resid192":
         epilogue_resid192(e)
@@ -843,7 +1048,7 @@ def first_prologue(tag="pro"):
     e = Emit(tag)
     unpack(e, (0, 2, 8))
     tile_prologue(e, S_NXB, S_NWB)
-    e("s_waitcnt vmcnt(8)")
+    e(f"s_waitcnt vmcnt({pro_pieces()})")
     return e
 
 
@@ -853,6 +1058,28 @@ def main():
     configure(3)                                                 # the 256 x 192 gated-residual stream (old C prefetched)
     streams += [("PRO192", first_prologue("pro192")), ("RESID192", generate("resid192")),
                 ("F32_192", generate("f32", "f32n3")), ("BF16_192", generate("bf16", "bf16n3"))]
+    # Round 6 experiment, NOT part of the shipped library (the tracked .inc is generated without it): the 256 x 256 streams
+    # with two k tiles in flight in registers (main_loop_pgr).  OMH_GW64_P256=1 generates them (gemm_w64.hip compiles its
+    # K_*_P kinds when the macros exist), OMH_GW64_ABLATIONS=1 adds five timing-only builds of the fp32 one
+    # (OMH_GW64_ABL_SET=ldmod: cache-policy variants of its loads instead).  Measured (profiles/r06_gemm_p256.txt): bit for
+    # bit the shipped kernels' results, 4-12 % SLOWER than the 256 x 384 LDS-DMA streams — the L2 -> CU fill path delivers
+    # ~21 B/clk/CU however early the loads are issued, so bytes per flop (tile area) decide, not prefetch depth.
+    if os.environ.get("OMH_GW64_P256", "0") == "1" or os.environ.get("OMH_GW64_ABLATIONS", "0") == "1":
+        configure(4, pgr=True)
+        streams += [("PRO256", first_prologue("pro256"))] + [(f"{kind.upper()}_P256", generate(kind, f"{kind}p4"))
+                                                             for kind in ("f32", "bf16", "gelu", "resid")]
+    if os.environ.get("OMH_GW64_ABLATIONS", "0") == "1":          # timing-only builds
+        global PABL, LDMOD
+        if os.environ.get("OMH_GW64_ABL_SET", "abl") == "ldmod":
+            for tag, mod in (("A", " nt"), ("B", " sc1"), ("C", " sc0"), ("D", " sc0 sc1"), ("E", " sc1 nt")):
+                LDMOD = mod
+                streams.append((f"F32_P256_{tag}", generate("f32", f"f32p4{tag.lower()}")))
+            LDMOD = ""
+        else:
+            for tag, abl in (("A", "noload"), ("B", "nowrite"), ("C", "nomem"), ("D", "nobar"), ("E", "noread")):
+                PABL = abl
+                streams.append((f"F32_P256_{tag}", generate("f32", f"f32p4{tag.lower()}")))
+            PABL = ""
     configure(6)
     for name, e in streams:
         print(f"#define OMH_GEMM_W64_ASM_{name} \\")
