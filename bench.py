@@ -412,8 +412,8 @@ def encoders_bench(device):
 
 def single_frame_bench(model, device, iters=20):
     """BASELINE config 1 on the GPU: the CFG teacher pair of generate.py:205-229 — two DiT forwards on one
-    [16,1,60,104] latent (S = 1560, t = 999) + v = u + 7.5 (c - u) — as eager launches and as hipGraph replays."""
-    graphs = importlib.import_module(PKG + ".graphs")
+    [16,1,60,104] latent (S = 1560, t = 999) + v = u + 7.5 (c - u) — as two forwards and as one forward on a batch of two.
+    (hipGraph replays of either measured exactly the eager time in rounds 1-6 and were removed with graphs.py.)"""
     g = torch.Generator(device=device).manual_seed(11)
     x = [torch.randn(16, 1, 60, 104, device=device, generator=g)]
     t = torch.tensor([999.0], device=device)
@@ -437,17 +437,6 @@ def single_frame_bench(model, device, iters=20):
     te, ve = timed(eager)
     res = {"workload": "CFG teacher pair: 2 DiT forwards at S=1560 + guidance combine",
            "eager_ms": round(te * 1e3, 3)}
-    try:
-        gc, gu = graphs.GraphedForward(model, x, t, st_c, 1560), graphs.GraphedForward(model, x, t, st_u, 1560)
-
-        def graphed():
-            c, u = gc(x, t)[0], gu(x, t)[0]
-            return torch.add(u, c - u, alpha=7.5)
-        tg, vg = timed(graphed)
-        res.update({"hipgraph_ms": round(tg * 1e3, 3), "hipgraph_equals_eager": bool(torch.equal(vg, ve))})
-    except Exception as e:
-        tg = None
-        res["hipgraph_error"] = repr(e)[:200]
     # the same pair as ONE forward on a batch of two (cond and uncond share x and t): twice the rows per launch
     try:
         st_cu = model.encode_context([st_c_ctx, st_u_ctx])
@@ -462,19 +451,7 @@ def single_frame_bench(model, device, iters=20):
     except Exception as e:
         tb = None
         res["batched_error"] = repr(e)[:200]
-    tbg = None
-    if tb:                                                      # ... and that forward as one hipGraph replay
-        try:
-            gb = graphs.GraphedForward(model, x2, t2, st_cu, 1560)
-
-            def batched_graphed():
-                c, u = gb(x2, t2)
-                return torch.add(u, c - u, alpha=7.5)
-            tbg, vbg = timed(batched_graphed)
-            res.update({"batched_hipgraph_ms": round(tbg * 1e3, 3), "batched_hipgraph_equals_batched": bool(torch.equal(vbg, vb))})
-        except Exception as e:
-            res["batched_hipgraph_error"] = repr(e)[:200]
-    best = min(v for v in (te, tg, tb, tbg) if v)
+    best = min(v for v in (te, tb) if v)
     fl = 2 * dit_forward_flops(1560)
     res.update({"pairs_per_s": round(1 / best, 2), "achieved_tflops": round(fl / best / 1e12, 1),
                 "mfma_roofline_frac": round(fl / best / 1e12 / PEAK_BF16_TFLOPS, 4)})
@@ -556,21 +533,7 @@ def train_bench(model, device, world, dist, steps=20, warmup=3, bsz=4, ffn_freez
         opt.zero_grad(set_to_none=True)
         return loss
 
-    # OMH_TRAIN_GRAPH=1 replays the step as one hipGraph (graphs.py), all-reduce + AdamW after the replay.  Measured
-    # (profiles/r01_graph_vs_eager_probe.json): replay time = eager time (87.8 / 87.8 ms at 1 clip, 217 / 217 ms at
-    # 4) — the ~4 600 short kernels per clip are executed back to back by the GPU either way, the host is not the
-    # limit — so the default stays eager, which also keeps the all-reduce overlapped with the backward.
     one, mode = one_eager, "eager launches"
-    if os.environ.get("OMH_TRAIN_GRAPH", "0") == "1":
-        graphs = importlib.import_module(PKG + ".graphs")
-        try:
-            gstep = graphs.GraphedTrainingStep(model, batch, optimizer=opt, reducer=red, num_train_timesteps=1000,
-                                               reference_loss_quirk=loss_quirk)
-            one, mode = (lambda timed=False: gstep(batch)), "hipGraph replay of fwd+recompute+bwd, then all-reduce + AdamW"
-        except Exception as e:          # keep the leg alive on a capture failure, and say so
-            mode = f"eager launches (hipGraph capture failed: {repr(e)[:160]})"
-            for p in model.parameters():
-                p.grad = None
 
     for _ in range(warmup):
         one()
@@ -768,8 +731,11 @@ def main():
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-single-frame", action="store_true")
     ap.add_argument("--no-encoders", action="store_true")
-    ap.add_argument("--cfg", choices=["batched", "two", "split"], default="two",
-                    help="split: ranks (2i, 2i+1) share ONE clip, one CFG branch each + one all-gather per step "
+    ap.add_argument("--cfg", choices=["batched", "two", "independent", "split"], default="two",
+                    help="two (default): cond + uncond of a step through WanModel.forward_cfg_pair, what WanT2V.generate runs "
+                         "at this length — two batch-1 forwards that compute block 0's self-attention sub-layer (inputs: x and "
+                         "t alone) once, the same bits as two calls; independent: two plain forward() calls (rounds 1-5); "
+                         "split: ranks (2i, 2i+1) share ONE clip, one CFG branch each + one all-gather per step "
                          "(parallel.CFGPairSplit, SURVEY.md 8e; needs an even --gpus; value = clips in flight x steps/s). "
                          "cond+uncond of a step as two batch-1 forwards (default: one roofline launch = one clip's "
                          "self-attention, comparable across rounds) or as one batch-2 forward as WanT2V.generate does "
@@ -895,6 +861,9 @@ def main():
                 c, u = split.exchange(model([x], t, st_c if split.runs_conditional else st_u, seq_len)[0])
             elif nb == 2:
                 c, u = model([x, x], torch.cat([t, t]), st_cu, seq_len)
+            elif args.cfg == "two":
+                c, u = model.forward_cfg_pair([x], t, st_c, st_u, seq_len)
+                c, u = c[0], u[0]
             else:
                 c = model([x], t, st_c, seq_len)[0]
                 u = model([x], t, st_u, seq_len)[0]
@@ -954,6 +923,8 @@ def main():
     lc_eff = 0.5 * (ctx.shape[0] + ctx_null.shape[0])
     executed_flops = fwd_flops - 30 * (4 * 512 * 1536 * 1536 + 4 * seq_len * (512 - lc_eff) * 1536) \
         - 2 * 512 * (4096 * 1536 + 1536 * 1536)
+    if args.cfg == "two":          # forward_cfg_pair: block 0's self-attention sub-layer once per PAIR of forwards
+        executed_flops -= 0.5 * (8.0 * seq_len * 1536 * 1536 + 4.0 * seq_len * seq_len * 1536)
     attn_ms = timer.avg_ms()
     attn_flops = 4.0 * seq_len * seq_len * 1536 * nb             # one launch covers the batch
     roofline = None
@@ -1160,7 +1131,12 @@ def main():
                             f"CFG/UniPC update, "
                             + ("one clip per PAIR of GPUs (one CFG branch per rank, one all-gather per step)"
                                if split is not None else "one clip per GPU"
-                               + (" (cond+uncond as one batch-2 forward)" if nb == 2 else " (two batch-1 forwards)")),
+                               + (" (cond+uncond as one batch-2 forward)" if nb == 2 else
+                                  " (two batch-1 forwards sharing block 0's self-attention sub-layer: forward_cfg_pair)"
+                                  if args.cfg == "two" else " (two independent batch-1 forwards)")),
+                "cfg_pair": {"two": "forward_cfg_pair: embeddings + block 0 self-attention computed once per step (exact)",
+                             "independent": "two forward() calls", "batched": "one batch-2 forward",
+                             "split": "one branch per rank"}[args.cfg],
                 "weights": "random-init (xavier) Wan2.1-T2V-1.3B architecture",
                 "parallelism": ("cfg-split: one clip per pair of GPUs, %d pair(s)" % (world // 2)) if split is not None
                                else "dp%d: replicas, one clip per GPU, no data-path collective" % world,

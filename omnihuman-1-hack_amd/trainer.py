@@ -26,8 +26,7 @@ def teacher_cfg_velocity(model, noise, t, context, context_null, guide_scale: fl
 def forward_backward(batch, distilled_model, num_train_timesteps=1000, gradient_accumulation_steps=1, loss_scale=1.0,
                      reference_loss_quirk=True):
     """The device side of ``training_step``: forward, loss, backward; returns the (accumulation-divided) loss as
-    a 0-d device tensor without reading it back, so the whole function can be captured into a hipGraph
-    (graphs.GraphedTrainingStep)."""
+    a 0-d device tensor without reading it back (no host synchronisation inside a step)."""
     noise, context, v_teacher = batch
     device = next(distilled_model.parameters()).device
     noise, context, v_teacher = noise.to(device), context.to(device), v_teacher.to(device)

@@ -182,10 +182,16 @@ class WanI2V:
             # cond / uncond as one forward on a batch of two where the operands stay below the kernels' 2 GiB limit
             # (see WanT2V.generate); bit-identical to two calls
             batched = batched_cfg and 2 * (max_seq_len + 128) * getattr(self.model, "ffn_dim", 0) * 2 < 0x7fffffff
+            # long sequences: the pair that shares block 0's self-attention sub-layer (see WanT2V.generate)
+            pair = cfg_split is None and max_seq_len >= 8192
             if cfg_split is not None:
                 batched = False
                 mine = self.model.encode_context([context[0]] if cfg_split.runs_conditional else context_null,
                                                  clip_fea=clip_context)
+            elif pair:
+                batched = False
+                arg_c = self.model.encode_context([context[0]], clip_fea=clip_context)
+                arg_null = self.model.encode_context(context_null, clip_fea=clip_context)
             elif batched:
                 both = self.model.encode_context([context[0], context_null[0]],
                                                  clip_fea=torch.cat([clip_context, clip_context]))
@@ -196,6 +202,10 @@ class WanI2V:
                 if cfg_split is not None:
                     cond, uncond = cfg_split.exchange(self.model(
                         [latent], t=torch.stack([t]).to(self.device), context=mine, seq_len=max_seq_len, y=[y])[0])
+                elif pair:
+                    cond, uncond = self.model.forward_cfg_pair([latent], torch.stack([t]).to(self.device), arg_c, arg_null,
+                                                               max_seq_len, y=[y])
+                    cond, uncond = cond[0], uncond[0]
                 elif batched:
                     cond, uncond = self.model([latent, latent], t=torch.stack([t, t]).to(self.device), context=both,
                                               seq_len=max_seq_len, y=[y, y])

@@ -60,13 +60,7 @@ def rope_params(max_seq_len, dim, theta=10000):
 
 
 class _Packed:
-    """bf16 copies of weights, rebuilt when the source parameter changes.
-
-    ``always_rebuild`` (set by graphs.py while a training step is captured into a hipGraph): every lookup runs
-    its builder, so the packing kernels are nodes of the graph and each replay re-packs the weights the
-    optimizer has just updated — a host-side version check cannot run inside a replay."""
-
-    always_rebuild = False
+    """bf16 copies of weights, rebuilt when the source parameter changes."""
 
     def __init__(self):
         self.store = {}
@@ -74,7 +68,7 @@ class _Packed:
     def get(self, key, params, builder):
         sig = tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
         ent = self.store.get(key)
-        if ent is None or ent[0] != sig or _Packed.always_rebuild:
+        if ent is None or ent[0] != sig:
             with torch.no_grad():
                 ent = (sig, builder())
             self.store[key] = ent
@@ -367,8 +361,9 @@ class WanAttentionBlock(nn.Module):
                                 lambda: (_bf16(lin.weight), lin.bias.detach().float().contiguous()))
 
     def forward(self, x, e, seq_lens, grid_sizes, freqs, context, context_lens, block_idx=0,
-                _fc: Optional["_FwdCtx"] = None):
-        """x fp32 [B, L, C] residual stream (updated and returned), e fp32 [B, 6, C]."""
+                _fc: Optional["_FwdCtx"] = None, _part: str = "all"):
+        """x fp32 [B, L, C] residual stream (updated and returned), e fp32 [B, 6, C].
+        ``_part`` (WanModel.forward_cfg_pair): "self" = the self-attention sub-layer only, "rest" = what follows it."""
         assert e.dtype == torch.float32
         B, S, d = x.shape
         fc = _fc or _make_ctx_for_block(self, x, e, seq_lens, grid_sizes, freqs, context, context_lens)
@@ -401,11 +396,14 @@ class WanAttentionBlock(nn.Module):
                              gate_const=0.0, split_k=fc.split_k)
 
         # ---- self-attention: x += o(attn(LN(x)(1+e1)+e0)) * e2        model.py:292-296
-        h = ln_mod(0, 1)
-        o = self.self_attn._attend(h, fc)
-        wo, bo = self.self_attn._w("o")
-        resid(o, wo, bo, 2)
-        del h, o
+        if _part != "rest":
+            h = ln_mod(0, 1)
+            o = self.self_attn._attend(h, fc)
+            wo, bo = self.self_attn._w("o")
+            resid(o, wo, bo, 2)
+            del h, o
+            if _part == "self":
+                return x
         # ---- cross-attention: x += o(attn(norm3(x), context))          model.py:313
         h = torch.empty(R, d, dtype=torch.bfloat16, device=x.device)
         if self.cross_attn_norm:
@@ -683,10 +681,23 @@ class WanModel(nn.Module):
         e = ops.dense_f32(ops.dense_f32(sin, te0.weight.detach().float(), te0.bias.detach().float(), 0, 1),
                           te2.weight.detach().float(), te2.bias.detach().float(), 0, 0)
         e0 = ops.dense_f32(e, tp1.weight.detach().float(), tp1.bias.detach().float(), 1, 0).view(B, 6, d)
-        # ---- text (+ image) embedding                                           model.py:531-537
+        fc = _FwdCtx()
+        fc.B, fc.S, fc.dim = B, seq_len, d
+        fc.split_k = not getattr(self, "batch_invariant", False)
+        fc.e0 = e0.contiguous()
+        fc.seq_lens32 = _dev_ints(lens, torch.int32, device)
+        fc.grid32 = _dev_ints(grids, torch.int32, device)
+        fc.rope_cos, fc.rope_sin = self._rope(device)
+        fc.seq_lens_host = list(lens)                                       # host copies: no device sync later
+        ctx_lens = self._attach_context(fc, context, clip_fea, extra_conditions)
+        return xs, e, fc, grids, lens, ctx_lens
+
+    def _attach_context(self, fc, context, clip_fea=None, extra_conditions=None):
+        """The context-dependent fields of a forward's shared state: text (+ image) embedding, model.py:531-537."""
+        device = self.patch_embedding.weight.device
         state = context if isinstance(context, ContextState) else None
         if state is not None:
-            if state.model_id != id(self) or state.version != self._context_signature() or state.B != B:
+            if state.model_id != id(self) or state.version != self._context_signature() or state.B != fc.B:
                 raise ValueError("ContextState does not belong to this model / batch or the weights changed since "
                                  "encode_context(): call encode_context() again")
             ctx, ctx_lens = state.ctx, list(state.ctx_lens)
@@ -694,18 +705,11 @@ class WanModel(nn.Module):
                 raise ValueError("pass extra condition tokens to encode_context(), not next to a ContextState")
         else:
             ctx, ctx_lens = self._embed_context(context, clip_fea, extra_conditions)
-        fc = _FwdCtx()
-        fc.B, fc.S, fc.dim = B, seq_len, d
-        fc.split_k = not getattr(self, "batch_invariant", False)
-        fc.e0 = e0.contiguous()
-        fc.seq_lens32 = _dev_ints(lens, torch.int32, device)
-        fc.grid32 = _dev_ints(grids, torch.int32, device)
         fc.ctx_lens32 = _dev_ints(ctx_lens, torch.int32, device)
-        fc.rope_cos, fc.rope_sin = self._rope(device)
         fc.ctx, fc.Lc = ctx, ctx.shape[1]
         fc.kv = state.kv if state is not None else None
-        fc.seq_lens_host, fc.ctx_lens_host = list(lens), list(ctx_lens)     # host copies: no device sync later
-        return xs, e, fc, grids, lens, ctx_lens
+        fc.ctx_lens_host = list(ctx_lens)
+        return ctx_lens
 
     def _embed_context(self, context, clip_fea=None, extra_tokens=None):
         """text_embedding (and img_emb) of zero-padded contexts: bf16 [B, (257+ | Ne+)text_len, dim] and true lengths."""
@@ -773,6 +777,37 @@ class WanModel(nn.Module):
             xs = block(xs, fc.e0, seq_lens, grid_sizes, freqs, fc.ctx, context_lens, block_idx=i, _fc=fc)
         out = self.head(xs, e)                                   # fp32 [B, seq_len, prod(patch)*out_dim]
         return self.unpatchify(out, grid_sizes, _grids=grids)
+
+    @torch.no_grad()
+    def forward_cfg_pair(self, x, t, context, context_null, seq_len, clip_fea=None, y=None):
+        """The two forwards of a classifier-free-guided step — ``forward(x, t, context, ...)`` and ``forward(x, t,
+        context_null, ...)`` on the SAME latents and timestep (text2video.py:238-241, generate.py:205-229) — with what
+        they share computed once: the patch / time embedding and block 0's self-attention sub-layer (LayerNorm + modulate,
+        q | k | v, RoPE, self-attention, o-projection: its inputs are x and t alone; the context enters at block 0's
+        cross-attention).  Everything after that point runs per branch, with the launches of a batch-of-one forward, so
+        both results equal the two separate calls BIT FOR BIT (the kernels are deterministic); at S = 32 760 it is one
+        self-attention launch of 60 less per step.  Inference only; contexts may be ContextStates.
+        Returns (list of cond outputs, list of uncond outputs)."""
+        xs, e, fc, grids, lens, ctx_lens = self._embed(x, t, context, seq_len, clip_fea, y)
+        seq_lens = _dev_ints(lens, torch.long, xs.device)
+        grid_sizes = _dev_ints(grids, torch.long, xs.device)
+        freqs = (fc.rope_cos, fc.rope_sin)
+        blk0 = self.blocks[0]
+        # (no module __call__ here: a forward hook on block 0 fires once per branch, below, with the block's full output)
+        xs = blk0.forward(xs, fc.e0, seq_lens, grid_sizes, freqs, fc.ctx, None, block_idx=0, _fc=fc, _part="self")
+        fc_u = _FwdCtx()
+        for name in _FwdCtx.__slots__:
+            if hasattr(fc, name):
+                setattr(fc_u, name, getattr(fc, name))
+        self._attach_context(fc_u, context_null, clip_fea)
+        outs = []
+        for f, xb in ((fc, xs.clone()), (fc_u, xs)):
+            context_lens = _dev_ints(f.ctx_lens_host, torch.long, xs.device)
+            for i, block in enumerate(self.blocks):
+                xb = block(xb, f.e0, seq_lens, grid_sizes, freqs, f.ctx, context_lens, block_idx=i, _fc=f,
+                           _part="rest" if i == 0 else "all")
+            outs.append(self.unpatchify(self.head(xb, e), grid_sizes, _grids=grids))
+        return outs[0], outs[1]
 
     def unpatchify(self, x, grid_sizes, _grids=None):
         """model.py:565-588 — 'fhwpqrc->cfphqwr' per sample."""

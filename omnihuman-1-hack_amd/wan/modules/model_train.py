@@ -219,7 +219,7 @@ class TrainPacks:
             self._layout(model)
             self.key, self.ptrs, self.sig = (freeze, str(dev)), [p.data_ptr() for p in self.params], None
         sig = [p._version for p in self.params]
-        if self.sig is None or _model_mod._Packed.always_rebuild:  # (under hipGraph capture the launch is a graph node)
+        if self.sig is None:
             ops.pack_weights_multi(self.table, self.n, self.total_tiles)
         elif sig != self.sig:
             # only what the optimizer touched: the FFNs the reference's quirk freezes (523 M of the 1.3B model's

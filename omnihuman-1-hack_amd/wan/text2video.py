@@ -126,9 +126,16 @@ class WanT2V:
             # batch of two (same kernels on twice the rows, bit-identical outputs) unless that would push a GEMM
             # operand past the kernels' 2 GiB limit (14B at 720p); ``batched_cfg=False`` keeps two calls.
             batched = batched_cfg and 2 * (seq_len + 128) * getattr(self.model, "ffn_dim", 0) * 2 < 0x7fffffff
+            # Long sequences (every launch fills the chip with one clip's rows): the two forwards as a PAIR that computes
+            # what they share — embeddings and block 0's self-attention sub-layer, whose inputs are x and t alone — once
+            # (WanModel.forward_cfg_pair: the same bits as two calls, one self-attention launch of 60 less per step)
+            pair = cfg_split is None and seq_len >= 8192
             if cfg_split is not None:
                 batched = False
                 mine = self.model.encode_context(context if cfg_split.runs_conditional else context_null)
+            elif pair:
+                batched = False
+                context, context_null = self.model.encode_context(context), self.model.encode_context(context_null)
             elif batched:
                 both = self.model.encode_context([context[0], context_null[0]])
             else:
@@ -137,6 +144,9 @@ class WanT2V:
                 if cfg_split is not None:
                     cond, uncond = cfg_split.exchange(
                         self.model(latents, t=torch.stack([t]), context=mine, seq_len=seq_len)[0])
+                elif pair:
+                    cond, uncond = self.model.forward_cfg_pair(latents, torch.stack([t]), context, context_null, seq_len)
+                    cond, uncond = cond[0], uncond[0]
                 elif batched:
                     cond, uncond = self.model([latents[0], latents[0]], t=torch.stack([t, t]), context=both,
                                               seq_len=seq_len)

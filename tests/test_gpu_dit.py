@@ -255,3 +255,68 @@ def test_fused_qkv_projection_in_the_forward_changes_no_bit(wan_model_mod):
     set_option("GEMM_QKV", "0")
     plain = m([x], t, [c], 9360)[0]
     assert torch.isfinite(fused).all() and torch.equal(fused, plain)
+
+
+def test_cfg_pair_shares_block_0_self_attention_and_changes_no_bit(wan_model_mod):
+    """WanModel.forward_cfg_pair (round 6): the conditional and the unconditional forward of a CFG step on the same
+    latents and timestep (text2video.py:238-241, generate.py:205-229) share everything that does not see the context —
+    the embeddings and block 0's self-attention sub-layer — and must equal two forward() calls BIT FOR BIT: t2v with raw
+    contexts and with ContextStates, i2v with y / clip_fea, a two-clip batch with unequal grids, a sequence past the
+    long-sequence threshold (fused q | k | v + the attention stream); the shared sub-layer is launched once, block
+    forward hooks fire once per branch with the block's full output."""
+    from oracle import wan_dit_oracle as O, make_golden
+    ops = __import__("importlib").import_module(wan_model_mod.__name__.rsplit(".", 3)[0] + ".ops")
+    cfg = O.DiTConfig(dim=256, ffn_dim=512, num_heads=2, num_layers=3, text_dim=64, text_len=32, freq_dim=64)
+    m = wan_model_mod.WanModel(dim=256, ffn_dim=512, num_heads=2, num_layers=3, text_dim=64, text_len=32, freq_dim=64)
+    m.load_state_dict(O.synth_state_dict(cfg, "ctxstate"))
+    m = m.cuda().eval().requires_grad_(False)
+    xs, ctx = _inputs(cfg, [(2, 3, 4), (1, 2, 3)], [32, 11], "pair")
+    xs = [u.cuda() for u in xs]
+    ctx = [c.cuda() for c in ctx]
+    null = [c[:5].clone() * 0.5 for c in ctx]
+    t = torch.tensor([999., 250.]).cuda()
+    want_c, want_u = m(xs, t, ctx, 30), m(xs, t, null, 30)
+    calls = {"self": 0}
+    raw = ops.flash_attn_raw
+
+    def counting(*a, **k):
+        calls["self"] += int(a[7] == a[8] == 30)                 # Lq == Lk == seq_len: a self-attention launch
+        return raw(*a, **k)
+    taps = []
+    hook = m.blocks[0].register_forward_hook(lambda mod, i, o: taps.append(o.clone()))
+    try:
+        ops.flash_attn_raw = counting
+        got_c, got_u = m.forward_cfg_pair(xs, t, ctx, null, 30)
+    finally:
+        ops.flash_attn_raw = raw
+        hook.remove()
+    assert calls["self"] == 2 * 3 - 1                            # block 0's once, blocks 1, 2 once per branch
+    assert len(taps) == 2 and not torch.equal(taps[0], taps[1])  # one hook call per branch, with that branch's output
+    for a, b in zip(got_c + got_u, want_c + want_u):
+        assert torch.equal(a, b)
+    st_c, st_u = m.encode_context(ctx), m.encode_context(null)
+    got_c, got_u = m.forward_cfg_pair(xs, t, st_c, st_u, 30)
+    for a, b in zip(got_c + got_u, want_c + want_u):
+        assert torch.equal(a, b)
+    # i2v: y and clip_fea ride along
+    cfg_i, tag, xi, ci, tt, seq_i, ys, clip = make_golden.tiny_case("i2v", 2)
+    mi = wan_model_mod.WanModel(model_type="i2v", in_dim=36, num_layers=2, **make_golden.TINY)
+    mi.load_state_dict(O.synth_state_dict(cfg_i, tag))
+    mi = mi.cuda().eval().requires_grad_(False)
+    xi, ci, ys, clip = [u.cuda() for u in xi], [c.cuda() for c in ci], [u.cuda() for u in ys], clip.cuda()
+    c0 = [c[:3] * 0.25 for c in ci]
+    a_c, a_u = mi.encode_context(ci, clip_fea=clip), mi.encode_context(c0, clip_fea=clip)
+    want = mi(xi, tt.cuda(), a_c, seq_i, y=ys), mi(xi, tt.cuda(), a_u, seq_i, y=ys)
+    got = mi.forward_cfg_pair(xi, tt.cuda(), a_c, a_u, seq_i, y=ys)
+    assert all(torch.equal(p, q) for p, q in zip(got[0] + got[1], want[0] + want[1]))
+    g = torch.Generator().manual_seed(5)
+    # past the long-sequence threshold: S = 2 x 64 x 68 = 8 704 >= 8 192 (fused q | k | v, the attention stream where it applies)
+    cfg_l = O.DiTConfig(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64, text_len=32, freq_dim=64)
+    ml = wan_model_mod.WanModel(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64, text_len=32, freq_dim=64)
+    ml.load_state_dict(O.synth_state_dict(cfg_l, "pairlong"))
+    ml = ml.cuda().eval().requires_grad_(False)
+    xl = [torch.randn(16, 2, 128, 136, generator=g).cuda()]
+    tl = torch.tensor([321.]).cuda()
+    w_c, w_u = ml(xl, tl, ctx[:1], 8704)[0], ml(xl, tl, null[:1], 8704)[0]
+    g_c, g_u = ml.forward_cfg_pair(xl, tl, ctx[:1], null[:1], 8704)
+    assert torch.equal(g_c[0], w_c) and torch.equal(g_u[0], w_u) and not torch.equal(w_c, w_u)
