@@ -949,7 +949,7 @@ def main():
                     round(ach / telemetry["mfma_peak_at_mean_clock_tflops"], 4), "traffic": traffic,
                     "traffic_source": None if traffic is None else
                     "NOT a counter of this run: HBM-side bytes per launch of this kernel from separate rocprofv3 --pmc "
-                    "passes (2 x FETCH_SIZE + WRITE_SIZE, tools/pmc_attn.sh), recorded in profiles/traffic_latest.json "
+                    "passes (2 x FETCH_SIZE + WRITE_SIZE; tools/r06_pmc.sh), recorded in profiles/traffic_latest.json "
                     "(" + str(tsrc) + ")",
                     "launches_timed": len(timer.pairs), "avg_launch_ms": round(attn_ms, 4),
                     "algorithmic_flops_per_launch": attn_flops}
