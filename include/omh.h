@@ -55,7 +55,8 @@ int omh_set_deterministic(int on);
  * (one product on every kernel that can take it) and by A/B timing — is an entry of one table:
  *   ATTN_KERNEL ("w64" / "base")   ATTN_SPLIT ("0" / "tail")   W64_SPLIT ("0")   W64_VARIANT (ablation builds only)
  *   GEMM_KERNEL ("w64" / "8w")   GEMM_TILE ("big" / "small" / "tiny")   GEMM_RULE   GEMM_GROUP_M   GEMM_SPLITK ("0")
- *   GEMM_QKV ("0" / "1")   GEMM_W64_R192 / N192 / BF16M / GBWD / GAUX ("0" / "1")
+ *   GEMM_QKV ("0" / "1")   GEMM_W64_R192 / N192 / BF16M / GBWD / GAUX ("0" / "1")   GEMM_W64_P256 (experiment builds only)
+ *   RMS_PAIR_ROW ("0" / "1": omh_rmsnorm_rope_bf16_pair's two-workgroup / one-wave-per-row form)
  *   GEMM_TN_W64 ("0" / "1")   GEMM_TN_TILE   GEMM_TN_GROUP_TILE ("big" / "small")   GEMM_TN_SPLIT (count)
  *   CONV_TILE ("w64" / "wide" / "small")   CONV_W64   CONV_WIDE_MIN   CONV_FUSE_NORM   CONV_KW3   CONV_PERSIST
  *   CONV_W64_UP2   LN_RPW ("1" / "2" / "4")   DETERMINISTIC ("0" / "1")

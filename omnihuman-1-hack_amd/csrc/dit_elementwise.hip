@@ -227,6 +227,100 @@ void rmsnorm_rope_pair_kernel(const uint16_t* __restrict__ x, int64_t ldx, int64
                                  rope_len, head_dim, grid, seq_len, s ? scale1 : scale0);
 }
 
+// Long inputs (round 6): ONE wave takes both segments of its row — the 2 x MAXV loads of q and k are in flight together
+// (6 KB per wave instead of 3), the token position (four integer divisions) and the lane's four rotary-table entries are
+// computed once for the two (q and k share the row and the head layout) — and the arithmetic of each segment is
+// rmsnorm_rope_row's, operation for operation: the same bits.  rope on, head_dim dividing 256 (every Wan model).
+// Measured at 32 760 rows x 2 x 1 536: 120 -> see DESIGN.md 4.1 (the two-workgroup form streams the q halves of all rows
+// first and the k halves afterwards: 3 KB pieces of 6 KB rows).
+template <int MAXV>
+__global__ __launch_bounds__(256)
+void rmsnorm_rope_pair_row_kernel(const uint16_t* __restrict__ x, int64_t ldx, int64_t seg_x, uint16_t* __restrict__ y0,
+                                  uint16_t* __restrict__ y1, int64_t rows, int dim, const float* __restrict__ w0,
+                                  const float* __restrict__ w1, float eps, int do_norm, const float* __restrict__ rope_cos,
+                                  const float* __restrict__ rope_sin, int rope_len, int head_dim,
+                                  const int* __restrict__ grid, int seq_len, float scale0, float scale1) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = dim >> 2;
+    const uint2* xa = (const uint2*)(x + row * ldx);
+    const uint2* xb = (const uint2*)(x + seg_x + row * ldx);
+    uint2 ha[MAXV], hb[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        ha[i] = c < nv ? xa[c] : make_uint2(0u, 0u);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        hb[i] = c < nv ? xb[c] : make_uint2(0u, 0u);
+    }
+    // token position and the lane's two complex pairs (the same for every vector of the lane and for both segments)
+    const int hc = head_dim >> 1, c3 = hc / 3, cf = hc - 2 * c3;
+    bool rot = false;
+    float cs2[2] = {1.f, 1.f}, sn2[2] = {0.f, 0.f};
+    {
+        const int b = (int)(row / seq_len), sidx = (int)(row % seq_len);
+        const int gf = grid[3 * b], gh = grid[3 * b + 1], gw = grid[3 * b + 2];
+        if (sidx < gf * gh * gw) {
+            rot = true;
+            const int pf = sidx / (gh * gw), ph = (sidx / gw) % gh, pw = sidx % gw;
+            const int p0 = ((4 * lane) % head_dim) >> 1;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int pc = p0 + e;
+                const int pos = pc < cf ? pf : (pc < cf + c3 ? ph : pw);
+                const int idx = min(pos, rope_len - 1) * hc + pc;
+                cs2[e] = rope_cos[idx]; sn2[e] = rope_sin[idx];
+            }
+        }
+    }
+    auto finish = [&](uint2 (&h)[MAXV], uint16_t* __restrict__ y, const float* __restrict__ weight, float out_scale) {
+        float4 v[MAXV];
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                v[i] = make_float4(bf2f((uint16_t)(h[i].x & 0xffff)), bf2f((uint16_t)(h[i].x >> 16)),
+                                   bf2f((uint16_t)(h[i].y & 0xffff)), bf2f((uint16_t)(h[i].y >> 16)));
+                q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+            }
+        }
+        const float rinv = (do_norm ? rsqrtf(wave_sum(q) / dim + eps) : 1.0f) * out_scale;
+        const float4* wv = (const float4*)weight;
+        uint2* yr = (uint2*)(y + row * dim);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                float4 t = v[i];
+                t.x *= rinv; t.y *= rinv; t.z *= rinv; t.w *= rinv;
+                if (wv) { const float4 g = wv[c]; t.x *= g.x; t.y *= g.y; t.z *= g.z; t.w *= g.w; }
+                if (rot) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float cs = cs2[e], sn = sn2[e];
+                        float& re = e == 0 ? t.x : t.z;
+                        float& im = e == 0 ? t.y : t.w;
+                        const float nr = re * cs - im * sn;
+                        const float ni = re * sn + im * cs;
+                        re = nr; im = ni;
+                    }
+                }
+                uint2 o;
+                o.x = pack_bf2(t.x, t.y);
+                o.y = pack_bf2(t.z, t.w);
+                yr[c] = o;
+            }
+        }
+    };
+    finish(ha, y0, w0, scale0);
+    finish(hb, y1, w1, scale1);
+}
+
 // ------------------------------------------------------------------ cast
 __global__ __launch_bounds__(256)
 void cast_f32_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t n) {
@@ -425,6 +519,19 @@ extern "C" int omh_rmsnorm_rope_bf16_pair(const void* x_bf16, int64_t ldx, int64
         return OMH_E_BADARG;
     if (((uintptr_t)x_bf16 & 7) || ((uintptr_t)y0 & 7) || ((uintptr_t)y1 & 7)) return OMH_E_ALIGN;
     omh_clear_status();
+    // long inputs with the rotary table on a 256-periodic head layout: one wave per row takes both segments (RMS_PAIR_ROW
+    // = "0": never, "1": any row count)
+    {
+        const char* pr = omh_opt(OMH_OPT_RMS_PAIR_ROW);
+        const bool off = pr && pr[0] == '0', on = pr && pr[0] == '1';
+        if (!off && rope_cos && head_dim > 0 && (256 % head_dim) == 0 && dim <= 20 * 256 && (on || rows >= 8192)) {
+            auto k2 = dim <= 6 * 256 ? rmsnorm_rope_pair_row_kernel<6> : rmsnorm_rope_pair_row_kernel<20>;
+            hipLaunchKernelGGL(k2, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                               (const uint16_t*)x_bf16, ldx, seg_x, (uint16_t*)y0, (uint16_t*)y1, rows, dim, weight0, weight1,
+                               eps, do_norm, rope_cos, rope_sin, rope_len, head_dim, grid, seq_len, out_scale0, out_scale1);
+            return omh_launch_status();
+        }
+    }
     auto kern = dim <= 6 * 256 ? rmsnorm_rope_pair_kernel<6>
                                : (dim <= 20 * 256 ? rmsnorm_rope_pair_kernel<20> : rmsnorm_rope_pair_kernel<MAXV_GENERIC>);
     hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 3) / 4), 2), dim3(256), 0, (hipStream_t)stream,

@@ -14,7 +14,7 @@
     X(ATTN_KERNEL) X(ATTN_SPLIT) X(W64_SPLIT) X(W64_VARIANT) X(CONV_PERSIST) X(CONV_W64_UP2) X(LN_RPW) X(GEMM_GROUP_M)    \
     X(GEMM_TILE) X(GEMM_RULE) X(GEMM_KERNEL) X(GEMM_W64_GBWD) X(GEMM_W64_GAUX) X(GEMM_W64_R192) X(GEMM_W64_BF16M)        \
     X(GEMM_W64_N192) X(GEMM_TN_SPLIT) X(GEMM_TN_W64) X(GEMM_TN_TILE) X(GEMM_TN_GROUP_TILE) X(GEMM_SPLITK) X(CONV_TILE)   \
-    X(CONV_WIDE_MIN) X(CONV_W64) X(CONV_FUSE_NORM) X(CONV_KW3) X(GEMM_QKV) X(ATTN_BWD_W64) X(GEMM_W64_P256)
+    X(CONV_WIDE_MIN) X(CONV_W64) X(CONV_FUSE_NORM) X(CONV_KW3) X(GEMM_QKV) X(ATTN_BWD_W64) X(GEMM_W64_P256) X(RMS_PAIR_ROW)
 enum OmhOpt {
 #define X(n) OMH_OPT_##n,
     OMH_OPTIONS(X)

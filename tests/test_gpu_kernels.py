@@ -694,11 +694,12 @@ def test_rmsnorm_rope_matches_oracle(ops):
     assert rel_rms(y2.float(), O.rms_norm(x[:, :d].cpu(), torch.ones(d), 1e-6)) < 4e-3
 
 
-@pytest.mark.parametrize("rows,d,S", [(60, 256, 30), (3120, 1536, 1560), (1001, 5120, 1001)])
+@pytest.mark.parametrize("rows,d,S", [(60, 256, 30), (3120, 1536, 1560), (1001, 5120, 1001), (9362, 1536, 4681)])
 def test_rmsnorm_rope_pair_equals_two_launches(ops, rows, d, S):
     """ABI v9: q and k of the self-attention normalised + rotated out of the fused q|k projection in ONE launch (two column
     segments, each with its own gain, output and output scale): bit for bit the two single-segment launches; without gains
-    and without RoPE too; ragged row count (rows % 4 != 0)."""
+    and without RoPE too; ragged row count (rows % 4 != 0).  Round 6: also the one-wave-per-row form that long inputs take
+    (RMS_PAIR_ROW = 1 forces it at any row count; 9 362 rows take it by themselves)."""
     from oracle import wan_dit_oracle as O
     torch.manual_seed(rows)
     D = 128
@@ -707,7 +708,7 @@ def test_rmsnorm_rope_pair_equals_two_launches(ops, rows, d, S):
     wq, wk = torch.rand(d, device="cuda") + 0.5, torch.rand(d, device="cuda") + 0.5
     ang = O.rope_table(D)
     cos, sin = torch.cos(ang).float().cuda(), torch.sin(ang).float().cuda()
-    gs = {30: (2, 3, 4), 1560: (1, 30, 52), 1001: (1, 25, 40)}[S]
+    gs = {30: (2, 3, 4), 1560: (1, 30, 52), 1001: (1, 25, 40), 4681: (3, 30, 52)}[S]
     grid = torch.tensor([gs] * B, dtype=torch.int32, device="cuda")
     for gains, rope in ((True, True), (False, True), (True, False)):
         rk = (ops.ptr(cos), ops.ptr(sin), 1024, D, ops.ptr(grid), S) if rope else (None, None, 0, D, None, 0)
@@ -715,10 +716,13 @@ def test_rmsnorm_rope_pair_equals_two_launches(ops, rows, d, S):
         q0, k0 = torch.empty(rows, d, dtype=torch.bfloat16, device="cuda"), torch.empty(rows, d, dtype=torch.bfloat16, device="cuda")
         ops.rmsnorm_rope_bf16_raw(ops.ptr(qk), 2 * d, ops.ptr(q0), rows, d, w0, 1e-6, 1, *rk, out_scale=0.1275)
         ops.rmsnorm_rope_bf16_raw(ops.ptr(qk, d), 2 * d, ops.ptr(k0), rows, d, w1, 1e-6, 1, *rk, out_scale=1.0)
-        q1, k1 = torch.full_like(q0, 3.0), torch.full_like(k0, 3.0)
-        ops.rmsnorm_rope_bf16_pair_raw(ops.ptr(qk), 2 * d, d, ops.ptr(q1), ops.ptr(k1), rows, d, w0, w1, 1e-6, 1, *rk,
-                                       out_scale0=0.1275, out_scale1=1.0)
-        assert torch.equal(q1, q0) and torch.equal(k1, k0), (gains, rope)
+        for form in (None, "0", "1"):                          # the shipped dispatch, the two-workgroup form, one wave per row
+            set_option("RMS_PAIR_ROW", form)
+            q1, k1 = torch.full_like(q0, 3.0), torch.full_like(k0, 3.0)
+            ops.rmsnorm_rope_bf16_pair_raw(ops.ptr(qk), 2 * d, d, ops.ptr(q1), ops.ptr(k1), rows, d, w0, w1, 1e-6, 1, *rk,
+                                           out_scale0=0.1275, out_scale1=1.0)
+            assert torch.equal(q1, q0) and torch.equal(k1, k0), (gains, rope, form)
+        set_option("RMS_PAIR_ROW", None)
     assert float(q0.float().abs().mean()) > 1e-3 and not torch.equal(q0, k0)
 
 
