@@ -21,7 +21,8 @@ enum { K_F32 = 0, K_BF16 = 1, K_GELU = 2, K_RESID = 3, K_GELUBWD = 4, K_BF16M = 
        K_QKV = 10,          // 256 x 384: columns < n_split -> C bf16 (the BF16 stream), columns >= n_split -> aux TRANSPOSED (BF16VT)
        // round 6: 256 x 256, the k loop with two k tiles of operands in flight in registers (gen_gemm_w64.py: main_loop_pgr)
        K_F32_P = 11, K_BF16_P = 12, K_GELU_P = 13, K_RESID_P = 14,
-       K_ABL_A = 15, K_ABL_B = 16, K_ABL_C = 17, K_ABL_D = 18, K_ABL_E = 19 };      // timing-only ablation builds of K_F32_P
+       K_ABL_A = 15, K_ABL_B = 16, K_ABL_C = 17, K_ABL_D = 18, K_ABL_E = 19,        // timing-only ablation builds of K_F32_P
+       K_F32_M16 = 20 };    // timing-only: the 256 x 384 fp32 stream with every MFMA as two v_mfma_f32_16x16x32_bf16
 constexpr bool is_n192(int kind) { return kind >= K_RESID192 && kind <= K_BF16_192; }
 constexpr bool is_p256(int kind) { return kind >= K_F32_P && kind <= K_ABL_E; }
 constexpr int TN256 = 256;
@@ -243,6 +244,9 @@ void gemm_bf16_nt_w64_kernel(const omh_gemm_args p, const int tiles_m, const int
         else if (KIND == K_GELU_P) OMH_GW64_RUN(OMH_GEMM_W64_ASM_GELU_P256);
         else if (KIND == K_RESID_P) OMH_GW64_RUN(OMH_GEMM_W64_ASM_RESID_P256);
 #endif
+#ifdef OMH_GEMM_W64_ASM_F32_M16
+        else if (KIND == K_F32_M16) OMH_GW64_RUN(OMH_GEMM_W64_ASM_F32_M16);
+#endif
 #ifdef OMH_GEMM_W64_ASM_F32_P256_A
         else if (KIND == K_ABL_A) OMH_GW64_RUN(OMH_GEMM_W64_ASM_F32_P256_A);
         else if (KIND == K_ABL_B) OMH_GW64_RUN(OMH_GEMM_W64_ASM_F32_P256_B);
@@ -369,6 +373,9 @@ int omh_launch_gemm_w64_p256(const omh_gemm_args& a, hipStream_t stream) {
     (void)a; (void)stream;
     return OMH_E_SHAPE;
 #else
+#ifdef OMH_GEMM_W64_ASM_F32_M16
+    { const char* m = omh_opt(OMH_OPT_GEMM_W64_P256); if (m && m[0] == 'm' && a.epilogue == OMH_EPI_F32) return launch_w64<K_F32_M16>(a, stream); }
+#endif
 #ifdef OMH_GEMM_W64_ASM_F32_P256_A
     const char* ab = omh_opt(OMH_OPT_GEMM_W64_P256);             // "a".."e": the timing-only ablations (results are garbage)
     if (ab && a.epilogue == OMH_EPI_F32) switch (ab[0]) {

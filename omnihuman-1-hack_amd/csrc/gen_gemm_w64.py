@@ -125,12 +125,26 @@ def frag_reads(stage, kk, buf):
 SWAP = False                    # "bf16vt": activations in the MFMA A slot, weights in the B slot -> a lane holds 4 consecutive m
 
 
+M16 = False                     # timing-only ablation: every 32x32x16 MFMA as TWO v_mfma_f32_16x16x32_bf16 on the same operand
+#                                 registers (the same flops, LDS and global traffic; the results are garbage) — does the shape
+#                                 that sustains 2.16 instead of 1.88 PFLOP/s on data-like operands (tools/mfma_shape_probe.py) pay
+#                                 inside a real k loop?
+
+
 def group_mfmas(buf, first=False):
     out = []
     for i in range(NI):
         for j in range(NJ):
             c = "0" if first else acc(i, j)
             a_, b_ = (xfrag(buf, j), wfrag(buf, i)) if SWAP else (wfrag(buf, i), xfrag(buf, j))
+            if M16:
+                t = i * NJ + j
+                base, f = (t * 16, "a") if t < 16 else (128 + (t - 16) * 16, "v")
+                for half in range(2):
+                    d = f"{f}[{base + 4 * half}:{base + 4 * half + 3}]"
+                    out.append(("m", f"v_mfma_f32_16x16x32_bf16 {d}, {vr(a_, 4)}, {vr(b_, 4)}, {d}",
+                                [f"W{buf}.{i}", f"X{buf}.{j}"] if half == 0 else []))
+                continue
             out.append(("m", f"v_mfma_f32_32x32x16_bf16 {acc(i, j)}, {vr(a_, 4)}, {vr(b_, 4)}, {c}",
                         [f"W{buf}.{i}", f"X{buf}.{j}"]))
     return out
@@ -1069,7 +1083,13 @@ def main():
         streams += [("PRO256", first_prologue("pro256"))] + [(f"{kind.upper()}_P256", generate(kind, f"{kind}p4"))
                                                              for kind in ("f32", "bf16", "gelu", "resid")]
     if os.environ.get("OMH_GW64_ABLATIONS", "0") == "1":          # timing-only builds
-        global PABL, LDMOD
+        global PABL, LDMOD, M16
+        if os.environ.get("OMH_GW64_ABL_SET", "abl") == "m16":    # the SHIPPED 256 x 384 fp32 stream on 16x16x32 MFMAs (garbage results)
+            configure(6)
+            M16 = True
+            streams.append(("F32_M16", generate("f32", "f32m16")))
+            M16 = False
+            configure(4, pgr=True)
         if os.environ.get("OMH_GW64_ABL_SET", "abl") == "ldmod":
             for tag, mod in (("A", " nt"), ("B", " sc1"), ("C", " sc0"), ("D", " sc0 sc1"), ("E", " sc1 nt")):
                 LDMOD = mod

@@ -45,6 +45,44 @@ __global__ __launch_bounds__(256, 1) void mfma_rate_kernel(float* out, int iters
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// The same measurement on v_mfma_f32_16x16x32_bf16 (the shape the vendor library's GEMM kernels use: MI16x16x1): same flops
+// per cycle on paper, a quarter of the accumulator registers per instruction, twice the operand registers per flop.
+template <bool RND>
+__global__ __launch_bounds__(256, 1) void mfma16_rate_kernel(float* out, int iters, int salt) {
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+    bf16x8 ra[8], rb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (RND) {
+                uint32_t h = (threadIdx.x * 2654435761u) ^ ((i * 8 + e + salt) * 40503u + blockIdx.x * 977u);
+                h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+                uint32_t g = h * 3266489917u; g ^= g >> 16;
+                ra[i][e] = (__bf16)(((int)(h & 0xffff) - 32768) * (1.0f / 16384.0f));
+                rb[i][e] = (__bf16)(((int)(g & 0xffff) - 32768) * (1.0f / 16384.0f));
+            } else {
+                ra[i][e] = (__bf16)(float)((threadIdx.x & 63) + e + salt);
+                rb[i][e] = (__bf16)(float)(e + salt);
+            }
+        }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 128; ++j)
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[j & 15]) : "v"(ra[RND ? (j & 7) : 0]), "v"(rb[RND ? ((j >> 3) & 7) : 0]));
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += acc[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 }  // namespace
 
 extern "C" int omh_probe_mfma_tflops(int32_t random_operands, int32_t iters, float* scratch, int64_t scratch_floats,
@@ -58,9 +96,13 @@ extern "C" int omh_probe_mfma_tflops(int32_t random_operands, int32_t iters, flo
     if (err != hipSuccess) return (int)err;
     err = hipEventCreate(&e1);
     if (err != hipSuccess) { (void)hipEventDestroy(e0); return (int)err; }
+    // random_operands: 0 / 1 = 32x32x16 on constant / random operands (64 per iteration), 2 / 3 = 16x16x32 likewise (128 per
+    // iteration: the same flops per iteration)
     auto launch = [&](int n) {
-        if (random_operands) hipLaunchKernelGGL(mfma_rate_kernel<true>, dim3(grid), dim3(256), 0, s, scratch, n, 1);
-        else hipLaunchKernelGGL(mfma_rate_kernel<false>, dim3(grid), dim3(256), 0, s, scratch, n, 1);
+        if (random_operands == 1) hipLaunchKernelGGL(mfma_rate_kernel<true>, dim3(grid), dim3(256), 0, s, scratch, n, 1);
+        else if (random_operands == 0) hipLaunchKernelGGL(mfma_rate_kernel<false>, dim3(grid), dim3(256), 0, s, scratch, n, 1);
+        else if (random_operands == 3) hipLaunchKernelGGL(mfma16_rate_kernel<true>, dim3(grid), dim3(256), 0, s, scratch, n, 1);
+        else hipLaunchKernelGGL(mfma16_rate_kernel<false>, dim3(grid), dim3(256), 0, s, scratch, n, 1);
     };
     launch(iters / 8 + 1);                                           // warm the clocks
     (void)hipEventRecord(e0, s);

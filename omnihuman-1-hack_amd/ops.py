@@ -815,7 +815,7 @@ def probe_mfma_tflops(random_operands: bool, iters: int = 400) -> float:
     import ctypes as _C
     scratch = torch.empty(1024 * 256, device="cuda", dtype=torch.float32)
     out = _C.c_float(0.0)
-    check(lib.omh_probe_mfma_tflops(int(bool(random_operands)), int(iters), _p(scratch), scratch.numel(),
+    check(lib.omh_probe_mfma_tflops(int(random_operands), int(iters), _p(scratch), scratch.numel(),
                                     _C.cast(_C.byref(out), _C.c_void_p), _stream()), "omh_probe_mfma_tflops")
     return float(out.value)
 

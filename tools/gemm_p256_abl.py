@@ -10,12 +10,14 @@ if os.environ.get("ZERO") == "1":            # constant operands: the multiplier
     a.zero_(); w.zero_()
 x = torch.empty(M, N, device="cuda"); ptr = ops.ptr
 def run(): ops.gemm_raw(ptr(a), ptr(w), ptr(x), M, N, K, K, K, N, ops.EPI_F32)
-if os.environ.get("SET") == "ldmod":
+if os.environ.get("SET") == "m16":
+    names = {"0": "shipped 256x384 stream", "m": "the same on 16x16x32 MFMAs"}
+elif os.environ.get("SET") == "ldmod":
     names = {"0": "shipped dispatch", "1": "p256", "a": "loads nt", "b": "loads sc1", "c": "loads sc0", "d": "loads sc0 sc1", "e": "loads sc1 nt"}
 else:
     names = {"0": "shipped dispatch", "1": "p256", "a": "no global loads", "b": "no LDS writes", "c": "no loads, no writes", "d": "no barrier", "e": "no fragment reads"}
 for rep in range(2):
-    for v in "01abcde":
+    for v in ("0m" if os.environ.get("SET") == "m16" else "01abcde"):
         ops.set_option("GEMM_W64_P256", v)
         for _ in range(3): run()
         torch.cuda.synchronize(); s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True); s.record()
