@@ -117,7 +117,8 @@ def linearize(e, ops, pending):
                 assert allowed <= 15
                 e(f"s_waitcnt lgkmcnt({allowed})")
                 pending = pending[last + 1:]
-            e(op[1])
+            for ln in (op[1] if isinstance(op[1], tuple) else (op[1],)):      # (M16 ablation: two instructions per op)
+                e(ln)
         else:
             e(op[1])
     return pending
@@ -159,12 +160,25 @@ def vread_op(i, vbase):
     return ("r", f"V{i}", f"ds_read_b128 {ar(VR(i % 4), 4)}, {vr(VA[2 * kb + a])} offset:{vbase + db * 4096}")
 
 
+M16 = False     # OMH_ATTN_ABL=4, variant 0 (timing only, round 6): every 32x32x16 MFMA as TWO v_mfma_f32_16x16x32_bf16 on the
+#                 same operand registers — the same flops and traffic, garbage results: what would the MFMA shape that sustains
+#                 2.16 instead of 1.88 PFLOP/s on data-like operands (tools/mfma_shape_probe.py) buy this stream?
+
+
 def qk_mfmas(nxt, c_zero=False):
     """32 MFMAs of K.Q^T into score set nxt (C = MI = -m_run on the first k step), + the fragment reads that ride
     behind them (steps kk+2, after the 2nd MFMA of step kk)."""
     mf = []
     for kk in range(8):
         for kb, qb in ((0, 0), (0, 1), (1, 0), (1, 1)):
+            if M16:
+                two = []
+                for half in range(2):
+                    d = vr(S(nxt, qb, kb) + 4 * half, 4)
+                    c = ("0" if c_zero else vr(MI(qb) + 4 * half, 4)) if kk == 0 else d
+                    two.append(f"v_mfma_f32_16x16x32_bf16 {d}, {ar(KR(kk % 3, kb), 4)}, {ar(Q(qb, kk), 4)}, {c}")
+                mf.append(("m", tuple(two), [f"K{kk}.{kb}"]))
+                continue
             c = ("0" if c_zero else vr(MI(qb), 16)) if kk == 0 else vr(S(nxt, qb, kb), 16)
             mf.append(("m", f"v_mfma_f32_32x32x16_bf16 {vr(S(nxt, qb, kb), 16)}, {ar(KR(kk % 3, kb), 4)}, "
                             f"{ar(Q(qb, kk), 4)}, {c}", [f"K{kk}.{kb}"]))
@@ -256,6 +270,13 @@ def pv_mfmas(cur):
     for i in range(16):
         kb, a, db = i >> 3, (i >> 2) & 1, i & 3
         for qb in range(2):
+            if M16:
+                two = []
+                for half in range(2):
+                    d = ar(O(qb, db) + 4 * half, 4)
+                    two.append(f"v_mfma_f32_16x16x32_bf16 {d}, {ar(VR(i % 4), 4)}, {vr(P(qb, kb, a), 4)}, {d}")
+                mf.append(("m", tuple(two), [f"V{i}"]))
+                continue
             mf.append(("m", f"v_mfma_f32_32x32x16_bf16 {ar(O(qb, db), 16)}, {ar(VR(i % 4), 4)}, "
                             f"{vr(P(qb, kb, a), 4)}, {ar(O(qb, db), 16)}", [f"V{i}"]))
     return mf
@@ -357,7 +378,9 @@ def generate(variant):
     # worst-case bound is 196 (log2 units) instead of 16 — not usable (p would underflow), not built.
     abl_nomax = ABL == "3" and variant in (0, 1)
     abl_nosum = ABL == "3" and variant == 1
-    base = 2 if (abl_poly or abl_salu or abl_traffic or abl_nomax) else min(variant, 2)
+    global M16
+    M16 = ABL == "4" and variant == 0
+    base = 2 if (abl_poly or abl_salu or abl_traffic or abl_nomax or M16) else min(variant, 2)
     dma_spread = base >= 1
     vpre = base >= 1
     k3 = base >= 2
