@@ -778,7 +778,6 @@ class WanModel(nn.Module):
         out = self.head(xs, e)                                   # fp32 [B, seq_len, prod(patch)*out_dim]
         return self.unpatchify(out, grid_sizes, _grids=grids)
 
-    @torch.no_grad()
     def forward_cfg_pair(self, x, t, context, context_null, seq_len, clip_fea=None, y=None):
         """The two forwards of a classifier-free-guided step — ``forward(x, t, context, ...)`` and ``forward(x, t,
         context_null, ...)`` on the SAME latents and timestep (text2video.py:238-241, generate.py:205-229) — with what
@@ -786,8 +785,20 @@ class WanModel(nn.Module):
         q | k | v, RoPE, self-attention, o-projection: its inputs are x and t alone; the context enters at block 0's
         cross-attention).  Everything after that point runs per branch, with the launches of a batch-of-one forward, so
         both results equal the two separate calls BIT FOR BIT (the kernels are deterministic); at S = 32 760 it is one
-        self-attention launch of 60 less per step.  Inference only; contexts may be ContextStates.
+        self-attention launch of 60 less per step.  Inference only (a model whose parameters require grad must be called
+        under torch.no_grad(): the training step has no such pair); contexts may be ContextStates.
         Returns (list of cond outputs, list of uncond outputs)."""
+        device = self.patch_embedding.weight.device
+        if device.type != "cuda":
+            raise ops.OmhError("WanModel.forward_cfg_pair runs on the MI355X only (no CPU fallback): move the model "
+                               "to a GPU device")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("forward_cfg_pair is an inference path: call it under torch.no_grad() or on a model "
+                               "with requires_grad_(False) (training goes through forward())")
+        with torch.no_grad():
+            return self._forward_cfg_pair(x, t, context, context_null, seq_len, clip_fea, y)
+
+    def _forward_cfg_pair(self, x, t, context, context_null, seq_len, clip_fea, y):
         xs, e, fc, grids, lens, ctx_lens = self._embed(x, t, context, seq_len, clip_fea, y)
         seq_lens = _dev_ints(lens, torch.long, xs.device)
         grid_sizes = _dev_ints(grids, torch.long, xs.device)

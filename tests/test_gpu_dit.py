@@ -320,3 +320,10 @@ def test_cfg_pair_shares_block_0_self_attention_and_changes_no_bit(wan_model_mod
     w_c, w_u = ml(xl, tl, ctx[:1], 8704)[0], ml(xl, tl, null[:1], 8704)[0]
     g_c, g_u = ml.forward_cfg_pair(xl, tl, ctx[:1], null[:1], 8704)
     assert torch.equal(g_c[0], w_c) and torch.equal(g_u[0], w_u) and not torch.equal(w_c, w_u)
+    # an inference path: refused when autograd would be expected to follow it
+    ml.requires_grad_(True)
+    with pytest.raises(RuntimeError):
+        ml.forward_cfg_pair(xl, tl, ctx[:1], null[:1], 8704)
+    with torch.no_grad():
+        g2 = ml.forward_cfg_pair(xl, tl, ctx[:1], null[:1], 8704)
+    assert torch.equal(g2[0][0], w_c)
